@@ -1,0 +1,113 @@
+/*
+ * ngsld_oracle.h -- CPU ORACLE for the ngsLD pairwise-LD hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the reference algorithm (fgvieira/ngsLD v1.2.1), written by
+ * reading the reference and citing the file:line each function follows.  It is the checker the
+ * HIP path is compared against.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load or execute anything under oracle/; the product (ngsld_amd/, include/) never does.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - EM (haplo_freq / pair_freq_iter), est_maf, post_prob/logsum, conv_space, miss_data, the binary
+ *     GL reader and the pos reader are checked BIT-FOR-BIT against the reference's own code compiled
+ *     from /root/reference (oracle/build_ref.sh -> oracle/_ref/libngsld_ref.so; only the GSL-free part
+ *     of shared/gen_func.cpp + shared/read_data.cpp can be built here, GSL is not installed and no
+ *     stand-in for it is written).  Golden vectors from that build are committed under tests/golden/.
+ *   - PARITY UNPINNED for what lives in ngsLD.cpp (needs GSL to compile): the window walk
+ *     (calc_pair_LD), the derived statistics D/D'/r2/chi2, the TSV formats, and the Pearson r2 of
+ *     expected genotypes (gsl_stats_correlation, GSL itself is absent).  These are restated from the
+ *     source text / GSL's published algorithm only.
+ */
+#ifndef NGSLD_ORACLE_H
+#define NGSLD_ORACLE_H
+
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* constants: shared/gen_func.hpp:14-18 */
+#define ORC_N_GENO 3
+#define ORC_INF 1e15
+#define ORC_EPSILON 1e-5
+#define ORC_ITER_MAX 100
+
+/* mirrors `params` (ngsLD.hpp:11-44), flat arrays instead of jagged pointers */
+typedef struct {
+  const char *in_geno;
+  int in_logscale;
+  uint64_t n_ind;
+  uint64_t n_sites;
+  const char *in_pos;
+  int in_pos_header;
+  uint64_t max_kb_dist;
+  uint64_t max_snp_dist;
+  double min_maf;
+  int ignore_miss_data;
+  int extend_out;
+  int n_threads;
+
+  double *geno_lkl;      /* [n_sites][n_ind][3]; log space after read, normal space after preprocess */
+  double *maf;           /* [n_sites] */
+  double *expected_geno; /* [n_sites][n_ind] */
+  double *pos_dist;      /* [n_sites] */
+  char **labels;         /* [n_sites] or NULL */
+} orc_params;
+
+/* one result per surviving pair (full precision; what calc_pair_LD would print) */
+typedef struct {
+  uint64_t s1, s2;
+  double dist;
+  double r2pear, D, Dp, r2;
+  uint64_t n_ind_data;
+  double hap[4];
+  double hap_maf[2];
+  float chi2;
+  uint64_t n_iter;
+} orc_pair;
+
+/* --- math kernels (each cites the reference lines it follows in the .c file) --- */
+double orc_logsum(const double *a, uint64_t n);
+void orc_post_prob(double *pp, const double *lkl, uint64_t n_geno);
+void orc_conv_space_log(double *g, int n);
+void orc_conv_space_exp(double *g, int n);
+int orc_miss_data(const double *g);
+double orc_est_maf(uint64_t n_ind, const double *pdg /* [n_ind][3] log space */, int ignore_miss_data);
+uint64_t orc_pair_freq_iter(double f[4], const double *s1, const double *s2, uint64_t n, int ignore_miss_data,
+                            int *err);
+uint64_t orc_haplo_freq(double hap_freq[4], uint64_t *n, const double *gl1, const double *gl2, double maf1,
+                        double maf2, uint64_t n_ind, int ignore_miss_data, int *err);
+double orc_correlation(const double *x, const double *y, uint64_t n);
+double orc_pearson_r2(const double *x, const double *y, uint64_t n);
+void orc_pair_stats(const double hap[4], double *D, double *Dp, double *r2, double hap_maf[2], float *chi2);
+
+/* --- data stages --- */
+/* binary GL reader: returns 0 ok, <0 error (message in errbuf). out = [n_sites][n_ind][3] log-normalised */
+int orc_read_geno_bin(const char *path, int log_scale, uint64_t n_ind, uint64_t n_sites, double *out, char *errbuf,
+                      size_t errlen);
+/* same arithmetic as the reader on an in-memory raw buffer (raw is not modified) */
+int orc_normalise_raw(const double *raw, int log_scale, uint64_t n_ind, uint64_t n_sites, double *out);
+/* ngsLD.cpp:103-114: maf on log GL, exp() in place, expected genotypes */
+void orc_preprocess(orc_params *p);
+/* read_dist + labels; allocates p->pos_dist, p->labels.  returns 0 ok */
+int orc_read_pos(orc_params *p, char *errbuf, size_t errlen);
+void orc_free_pos(orc_params *p);
+
+/* --- the hot path --- */
+/* number of pairs row s1 emits; when out != NULL the records are written there (capacity cap). */
+uint64_t orc_row(const orc_params *p, uint64_t s1, orc_pair *out, uint64_t cap, int *err);
+/* all rows [s1_begin, s1_end), n_threads pthreads striped over rows. returns #pairs; records optional,
+   written in (s1,s2) order when out != NULL (two-pass: count, then fill). */
+uint64_t orc_run(const orc_params *p, uint64_t s1_begin, uint64_t s1_end, orc_pair *out, uint64_t cap, int *err);
+/* exclusive end of the contiguous s2 range row s1 walks (before the maf[s2] skip) */
+uint64_t orc_row_end(const orc_params *p, uint64_t s1);
+
+/* --- text --- */
+void orc_print_header(FILE *fh, int extend_out);
+void orc_print_pair(FILE *fh, const orc_params *p, const orc_pair *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

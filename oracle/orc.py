@@ -1,0 +1,170 @@
+"""ctypes binding of the CPU ORACLE (oracle/liborc.so) and, when present, of the reference's own
+functions (oracle/_ref/libngsld_ref.so).  TEST INFRASTRUCTURE: imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBORC = os.path.join(HERE, "liborc.so")
+ORC_CLI = os.path.join(HERE, "ngsld_oracle")
+LIBREF = os.path.join(HERE, "_ref", "libngsld_ref.so")
+
+c_double_p = C.POINTER(C.c_double)
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("in_geno", C.c_char_p), ("in_logscale", C.c_int), ("n_ind", C.c_uint64), ("n_sites", C.c_uint64),
+        ("in_pos", C.c_char_p), ("in_pos_header", C.c_int), ("max_kb_dist", C.c_uint64),
+        ("max_snp_dist", C.c_uint64), ("min_maf", C.c_double), ("ignore_miss_data", C.c_int),
+        ("extend_out", C.c_int), ("n_threads", C.c_int),
+        ("geno_lkl", c_double_p), ("maf", c_double_p), ("expected_geno", c_double_p), ("pos_dist", c_double_p),
+        ("labels", C.POINTER(C.c_char_p)),
+    ]
+
+
+PAIR_DTYPE = np.dtype([
+    ("s1", "<u8"), ("s2", "<u8"), ("dist", "<f8"), ("r2pear", "<f8"), ("D", "<f8"), ("Dp", "<f8"), ("r2", "<f8"),
+    ("n_ind_data", "<u8"), ("hap", "<f8", (4,)), ("hap_maf", "<f8", (2,)), ("chi2", "<f4"), ("_pad", "<u4"),
+    ("n_iter", "<u8")])
+
+
+def build(force: bool = False) -> None:
+    if force or not (os.path.exists(LIBORC) and os.path.exists(ORC_CLI)) or \
+            os.path.getmtime(LIBORC) < os.path.getmtime(os.path.join(HERE, "ngsld_oracle.c")):
+        subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+
+
+def build_ref() -> bool:
+    """Build oracle/_ref from /root/reference when that tree exists; returns whether the .so is available."""
+    if os.path.isdir("/root/reference/shared"):
+        subprocess.check_call([os.path.join(HERE, "build_ref.sh")], stdout=subprocess.DEVNULL)
+    return os.path.exists(LIBREF)
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIBORC)
+        assert C.sizeof(OrcParams) > 0 and PAIR_DTYPE.itemsize == 128
+        L.orc_logsum.restype = C.c_double
+        L.orc_logsum.argtypes = [c_double_p, C.c_uint64]
+        L.orc_est_maf.restype = C.c_double
+        L.orc_est_maf.argtypes = [C.c_uint64, c_double_p, C.c_int]
+        L.orc_pair_freq_iter.restype = C.c_uint64
+        L.orc_pair_freq_iter.argtypes = [c_double_p, c_double_p, c_double_p, C.c_uint64, C.c_int, C.POINTER(C.c_int)]
+        L.orc_haplo_freq.restype = C.c_uint64
+        L.orc_haplo_freq.argtypes = [c_double_p, C.POINTER(C.c_uint64), c_double_p, c_double_p, C.c_double,
+                                     C.c_double, C.c_uint64, C.c_int, C.POINTER(C.c_int)]
+        L.orc_correlation.restype = C.c_double
+        L.orc_correlation.argtypes = [c_double_p, c_double_p, C.c_uint64]
+        L.orc_pearson_r2.restype = C.c_double
+        L.orc_pearson_r2.argtypes = [c_double_p, c_double_p, C.c_uint64]
+        L.orc_normalise_raw.restype = C.c_int
+        L.orc_normalise_raw.argtypes = [c_double_p, C.c_int, C.c_uint64, C.c_uint64, c_double_p]
+        L.orc_read_geno_bin.restype = C.c_int
+        L.orc_read_geno_bin.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_uint64, c_double_p, C.c_char_p,
+                                        C.c_size_t]
+        L.orc_preprocess.restype = None
+        L.orc_preprocess.argtypes = [C.POINTER(OrcParams)]
+        L.orc_read_pos.restype = C.c_int
+        L.orc_read_pos.argtypes = [C.POINTER(OrcParams), C.c_char_p, C.c_size_t]
+        L.orc_free_pos.restype = None
+        L.orc_free_pos.argtypes = [C.POINTER(OrcParams)]
+        L.orc_run.restype = C.c_uint64
+        L.orc_run.argtypes = [C.POINTER(OrcParams), C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
+                              C.POINTER(C.c_int)]
+        L.orc_row_end.restype = C.c_uint64
+        L.orc_row_end.argtypes = [C.POINTER(OrcParams), C.c_uint64]
+        _lib = L
+    return _lib
+
+
+_ref = None
+
+
+def ref():
+    """The reference's own functions (None when oracle/_ref was not built / did not travel)."""
+    global _ref
+    if _ref is None and os.path.exists(LIBREF):
+        R = C.CDLL(LIBREF)
+        R.ref_logsum.restype = C.c_double
+        R.ref_logsum.argtypes = [c_double_p, C.c_uint64]
+        R.ref_est_maf.restype = C.c_double
+        R.ref_est_maf.argtypes = [C.c_uint64, c_double_p, C.c_int]
+        R.ref_pair_freq_iter.restype = C.c_uint64
+        R.ref_pair_freq_iter.argtypes = [c_double_p, c_double_p, c_double_p, C.c_uint64, C.c_int]
+        R.ref_haplo_freq.restype = C.c_uint64
+        R.ref_haplo_freq.argtypes = [c_double_p, C.POINTER(C.c_uint64), c_double_p, c_double_p, C.c_double,
+                                     C.c_double, C.c_uint64, C.c_int]
+        R.ref_read_geno_bin.restype = C.c_int
+        R.ref_read_geno_bin.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_uint64, c_double_p]
+        R.ref_preprocess.restype = None
+        R.ref_preprocess.argtypes = [c_double_p, C.c_uint64, C.c_uint64, C.c_int, c_double_p, c_double_p]
+        R.ref_read_dist.restype = C.c_int
+        R.ref_read_dist.argtypes = [C.c_char_p, C.c_int, C.c_uint64, c_double_p]
+        R.ref_read_labels.restype = C.c_uint64
+        R.ref_read_labels.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_uint64, C.c_uint64]
+        _ref = R
+    return _ref
+
+
+def dp(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_double_p)
+
+
+class Oracle:
+    """In-memory run of the oracle: raw GL array [n_sites, n_ind, 3] (+ pos_dist) -> pair records."""
+
+    def __init__(self, raw_gl: np.ndarray, pos_dist: np.ndarray | None = None, log_scale: bool = False,
+                 ignore_miss_data: bool = False, max_kb_dist: int = 0, max_snp_dist: int = 0, min_maf: float = 0.0,
+                 n_threads: int = 1):
+        L = lib()
+        raw_gl = np.ascontiguousarray(raw_gl, dtype=np.float64)
+        self.n_sites, self.n_ind = raw_gl.shape[0], raw_gl.shape[1]
+        self.gl = np.empty_like(raw_gl)
+        rc = L.orc_normalise_raw(dp(raw_gl), int(log_scale), self.n_ind, self.n_sites, dp(self.gl))
+        if rc:
+            raise ValueError("NaN found! Is the file format correct?")
+        self.gl_log = self.gl.copy()
+        self.maf = np.empty(self.n_sites)
+        self.expg = np.empty((self.n_sites, self.n_ind))
+        if pos_dist is None:
+            pos_dist = np.full(self.n_sites, np.inf)
+        self.pos_dist = np.ascontiguousarray(pos_dist, dtype=np.float64)
+        self.p = OrcParams()
+        self.p.n_ind, self.p.n_sites = self.n_ind, self.n_sites
+        self.p.max_kb_dist, self.p.max_snp_dist, self.p.min_maf = max_kb_dist, max_snp_dist, min_maf
+        self.p.ignore_miss_data, self.p.n_threads = int(ignore_miss_data), n_threads
+        self.p.geno_lkl, self.p.maf, self.p.expected_geno = dp(self.gl), dp(self.maf), dp(self.expg)
+        self.p.pos_dist = dp(self.pos_dist)
+        L.orc_preprocess(C.byref(self.p))  # gl -> normal space in place
+
+    def count(self, s1_begin: int = 0, s1_end: int | None = None) -> int:
+        e = C.c_int(0)
+        return lib().orc_run(C.byref(self.p), s1_begin, self.n_sites if s1_end is None else s1_end, None, 0,
+                             C.byref(e))
+
+    def run(self, s1_begin: int = 0, s1_end: int | None = None) -> np.ndarray:
+        s1_end = self.n_sites if s1_end is None else s1_end
+        n = self.count(s1_begin, s1_end)
+        out = np.zeros(n, dtype=PAIR_DTYPE)
+        e = C.c_int(0)
+        lib().orc_run(C.byref(self.p), s1_begin, s1_end, out.ctypes.data_as(C.c_void_p), n, C.byref(e))
+        if e.value:
+            raise RuntimeError(f"oracle error code {e.value}")
+        return out
+
+    def row_ends(self) -> np.ndarray:
+        return np.array([lib().orc_row_end(C.byref(self.p), s) for s in range(self.n_sites)], dtype=np.uint64)

@@ -1,0 +1,98 @@
+/*
+ * ref_shim.cpp -- extern "C" doors into the REFERENCE's own functions (test infrastructure).
+ *
+ * This file is appended by oracle/build_ref.sh to a translation unit made of the reference's
+ * shared/gen_func.{hpp,cpp} and shared/read_data.{hpp,cpp}, read where they lie under
+ * /root/reference at build time (never copied into the repo), so every function called below is the
+ * reference's code, compiled here.  The shim itself adds no arithmetic except the flat <-> jagged
+ * array plumbing and, in ref_preprocess, the one expression of ngsLD.cpp:113 (p1 + 2*p2) that lives
+ * in main() and cannot be compiled without GSL.
+ *
+ * NB: the reference headers define abs/min/max as MACROS (gen_func.hpp:21-23); do not use those
+ * names here and do not include further standard headers.
+ */
+
+static double **ref_rows(const double *flat, uint64_t n) {
+  double **p = new double *[n];
+  for (uint64_t i = 0; i < n; i++) p[i] = const_cast<double *>(flat) + 3 * i;
+  return p;
+}
+
+extern "C" {
+
+double ref_logsum(double *a, uint64_t n) { return logsum(a, n); }
+void ref_post_prob(double *pp, double *lkl, uint64_t n) { post_prob(pp, lkl, NULL, n); }
+int ref_miss_data(double *g) { return miss_data(g) ? 1 : 0; }
+void ref_conv_space_log(double *g, int n) { conv_space(g, n, log); }
+void ref_conv_space_exp(double *g, int n) { conv_space(g, n, exp); }
+
+double ref_est_maf(uint64_t n_ind, const double *pdg, int ignore_miss) {
+  double **rows = ref_rows(pdg, n_ind);
+  double m = est_maf(n_ind, rows, (double *)NULL, ignore_miss != 0);
+  delete[] rows;
+  return m;
+}
+
+uint64_t ref_pair_freq_iter(double f[4], const double *gl1, const double *gl2, uint64_t n, int ignore_miss) {
+  double **a = ref_rows(gl1, n), **b = ref_rows(gl2, n);
+  uint64_t x = pair_freq_iter(f, a, b, n, ignore_miss != 0);
+  delete[] a;
+  delete[] b;
+  return x;
+}
+
+uint64_t ref_haplo_freq(double hap[4], uint64_t *n, const double *gl1, const double *gl2, double maf1, double maf2,
+                        uint64_t n_ind, int ignore_miss) {
+  double **a = ref_rows(gl1, n_ind), **b = ref_rows(gl2, n_ind);
+  double loglkl = 0;
+  uint64_t it = haplo_freq(hap, &loglkl, n, a, b, maf1, maf2, n_ind, ignore_miss != 0, false); /* ngsLD.cpp:294 */
+  delete[] a;
+  delete[] b;
+  return it;
+}
+
+/* read_geno (binary) + transp_matrix, flattened to [site][ind][3] (log space, normalised) */
+int ref_read_geno_bin(const char *path, int log_scale, uint64_t n_ind, uint64_t n_sites, double *out) {
+  bool ls = log_scale != 0;
+  double ***tmp = read_geno(const_cast<char *>(path), true, true, &ls, n_ind, n_sites); /* ngsLD.cpp:87 */
+  double ***g = transp_matrix(tmp, n_ind, n_sites);                                    /* ngsLD.cpp:88 */
+  for (uint64_t s = 0; s < n_sites; s++)
+    for (uint64_t i = 0; i < n_ind; i++)
+      for (int k = 0; k < 3; k++) out[(s * n_ind + i) * 3 + k] = g[s][i][k];
+  free_ptr((void ***)tmp, n_ind, n_sites);
+  free_ptr((void **)g, n_sites);
+  return 0;
+}
+
+/* ngsLD.cpp:103-114 with the reference's est_maf / conv_space; in/out flat [site][ind][3] */
+void ref_preprocess(double *gl, uint64_t n_ind, uint64_t n_sites, int ignore_miss, double *maf, double *expg) {
+  for (uint64_t s = 0; s < n_sites; s++) maf[s] = ref_est_maf(n_ind, gl + s * n_ind * 3, ignore_miss);
+  for (uint64_t s = 0; s < n_sites; s++)
+    for (uint64_t i = 0; i < n_ind; i++) {
+      double *t = gl + (s * n_ind + i) * 3;
+      conv_space(t, N_GENO, exp);
+      expg[s * n_ind + i] = t[1] + 2 * t[2];
+    }
+}
+
+int ref_read_dist(const char *path, int header, uint64_t n_sites, double *out) {
+  double *d = read_dist(const_cast<char *>(path), header ? 1 : 0, n_sites); /* ngsLD.cpp:120 */
+  for (uint64_t s = 0; s < n_sites; s++) out[s] = d[s];
+  delete[] d;
+  return 0;
+}
+
+/* ngsLD.cpp:124-132: labels = lines of the pos file with the first TAB turned into ':' */
+uint64_t ref_read_labels(const char *path, int header, char *out, uint64_t stride, uint64_t cap) {
+  char **lines = NULL;
+  uint64_t n = read_file(path, &lines, header ? 1 : 0);
+  for (uint64_t s = 0; s < n && s < cap; s++) {
+    char *t = strchr(lines[s], '\t');
+    if (t != NULL) *t = ':';
+    strncpy(out + s * stride, lines[s], stride - 1);
+    out[s * stride + stride - 1] = '\0';
+  }
+  return n;
+}
+
+} /* extern "C" */
