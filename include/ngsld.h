@@ -1,0 +1,142 @@
+/*
+ * ngsld.h -- C-ABI of the MI355X-native pairwise-LD engine (drop-in for the pair-LD path of
+ * fgvieira/ngsLD v1.2.1).  Plain C: opaque handle, pointers and sizes, int return codes, no C++ or
+ * torch types, no exceptions across the boundary.
+ *
+ * What this boundary replaces in the reference (paths relative to the reference tree):
+ *   ngsLD.cpp:153-198   threadpool_create -> per-s1 threadpool_add(calc_pair_LD) -> threadpool_wait
+ *                       -> threadpool_destroy            => ngsld_create / ngsld_plan / ngsld_run / ngsld_destroy
+ *   ngsLD.cpp:229-359   calc_pair_LD (window walk, filters, haplo_freq, pearson_r, D/D'/r2)
+ *                                                         => the HIP pair kernel behind ngsld_run
+ *   ngsLD.cpp:103-114   est_maf + exp() + expected genotypes => ngsld_set_geno_raw (device prep kernel)
+ *   ngsLD.hpp:11-44     `params`: geno_lkl, maf, pos_dist, max_kb_dist, max_snp_dist, min_maf,
+ *                       ignore_miss_data, extend_out      => ngsld_set_geno_*, ngsld_set_pos_dist, ngsld_params
+ * The text side (labels, dist column, %f formatting, chi2 in float) stays with the caller; helpers
+ * that mirror it live in ngsld_host.h.
+ *
+ * Errors: the reference is fatal-on-error (error(), gen_func.cpp:12-18).  This library never exits:
+ * every entry point returns NGSLD_OK or a negative code and ngsld_last_error() gives the text; the
+ * ngsLD command-line wrapper turns them back into the reference's stderr format and exit(-1).
+ *
+ * Threading: one thread per ngsld_ctx at a time.  ngsld_run blocks; the sink is called on the calling
+ * thread, batches arrive in increasing (s1, s2) order.
+ */
+#ifndef NGSLD_H
+#define NGSLD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ngsld_ctx ngsld_ctx;
+
+enum {
+  NGSLD_OK = 0,
+  NGSLD_ERR_INVALID = -1,    /* bad argument or call order (cf. threadpool_invalid, threadpool.h:39) */
+  NGSLD_ERR_DEVICE = -2,     /* HIP runtime failure, or no usable gfx950 device */
+  NGSLD_ERR_NOMEM = -3,      /* host or device allocation failed */
+  NGSLD_ERR_NAN = -4,        /* "NaN found! Is the file format correct?" (read_data.cpp:42-45) */
+  NGSLD_ERR_MAF_RANGE = -5,  /* "invalid allele frequencies" (gen_func.cpp:1030-1031) */
+  NGSLD_ERR_SINK = -6,       /* the sink callback returned non-zero */
+  NGSLD_ERR_UNSUPPORTED = -7 /* problem shape outside the built kernel set (n_ind > 4096) */
+};
+
+/* The fields of `params` (ngsLD.hpp:11-44) that calc_pair_LD reads. */
+typedef struct {
+  uint64_t max_kb_dist;      /* 0 = no distance limit (ngsLD.cpp:252) */
+  uint64_t max_snp_dist;     /* 0 = no limit (ngsLD.cpp:258) */
+  double min_maf;            /* ngsLD.cpp:264-275: s1 below -> row empty, s2 below -> pair skipped */
+  int32_t ignore_miss_data;  /* gen_func.cpp:1089 */
+  int32_t extend_out;        /* also produce ngsld_rec_ext */
+} ngsld_params;
+
+/* Standard columns computed per pair (ngsLD.cpp:290-306): 32 bytes. */
+typedef struct {
+  double r2_ExpG; /* pearson_r(expected_geno[s1], expected_geno[s2])^2 */
+  double D;
+  double Dp;
+  double r2;
+} ngsld_rec_std;
+
+/* What the extended columns (ngsLD.cpp:336-349) need beyond per-site data: 40 bytes. */
+typedef struct {
+  double hap[4];       /* hap_freq[0..3] after the EM */
+  uint32_t n_ind_data; /* sample_size: individuals used by the EM (bit-exact) */
+  uint32_t n_iter;     /* return value of haplo_freq */
+} ngsld_rec_ext;
+
+/* One batch of results: all pairs of rows [s1_begin, s1_end), in (s1, s2) order.
+ * Row s1 owns records [row_off[s1 - s1_begin], row_off[s1 - s1_begin + 1]); its pairs are the sites
+ * s2 in (s1, row_end[s1 - s1_begin]) with keep[s2] != 0, in increasing s2.  Pointers are valid only
+ * during the callback. */
+typedef struct {
+  uint64_t s1_begin, s1_end;
+  uint64_t n_pairs;
+  const uint64_t *row_off;   /* [s1_end - s1_begin + 1], batch-relative */
+  const uint32_t *row_end;   /* [s1_end - s1_begin], exclusive end of the walk of each row */
+  const uint8_t *keep;       /* [n_sites], global: 0 where maf[s] < min_maf */
+  const ngsld_rec_std *std;  /* [n_pairs] */
+  const ngsld_rec_ext *ext;  /* [n_pairs] or NULL when extend_out == 0 */
+} ngsld_batch;
+
+typedef int (*ngsld_sink_fn)(void *user, const ngsld_batch *batch);
+
+const char *ngsld_version(void);
+
+/* Bind to HIP device `device` (must be gfx950).  Fails with NGSLD_ERR_DEVICE when there is no GPU:
+ * there is no CPU fallback behind this API. */
+int ngsld_create(int device, ngsld_ctx **ctx);
+void ngsld_destroy(ngsld_ctx *ctx);
+/* Text of the last failure on ctx (ctx may be NULL: last ngsld_create failure of this thread). */
+const char *ngsld_last_error(const ngsld_ctx *ctx);
+
+/* Genotype likelihoods exactly as the reference's binary input holds them: n_sites*n_ind*3 doubles,
+ * [site][ind][geno] (read_data.cpp:28-47), natural scale or logs (log_scale).  The device does what
+ * read_geno + main do to them: log, -inf -> -1e15, log-normalise, NaN check, est_maf, exp, expected
+ * genotypes.  `on_device` != 0: gl_raw is a device pointer on this ctx's device (not modified). */
+int ngsld_set_geno_raw(ngsld_ctx *ctx, const double *gl_raw, uint64_t n_sites, uint64_t n_ind, int log_scale,
+                       int ignore_miss_data, int on_device);
+/* The reference's own data contract at calc_pair_LD: normalised normal-space geno_lkl
+ * [site][ind][3] and maf[site] already computed by the caller (ngsLD.hpp:36-37). */
+int ngsld_set_geno_lkl(ngsld_ctx *ctx, const double *geno_lkl, const double *maf, uint64_t n_sites, uint64_t n_ind,
+                       int on_device);
+/* Copy the per-site allele frequencies (est_maf) to host memory, n_sites doubles. */
+int ngsld_get_maf(ngsld_ctx *ctx, double *maf_out);
+/* pos_dist[s] = bp gap to the previous site, INFINITY at a chromosome change (read_data.cpp:165-218).
+ * NULL = all INFINITY (the reference's no --pos case, ngsLD.cpp:134).  Host pointer, n_sites doubles. */
+int ngsld_set_pos_dist(ngsld_ctx *ctx, const double *pos_dist);
+
+/* Fix the filters and enumerate the pair space (the s2 walk of ngsLD.cpp:240-282 for every s1).
+ * Returns the total number of pairs that reach haplo_freq. */
+int ngsld_plan(ngsld_ctx *ctx, const ngsld_params *params, uint64_t *n_pairs);
+/* Host views of the plan, valid until the next ngsld_plan/ngsld_set_*: row_off [n_sites+1] (pairs
+ * before each row), row_end [n_sites].  Used to shard rows across GPUs by pair count. */
+int ngsld_plan_rows(ngsld_ctx *ctx, const uint64_t **row_off, const uint32_t **row_end);
+
+/* Compute every pair of rows [s1_begin, s1_end) and hand the records to `sink`, batch by batch. */
+int ngsld_run(ngsld_ctx *ctx, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user);
+
+/* Same computation with the records left in caller-owned DEVICE memory (no host transfer):
+ * d_std holds ngsld_rec_std[n], d_ext ngsld_rec_ext[n] (may be NULL), n = row_off[s1_end] -
+ * row_off[s1_begin], record k = global pair index - row_off[s1_begin].  `hip_stream` is a hipStream_t
+ * (NULL = the ctx's own stream); the call returns after enqueueing when a stream is given. */
+int ngsld_run_device(ngsld_ctx *ctx, uint64_t s1_begin, uint64_t s1_end, void *d_std, void *d_ext, void *hip_stream);
+
+/* Timing of the pair kernel launches issued by the last ngsld_run / ngsld_run_device, measured with
+ * HIP events on the stream they ran on (synchronises that stream).  Any pointer may be NULL. */
+int ngsld_last_kernel_time(ngsld_ctx *ctx, double *total_ms, uint64_t *n_launches, uint64_t *n_pairs);
+
+/* Tuning knobs (optional): pairs per work item, max pairs per batch of ngsld_run. 0 keeps the default. */
+int ngsld_set_tuning(ngsld_ctx *ctx, uint32_t pairs_per_item, uint64_t batch_pairs);
+
+/* On-device self test of the wavefront primitives the pair kernel relies on (cross-lane fold
+ * reduction, refined reciprocal).  Returns NGSLD_OK or NGSLD_ERR_DEVICE with a message. */
+int ngsld_selftest(ngsld_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

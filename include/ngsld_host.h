@@ -1,0 +1,52 @@
+/*
+ * ngsld_host.h -- host-side helpers of the drop-in (no device needed): the input readers and the TSV
+ * writer, with the reference's semantics.  Plain C ABI so they can be bound and tested like ngsld.h.
+ *
+ * Reference interfaces mirrored here (paths relative to the reference tree):
+ *   shared/read_data.cpp:165-218  read_dist       => ngsld_host_read_pos (pos_dist)
+ *   ngsLD.cpp:124-132             labels          => ngsld_host_read_pos (labels, first TAB -> ':')
+ *   shared/gen_func.cpp:238-282   read_file       => line rules (skip empty and '#' lines, header offset)
+ *   shared/read_data.cpp:28-47    read_geno (bin) => ngsld_host_read_geno_bin (raw doubles; the arithmetic
+ *                                                    of that loop runs on the device, ngsld_set_geno_raw)
+ *   ngsLD.cpp:55-56               size check      => ngsld_host_geno_size_ok
+ *   ngsLD.cpp:77,314-351          TSV header/rows => ngsld_host_format_header / ngsld_host_format_pair
+ *   ngsLD.cpp:296-298,328-333     hap_maf, chi2   => inside ngsld_host_format_pair (float chi2)
+ */
+#ifndef NGSLD_HOST_H
+#define NGSLD_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "ngsld.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ngsld_pos ngsld_pos;
+
+/* Read a position file (chr TAB pos [TAB ...]); `header` != 0 skips one line (--posH).
+ * Returns NGSLD_OK or NGSLD_ERR_INVALID with the reference's message text in err. */
+int ngsld_host_read_pos(const char *path, int header, uint64_t n_sites, ngsld_pos **out, char *err, size_t errlen);
+const double *ngsld_host_pos_dist(const ngsld_pos *p);
+const char *ngsld_host_label(const ngsld_pos *p, uint64_t site);
+void ngsld_host_free_pos(ngsld_pos *p);
+
+/* n_sites == file_size / 8 / n_ind / 3 with the reference's integer divisions (ngsLD.cpp:55). */
+int ngsld_host_geno_size_ok(uint64_t file_size, uint64_t n_ind, uint64_t n_sites);
+/* Read n_sites*n_ind*3 raw doubles (plain or gzip-compressed file, like gzread) and require EOF after them. */
+int ngsld_host_read_geno_bin(const char *path, uint64_t n_ind, uint64_t n_sites, double *out_raw, char *err,
+                             size_t errlen);
+
+/* TSV text.  Both return the number of bytes written (no NUL needed), 0 if cap is too small.
+ * NaN is printed as "-nan": every NaN the reference prints comes from an x86 invalid operation
+ * (0/0 ...), whose default NaN has the sign bit set, and glibc's %f shows that sign. */
+size_t ngsld_host_format_header(char *buf, size_t cap, int extend_out);
+size_t ngsld_host_format_pair(char *buf, size_t cap, const char *label1, const char *label2, double dist,
+                              const ngsld_rec_std *std_rec, const ngsld_rec_ext *ext_rec, double maf1, double maf2);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

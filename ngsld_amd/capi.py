@@ -1,0 +1,273 @@
+"""ctypes binding of the C-ABI in include/ngsld.h and include/ngsld_host.h (libngsld.so, built in-tree).
+
+This is plumbing: every call goes straight into the HIP library.  There is no Python or CPU fallback --
+if the library is missing or no gfx950 device is present the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "libngsld.so")
+CLI_PATH = os.path.join(PKG_DIR, "bin", "ngsLD")
+
+OK, ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_NAN, ERR_MAF_RANGE, ERR_SINK, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
+
+
+class Params(C.Structure):
+    _fields_ = [("max_kb_dist", C.c_uint64), ("max_snp_dist", C.c_uint64), ("min_maf", C.c_double),
+                ("ignore_miss_data", C.c_int32), ("extend_out", C.c_int32)]
+
+
+REC_STD = np.dtype([("r2_ExpG", "<f8"), ("D", "<f8"), ("Dp", "<f8"), ("r2", "<f8")])
+REC_EXT = np.dtype([("hap", "<f8", (4,)), ("n_ind_data", "<u4"), ("n_iter", "<u4")])
+
+
+class Batch(C.Structure):
+    _fields_ = [("s1_begin", C.c_uint64), ("s1_end", C.c_uint64), ("n_pairs", C.c_uint64),
+                ("row_off", C.POINTER(C.c_uint64)), ("row_end", C.POINTER(C.c_uint32)),
+                ("keep", C.POINTER(C.c_uint8)), ("std", C.c_void_p), ("ext", C.c_void_p)]
+
+
+SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Batch))
+
+# every symbol the two headers declare (checked by tests/test_abi.py against the headers' text)
+SYMBOLS = [
+    "ngsld_version", "ngsld_create", "ngsld_destroy", "ngsld_last_error", "ngsld_set_geno_raw", "ngsld_set_geno_lkl",
+    "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device",
+    "ngsld_last_kernel_time", "ngsld_set_tuning", "ngsld_selftest",
+    "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos",
+    "ngsld_host_geno_size_ok", "ngsld_host_read_geno_bin", "ngsld_host_format_header", "ngsld_host_format_pair",
+]
+
+
+class NgsldError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"ngsld error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def build(force: bool = False, jobs: int = 8) -> None:
+    """Compile the HIP library and the CLI in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(PKG_DIR, "csrc")
+    if force:
+        subprocess.check_call(["make", "-s", "-C", csrc, "clean"])
+    subprocess.check_call(["make", "-s", f"-j{jobs}", "-C", csrc, "all"])
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} is missing: run ngsld_amd.capi.build() (or make -C ngsld_amd/csrc); "
+                                    "there is no fallback implementation")
+        L = C.CDLL(LIB_PATH)
+        vp, u64, dbl = C.c_void_p, C.c_uint64, C.c_double
+        L.ngsld_version.restype = C.c_char_p
+        L.ngsld_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.ngsld_destroy.argtypes = [vp]
+        L.ngsld_destroy.restype = None
+        L.ngsld_last_error.argtypes = [vp]
+        L.ngsld_last_error.restype = C.c_char_p
+        L.ngsld_set_geno_raw.argtypes = [vp, vp, u64, u64, C.c_int, C.c_int, C.c_int]
+        L.ngsld_set_geno_lkl.argtypes = [vp, vp, vp, u64, u64, C.c_int]
+        L.ngsld_get_maf.argtypes = [vp, vp]
+        L.ngsld_set_pos_dist.argtypes = [vp, vp]
+        L.ngsld_plan.argtypes = [vp, C.POINTER(Params), C.POINTER(u64)]
+        L.ngsld_plan_rows.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint32))]
+        L.ngsld_run.argtypes = [vp, u64, u64, SINK_FN, vp]
+        L.ngsld_run_device.argtypes = [vp, u64, u64, vp, vp, vp]
+        L.ngsld_last_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
+        L.ngsld_set_tuning.argtypes = [vp, C.c_uint32, u64]
+        L.ngsld_selftest.argtypes = [vp]
+        L.ngsld_host_read_pos.argtypes = [C.c_char_p, C.c_int, u64, C.POINTER(vp), C.c_char_p, C.c_size_t]
+        L.ngsld_host_pos_dist.argtypes = [vp]
+        L.ngsld_host_pos_dist.restype = C.POINTER(dbl)
+        L.ngsld_host_label.argtypes = [vp, u64]
+        L.ngsld_host_label.restype = C.c_char_p
+        L.ngsld_host_free_pos.argtypes = [vp]
+        L.ngsld_host_free_pos.restype = None
+        L.ngsld_host_geno_size_ok.argtypes = [u64, u64, u64]
+        L.ngsld_host_read_geno_bin.argtypes = [C.c_char_p, u64, u64, vp, C.c_char_p, C.c_size_t]
+        L.ngsld_host_format_header.argtypes = [C.c_char_p, C.c_size_t, C.c_int]
+        L.ngsld_host_format_header.restype = C.c_size_t
+        L.ngsld_host_format_pair.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, dbl, vp, vp, dbl, dbl]
+        L.ngsld_host_format_pair.restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+# ------------------------------------------------------------------------------------------------
+# host helpers (no device)
+# ------------------------------------------------------------------------------------------------
+def read_pos(path: str, header: bool, n_sites: int) -> tuple[np.ndarray, list[str]]:
+    L = lib()
+    h = C.c_void_p()
+    err = C.create_string_buffer(512)
+    rc = L.ngsld_host_read_pos(path.encode(), int(header), n_sites, C.byref(h), err, len(err))
+    if rc != OK:
+        raise NgsldError(rc, err.value.decode())
+    try:
+        pd = np.ctypeslib.as_array(L.ngsld_host_pos_dist(h), shape=(n_sites,)).copy()
+        labels = [L.ngsld_host_label(h, s).decode() for s in range(n_sites)]
+    finally:
+        L.ngsld_host_free_pos(h)
+    return pd, labels
+
+
+def read_geno_bin(path: str, n_ind: int, n_sites: int) -> np.ndarray:
+    L = lib()
+    out = np.empty((n_sites, n_ind, 3), dtype=np.float64)
+    err = C.create_string_buffer(512)
+    rc = L.ngsld_host_read_geno_bin(path.encode(), n_ind, n_sites, out.ctypes.data, err, len(err))
+    if rc != OK:
+        raise NgsldError(rc, err.value.decode())
+    return out
+
+
+def format_header(extend_out: bool) -> str:
+    buf = C.create_string_buffer(512)
+    n = lib().ngsld_host_format_header(buf, len(buf), int(extend_out))
+    return buf.raw[:n].decode()
+
+
+def format_pair(l1, l2, dist: float, std_rec: np.ndarray, ext_rec: np.ndarray | None, maf1: float, maf2: float) -> str:
+    buf = C.create_string_buffer(8192)
+    s = np.ascontiguousarray(std_rec).reshape(1).view(REC_STD) if std_rec.dtype != REC_STD else std_rec.reshape(1)
+    e_ptr = None
+    if ext_rec is not None:
+        e = ext_rec.reshape(1)
+        e_ptr = e.ctypes.data
+    n = lib().ngsld_host_format_pair(buf, len(buf), None if l1 is None else l1.encode(),
+                                     None if l2 is None else l2.encode(), dist, s.ctypes.data, e_ptr, maf1, maf2)
+    return buf.raw[:n].decode()
+
+
+# ------------------------------------------------------------------------------------------------
+# the engine
+# ------------------------------------------------------------------------------------------------
+class Engine:
+    """One ngsld_ctx.  Mirrors the call order of the reference's main(): data -> positions -> run."""
+
+    def __init__(self, device: int = 0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        rc = self._L.ngsld_create(device, C.byref(self._h))
+        if rc != OK:
+            raise NgsldError(rc, self._L.ngsld_last_error(None).decode())
+        self.n_sites = self.n_ind = 0
+        self.extend_out = False
+
+    def close(self) -> None:
+        if self._h:
+            self._L.ngsld_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        if rc != OK:
+            raise NgsldError(rc, self._L.ngsld_last_error(self._h).decode())
+
+    def selftest(self) -> None:
+        self._check(self._L.ngsld_selftest(self._h))
+
+    def set_geno_raw(self, gl, n_sites: int | None = None, n_ind: int | None = None, log_scale: bool = False,
+                     ignore_miss_data: bool = False) -> None:
+        """gl: numpy float64 [n_sites, n_ind, 3] (host) or an int device pointer with explicit sizes."""
+        if isinstance(gl, np.ndarray):
+            gl = np.ascontiguousarray(gl, dtype=np.float64)
+            n_sites, n_ind = gl.shape[0], gl.shape[1]
+            ptr, on_dev = gl.ctypes.data, 0
+        else:
+            ptr, on_dev = int(gl), 1
+        self._check(self._L.ngsld_set_geno_raw(self._h, ptr, n_sites, n_ind, int(log_scale), int(ignore_miss_data),
+                                               on_dev))
+        self.n_sites, self.n_ind = n_sites, n_ind
+
+    def set_geno_lkl(self, geno_lkl: np.ndarray, maf: np.ndarray) -> None:
+        g = np.ascontiguousarray(geno_lkl, dtype=np.float64)
+        m = np.ascontiguousarray(maf, dtype=np.float64)
+        self._check(self._L.ngsld_set_geno_lkl(self._h, g.ctypes.data, m.ctypes.data, g.shape[0], g.shape[1], 0))
+        self.n_sites, self.n_ind = g.shape[0], g.shape[1]
+
+    def maf(self) -> np.ndarray:
+        out = np.empty(self.n_sites, dtype=np.float64)
+        self._check(self._L.ngsld_get_maf(self._h, out.ctypes.data))
+        return out
+
+    def set_pos_dist(self, pos_dist: np.ndarray | None) -> None:
+        if pos_dist is None:
+            self._check(self._L.ngsld_set_pos_dist(self._h, None))
+        else:
+            pd = np.ascontiguousarray(pos_dist, dtype=np.float64)
+            assert pd.shape[0] == self.n_sites
+            self._check(self._L.ngsld_set_pos_dist(self._h, pd.ctypes.data))
+
+    def set_tuning(self, pairs_per_item: int = 0, batch_pairs: int = 0) -> None:
+        self._check(self._L.ngsld_set_tuning(self._h, pairs_per_item, batch_pairs))
+
+    def plan(self, max_kb_dist: int = 0, max_snp_dist: int = 0, min_maf: float = 0.0, ignore_miss_data: bool = False,
+             extend_out: bool = True) -> int:
+        p = Params(max_kb_dist, max_snp_dist, min_maf, int(ignore_miss_data), int(extend_out))
+        n = C.c_uint64()
+        self._check(self._L.ngsld_plan(self._h, C.byref(p), C.byref(n)))
+        self.extend_out = extend_out
+        return n.value
+
+    def plan_rows(self) -> tuple[np.ndarray, np.ndarray]:
+        ro, re = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint32)()
+        self._check(self._L.ngsld_plan_rows(self._h, C.byref(ro), C.byref(re)))
+        return (np.ctypeslib.as_array(ro, shape=(self.n_sites + 1,)).copy(),
+                np.ctypeslib.as_array(re, shape=(self.n_sites,)).copy())
+
+    def run(self, s1_begin: int = 0, s1_end: int | None = None):
+        """Run rows [s1_begin, s1_end) through the sink path; returns (s1, s2, std, ext) arrays."""
+        s1_end = self.n_sites if s1_end is None else s1_end
+        s1s, s2s, stds, exts = [], [], [], []
+
+        def sink(_user, bp):
+            b = bp.contents
+            n, rows = b.n_pairs, b.s1_end - b.s1_begin
+            if n:
+                stds.append(np.frombuffer(C.string_at(b.std, n * REC_STD.itemsize), dtype=REC_STD).copy())
+                if b.ext:
+                    exts.append(np.frombuffer(C.string_at(b.ext, n * REC_EXT.itemsize), dtype=REC_EXT).copy())
+            keep = np.ctypeslib.as_array(b.keep, shape=(self.n_sites,))
+            row_end = np.ctypeslib.as_array(b.row_end, shape=(rows,))
+            row_off = np.ctypeslib.as_array(b.row_off, shape=(rows + 1,))
+            for r in range(rows):
+                s1 = b.s1_begin + r
+                s2 = np.arange(s1 + 1, max(int(row_end[r]), s1 + 1))
+                s2 = s2[keep[s2] != 0]
+                assert len(s2) == row_off[r + 1] - row_off[r]
+                s1s.append(np.full(len(s2), s1, dtype=np.uint64))
+                s2s.append(s2.astype(np.uint64))
+            return 0
+
+        cb = SINK_FN(sink)
+        self._check(self._L.ngsld_run(self._h, s1_begin, s1_end, cb, None))
+        cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)
+        return (cat(s1s, np.uint64), cat(s2s, np.uint64), cat(stds, REC_STD),
+                cat(exts, REC_EXT) if self.extend_out else None)
+
+    def run_device(self, s1_begin: int, s1_end: int, d_std: int, d_ext: int | None, stream: int | None = None) -> None:
+        self._check(self._L.ngsld_run_device(self._h, s1_begin, s1_end, d_std, d_ext, stream))
+
+    def last_kernel_time(self) -> tuple[float, int, int]:
+        ms, nl, npairs = C.c_double(), C.c_uint64(), C.c_uint64()
+        self._check(self._L.ngsld_last_kernel_time(self._h, C.byref(ms), C.byref(nl), C.byref(npairs)))
+        return ms.value, nl.value, npairs.value

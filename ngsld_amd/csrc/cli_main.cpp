@@ -1,0 +1,263 @@
+// cli_main.cpp -- the `ngsLD` command line of the MI355X-native engine: same flags, defaults, validation
+// messages, stderr chatter and TSV as the reference binary (parse_args.cpp:6-184, ngsLD.cpp:27-223), with
+// the thread-pool section (ngsLD.cpp:153-198) replaced by the C-ABI in include/ngsld.h.
+//
+// Differences a user can see (all listed in DESIGN.md):
+//   * rows are written in (site1, site2) order (the reference's order is arbitrary for --n_threads > 1);
+//   * --n_threads is accepted and ignored by the GPU path; --device N (new) picks the GPU;
+//   * text/.gz genotype input, --call_geno/--N_thresh/--call_thresh and --rnd_sample < 1 are not part of
+//     the accelerated path yet and end with an error instead of being silently ignored.
+#include <getopt.h>
+#include <sys/stat.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+#include "../../include/ngsld.h"
+#include "../../include/ngsld_host.h"
+
+namespace {
+
+const char *kVersion = "1.2.1-mi355x";
+
+struct Params {  // ngsLD.hpp:11-44
+  char *in_geno = nullptr;
+  bool in_bin = false, in_probs = false, in_logscale = false;
+  uint64_t n_ind = 0, n_sites = 0;
+  char *in_pos = nullptr;
+  bool in_pos_header = false;
+  uint64_t max_kb_dist = 100, max_snp_dist = 0;
+  double min_maf = 0;
+  bool ignore_miss_data = false, call_geno = false;
+  double N_thresh = 0, call_thresh = 0, rnd_sample = 1;
+  uint64_t seed = 0;
+  bool extend_out = false;
+  char *out = nullptr;
+  FILE *out_fh = stdout;
+  unsigned n_threads = 1, verbose = 1;
+  int device = 0;
+};
+
+[[noreturn]] void error(const char *func, const char *msg) {  // gen_func.cpp:12-18
+  fflush(stdout);
+  fprintf(stderr, "\n=====\nERROR: [%s] %s\n=====\n\n", func, msg);
+  perror("\t");
+  fflush(stderr);
+  exit(-1);
+}
+
+void parse_cmd_args(Params *pars, int argc, char **argv) {
+  static struct option long_options[] = {{"geno", required_argument, NULL, 'g'},
+                                         {"probs", no_argument, NULL, 'p'},
+                                         {"log_scale", no_argument, NULL, 'l'},
+                                         {"n_ind", required_argument, NULL, 'n'},
+                                         {"n_sites", required_argument, NULL, 's'},
+                                         {"pos", required_argument, NULL, 'a'},
+                                         {"posH", required_argument, NULL, 'A'},
+                                         {"max_kb_dist", required_argument, NULL, 'd'},
+                                         {"max_snp_dist", required_argument, NULL, 'D'},
+                                         {"min_maf", required_argument, NULL, 'f'},
+                                         {"ignore_miss_data", no_argument, NULL, 'm'},
+                                         {"call_geno", no_argument, NULL, 'c'},
+                                         {"N_thresh", required_argument, NULL, 'N'},
+                                         {"call_thresh", required_argument, NULL, 'C'},
+                                         {"rnd_sample", required_argument, NULL, 'r'},
+                                         {"seed", required_argument, NULL, 'S'},
+                                         {"extend_out", no_argument, NULL, 'x'},
+                                         {"out", required_argument, NULL, 'o'},
+                                         {"outH", required_argument, NULL, 'O'},
+                                         {"n_threads", required_argument, NULL, 't'},
+                                         {"verbose", required_argument, NULL, 'V'},
+                                         {"device", required_argument, NULL, 1001},
+                                         {0, 0, 0, 0}};
+  pars->seed = (uint64_t)(time(NULL) + rand() % 1000);  // parse_args.cpp:23
+  int c = 0;
+  while ((c = getopt_long_only(argc, argv, "g:pln:s:Z:d:D:f:mcN:C:r:S:xo:t:V:", long_options, NULL)) != -1)
+    switch (c) {
+      case 'g': pars->in_geno = optarg; break;
+      case 'p': pars->in_probs = true; break;
+      case 'l': pars->in_logscale = true; pars->in_probs = true; break;
+      case 'n': pars->n_ind = (uint64_t)atoi(optarg); break;
+      case 's': pars->n_sites = (uint64_t)atoi(optarg); break;
+      case 'a': pars->in_pos = optarg; pars->in_pos_header = false; break;
+      case 'A': pars->in_pos = optarg; pars->in_pos_header = true; break;
+      case 'd': pars->max_kb_dist = (uint64_t)atoi(optarg); break;
+      case 'D': pars->max_snp_dist = (uint64_t)atoi(optarg); break;
+      case 'f': pars->min_maf = atof(optarg); break;
+      case 'm': pars->ignore_miss_data = true; break;
+      case 'c': pars->call_geno = true; break;
+      case 'N': pars->N_thresh = atof(optarg); pars->call_geno = true; break;
+      case 'C': pars->call_thresh = atof(optarg); pars->call_geno = true; break;
+      case 'r': pars->rnd_sample = atof(optarg); break;
+      case 'S': pars->seed = (uint64_t)atoi(optarg); break;
+      case 'x': pars->extend_out = true; break;
+      case 'o': pars->out = optarg; break;
+      case 't': pars->n_threads = (unsigned)atoi(optarg); break;
+      case 'V': pars->verbose = (unsigned)atoi(optarg); break;
+      case 1001: pars->device = atoi(optarg); break;
+      default: exit(-1);  // unknown flags and --outH (declared, no case: parse_args.cpp:55,130)
+    }
+
+  if (pars->verbose >= 1) {  // parse_args.cpp:135-159
+    fprintf(stderr, "==> Input Arguments:\n");
+    fprintf(stderr,
+            "\tgeno: %s\n\tprobs: %s\n\tlog_scale: %s\n\tn_ind: %lu\n\tn_sites: %lu\n\tpos: %s (%s header)\n\t"
+            "max_kb_dist (kb): %lu\n\tmax_snp_dist: %lu\n\tmin_maf: %f\n\tignore_miss_data: %s\n\tcall_geno: %s\n\t"
+            "N_thresh: %f\n\tcall_thresh: %f\n\trnd_sample: %f\n\tseed: %lu\n\textend_out: %s\n\tout: %s\n\t"
+            "n_threads: %d\n\tverbose: %d\n\tversion: %s (%s @ %s)\n\n",
+            pars->in_geno, pars->in_probs ? "true" : "false", pars->in_logscale ? "true" : "false",
+            (unsigned long)pars->n_ind, (unsigned long)pars->n_sites, pars->in_pos,
+            pars->in_pos_header ? "WITH" : "WITHOUT", (unsigned long)pars->max_kb_dist,
+            (unsigned long)pars->max_snp_dist, pars->min_maf, pars->ignore_miss_data ? "true" : "false",
+            pars->call_geno ? "true" : "false", pars->N_thresh, pars->call_thresh, pars->rnd_sample,
+            (unsigned long)pars->seed, pars->extend_out ? "true" : "false", pars->out, pars->n_threads,
+            pars->verbose, kVersion, __DATE__, __TIME__);
+  }
+  if (pars->verbose > 4)
+    fprintf(stderr,
+            "==> Verbose values greater than 4 for debugging purpose only. Expect large amounts of info on screen\n");
+
+  // parse_args.cpp:168-183
+  if (pars->in_geno == NULL) error(__FUNCTION__, "genotype input file (--geno) missing!");
+  if (pars->n_ind == 0) error(__FUNCTION__, "number of individuals (--n_ind) missing!");
+  if (pars->n_sites == 0) error(__FUNCTION__, "number of sites (--n_sites) missing!");
+  if (pars->in_pos == NULL && pars->max_kb_dist > 0)
+    error(__FUNCTION__, "position file necessary in order to filter by maximum distance!");
+  if (pars->min_maf < 0 || pars->min_maf > 1) error(__FUNCTION__, "minimum allele frequency must be in [0,1]!");
+  if (pars->call_geno && !pars->in_probs)
+    error(__FUNCTION__, "can only call genotypes from likelihoods/probabilities!");
+  if (pars->rnd_sample <= 0 || pars->rnd_sample > 1)
+    error(__FUNCTION__, "proportion of comparisons to sample must be in ]0,1]!");
+  if (pars->n_threads < 1) error(__FUNCTION__, "number of threads cannot be less than 1!");
+}
+
+struct SinkState {
+  const Params *pars;
+  const ngsld_pos *pos;        // may be NULL (no --pos)
+  const double *pos_dist;      // NULL => all INFINITY
+  const std::vector<double> *maf;
+  std::vector<char> buf;
+};
+
+// Writes one batch in (s1, s2) order.  dist is the reference's running sum (ngsLD.cpp:241).
+int write_batch(void *user, const ngsld_batch *b) {
+  SinkState *st = static_cast<SinkState *>(user);
+  FILE *fh = st->pars->out_fh;
+  size_t used = 0;
+  st->buf.resize(1 << 22);
+  for (uint64_t s1 = b->s1_begin; s1 < b->s1_end; ++s1) {
+    uint64_t k = b->row_off[s1 - b->s1_begin];
+    const uint32_t end = b->row_end[s1 - b->s1_begin];
+    double dist = 0;
+    const char *l1 = st->pos ? ngsld_host_label(st->pos, s1) : nullptr;
+    for (uint64_t s2 = s1 + 1; s2 < end; ++s2) {
+      dist += st->pos_dist ? st->pos_dist[s2] : INFINITY;
+      if (!b->keep[s2]) continue;
+      if (st->buf.size() - used < 8192) {
+        if (fwrite(st->buf.data(), 1, used, fh) != used) return 1;
+        used = 0;
+      }
+      const char *l2 = st->pos ? ngsld_host_label(st->pos, s2) : nullptr;
+      const size_t n = ngsld_host_format_pair(st->buf.data() + used, st->buf.size() - used, l1, l2, dist, &b->std[k],
+                                              b->ext ? &b->ext[k] : nullptr, (*st->maf)[s1], (*st->maf)[s2]);
+      if (n == 0) return 1;
+      used += n;
+      ++k;
+    }
+  }
+  if (used && fwrite(st->buf.data(), 1, used, fh) != used) return 1;
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  Params pars;
+  parse_cmd_args(&pars, argc, argv);
+
+  // ---- check input files (ngsLD.cpp:41-57) ----
+  struct stat st;
+  if (stat(pars.in_geno, &st) != 0) error(__FUNCTION__, "cannot check GENO file size!");
+  const char *dot = strrchr(pars.in_geno, '.');
+  if (dot != NULL && strcmp(dot, ".gz") == 0) {
+    if (pars.verbose >= 1) fprintf(stderr, "==> GZIP input file (not BINARY)\n");
+    error(__FUNCTION__, "text (.gz) genotype input is not part of the MI355X path yet; use a binary GL file");
+  }
+  if (pars.verbose >= 1) fprintf(stderr, "==> BINARY input file (always lkl)\n");
+  pars.in_bin = true;
+  pars.in_probs = true;
+  if (!ngsld_host_geno_size_ok((uint64_t)st.st_size, pars.n_ind, pars.n_sites))
+    error(__FUNCTION__, "invalid/corrupt genotype input file!");
+  if (pars.call_geno) error(__FUNCTION__, "--call_geno/--N_thresh/--call_thresh are not part of the MI355X path yet");
+  if (pars.rnd_sample != 1) error(__FUNCTION__, "--rnd_sample < 1 is not part of the MI355X path yet");
+
+  // ---- prepare output (ngsLD.cpp:73-77): the header is always written ----
+  if (pars.out != NULL) pars.out_fh = fopen(pars.out, "w");
+  if (pars.out_fh == NULL) error(__FUNCTION__, "cannot open output file!");
+  char hdr[512];
+  const size_t hn = ngsld_host_format_header(hdr, sizeof(hdr), pars.extend_out);
+  fwrite(hdr, 1, hn, pars.out_fh);
+
+  // ---- device ----
+  ngsld_ctx *ctx = nullptr;
+  if (ngsld_create(pars.device, &ctx) != NGSLD_OK) error("ngsld_create", ngsld_last_error(nullptr));
+
+  // ---- read input data (ngsLD.cpp:85-114; the arithmetic runs on the device) ----
+  if (pars.verbose >= 1) fprintf(stderr, "> Reading data from file...\n");
+  char err[512];
+  std::vector<double> raw((size_t)pars.n_sites * pars.n_ind * 3);
+  if (ngsld_host_read_geno_bin(pars.in_geno, pars.n_ind, pars.n_sites, raw.data(), err, sizeof(err)) != NGSLD_OK)
+    error("read_geno", err);
+  if (pars.verbose >= 1) fprintf(stderr, "==> Calculating MAF for all sites...\n");
+  int rc = ngsld_set_geno_raw(ctx, raw.data(), pars.n_sites, pars.n_ind, pars.in_logscale, pars.ignore_miss_data, 0);
+  if (rc == NGSLD_ERR_NAN) error("read_geno", ngsld_last_error(ctx));
+  if (rc != NGSLD_OK) error("ngsld_set_geno_raw", ngsld_last_error(ctx));
+  std::vector<double>().swap(raw);
+  std::vector<double> maf(pars.n_sites);
+  if (ngsld_get_maf(ctx, maf.data()) != NGSLD_OK) error("ngsld_get_maf", ngsld_last_error(ctx));
+
+  if (pars.verbose >= 1) fprintf(stderr, "==> Getting sites coordinates\n");
+  ngsld_pos *pos = nullptr;
+  if (pars.in_pos) {
+    if (ngsld_host_read_pos(pars.in_pos, pars.in_pos_header ? 1 : 0, pars.n_sites, &pos, err, sizeof(err)) != NGSLD_OK)
+      error("read_dist", err);
+    if (pars.verbose >= 6)
+      for (uint64_t s = 0; s < (pars.n_sites < 10 ? pars.n_sites : 10); s++)
+        fprintf(stderr, "%lu\t%f\n", (unsigned long)s, ngsld_host_pos_dist(pos)[s]);
+  }
+  if (ngsld_set_pos_dist(ctx, pos ? ngsld_host_pos_dist(pos) : nullptr) != NGSLD_OK)
+    error("ngsld_set_pos_dist", ngsld_last_error(ctx));
+
+  // ---- analyze data (replaces ngsLD.cpp:150-198) ----
+  if (pars.verbose >= 1) fprintf(stderr, "==> Launching threads...\n");
+  ngsld_params lp;
+  lp.max_kb_dist = pars.max_kb_dist;
+  lp.max_snp_dist = pars.max_snp_dist;
+  lp.min_maf = pars.min_maf;
+  lp.ignore_miss_data = pars.ignore_miss_data ? 1 : 0;
+  lp.extend_out = pars.extend_out ? 1 : 0;
+  uint64_t n_pairs = 0;
+  if (ngsld_plan(ctx, &lp, &n_pairs) != NGSLD_OK) error("ngsld_plan", ngsld_last_error(ctx));
+  if (pars.verbose >= 1) fprintf(stderr, "==> Waiting for all threads to finish...\n");
+  SinkState sink;
+  sink.pars = &pars;
+  sink.pos = pos;
+  sink.pos_dist = pos ? ngsld_host_pos_dist(pos) : nullptr;
+  sink.maf = &maf;
+  rc = ngsld_run(ctx, 0, pars.n_sites, write_batch, &sink);
+  if (rc == NGSLD_ERR_MAF_RANGE) error("haplo_freq", ngsld_last_error(ctx));
+  if (rc != NGSLD_OK) error("ngsld_run", ngsld_last_error(ctx));
+
+  // ---- free memory (ngsLD.cpp:205-222) ----
+  if (pars.verbose >= 1) fprintf(stderr, "==> Freeing memory...\n");
+  fclose(pars.out_fh);
+  ngsld_host_free_pos(pos);
+  ngsld_destroy(ctx);
+  if (pars.verbose >= 1) fprintf(stderr, "Done!\n");
+  return 0;
+}

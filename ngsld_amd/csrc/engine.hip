@@ -1,0 +1,625 @@
+// engine.hip -- host side of the C-ABI in include/ngsld.h: device state, the pair-space plan (the
+// batched replacement of the reference's per-s1 thread-pool dispatch, ngsLD.cpp:153-198) and the
+// batch pipeline kernel -> async D2H -> sink.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/ngsld.h"
+#include "ld_device.h"
+#include "ld_prep.h"
+
+using namespace ngsld;
+
+namespace {
+thread_local std::string g_create_error;
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  hipError_t resize(size_t count) {
+    if (count <= n && p != nullptr) return hipSuccess;
+    release();
+    if (count == 0) return hipSuccess;
+    hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+template <typename T>
+struct PinBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  hipError_t resize(size_t count) {
+    if (count <= n && p != nullptr) return hipSuccess;
+    release();
+    if (count == 0) return hipSuccess;
+    hipError_t e = hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault);
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+}  // namespace
+
+struct ngsld_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  std::string err;
+
+  // data
+  uint64_t n_sites = 0, n_ind = 0;
+  uint32_t np = 0;
+  int slots = 0, waves = 0;
+  bool have_geno = false;
+  DevBuf<double> d_planes, d_maf, d_mean, d_sxx, d_stage;
+  DevBuf<int> d_status;
+  std::vector<double> h_maf, h_pos_dist;
+
+  // plan
+  bool planned = false;
+  ngsld_params params{};
+  std::vector<uint64_t> h_row_off, h_item_off;
+  std::vector<uint32_t> h_row_end, h_cumkeep;
+  std::vector<uint8_t> h_keep;
+  DevBuf<uint64_t> d_row_off, d_item_off;
+  DevBuf<uint32_t> d_row_end, d_cumkeep;
+  DevBuf<uint8_t> d_keep;
+  DevBuf<Item> d_items;
+  uint64_t n_items = 0;
+
+  // tuning
+  uint32_t pairs_per_item = 16;
+  uint64_t batch_pairs = 1ull << 23;
+
+  // batch pipeline (two slots)
+  DevBuf<ngsld_rec_std> d_std[2];
+  DevBuf<ngsld_rec_ext> d_ext[2];
+  PinBuf<ngsld_rec_std> h_std[2];
+  PinBuf<ngsld_rec_ext> h_ext[2];
+  hipEvent_t ev_kernel_done[2] = {nullptr, nullptr}, ev_copy_done[2] = {nullptr, nullptr};
+
+  // timing of pair-kernel launches
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  hipStream_t timed_stream = nullptr;
+  uint64_t timed_pairs = 0;
+};
+
+namespace {
+
+int fail(ngsld_ctx *c, int code, const std::string &msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+int hip_fail(ngsld_ctx *c, hipError_t e, const char *what) {
+  return fail(c, e == hipErrorOutOfMemory ? NGSLD_ERR_NOMEM : NGSLD_ERR_DEVICE,
+              std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(c, call)                                \
+  do {                                                  \
+    hipError_t e_ = (call);                             \
+    if (e_ != hipSuccess) return hip_fail(c, e_, #call); \
+  } while (0)
+
+int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t n_sites, uint64_t n_ind,
+                    int log_scale, int ignore_miss, int on_device, bool normalised) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (gl == nullptr || n_sites == 0 || n_ind == 0) return fail(c, NGSLD_ERR_INVALID, "empty genotype matrix");
+  if (normalised && maf == nullptr) return fail(c, NGSLD_ERR_INVALID, "maf missing");
+  if (n_sites >= 0xffffffffull) return fail(c, NGSLD_ERR_UNSUPPORTED, "n_sites must be below 2^32 - 1");
+  int slots, waves;
+  if (!pair_config(n_ind, &slots, &waves))
+    return fail(c, NGSLD_ERR_UNSUPPORTED, "n_ind above 4096 is outside the built kernel set");
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->have_geno = false;
+  c->planned = false;
+  c->n_sites = n_sites;
+  c->n_ind = n_ind;
+  c->slots = slots;
+  c->waves = waves;
+  c->np = (uint32_t)(slots * waves * 64);
+  const size_t plane_elems = (size_t)n_sites * 3 * c->np;
+  HIP_TRY(c, c->d_planes.resize(plane_elems));
+  HIP_TRY(c, c->d_maf.resize(n_sites));
+  HIP_TRY(c, c->d_mean.resize(n_sites));
+  HIP_TRY(c, c->d_sxx.resize(n_sites));
+  HIP_TRY(c, c->d_status.resize(1));
+  HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, sizeof(int), c->stream));
+
+  const double *d_raw = gl;
+  DevBuf<double> d_maf_in;
+  const size_t raw_elems = (size_t)n_sites * n_ind * 3;
+  if (!on_device) {
+    HIP_TRY(c, c->d_stage.resize(raw_elems));
+    HIP_TRY(c, hipMemcpyAsync(c->d_stage.p, gl, raw_elems * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    d_raw = c->d_stage.p;
+  }
+  const double *d_maf_src = nullptr;
+  if (normalised) {
+    if (on_device) {
+      d_maf_src = maf;
+    } else {
+      HIP_TRY(c, d_maf_in.resize(n_sites));
+      HIP_TRY(c, hipMemcpyAsync(d_maf_in.p, maf, n_sites * sizeof(double), hipMemcpyHostToDevice, c->stream));
+      d_maf_src = d_maf_in.p;
+    }
+  }
+  PrepArgs a{};
+  a.raw = d_raw;
+  a.maf_in = d_maf_src;
+  a.planes = c->d_planes.p;
+  a.site_stride = 3ull * c->np;
+  a.n_sites = n_sites;
+  a.np = c->np;
+  a.n_ind = (uint32_t)n_ind;
+  a.log_scale = log_scale;
+  a.ignore_miss = ignore_miss;
+  a.normalised_input = normalised ? 1 : 0;
+  a.maf = c->d_maf.p;
+  a.mean_e = c->d_mean.p;
+  a.sxx = c->d_sxx.p;
+  a.status = c->d_status.p;
+  HIP_TRY(c, launch_prep(a, c->stream));
+  c->h_maf.resize(n_sites);
+  int status = 0;
+  HIP_TRY(c, hipMemcpyAsync(c->h_maf.data(), c->d_maf.p, n_sites * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&status, c->d_status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  d_maf_in.release();
+  c->d_stage.release();
+  if (status == NGSLD_ERR_NAN) return fail(c, NGSLD_ERR_NAN, "NaN found! Is the file format correct?");
+  c->have_geno = true;
+  return NGSLD_OK;
+}
+
+// The s2 walk of calc_pair_LD (ngsLD.cpp:240-262) for every s1, in O(n_sites) when the gaps are the
+// positive integers read_dist produces (prefix sums are then exact and the walk is monotone);
+// any other pos_dist falls back to the literal running-sum walk.
+void plan_rows(const std::vector<double> &pos_dist, const std::vector<double> &maf, const ngsld_params &p,
+               uint64_t n, std::vector<uint32_t> &row_end) {
+  row_end.assign(n, 0);
+  const bool use_dist = p.max_kb_dist > 0;
+  const double limit = (double)(p.max_kb_dist * 1000);
+  bool exact = true;
+  std::vector<double> cum;
+  std::vector<uint32_t> seg;
+  if (use_dist) {
+    cum.assign(n, 0.0);
+    seg.assign(n, 0);
+    double run = 0.0;
+    uint32_t sg = 0;
+    for (uint64_t s = 0; s < n; ++s) {
+      const double g = pos_dist[s];
+      if (std::isinf(g) && g > 0) {
+        if (s > 0) ++sg;
+      } else if (s > 0) {
+        if (!(g >= 1.0) || g != std::floor(g) || run + g > 9.0e15) exact = false;
+        run += g;
+      }
+      cum[s] = run;
+      seg[s] = sg;
+    }
+  }
+  uint64_t e = 0;
+  for (uint64_t s1 = 0; s1 < n; ++s1) {
+    uint64_t end;
+    if (maf[s1] < p.min_maf) {  // ngsLD.cpp:264 (a NaN maf compares false and passes)
+      end = s1 + 1;
+    } else if (!use_dist) {
+      end = n;
+    } else if (exact) {
+      if (e < s1 + 1) e = s1 + 1;
+      while (e < n && seg[e] == seg[s1] && !(limit < cum[e] - cum[s1])) ++e;  // ngsLD.cpp:252
+      end = e;
+    } else {
+      double dist = 0.0;
+      end = s1 + 1;
+      while (end < n) {
+        dist += pos_dist[end];
+        if (limit < dist) break;
+        ++end;
+      }
+    }
+    if (p.max_snp_dist > 0 && end > s1 + 1 + p.max_snp_dist) end = s1 + 1 + p.max_snp_dist;  // ngsLD.cpp:258
+    if (end > n) end = n;
+    row_end[s1] = (uint32_t)end;
+  }
+}
+
+hipError_t timed_launch(ngsld_ctx *c, const PairArgs &a, hipStream_t stream) {
+  if (c->ev_used == c->ev_pool.size()) {
+    hipEvent_t b, e;
+    hipError_t r = hipEventCreate(&b);
+    if (r != hipSuccess) return r;
+    r = hipEventCreate(&e);
+    if (r != hipSuccess) return r;
+    c->ev_pool.emplace_back(b, e);
+  }
+  auto &ev = c->ev_pool[c->ev_used++];
+  hipError_t r = hipEventRecord(ev.first, stream);
+  if (r != hipSuccess) return r;
+  r = launch_pair_kernel(c->slots, c->waves, c->params.ignore_miss_data != 0, a, stream);
+  if (r != hipSuccess) return r;
+  return hipEventRecord(ev.second, stream);
+}
+
+PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext) {
+  PairArgs a{};
+  a.planes = c->d_planes.p;
+  a.site_stride = 3ull * c->np;
+  a.np = c->np;
+  a.n_ind = (uint32_t)c->n_ind;
+  a.maf = c->d_maf.p;
+  a.mean_e = c->d_mean.p;
+  a.sxx = c->d_sxx.p;
+  a.keep = c->d_keep.p;
+  a.cumkeep = c->d_cumkeep.p;
+  a.row_off = c->d_row_off.p;
+  a.items = c->d_items.p + c->h_item_off[r0];
+  a.n_items = c->h_item_off[r1] - c->h_item_off[r0];
+  a.out_base = c->h_row_off[r0];
+  a.out_std = d_std;
+  a.out_ext = d_ext;
+  a.status = c->d_status.p;
+  return a;
+}
+
+int check_status(ngsld_ctx *c) {
+  int status = 0;
+  HIP_TRY(c, hipMemcpy(&status, c->d_status.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (status == NGSLD_ERR_MAF_RANGE) return fail(c, NGSLD_ERR_MAF_RANGE, "invalid allele frequencies");
+  return NGSLD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ngsld_version(void) { return "ngsld-amd 0.1.0 (gfx950; reference ngsLD 1.2.1)"; }
+
+int ngsld_create(int device, ngsld_ctx **out) {
+  if (out == nullptr) return NGSLD_ERR_INVALID;
+  *out = nullptr;
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount(&n_dev);
+  if (e != hipSuccess || n_dev == 0) {
+    g_create_error = std::string("no HIP device available (") + hipGetErrorString(e) +
+                     "); this library has no CPU fallback";
+    return NGSLD_ERR_DEVICE;
+  }
+  if (device < 0 || device >= n_dev) {
+    g_create_error = "device index out of range";
+    return NGSLD_ERR_INVALID;
+  }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+    return NGSLD_ERR_DEVICE;
+  }
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 (MI355X) only";
+    return NGSLD_ERR_DEVICE;
+  }
+  ngsld_ctx *c = new (std::nothrow) ngsld_ctx();
+  if (c == nullptr) return NGSLD_ERR_NOMEM;
+  c->device = device;
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
+      (e = hipStreamCreate(&c->copy_stream)) != hipSuccess) {
+    g_create_error = std::string("stream setup: ") + hipGetErrorString(e);
+    delete c;
+    return NGSLD_ERR_DEVICE;
+  }
+  for (int k = 0; k < 2; ++k) {
+    (void)hipEventCreateWithFlags(&c->ev_kernel_done[k], hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&c->ev_copy_done[k], hipEventDisableTiming);
+  }
+  *out = c;
+  return NGSLD_OK;
+}
+
+void ngsld_destroy(ngsld_ctx *c) {
+  if (c == nullptr) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_sxx.release(); c->d_stage.release();
+  c->d_status.release(); c->d_row_off.release(); c->d_item_off.release(); c->d_row_end.release();
+  c->d_cumkeep.release(); c->d_keep.release(); c->d_items.release();
+  for (int k = 0; k < 2; ++k) {
+    c->d_std[k].release(); c->d_ext[k].release(); c->h_std[k].release(); c->h_ext[k].release();
+    if (c->ev_kernel_done[k]) (void)hipEventDestroy(c->ev_kernel_done[k]);
+    if (c->ev_copy_done[k]) (void)hipEventDestroy(c->ev_copy_done[k]);
+  }
+  for (auto &ev : c->ev_pool) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  delete c;
+}
+
+const char *ngsld_last_error(const ngsld_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int ngsld_set_geno_raw(ngsld_ctx *c, const double *gl_raw, uint64_t n_sites, uint64_t n_ind, int log_scale,
+                       int ignore_miss_data, int on_device) {
+  return set_geno_common(c, gl_raw, nullptr, n_sites, n_ind, log_scale, ignore_miss_data, on_device, false);
+}
+
+int ngsld_set_geno_lkl(ngsld_ctx *c, const double *geno_lkl, const double *maf, uint64_t n_sites, uint64_t n_ind,
+                       int on_device) {
+  return set_geno_common(c, geno_lkl, maf, n_sites, n_ind, 0, 0, on_device, true);
+}
+
+int ngsld_get_maf(ngsld_ctx *c, double *maf_out) {
+  if (c == nullptr || maf_out == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "no genotype data set");
+  std::memcpy(maf_out, c->h_maf.data(), c->n_sites * sizeof(double));
+  return NGSLD_OK;
+}
+
+int ngsld_set_pos_dist(ngsld_ctx *c, const double *pos_dist) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "set the genotype data before the positions");
+  c->planned = false;
+  if (pos_dist == nullptr)
+    c->h_pos_dist.assign(c->n_sites, std::numeric_limits<double>::infinity());  // ngsLD.cpp:134
+  else
+    c->h_pos_dist.assign(pos_dist, pos_dist + c->n_sites);
+  return NGSLD_OK;
+}
+
+int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) {
+  if (c == nullptr || p == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "no genotype data set");
+  if (c->h_pos_dist.size() != c->n_sites) {
+    if (p->max_kb_dist > 0)  // parse_args.cpp:174-175
+      return fail(c, NGSLD_ERR_INVALID, "position file necessary in order to filter by maximum distance!");
+    c->h_pos_dist.assign(c->n_sites, std::numeric_limits<double>::infinity());
+  }
+  if (p->min_maf < 0 || p->min_maf > 1)  // parse_args.cpp:176-177
+    return fail(c, NGSLD_ERR_INVALID, "minimum allele frequency must be in [0,1]!");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint64_t n = c->n_sites;
+  c->params = *p;
+  c->planned = false;
+  plan_rows(c->h_pos_dist, c->h_maf, *p, n, c->h_row_end);
+  c->h_keep.resize(n);
+  c->h_cumkeep.resize(n + 1);
+  c->h_cumkeep[0] = 0;
+  for (uint64_t s = 0; s < n; ++s) {
+    c->h_keep[s] = (c->h_maf[s] < p->min_maf) ? 0 : 1;  // ngsLD.cpp:270
+    c->h_cumkeep[s + 1] = c->h_cumkeep[s] + c->h_keep[s];
+  }
+  c->h_row_off.resize(n + 1);
+  c->h_item_off.resize(n + 1);
+  c->h_row_off[0] = 0;
+  c->h_item_off[0] = 0;
+  const uint64_t ch = c->pairs_per_item;
+  for (uint64_t s1 = 0; s1 < n; ++s1) {
+    const uint64_t end = c->h_row_end[s1];
+    const uint64_t span = end > s1 + 1 ? end - (s1 + 1) : 0;
+    const uint64_t pairs = span ? c->h_cumkeep[end] - c->h_cumkeep[s1 + 1] : 0;
+    c->h_row_off[s1 + 1] = c->h_row_off[s1] + pairs;
+    c->h_item_off[s1 + 1] = c->h_item_off[s1] + (span + ch - 1) / ch;
+  }
+  c->n_items = c->h_item_off[n];
+  HIP_TRY(c, c->d_row_end.resize(n));
+  HIP_TRY(c, c->d_keep.resize(n));
+  HIP_TRY(c, c->d_cumkeep.resize(n + 1));
+  HIP_TRY(c, c->d_row_off.resize(n + 1));
+  HIP_TRY(c, c->d_item_off.resize(n + 1));
+  HIP_TRY(c, c->d_items.resize(c->n_items ? c->n_items : 1));
+  HIP_TRY(c, hipMemcpyAsync(c->d_row_end.p, c->h_row_end.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_keep.p, c->h_keep.data(), n, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_cumkeep.p, c->h_cumkeep.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_row_off.p, c->h_row_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_item_off.p, c->h_item_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, launch_build_items(c->d_row_end.p, c->d_item_off.p, (uint32_t)n, (uint32_t)ch, c->d_items.p, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->planned = true;
+  if (n_pairs) *n_pairs = c->h_row_off[n];
+  return NGSLD_OK;
+}
+
+int ngsld_plan_rows(ngsld_ctx *c, const uint64_t **row_off, const uint32_t **row_end) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->planned) return fail(c, NGSLD_ERR_INVALID, "ngsld_plan has not been called");
+  if (row_off) *row_off = c->h_row_off.data();
+  if (row_end) *row_end = c->h_row_end.data();
+  return NGSLD_OK;
+}
+
+int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_std, void *d_ext, void *hip_stream) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->planned) return fail(c, NGSLD_ERR_INVALID, "ngsld_plan has not been called");
+  if (s1_begin > s1_end || s1_end > c->n_sites) return fail(c, NGSLD_ERR_INVALID, "row range out of bounds");
+  if (d_std == nullptr) return fail(c, NGSLD_ERR_INVALID, "d_std is NULL");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  c->ev_used = 0;
+  c->timed_stream = st;
+  c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
+  // one launch per <= 2^31-1 workgroups; rows are cut so that each launch's grid fits
+  const uint64_t max_items = 0x7ffffff0ull;
+  uint64_t r0 = s1_begin;
+  while (r0 < s1_end) {
+    uint64_t r1 = r0 + 1;
+    while (r1 < s1_end && c->h_item_off[r1 + 1] - c->h_item_off[r0] <= max_items) ++r1;
+    PairArgs a = make_args(c, r0, r1, (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext);
+    a.out_base = c->h_row_off[s1_begin];
+    HIP_TRY(c, timed_launch(c, a, st));
+    r0 = r1;
+  }
+  if (hip_stream == nullptr) {
+    HIP_TRY(c, hipStreamSynchronize(st));
+    return check_status(c);
+  }
+  return NGSLD_OK;
+}
+
+int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user) {
+  if (c == nullptr || sink == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->planned) return fail(c, NGSLD_ERR_INVALID, "ngsld_plan has not been called");
+  if (s1_begin > s1_end || s1_end > c->n_sites) return fail(c, NGSLD_ERR_INVALID, "row range out of bounds");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const bool ext = c->params.extend_out != 0;
+  c->ev_used = 0;
+  c->timed_stream = c->stream;
+  c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
+
+  struct Batch {
+    uint64_t r0, r1, n;
+  };
+  std::vector<Batch> batches;
+  for (uint64_t r0 = s1_begin; r0 < s1_end;) {
+    uint64_t r1 = r0 + 1;
+    while (r1 < s1_end && c->h_row_off[r1 + 1] - c->h_row_off[r0] <= c->batch_pairs) ++r1;
+    batches.push_back({r0, r1, c->h_row_off[r1] - c->h_row_off[r0]});
+    r0 = r1;
+  }
+  uint64_t cap = 1;
+  for (auto &b : batches) cap = std::max(cap, b.n);
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(c, c->d_std[k].resize(cap));
+    HIP_TRY(c, c->h_std[k].resize(cap));
+    if (ext) {
+      HIP_TRY(c, c->d_ext[k].resize(cap));
+      HIP_TRY(c, c->h_ext[k].resize(cap));
+    }
+  }
+  std::vector<uint64_t> rel_off;
+  auto issue = [&](size_t bi) -> int {  // kernel on `stream`, D2H on `copy_stream`
+    const int k = (int)(bi & 1);
+    const Batch &b = batches[bi];
+    PairArgs a = make_args(c, b.r0, b.r1, c->d_std[k].p, ext ? c->d_ext[k].p : nullptr);
+    HIP_TRY(c, timed_launch(c, a, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_kernel_done[k], c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_kernel_done[k], 0));
+    if (b.n) {
+      HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, c->d_std[k].p, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost,
+                                c->copy_stream));
+      if (ext)
+        HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, c->d_ext[k].p, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost,
+                                  c->copy_stream));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_copy_done[k], c->copy_stream));
+    return NGSLD_OK;
+  };
+  int rc = NGSLD_OK;
+  if (!batches.empty()) rc = issue(0);
+  for (size_t bi = 0; rc == NGSLD_OK && bi < batches.size(); ++bi) {
+    const int k = (int)(bi & 1);
+    if (bi + 1 < batches.size()) {
+      // slot of batch bi+1 was last used by batch bi-1, whose sink call has already returned
+      rc = issue(bi + 1);
+      if (rc != NGSLD_OK) break;
+    }
+    HIP_TRY(c, hipEventSynchronize(c->ev_copy_done[k]));
+    const Batch &b = batches[bi];
+    rel_off.resize(b.r1 - b.r0 + 1);
+    for (uint64_t r = b.r0; r <= b.r1; ++r) rel_off[r - b.r0] = c->h_row_off[r] - c->h_row_off[b.r0];
+    ngsld_batch out{};
+    out.s1_begin = b.r0;
+    out.s1_end = b.r1;
+    out.n_pairs = b.n;
+    out.row_off = rel_off.data();
+    out.row_end = c->h_row_end.data() + b.r0;
+    out.keep = c->h_keep.data();
+    out.std = c->h_std[k].p;
+    out.ext = ext ? c->h_ext[k].p : nullptr;
+    if (sink(user, &out) != 0) rc = fail(c, NGSLD_ERR_SINK, "sink callback failed");
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+  if (rc != NGSLD_OK) return rc;
+  return check_status(c);
+}
+
+int ngsld_last_kernel_time(ngsld_ctx *c, double *total_ms, uint64_t *n_launches, uint64_t *n_pairs) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (c->timed_stream) HIP_TRY(c, hipStreamSynchronize(c->timed_stream));
+  double ms = 0.0;
+  for (size_t k = 0; k < c->ev_used; ++k) {
+    float t = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&t, c->ev_pool[k].first, c->ev_pool[k].second));
+    ms += (double)t;
+  }
+  if (total_ms) *total_ms = ms;
+  if (n_launches) *n_launches = c->ev_used;
+  if (n_pairs) *n_pairs = c->timed_pairs;
+  return NGSLD_OK;
+}
+
+int ngsld_set_tuning(ngsld_ctx *c, uint32_t pairs_per_item, uint64_t batch_pairs) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (pairs_per_item) {
+    c->pairs_per_item = pairs_per_item;
+    c->planned = false;
+  }
+  if (batch_pairs) c->batch_pairs = batch_pairs;
+  return NGSLD_OK;
+}
+
+int ngsld_selftest(ngsld_ctx *c) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  std::vector<double> in(320), out(68, 0.0);
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  for (auto &v : in) {
+    st = st * 6364136223846793005ull + 1442695040888963407ull;
+    v = (double)(st >> 11) / 9007199254740992.0 + 1e-3;
+  }
+  for (int l = 0; l < 64; ++l) in[256 + l] *= std::pow(10.0, -(l % 30));
+  DevBuf<double> d_in, d_out;
+  HIP_TRY(c, d_in.resize(in.size()));
+  HIP_TRY(c, d_out.resize(out.size()));
+  HIP_TRY(c, hipMemcpy(d_in.p, in.data(), in.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(c, launch_selftest(d_in.p, d_out.p, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(out.data(), d_out.p, out.size() * sizeof(double), hipMemcpyDeviceToHost));
+  d_in.release();
+  d_out.release();
+  for (int k = 0; k < 4; ++k) {
+    long double ref = 0;
+    for (int l = 0; l < 64; ++l) ref += in[k * 64 + l];
+    if (std::fabs((double)(out[k] - ref)) > 1e-12 * std::fabs((double)ref)) {
+      char buf[160];
+      std::snprintf(buf, sizeof(buf), "wave_sum4 value %d: got %.17g expected %.17Lg", k, out[k], ref);
+      return fail(c, NGSLD_ERR_DEVICE, buf);
+    }
+  }
+  for (int l = 0; l < 64; ++l) {
+    const double ref = 1.0 / in[256 + l];
+    if (std::fabs(out[4 + l] - ref) > 4.5e-16 * ref) {
+      char buf[160];
+      std::snprintf(buf, sizeof(buf), "rcp_refined lane %d: got %.17g expected %.17g", l, out[4 + l], ref);
+      return fail(c, NGSLD_ERR_DEVICE, buf);
+    }
+  }
+  return NGSLD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,314 @@
+// ld_device.h -- gfx950 (MI355X, CDNA4) device code of the pair-LD path.
+//
+// One wavefront (64 lanes) owns one SNP pair; for n_ind > 512 a workgroup of 2..8 wavefronts
+// shares one pair.  Replaces calc_pair_LD / haplo_freq / pair_freq_iter / pearson_r of the reference
+// (ngsLD.cpp:229-367, shared/gen_func.cpp:1027-1119); see DESIGN.md for the derivation.
+//
+// EM step, restated for the hardware.  With a = site-1 GL triple and b = site-2 GL triple of an
+// individual, P[g1][g2] = a[g1]*b[g2] (9 products, invariant over EM iterations, held in VGPRs for
+// the whole pair).  The reference's 16-term `sum` (gen_func.cpp:1093-1096) is the bilinear form
+// s = sum_G W[G]*P[G] with the 3x3 two-locus genotype weights W(f) (uniform per iteration), and
+// its four `tmp/sum` accumulations (gen_func.cpp:1098-1104) are linear in R[G] = sum_i P_i[G]/s_i:
+//   ff_k/(2x) = f_k * sum_h f_h * R[G(k,h)] / x.
+// Per individual and iteration that is 9 FMA (s) + one refined reciprocal + 9 FMA (R) instead of the
+// reference's ~168 flops; f64 throughout, no MFMA (nothing is shared across pairs to contract over).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ngsld.h"
+
+namespace ngsld {
+
+constexpr int kIterMax = 100;      // ITER_MAX, gen_func.hpp:18
+constexpr double kEpsilon = 1e-5;  // EPSILON,  gen_func.hpp:16
+
+// One unit of work: pairs (s1, s2) for s2 in [s2_begin, s2_begin + count).
+struct Item {
+  uint32_t s1, s2_begin, count, pad;
+};
+
+struct PairArgs {
+  const double *planes;  // [n_sites][3][np] normal-space normalised GLs, zero padded to np
+  uint64_t site_stride;  // 3 * np
+  uint32_t np;
+  uint32_t n_ind;
+  const double *maf;     // [n_sites] est_maf
+  const double *mean_e;  // [n_sites] mean expected genotype
+  const double *sxx;     // [n_sites] sum (e - mean)^2
+  const uint8_t *keep;   // [n_sites] 0 where maf < min_maf
+  const uint32_t *cumkeep;  // [n_sites + 1] prefix count of keep
+  const uint64_t *row_off;  // [n_sites + 1] pairs before row s1
+  const Item *items;
+  uint64_t n_items;
+  uint64_t out_base;  // row_off of the first row of this launch
+  ngsld_rec_std *out_std;
+  ngsld_rec_ext *out_ext;  // may be null
+  int *status;             // set to NGSLD_ERR_MAF_RANGE when haplo_freq would error()
+};
+
+// ---------------------------------------------------------------------------------------------
+// cross-lane primitives
+// ---------------------------------------------------------------------------------------------
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double mk_double(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
+
+__device__ __forceinline__ double uniform(double v) {  // value is wave-uniform: move it to SGPRs
+  return mk_double((unsigned)__builtin_amdgcn_readfirstlane(__double2loint(v)),
+                   (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(v)));
+}
+
+__device__ __forceinline__ double read_lane(double v, int lane) {
+  return mk_double((unsigned)__builtin_amdgcn_readlane(__double2loint(v), lane),
+                   (unsigned)__builtin_amdgcn_readlane(__double2hiint(v), lane));
+}
+
+// v_permlane32_swap: lanes 32..63 of x trade places with lanes 0..31 of y.  The sum then holds
+// x[l] + x[l+32] in lanes 0..31 and y[l-32] + y[l] in lanes 32..63: two values folded into one register.
+__device__ __forceinline__ double fold32(double x, double y) {
+  u32x2 l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  u32x2 h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return mk_double(l[0], h[0]) + mk_double(l[1], h[1]);
+}
+
+// v_permlane16_swap: odd 16-lane rows of x trade places with even rows of y.
+__device__ __forceinline__ double fold16(double x, double y) {
+  u32x2 l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+  u32x2 h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+  return mk_double(l[0], h[0]) + mk_double(l[1], h[1]);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Sum four per-lane values over the 64 lanes with a FIXED order (deterministic per pair):
+// 2 fold steps (64 -> 16 lanes, four values packed into one register, one per 16-lane row),
+// 4 DPP steps inside each row, then one readlane per value.  7 f64 adds instead of 24.
+__device__ __forceinline__ void wave_sum4(double &t0, double &t1, double &t2, double &t3) {
+  double z01 = fold32(t0, t1);  // lanes <32: t0, lanes >=32: t1
+  double z23 = fold32(t2, t3);
+  double w = fold16(z01, z23);  // row0: t0, row1: t2, row2: t1, row3: t3
+  w += dpp_mov<0x128>(w);       // row_ror:8
+  w += dpp_mov<0x124>(w);       // row_ror:4
+  w += dpp_mov<0x4E>(w);        // quad_perm:[2,3,0,1]
+  w += dpp_mov<0xB1>(w);        // quad_perm:[1,0,3,2]
+  t0 = read_lane(w, 0);
+  t2 = read_lane(w, 16);
+  t1 = read_lane(w, 32);
+  t3 = read_lane(w, 48);
+}
+
+__device__ __forceinline__ double wave_sum1(double v) {
+  double a = v, b = 0.0, c = 0.0, d = 0.0;
+  wave_sum4(a, b, c, d);
+  return a;
+}
+
+// 1/s to ~1 ulp: v_rcp_f64 seed + two Newton steps.  s == 0 gives NaN (inf * 0), which is what the
+// caller wants: the reference's tmp/sum is 0/0 there (gen_func.cpp:1103).
+__device__ __forceinline__ double rcp_refined(double s) {
+  double r = __builtin_amdgcn_rcp(s);
+  double e = fma(-s, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-s, r, 1.0);
+  r = fma(r, e, r);
+  return r;
+}
+
+// gen_func.cpp:862-868 miss_data with the reference's abs() macro semantics
+__device__ __forceinline__ bool miss_data(double g0, double g1, double g2) {
+  double d01 = g0 - g1, d12 = g1 - g2;
+  d01 = d01 >= 0 ? d01 : -d01;
+  d12 = d12 >= 0 ? d12 : -d12;
+  return d01 < kEpsilon && d12 < kEpsilon;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The pair kernel.
+//   SLOTS  individuals per lane (compile time, P lives in 18*SLOTS VGPRs)
+//   WAVES  wavefronts sharing one pair (1: four independent wavefronts per 256-thread workgroup)
+//   MASKED --ignore_miss_data: individuals missing at either site are left out (gen_func.cpp:1089)
+// ---------------------------------------------------------------------------------------------
+template <int SLOTS, int WAVES, bool MASKED>
+__global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
+  constexpr bool kCheckAll = MASKED || WAVES > 1;  // otherwise only the last slot can hold padding
+  __shared__ double xch[2][WAVES > 1 ? WAVES : 1][4];
+  __shared__ double xch0[WAVES > 1 ? WAVES : 1][2];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint64_t item_id = WAVES == 1 ? (uint64_t)blockIdx.x * 4 + (uint64_t)wave : (uint64_t)blockIdx.x;
+  if (item_id >= A.n_items) return;
+  const int sub = WAVES == 1 ? 0 : wave;
+
+  const Item it = A.items[item_id];
+  const uint32_t s1 = it.s1;
+  const double m1 = A.maf[s1];
+  const double mean1 = A.mean_e[s1];
+  const double sxx1 = A.sxx[s1];
+  const uint64_t row_base = A.row_off[s1] - A.out_base;
+  const uint32_t ck1 = A.cumkeep[s1 + 1];
+  const double *pa = A.planes + (uint64_t)s1 * A.site_stride;
+  const uint32_t np = A.np;
+  const uint32_t i0 = (uint32_t)sub * (SLOTS * 64) + (uint32_t)lane;
+
+  for (uint32_t s2 = it.s2_begin; s2 < it.s2_begin + it.count; ++s2) {
+    if (!A.keep[s2]) continue;  // ngsLD.cpp:270-275
+    const double *pb = A.planes + (uint64_t)s2 * A.site_stride;
+    const double m2 = A.maf[s2];
+    const double mean2 = A.mean_e[s2];
+
+    // ---- stage both sites: P = a (x) b, validity bits, Pearson cross moment --------------------
+    double P[SLOTS][9];
+    uint32_t vbits = 0;
+    double sxy = 0.0;
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+      const uint32_t i = i0 + (uint32_t)j * 64;
+      const double a0 = pa[i], a1 = pa[np + i], a2 = pa[2 * np + i];
+      const double b0 = pb[i], b1 = pb[np + i], b2 = pb[2 * np + i];
+      const bool inb = i < A.n_ind;
+      bool ok = inb;
+      if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);
+      vbits |= (ok ? 1u : 0u) << j;
+      P[j][0] = a0 * b0; P[j][1] = a0 * b1; P[j][2] = a0 * b2;
+      P[j][3] = a1 * b0; P[j][4] = a1 * b1; P[j][5] = a1 * b2;
+      P[j][6] = a2 * b0; P[j][7] = a2 * b1; P[j][8] = a2 * b2;
+      // expected genotypes p1 + 2*p2 (ngsLD.cpp:113); pearson_r runs over ALL individuals (ngsLD.cpp:290)
+      const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;
+      const double c2 = inb ? fma(2.0, b2, b1) - mean2 : 0.0;
+      sxy = fma(c1, c2, sxy);
+    }
+    // x = individuals with data (gen_func.cpp:1091), integer exact
+    uint32_t x = 0;
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) x += (uint32_t)__popcll(__ballot((vbits >> j) & 1u));
+    sxy = wave_sum1(sxy);
+    if (WAVES > 1) {
+      if (lane == 0) {
+        xch0[sub][0] = sxy;
+        xch0[sub][1] = (double)x;
+      }
+      __syncthreads();
+      double sx = 0.0, xs = 0.0;
+      for (int w = 0; w < WAVES; ++w) {
+        sx += xch0[w][0];
+        xs += xch0[w][1];
+      }
+      sxy = sx;
+      x = (uint32_t)xs;
+      __syncthreads();
+    }
+
+    // ---- haplo_freq (gen_func.cpp:1027-1059) ---------------------------------------------------
+    double f0 = (1 - m1) * (1 - m2), f1 = (1 - m1) * m2, f2 = m1 * (1 - m2), f3 = m1 * m2;
+    if (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1) {  // error() in the reference; reported through status
+      if (lane == 0 && sub == 0) atomicExch(A.status, (int)NGSLD_ERR_MAF_RANGE);
+      f0 = f1 = f2 = f3 = __builtin_nan("");
+    }
+    uint32_t n_iter = 0;
+    for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
+      // two-locus genotype weights: s = sum_{k,h} f_k f_h a[G1(k,h)] b[G2(k,h)] = sum_G W[G] P[G]
+      const double w0 = f0 * f0, w1 = 2.0 * (f0 * f1), w2 = f1 * f1;
+      const double w3 = 2.0 * (f0 * f2), w4 = 2.0 * fma(f0, f3, f1 * f2), w5 = 2.0 * (f1 * f3);
+      const double w6 = f2 * f2, w7 = 2.0 * (f2 * f3), w8 = f3 * f3;
+      double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
+#pragma unroll
+      for (int j = 0; j < SLOTS; ++j) {
+        if ((!kCheckAll && j < SLOTS - 1) || ((vbits >> j) & 1u)) {
+          double s = w0 * P[j][0];
+          s = fma(w1, P[j][1], s); s = fma(w2, P[j][2], s);
+          s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
+          s = fma(w6, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(w8, P[j][8], s);
+          const double r = rcp_refined(s);
+          R0 = fma(P[j][0], r, R0); R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
+          R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
+          R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
+        }
+      }
+      // t_k = f_k * sum_h f_h R[G(k,h)]  (= this lane's share of ff_k / 2, gen_func.cpp:1098-1104)
+      double t0 = f0 * fma(f3, R4, fma(f2, R3, fma(f1, R1, f0 * R0)));
+      double t1 = f1 * fma(f3, R5, fma(f2, R4, fma(f1, R2, f0 * R1)));
+      double t2 = f2 * fma(f3, R7, fma(f2, R6, fma(f1, R4, f0 * R3)));
+      double t3 = f3 * fma(f3, R8, fma(f2, R7, fma(f1, R5, f0 * R4)));
+      wave_sum4(t0, t1, t2, t3);
+      if (WAVES > 1) {
+        const int par = (int)(n_iter & 1u);
+        if (lane == 0) {
+          xch[par][sub][0] = t0; xch[par][sub][1] = t1; xch[par][sub][2] = t2; xch[par][sub][3] = t3;
+        }
+        __syncthreads();
+        t0 = t1 = t2 = t3 = 0.0;
+        for (int w = 0; w < WAVES; ++w) {
+          t0 += xch[par][w][0]; t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
+        }
+      }
+      // f = ff/(2x), then normalise (gen_func.cpp:1108-1113); the /(2x) cancels in the normalisation,
+      // x == 0 gives 0/0 = NaN exactly as there.
+      const double tot = ((t0 + t1) + t2) + t3;
+      const double inv = 1.0 / tot;
+      double n0 = t0 * inv, n1 = t1 * inv, n2 = t2 * inv, n3 = t3 * inv;
+      // Any individual with s == 0 makes every tmp/sum NaN in the reference, hence all four f NaN.
+      // Here s == 0 poisons every R with inf/NaN, so "any non-finite" <=> "reference is all NaN".
+      const bool bad = !(__builtin_isfinite(n0) && __builtin_isfinite(n1) && __builtin_isfinite(n2) &&
+                         __builtin_isfinite(n3));
+      if (bad) n0 = n1 = n2 = n3 = __builtin_nan("");
+      double eps = 0.0;  // gen_func.cpp:1049-1053: a NaN difference never raises eps
+      double d;
+      d = fabs(n0 - f0); if (d > eps) eps = d;
+      d = fabs(n1 - f1); if (d > eps) eps = d;
+      d = fabs(n2 - f2); if (d > eps) eps = d;
+      d = fabs(n3 - f3); if (d > eps) eps = d;
+      f0 = n0; f1 = n1; f2 = n2; f3 = n3;
+      if (__builtin_amdgcn_readfirstlane((int)(eps < kEpsilon))) break;  // gen_func.cpp:1054-1055
+    }
+
+    // ---- ngsLD.cpp:296-306 + pearson_r; written by one lane --------------------------------------
+    if (lane == 0 && sub == 0) {
+      // 1 - (f0 + f1) carries ~1e-16 of rounding noise; at a monomorphic site that noise alone decides in
+      // the reference whether D' and r2 come out as 0/0 = NaN or 0/1e-16 = 0.  Noise-sized values are
+      // snapped to the exact 0 / 1 they stand for, which is the reference's outcome whenever its own
+      // rounding happens to cancel (DESIGN.md "degenerate pairs").
+      double hm0 = 1 - (f0 + f1);
+      double hm1 = 1 - (f0 + f2);
+      if (fabs(hm0) < 1e-15) hm0 = 0.0;
+      if (fabs(1 - hm0) < 1e-15) hm0 = 1.0;
+      if (fabs(hm1) < 1e-15) hm1 = 0.0;
+      if (fabs(1 - hm1) < 1e-15) hm1 = 1.0;
+      const double D = f0 * f3 - f1 * f2;
+      const double q00 = hm0 * hm1, q11 = (1 - hm0) * (1 - hm1);
+      const double q01 = hm0 * (1 - hm1), q10 = (1 - hm0) * hm1;
+      const double den = D < 0 ? -(q00 <= q11 ? q00 : q11) : (q01 <= q10 ? q01 : q10);
+      const double Dp = D / den;
+      const double rr = D / sqrt(hm0 * hm1 * (1 - hm0) * (1 - hm1));
+      const double r = sxy / (sqrt(sxx1) * sqrt(A.sxx[s2]));
+      const uint64_t slot = row_base + (uint64_t)(A.cumkeep[s2] - ck1);
+      ngsld_rec_std o;
+      o.r2_ExpG = r * r;
+      o.D = D;
+      o.Dp = Dp;
+      o.r2 = rr * rr;
+      A.out_std[slot] = o;
+      if (A.out_ext != nullptr) {
+        ngsld_rec_ext e;
+        e.hap[0] = f0; e.hap[1] = f1; e.hap[2] = f2; e.hap[3] = f3;
+        e.n_ind_data = x;
+        e.n_iter = n_iter;
+        A.out_ext[slot] = e;
+      }
+    }
+  }
+}
+
+// host-callable launcher, defined in ld_pair.hip
+hipError_t launch_pair_kernel(int slots, int waves, bool masked, const PairArgs &args, hipStream_t stream);
+bool pair_config(uint64_t n_ind, int *slots, int *waves);
+
+}  // namespace ngsld

@@ -1,0 +1,47 @@
+// ld_pair_w1.hip -- instantiations of the one-wavefront-per-pair kernel (n_ind <= 512) and the launcher.
+#include "ld_device.h"
+
+namespace ngsld {
+
+// n_ind -> (individuals per lane, wavefronts per pair).  One wavefront holds up to 8*64 = 512
+// individuals as 18*8 = 144 VGPRs of P; above that 2..8 wavefronts of a workgroup share the pair.
+bool pair_config(uint64_t n_ind, int *slots, int *waves) {
+  if (n_ind == 0 || n_ind > 4096) return false;  // 8 wavefronts x 8 slots x 64 lanes
+  int w = 1;
+  while ((n_ind + 64ull * w - 1) / (64ull * w) > 8) w *= 2;
+  *waves = w;
+  *slots = (int)((n_ind + 64ull * w - 1) / (64ull * w));
+  return true;
+}
+
+template <int SLOTS, int WAVES>
+static hipError_t launch_sw(bool masked, const PairArgs &a, hipStream_t stream) {
+  const uint64_t blocks = WAVES == 1 ? (a.n_items + 3) / 4 : a.n_items;
+  if (blocks == 0) return hipSuccess;
+  if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)blocks), block(WAVES == 1 ? 256 : WAVES * 64);
+  if (masked)
+    hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, true>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, false>), grid, block, 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_pair_wn(int slots, int waves, bool masked, const PairArgs &a, hipStream_t stream);
+
+hipError_t launch_pair_kernel(int slots, int waves, bool masked, const PairArgs &a, hipStream_t stream) {
+  if (waves != 1) return launch_pair_wn(slots, waves, masked, a, stream);
+  switch (slots) {
+    case 1: return launch_sw<1, 1>(masked, a, stream);
+    case 2: return launch_sw<2, 1>(masked, a, stream);
+    case 3: return launch_sw<3, 1>(masked, a, stream);
+    case 4: return launch_sw<4, 1>(masked, a, stream);
+    case 5: return launch_sw<5, 1>(masked, a, stream);
+    case 6: return launch_sw<6, 1>(masked, a, stream);
+    case 7: return launch_sw<7, 1>(masked, a, stream);
+    case 8: return launch_sw<8, 1>(masked, a, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace ngsld

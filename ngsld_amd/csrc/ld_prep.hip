@@ -1,0 +1,156 @@
+// ld_prep.hip -- per-site preprocessing, work-item construction and the primitive self test (gfx950).
+//
+// prep_sites_kernel does on the device what read_geno's binary branch (shared/read_data.cpp:28-47)
+// and main() (ngsLD.cpp:103-114) do on the host in the reference, one workgroup per site:
+//   raw [site][ind][3] doubles -> log (-inf -> -1e15) -> log-normalise -> NaN check -> est_maf ->
+//   exp -> planes [site][geno][np] (+ mean and centred second moment of the expected genotypes, which
+//   is everything pearson_r needs per site).
+#include "ld_prep.h"
+
+namespace ngsld {
+
+// shared/gen_func.cpp:135-151 logsum over a triple (macro max, left-to-right sum)
+__device__ __forceinline__ double logsum3(double g0, double g1, double g2) {
+  double M = g0;
+  M = g1 >= M ? g1 : M;
+  M = g2 >= M ? g2 : M;
+  if (M == -__builtin_inf()) return -__builtin_inf();
+  double sum = 0.0;
+  sum += exp(g0 - M);
+  sum += exp(g1 - M);
+  sum += exp(g2 - M);
+  return log(sum) + M;
+}
+
+__device__ __forceinline__ double conv_log(double g) {  // conv_space(log), gen_func.cpp:123-130
+  g = log(g);
+  return g == -__builtin_inf() ? -1e15 : g;
+}
+
+// fixed-order workgroup sum of up to 3 values (256 threads)
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], double (*sh)[N]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = wave_sum1(v[k]);
+  __syncthreads();
+  if (lane == 0)
+    for (int k = 0; k < N; ++k) sh[wave][k] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = ((sh[0][k] + sh[1][k]) + sh[2][k]) + sh[3][k];
+}
+
+__global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
+  __shared__ double sh3[4][3];
+  __shared__ double sh1[4][1];
+  for (uint64_t site = blockIdx.x; site < A.n_sites; site += gridDim.x) {
+    const double *raw = A.raw + site * (uint64_t)A.n_ind * 3;
+    double *pl = A.planes + site * A.site_stride;
+    double acc[3] = {0.0, 0.0, 0.0};  // num, den (est_maf), sum of expected genotypes
+    bool nan_seen = false;
+    for (uint32_t i = threadIdx.x; i < A.np; i += 256) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+      if (i < A.n_ind) {
+        double g0 = raw[3 * (uint64_t)i], g1 = raw[3 * (uint64_t)i + 1], g2 = raw[3 * (uint64_t)i + 2];
+        if (!A.normalised_input) {
+          if (!A.log_scale) {  // read_data.cpp:37-38
+            g0 = conv_log(g0);
+            g1 = conv_log(g1);
+            g2 = conv_log(g2);
+          }
+          const double norm = logsum3(g0, g1, g2);  // post_prob, read_data.cpp:40
+          g0 -= norm;
+          g1 -= norm;
+          g2 -= norm;
+          if (g0 != g0 || g1 != g1 || g2 != g2) nan_seen = true;  // read_data.cpp:42-45
+          // est_maf (gen_func.cpp:974-1009, indF == NULL): closed form of its two identical passes
+          if (!(A.ignore_miss && miss_data(g0, g1, g2))) {  // miss_data on LOG values, :985
+            const double n2 = logsum3(g0, g1, g2);
+            const double p0 = exp(g0 - n2), p1 = exp(g1 - n2), p2 = exp(g2 - n2);
+            acc[0] += p1 + p2 * 2.0;
+            acc[1] += 2.0 * p1 + (p0 + p2) * 2.0;
+          }
+          a0 = exp(g0);  // ngsLD.cpp:110
+          a1 = exp(g1);
+          a2 = exp(g2);
+        } else {
+          a0 = g0;
+          a1 = g1;
+          a2 = g2;
+        }
+        acc[2] += fma(2.0, a2, a1);  // expected genotype, ngsLD.cpp:113
+      }
+      pl[i] = a0;
+      pl[A.np + i] = a1;
+      pl[2 * (uint64_t)A.np + i] = a2;
+    }
+    block_sum<3>(acc, sh3);
+    const double mean = acc[2] / (double)A.n_ind;
+    double sq[1] = {0.0};
+    for (uint32_t i = threadIdx.x; i < A.n_ind; i += 256) {
+      const double d = fma(2.0, pl[2 * (uint64_t)A.np + i], pl[A.np + i]) - mean;
+      sq[0] = fma(d, d, sq[0]);
+    }
+    block_sum<1>(sq, sh1);
+    if (threadIdx.x == 0) {
+      A.maf[site] = A.normalised_input ? A.maf_in[site] : acc[0] / acc[1];
+      A.mean_e[site] = mean;
+      A.sxx[site] = sq[0];
+    }
+    if (nan_seen) atomicExch(A.status, (int)NGSLD_ERR_NAN);
+  }
+}
+
+hipError_t launch_prep(const PrepArgs &a, hipStream_t stream) {
+  if (a.n_sites == 0) return hipSuccess;
+  const unsigned grid = (unsigned)(a.n_sites < 65536 ? a.n_sites : 65536);
+  hipLaunchKernelGGL(prep_sites_kernel, dim3(grid), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+// One thread per row: cut the row's s2 range [s1+1, row_end) into items of `ch` consecutive sites.
+__global__ void build_items_kernel(const uint32_t *row_end, const uint64_t *item_off, uint32_t n_sites, uint32_t ch,
+                                   Item *items) {
+  const uint32_t s1 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s1 >= n_sites) return;
+  const uint32_t end = row_end[s1];
+  uint64_t k = item_off[s1];
+  for (uint32_t b = s1 + 1; b < end; b += ch) {
+    Item it;
+    it.s1 = s1;
+    it.s2_begin = b;
+    it.count = end - b < ch ? end - b : ch;
+    it.pad = 0;
+    items[k++] = it;
+  }
+}
+
+hipError_t launch_build_items(const uint32_t *row_end, const uint64_t *item_off, uint32_t n_sites, uint32_t ch,
+                              Item *items, hipStream_t stream) {
+  if (n_sites == 0) return hipSuccess;
+  hipLaunchKernelGGL(build_items_kernel, dim3((n_sites + 255) / 256), dim3(256), 0, stream, row_end, item_off,
+                     n_sites, ch, items);
+  return hipGetLastError();
+}
+
+// Self test: out[0..3] = wave_sum4 of in[k*64 + lane]; out[4 + lane] = rcp_refined(in[256 + lane]).
+__global__ void selftest_kernel(const double *in, double *out) {
+  const int lane = threadIdx.x;
+  double t0 = in[lane], t1 = in[64 + lane], t2 = in[128 + lane], t3 = in[192 + lane];
+  wave_sum4(t0, t1, t2, t3);
+  if (lane == 0) {
+    out[0] = t0;
+    out[1] = t1;
+    out[2] = t2;
+    out[3] = t3;
+  }
+  out[4 + lane] = rcp_refined(in[256 + lane]);
+}
+
+hipError_t launch_selftest(const double *in, double *out, hipStream_t stream) {
+  hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, stream, in, out);
+  return hipGetLastError();
+}
+
+}  // namespace ngsld

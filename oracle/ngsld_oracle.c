@@ -537,6 +537,67 @@ uint64_t orc_run(const orc_params *p, uint64_t s1_begin, uint64_t s1_end, orc_pa
   return total;
 }
 
+typedef struct {
+  const orc_params *p;
+  uint64_t s1_begin, s1_end;
+  int tid, n_threads;
+  uint64_t pairs, iters;
+  double sum;
+} orc_bjob;
+
+static void *orc_bench_worker(void *arg) {
+  orc_bjob *j = (orc_bjob *)arg;
+  orc_pair r[64];
+  int err = 0;
+  for (uint64_t s1 = j->s1_begin + (uint64_t)j->tid; s1 < j->s1_end; s1 += (uint64_t)j->n_threads) {
+    /* same work as orc_row, a row at a time in chunks of 64 records */
+    orc_params q = *j->p;
+    uint64_t end = orc_row_end(&q, s1);
+    for (uint64_t b = s1 + 1; b < end; b += 64) {
+      uint64_t e = b + 64 < end ? b + 64 : end;
+      for (uint64_t s2 = b; s2 < e; s2++) {
+        if (q.maf[s2] < q.min_maf) continue;
+        orc_pair *o = &r[s2 - b];
+        o->r2pear = orc_pearson_r2(q.expected_geno + s1 * q.n_ind, q.expected_geno + s2 * q.n_ind, q.n_ind);
+        o->n_iter = orc_haplo_freq(o->hap, &o->n_ind_data, q.geno_lkl + s1 * q.n_ind * 3, q.geno_lkl + s2 * q.n_ind * 3,
+                                   q.maf[s1], q.maf[s2], q.n_ind, q.ignore_miss_data, &err);
+        orc_pair_stats(o->hap, &o->D, &o->Dp, &o->r2, o->hap_maf, &o->chi2);
+        if (isfinite(o->r2)) j->sum += o->r2;
+        j->iters += o->n_iter < ORC_ITER_MAX ? o->n_iter + 1 : ORC_ITER_MAX;
+        j->pairs++;
+      }
+    }
+  }
+  return NULL;
+}
+
+uint64_t orc_bench(const orc_params *p, uint64_t s1_begin, uint64_t s1_end, double *checksum, uint64_t *iters) {
+  int nt = p->n_threads > 0 ? p->n_threads : 1;
+  pthread_t *th = (pthread_t *)malloc((size_t)nt * sizeof(pthread_t));
+  orc_bjob *jobs = (orc_bjob *)calloc((size_t)nt, sizeof(orc_bjob));
+  for (int t = 0; t < nt; t++) {
+    jobs[t].p = p;
+    jobs[t].s1_begin = s1_begin;
+    jobs[t].s1_end = s1_end;
+    jobs[t].tid = t;
+    jobs[t].n_threads = nt;
+    pthread_create(&th[t], NULL, orc_bench_worker, &jobs[t]);
+  }
+  uint64_t pairs = 0, it = 0;
+  double sum = 0;
+  for (int t = 0; t < nt; t++) {
+    pthread_join(th[t], NULL);
+    pairs += jobs[t].pairs;
+    it += jobs[t].iters;
+    sum += jobs[t].sum;
+  }
+  if (checksum) *checksum = sum;
+  if (iters) *iters = it;
+  free(th);
+  free(jobs);
+  return pairs;
+}
+
 /* ngsLD.cpp:77 header, :314-351 rows */
 void orc_print_header(FILE *fh, int extend_out) {
   fprintf(fh, "site1\tsite2\tdist\tr2_ExpG\tD\tDp\tr2%s\n",

@@ -100,6 +100,9 @@ uint64_t orc_row(const orc_params *p, uint64_t s1, orc_pair *out, uint64_t cap, 
 /* all rows [s1_begin, s1_end), n_threads pthreads striped over rows. returns #pairs; records optional,
    written in (s1,s2) order when out != NULL (two-pass: count, then fill). */
 uint64_t orc_run(const orc_params *p, uint64_t s1_begin, uint64_t s1_end, orc_pair *out, uint64_t cap, int *err);
+/* cpu_baseline leg of bench.py: compute every pair of rows [s1_begin, s1_end) with n_threads pthreads and
+   keep only a checksum (sum of finite r2) so nothing is stored; returns #pairs. */
+uint64_t orc_bench(const orc_params *p, uint64_t s1_begin, uint64_t s1_end, double *checksum, uint64_t *iters);
 /* exclusive end of the contiguous s2 range row s1 walks (before the maf[s2] skip) */
 uint64_t orc_row_end(const orc_params *p, uint64_t s1);
 

@@ -84,6 +84,8 @@ def lib() -> C.CDLL:
         L.orc_run.restype = C.c_uint64
         L.orc_run.argtypes = [C.POINTER(OrcParams), C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                               C.POINTER(C.c_int)]
+        L.orc_bench.restype = C.c_uint64
+        L.orc_bench.argtypes = [C.POINTER(OrcParams), C.c_uint64, C.c_uint64, c_double_p, C.POINTER(C.c_uint64)]
         L.orc_row_end.restype = C.c_uint64
         L.orc_row_end.argtypes = [C.POINTER(OrcParams), C.c_uint64]
         _lib = L
@@ -165,6 +167,12 @@ class Oracle:
         if e.value:
             raise RuntimeError(f"oracle error code {e.value}")
         return out
+
+    def bench(self, s1_begin: int, s1_end: int) -> tuple[int, float, int]:
+        """Compute rows [s1_begin, s1_end) and discard the records: (#pairs, checksum, executed EM iterations)."""
+        chk, it = C.c_double(0.0), C.c_uint64(0)
+        n = lib().orc_bench(C.byref(self.p), s1_begin, s1_end, C.byref(chk), C.byref(it))
+        return n, chk.value, it.value
 
     def row_ends(self) -> np.ndarray:
         return np.array([lib().orc_row_end(C.byref(self.p), s) for s in range(self.n_sites)], dtype=np.uint64)

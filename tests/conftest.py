@@ -1,0 +1,38 @@
+"""pytest configuration: the `gpu` marker and shared helpers.
+
+`-m "not gpu"`: oracle vs golden vectors / reference build, host logic, C-ABI symbol checks, gloo sharding.
+`-m gpu`     : parity tests proper -- the HIP path, called through the C-ABI, against the oracle.
+"""
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def _have_gpu() -> bool:
+    return os.path.exists("/dev/kfd")
+
+
+def pytest_collection_modifyitems(config, items):
+    if _have_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container (/dev/kfd missing)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def engine():
+    from ngsld_amd import capi
+    eng = capi.Engine(0)
+    yield eng
+    eng.close()
