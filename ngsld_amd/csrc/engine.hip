@@ -178,7 +178,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   a.normalised_input = normalised ? 1 : 0;
   a.maf = c->d_maf.p;
   a.mean_e = c->d_mean.p;
-  a.sxx = c->d_sxx.p;
+  a.rsx = c->d_sxx.p;
   a.status = c->d_status.p;
   HIP_TRY(c, launch_prep(a, c->stream));
   c->h_maf.resize(n_sites);
@@ -272,7 +272,7 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
   a.n_ind = (uint32_t)c->n_ind;
   a.maf = c->d_maf.p;
   a.mean_e = c->d_mean.p;
-  a.sxx = c->d_sxx.p;
+  a.rsx = c->d_sxx.p;
   a.keep = c->d_keep.p;
   a.cumkeep = c->d_cumkeep.p;
   a.row_off = c->d_row_off.p;

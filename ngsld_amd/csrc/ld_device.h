@@ -36,7 +36,7 @@ struct PairArgs {
   uint32_t n_ind;
   const double *maf;     // [n_sites] est_maf
   const double *mean_e;  // [n_sites] mean expected genotype
-  const double *sxx;     // [n_sites] sum (e - mean)^2
+  const double *rsx;     // [n_sites] 1 / sqrt(sum (e - mean)^2)  (inf for a constant site)
   const uint8_t *keep;   // [n_sites] 0 where maf < min_maf
   const uint32_t *cumkeep;  // [n_sites + 1] prefix count of keep
   const uint64_t *row_off;  // [n_sites + 1] pairs before row s1
@@ -111,15 +111,15 @@ __device__ __forceinline__ double wave_sum1(double v) {
   return a;
 }
 
-// 1/s to ~1 ulp: v_rcp_f64 seed + two Newton steps.  s == 0 gives NaN (inf * 0), which is what the
-// caller wants: the reference's tmp/sum is 0/0 there (gen_func.cpp:1103).
+// 1/s to 0.5 ulp: v_rcp_f64 seed (measured 2^-24.4 on gfx950, tools/probe_rcp.hip) + ONE cubic step
+// r0*(1 + e + e^2), e = 1 - s*r0, which leaves e^3 ~ 2^-73: same accuracy as two Newton steps for one FMA
+// less.  s == 0 gives NaN (inf * 0), which is what the caller wants: the reference's tmp/sum is 0/0 there
+// (gen_func.cpp:1103).
 __device__ __forceinline__ double rcp_refined(double s) {
-  double r = __builtin_amdgcn_rcp(s);
-  double e = fma(-s, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-s, r, 1.0);
-  r = fma(r, e, r);
-  return r;
+  const double r0 = __builtin_amdgcn_rcp(s);
+  const double e = fma(-s, r0, 1.0);
+  const double t = fma(e, e, e);
+  return fma(r0, t, r0);
 }
 
 // gen_func.cpp:862-868 miss_data with the reference's abs() macro semantics
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
   const uint32_t s1 = it.s1;
   const double m1 = A.maf[s1];
   const double mean1 = A.mean_e[s1];
-  const double sxx1 = A.sxx[s1];
+  const double rsx1 = A.rsx[s1];
   const uint64_t row_base = A.row_off[s1] - A.out_base;
   const uint32_t ck1 = A.cumkeep[s1 + 1];
   const double *pa = A.planes + (uint64_t)s1 * A.site_stride;
@@ -213,31 +213,37 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
       if (lane == 0 && sub == 0) atomicExch(A.status, (int)NGSLD_ERR_MAF_RANGE);
       f0 = f1 = f2 = f3 = __builtin_nan("");
     }
+    // f = ff/(2x) (gen_func.cpp:1108-1109).  The renormalisation that follows there (:1112-1113) divides
+    // by sum_k ff_k/(2x) = (1/x) sum_i s_i/s_i = 1 up to rounding, and the EM map does not depend on the
+    // scale of f, so it is not repeated per iteration.  x == 0 gives 0 * inf = NaN like the reference's 0/0.
+    const double inv_x = 1.0 / (double)x;
+    bool bad = false;
     uint32_t n_iter = 0;
     for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
-      // two-locus genotype weights: s = sum_{k,h} f_k f_h a[G1(k,h)] b[G2(k,h)] = sum_G W[G] P[G]
-      const double w0 = f0 * f0, w1 = 2.0 * (f0 * f1), w2 = f1 * f1;
-      const double w3 = 2.0 * (f0 * f2), w4 = 2.0 * fma(f0, f3, f1 * f2), w5 = 2.0 * (f1 * f3);
-      const double w6 = f2 * f2, w7 = 2.0 * (f2 * f3), w8 = f3 * f3;
+      // products f_k f_h: they build the two-locus genotype weights W (s = sum_G W[G] P[G] is the
+      // reference's 16-term `sum`) and are reused by the t_k contraction below
+      const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
+      const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
+      const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
       double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
 #pragma unroll
       for (int j = 0; j < SLOTS; ++j) {
         if ((!kCheckAll && j < SLOTS - 1) || ((vbits >> j) & 1u)) {
-          double s = w0 * P[j][0];
-          s = fma(w1, P[j][1], s); s = fma(w2, P[j][2], s);
+          double s = p00 * P[j][0];
+          s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
           s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
-          s = fma(w6, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(w8, P[j][8], s);
+          s = fma(p22, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(p33, P[j][8], s);
           const double r = rcp_refined(s);
           R0 = fma(P[j][0], r, R0); R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
           R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
           R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
         }
       }
-      // t_k = f_k * sum_h f_h R[G(k,h)]  (= this lane's share of ff_k / 2, gen_func.cpp:1098-1104)
-      double t0 = f0 * fma(f3, R4, fma(f2, R3, fma(f1, R1, f0 * R0)));
-      double t1 = f1 * fma(f3, R5, fma(f2, R4, fma(f1, R2, f0 * R1)));
-      double t2 = f2 * fma(f3, R7, fma(f2, R6, fma(f1, R4, f0 * R3)));
-      double t3 = f3 * fma(f3, R8, fma(f2, R7, fma(f1, R5, f0 * R4)));
+      // t_k = sum_h f_k f_h R[G(k,h)]  (= this lane's share of ff_k / 2, gen_func.cpp:1098-1104)
+      double t0 = fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0)));
+      double t1 = fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1)));
+      double t2 = fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3)));
+      double t3 = fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4)));
       wave_sum4(t0, t1, t2, t3);
       if (WAVES > 1) {
         const int par = (int)(n_iter & 1u);
@@ -250,25 +256,20 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
           t0 += xch[par][w][0]; t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
         }
       }
-      // f = ff/(2x), then normalise (gen_func.cpp:1108-1113); the /(2x) cancels in the normalisation,
-      // x == 0 gives 0/0 = NaN exactly as there.
-      const double tot = ((t0 + t1) + t2) + t3;
-      const double inv = 1.0 / tot;
-      double n0 = t0 * inv, n1 = t1 * inv, n2 = t2 * inv, n3 = t3 * inv;
-      // Any individual with s == 0 makes every tmp/sum NaN in the reference, hence all four f NaN.
-      // Here s == 0 poisons every R with inf/NaN, so "any non-finite" <=> "reference is all NaN".
-      const bool bad = !(__builtin_isfinite(n0) && __builtin_isfinite(n1) && __builtin_isfinite(n2) &&
-                         __builtin_isfinite(n3));
-      if (bad) n0 = n1 = n2 = n3 = __builtin_nan("");
-      double eps = 0.0;  // gen_func.cpp:1049-1053: a NaN difference never raises eps
-      double d;
-      d = fabs(n0 - f0); if (d > eps) eps = d;
-      d = fabs(n1 - f1); if (d > eps) eps = d;
-      d = fabs(n2 - f2); if (d > eps) eps = d;
-      d = fabs(n3 - f3); if (d > eps) eps = d;
+      const double n0 = t0 * inv_x, n1 = t1 * inv_x, n2 = t2 * inv_x, n3 = t3 * inv_x;
+      // Any individual with s == 0 makes every tmp/sum NaN in the reference, hence all four f NaN and, as a
+      // NaN difference never raises eps (gen_func.cpp:1049-1053), "convergence" at this iteration.  Here
+      // s == 0 poisons every R with inf/NaN, so a sum that is not a sane ~1 <=> the reference is all NaN.
+      const double sn = (n0 + n1) + (n2 + n3);
+      if (__builtin_amdgcn_readfirstlane((int)!(sn < 2.0))) {
+        bad = true;
+        break;
+      }
+      const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
       f0 = n0; f1 = n1; f2 = n2; f3 = n3;
       if (__builtin_amdgcn_readfirstlane((int)(eps < kEpsilon))) break;  // gen_func.cpp:1054-1055
     }
+    if (bad) f0 = f1 = f2 = f3 = __builtin_nan("");
 
     // ---- ngsLD.cpp:296-306 + pearson_r; written by one lane --------------------------------------
     if (lane == 0 && sub == 0) {
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
       const double den = D < 0 ? -(q00 <= q11 ? q00 : q11) : (q01 <= q10 ? q01 : q10);
       const double Dp = D / den;
       const double rr = D / sqrt(hm0 * hm1 * (1 - hm0) * (1 - hm1));
-      const double r = sxy / (sqrt(sxx1) * sqrt(A.sxx[s2]));
+      const double r = sxy * rsx1 * A.rsx[s2];  // 0 * inf = NaN for a constant site, like the 0/0 there
       const uint64_t slot = row_base + (uint64_t)(A.cumkeep[s2] - ck1);
       ngsld_rec_std o;
       o.r2_ExpG = r * r;

@@ -13,7 +13,7 @@ struct PrepArgs {
   uint64_t n_sites;
   uint32_t np, n_ind;
   int log_scale, ignore_miss, normalised_input;
-  double *maf, *mean_e, *sxx;  // [n_sites]
+  double *maf, *mean_e, *rsx;  // [n_sites]; rsx = 1/sqrt(sum (e - mean)^2)
   int *status;
 };
 

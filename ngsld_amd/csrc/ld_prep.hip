@@ -41,6 +41,28 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double (*sh)[N]) {
   for (int k = 0; k < N; ++k) v[k] = ((sh[0][k] + sh[1][k]) + sh[2][k]) + sh[3][k];
 }
 
+// workgroup min and max of one value per thread (256 threads), through shuffles + LDS
+__device__ __forceinline__ void block_minmax(double (&mn)[1], double (&mx)[1], double (*sh)[1]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int off = 32; off > 0; off >>= 1) {
+    const double a = __shfl_xor(mn[0], off), b = __shfl_xor(mx[0], off);
+    mn[0] = a < mn[0] ? a : mn[0];
+    mx[0] = b > mx[0] ? b : mx[0];
+  }
+  __syncthreads();
+  if (lane == 0) sh[wave][0] = mn[0];
+  __syncthreads();
+  double m = sh[0][0];
+  for (int w = 1; w < 4; ++w) m = sh[w][0] < m ? sh[w][0] : m;
+  __syncthreads();
+  if (lane == 0) sh[wave][0] = mx[0];
+  __syncthreads();
+  double M = sh[0][0];
+  for (int w = 1; w < 4; ++w) M = sh[w][0] > M ? sh[w][0] : M;
+  mn[0] = m;
+  mx[0] = M;
+}
+
 __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
   __shared__ double sh3[4][3];
   __shared__ double sh1[4][1];
@@ -86,7 +108,17 @@ __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
       pl[2 * (uint64_t)A.np + i] = a2;
     }
     block_sum<3>(acc, sh3);
-    const double mean = acc[2] / (double)A.n_ind;
+    // A site whose expected genotypes are all the same value must come out with variance exactly 0
+    // (gsl_stats_correlation's running mean has delta == 0 there and returns 0/0): take min/max so the
+    // mean is that value itself rather than a rounded sum / n.
+    double mn[1] = {__builtin_inf()}, mx[1] = {-__builtin_inf()};
+    for (uint32_t i = threadIdx.x; i < A.n_ind; i += 256) {
+      const double e = fma(2.0, pl[2 * (uint64_t)A.np + i], pl[A.np + i]);
+      mn[0] = e < mn[0] ? e : mn[0];
+      mx[0] = e > mx[0] ? e : mx[0];
+    }
+    block_minmax(mn, mx, sh1);
+    const double mean = mn[0] == mx[0] ? mn[0] : acc[2] / (double)A.n_ind;
     double sq[1] = {0.0};
     for (uint32_t i = threadIdx.x; i < A.n_ind; i += 256) {
       const double d = fma(2.0, pl[2 * (uint64_t)A.np + i], pl[A.np + i]) - mean;
@@ -96,7 +128,7 @@ __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
     if (threadIdx.x == 0) {
       A.maf[site] = A.normalised_input ? A.maf_in[site] : acc[0] / acc[1];
       A.mean_e[site] = mean;
-      A.sxx[site] = sq[0];
+      A.rsx[site] = 1.0 / sqrt(sq[0]);
     }
     if (nan_seen) atomicExch(A.status, (int)NGSLD_ERR_NAN);
   }
