@@ -33,8 +33,9 @@ def row_ends(pos_dist: np.ndarray, max_kb_dist: int, max_snp_dist: int) -> np.nd
         brk = np.isinf(pos_dist)
         brk[0] = False
         seg = np.cumsum(brk)
-        cum = np.cumsum(np.where(np.isinf(pos_dist), 0.0, pos_dist))
-        cum[0] = 0.0
+        gaps = np.where(np.isinf(pos_dist), 0.0, pos_dist)
+        gaps[0] = 0.0                      # the first site's gap (pos - 0) belongs to no pair
+        cum = np.cumsum(gaps)
         # sites of later segments are "infinitely far": shift each segment beyond any window
         key = cum + seg * (cum[-1] + max_kb_dist * 1000.0 + 1.0)
         end = np.searchsorted(key, key + max_kb_dist * 1000.0, side="right").astype(np.int64)

@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ (run in the build container, where /root/reference exists).
+
+Every fixture is DATA: a synthetic input (raw GL matrix, position file text, flags) and the expected
+outputs.  Which code produced which expected field:
+
+  * `ref_*` fields  -- the REFERENCE's own functions, compiled from /root/reference by oracle/build_ref.sh
+                       (read_geno binary branch, est_maf, conv_space, haplo_freq, read_dist, labels):
+                       reader hash, maf, hap[4], n_iter, n_ind_data, pos_dist, labels.
+  * `orc_*` fields  -- the CPU oracle (oracle/ngsld_oracle.c), for what cannot be built from the reference
+                       here because it needs GSL (ngsLD.cpp): the pair walk (s1, s2, dist), r2_ExpG (Pearson),
+                       D, D', r2, chi2 and the TSV text.  The script asserts oracle == reference bit for bit
+                       on every `ref_*` field before it writes anything.
+
+No reference source text is stored; the fixtures hold inputs and numbers only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+from ngsld_amd import shard, synth  # noqa: E402
+from oracle import orc  # noqa: E402
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def pos_text(chrs, pos, extra_col=False, header=False) -> str:
+    lines = []
+    if header:
+        lines.append("chr\tpos\tid" if extra_col else "chr\tpos")
+    for k, (c, p) in enumerate(zip(chrs, pos)):
+        lines.append(f"{c}\t{int(p)}\tsnp{k}" if extra_col else f"{c}\t{int(p)}")
+    return "\n".join(lines) + "\n"
+
+
+def run_cli(raw, ptxt, flags, header=False):
+    """Oracle CLI -> TSV text (sorted the way the reference's test does, examples/test.sh:16)."""
+    with tempfile.TemporaryDirectory() as d:
+        g = os.path.join(d, "in.glf")
+        raw.tofile(g)
+        cmd = [orc.ORC_CLI, "--geno", g, "--n_ind", str(raw.shape[1]), "--n_sites", str(raw.shape[0]), "--verbose", "0"]
+        if ptxt is not None:
+            p = os.path.join(d, "in.pos")
+            open(p, "w").write(ptxt)
+            cmd += ["--posH" if header else "--pos", p]
+        cmd += flags
+        out = subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+    return out
+
+
+def make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max_kb=0, max_snp=0, min_maf=0.0,
+         extra_col=False, header=False, with_text=True):
+    R = orc.ref()
+    assert R is not None, "oracle/_ref/libngsld_ref.so missing: run oracle/build_ref.sh (needs /root/reference)"
+    raw = np.ascontiguousarray(raw, dtype=np.float64)
+    n_sites, n_ind = raw.shape[:2]
+    ptxt = pos_text(chrs, pos, extra_col, header) if chrs is not None else None
+    pd = shard.pos_dist_from_positions(chrs, pos) if chrs is not None else None
+
+    # ---- reference: reader, maf, preprocessing ----
+    with tempfile.TemporaryDirectory() as d:
+        g = os.path.join(d, "in.glf")
+        raw.tofile(g)
+        gl_log = np.empty_like(raw)
+        R.ref_read_geno_bin(g.encode(), int(log_scale), n_ind, n_sites, orc.dp(gl_log))
+        ref_pd, ref_labels = None, None
+        if ptxt is not None:
+            p = os.path.join(d, "in.pos")
+            open(p, "w").write(ptxt)
+            ref_pd = np.empty(n_sites)
+            R.ref_read_dist(p.encode(), int(header), n_sites, orc.dp(ref_pd))
+            buf = C.create_string_buffer(n_sites * 128)
+            n = R.ref_read_labels(p.encode(), int(header), buf, 128, n_sites)
+            assert n == n_sites
+            ref_labels = [buf.raw[s * 128:(s + 1) * 128].split(b"\0")[0].decode() for s in range(n_sites)]
+    gl = gl_log.copy()
+    maf = np.empty(n_sites)
+    expg = np.empty((n_sites, n_ind))
+    R.ref_preprocess(orc.dp(gl), n_ind, n_sites, int(ignore_miss), orc.dp(maf), orc.dp(expg))
+
+    # ---- oracle on the same input; must equal the reference wherever the reference can be built ----
+    o = orc.Oracle(raw, pd, log_scale=log_scale, ignore_miss_data=ignore_miss, max_kb_dist=max_kb,
+                   max_snp_dist=max_snp, min_maf=min_maf, n_threads=4)
+    assert np.array_equal(o.gl_log, gl_log, equal_nan=True), "reader: oracle != reference"
+    assert np.array_equal(o.maf, maf, equal_nan=True) and np.array_equal(o.gl, gl) and np.array_equal(o.expg, expg)
+    if ref_pd is not None:
+        assert np.array_equal(ref_pd, pd), "pos_dist: host mirror != reference read_dist"
+    rec = o.run()
+    hap = np.empty((len(rec), 4))
+    n_iter = np.empty(len(rec), dtype=np.uint64)
+    n_data = np.empty(len(rec), dtype=np.uint64)
+    for k, r in enumerate(rec):
+        h = np.zeros(4)
+        n = C.c_uint64()
+        n_iter[k] = R.ref_haplo_freq(orc.dp(h), C.byref(n), orc.dp(gl[r["s1"]]), orc.dp(gl[r["s2"]]), maf[r["s1"]],
+                                     maf[r["s2"]], n_ind, int(ignore_miss))
+        hap[k], n_data[k] = h, n.value
+    assert np.array_equal(hap, rec["hap"], equal_nan=True), "EM: oracle != reference haplo_freq"
+    assert np.array_equal(n_iter, rec["n_iter"]) and np.array_equal(n_data, rec["n_ind_data"])
+
+    fx = dict(
+        raw=raw, pos_text=np.array(ptxt if ptxt is not None else ""), has_pos=np.array(ptxt is not None),
+        header=np.array(header), log_scale=np.array(log_scale), ignore_miss=np.array(ignore_miss),
+        max_kb=np.array(max_kb), max_snp=np.array(max_snp), min_maf=np.array(min_maf),
+        ref_reader_sha=np.array(sha(gl_log)), ref_gl_sha=np.array(sha(gl)), ref_expg_sha=np.array(sha(expg)),
+        ref_maf=maf, ref_hap=hap, ref_n_iter=n_iter, ref_n_ind_data=n_data,
+        ref_pos_dist=ref_pd if ref_pd is not None else np.zeros(0),
+        ref_labels=np.array(ref_labels if ref_labels is not None else [], dtype=str),
+        orc_s1=rec["s1"], orc_s2=rec["s2"], orc_dist=rec["dist"], orc_r2pear=rec["r2pear"], orc_D=rec["D"],
+        orc_Dp=rec["Dp"], orc_r2=rec["r2"], orc_hap_maf=rec["hap_maf"], orc_chi2=rec["chi2"],
+    )
+    if with_text:
+        flags = ["--max_kb_dist", str(max_kb), "--max_snp_dist", str(max_snp), "--min_maf", repr(min_maf)]
+        if log_scale:
+            flags.append("--log_scale")
+        if ignore_miss:
+            flags.append("--ignore_miss_data")
+        for tag, extra in (("std", []), ("ext", ["--extend_out"])):
+            txt = run_cli(raw, ptxt, flags + extra, header)
+            lines = txt.splitlines(keepends=True)
+            body = "".join(sorted(lines[1:]))
+            fx[f"orc_tsv_{tag}_header"] = np.array(lines[0])
+            fx[f"orc_tsv_{tag}_md5"] = np.array(hashlib.md5((lines[0] + body).encode()).hexdigest())
+            if len(rec) <= 2000:
+                fx[f"orc_tsv_{tag}"] = np.array(txt)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **fx)
+    print(f"{name:24s} {n_sites:5d} sites x {n_ind:4d} ind  {len(rec):6d} pairs  mean nIter {rec['n_iter'].mean():6.2f}"
+          f"  max {rec['n_iter'].max():3d}  nan-r2 {np.isnan(rec['r2']).sum():3d}  {os.path.getsize(path) / 1024:7.1f} KiB")
+
+
+def main():
+    orc.build()
+    assert orc.build_ref(), "need the reference tree to (re)generate goldens"
+
+    # F1: BASELINE configs[0] shape -- 24 ind x 100 sites, depth 2 (slow convergence, some nIter == 100)
+    raw = synth.make_gl_numpy(100, 24, seed=1, depth=2.0)
+    chrs, pos = synth.make_positions(100, 1)
+    make("f1_c1_24x100", raw, chrs, pos)
+    # F4: the same GLs as natural logs, --log_scale
+    with np.errstate(divide="ignore"):
+        make("f4_logscale", np.log(raw), chrs, pos, log_scale=True)
+    # F2: two chromosomes, 3-column pos file (label keeps the extra TAB), windows
+    raw = synth.make_gl_numpy(60, 24, seed=2, depth=4.0)
+    chrs, pos = synth.make_positions(60, 2, n_chr=2)
+    make("f2_twochr_all", raw, chrs, pos, extra_col=True)
+    make("f2_twochr_kb5", raw, chrs, pos, extra_col=True, max_kb=5)
+    make("f2_twochr_snp7", raw, chrs, pos, extra_col=True, max_snp=7, header=True)
+    # F3: degenerate sites, with and without --ignore_miss_data
+    n_ind = 12
+    raw = synth.make_gl_numpy(10, n_ind, seed=61, depth=3.0)
+    raw[2] = np.array([1.0, 0.0, 0.0])
+    raw[3] = np.array([0.0, 0.0, 1.0])
+    g = np.random.default_rng(61).integers(0, 3, size=n_ind)
+    raw[4] = np.eye(3)[g]
+    raw[6] = raw[4]
+    raw[8] = 1.0 / 3.0                                   # missing for everybody
+    raw[9, ::2] = 0.25                                   # missing for half
+    chrs, pos = synth.make_positions(10, 3)
+    make("f3_degenerate", raw, chrs, pos)
+    make("f3_degenerate_ignmiss", raw, chrs, pos, ignore_miss=True)
+    # F5: --min_maf: s1 below -> row empty, s2 below -> skipped
+    raw = synth.make_gl_numpy(100, 24, seed=5, depth=3.0)
+    chrs, pos = synth.make_positions(100, 5)
+    thr = float(np.round(np.quantile(orc.Oracle(raw).maf, 0.25), 3))
+    make("f5_minmaf", raw, chrs, pos, min_maf=thr, max_kb=10)
+    # F6/F7: the benchmark n_ind values (slot / multi-wavefront paths of the kernel)
+    for name, ns, ni, seed in (("f7_n100", 128, 100, 7), ("f6_n500", 48, 500, 6), ("f6_n1000", 24, 1000, 8),
+                               ("f6_n2000", 12, 2000, 9)):
+        raw = synth.make_gl_numpy(ns, ni, seed=seed, depth=10.0)
+        chrs, pos = synth.make_positions(ns, seed)
+        make(name, raw, chrs, pos, with_text=(ni <= 500))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+"""GPU: BASELINE.json's full-size configurations through size-independent properties, plus sampled pairs
+checked against the oracle (the oracle cannot run 1e7..1e8 pairs in a test, it can run a few hundred)."""
+import numpy as np
+import pytest
+
+from ngsld_amd import capi, shard, synth
+from oracle import orc
+from util import TOL, close
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _run_device(eng, n_rows, n_pairs, dev):
+    d_std = torch.empty(max(n_pairs, 1) * 32, dtype=torch.uint8, device=dev)
+    d_ext = torch.empty(max(n_pairs, 1) * 40, dtype=torch.uint8, device=dev)
+    eng.run_device(0, n_rows, d_std.data_ptr(), d_ext.data_ptr(), None)
+    std = d_std.view(torch.float64).view(-1, 4)[:n_pairs]
+    ext = d_ext.view(torch.float64).view(-1, 5)[:n_pairs]
+    meta = d_ext.view(torch.int32).view(-1, 10)[:n_pairs, 8:10]
+    return std, ext[:, :4], meta[:, 0], meta[:, 1]
+
+
+def _sample_check(raw_t, pos_dist, row_off, row_end, std, hap, n_data, n_iter, n_sample, seed, max_kb):
+    rng = np.random.default_rng(seed)
+    n_sites = raw_t.shape[0]
+    rows = rng.integers(0, n_sites - 1, size=n_sample)
+    for s1 in rows:
+        span = int(row_end[s1]) - (s1 + 1)
+        if span <= 0:
+            continue
+        s2 = s1 + 1 + int(rng.integers(0, span))
+        k = int(row_off[s1]) + (s2 - s1 - 1)
+        two = raw_t[[s1, s2]].cpu().numpy()
+        o = orc.Oracle(two, None)
+        r = o.run()[0]
+        assert int(n_iter[k]) == r["n_iter"] and int(n_data[k]) == r["n_ind_data"], (s1, s2)
+        assert np.all(close(hap[k].cpu().numpy(), r["hap"])) and np.all(
+            close(std[k].cpu().numpy(), [r["r2pear"], r["D"], r["Dp"], r["r2"]])), (s1, s2)
+
+
+def test_c2_all_pairs_5000x100():
+    """configs[1]: 5,000 sites x 100 ind, all 12,497,500 pairs."""
+    dev = torch.device("cuda", 0)
+    n_sites, n_ind = 5000, 100
+    raw = synth.make_gl_torch(n_sites, n_ind, 2, dev, depth=10.0)
+    eng = capi.Engine(0)
+    try:
+        eng.set_geno_raw(raw.data_ptr(), n_sites=n_sites, n_ind=n_ind)
+        eng.set_pos_dist(None)
+        n = eng.plan(extend_out=True)
+        assert n == n_sites * (n_sites - 1) // 2
+        row_off, row_end = eng.plan_rows()
+        std, hap, n_data, n_iter = _run_device(eng, n_sites, n, dev)
+        # properties that hold for every pair
+        assert bool(torch.all(n_data == n_ind)) and bool(torch.all((n_iter >= 0) & (n_iter <= 100)))
+        assert float((hap.sum(dim=1) - 1).abs().max()) < 1e-12 and float(hap.min()) >= 0.0
+        r2 = std[:, 3]
+        assert float(r2.min()) >= 0.0 and float(r2.max()) <= 1.0 + 1e-9
+        assert float(std[:, 2].abs().max()) <= 1.0 + 1e-9                     # |D'| <= 1
+        assert float(std[:, 0].min()) >= 0.0 and float(std[:, 0].max()) <= 1.0 + 1e-12
+        # determinism: a second pass is bit-identical (fixed per-pair reduction order)
+        std2, hap2, _, it2 = _run_device(eng, n_sites, n, dev)
+        assert torch.equal(std.view(torch.int64), std2.view(torch.int64)) and torch.equal(n_iter, it2)
+        # allele-flip invariance: swapping genotype 0 <-> 2 at every site leaves r2 and |D| alone, hap00 <-> hap11
+        eng.set_geno_raw(raw.flip(2).contiguous().data_ptr(), n_sites=n_sites, n_ind=n_ind)
+        eng.set_pos_dist(None)
+        eng.plan(extend_out=True)
+        std3, hap3, _, it3 = _run_device(eng, n_sites, n, dev)
+        same_iter = it3 == n_iter
+        assert float(same_iter.double().mean()) > 0.9999                      # threshold flips are ~1e-10 events
+        assert float((std3[:, 3] - r2)[same_iter].abs().max()) < TOL
+        assert float((std3[:, 1] - std[:, 1])[same_iter].abs().max()) < TOL   # D -> (-)(-)D = D under a double flip
+        assert float((hap3[:, 3] - hap[:, 0])[same_iter].abs().max()) < TOL
+        eng.set_geno_raw(raw.data_ptr(), n_sites=n_sites, n_ind=n_ind)
+        _sample_check(raw, None, row_off, row_end, std, hap, n_data, n_iter, 300, 5, 0)
+    finally:
+        eng.close()
+
+
+def test_c3_windowed_100000x500():
+    """configs[2]: 100,000 sites x 500 ind, --max_kb_dist 100 (~1e8 pairs), --extend_out records."""
+    dev = torch.device("cuda", 0)
+    n_sites, n_ind, max_kb = 100_000, 500, 100
+    chrs, pos = synth.make_positions(n_sites, 3)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    raw = synth.make_gl_torch(n_sites, n_ind, 3, dev, depth=10.0)
+    eng = capi.Engine(0)
+    try:
+        eng.set_geno_raw(raw.data_ptr(), n_sites=n_sites, n_ind=n_ind)
+        eng.set_pos_dist(pd)
+        n = eng.plan(max_kb_dist=max_kb, extend_out=True)
+        row_off, row_end = eng.plan_rows()
+        assert np.array_equal(row_end.astype(np.int64), shard.row_ends(pd, max_kb, 0))   # host mirror == engine
+        assert n == int(row_off[-1]) and 9.0e7 < n < 1.1e8
+        std, hap, n_data, n_iter = _run_device(eng, n_sites, n, dev)
+        assert bool(torch.all(n_data == n_ind))
+        assert float((hap.sum(dim=1) - 1).abs().max()) < 1e-12 and float(hap.min()) >= 0.0
+        assert float(std[:, 3].min()) >= 0.0 and float(std[:, 3].max()) <= 1.0 + 1e-9
+        # sharding invariance: rows [lo, hi) computed from a slab (local indices) give the same records
+        lo, hi = 40_000, 40_400
+        slab_lo, slab_hi = shard.slab_for_rows(shard.row_ends(pd, max_kb, 0), lo, hi)
+        eng2 = capi.Engine(0)
+        try:
+            eng2.set_geno_raw(raw[slab_lo:slab_hi].data_ptr(), n_sites=slab_hi - slab_lo, n_ind=n_ind)
+            eng2.set_pos_dist(pd[slab_lo:slab_hi].copy())
+            eng2.plan(max_kb_dist=max_kb, extend_out=True)
+            ro2, _ = eng2.plan_rows()
+            m = int(ro2[hi - lo])
+            std_s, hap_s, _, it_s = _run_device(eng2, hi - lo, m, dev)
+            a, b = int(row_off[lo]), int(row_off[hi])
+            assert b - a == m
+            assert torch.equal(std_s.view(torch.int64), std[a:b].view(torch.int64)) and torch.equal(it_s, n_iter[a:b])
+        finally:
+            eng2.close()
+        _sample_check(raw, pd, row_off, row_end, std, hap, n_data, n_iter, 200, 7, max_kb)
+    finally:
+        eng.close()

@@ -1,0 +1,110 @@
+"""Host-side logic of the product (include/ngsld_host.h) on the CPU: readers and the TSV writer, against the
+golden vectors (reference-produced pos_dist/labels, oracle TSV text)."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from ngsld_amd import capi, shard
+from util import Fixture, fixtures
+
+POS_FIXTURES = [n for n in fixtures() if Fixture(n).has_pos]
+
+
+@pytest.mark.parametrize("name", POS_FIXTURES)
+def test_read_pos_matches_reference(name, tmp_path):
+    fx = Fixture(name)
+    _, p = fx.write_inputs(str(tmp_path))
+    pd, labels = capi.read_pos(p, fx.header, fx.n_sites)
+    assert np.array_equal(pd, fx.pos_dist)          # produced by the reference's read_dist
+    assert labels == fx.labels                      # reference's labels (first TAB -> ':')
+
+
+def test_read_pos_gz_comments_and_last_line(tmp_path):
+    p = tmp_path / "x.pos.gz"
+    with gzip.open(p, "wt") as fh:
+        fh.write("#comment\n\nchr1\t10\nchr1\t25\nchr2\t7\nchr2\t9")   # no trailing newline
+    pd, labels = capi.read_pos(str(p), False, 4)
+    assert np.array_equal(pd, [10.0, 15.0, np.inf, 2.0]) and labels == ["chr1:10", "chr1:25", "chr2:7", "chr2:9"]
+
+
+@pytest.mark.parametrize("text,n,msg", [
+    ("chr1\t10\nchr1\t5\n", 2, "invalid distance between adjacent sites!"),
+    ("chr1\t10\nchr1\t10\n", 2, "invalid distance between adjacent sites!"),
+    ("chr1\t10\n", 2, "wrong number of lines in POS file!"),
+    ("chr1 10\nchr1 20\n", 2, "wrong POS file format!"),
+    ("chr1\t10\nchr1\t20\t3\n", 2, "invalid number of fields in file!"),
+    ("chr\tpos\nchr1\t20\n", 2, "header line found"),
+])
+def test_read_pos_errors(tmp_path, text, n, msg):
+    p = tmp_path / "bad.pos"
+    p.write_text(text)
+    with pytest.raises(capi.NgsldError) as e:
+        capi.read_pos(str(p), False, n)
+    assert msg in e.value.msg
+
+
+def test_read_pos_missing_file(tmp_path):
+    with pytest.raises(capi.NgsldError) as e:
+        capi.read_pos(str(tmp_path / "nope.pos"), False, 3)
+    assert "cannot open file!" in e.value.msg
+
+
+def test_pos_dist_mirror_matches_reference():
+    for name in POS_FIXTURES:
+        fx = Fixture(name)
+        lines = [l.split("\t") for l in fx.pos_text.splitlines()][1 if fx.header else 0:]
+        pd = shard.pos_dist_from_positions([l[0] for l in lines], np.array([int(l[1]) for l in lines]))
+        assert np.array_equal(pd, fx.pos_dist)
+
+
+def test_read_geno_bin_and_size_rule(tmp_path):
+    fx = Fixture("f3_degenerate")
+    g, _ = fx.write_inputs(str(tmp_path))
+    raw = capi.read_geno_bin(g, fx.n_ind, fx.n_sites)
+    assert np.array_equal(raw, fx.raw)
+    gz = str(tmp_path / "z.glf")                      # gzread semantics: a gzip-compressed binary file works too
+    with gzip.open(gz, "wb") as fh:
+        fh.write(fx.raw.tobytes())
+    assert np.array_equal(capi.read_geno_bin(gz, fx.n_ind, fx.n_sites), fx.raw)
+    L = capi.lib()
+    size = os.path.getsize(g)
+    assert L.ngsld_host_geno_size_ok(size, fx.n_ind, fx.n_sites) == 1
+    assert L.ngsld_host_geno_size_ok(size + 7, fx.n_ind, fx.n_sites) == 1    # integer division, ngsLD.cpp:55
+    assert L.ngsld_host_geno_size_ok(size, fx.n_ind, fx.n_sites + 1) == 0
+    with pytest.raises(capi.NgsldError) as e:
+        capi.read_geno_bin(g, fx.n_ind, fx.n_sites + 1)
+    assert "premature EOF" in e.value.msg
+    with pytest.raises(capi.NgsldError) as e:
+        capi.read_geno_bin(g, fx.n_ind, fx.n_sites - 1)
+    assert "not at EOF" in e.value.msg
+
+
+@pytest.mark.parametrize("name", [n for n in fixtures() if "orc_tsv_ext" in Fixture(n)])
+@pytest.mark.parametrize("extend", [False, True])
+def test_formatter_reproduces_oracle_text(name, extend):
+    """Feed the golden records through the product's TSV writer: every line must equal the oracle's text,
+    including -nan / inf and the float-chi2 column."""
+    fx = Fixture(name)
+    tag = "ext" if extend else "std"
+    want = str(fx[f"orc_tsv_{tag}"]).splitlines(keepends=True)
+    assert capi.format_header(extend) == want[0]
+    n = len(fx["orc_s1"])
+    std = np.zeros(n, dtype=capi.REC_STD)
+    std["r2_ExpG"], std["D"], std["Dp"], std["r2"] = fx["orc_r2pear"], fx["orc_D"], fx["orc_Dp"], fx["orc_r2"]
+    ext = np.zeros(n, dtype=capi.REC_EXT)
+    ext["hap"], ext["n_ind_data"], ext["n_iter"] = fx["ref_hap"], fx["ref_n_ind_data"], fx["ref_n_iter"]
+    maf = fx["ref_maf"]
+    for k in range(n):
+        s1, s2 = int(fx["orc_s1"][k]), int(fx["orc_s2"][k])
+        line = capi.format_pair(fx.labels[s1], fx.labels[s2], float(fx["orc_dist"][k]), std[k:k + 1],
+                                ext[k:k + 1] if extend else None, float(maf[s1]), float(maf[s2]))
+        assert line == want[1 + k], f"pair {k}: {line!r} != {want[1 + k]!r}"
+
+
+def test_formatter_nan_inf_and_null_labels():
+    std = np.zeros(1, dtype=capi.REC_STD)
+    std["r2_ExpG"], std["D"], std["Dp"], std["r2"] = np.nan, -0.0, -np.inf, np.inf
+    line = capi.format_pair(None, None, np.inf, std, None, 0.1, 0.2)
+    assert line == "(null)\t(null)\tinf\t-nan\t-0.000000\t-inf\tinf\n"

@@ -1,0 +1,81 @@
+"""The oracle against the committed golden vectors (CPU).  `ref_*` fields were produced by the reference's
+own compiled functions (tests/golden/make_golden.py), so this pins the oracle wherever the reference can
+be built; `orc_*` fields freeze the oracle's own output for the unpinned parts (ngsLD.cpp needs GSL)."""
+import hashlib
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import orc
+from util import Fixture, fixtures
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("name", fixtures())
+def test_oracle_reproduces_golden(name):
+    fx = Fixture(name)
+    o = orc.Oracle(fx.raw, fx.pos_dist, log_scale=fx.log_scale, ignore_miss_data=fx.ignore_miss,
+                   max_kb_dist=fx.max_kb, max_snp_dist=fx.max_snp, min_maf=fx.min_maf, n_threads=2)
+    # reference-pinned stages: reader, maf, preprocessing (bit for bit)
+    assert _sha(o.gl_log) == str(fx["ref_reader_sha"])
+    assert _sha(o.gl) == str(fx["ref_gl_sha"]) and _sha(o.expg) == str(fx["ref_expg_sha"])
+    assert np.array_equal(o.maf, fx["ref_maf"], equal_nan=True)
+    rec = o.run()
+    assert np.array_equal(rec["s1"], fx["orc_s1"]) and np.array_equal(rec["s2"], fx["orc_s2"])
+    # reference-pinned EM
+    assert np.array_equal(rec["hap"], fx["ref_hap"], equal_nan=True)
+    assert np.array_equal(rec["n_iter"], fx["ref_n_iter"]) and np.array_equal(rec["n_ind_data"], fx["ref_n_ind_data"])
+    # frozen oracle output (unpinned parts)
+    for col, key in (("dist", "orc_dist"), ("r2pear", "orc_r2pear"), ("D", "orc_D"), ("Dp", "orc_Dp"), ("r2", "orc_r2"),
+                     ("hap_maf", "orc_hap_maf"), ("chi2", "orc_chi2")):
+        assert np.array_equal(rec[col], fx[key], equal_nan=True), col
+
+
+@pytest.mark.parametrize("name", [n for n in fixtures() if "orc_tsv_std_md5" in Fixture(n)])
+@pytest.mark.parametrize("extend", [False, True])
+def test_oracle_cli_text(name, extend):
+    fx = Fixture(name)
+    tag = "ext" if extend else "std"
+    with tempfile.TemporaryDirectory() as d:
+        g, p = fx.write_inputs(d)
+        cmd = [orc.ORC_CLI, "--geno", g, "--n_ind", str(fx.n_ind), "--n_sites", str(fx.n_sites), "--verbose", "0"]
+        if p:
+            cmd += ["--posH" if fx.header else "--pos", p]
+        txt = subprocess.run(cmd + fx.cli_flags(extend), check=True, capture_output=True, text=True).stdout
+    lines = txt.splitlines(keepends=True)
+    assert lines[0] == str(fx[f"orc_tsv_{tag}_header"])
+    md5 = hashlib.md5((lines[0] + "".join(sorted(lines[1:]))).encode()).hexdigest()
+    assert md5 == str(fx[f"orc_tsv_{tag}_md5"])
+
+
+def test_pearson_against_textbook():
+    """gsl_stats_correlation is restated from GSL's published algorithm (GSL itself is absent): hold it to the
+    textbook formula at 1e-12 (parity unpinned at the GSL boundary, see oracle/ngsld_oracle.h)."""
+    rng = np.random.default_rng(3)
+    for n in (2, 3, 24, 500, 2000):
+        x, y = rng.random(n) * 2, rng.random(n) * 2
+        got = orc.lib().orc_correlation(orc.dp(x), orc.dp(y), n)
+        assert abs(got - np.corrcoef(x, y)[0, 1]) < 1e-12
+    x = np.full(10, 0.7)
+    assert np.isnan(orc.lib().orc_correlation(orc.dp(x), orc.dp(rng.random(10)), 10))   # zero variance -> 0/0
+
+
+def test_em_known_answers():
+    """Closed-form cases of the 4-haplotype EM (independent of any reference build)."""
+    L = orc.lib()
+    import ctypes as C
+    n = 40
+    # hard calls, every individual double-homozygous: haplotype counts are observed directly
+    g1 = np.array([0] * 10 + [2] * 30)
+    g2 = np.array([0] * 10 + [2] * 10 + [0] * 20)
+    a, b = np.eye(3)[g1], np.eye(3)[g2]
+    hap, nn, e = np.zeros(4), C.c_uint64(), C.c_int(0)
+    it = L.orc_haplo_freq(orc.dp(hap), C.byref(nn), orc.dp(np.ascontiguousarray(a)), orc.dp(np.ascontiguousarray(b)),
+                          0.75, 0.25, n, 0, C.byref(e))
+    # haplotypes: 10 ind x (0,0) -> h00, 10 ind x (1,1) -> h11, 20 ind x (1,0) -> h10
+    assert np.allclose(hap, [0.25, 0.0, 0.5, 0.25], atol=1e-12) and nn.value == n and it <= 2 and e.value == 0
