@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--pairs-per-item", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sink", action="store_true", help="also time ngsld_run (records copied to pinned host memory)")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "hbm_traffic.json"))
     return ap.parse_args()
 
@@ -167,6 +168,14 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
+    sink_rate = None
+    if args.sink:                       # PCIe-inclusive hand-off; reported beside, never as `value`
+        eng.run_discard(0, n_rows)
+        t1 = time.perf_counter()
+        got = eng.run_discard(0, n_rows)
+        sink_rate = got / (time.perf_counter() - t1)
+        assert got == n_pairs
+
     # ---- aggregate over ranks: MAX time, SUM pairs ----
     stats = torch.tensor([elapsed, kernel_ms / max(launches, 1), float(n_pairs)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -210,7 +219,8 @@ def main():
                        "n_sites_total": n_sites, "pairs_per_step": total_pairs,
                        "mean_executed_em_iterations": round(mean_exec, 3),
                        "parallelism": f"rows sharded by pair count over {world} GPU(s), no data-path collective",
-                       "gl_generate_s": round(t_gen, 3), "gl_broadcast_s": round(t_bc, 3)},
+                       "gl_generate_s": round(t_gen, 3), "gl_broadcast_s": round(t_bc, 3),
+                       "host_handoff_pairs_per_s_rank0": sink_rate},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "pair_ld_kernel", "kernel_ms_per_launch": launch_s * 1e3,

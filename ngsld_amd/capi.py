@@ -264,6 +264,19 @@ class Engine:
         return (cat(s1s, np.uint64), cat(s2s, np.uint64), cat(stds, REC_STD),
                 cat(exts, REC_EXT) if self.extend_out else None)
 
+    def run_discard(self, s1_begin: int = 0, s1_end: int | None = None) -> int:
+        """Run through the sink path (kernel + D2H of every record into pinned host memory) and only count the
+        pairs delivered: the host-buffer hand-off rate without any formatting."""
+        s1_end = self.n_sites if s1_end is None else s1_end
+        total = [0]
+
+        def sink(_user, bp):
+            total[0] += bp.contents.n_pairs
+            return 0
+
+        self._check(self._L.ngsld_run(self._h, s1_begin, s1_end, SINK_FN(sink), None))
+        return total[0]
+
     def run_device(self, s1_begin: int, s1_end: int, d_std: int, d_ext: int | None, stream: int | None = None) -> None:
         self._check(self._L.ngsld_run_device(self._h, s1_begin, s1_end, d_std, d_ext, stream))
 

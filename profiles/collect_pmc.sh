@@ -35,5 +35,5 @@ with open(dst, "w", newline="") as fh:
 print(dst, len(rows), "rows")
 PY
 done
-tail -2 $OUT/pmc_*.log | grep -v "^$" | tail -8
-cat $OUT/pmc_*.csv | cut -c1-300
+cat $OUT/kernel_stats.csv | head -3 | cut -c1-200
+cat $OUT/pmc_*.csv | grep -v Dispatch_Id | cut -d, -f1,2,10,11 | sort -u -t, -k3,3 | cut -c1-160
