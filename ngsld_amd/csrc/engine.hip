@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -87,6 +88,7 @@ struct ngsld_ctx {
   uint64_t n_items = 0;
 
   // tuning
+  bool prefetch = true;  // n_ind <= 512: LDS-prefetch kernel (NGSLD_PAIR_KERNEL=direct selects the A/B baseline)
   uint32_t pairs_per_item = 16;
   uint64_t batch_pairs = 1ull << 23;
 
@@ -259,7 +261,7 @@ hipError_t timed_launch(ngsld_ctx *c, const PairArgs &a, hipStream_t stream) {
   auto &ev = c->ev_pool[c->ev_used++];
   hipError_t r = hipEventRecord(ev.first, stream);
   if (r != hipSuccess) return r;
-  r = launch_pair_kernel(c->slots, c->waves, c->params.ignore_miss_data != 0, a, stream);
+  r = launch_pair_kernel(c->slots, c->waves, c->params.ignore_miss_data != 0, c->prefetch, a, stream);
   if (r != hipSuccess) return r;
   return hipEventRecord(ev.second, stream);
 }
@@ -325,6 +327,7 @@ int ngsld_create(int device, ngsld_ctx **out) {
   ngsld_ctx *c = new (std::nothrow) ngsld_ctx();
   if (c == nullptr) return NGSLD_ERR_NOMEM;
   c->device = device;
+  if (const char *k = std::getenv("NGSLD_PAIR_KERNEL")) c->prefetch = std::strcmp(k, "direct") != 0;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
       (e = hipStreamCreate(&c->copy_stream)) != hipSuccess) {
     g_create_error = std::string("stream setup: ") + hipGetErrorString(e);
@@ -416,7 +419,7 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) {
   c->h_item_off.resize(n + 1);
   c->h_row_off[0] = 0;
   c->h_item_off[0] = 0;
-  const uint64_t ch = c->pairs_per_item;
+  const uint64_t ch = item_span(c->waves, c->prefetch, c->pairs_per_item);
   for (uint64_t s1 = 0; s1 < n; ++s1) {
     const uint64_t end = c->h_row_end[s1];
     const uint64_t span = end > s1 + 1 ? end - (s1 + 1) : 0;

@@ -131,16 +131,166 @@ __device__ __forceinline__ bool miss_data(double g0, double g1, double g2) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// The pair kernel.
+// Building blocks of the pair kernels
+// ---------------------------------------------------------------------------------------------
+
+// Stage both sites of one pair: P = a (x) b for this lane's SLOTS individuals, their validity bits and the
+// Pearson cross moment.  pa / pb point at a site's three planes [3][np] -- in HBM/L2 (direct kernel) or in
+// LDS (prefetch kernel); after inlining the compiler knows which and emits global_load or ds_read.
+template <int SLOTS, bool MASKED>
+__device__ __forceinline__ void stage_pair(const double *pa, const double *pb, uint32_t np, uint32_t i0,
+                                           uint32_t n_ind, double mean1, double mean2, double (&P)[SLOTS][9],
+                                           uint32_t &vbits, double &sxy) {
+  vbits = 0;
+  sxy = 0.0;
+#pragma unroll
+  for (int j = 0; j < SLOTS; ++j) {
+    const uint32_t i = i0 + (uint32_t)j * 64;
+    const double a0 = pa[i], a1 = pa[np + i], a2 = pa[2 * np + i];
+    const double b0 = pb[i], b1 = pb[np + i], b2 = pb[2 * np + i];
+    const bool inb = i < n_ind;
+    bool ok = inb;
+    if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);  // gen_func.cpp:1089
+    vbits |= (ok ? 1u : 0u) << j;
+    P[j][0] = a0 * b0; P[j][1] = a0 * b1; P[j][2] = a0 * b2;
+    P[j][3] = a1 * b0; P[j][4] = a1 * b1; P[j][5] = a1 * b2;
+    P[j][6] = a2 * b0; P[j][7] = a2 * b1; P[j][8] = a2 * b2;
+    // expected genotypes p1 + 2*p2 (ngsLD.cpp:113); pearson_r runs over ALL individuals (ngsLD.cpp:290)
+    const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;
+    const double c2 = inb ? fma(2.0, b2, b1) - mean2 : 0.0;
+    sxy = fma(c1, c2, sxy);
+  }
+}
+
+// x = individuals with data (gen_func.cpp:1091): popcount of ballots, integer exact
+template <int SLOTS>
+__device__ __forceinline__ uint32_t count_valid(uint32_t vbits) {
+  uint32_t x = 0;
+#pragma unroll
+  for (int j = 0; j < SLOTS; ++j) x += (uint32_t)__popcll(__ballot((vbits >> j) & 1u));
+  return x;
+}
+
+// haplo_freq (gen_func.cpp:1027-1059) on the staged pair.  Returns n_iter; f0..f3 hold hap_freq on exit.
+//   CHECK_ALL: every slot may hold padding / missing individuals (otherwise only the last one can)
+//   WAVES > 1: the pair is spread over WAVES wavefronts, partial sums meet in xch (LDS, double buffered)
+template <int SLOTS, int WAVES, bool CHECK_ALL>
+__device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_t vbits, uint32_t x, double m1,
+                                            double m2, double &f0, double &f1, double &f2, double &f3,
+                                            double (*xch)[WAVES][4], int sub, int lane, int *status) {
+  f0 = (1 - m1) * (1 - m2); f1 = (1 - m1) * m2; f2 = m1 * (1 - m2); f3 = m1 * m2;  // gen_func.cpp:1034-1037
+  if (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1) {  // error() in the reference (:1030); reported through status
+    if (lane == 0 && sub == 0) atomicExch(status, (int)NGSLD_ERR_MAF_RANGE);
+    f0 = f1 = f2 = f3 = __builtin_nan("");
+  }
+  // f = ff/(2x) (gen_func.cpp:1108-1109).  The renormalisation that follows there (:1112-1113) divides
+  // by sum_k ff_k/(2x) = (1/x) sum_i s_i/s_i = 1 up to rounding, and the EM map does not depend on the
+  // scale of f, so it is not repeated per iteration.  x == 0 gives 0 * inf = NaN like the reference's 0/0.
+  const double inv_x = 1.0 / (double)x;
+  bool bad = false;
+  uint32_t n_iter = 0;
+  for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
+    // products f_k f_h: they build the two-locus genotype weights W (s = sum_G W[G] P[G] is the
+    // reference's 16-term `sum`, gen_func.cpp:1093-1096) and are reused by the t_k contraction below
+    const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
+    const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
+    const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
+    double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+      if ((!CHECK_ALL && j < SLOTS - 1) || ((vbits >> j) & 1u)) {
+        double s = p00 * P[j][0];
+        s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
+        s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
+        s = fma(p22, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(p33, P[j][8], s);
+        const double r = rcp_refined(s);
+        R0 = fma(P[j][0], r, R0); R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
+        R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
+        R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
+      }
+    }
+    // t_k = sum_h f_k f_h R[G(k,h)]  (= this lane's share of ff_k / 2, gen_func.cpp:1098-1104)
+    double t0 = fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0)));
+    double t1 = fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1)));
+    double t2 = fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3)));
+    double t3 = fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4)));
+    wave_sum4(t0, t1, t2, t3);
+    if (WAVES > 1) {
+      const int par = (int)(n_iter & 1u);
+      if (lane == 0) {
+        xch[par][sub][0] = t0; xch[par][sub][1] = t1; xch[par][sub][2] = t2; xch[par][sub][3] = t3;
+      }
+      __syncthreads();
+      t0 = t1 = t2 = t3 = 0.0;
+      for (int w = 0; w < WAVES; ++w) {
+        t0 += xch[par][w][0]; t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
+      }
+    }
+    const double n0 = t0 * inv_x, n1 = t1 * inv_x, n2 = t2 * inv_x, n3 = t3 * inv_x;
+    // Any individual with s == 0 makes every tmp/sum NaN in the reference, hence all four f NaN and, as a
+    // NaN difference never raises eps (gen_func.cpp:1049-1053), "convergence" at this iteration.  Here
+    // s == 0 poisons every R with inf/NaN, so a sum that is not a sane ~1 <=> the reference is all NaN.
+    const double sn = (n0 + n1) + (n2 + n3);
+    if (__builtin_amdgcn_readfirstlane((int)!(sn < 2.0))) {
+      bad = true;
+      break;
+    }
+    const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
+    f0 = n0; f1 = n1; f2 = n2; f3 = n3;
+    if (__builtin_amdgcn_readfirstlane((int)(eps < kEpsilon))) break;  // gen_func.cpp:1054-1055
+  }
+  if (bad) f0 = f1 = f2 = f3 = __builtin_nan("");
+  return n_iter;
+}
+
+// ngsLD.cpp:296-306 (hap-derived maf, D, D', r2) + pearson_r, one record per pair.
+__device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, double f0, double f1, double f2,
+                                           double f3, double sxy, double rsx1, double rsx2, uint32_t x,
+                                           uint32_t n_iter) {
+  // 1 - (f0 + f1) carries ~1e-16 of rounding noise; at a monomorphic site that noise alone decides in
+  // the reference whether D' and r2 come out as 0/0 = NaN or 0/1e-16 = 0.  Noise-sized values are
+  // snapped to the exact 0 / 1 they stand for, which is the reference's outcome whenever its own
+  // rounding happens to cancel (DESIGN.md "degenerate pairs").
+  double hm0 = 1 - (f0 + f1);
+  double hm1 = 1 - (f0 + f2);
+  if (fabs(hm0) < 1e-15) hm0 = 0.0;
+  if (fabs(1 - hm0) < 1e-15) hm0 = 1.0;
+  if (fabs(hm1) < 1e-15) hm1 = 0.0;
+  if (fabs(1 - hm1) < 1e-15) hm1 = 1.0;
+  const double D = f0 * f3 - f1 * f2;
+  const double q00 = hm0 * hm1, q11 = (1 - hm0) * (1 - hm1);
+  const double q01 = hm0 * (1 - hm1), q10 = (1 - hm0) * hm1;
+  const double den = D < 0 ? -(q00 <= q11 ? q00 : q11) : (q01 <= q10 ? q01 : q10);
+  const double Dp = D / den;
+  const double rr = D / sqrt(hm0 * hm1 * (1 - hm0) * (1 - hm1));
+  const double r = sxy * rsx1 * rsx2;  // 0 * inf = NaN for a constant site, like the 0/0 there
+  ngsld_rec_std o;
+  o.r2_ExpG = r * r;
+  o.D = D;
+  o.Dp = Dp;
+  o.r2 = rr * rr;
+  A.out_std[slot] = o;
+  if (A.out_ext != nullptr) {
+    ngsld_rec_ext e;
+    e.hap[0] = f0; e.hap[1] = f1; e.hap[2] = f2; e.hap[3] = f3;
+    e.n_ind_data = x;
+    e.n_iter = n_iter;
+    A.out_ext[slot] = e;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Direct kernel: site vectors read straight from HBM/L2 at every pair start.
 //   SLOTS  individuals per lane (compile time, P lives in 18*SLOTS VGPRs)
-//   WAVES  wavefronts sharing one pair (1: four independent wavefronts per 256-thread workgroup)
+//   WAVES  wavefronts sharing one pair (1: four independent wavefronts per 256-thread workgroup, one item each)
 //   MASKED --ignore_miss_data: individuals missing at either site are left out (gen_func.cpp:1089)
+// Used for n_ind > 512 (WAVES > 1); for WAVES == 1 it is the A/B baseline of the prefetch kernel below.
 // ---------------------------------------------------------------------------------------------
 template <int SLOTS, int WAVES, bool MASKED>
 __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
   constexpr bool kCheckAll = MASKED || WAVES > 1;  // otherwise only the last slot can hold padding
-  __shared__ double xch[2][WAVES > 1 ? WAVES : 1][4];
-  __shared__ double xch0[WAVES > 1 ? WAVES : 1][2];
+  __shared__ double xch[2][WAVES][4];
+  __shared__ double xch0[WAVES][2];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -156,40 +306,16 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
   const uint64_t row_base = A.row_off[s1] - A.out_base;
   const uint32_t ck1 = A.cumkeep[s1 + 1];
   const double *pa = A.planes + (uint64_t)s1 * A.site_stride;
-  const uint32_t np = A.np;
   const uint32_t i0 = (uint32_t)sub * (SLOTS * 64) + (uint32_t)lane;
 
   for (uint32_t s2 = it.s2_begin; s2 < it.s2_begin + it.count; ++s2) {
     if (!A.keep[s2]) continue;  // ngsLD.cpp:270-275
-    const double *pb = A.planes + (uint64_t)s2 * A.site_stride;
-    const double m2 = A.maf[s2];
-    const double mean2 = A.mean_e[s2];
-
-    // ---- stage both sites: P = a (x) b, validity bits, Pearson cross moment --------------------
     double P[SLOTS][9];
-    uint32_t vbits = 0;
-    double sxy = 0.0;
-#pragma unroll
-    for (int j = 0; j < SLOTS; ++j) {
-      const uint32_t i = i0 + (uint32_t)j * 64;
-      const double a0 = pa[i], a1 = pa[np + i], a2 = pa[2 * np + i];
-      const double b0 = pb[i], b1 = pb[np + i], b2 = pb[2 * np + i];
-      const bool inb = i < A.n_ind;
-      bool ok = inb;
-      if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);
-      vbits |= (ok ? 1u : 0u) << j;
-      P[j][0] = a0 * b0; P[j][1] = a0 * b1; P[j][2] = a0 * b2;
-      P[j][3] = a1 * b0; P[j][4] = a1 * b1; P[j][5] = a1 * b2;
-      P[j][6] = a2 * b0; P[j][7] = a2 * b1; P[j][8] = a2 * b2;
-      // expected genotypes p1 + 2*p2 (ngsLD.cpp:113); pearson_r runs over ALL individuals (ngsLD.cpp:290)
-      const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;
-      const double c2 = inb ? fma(2.0, b2, b1) - mean2 : 0.0;
-      sxy = fma(c1, c2, sxy);
-    }
-    // x = individuals with data (gen_func.cpp:1091), integer exact
-    uint32_t x = 0;
-#pragma unroll
-    for (int j = 0; j < SLOTS; ++j) x += (uint32_t)__popcll(__ballot((vbits >> j) & 1u));
+    uint32_t vbits;
+    double sxy;
+    stage_pair<SLOTS, MASKED>(pa, A.planes + (uint64_t)s2 * A.site_stride, A.np, i0, A.n_ind, mean1, A.mean_e[s2], P,
+                              vbits, sxy);
+    uint32_t x = count_valid<SLOTS>(vbits);
     sxy = wave_sum1(sxy);
     if (WAVES > 1) {
       if (lane == 0) {
@@ -206,110 +332,131 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
       x = (uint32_t)xs;
       __syncthreads();
     }
-
-    // ---- haplo_freq (gen_func.cpp:1027-1059) ---------------------------------------------------
-    double f0 = (1 - m1) * (1 - m2), f1 = (1 - m1) * m2, f2 = m1 * (1 - m2), f3 = m1 * m2;
-    if (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1) {  // error() in the reference; reported through status
-      if (lane == 0 && sub == 0) atomicExch(A.status, (int)NGSLD_ERR_MAF_RANGE);
-      f0 = f1 = f2 = f3 = __builtin_nan("");
-    }
-    // f = ff/(2x) (gen_func.cpp:1108-1109).  The renormalisation that follows there (:1112-1113) divides
-    // by sum_k ff_k/(2x) = (1/x) sum_i s_i/s_i = 1 up to rounding, and the EM map does not depend on the
-    // scale of f, so it is not repeated per iteration.  x == 0 gives 0 * inf = NaN like the reference's 0/0.
-    const double inv_x = 1.0 / (double)x;
-    bool bad = false;
-    uint32_t n_iter = 0;
-    for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
-      // products f_k f_h: they build the two-locus genotype weights W (s = sum_G W[G] P[G] is the
-      // reference's 16-term `sum`) and are reused by the t_k contraction below
-      const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
-      const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
-      const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
-      double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
-#pragma unroll
-      for (int j = 0; j < SLOTS; ++j) {
-        if ((!kCheckAll && j < SLOTS - 1) || ((vbits >> j) & 1u)) {
-          double s = p00 * P[j][0];
-          s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
-          s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
-          s = fma(p22, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(p33, P[j][8], s);
-          const double r = rcp_refined(s);
-          R0 = fma(P[j][0], r, R0); R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
-          R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
-          R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
-        }
-      }
-      // t_k = sum_h f_k f_h R[G(k,h)]  (= this lane's share of ff_k / 2, gen_func.cpp:1098-1104)
-      double t0 = fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0)));
-      double t1 = fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1)));
-      double t2 = fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3)));
-      double t3 = fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4)));
-      wave_sum4(t0, t1, t2, t3);
-      if (WAVES > 1) {
-        const int par = (int)(n_iter & 1u);
-        if (lane == 0) {
-          xch[par][sub][0] = t0; xch[par][sub][1] = t1; xch[par][sub][2] = t2; xch[par][sub][3] = t3;
-        }
-        __syncthreads();
-        t0 = t1 = t2 = t3 = 0.0;
-        for (int w = 0; w < WAVES; ++w) {
-          t0 += xch[par][w][0]; t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
-        }
-      }
-      const double n0 = t0 * inv_x, n1 = t1 * inv_x, n2 = t2 * inv_x, n3 = t3 * inv_x;
-      // Any individual with s == 0 makes every tmp/sum NaN in the reference, hence all four f NaN and, as a
-      // NaN difference never raises eps (gen_func.cpp:1049-1053), "convergence" at this iteration.  Here
-      // s == 0 poisons every R with inf/NaN, so a sum that is not a sane ~1 <=> the reference is all NaN.
-      const double sn = (n0 + n1) + (n2 + n3);
-      if (__builtin_amdgcn_readfirstlane((int)!(sn < 2.0))) {
-        bad = true;
-        break;
-      }
-      const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
-      f0 = n0; f1 = n1; f2 = n2; f3 = n3;
-      if (__builtin_amdgcn_readfirstlane((int)(eps < kEpsilon))) break;  // gen_func.cpp:1054-1055
-    }
-    if (bad) f0 = f1 = f2 = f3 = __builtin_nan("");
-
-    // ---- ngsLD.cpp:296-306 + pearson_r; written by one lane --------------------------------------
-    if (lane == 0 && sub == 0) {
-      // 1 - (f0 + f1) carries ~1e-16 of rounding noise; at a monomorphic site that noise alone decides in
-      // the reference whether D' and r2 come out as 0/0 = NaN or 0/1e-16 = 0.  Noise-sized values are
-      // snapped to the exact 0 / 1 they stand for, which is the reference's outcome whenever its own
-      // rounding happens to cancel (DESIGN.md "degenerate pairs").
-      double hm0 = 1 - (f0 + f1);
-      double hm1 = 1 - (f0 + f2);
-      if (fabs(hm0) < 1e-15) hm0 = 0.0;
-      if (fabs(1 - hm0) < 1e-15) hm0 = 1.0;
-      if (fabs(hm1) < 1e-15) hm1 = 0.0;
-      if (fabs(1 - hm1) < 1e-15) hm1 = 1.0;
-      const double D = f0 * f3 - f1 * f2;
-      const double q00 = hm0 * hm1, q11 = (1 - hm0) * (1 - hm1);
-      const double q01 = hm0 * (1 - hm1), q10 = (1 - hm0) * hm1;
-      const double den = D < 0 ? -(q00 <= q11 ? q00 : q11) : (q01 <= q10 ? q01 : q10);
-      const double Dp = D / den;
-      const double rr = D / sqrt(hm0 * hm1 * (1 - hm0) * (1 - hm1));
-      const double r = sxy * rsx1 * A.rsx[s2];  // 0 * inf = NaN for a constant site, like the 0/0 there
-      const uint64_t slot = row_base + (uint64_t)(A.cumkeep[s2] - ck1);
-      ngsld_rec_std o;
-      o.r2_ExpG = r * r;
-      o.D = D;
-      o.Dp = Dp;
-      o.r2 = rr * rr;
-      A.out_std[slot] = o;
-      if (A.out_ext != nullptr) {
-        ngsld_rec_ext e;
-        e.hap[0] = f0; e.hap[1] = f1; e.hap[2] = f2; e.hap[3] = f3;
-        e.n_ind_data = x;
-        e.n_iter = n_iter;
-        A.out_ext[slot] = e;
-      }
-    }
+    double f0, f1, f2, f3;
+    const uint32_t n_iter =
+        em_pair<SLOTS, WAVES, kCheckAll>(P, vbits, x, m1, A.maf[s2], f0, f1, f2, f3, xch, sub, lane, A.status);
+    if (lane == 0 && sub == 0)
+      write_pair(A, row_base + (uint64_t)(A.cumkeep[s2] - ck1), f0, f1, f2, f3, sxy, rsx1, A.rsx[s2], x, n_iter);
   }
 }
 
-// host-callable launcher, defined in ld_pair.hip
-hipError_t launch_pair_kernel(int slots, int waves, bool masked, const PairArgs &args, hipStream_t stream);
+// ---------------------------------------------------------------------------------------------
+// Prefetch kernel (n_ind <= 512): the four wavefronts of a workgroup work on ONE row s1.
+//   LDS: [row vector a : 24*SLOTS*64 B] [next-site buffer of wavefront 0..3 : 24*SLOTS*64 B each] [claim counter]
+// The row's vector is brought in once per item.  Each wavefront claims the next s2 of the item from an LDS
+// counter (dynamic balance of the 3..100-iteration spread), and as soon as it has turned the current
+// buffer into P it starts the asynchronous copy (global_load_lds, 16 B per lane, no VGPR round trip) of the
+// site it will work on NEXT -- the copy flies during the whole EM loop, so the ~2.5 us HBM/Infinity-Cache
+// latency that the direct kernel pays at every pair start is off the critical path.
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// Asynchronous copy of one site's planes (SLOTS*1536 B, contiguous) into LDS, 1 KiB per wave-instruction
+// (lane l moves 16 B to lds_dst + k*1024 + l*16).  With `stride` > 1 only chunks k % stride == first are
+// issued (several wavefronts sharing one copy).  A trailing half chunk (odd SLOTS) is issued by lanes 0..31.
+template <int SLOTS>
+__device__ __forceinline__ void dma_site_to_lds(const double *site, char *lds_dst, int lane, int first, int stride) {
+  constexpr int kBytes = SLOTS * 64 * 3 * 8;
+  constexpr int kChunks = (kBytes + 1023) / 1024;
+  const char *g = reinterpret_cast<const char *>(site) + lane * 16;
+#pragma unroll
+  for (int k = 0; k < kChunks; ++k) {
+    if (stride != 1 && (k % stride) != first) continue;
+    if ((k + 1) * 1024 <= kBytes || lane * 16 < kBytes - k * 1024)
+      __builtin_amdgcn_global_load_lds((glb_void_t *)(g + k * 1024), (lds_void_t *)(lds_dst + k * 1024), 16, 0, 0);
+  }
+}
+
+template <int SLOTS, bool MASKED>
+__global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
+  constexpr int kSiteBytes = SLOTS * 64 * 3 * 8;
+  constexpr uint32_t kNp = SLOTS * 64;
+  __shared__ __attribute__((aligned(16))) char smem[kSiteBytes * 5 + 16];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const Item it = A.items[blockIdx.x];
+  const uint32_t s1 = it.s1;
+  const double m1 = A.maf[s1];
+  const double mean1 = A.mean_e[s1];
+  const double rsx1 = A.rsx[s1];
+  const uint64_t row_base = A.row_off[s1] - A.out_base;
+  const uint32_t ck1 = A.cumkeep[s1 + 1];
+  char *lds_a = smem;
+  char *lds_b = smem + kSiteBytes * (1 + wave);
+  uint32_t *claim = reinterpret_cast<uint32_t *>(smem + kSiteBytes * 5);
+
+  // next unclaimed offset inside the item; offsets 0..3 are pre-assigned to the four wavefronts
+  if (threadIdx.x == 0) *claim = 4;
+  auto claim_next = [&]() -> uint32_t {  // skips sites below min_maf (ngsLD.cpp:270-275)
+    for (;;) {
+      uint32_t c = 0;
+      if (lane == 0) c = atomicAdd(claim, 1u);
+      c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+      if (c >= it.count || A.keep[it.s2_begin + c]) return c;
+    }
+  };
+  // Per-site scalars of the site a wavefront will work on are fetched when the site is CLAIMED, one pair
+  // ahead, and parked in SGPRs: an ordinary load waited for while a site copy is in flight would drain the
+  // copy too (vmcnt is in-order), which is exactly the stall this kernel exists to remove.
+  struct SiteScalars {
+    double maf, mean, rsx;
+    uint32_t ck;
+  };
+  auto load_scalars = [&](uint32_t c) -> SiteScalars {
+    SiteScalars v{0.0, 0.0, 0.0, 0u};
+    if (c < it.count) {
+      const uint32_t s2 = it.s2_begin + c;
+      v.maf = uniform(A.maf[s2]);
+      v.mean = uniform(A.mean_e[s2]);
+      v.rsx = uniform(A.rsx[s2]);
+      v.ck = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.cumkeep[s2]);
+    }
+    return v;
+  };
+
+  // the row vector: every wavefront copies a quarter of it
+  dma_site_to_lds<SLOTS>(A.planes + (uint64_t)s1 * A.site_stride, lds_a, lane, wave, 4);
+  __syncthreads();  // claim counter initialised before anybody claims
+  uint32_t c = (uint32_t)wave;
+  if (c < it.count && !A.keep[it.s2_begin + c]) c = claim_next();
+  SiteScalars cur = load_scalars(c);
+  if (c < it.count) dma_site_to_lds<SLOTS>(A.planes + (uint64_t)(it.s2_begin + c) * A.site_stride, lds_b, lane, 0, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // row vector complete in LDS
+
+  while (c < it.count) {
+    const uint32_t cn = claim_next();
+    const SiteScalars nxt = load_scalars(cn);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's site copy (issued a pair ago) has landed
+    double P[SLOTS][9];
+    uint32_t vbits;
+    double sxy;
+    stage_pair<SLOTS, MASKED>(reinterpret_cast<const double *>(lds_a), reinterpret_cast<const double *>(lds_b), kNp,
+                              (uint32_t)lane, A.n_ind, mean1, cur.mean, P, vbits, sxy);
+    // all ds_reads of the buffer are consumed (P is computed): start the copy of the next site over it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (cn < it.count)
+      dma_site_to_lds<SLOTS>(A.planes + (uint64_t)(it.s2_begin + cn) * A.site_stride, lds_b, lane, 0, 1);
+    const uint32_t x = count_valid<SLOTS>(vbits);
+    sxy = wave_sum1(sxy);
+    double f0, f1, f2, f3;
+    const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, x, m1, cur.maf, f0, f1, f2, f3,
+                                                      (double (*)[1][4]) nullptr, 0, lane, A.status);
+    if (lane == 0) write_pair(A, row_base + (uint64_t)(cur.ck - ck1), f0, f1, f2, f3, sxy, rsx1, cur.rsx, x, n_iter);
+    c = cn;
+    cur = nxt;
+  }
+}
+
+// host-callable launchers, defined in ld_pair_w1.hip / ld_pair_wn.hip
+hipError_t launch_pair_kernel(int slots, int waves, bool masked, bool prefetch, const PairArgs &args,
+                              hipStream_t stream);
 bool pair_config(uint64_t n_ind, int *slots, int *waves);
+// s2 sites per work item: the prefetch kernel's item is shared by four wavefronts
+inline uint32_t item_span(int waves, bool prefetch, uint32_t pairs_per_item) {
+  return (waves == 1 && prefetch) ? 4u * pairs_per_item : pairs_per_item;
+}
 
 }  // namespace ngsld

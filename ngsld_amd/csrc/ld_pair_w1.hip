@@ -14,32 +14,40 @@ bool pair_config(uint64_t n_ind, int *slots, int *waves) {
   return true;
 }
 
-template <int SLOTS, int WAVES>
-static hipError_t launch_sw(bool masked, const PairArgs &a, hipStream_t stream) {
-  const uint64_t blocks = WAVES == 1 ? (a.n_items + 3) / 4 : a.n_items;
+template <int SLOTS>
+static hipError_t launch_s(bool masked, bool prefetch, const PairArgs &a, hipStream_t stream) {
+  const uint64_t blocks = prefetch ? a.n_items : (a.n_items + 3) / 4;
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)blocks), block(WAVES == 1 ? 256 : WAVES * 64);
-  if (masked)
-    hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, true>), grid, block, 0, stream, a);
-  else
-    hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, false>), grid, block, 0, stream, a);
+  const dim3 grid((unsigned)blocks), block(256);
+  if (prefetch) {
+    if (masked)
+      hipLaunchKernelGGL((pair_ld_pf_kernel<SLOTS, true>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((pair_ld_pf_kernel<SLOTS, false>), grid, block, 0, stream, a);
+  } else {
+    if (masked)
+      hipLaunchKernelGGL((pair_ld_kernel<SLOTS, 1, true>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((pair_ld_kernel<SLOTS, 1, false>), grid, block, 0, stream, a);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_pair_wn(int slots, int waves, bool masked, const PairArgs &a, hipStream_t stream);
 
-hipError_t launch_pair_kernel(int slots, int waves, bool masked, const PairArgs &a, hipStream_t stream) {
+hipError_t launch_pair_kernel(int slots, int waves, bool masked, bool prefetch, const PairArgs &a,
+                              hipStream_t stream) {
   if (waves != 1) return launch_pair_wn(slots, waves, masked, a, stream);
   switch (slots) {
-    case 1: return launch_sw<1, 1>(masked, a, stream);
-    case 2: return launch_sw<2, 1>(masked, a, stream);
-    case 3: return launch_sw<3, 1>(masked, a, stream);
-    case 4: return launch_sw<4, 1>(masked, a, stream);
-    case 5: return launch_sw<5, 1>(masked, a, stream);
-    case 6: return launch_sw<6, 1>(masked, a, stream);
-    case 7: return launch_sw<7, 1>(masked, a, stream);
-    case 8: return launch_sw<8, 1>(masked, a, stream);
+    case 1: return launch_s<1>(masked, prefetch, a, stream);
+    case 2: return launch_s<2>(masked, prefetch, a, stream);
+    case 3: return launch_s<3>(masked, prefetch, a, stream);
+    case 4: return launch_s<4>(masked, prefetch, a, stream);
+    case 5: return launch_s<5>(masked, prefetch, a, stream);
+    case 6: return launch_s<6>(masked, prefetch, a, stream);
+    case 7: return launch_s<7>(masked, prefetch, a, stream);
+    case 8: return launch_s<8>(masked, prefetch, a, stream);
     default: return hipErrorInvalidValue;
   }
 }
