@@ -88,11 +88,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda is not available (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # NGSLD_BENCH_ONE_DEVICE=1 (debug only): put every rank on GPU 0 with the gloo backend, so the N > 1 code
+    # path can be exercised on a 1-GPU box; the driver's runs use one GPU per rank over RCCL (backend nccl).
+    one_dev = os.environ.get("NGSLD_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_dev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     n_sites = args.sites * world
@@ -120,7 +127,7 @@ def main():
     t_bc = time.perf_counter() - t_bc
 
     # ---- engine: this rank's slab (its rows + halo) goes through the device prep kernel ----
-    eng = capi.Engine(local_rank)
+    eng = capi.Engine(dev_index)
     slab = raw[slab_lo:slab_hi]
     eng.set_geno_raw(slab.data_ptr(), n_sites=slab_hi - slab_lo, n_ind=n_ind)
     local_pd = pos_dist[slab_lo:slab_hi].copy()

@@ -23,7 +23,7 @@ rows = []
 for f in glob.glob(src + "/*counter_collection.csv"):
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            if "pair_ld_kernel" in r.get("Kernel_Name", ""):
+            if "ngsld::" in r.get("Kernel_Name", ""):     # pair kernel + prep kernel (the byte-count calibration)
                 rows.append(r)
 keys = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
         "Accum_VGPR_Count", "SGPR_Count", "Counter_Name", "Counter_Value"]
@@ -35,5 +35,5 @@ with open(dst, "w", newline="") as fh:
 print(dst, len(rows), "rows")
 PY
 done
-cat $OUT/kernel_stats.csv | head -3 | cut -c1-200
-cat $OUT/pmc_*.csv | grep -v Dispatch_Id | cut -d, -f1,2,10,11 | sort -u -t, -k3,3 | cut -c1-160
+grep ngsld $OUT/kernel_stats.csv | cut -c1-200
+python $R/profiles/summarise.py $OUT
