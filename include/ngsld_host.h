@@ -11,6 +11,7 @@
  *   ngsLD.cpp:55-56               size check      => ngsld_host_geno_size_ok
  *   ngsLD.cpp:77,314-351          TSV header/rows => ngsld_host_format_header / ngsld_host_format_pair
  *   ngsLD.cpp:296-298,328-333     hap_maf, chi2   => inside ngsld_host_format_pair (float chi2)
+ *   ngsLD.cpp:310-352             fprintf under the mutex => ngsld_host_write_batch (threads format, one ordered write)
  */
 #ifndef NGSLD_HOST_H
 #define NGSLD_HOST_H
@@ -45,6 +46,16 @@ int ngsld_host_read_geno_bin(const char *path, uint64_t n_ind, uint64_t n_sites,
 size_t ngsld_host_format_header(char *buf, size_t cap, int extend_out);
 size_t ngsld_host_format_pair(char *buf, size_t cap, const char *label1, const char *label2, double dist,
                               const ngsld_rec_std *std_rec, const ngsld_rec_ext *ext_rec, double maf1, double maf2);
+
+/* "%f" (decimals = 6) or "%.0f" (decimals = 0) of one double, byte-identical to glibc's printf for finite
+ * values (exact binary value, round-half-even), with "-nan" / "inf" / "-inf".  cap >= 400.  Returns bytes written. */
+size_t ngsld_host_format_double(char *buf, size_t cap, double v, int decimals);
+
+/* Format a whole batch (what calc_pair_LD's fprintf block does for every pair of the batch, ngsLD.cpp:310-352)
+ * with n_threads threads and write it to file descriptor fd in (s1, s2) order.  pos may be NULL (labels print as
+ * "(null)"), pos_dist NULL = all INFINITY; maf = per-site allele frequencies (ngsld_get_maf). */
+int ngsld_host_write_batch(const ngsld_batch *b, const ngsld_pos *pos, const double *pos_dist, const double *maf,
+                           int n_threads, int fd);
 
 #ifdef __cplusplus
 }

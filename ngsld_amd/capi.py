@@ -43,6 +43,7 @@ SYMBOLS = [
     "ngsld_last_kernel_time", "ngsld_set_tuning", "ngsld_selftest",
     "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos",
     "ngsld_host_geno_size_ok", "ngsld_host_read_geno_bin", "ngsld_host_format_header", "ngsld_host_format_pair",
+    "ngsld_host_format_double", "ngsld_host_write_batch",
 ]
 
 
@@ -102,6 +103,9 @@ def lib() -> C.CDLL:
         L.ngsld_host_format_header.restype = C.c_size_t
         L.ngsld_host_format_pair.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, dbl, vp, vp, dbl, dbl]
         L.ngsld_host_format_pair.restype = C.c_size_t
+        L.ngsld_host_format_double.argtypes = [C.c_char_p, C.c_size_t, dbl, C.c_int]
+        L.ngsld_host_format_double.restype = C.c_size_t
+        L.ngsld_host_write_batch.argtypes = [C.POINTER(Batch), vp, vp, vp, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -132,6 +136,12 @@ def read_geno_bin(path: str, n_ind: int, n_sites: int) -> np.ndarray:
     if rc != OK:
         raise NgsldError(rc, err.value.decode())
     return out
+
+
+def format_double(v: float, decimals: int = 6) -> str:
+    buf = C.create_string_buffer(512)
+    n = lib().ngsld_host_format_double(buf, len(buf), v, decimals)
+    return buf.raw[:n].decode()
 
 
 def format_header(extend_out: bool) -> str:

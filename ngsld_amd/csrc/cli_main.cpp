@@ -4,7 +4,7 @@
 //
 // Differences a user can see (all listed in DESIGN.md):
 //   * rows are written in (site1, site2) order (the reference's order is arbitrary for --n_threads > 1);
-//   * --n_threads is accepted and ignored by the GPU path; --device N (new) picks the GPU;
+//   * --n_threads sets the number of host threads that format the TSV; --device N (new) picks the GPU;
 //   * text/.gz genotype input, --call_geno/--N_thresh/--call_thresh and --rnd_sample < 1 are not part of
 //     the accelerated path yet and end with an error instead of being silently ignored.
 #include <getopt.h>
@@ -138,40 +138,18 @@ void parse_cmd_args(Params *pars, int argc, char **argv) {
 
 struct SinkState {
   const Params *pars;
-  const ngsld_pos *pos;        // may be NULL (no --pos)
-  const double *pos_dist;      // NULL => all INFINITY
+  const ngsld_pos *pos;    // may be NULL (no --pos)
+  const double *pos_dist;  // NULL => all INFINITY
   const std::vector<double> *maf;
-  std::vector<char> buf;
 };
 
-// Writes one batch in (s1, s2) order.  dist is the reference's running sum (ngsLD.cpp:241).
+// One batch, in (s1, s2) order: --n_threads threads format (the reference's threads each fprintf under a mutex,
+// ngsLD.cpp:310-352), one ordered write.
 int write_batch(void *user, const ngsld_batch *b) {
   SinkState *st = static_cast<SinkState *>(user);
-  FILE *fh = st->pars->out_fh;
-  size_t used = 0;
-  st->buf.resize(1 << 22);
-  for (uint64_t s1 = b->s1_begin; s1 < b->s1_end; ++s1) {
-    uint64_t k = b->row_off[s1 - b->s1_begin];
-    const uint32_t end = b->row_end[s1 - b->s1_begin];
-    double dist = 0;
-    const char *l1 = st->pos ? ngsld_host_label(st->pos, s1) : nullptr;
-    for (uint64_t s2 = s1 + 1; s2 < end; ++s2) {
-      dist += st->pos_dist ? st->pos_dist[s2] : INFINITY;
-      if (!b->keep[s2]) continue;
-      if (st->buf.size() - used < 8192) {
-        if (fwrite(st->buf.data(), 1, used, fh) != used) return 1;
-        used = 0;
-      }
-      const char *l2 = st->pos ? ngsld_host_label(st->pos, s2) : nullptr;
-      const size_t n = ngsld_host_format_pair(st->buf.data() + used, st->buf.size() - used, l1, l2, dist, &b->std[k],
-                                              b->ext ? &b->ext[k] : nullptr, (*st->maf)[s1], (*st->maf)[s2]);
-      if (n == 0) return 1;
-      used += n;
-      ++k;
-    }
-  }
-  if (used && fwrite(st->buf.data(), 1, used, fh) != used) return 1;
-  return 0;
+  fflush(st->pars->out_fh);
+  return ngsld_host_write_batch(b, st->pos, st->pos_dist, st->maf->data(), (int)st->pars->n_threads,
+                                fileno(st->pars->out_fh)) == NGSLD_OK ? 0 : 1;
 }
 
 }  // namespace
@@ -202,6 +180,7 @@ int main(int argc, char **argv) {
   char hdr[512];
   const size_t hn = ngsld_host_format_header(hdr, sizeof(hdr), pars.extend_out);
   fwrite(hdr, 1, hn, pars.out_fh);
+  fflush(pars.out_fh);
 
   // ---- device ----
   ngsld_ctx *ctx = nullptr;

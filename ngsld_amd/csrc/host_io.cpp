@@ -1,13 +1,16 @@
 // host_io.cpp -- host-side readers and TSV writer of the drop-in (declared in include/ngsld_host.h).
 // Pure C++17 + zlib, no device code: this is the part of the reference's L0/L4 layers
 // (shared/read_data.cpp, shared/gen_func.cpp read_file, ngsLD.cpp fprintf) the new engine keeps on the host.
+#include <unistd.h>
 #include <zlib.h>
 
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ngsld_host.h"
@@ -38,10 +41,123 @@ bool slurp(const char *path, std::string &out) {
   return true;
 }
 
-// "%f" with the reference's text for the non-finite cases ("-nan", "inf", "-inf")
-inline size_t put_f(char *p, size_t cap, double v) {
-  if (std::isnan(v)) return (size_t)std::snprintf(p, cap, "-nan");
-  return (size_t)std::snprintf(p, cap, "%f", v);
+// ---- exact "%f" / "%.0f" without printf ------------------------------------------------------------
+// glibc prints the EXACT binary value rounded half-to-even at the requested decimal.  |v| = m * 2^e with a
+// 53-bit m; m * 10^6 < 2^73 fits an unsigned __int128, so round(m * 10^6 / 2^-e) is computed exactly with
+// integer arithmetic.  Values too large for the 64-bit quotient (>= ~9.2e12) fall back to snprintf; NaN is
+// "-nan" (see the header), +-inf "inf"/"-inf".  Checked against snprintf on millions of values (tests).
+inline char *put_u64(char *p, uint64_t v) {
+  char tmp[24];
+  int n = 0;
+  do {
+    tmp[n++] = (char)('0' + v % 10);
+    v /= 10;
+  } while (v);
+  while (n) *p++ = tmp[--n];
+  return p;
+}
+
+template <int DECIMALS>  // 6 -> "%f", 0 -> "%.0f"
+inline char *put_fixed(char *p, double v) {
+  uint64_t bits;
+  std::memcpy(&bits, &v, 8);
+  const bool neg = bits >> 63;
+  const int ebits = (int)((bits >> 52) & 0x7ff);
+  uint64_t m = bits & 0xfffffffffffffull;
+  if (ebits == 0x7ff) {
+    if (m) return (char *)std::memcpy(p, "-nan", 4) + 4;
+    if (neg) *p++ = '-';
+    return (char *)std::memcpy(p, "inf", 3) + 3;
+  }
+  int e;  // value = m * 2^e
+  if (ebits == 0) {
+    e = -1074;
+  } else {
+    m |= 1ull << 52;
+    e = ebits - 1075;
+  }
+  constexpr uint64_t kScale = DECIMALS == 6 ? 1000000ull : 1ull;
+  uint64_t q;
+  if (e >= 0) {
+    if (e > 10 || (DECIMALS == 6 && e > -1)) {  // >= 2^53: beyond the fast path
+      return p + std::snprintf(p, 400, DECIMALS == 6 ? "%f" : "%.0f", v);
+    }
+    q = (m << e) * kScale;
+  } else {
+    const int k = -e;
+    const unsigned __int128 M = (unsigned __int128)m * kScale;
+    if (k >= 127) {
+      q = 0;  // M < 2^73: far below one half unit
+    } else {
+      const unsigned __int128 quo = M >> k;
+      if (quo >> 63) return p + std::snprintf(p, 400, DECIMALS == 6 ? "%f" : "%.0f", v);
+      q = (uint64_t)quo;
+      const unsigned __int128 rem = M - (quo << k), half = (unsigned __int128)1 << (k - 1);
+      if (rem > half || (rem == half && (q & 1))) ++q;
+    }
+  }
+  if (neg) *p++ = '-';
+  if (DECIMALS == 0) return put_u64(p, q);
+  p = put_u64(p, q / 1000000ull);
+  uint32_t f = (uint32_t)(q % 1000000ull);
+  *p++ = '.';
+  for (int i = 5; i >= 0; --i) {
+    p[i] = (char)('0' + f % 10);
+    f /= 10;
+  }
+  return p + 6;
+}
+
+inline char *put_str(char *p, const char *s) {
+  const size_t n = std::strlen(s);
+  std::memcpy(p, s, n);
+  return p + n;
+}
+
+// one TSV row; the caller guarantees room for the two labels + 1024 bytes
+inline char *format_row(char *p, const char *label1, const char *label2, double dist, const ngsld_rec_std *sr,
+                        const ngsld_rec_ext *er, double maf1, double maf2) {
+  // glibc prints "(null)" for the reference's NULL labels when no --pos is given (ngsLD.cpp:135)
+  p = put_str(p, label1 ? label1 : "(null)");
+  *p++ = '\t';
+  p = put_str(p, label2 ? label2 : "(null)");
+  *p++ = '\t';
+  p = put_fixed<0>(p, dist);  // ngsLD.cpp:314-322
+  *p++ = '\t';
+  p = put_fixed<6>(p, sr->r2_ExpG); *p++ = '\t';
+  p = put_fixed<6>(p, sr->D);       *p++ = '\t';
+  p = put_fixed<6>(p, sr->Dp);      *p++ = '\t';
+  p = put_fixed<6>(p, sr->r2);
+  if (er != nullptr) {
+    const double *h = er->hap;
+    const double hm0 = 1 - (h[0] + h[1]);  // ngsLD.cpp:297-298
+    const double hm1 = 1 - (h[0] + h[2]);
+    float chi2 = 0;  // ngsLD.cpp:328-333, float arithmetic as there
+    const float freq_A = (float)(h[0] + h[1]);
+    const float freq_B = (float)(h[0] + h[2]);
+    const float exp_hap[4] = {freq_A * freq_B, freq_A * (1 - freq_B), (1 - freq_A) * freq_B,
+                              (1 - freq_A) * (1 - freq_B)};
+    for (int i = 0; i < 4; i++) {
+      const double d = h[i] - (double)exp_hap[i];
+      chi2 = (float)((double)chi2 + d * d / (double)exp_hap[i]);  // pow(d, 2) is d*d exactly
+    }
+    *p++ = '\t';
+    p = put_u64(p, er->n_ind_data);  // ngsLD.cpp:336-349
+    *p++ = '\t';
+    p = put_fixed<6>(p, maf1); *p++ = '\t';
+    p = put_fixed<6>(p, maf2); *p++ = '\t';
+    for (int i = 0; i < 4; i++) {
+      p = put_fixed<6>(p, h[i]);
+      *p++ = '\t';
+    }
+    p = put_fixed<6>(p, hm0); *p++ = '\t';
+    p = put_fixed<6>(p, hm1); *p++ = '\t';
+    p = put_fixed<6>(p, (double)chi2);
+    p = put_str(p, "\t0.000000\t");  // loglike is the literal 0.0 (ngsLD.cpp:347)
+    p = put_u64(p, er->n_iter);
+  }
+  *p++ = '\n';
+  return p;
 }
 
 }  // namespace
@@ -178,44 +294,77 @@ size_t ngsld_host_format_header(char *buf, size_t cap, int extend_out) {
 
 size_t ngsld_host_format_pair(char *buf, size_t cap, const char *label1, const char *label2, double dist,
                               const ngsld_rec_std *sr, const ngsld_rec_ext *er, double maf1, double maf2) {
-  // glibc prints "(null)" for the reference's NULL labels when no --pos is given (ngsLD.cpp:135)
-  if (label1 == nullptr) label1 = "(null)";
-  if (label2 == nullptr) label2 = "(null)";
-  const size_t need = std::strlen(label1) + std::strlen(label2) + 1024;
+  const size_t need = std::strlen(label1 ? label1 : "(null)") + std::strlen(label2 ? label2 : "(null)") + 1024;
   if (cap < need) return 0;
-  char *p = buf;
-  p += std::snprintf(p, cap, "%s\t%s\t%.0f\t", label1, label2, dist);  // ngsLD.cpp:314-322
-  p += put_f(p, 400, sr->r2_ExpG); *p++ = '\t';
-  p += put_f(p, 400, sr->D);       *p++ = '\t';
-  p += put_f(p, 400, sr->Dp);      *p++ = '\t';
-  p += put_f(p, 400, sr->r2);
-  if (er != nullptr) {
-    const double *h = er->hap;
-    const double hm0 = 1 - (h[0] + h[1]);  // ngsLD.cpp:297-298
-    const double hm1 = 1 - (h[0] + h[2]);
-    float chi2 = 0;  // ngsLD.cpp:328-333, float arithmetic as there
-    const float freq_A = (float)(h[0] + h[1]);
-    const float freq_B = (float)(h[0] + h[2]);
-    const float exp_hap[4] = {freq_A * freq_B, freq_A * (1 - freq_B), (1 - freq_A) * freq_B,
-                              (1 - freq_A) * (1 - freq_B)};
-    for (int i = 0; i < 4; i++) {
-      const double d = h[i] - (double)exp_hap[i];
-      chi2 = (float)((double)chi2 + std::pow(d, 2) / (double)exp_hap[i]);
-    }
-    p += std::snprintf(p, 64, "\t%lu\t", (unsigned long)er->n_ind_data);  // ngsLD.cpp:336-349
-    p += put_f(p, 400, maf1); *p++ = '\t';
-    p += put_f(p, 400, maf2); *p++ = '\t';
-    for (int i = 0; i < 4; i++) {
-      p += put_f(p, 400, h[i]);
-      *p++ = '\t';
-    }
-    p += put_f(p, 400, hm0); *p++ = '\t';
-    p += put_f(p, 400, hm1); *p++ = '\t';
-    p += put_f(p, 400, (double)chi2);
-    p += std::snprintf(p, 64, "\t%f\t%lu", 0.0, (unsigned long)er->n_iter);
+  return (size_t)(format_row(buf, label1, label2, dist, sr, er, maf1, maf2) - buf);
+}
+
+size_t ngsld_host_format_double(char *buf, size_t cap, double v, int decimals) {
+  if (cap < 400 || (decimals != 6 && decimals != 0)) return 0;
+  return (size_t)((decimals == 6 ? put_fixed<6>(buf, v) : put_fixed<0>(buf, v)) - buf);
+}
+
+int ngsld_host_write_batch(const ngsld_batch *b, const ngsld_pos *pos, const double *pos_dist, const double *maf,
+                           int n_threads, int fd) {
+  if (b == nullptr || maf == nullptr) return NGSLD_ERR_INVALID;
+  const uint64_t rows = b->s1_end - b->s1_begin;
+  if (rows == 0 || b->n_pairs == 0) return NGSLD_OK;
+  if (n_threads < 1) n_threads = 1;
+  if ((uint64_t)n_threads > rows) n_threads = (int)rows;
+  size_t max_label = 6;  // "(null)"
+  if (pos)
+    for (const auto &l : pos->labels) max_label = std::max(max_label, l.size());
+  const size_t row_bytes = 2 * max_label + 1024;
+  // contiguous row ranges with equal pair counts; every thread formats into its own buffer
+  std::vector<uint64_t> cut(n_threads + 1, rows);
+  cut[0] = 0;
+  for (int t = 1; t < n_threads; ++t) {
+    const uint64_t target = b->n_pairs * (uint64_t)t / (uint64_t)n_threads;
+    cut[t] = (uint64_t)(std::lower_bound(b->row_off, b->row_off + rows, target) - b->row_off);
+    if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
   }
-  *p++ = '\n';
-  return (size_t)(p - buf);
+  std::vector<std::vector<char>> out(n_threads);
+  auto work = [&](int t) {
+    const uint64_t r0 = cut[t], r1 = cut[t + 1];
+    const uint64_t np = b->row_off[r1] - b->row_off[r0];
+    std::vector<char> &buf = out[t];
+    buf.resize(np * (b->ext ? 200 : 96) + np * 2 * max_label / 1 + row_bytes);
+    char *p = buf.data();
+    for (uint64_t r = r0; r < r1; ++r) {
+      const uint64_t s1 = b->s1_begin + r;
+      uint64_t k = b->row_off[r];
+      const char *l1 = pos ? pos->labels[s1].c_str() : nullptr;
+      double dist = 0;
+      for (uint64_t s2 = s1 + 1; s2 < b->row_end[r]; ++s2) {
+        dist += pos_dist ? pos_dist[s2] : INFINITY;  // the reference's running sum (ngsLD.cpp:241)
+        if (!b->keep[s2]) continue;
+        if ((size_t)(buf.data() + buf.size() - p) < row_bytes) {  // extreme values printed long: grow
+          const size_t used = (size_t)(p - buf.data());
+          buf.resize(buf.size() * 2 + row_bytes);
+          p = buf.data() + used;
+        }
+        p = format_row(p, l1, pos ? pos->labels[s2].c_str() : nullptr, dist, &b->std[k], b->ext ? &b->ext[k] : nullptr,
+                       maf[s1], maf[s2]);
+        ++k;
+      }
+    }
+    buf.resize((size_t)(p - buf.data()));
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto &x : th) x.join();
+  for (int t = 0; t < n_threads; ++t) {
+    const char *q = out[t].data();
+    size_t left = out[t].size();
+    while (left) {
+      const ssize_t w = ::write(fd, q, left);
+      if (w <= 0) return NGSLD_ERR_INVALID;
+      q += w;
+      left -= (size_t)w;
+    }
+  }
+  return NGSLD_OK;
 }
 
 }  // extern "C"

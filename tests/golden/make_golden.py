@@ -134,7 +134,7 @@ def make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max
             body = "".join(sorted(lines[1:]))
             fx[f"orc_tsv_{tag}_header"] = np.array(lines[0])
             fx[f"orc_tsv_{tag}_md5"] = np.array(hashlib.md5((lines[0] + body).encode()).hexdigest())
-            if len(rec) <= 2000:
+            if len(rec) <= 3000:
                 fx[f"orc_tsv_{tag}"] = np.array(txt)
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **fx)

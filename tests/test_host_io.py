@@ -108,3 +108,63 @@ def test_formatter_nan_inf_and_null_labels():
     std["r2_ExpG"], std["D"], std["Dp"], std["r2"] = np.nan, -0.0, -np.inf, np.inf
     line = capi.format_pair(None, None, np.inf, std, None, 0.1, 0.2)
     assert line == "(null)\t(null)\tinf\t-nan\t-0.000000\t-inf\tinf\n"
+
+
+def test_format_double_is_printf_exact():
+    """The fast %f / %.0f path against the C library's exact conversion (Python's % formatting is correctly
+    rounded on the exact binary value, like glibc), over magnitudes, ties, subnormals and non-finite values."""
+    import struct
+    rng = np.random.default_rng(11)
+    vals = [0.0, -0.0, 1.0, -1.0, 0.5, 0.0078125, 0.00390625, 2.5e-7, 5e-7, 4.9999999999999998e-7, 1.5e-6, 0.1, 0.7,
+            1e-300, 5e-324, 123456789.987654321, 9.2e12, 9.3e12, 1e15, 2.0 ** 53, 2.0 ** 63, 1e22, 1e300,
+            999999.9999995, 0.9999995, 0.9999994999999999, 1 - 2.0 ** -53]
+    vals += list(rng.random(60000))                                        # [0,1): the bulk of what is printed
+    vals += list((rng.random(60000) - 0.5) * 10.0 ** rng.integers(-12, 14, 60000))
+    vals += [struct.unpack("<d", struct.pack("<Q", int(b)))[0] for b in rng.integers(0, 2 ** 63, 40000)]
+    # exact ties at the 6th decimal: k / 2^j with 7+ decimals
+    vals += [float(k) / 2.0 ** j for j in range(7, 20) for k in range(1, 200, 2)]
+    for v in vals:
+        if np.isnan(v):
+            continue
+        assert capi.format_double(v, 6) == "%f" % v, repr(v)
+        assert capi.format_double(-v, 6) == "%f" % -v, repr(-v)
+        assert capi.format_double(v, 0) == "%.0f" % v, repr(v)
+    assert capi.format_double(np.nan) == "-nan" and capi.format_double(-np.nan) == "-nan"
+    assert capi.format_double(np.inf) == "inf" and capi.format_double(-np.inf, 0) == "-inf"
+
+
+@pytest.mark.parametrize("name", ["f2_twochr_kb5", "f3_degenerate_ignmiss", "f5_minmaf", "f6_n500"])
+@pytest.mark.parametrize("threads", [1, 3, 16])
+def test_write_batch_threads_reproduce_oracle_text(name, threads, tmp_path):
+    """ngsld_host_write_batch (threads format, one ordered write) == the oracle's TSV body, for a batch
+    assembled from the golden records (keep / row_end / row_off as the engine would deliver them)."""
+    import ctypes as C
+    fx = Fixture(name)
+    want = str(fx["orc_tsv_ext"]).splitlines(keepends=True)[1:]
+    n, ns = len(fx["orc_s1"]), fx.n_sites
+    std = np.zeros(n, dtype=capi.REC_STD)
+    std["r2_ExpG"], std["D"], std["Dp"], std["r2"] = fx["orc_r2pear"], fx["orc_D"], fx["orc_Dp"], fx["orc_r2"]
+    ext = np.zeros(n, dtype=capi.REC_EXT)
+    ext["hap"], ext["n_ind_data"], ext["n_iter"] = fx["ref_hap"], fx["ref_n_ind_data"], fx["ref_n_iter"]
+    maf = np.ascontiguousarray(fx["ref_maf"])
+    keep = np.ascontiguousarray((~(maf < fx.min_maf)).astype(np.uint8))
+    row_end = np.ascontiguousarray(shard.row_ends(fx.pos_dist, fx.max_kb, fx.max_snp).astype(np.uint32))
+    row_end[maf < fx.min_maf] = np.arange(ns, dtype=np.uint32)[maf < fx.min_maf] + 1     # ngsLD.cpp:264: row empty
+    s1 = fx["orc_s1"].astype(np.int64)
+    row_off = np.zeros(ns + 1, dtype=np.uint64)
+    row_off[1:] = np.cumsum(np.bincount(s1, minlength=ns))
+    p = tmp_path / "in.pos"
+    p.write_text(fx.pos_text)
+    L = capi.lib()
+    h = C.c_void_p()
+    err = C.create_string_buffer(256)
+    assert L.ngsld_host_read_pos(str(p).encode(), int(fx.header), ns, C.byref(h), err, 256) == 0
+    pd = np.ascontiguousarray(fx.pos_dist)
+    b = capi.Batch(0, ns, n, row_off.ctypes.data_as(C.POINTER(C.c_uint64)), row_end.ctypes.data_as(C.POINTER(C.c_uint32)),
+                   keep.ctypes.data_as(C.POINTER(C.c_uint8)), std.ctypes.data, ext.ctypes.data)
+    out = tmp_path / "out.tsv"
+    with open(out, "wb") as fh:
+        rc = L.ngsld_host_write_batch(C.byref(b), h, pd.ctypes.data, maf.ctypes.data, threads, fh.fileno())
+    L.ngsld_host_free_pos(h)
+    assert rc == 0
+    assert out.read_text().splitlines(keepends=True) == want
