@@ -99,6 +99,23 @@ const char *ngsld_last_error(const ngsld_ctx *ctx);
  * genotypes.  `on_device` != 0: gl_raw is a device pointer on this ctx's device (not modified). */
 int ngsld_set_geno_raw(ngsld_ctx *ctx, const double *gl_raw, uint64_t n_sites, uint64_t n_ind, int log_scale,
                        int ignore_miss_data, int on_device);
+/* The same with every input-side switch of the reference's main():
+ *   text_semantics  the values came from a text (.gz) genotype file: plain log() with no -inf -> -1e15
+ *                   replacement and no NaN check, as the text branch of read_geno (read_data.cpp:83-99)
+ *   call_geno       harden the likelihoods first (ngsLD.cpp:92-98 -> call_geno, gen_func.cpp:886-914):
+ *                   best genotype below N_thresh -> missing, at or above call_thresh -> called */
+typedef struct {
+  int32_t log_scale;
+  int32_t ignore_miss_data;
+  int32_t on_device;
+  int32_t text_semantics;
+  int32_t call_geno;
+  int32_t reserved;
+  double N_thresh;
+  double call_thresh;
+} ngsld_geno_opts;
+int ngsld_set_geno_raw_opts(ngsld_ctx *ctx, const double *gl_raw, uint64_t n_sites, uint64_t n_ind,
+                            const ngsld_geno_opts *opts);
 /* The reference's own data contract at calc_pair_LD: normalised normal-space geno_lkl
  * [site][ind][3] and maf[site] already computed by the caller (ngsLD.hpp:36-37). */
 int ngsld_set_geno_lkl(ngsld_ctx *ctx, const double *geno_lkl, const double *maf, uint64_t n_sites, uint64_t n_ind,

@@ -8,6 +8,7 @@
  *   shared/gen_func.cpp:238-282   read_file       => line rules (skip empty and '#' lines, header offset)
  *   shared/read_data.cpp:28-47    read_geno (bin) => ngsld_host_read_geno_bin (raw doubles; the arithmetic
  *                                                    of that loop runs on the device, ngsld_set_geno_raw)
+ *   shared/read_data.cpp:48-104   read_geno (text)=> ngsld_host_read_geno_text
  *   ngsLD.cpp:55-56               size check      => ngsld_host_geno_size_ok
  *   ngsLD.cpp:77,314-351          TSV header/rows => ngsld_host_format_header / ngsld_host_format_pair
  *   ngsLD.cpp:296-298,328-333     hap_maf, chi2   => inside ngsld_host_format_pair (float chi2)
@@ -39,6 +40,14 @@ int ngsld_host_geno_size_ok(uint64_t file_size, uint64_t n_ind, uint64_t n_sites
 /* Read n_sites*n_ind*3 raw doubles (plain or gzip-compressed file, like gzread) and require EOF after them. */
 int ngsld_host_read_geno_bin(const char *path, uint64_t n_ind, uint64_t n_sites, double *out_raw, char *err,
                              size_t errlen);
+
+/* Text genotype input (plain or .gz), the text branch of read_geno (read_data.cpp:48-104): one line per site,
+ * fields split on blanks and TABs, only fully numeric fields count and the LAST n_ind*3 (in_probs: GL or
+ * posterior triples) or n_ind (called genotypes {-1,0,1,2}) of them are the data; a first line with fewer
+ * numeric fields is a header.  out_raw receives n_sites*n_ind*3 doubles for ngsld_set_geno_raw_opts with
+ * text_semantics = 1 and log_scale = *out_log_scale (called genotypes are handed over as log triples). */
+int ngsld_host_read_geno_text(const char *path, int in_probs, int log_scale, uint64_t n_ind, uint64_t n_sites,
+                              double *out_raw, int *out_log_scale, char *err, size_t errlen);
 
 /* TSV text.  Both return the number of bytes written (no NUL needed), 0 if cap is too small.
  * NaN is printed as "-nan": every NaN the reference prints comes from an x86 invalid operation

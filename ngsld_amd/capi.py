@@ -24,6 +24,12 @@ class Params(C.Structure):
                 ("ignore_miss_data", C.c_int32), ("extend_out", C.c_int32)]
 
 
+class GenoOpts(C.Structure):
+    _fields_ = [("log_scale", C.c_int32), ("ignore_miss_data", C.c_int32), ("on_device", C.c_int32),
+                ("text_semantics", C.c_int32), ("call_geno", C.c_int32), ("reserved", C.c_int32),
+                ("N_thresh", C.c_double), ("call_thresh", C.c_double)]
+
+
 REC_STD = np.dtype([("r2_ExpG", "<f8"), ("D", "<f8"), ("Dp", "<f8"), ("r2", "<f8")])
 REC_EXT = np.dtype([("hap", "<f8", (4,)), ("n_ind_data", "<u4"), ("n_iter", "<u4")])
 
@@ -38,11 +44,12 @@ SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Batch))
 
 # every symbol the two headers declare (checked by tests/test_abi.py against the headers' text)
 SYMBOLS = [
-    "ngsld_version", "ngsld_create", "ngsld_destroy", "ngsld_last_error", "ngsld_set_geno_raw", "ngsld_set_geno_lkl",
+    "ngsld_version", "ngsld_create", "ngsld_destroy", "ngsld_last_error", "ngsld_set_geno_raw",
+    "ngsld_set_geno_raw_opts", "ngsld_set_geno_lkl",
     "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device",
     "ngsld_last_kernel_time", "ngsld_set_tuning", "ngsld_selftest",
     "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos",
-    "ngsld_host_geno_size_ok", "ngsld_host_read_geno_bin", "ngsld_host_format_header", "ngsld_host_format_pair",
+    "ngsld_host_geno_size_ok", "ngsld_host_read_geno_bin", "ngsld_host_read_geno_text", "ngsld_host_format_header", "ngsld_host_format_pair",
     "ngsld_host_format_double", "ngsld_host_write_batch",
 ]
 
@@ -80,6 +87,7 @@ def lib() -> C.CDLL:
         L.ngsld_last_error.argtypes = [vp]
         L.ngsld_last_error.restype = C.c_char_p
         L.ngsld_set_geno_raw.argtypes = [vp, vp, u64, u64, C.c_int, C.c_int, C.c_int]
+        L.ngsld_set_geno_raw_opts.argtypes = [vp, vp, u64, u64, C.POINTER(GenoOpts)]
         L.ngsld_set_geno_lkl.argtypes = [vp, vp, vp, u64, u64, C.c_int]
         L.ngsld_get_maf.argtypes = [vp, vp]
         L.ngsld_set_pos_dist.argtypes = [vp, vp]
@@ -99,6 +107,8 @@ def lib() -> C.CDLL:
         L.ngsld_host_free_pos.restype = None
         L.ngsld_host_geno_size_ok.argtypes = [u64, u64, u64]
         L.ngsld_host_read_geno_bin.argtypes = [C.c_char_p, u64, u64, vp, C.c_char_p, C.c_size_t]
+        L.ngsld_host_read_geno_text.argtypes = [C.c_char_p, C.c_int, C.c_int, u64, u64, vp, C.POINTER(C.c_int),
+                                                C.c_char_p, C.c_size_t]
         L.ngsld_host_format_header.argtypes = [C.c_char_p, C.c_size_t, C.c_int]
         L.ngsld_host_format_header.restype = C.c_size_t
         L.ngsld_host_format_pair.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, dbl, vp, vp, dbl, dbl]
@@ -136,6 +146,19 @@ def read_geno_bin(path: str, n_ind: int, n_sites: int) -> np.ndarray:
     if rc != OK:
         raise NgsldError(rc, err.value.decode())
     return out
+
+
+def read_geno_text(path: str, in_probs: bool, log_scale: bool, n_ind: int, n_sites: int) -> tuple[np.ndarray, bool]:
+    """Text/.gz genotype file -> (raw [n_sites, n_ind, 3], values_are_logs) for Engine.set_geno_raw(text=True)."""
+    L = lib()
+    out = np.empty((n_sites, n_ind, 3), dtype=np.float64)
+    err = C.create_string_buffer(512)
+    is_log = C.c_int(0)
+    rc = L.ngsld_host_read_geno_text(path.encode(), int(in_probs), int(log_scale), n_ind, n_sites, out.ctypes.data,
+                                     C.byref(is_log), err, len(err))
+    if rc != OK:
+        raise NgsldError(rc, err.value.decode())
+    return out, bool(is_log.value)
 
 
 def format_double(v: float, decimals: int = 6) -> str:
@@ -196,16 +219,18 @@ class Engine:
         self._check(self._L.ngsld_selftest(self._h))
 
     def set_geno_raw(self, gl, n_sites: int | None = None, n_ind: int | None = None, log_scale: bool = False,
-                     ignore_miss_data: bool = False) -> None:
-        """gl: numpy float64 [n_sites, n_ind, 3] (host) or an int device pointer with explicit sizes."""
+                     ignore_miss_data: bool = False, text: bool = False, call_geno: tuple | None = None) -> None:
+        """gl: numpy float64 [n_sites, n_ind, 3] (host) or an int device pointer with explicit sizes.
+        text: values come from a text genotype file (read_geno_text); call_geno = (N_thresh, call_thresh)."""
         if isinstance(gl, np.ndarray):
             gl = np.ascontiguousarray(gl, dtype=np.float64)
             n_sites, n_ind = gl.shape[0], gl.shape[1]
             ptr, on_dev = gl.ctypes.data, 0
         else:
             ptr, on_dev = int(gl), 1
-        self._check(self._L.ngsld_set_geno_raw(self._h, ptr, n_sites, n_ind, int(log_scale), int(ignore_miss_data),
-                                               on_dev))
+        o = GenoOpts(int(log_scale), int(ignore_miss_data), on_dev, int(text), int(call_geno is not None), 0,
+                     float(call_geno[0]) if call_geno else 0.0, float(call_geno[1]) if call_geno else 0.0)
+        self._check(self._L.ngsld_set_geno_raw_opts(self._h, ptr, n_sites, n_ind, C.byref(o)))
         self.n_sites, self.n_ind = n_sites, n_ind
 
     def set_geno_lkl(self, geno_lkl: np.ndarray, maf: np.ndarray) -> None:

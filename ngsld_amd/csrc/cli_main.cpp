@@ -5,8 +5,7 @@
 // Differences a user can see (all listed in DESIGN.md):
 //   * rows are written in (site1, site2) order (the reference's order is arbitrary for --n_threads > 1);
 //   * --n_threads sets the number of host threads that format the TSV; --device N (new) picks the GPU;
-//   * text/.gz genotype input, --call_geno/--N_thresh/--call_thresh and --rnd_sample < 1 are not part of
-//     the accelerated path yet and end with an error instead of being silently ignored.
+//   * --rnd_sample < 1 is not part of the accelerated path yet and ends with an error instead of being ignored.
 #include <getopt.h>
 #include <sys/stat.h>
 
@@ -161,17 +160,17 @@ int main(int argc, char **argv) {
   // ---- check input files (ngsLD.cpp:41-57) ----
   struct stat st;
   if (stat(pars.in_geno, &st) != 0) error(__FUNCTION__, "cannot check GENO file size!");
-  const char *dot = strrchr(pars.in_geno, '.');
+  const char *dot = strrchr(pars.in_geno, '.');  // the reference dereferences NULL for a name without '.' (ngsLD.cpp:45)
   if (dot != NULL && strcmp(dot, ".gz") == 0) {
     if (pars.verbose >= 1) fprintf(stderr, "==> GZIP input file (not BINARY)\n");
-    error(__FUNCTION__, "text (.gz) genotype input is not part of the MI355X path yet; use a binary GL file");
+    pars.in_bin = false;
+  } else {
+    if (pars.verbose >= 1) fprintf(stderr, "==> BINARY input file (always lkl)\n");
+    pars.in_bin = true;
+    pars.in_probs = true;
+    if (!ngsld_host_geno_size_ok((uint64_t)st.st_size, pars.n_ind, pars.n_sites))
+      error(__FUNCTION__, "invalid/corrupt genotype input file!");
   }
-  if (pars.verbose >= 1) fprintf(stderr, "==> BINARY input file (always lkl)\n");
-  pars.in_bin = true;
-  pars.in_probs = true;
-  if (!ngsld_host_geno_size_ok((uint64_t)st.st_size, pars.n_ind, pars.n_sites))
-    error(__FUNCTION__, "invalid/corrupt genotype input file!");
-  if (pars.call_geno) error(__FUNCTION__, "--call_geno/--N_thresh/--call_thresh are not part of the MI355X path yet");
   if (pars.rnd_sample != 1) error(__FUNCTION__, "--rnd_sample < 1 is not part of the MI355X path yet");
 
   // ---- prepare output (ngsLD.cpp:73-77): the header is always written ----
@@ -190,11 +189,29 @@ int main(int argc, char **argv) {
   if (pars.verbose >= 1) fprintf(stderr, "> Reading data from file...\n");
   char err[512];
   std::vector<double> raw((size_t)pars.n_sites * pars.n_ind * 3);
-  if (ngsld_host_read_geno_bin(pars.in_geno, pars.n_ind, pars.n_sites, raw.data(), err, sizeof(err)) != NGSLD_OK)
-    error("read_geno", err);
+  ngsld_geno_opts go;
+  memset(&go, 0, sizeof(go));
+  go.log_scale = pars.in_logscale ? 1 : 0;
+  go.ignore_miss_data = pars.ignore_miss_data ? 1 : 0;
+  go.call_geno = pars.call_geno ? 1 : 0;
+  go.N_thresh = pars.N_thresh;
+  go.call_thresh = pars.call_thresh;
+  if (pars.in_bin) {
+    if (ngsld_host_read_geno_bin(pars.in_geno, pars.n_ind, pars.n_sites, raw.data(), err, sizeof(err)) != NGSLD_OK)
+      error("read_geno", err);
+  } else {
+    int is_log = 0;
+    if (ngsld_host_read_geno_text(pars.in_geno, pars.in_probs ? 1 : 0, pars.in_logscale ? 1 : 0, pars.n_ind,
+                                  pars.n_sites, raw.data(), &is_log, err, sizeof(err)) != NGSLD_OK)
+      error("read_geno", err);
+    go.log_scale = is_log;
+    go.text_semantics = 1;
+  }
+  if (pars.call_geno && pars.verbose >= 1) fprintf(stderr, "> Calling genotypes...\n");
   if (pars.verbose >= 1) fprintf(stderr, "==> Calculating MAF for all sites...\n");
-  int rc = ngsld_set_geno_raw(ctx, raw.data(), pars.n_sites, pars.n_ind, pars.in_logscale, pars.ignore_miss_data, 0);
+  int rc = ngsld_set_geno_raw_opts(ctx, raw.data(), pars.n_sites, pars.n_ind, &go);
   if (rc == NGSLD_ERR_NAN) error("read_geno", ngsld_last_error(ctx));
+  if (rc == NGSLD_ERR_INVALID && pars.call_geno) error("call_geno", ngsld_last_error(ctx));
   if (rc != NGSLD_OK) error("ngsld_set_geno_raw", ngsld_last_error(ctx));
   std::vector<double>().swap(raw);
   std::vector<double> maf(pars.n_sites);

@@ -125,8 +125,11 @@ int hip_fail(ngsld_ctx *c, hipError_t e, const char *what) {
   } while (0)
 
 int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t n_sites, uint64_t n_ind,
-                    int log_scale, int ignore_miss, int on_device, bool normalised) {
+                    const ngsld_geno_opts &o, bool normalised) {
   if (c == nullptr) return NGSLD_ERR_INVALID;
+  const int log_scale = o.log_scale, ignore_miss = o.ignore_miss_data, on_device = o.on_device;
+  if (o.call_geno && o.N_thresh > o.call_thresh)  // gen_func.cpp:887-888
+    return fail(c, NGSLD_ERR_INVALID, "missing data threshold must be smaller than calling genotype threshold!");
   if (gl == nullptr || n_sites == 0 || n_ind == 0) return fail(c, NGSLD_ERR_INVALID, "empty genotype matrix");
   if (normalised && maf == nullptr) return fail(c, NGSLD_ERR_INVALID, "maf missing");
   if (n_sites >= 0xffffffffull) return fail(c, NGSLD_ERR_UNSUPPORTED, "n_sites must be below 2^32 - 1");
@@ -178,6 +181,10 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   a.log_scale = log_scale;
   a.ignore_miss = ignore_miss;
   a.normalised_input = normalised ? 1 : 0;
+  a.text_semantics = o.text_semantics;
+  a.call_geno = o.call_geno;
+  a.N_thresh = o.N_thresh;
+  a.call_thresh = o.call_thresh;
   a.maf = c->d_maf.p;
   a.mean_e = c->d_mean.p;
   a.rsx = c->d_sxx.p;
@@ -367,12 +374,24 @@ const char *ngsld_last_error(const ngsld_ctx *c) { return c ? c->err.c_str() : g
 
 int ngsld_set_geno_raw(ngsld_ctx *c, const double *gl_raw, uint64_t n_sites, uint64_t n_ind, int log_scale,
                        int ignore_miss_data, int on_device) {
-  return set_geno_common(c, gl_raw, nullptr, n_sites, n_ind, log_scale, ignore_miss_data, on_device, false);
+  ngsld_geno_opts o{};
+  o.log_scale = log_scale;
+  o.ignore_miss_data = ignore_miss_data;
+  o.on_device = on_device;
+  return set_geno_common(c, gl_raw, nullptr, n_sites, n_ind, o, false);
+}
+
+int ngsld_set_geno_raw_opts(ngsld_ctx *c, const double *gl_raw, uint64_t n_sites, uint64_t n_ind,
+                            const ngsld_geno_opts *opts) {
+  if (opts == nullptr) return c ? fail(c, NGSLD_ERR_INVALID, "opts is NULL") : NGSLD_ERR_INVALID;
+  return set_geno_common(c, gl_raw, nullptr, n_sites, n_ind, *opts, false);
 }
 
 int ngsld_set_geno_lkl(ngsld_ctx *c, const double *geno_lkl, const double *maf, uint64_t n_sites, uint64_t n_ind,
                        int on_device) {
-  return set_geno_common(c, geno_lkl, maf, n_sites, n_ind, 0, 0, on_device, true);
+  ngsld_geno_opts o{};
+  o.on_device = on_device;
+  return set_geno_common(c, geno_lkl, maf, n_sites, n_ind, o, true);
 }
 
 int ngsld_get_maf(ngsld_ctx *c, double *maf_out) {

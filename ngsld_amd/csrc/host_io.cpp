@@ -284,6 +284,68 @@ int ngsld_host_read_geno_bin(const char *path, uint64_t n_ind, uint64_t n_sites,
   return NGSLD_OK;
 }
 
+int ngsld_host_read_geno_text(const char *path, int in_probs, int log_scale, uint64_t n_ind, uint64_t n_sites,
+                              double *out_raw, int *out_log_scale, char *err, size_t errlen) {
+  if (path == nullptr || out_raw == nullptr || out_log_scale == nullptr) return set_err(err, errlen, "invalid argument");
+  std::string text;
+  if (!slurp(path, text)) return set_err(err, errlen, "cannot open GENO file!");
+  *out_log_scale = in_probs ? (log_scale ? 1 : 0) : 1;
+  const uint64_t need = n_ind * (in_probs ? 3 : 1);
+  std::vector<double> vals;
+  size_t b = 0;
+  uint64_t s = 0;
+  while (s < n_sites) {
+    if (b >= text.size())
+      return set_err(err, errlen, "GENO file at premature EOF. Check GENO file and number of sites!");
+    size_t e = text.find('\n', b);
+    if (e == std::string::npos) e = text.size();
+    size_t len = e - b;
+    if (e == text.size() && len > 0 && text[b + len - 1] == '\r') --len;
+    if (len == 0) return set_err(err, errlen, "empty line in GENO file");
+    // numeric fields only (split(char*, sep, double**), gen_func.cpp:381-410: a token counts iff strtod eats all of it)
+    vals.clear();
+    size_t p = b;
+    const size_t end = b + len;
+    while (p < end) {
+      size_t q = p;
+      while (q < end && text[q] != ' ' && text[q] != '\t') ++q;
+      if (q > p) {
+        const char save = text[q == text.size() ? q - 1 : q];
+        char *stop = nullptr;
+        if (q < text.size()) text[q] = '\0';
+        const double v = std::strtod(text.c_str() + p, &stop);
+        const bool whole = stop == text.c_str() + q;
+        if (q < text.size()) text[q] = save;
+        if (whole) vals.push_back(v);
+      }
+      p = q + 1;
+    }
+    b = e + 1;
+    if (vals.empty() || (s == 0 && vals.size() < need)) continue;  // header line (read_data.cpp:64-72)
+    if (vals.size() < need) return set_err(err, errlen, "wrong GENO file format. Less fields than expected!");
+    const double *ptr = vals.data() + (vals.size() - need);  // last n_ind*n_geno columns (read_data.cpp:80-81)
+    double *row = out_raw + s * n_ind * 3;
+    if (in_probs) {
+      std::memcpy(row, ptr, need * sizeof(double));
+    } else {
+      for (uint64_t i = 0; i < n_ind; ++i) {
+        const int g = (int)ptr[i];
+        double *t = row + 3 * i;
+        if (g >= 0) {
+          if (g > 2) return set_err(err, errlen, "wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !");
+          t[0] = t[1] = t[2] = -1e15;  // init_ptr(..., -INF), read_data.cpp:21
+          t[g] = 0.0;                  // log(1), :92
+        } else {
+          t[0] = t[1] = t[2] = std::log(1.0 / 3.0);  // :94
+        }
+      }
+    }
+    ++s;
+  }
+  if (b < text.size()) return set_err(err, errlen, "GENO file not at EOF. Check GENO file and number of sites!");
+  return NGSLD_OK;
+}
+
 size_t ngsld_host_format_header(char *buf, size_t cap, int extend_out) {
   const int n = std::snprintf(
       buf, cap, "site1\tsite2\tdist\tr2_ExpG\tD\tDp\tr2%s\n",

@@ -27,6 +27,30 @@ __device__ __forceinline__ double conv_log(double g) {  // conv_space(log), gen_
   return g == -__builtin_inf() ? -1e15 : g;
 }
 
+// gen_func.cpp:886-914 call_geno(geno, 3, log_scale = true, N_thresh, call_thresh, miss_data = 0) as called at
+// ngsLD.cpp:97; array_max_pos / array_min_pos (gen_func.cpp:73-98) keep the FIRST extreme.
+__device__ __forceinline__ void call_geno(double &g0, double &g1, double &g2, double N_thresh, double call_thresh) {
+  int max_pos = 0;
+  double mx = -__builtin_inf();
+  if (g0 > mx) { max_pos = 0; mx = g0; }
+  if (g1 > mx) { max_pos = 1; mx = g1; }
+  if (g2 > mx) { max_pos = 2; mx = g2; }
+  double mn = __builtin_inf();
+  if (g0 < mn) mn = g0;
+  if (g1 < mn) mn = g1;
+  if (g2 < mn) mn = g2;
+  const double vmax = max_pos == 0 ? g0 : (max_pos == 1 ? g1 : g2);
+  double max_pp = exp(vmax);
+  if (mn == vmax) max_pp = -1.0;  // missing data
+  if (max_pp < N_thresh) g0 = g1 = g2 = log(1.0 / 3.0);
+  if (max_pp >= call_thresh) {
+    g0 = g1 = g2 = -1e15;
+    if (max_pos == 0) g0 = 0.0;
+    if (max_pos == 1) g1 = 0.0;
+    if (max_pos == 2) g2 = 0.0;
+  }
+}
+
 // fixed-order workgroup sum of up to 3 values (256 threads)
 template <int N>
 __device__ __forceinline__ void block_sum(double (&v)[N], double (*sh)[N]) {
@@ -76,16 +100,23 @@ __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
       if (i < A.n_ind) {
         double g0 = raw[3 * (uint64_t)i], g1 = raw[3 * (uint64_t)i + 1], g2 = raw[3 * (uint64_t)i + 2];
         if (!A.normalised_input) {
-          if (!A.log_scale) {  // read_data.cpp:37-38
-            g0 = conv_log(g0);
-            g1 = conv_log(g1);
-            g2 = conv_log(g2);
+          if (!A.log_scale) {
+            if (A.text_semantics) {  // read_data.cpp:86: plain log(), -inf stays
+              g0 = log(g0);
+              g1 = log(g1);
+              g2 = log(g2);
+            } else {  // read_data.cpp:37-38
+              g0 = conv_log(g0);
+              g1 = conv_log(g1);
+              g2 = conv_log(g2);
+            }
           }
           const double norm = logsum3(g0, g1, g2);  // post_prob, read_data.cpp:40
           g0 -= norm;
           g1 -= norm;
           g2 -= norm;
-          if (g0 != g0 || g1 != g1 || g2 != g2) nan_seen = true;  // read_data.cpp:42-45
+          if (!A.text_semantics && (g0 != g0 || g1 != g1 || g2 != g2)) nan_seen = true;  // read_data.cpp:42-45
+          if (A.call_geno) call_geno(g0, g1, g2, A.N_thresh, A.call_thresh);             // ngsLD.cpp:92-98
           // est_maf (gen_func.cpp:974-1009, indF == NULL): closed form of its two identical passes
           if (!(A.ignore_miss && miss_data(g0, g1, g2))) {  // miss_data on LOG values, :985
             const double n2 = logsum3(g0, g1, g2);

@@ -273,6 +273,154 @@ int orc_read_geno_bin(const char *path, int log_scale, uint64_t n_ind, uint64_t 
   return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * read_data.cpp:48-104 (text branch of read_geno).  Fields are split on ' ' and TAB; only tokens that
+ * strtod consumes completely count as fields (split(char*, sep, double**), gen_func.cpp:381-410), so
+ * chromosome names / alleles vanish and the LAST n_ind*n_geno numeric fields are the data (:80-81).
+ * A first line with fewer numeric fields is a header (:64-72).  No -inf -> -INF replacement and no NaN
+ * check in this branch (unlike the binary one).
+ * Deviations: lines of any length are accepted (the reference cuts at BUFF_LEN = 500000 bytes); an empty
+ * line is an error (the reference silently leaves that site uninitialised, :58-59).
+ * ---------------------------------------------------------------------------------------------- */
+static uint64_t split_doubles(char *line, double **out, uint64_t *cap) {
+  uint64_t n = 0;
+  char *p = line;
+  while (*p) {
+    size_t len = strcspn(p, " \t");
+    char save = p[len];
+    p[len] = '\0';
+    if (len > 0) {
+      char *end;
+      double v = strtod(p, &end);
+      if (*end == '\0') {
+        if (n == *cap) {
+          *cap = *cap ? *cap * 2 : 4096;
+          *out = (double *)realloc(*out, *cap * sizeof(double));
+        }
+        (*out)[n++] = v;
+      }
+    }
+    p[len] = save;
+    p += len;
+    if (*p) p++;
+  }
+  return n;
+}
+
+int orc_read_geno_text(const char *path, int in_probs, int log_scale, uint64_t n_ind, uint64_t n_sites, double *out,
+                       char *errbuf, size_t errlen) {
+  gzFile fh = (strcmp(path, "-") == 0) ? gzdopen(fileno(stdin), "r") : gzopen(path, "r");
+  if (fh == NULL) {
+    snprintf(errbuf, errlen, "cannot open GENO file!");
+    return -1;
+  }
+  gzbuffer(fh, 1 << 20);
+  const uint64_t n_geno = in_probs ? ORC_N_GENO : 1;
+  size_t lcap = 1 << 16, llen;
+  char *line = (char *)malloc(lcap);
+  double *t = NULL;
+  uint64_t tcap = 0;
+  int rc = 0;
+  for (uint64_t s = 0; s < n_sites && rc == 0; s++) {
+    llen = 0;
+    for (;;) { /* one line of any length */
+      if (gzgets(fh, line + llen, (int)(lcap - llen)) == NULL) break;
+      llen += strlen(line + llen);
+      if (llen > 0 && line[llen - 1] == '\n') break;
+      if (llen + 1 < lcap) break; /* EOF without newline */
+      lcap *= 2;
+      line = (char *)realloc(line, lcap);
+    }
+    if (llen == 0) {
+      snprintf(errbuf, errlen, "%s", gzeof(fh) ? "GENO file at premature EOF. Check GENO file and number of sites!"
+                                               : "cannot read GZip GENO file. Check GENO file and number of sites!");
+      rc = -2;
+      break;
+    }
+    if (line[llen - 1] == '\n' || line[llen - 1] == '\r') line[--llen] = '\0'; /* chomp */
+    if (llen == 0) {
+      snprintf(errbuf, errlen, "empty line in GENO file");
+      rc = -5;
+      break;
+    }
+    uint64_t n_fields = split_doubles(line, &t, &tcap);
+    if (!n_fields || (s == 0 && n_fields < n_ind * n_geno)) { /* header, :64-72 */
+      s--;
+      continue;
+    }
+    if (n_fields < n_ind * n_geno) {
+      snprintf(errbuf, errlen, "wrong GENO file format. Less fields than expected!");
+      rc = -6;
+      break;
+    }
+    const double *ptr = t + (n_fields - n_ind * n_geno);
+    for (uint64_t i = 0; i < n_ind; i++) {
+      double *g = out + (s * n_ind + i) * 3;
+      g[0] = g[1] = g[2] = -ORC_INF; /* init_ptr(..., -INF), read_data.cpp:21 */
+      if (in_probs) {
+        for (int k = 0; k < 3; k++) g[k] = log_scale ? ptr[i * 3 + k] : log(ptr[i * 3 + k]); /* :85-86 */
+      } else {
+        int gg = (int)ptr[i];
+        if (gg >= 0) {
+          if (gg > 2) {
+            snprintf(errbuf, errlen, "wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !");
+            rc = -7;
+            break;
+          }
+          g[gg] = log(1);
+        } else {
+          g[0] = g[1] = g[2] = log((double)1 / ORC_N_GENO);
+        }
+      }
+      orc_post_prob(g, g, ORC_N_GENO); /* :98 */
+    }
+  }
+  if (rc == 0) {
+    char c;
+    gzread(fh, &c, 1); /* :107-109 */
+    if (!gzeof(fh)) {
+      snprintf(errbuf, errlen, "GENO file not at EOF. Check GENO file and number of sites!");
+      rc = -4;
+    }
+  }
+  gzclose(fh);
+  free(line);
+  free(t);
+  return rc;
+}
+
+/* gen_func.cpp:886-914 call_geno(geno, 3, log_scale = true, N_thresh, call_thresh, miss_data = 0), as called
+ * from ngsLD.cpp:97 (in_logscale is true once read_geno has returned, read_data.cpp:114).
+ * array_max_pos / array_min_pos (gen_func.cpp:73-98) return the FIRST extreme. */
+void orc_call_geno(double *geno, double N_thresh, double call_thresh) {
+  int max_pos = 0, min_pos = 0;
+  double mx = -INFINITY, mn = +INFINITY;
+  for (int k = 0; k < 3; k++) {
+    if (geno[k] > mx) {
+      max_pos = k;
+      mx = geno[k];
+    }
+  }
+  for (int k = 0; k < 3; k++) {
+    if (geno[k] < mn) {
+      min_pos = k;
+      mn = geno[k];
+    }
+  }
+  double max_pp = exp(geno[max_pos]);
+  if (geno[min_pos] == geno[max_pos]) max_pp = -1; /* missing data, mode 0 */
+  if (max_pp < N_thresh)
+    for (int g = 0; g < 3; g++) geno[g] = log((double)1 / 3);
+  if (max_pp >= call_thresh) {
+    for (int g = 0; g < 3; g++) geno[g] = -ORC_INF;
+    geno[max_pos] = log(1);
+  }
+}
+
+void orc_call_geno_all(orc_params *p, double N_thresh, double call_thresh) { /* ngsLD.cpp:92-98 */
+  for (uint64_t k = 0; k < p->n_sites * p->n_ind; k++) orc_call_geno(p->geno_lkl + 3 * k, N_thresh, call_thresh);
+}
+
 /* ngsLD.cpp:103-114: est_maf on the log GLs, then exp() in place and expected genotype p1 + 2*p2 */
 void orc_preprocess(orc_params *p) {
   for (uint64_t s = 0; s < p->n_sites; s++)

@@ -86,6 +86,14 @@ void orc_pair_stats(const double hap[4], double *D, double *Dp, double *r2, doub
 /* binary GL reader: returns 0 ok, <0 error (message in errbuf). out = [n_sites][n_ind][3] log-normalised */
 int orc_read_geno_bin(const char *path, int log_scale, uint64_t n_ind, uint64_t n_sites, double *out, char *errbuf,
                       size_t errlen);
+/* text (.gz or plain) reader, read_data.cpp:48-104: GL/posterior triples (in_probs) or called genotypes
+   {-1,0,1,2}; uses the last n_ind*n_geno numeric fields of every line; out = [n_sites][n_ind][3] log-normalised */
+int orc_read_geno_text(const char *path, int in_probs, int log_scale, uint64_t n_ind, uint64_t n_sites, double *out,
+                       char *errbuf, size_t errlen);
+/* gen_func.cpp:886-914 call_geno on one log-space triple (miss_data mode 0, as ngsLD.cpp:97 calls it) */
+void orc_call_geno(double *geno, double N_thresh, double call_thresh);
+/* ngsLD.cpp:92-98 over the whole matrix (log space, before orc_preprocess) */
+void orc_call_geno_all(orc_params *p, double N_thresh, double call_thresh);
 /* same arithmetic as the reader on an in-memory raw buffer (raw is not modified) */
 int orc_normalise_raw(const double *raw, int log_scale, uint64_t n_ind, uint64_t n_sites, double *out);
 /* ngsLD.cpp:103-114: maf on log GL, exp() in place, expected genotypes */

@@ -32,7 +32,7 @@ int main(int argc, char **argv) {
   P.n_threads = 1;
   const char *out = NULL, *dump = NULL;
   int verbose = 1, in_probs = 0, call_geno = 0;
-  double rnd_sample = 1;
+  double rnd_sample = 1, N_thresh = 0, call_thresh = 0;
 
   static struct option lopts[] = {{"geno", required_argument, NULL, 'g'},
                                   {"probs", no_argument, NULL, 'p'},
@@ -71,8 +71,8 @@ int main(int argc, char **argv) {
       case 'f': P.min_maf = atof(optarg); break;
       case 'm': P.ignore_miss_data = 1; break;
       case 'c': call_geno = 1; break;
-      case 'N': call_geno = 1; break;
-      case 'C': call_geno = 1; break;
+      case 'N': N_thresh = atof(optarg); call_geno = 1; break;
+      case 'C': call_thresh = atof(optarg); call_geno = 1; break;
       case 'r': rnd_sample = atof(optarg); break;
       case 'S': break;
       case 'x': P.extend_out = 1; break;
@@ -83,7 +83,6 @@ int main(int argc, char **argv) {
       default: exit(-1); /* includes --outH, which has no case in the reference (parse_args.cpp:55,130) */
     }
   (void)verbose;
-  (void)in_probs;
 
   if (P.in_geno == NULL) die("parse_cmd_args", "genotype input file (--geno) missing!");
   if (P.n_ind == 0) die("parse_cmd_args", "number of individuals (--n_ind) missing!");
@@ -91,17 +90,21 @@ int main(int argc, char **argv) {
   if (P.in_pos == NULL && P.max_kb_dist > 0)
     die("parse_cmd_args", "position file necessary in order to filter by maximum distance!");
   if (P.min_maf < 0 || P.min_maf > 1) die("parse_cmd_args", "minimum allele frequency must be in [0,1]!");
+  if (call_geno && !in_probs) die("parse_cmd_args", "can only call genotypes from likelihoods/probabilities!");
   if (rnd_sample <= 0 || rnd_sample > 1)
     die("parse_cmd_args", "proportion of comparisons to sample must be in ]0,1]!");
   if (P.n_threads < 1) die("parse_cmd_args", "number of threads cannot be less than 1!");
-  if (rnd_sample != 1 || call_geno) die("main", "oracle: --rnd_sample/--call_geno are outside the restated path");
+  if (rnd_sample != 1) die("main", "oracle: --rnd_sample is outside the restated path");
 
   struct stat st;
   if (stat(P.in_geno, &st) != 0) die("main", "cannot check GENO file size!");
   const char *dot = strrchr(P.in_geno, '.');
-  if (dot != NULL && strcmp(dot, ".gz") == 0) die("main", "oracle: only BINARY GL input is restated");
-  if (P.n_sites != (uint64_t)st.st_size / sizeof(double) / P.n_ind / ORC_N_GENO) /* ngsLD.cpp:55-56 */
-    die("main", "invalid/corrupt genotype input file!");
+  int in_bin = !(dot != NULL && strcmp(dot, ".gz") == 0); /* ngsLD.cpp:45-57 */
+  if (in_bin) {
+    in_probs = 1;
+    if (P.n_sites != (uint64_t)st.st_size / sizeof(double) / P.n_ind / ORC_N_GENO) /* ngsLD.cpp:55-56 */
+      die("main", "invalid/corrupt genotype input file!");
+  }
 
   FILE *fh = stdout;
   if (out != NULL) fh = fopen(out, "w");
@@ -112,8 +115,14 @@ int main(int argc, char **argv) {
   P.geno_lkl = (double *)malloc(P.n_sites * P.n_ind * 3 * sizeof(double));
   P.maf = (double *)malloc(P.n_sites * sizeof(double));
   P.expected_geno = (double *)malloc(P.n_sites * P.n_ind * sizeof(double));
-  if (orc_read_geno_bin(P.in_geno, P.in_logscale, P.n_ind, P.n_sites, P.geno_lkl, err, sizeof(err)))
+  if (in_bin ? orc_read_geno_bin(P.in_geno, P.in_logscale, P.n_ind, P.n_sites, P.geno_lkl, err, sizeof(err))
+             : orc_read_geno_text(P.in_geno, in_probs, P.in_logscale, P.n_ind, P.n_sites, P.geno_lkl, err, sizeof(err)))
     die("read_geno", err);
+  if (call_geno) { /* ngsLD.cpp:92-98 */
+    if (N_thresh > call_thresh)
+      die("call_geno", "missing data threshold must be smaller than calling genotype threshold!");
+    orc_call_geno_all(&P, N_thresh, call_thresh);
+  }
   orc_preprocess(&P);
   if (P.in_pos) {
     if (orc_read_pos(&P, err, sizeof(err))) die("read_dist", err);

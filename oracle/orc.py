@@ -75,6 +75,15 @@ def lib() -> C.CDLL:
         L.orc_read_geno_bin.restype = C.c_int
         L.orc_read_geno_bin.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_uint64, c_double_p, C.c_char_p,
                                         C.c_size_t]
+        L.orc_read_geno_text.restype = C.c_int
+        L.orc_read_geno_text.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, c_double_p, C.c_char_p,
+                                         C.c_size_t]
+        L.orc_call_geno.restype = None
+        L.orc_call_geno.argtypes = [c_double_p, C.c_double, C.c_double]
+        L.orc_call_geno_all.restype = None
+        L.orc_call_geno_all.argtypes = [C.POINTER(OrcParams), C.c_double, C.c_double]
+        L.orc_post_prob.restype = None
+        L.orc_post_prob.argtypes = [c_double_p, c_double_p, C.c_uint64]
         L.orc_preprocess.restype = None
         L.orc_preprocess.argtypes = [C.POINTER(OrcParams)]
         L.orc_read_pos.restype = C.c_int
@@ -111,6 +120,10 @@ def ref():
                                      C.c_double, C.c_uint64, C.c_int]
         R.ref_read_geno_bin.restype = C.c_int
         R.ref_read_geno_bin.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_uint64, c_double_p]
+        R.ref_read_geno_text.restype = C.c_int
+        R.ref_read_geno_text.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, c_double_p]
+        R.ref_call_geno.restype = None
+        R.ref_call_geno.argtypes = [c_double_p, C.c_double, C.c_double]
         R.ref_preprocess.restype = None
         R.ref_preprocess.argtypes = [c_double_p, C.c_uint64, C.c_uint64, C.c_int, c_double_p, c_double_p]
         R.ref_read_dist.restype = C.c_int
@@ -131,14 +144,23 @@ class Oracle:
 
     def __init__(self, raw_gl: np.ndarray, pos_dist: np.ndarray | None = None, log_scale: bool = False,
                  ignore_miss_data: bool = False, max_kb_dist: int = 0, max_snp_dist: int = 0, min_maf: float = 0.0,
-                 n_threads: int = 1):
+                 n_threads: int = 1, already_normalised_log: bool = False, call_geno: tuple | None = None):
+        """raw_gl: what the binary reader would read, or (already_normalised_log) the log-normalised output of
+        a reader.  call_geno = (N_thresh, call_thresh) applies ngsLD.cpp:92-98 before est_maf."""
         L = lib()
         raw_gl = np.ascontiguousarray(raw_gl, dtype=np.float64)
         self.n_sites, self.n_ind = raw_gl.shape[0], raw_gl.shape[1]
-        self.gl = np.empty_like(raw_gl)
-        rc = L.orc_normalise_raw(dp(raw_gl), int(log_scale), self.n_ind, self.n_sites, dp(self.gl))
-        if rc:
-            raise ValueError("NaN found! Is the file format correct?")
+        if already_normalised_log:
+            self.gl = raw_gl.copy()
+        else:
+            self.gl = np.empty_like(raw_gl)
+            rc = L.orc_normalise_raw(dp(raw_gl), int(log_scale), self.n_ind, self.n_sites, dp(self.gl))
+            if rc:
+                raise ValueError("NaN found! Is the file format correct?")
+        if call_geno is not None:
+            for k in range(self.n_sites):
+                for i in range(self.n_ind):
+                    L.orc_call_geno(dp(self.gl[k, i]), float(call_geno[0]), float(call_geno[1]))
         self.gl_log = self.gl.copy()
         self.maf = np.empty(self.n_sites)
         self.expg = np.empty((self.n_sites, self.n_ind))

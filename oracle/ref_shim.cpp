@@ -64,6 +64,24 @@ int ref_read_geno_bin(const char *path, int log_scale, uint64_t n_ind, uint64_t 
   return 0;
 }
 
+/* read_geno, text branch (in_bin = false), flattened like ref_read_geno_bin */
+int ref_read_geno_text(const char *path, int in_probs, int log_scale, uint64_t n_ind, uint64_t n_sites, double *out) {
+  bool ls = log_scale != 0;
+  double ***tmp = read_geno(const_cast<char *>(path), false, in_probs != 0, &ls, n_ind, n_sites);
+  double ***g = transp_matrix(tmp, n_ind, n_sites);
+  for (uint64_t s = 0; s < n_sites; s++)
+    for (uint64_t i = 0; i < n_ind; i++)
+      for (int k = 0; k < 3; k++) out[(s * n_ind + i) * 3 + k] = g[s][i][k];
+  free_ptr((void ***)tmp, n_ind, n_sites);
+  free_ptr((void **)g, n_sites);
+  return 0;
+}
+
+/* ngsLD.cpp:97: call_geno(geno, N_GENO, in_logscale = true, N_thresh, call_thresh, 0) on one triple */
+void ref_call_geno(double *geno, double N_thresh, double call_thresh) {
+  call_geno(geno, N_GENO, true, N_thresh, call_thresh, 0);
+}
+
 /* ngsLD.cpp:103-114 with the reference's est_maf / conv_space; in/out flat [site][ind][3] */
 void ref_preprocess(double *gl, uint64_t n_ind, uint64_t n_sites, int ignore_miss, double *maf, double *expg) {
   for (uint64_t s = 0; s < n_sites; s++) maf[s] = ref_est_maf(n_ind, gl + s * n_ind * 3, ignore_miss);

@@ -46,11 +46,29 @@ def pos_text(chrs, pos, extra_col=False, header=False) -> str:
     return "\n".join(lines) + "\n"
 
 
-def run_cli(raw, ptxt, flags, header=False):
+def geno_text(mat, header: bool, prefix_cols: bool) -> str:
+    """A beagle-like text genotype file: optional header, optional non-numeric leading columns."""
+    lines = []
+    if header:
+        lines.append("marker\tallele1\tallele2\t" + "\t".join(f"Ind{i}" for i in range(mat.shape[1])))
+    for s in range(mat.shape[0]):
+        pre = f"chr1_{s}\tA\tC\t" if prefix_cols else ""
+        lines.append(pre + "\t".join(str(int(x)) if np.isfinite(x) and float(x) == int(x) and abs(x) <= 9
+                                     else repr(float(x)) for x in mat[s].reshape(-1)))
+    return "\n".join(lines) + "\n"
+
+
+def run_cli(raw, ptxt, flags, header=False, gtext=None):
     """Oracle CLI -> TSV text (sorted the way the reference's test does, examples/test.sh:16)."""
+    import gzip
     with tempfile.TemporaryDirectory() as d:
-        g = os.path.join(d, "in.glf")
-        raw.tofile(g)
+        if gtext is None:
+            g = os.path.join(d, "in.glf")
+            raw.tofile(g)
+        else:
+            g = os.path.join(d, "in.geno.gz")
+            with gzip.open(g, "wt") as fh:
+                fh.write(gtext)
         cmd = [orc.ORC_CLI, "--geno", g, "--n_ind", str(raw.shape[1]), "--n_sites", str(raw.shape[0]), "--verbose", "0"]
         if ptxt is not None:
             p = os.path.join(d, "in.pos")
@@ -62,20 +80,41 @@ def run_cli(raw, ptxt, flags, header=False):
 
 
 def make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max_kb=0, max_snp=0, min_maf=0.0,
-         extra_col=False, header=False, with_text=True):
+         extra_col=False, header=False, with_text=True, text_mode=None, call=None, geno_header=True):
+    """text_mode: None (binary GL file) | "probs" (text GL triples) | "called" (text genotypes, raw = [sites, ind]
+    of {-1,0,1,2}); call = (N_thresh, call_thresh) adds --call_geno."""
+    import gzip
     R = orc.ref()
     assert R is not None, "oracle/_ref/libngsld_ref.so missing: run oracle/build_ref.sh (needs /root/reference)"
     raw = np.ascontiguousarray(raw, dtype=np.float64)
     n_sites, n_ind = raw.shape[:2]
+    gtext = None
+    if text_mode is not None:
+        gtext = geno_text(raw.reshape(n_sites, -1) if text_mode == "probs" else raw, geno_header, text_mode == "probs")
     ptxt = pos_text(chrs, pos, extra_col, header) if chrs is not None else None
     pd = shard.pos_dist_from_positions(chrs, pos) if chrs is not None else None
 
     # ---- reference: reader, maf, preprocessing ----
     with tempfile.TemporaryDirectory() as d:
-        g = os.path.join(d, "in.glf")
-        raw.tofile(g)
-        gl_log = np.empty_like(raw)
-        R.ref_read_geno_bin(g.encode(), int(log_scale), n_ind, n_sites, orc.dp(gl_log))
+        gl_log = np.empty((n_sites, n_ind, 3))
+        gl_orc = np.empty((n_sites, n_ind, 3))
+        if text_mode is None:
+            g = os.path.join(d, "in.glf")
+            raw.tofile(g)
+            R.ref_read_geno_bin(g.encode(), int(log_scale), n_ind, n_sites, orc.dp(gl_log))
+        else:
+            g = os.path.join(d, "in.geno.gz")
+            with gzip.open(g, "wt") as fh:
+                fh.write(gtext)
+            R.ref_read_geno_text(g.encode(), int(text_mode == "probs"), int(log_scale), n_ind, n_sites, orc.dp(gl_log))
+            err = C.create_string_buffer(256)
+            assert orc.lib().orc_read_geno_text(g.encode(), int(text_mode == "probs"), int(log_scale), n_ind, n_sites,
+                                                orc.dp(gl_orc), err, 256) == 0, err.value
+            assert np.array_equal(gl_orc, gl_log, equal_nan=True), "text reader: oracle != reference"
+        if call is not None:
+            for k in range(n_sites):
+                for i in range(n_ind):
+                    R.ref_call_geno(orc.dp(gl_log[k, i]), float(call[0]), float(call[1]))
         ref_pd, ref_labels = None, None
         if ptxt is not None:
             p = os.path.join(d, "in.pos")
@@ -92,8 +131,12 @@ def make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max
     R.ref_preprocess(orc.dp(gl), n_ind, n_sites, int(ignore_miss), orc.dp(maf), orc.dp(expg))
 
     # ---- oracle on the same input; must equal the reference wherever the reference can be built ----
-    o = orc.Oracle(raw, pd, log_scale=log_scale, ignore_miss_data=ignore_miss, max_kb_dist=max_kb,
-                   max_snp_dist=max_snp, min_maf=min_maf, n_threads=4)
+    if text_mode is None:
+        o = orc.Oracle(raw, pd, log_scale=log_scale, ignore_miss_data=ignore_miss, max_kb_dist=max_kb,
+                       max_snp_dist=max_snp, min_maf=min_maf, n_threads=4, call_geno=call)
+    else:
+        o = orc.Oracle(gl_orc, pd, ignore_miss_data=ignore_miss, max_kb_dist=max_kb, max_snp_dist=max_snp,
+                       min_maf=min_maf, n_threads=4, already_normalised_log=True, call_geno=call)
     assert np.array_equal(o.gl_log, gl_log, equal_nan=True), "reader: oracle != reference"
     assert np.array_equal(o.maf, maf, equal_nan=True) and np.array_equal(o.gl, gl) and np.array_equal(o.expg, expg)
     if ref_pd is not None:
@@ -112,7 +155,11 @@ def make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max
     assert np.array_equal(n_iter, rec["n_iter"]) and np.array_equal(n_data, rec["n_ind_data"])
 
     fx = dict(
-        raw=raw, pos_text=np.array(ptxt if ptxt is not None else ""), has_pos=np.array(ptxt is not None),
+        raw=raw, geno_text=np.array(gtext if gtext is not None else ""),
+        text_mode=np.array(text_mode if text_mode is not None else ""),
+        call_geno=np.array(list(call) if call is not None else [], dtype=np.float64),
+        ref_gl_log=gl_log if text_mode is not None else np.zeros(0),
+        pos_text=np.array(ptxt if ptxt is not None else ""), has_pos=np.array(ptxt is not None),
         header=np.array(header), log_scale=np.array(log_scale), ignore_miss=np.array(ignore_miss),
         max_kb=np.array(max_kb), max_snp=np.array(max_snp), min_maf=np.array(min_maf),
         ref_reader_sha=np.array(sha(gl_log)), ref_gl_sha=np.array(sha(gl)), ref_expg_sha=np.array(sha(expg)),
@@ -128,8 +175,12 @@ def make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max
             flags.append("--log_scale")
         if ignore_miss:
             flags.append("--ignore_miss_data")
+        if text_mode == "probs" or call is not None:   # --call_geno needs --probs even for binary input (parse_args.cpp:178)
+            flags.append("--probs")
+        if call is not None:
+            flags += ["--call_geno", "--N_thresh", repr(float(call[0])), "--call_thresh", repr(float(call[1]))]
         for tag, extra in (("std", []), ("ext", ["--extend_out"])):
-            txt = run_cli(raw, ptxt, flags + extra, header)
+            txt = run_cli(raw, ptxt, flags + extra, header, gtext)
             lines = txt.splitlines(keepends=True)
             body = "".join(sorted(lines[1:]))
             fx[f"orc_tsv_{tag}_header"] = np.array(lines[0])
@@ -177,6 +228,21 @@ def main():
     chrs, pos = synth.make_positions(100, 5)
     thr = float(np.round(np.quantile(orc.Oracle(raw).maf, 0.25), 3))
     make("f5_minmaf", raw, chrs, pos, min_maf=thr, max_kb=10)
+    # F8: text (.gz) inputs -- beagle-like GL triples with header + name columns, called genotypes, and
+    # --call_geno on a binary GL file
+    raw = synth.make_gl_numpy(40, 20, seed=81, depth=3.0)
+    raw /= raw.sum(axis=2, keepdims=True)
+    raw[5, 3] = [0.0, 0.0, 1.0]                             # exact zeros: log(0) stays -inf in the text branch
+    chrs, pos = synth.make_positions(40, 81)
+    make("f8_text_probs", raw, chrs, pos, text_mode="probs")
+    with np.errstate(divide="ignore"):
+        make("f8_text_probs_log", np.log(raw), chrs, pos, text_mode="probs", log_scale=True, geno_header=False)
+    called = np.random.default_rng(82).choice([-1, 0, 1, 2], size=(40, 20), p=[0.1, 0.45, 0.3, 0.15]).astype(float)
+    make("f8_text_called", called, chrs, pos, text_mode="called", ignore_miss=True)
+    raw = synth.make_gl_numpy(60, 30, seed=83, depth=4.0)
+    chrs, pos = synth.make_positions(60, 83)
+    make("f8_call_geno", raw, chrs, pos, call=(0.4, 0.9))
+    make("f8_call_geno_default", raw, chrs, pos, call=(0.0, 0.0), ignore_miss=True)
     # F6/F7: the benchmark n_ind values (slot / multi-wavefront paths of the kernel)
     for name, ns, ni, seed in (("f7_n100", 128, 100, 7), ("f6_n500", 48, 500, 6), ("f6_n1000", 24, 1000, 8),
                                ("f6_n2000", 12, 2000, 9)):

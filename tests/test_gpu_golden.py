@@ -19,10 +19,9 @@ def _want(fx):
 
 
 @pytest.mark.parametrize("name", fixtures())
-def test_hip_matches_golden(engine, name):
+def test_hip_matches_golden(engine, name, tmp_path):
     fx = Fixture(name)
-    engine.set_geno_raw(fx.raw, log_scale=fx.log_scale, ignore_miss_data=fx.ignore_miss)
-    engine.set_pos_dist(fx.pos_dist)
+    fx.engine_load(engine, str(tmp_path))
     assert np.all(close(engine.maf(), fx["ref_maf"], MAF_TOL)), "est_maf vs reference"
     n = engine.plan(fx.max_kb, fx.max_snp, fx.min_maf, fx.ignore_miss, True)
     assert n == len(fx["orc_s1"])

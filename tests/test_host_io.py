@@ -168,3 +168,46 @@ def test_write_batch_threads_reproduce_oracle_text(name, threads, tmp_path):
     L.ngsld_host_free_pos(h)
     assert rc == 0
     assert out.read_text().splitlines(keepends=True) == want
+
+
+@pytest.mark.parametrize("name", [n for n in fixtures() if Fixture(n).text_mode])
+def test_read_geno_text_matches_reference_reader(name, tmp_path):
+    """Product text reader -> raw values; pushed through the reference branch's arithmetic (plain log, post_prob)
+    they must reproduce the reference's own text reader output (ref_gl_log in the fixture), bit for bit."""
+    from oracle import orc
+    fx = Fixture(name)
+    g, _ = fx.write_inputs(str(tmp_path))
+    raw, is_log = capi.read_geno_text(g, fx.text_mode == "probs", fx.log_scale, fx.n_ind, fx.n_sites)
+    assert raw.shape == (fx.n_sites, fx.n_ind, 3)
+    assert is_log == (fx.log_scale if fx.text_mode == "probs" else True)
+    want = fx["ref_gl_log"].copy()
+    if fx.call_geno is None:
+        got = raw.copy()
+        for t in got.reshape(-1, 3):
+            if not is_log:
+                with np.errstate(divide="ignore"):
+                    t[:] = np.log(t)
+            orc.lib().orc_post_prob(orc.dp(t), orc.dp(t.copy()), 3)
+        assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_read_geno_text_errors(tmp_path):
+    p = tmp_path / "bad.geno.gz"
+    with gzip.open(p, "wt") as fh:
+        fh.write("id\ta\tb\n" + "s1\t0.1\t0.2\t0.7\t0.3\t0.3\t0.4\n" + "s2\t0.1\t0.2\n")
+    with pytest.raises(capi.NgsldError) as e:
+        capi.read_geno_text(str(p), True, False, 2, 2)
+    assert "Less fields than expected" in e.value.msg
+    with pytest.raises(capi.NgsldError) as e:
+        capi.read_geno_text(str(p), True, False, 2, 3)
+    assert "Less fields than expected" in e.value.msg or "premature EOF" in e.value.msg
+    with gzip.open(p, "wt") as fh:
+        fh.write("0\t1\t3\n")
+    with pytest.raises(capi.NgsldError) as e:
+        capi.read_geno_text(str(p), False, False, 3, 1)
+    assert "Genotypes must be coded as {-1,0,1,2}" in e.value.msg
+    with gzip.open(p, "wt") as fh:
+        fh.write("0\t1\t2\n1\t1\t1\n")
+    with pytest.raises(capi.NgsldError) as e:
+        capi.read_geno_text(str(p), False, False, 3, 1)
+    assert "not at EOF" in e.value.msg

@@ -19,9 +19,8 @@ def _sha(a):
 @pytest.mark.parametrize("name", fixtures())
 def test_oracle_reproduces_golden(name):
     fx = Fixture(name)
-    o = orc.Oracle(fx.raw, fx.pos_dist, log_scale=fx.log_scale, ignore_miss_data=fx.ignore_miss,
-                   max_kb_dist=fx.max_kb, max_snp_dist=fx.max_snp, min_maf=fx.min_maf, n_threads=2)
-    # reference-pinned stages: reader, maf, preprocessing (bit for bit)
+    o = fx.oracle()
+    # reference-pinned stages: reader (+ call_geno), maf, preprocessing (bit for bit)
     assert _sha(o.gl_log) == str(fx["ref_reader_sha"])
     assert _sha(o.gl) == str(fx["ref_gl_sha"]) and _sha(o.expg) == str(fx["ref_expg_sha"])
     assert np.array_equal(o.maf, fx["ref_maf"], equal_nan=True)

@@ -29,8 +29,45 @@ class Fixture:
         self.log_scale = bool(z["log_scale"])
         self.ignore_miss = bool(z["ignore_miss"])
         self.max_kb, self.max_snp, self.min_maf = int(z["max_kb"]), int(z["max_snp"]), float(z["min_maf"])
+        self.text_mode = str(z["text_mode"]) if "text_mode" in z.files and str(z["text_mode"]) else None
+        self.geno_text = str(z["geno_text"]) if self.text_mode else None
+        cg = z["call_geno"] if "call_geno" in z.files else np.zeros(0)
+        self.call_geno = (float(cg[0]), float(cg[1])) if len(cg) == 2 else None
+        if self.text_mode == "called":
+            self.n_sites, self.n_ind = self.raw.shape
         self.pos_dist = z["ref_pos_dist"] if self.has_pos else None
         self.labels = [str(x) for x in z["ref_labels"]] if self.has_pos else None
+
+    def oracle(self, n_threads: int = 2):
+        """The oracle on this fixture's input, through the same reader the fixture's mode uses."""
+        import ctypes as C
+        import tempfile
+        from oracle import orc
+        kw = dict(ignore_miss_data=self.ignore_miss, max_kb_dist=self.max_kb, max_snp_dist=self.max_snp,
+                  min_maf=self.min_maf, n_threads=n_threads, call_geno=self.call_geno)
+        if not self.text_mode:
+            return orc.Oracle(self.raw, self.pos_dist, log_scale=self.log_scale, **kw)
+        with tempfile.TemporaryDirectory() as d:
+            g, _ = self.write_inputs(d)
+            gl = np.empty((self.n_sites, self.n_ind, 3))
+            err = C.create_string_buffer(256)
+            rc = orc.lib().orc_read_geno_text(g.encode(), int(self.text_mode == "probs"), int(self.log_scale), self.n_ind,
+                                              self.n_sites, orc.dp(gl), err, 256)
+            assert rc == 0, err.value
+        return orc.Oracle(gl, self.pos_dist, already_normalised_log=True, **kw)
+
+    def engine_load(self, engine, tmp_dir: str):
+        """Feed this fixture to the HIP engine the way the CLI would (binary raw, or text reader + text semantics)."""
+        from ngsld_amd import capi
+        if not self.text_mode:
+            engine.set_geno_raw(self.raw, log_scale=self.log_scale, ignore_miss_data=self.ignore_miss,
+                                call_geno=self.call_geno)
+        else:
+            g, _ = self.write_inputs(tmp_dir)
+            raw, is_log = capi.read_geno_text(g, self.text_mode == "probs", self.log_scale, self.n_ind, self.n_sites)
+            engine.set_geno_raw(raw, log_scale=is_log, ignore_miss_data=self.ignore_miss, text=True,
+                                call_geno=self.call_geno)
+        engine.set_pos_dist(self.pos_dist)
 
     def __getitem__(self, k):
         return self.z[k]
@@ -39,8 +76,14 @@ class Fixture:
         return k in self.z.files
 
     def write_inputs(self, d: str) -> tuple[str, str | None]:
-        g = os.path.join(d, self.name + ".glf")
-        self.raw.tofile(g)
+        if self.text_mode:
+            import gzip
+            g = os.path.join(d, self.name + ".geno.gz")
+            with gzip.open(g, "wt") as fh:
+                fh.write(self.geno_text)
+        else:
+            g = os.path.join(d, self.name + ".glf")
+            self.raw.tofile(g)
         p = None
         if self.has_pos:
             p = os.path.join(d, self.name + ".pos")
@@ -54,6 +97,10 @@ class Fixture:
             f.append("--log_scale")
         if self.ignore_miss:
             f.append("--ignore_miss_data")
+        if self.text_mode == "probs" or self.call_geno:
+            f.append("--probs")
+        if self.call_geno:
+            f += ["--call_geno", "--N_thresh", repr(self.call_geno[0]), "--call_thresh", repr(self.call_geno[1])]
         if extend:
             f.append("--extend_out")
         return f
