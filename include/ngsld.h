@@ -51,6 +51,8 @@ typedef struct {
   double min_maf;            /* ngsLD.cpp:264-275: s1 below -> row empty, s2 below -> pair skipped */
   int32_t ignore_miss_data;  /* gen_func.cpp:1089 */
   int32_t extend_out;        /* also produce ngsld_rec_ext */
+  double rnd_sample;         /* ngsLD.cpp:277: keep a pair iff its Tausworthe draw <= rnd_sample; 0 or 1 = keep all */
+  uint64_t seed;             /* --seed of the master gsl_rng_taus stream (ngsLD.cpp:69-70); used iff rnd_sample < 1 */
 } ngsld_params;
 
 /* Standard columns computed per pair (ngsLD.cpp:290-306): 32 bytes. */
@@ -68,16 +70,23 @@ typedef struct {
   uint32_t n_iter;     /* return value of haplo_freq */
 } ngsld_rec_ext;
 
-/* One batch of results: all pairs of rows [s1_begin, s1_end), in (s1, s2) order.
- * Row s1 owns records [row_off[s1 - s1_begin], row_off[s1 - s1_begin + 1]); its pairs are the sites
- * s2 in (s1, row_end[s1 - s1_begin]) with keep[s2] != 0, in increasing s2.  Pointers are valid only
+/* One unit of the pair space: the pairs (s1, s2_begin + c) for the bits c set in `mask` (c < count <= 64), i.e.
+ * the candidates of row s1 that survived the maf[s2] skip (ngsLD.cpp:270) and the random sub-sampling
+ * (ngsLD.cpp:277).  Their records are consecutive, starting at `first_record`, in increasing c. */
+typedef struct {
+  uint32_t s1, s2_begin, count, reserved;
+  uint64_t mask;
+  uint64_t first_record;
+} ngsld_item;
+
+/* One batch of results: all pairs of rows [s1_begin, s1_end), in (s1, s2) order.  `items` lists them row by row
+ * (increasing s1, then increasing s2_begin), first_record relative to this batch.  Pointers are valid only
  * during the callback. */
 typedef struct {
   uint64_t s1_begin, s1_end;
   uint64_t n_pairs;
-  const uint64_t *row_off;   /* [s1_end - s1_begin + 1], batch-relative */
-  const uint32_t *row_end;   /* [s1_end - s1_begin], exclusive end of the walk of each row */
-  const uint8_t *keep;       /* [n_sites], global: 0 where maf[s] < min_maf */
+  uint64_t n_items;
+  const ngsld_item *items;   /* [n_items] */
   const ngsld_rec_std *std;  /* [n_pairs] */
   const ngsld_rec_ext *ext;  /* [n_pairs] or NULL when extend_out == 0 */
 } ngsld_batch;

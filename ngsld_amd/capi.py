@@ -21,7 +21,8 @@ OK, ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_NAN, ERR_MAF_RANGE, ERR_SINK, ERR_UN
 
 class Params(C.Structure):
     _fields_ = [("max_kb_dist", C.c_uint64), ("max_snp_dist", C.c_uint64), ("min_maf", C.c_double),
-                ("ignore_miss_data", C.c_int32), ("extend_out", C.c_int32)]
+                ("ignore_miss_data", C.c_int32), ("extend_out", C.c_int32), ("rnd_sample", C.c_double),
+                ("seed", C.c_uint64)]
 
 
 class GenoOpts(C.Structure):
@@ -34,10 +35,40 @@ REC_STD = np.dtype([("r2_ExpG", "<f8"), ("D", "<f8"), ("Dp", "<f8"), ("r2", "<f8
 REC_EXT = np.dtype([("hap", "<f8", (4,)), ("n_ind_data", "<u4"), ("n_iter", "<u4")])
 
 
+ITEM = np.dtype([("s1", "<u4"), ("s2_begin", "<u4"), ("count", "<u4"), ("reserved", "<u4"), ("mask", "<u8"),
+                 ("first_record", "<u8")])
+
+
 class Batch(C.Structure):
-    _fields_ = [("s1_begin", C.c_uint64), ("s1_end", C.c_uint64), ("n_pairs", C.c_uint64),
-                ("row_off", C.POINTER(C.c_uint64)), ("row_end", C.POINTER(C.c_uint32)),
-                ("keep", C.POINTER(C.c_uint8)), ("std", C.c_void_p), ("ext", C.c_void_p)]
+    _fields_ = [("s1_begin", C.c_uint64), ("s1_end", C.c_uint64), ("n_pairs", C.c_uint64), ("n_items", C.c_uint64),
+                ("items", C.c_void_p), ("std", C.c_void_p), ("ext", C.c_void_p)]
+
+
+def items_to_pairs(items: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """(s1, s2) of every record described by an item array, in record order."""
+    if len(items) == 0:
+        return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64)
+    bits = (items["mask"][:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)
+    bits &= (np.arange(64)[None, :] < items["count"][:, None]).astype(np.uint64)
+    idx, c = np.nonzero(bits)
+    return items["s1"][idx].astype(np.uint64), (items["s2_begin"][idx].astype(np.uint64) + c.astype(np.uint64))
+
+
+def items_from_pairs(s1: np.ndarray, s2: np.ndarray, span: int = 64) -> np.ndarray:
+    """Build an item array for a list of pairs sorted by (s1, s2): chunks of `span` candidates from s1 + 1."""
+    s1, s2 = np.asarray(s1, dtype=np.int64), np.asarray(s2, dtype=np.int64)
+    chunk = (s2 - s1 - 1) // span
+    key = s1 * (1 << 32) + chunk
+    uniq, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    items = np.zeros(len(uniq), dtype=ITEM)
+    items["s1"] = s1[first]
+    items["s2_begin"] = s1[first] + 1 + chunk[first] * span
+    items["first_record"] = first
+    np.bitwise_or.at(items["mask"], inv, np.uint64(1) << (s2 - items["s2_begin"][inv]).astype(np.uint64))
+    last = np.zeros(len(uniq), dtype=np.int64)
+    np.maximum.at(last, inv, s2 - items["s2_begin"][inv].astype(np.int64))
+    items["count"] = last + 1
+    return items
 
 
 SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Batch))
@@ -256,8 +287,8 @@ class Engine:
         self._check(self._L.ngsld_set_tuning(self._h, pairs_per_item, batch_pairs))
 
     def plan(self, max_kb_dist: int = 0, max_snp_dist: int = 0, min_maf: float = 0.0, ignore_miss_data: bool = False,
-             extend_out: bool = True) -> int:
-        p = Params(max_kb_dist, max_snp_dist, min_maf, int(ignore_miss_data), int(extend_out))
+             extend_out: bool = True, rnd_sample: float = 1.0, seed: int = 0) -> int:
+        p = Params(max_kb_dist, max_snp_dist, min_maf, int(ignore_miss_data), int(extend_out), rnd_sample, seed)
         n = C.c_uint64()
         self._check(self._L.ngsld_plan(self._h, C.byref(p), C.byref(n)))
         self.extend_out = extend_out
@@ -276,21 +307,20 @@ class Engine:
 
         def sink(_user, bp):
             b = bp.contents
-            n, rows = b.n_pairs, b.s1_end - b.s1_begin
+            n = b.n_pairs
             if n:
                 stds.append(np.frombuffer(C.string_at(b.std, n * REC_STD.itemsize), dtype=REC_STD).copy())
                 if b.ext:
                     exts.append(np.frombuffer(C.string_at(b.ext, n * REC_EXT.itemsize), dtype=REC_EXT).copy())
-            keep = np.ctypeslib.as_array(b.keep, shape=(self.n_sites,))
-            row_end = np.ctypeslib.as_array(b.row_end, shape=(rows,))
-            row_off = np.ctypeslib.as_array(b.row_off, shape=(rows + 1,))
-            for r in range(rows):
-                s1 = b.s1_begin + r
-                s2 = np.arange(s1 + 1, max(int(row_end[r]), s1 + 1))
-                s2 = s2[keep[s2] != 0]
-                assert len(s2) == row_off[r + 1] - row_off[r]
-                s1s.append(np.full(len(s2), s1, dtype=np.uint64))
-                s2s.append(s2.astype(np.uint64))
+            items = np.frombuffer(C.string_at(b.items, b.n_items * ITEM.itemsize), dtype=ITEM) if b.n_items else \
+                np.zeros(0, dtype=ITEM)
+            a, bb = items_to_pairs(items)
+            assert len(a) == n
+            if len(items):
+                assert np.array_equal(items["first_record"], np.concatenate([[0], np.cumsum(
+                    [bin(int(m)).count("1") for m in items["mask"]])[:-1]]).astype(np.uint64))
+            s1s.append(a)
+            s2s.append(bb)
             return 0
 
         cb = SINK_FN(sink)

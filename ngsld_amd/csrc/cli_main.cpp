@@ -5,7 +5,6 @@
 // Differences a user can see (all listed in DESIGN.md):
 //   * rows are written in (site1, site2) order (the reference's order is arbitrary for --n_threads > 1);
 //   * --n_threads sets the number of host threads that format the TSV; --device N (new) picks the GPU;
-//   * --rnd_sample < 1 is not part of the accelerated path yet and ends with an error instead of being ignored.
 #include <getopt.h>
 #include <sys/stat.h>
 
@@ -171,8 +170,6 @@ int main(int argc, char **argv) {
     if (!ngsld_host_geno_size_ok((uint64_t)st.st_size, pars.n_ind, pars.n_sites))
       error(__FUNCTION__, "invalid/corrupt genotype input file!");
   }
-  if (pars.rnd_sample != 1) error(__FUNCTION__, "--rnd_sample < 1 is not part of the MI355X path yet");
-
   // ---- prepare output (ngsLD.cpp:73-77): the header is always written ----
   if (pars.out != NULL) pars.out_fh = fopen(pars.out, "w");
   if (pars.out_fh == NULL) error(__FUNCTION__, "cannot open output file!");
@@ -237,6 +234,8 @@ int main(int argc, char **argv) {
   lp.min_maf = pars.min_maf;
   lp.ignore_miss_data = pars.ignore_miss_data ? 1 : 0;
   lp.extend_out = pars.extend_out ? 1 : 0;
+  lp.rnd_sample = pars.rnd_sample;
+  lp.seed = pars.seed;
   uint64_t n_pairs = 0;
   if (ngsld_plan(ctx, &lp, &n_pairs) != NGSLD_OK) error("ngsld_plan", ngsld_last_error(ctx));
   if (pars.verbose >= 1) fprintf(stderr, "==> Waiting for all threads to finish...\n");

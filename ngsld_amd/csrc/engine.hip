@@ -79,10 +79,11 @@ struct ngsld_ctx {
   bool planned = false;
   ngsld_params params{};
   std::vector<uint64_t> h_row_off, h_item_off;
-  std::vector<uint32_t> h_row_end, h_cumkeep;
+  std::vector<uint32_t> h_row_end;
   std::vector<uint8_t> h_keep;
-  DevBuf<uint64_t> d_row_off, d_item_off;
-  DevBuf<uint32_t> d_row_end, d_cumkeep;
+  std::vector<Item> h_items;  // host copy for the sink (which pairs each record belongs to)
+  DevBuf<uint64_t> d_row_off, d_item_off, d_row_seed, d_row_count;
+  DevBuf<uint32_t> d_row_end;
   DevBuf<uint8_t> d_keep;
   DevBuf<Item> d_items;
   uint64_t n_items = 0;
@@ -282,9 +283,6 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
   a.maf = c->d_maf.p;
   a.mean_e = c->d_mean.p;
   a.rsx = c->d_sxx.p;
-  a.keep = c->d_keep.p;
-  a.cumkeep = c->d_cumkeep.p;
-  a.row_off = c->d_row_off.p;
   a.items = c->d_items.p + c->h_item_off[r0];
   a.n_items = c->h_item_off[r1] - c->h_item_off[r0];
   a.out_base = c->h_row_off[r0];
@@ -355,7 +353,7 @@ void ngsld_destroy(ngsld_ctx *c) {
   (void)hipDeviceSynchronize();
   c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_sxx.release(); c->d_stage.release();
   c->d_status.release(); c->d_row_off.release(); c->d_item_off.release(); c->d_row_end.release();
-  c->d_cumkeep.release(); c->d_keep.release(); c->d_items.release();
+  c->d_row_seed.release(); c->d_row_count.release(); c->d_keep.release(); c->d_items.release();
   for (int k = 0; k < 2; ++k) {
     c->d_std[k].release(); c->d_ext[k].release(); c->h_std[k].release(); c->h_ext[k].release();
     if (c->ev_kernel_done[k]) (void)hipEventDestroy(c->ev_kernel_done[k]);
@@ -426,39 +424,80 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) {
   const uint64_t n = c->n_sites;
   c->params = *p;
   c->planned = false;
+  if (!(p->rnd_sample >= 0 && p->rnd_sample <= 1))  // parse_args.cpp:180-181 (0 is taken as "off" here)
+    return fail(c, NGSLD_ERR_INVALID, "proportion of comparisons to sample must be in ]0,1]!");
+  const bool sampling = p->rnd_sample > 0 && p->rnd_sample < 1;
   plan_rows(c->h_pos_dist, c->h_maf, *p, n, c->h_row_end);
   c->h_keep.resize(n);
-  c->h_cumkeep.resize(n + 1);
-  c->h_cumkeep[0] = 0;
-  for (uint64_t s = 0; s < n; ++s) {
-    c->h_keep[s] = (c->h_maf[s] < p->min_maf) ? 0 : 1;  // ngsLD.cpp:270
-    c->h_cumkeep[s + 1] = c->h_cumkeep[s] + c->h_keep[s];
-  }
-  c->h_row_off.resize(n + 1);
-  c->h_item_off.resize(n + 1);
-  c->h_row_off[0] = 0;
-  c->h_item_off[0] = 0;
+  for (uint64_t s = 0; s < n; ++s) c->h_keep[s] = (c->h_maf[s] < p->min_maf) ? 0 : 1;  // ngsLD.cpp:270
   const uint64_t ch = item_span(c->waves, c->prefetch, c->pairs_per_item);
+  c->h_item_off.resize(n + 1);
+  c->h_item_off[0] = 0;
   for (uint64_t s1 = 0; s1 < n; ++s1) {
     const uint64_t end = c->h_row_end[s1];
     const uint64_t span = end > s1 + 1 ? end - (s1 + 1) : 0;
-    const uint64_t pairs = span ? c->h_cumkeep[end] - c->h_cumkeep[s1 + 1] : 0;
-    c->h_row_off[s1 + 1] = c->h_row_off[s1] + pairs;
     c->h_item_off[s1 + 1] = c->h_item_off[s1] + (span + ch - 1) / ch;
   }
   c->n_items = c->h_item_off[n];
   HIP_TRY(c, c->d_row_end.resize(n));
   HIP_TRY(c, c->d_keep.resize(n));
-  HIP_TRY(c, c->d_cumkeep.resize(n + 1));
   HIP_TRY(c, c->d_row_off.resize(n + 1));
   HIP_TRY(c, c->d_item_off.resize(n + 1));
+  HIP_TRY(c, c->d_row_count.resize(n));
   HIP_TRY(c, c->d_items.resize(c->n_items ? c->n_items : 1));
   HIP_TRY(c, hipMemcpyAsync(c->d_row_end.p, c->h_row_end.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_keep.p, c->h_keep.data(), n, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->d_cumkeep.p, c->h_cumkeep.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->d_row_off.p, c->h_row_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_item_off.p, c->h_item_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, launch_build_items(c->d_row_end.p, c->d_item_off.p, (uint32_t)n, (uint32_t)ch, c->d_items.p, c->stream));
+  std::vector<uint64_t> seeds;
+  if (sampling) {
+    // ngsLD.cpp:69-70,165-166: one master gsl_rng_taus stream, row s1's seed = (unsigned long)(uniform * 1e15),
+    // drawn for s1 = 0, 1, 2, ... (serial by construction; n_sites draws)
+    seeds.resize(n);
+    struct {
+      uint32_t s1, s2, s3;
+      uint32_t get() {
+        s1 = ((s1 & 4294967294u) << 12) ^ (((s1 << 13) ^ s1) >> 19);
+        s2 = ((s2 & 4294967288u) << 4) ^ (((s2 << 2) ^ s2) >> 25);
+        s3 = ((s3 & 4294967280u) << 17) ^ (((s3 << 3) ^ s3) >> 11);
+        return s1 ^ s2 ^ s3;
+      }
+    } m;
+    uint64_t sd = p->seed ? p->seed : 1;
+    m.s1 = (uint32_t)(69069ull * sd);
+    m.s2 = 69069u * m.s1;
+    m.s3 = 69069u * m.s2;
+    for (int k = 0; k < 6; ++k) m.get();
+    for (uint64_t s = 0; s < n; ++s) seeds[s] = (uint64_t)(0 + (m.get() / 4294967296.0) * (double)1000000000000000ull);
+    HIP_TRY(c, c->d_row_seed.resize(n));
+    HIP_TRY(c, hipMemcpyAsync(c->d_row_seed.p, seeds.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  }
+  ItemArgs ia{};
+  ia.row_end = c->d_row_end.p;
+  ia.keep = c->d_keep.p;
+  ia.row_seed = sampling ? c->d_row_seed.p : nullptr;
+  ia.row_off = c->d_row_off.p;
+  ia.item_off = c->d_item_off.p;
+  ia.row_count = c->d_row_count.p;
+  ia.items = c->d_items.p;
+  ia.n_sites = (uint32_t)n;
+  ia.span = (uint32_t)ch;
+  ia.rnd_sample = p->rnd_sample;
+  // pass 1: pairs per row (the sub-sampling makes this data dependent), prefix sum on the host
+  ia.count_only = 1;
+  HIP_TRY(c, launch_items(ia, c->stream));
+  std::vector<uint64_t> counts(n);
+  HIP_TRY(c, hipMemcpyAsync(counts.data(), c->d_row_count.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->h_row_off.resize(n + 1);
+  c->h_row_off[0] = 0;
+  for (uint64_t s1 = 0; s1 < n; ++s1) c->h_row_off[s1 + 1] = c->h_row_off[s1] + counts[s1];
+  HIP_TRY(c, hipMemcpyAsync(c->d_row_off.p, c->h_row_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  // pass 2: the items (same draws again), and a host copy for the sink
+  ia.count_only = 0;
+  HIP_TRY(c, launch_items(ia, c->stream));
+  c->h_items.resize(c->n_items);
+  if (c->n_items)
+    HIP_TRY(c, hipMemcpyAsync(c->h_items.data(), c->d_items.p, c->n_items * sizeof(Item), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->planned = true;
   if (n_pairs) *n_pairs = c->h_row_off[n];
@@ -531,7 +570,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       HIP_TRY(c, c->h_ext[k].resize(cap));
     }
   }
-  std::vector<uint64_t> rel_off;
+  std::vector<Item> rel_items;
   auto issue = [&](size_t bi) -> int {  // kernel on `stream`, D2H on `copy_stream`
     const int k = (int)(bi & 1);
     const Batch &b = batches[bi];
@@ -560,15 +599,15 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     }
     HIP_TRY(c, hipEventSynchronize(c->ev_copy_done[k]));
     const Batch &b = batches[bi];
-    rel_off.resize(b.r1 - b.r0 + 1);
-    for (uint64_t r = b.r0; r <= b.r1; ++r) rel_off[r - b.r0] = c->h_row_off[r] - c->h_row_off[b.r0];
+    const uint64_t i0 = c->h_item_off[b.r0], i1 = c->h_item_off[b.r1];
+    rel_items.assign(c->h_items.begin() + (ptrdiff_t)i0, c->h_items.begin() + (ptrdiff_t)i1);
+    for (auto &it : rel_items) it.first_record -= c->h_row_off[b.r0];
     ngsld_batch out{};
     out.s1_begin = b.r0;
     out.s1_end = b.r1;
     out.n_pairs = b.n;
-    out.row_off = rel_off.data();
-    out.row_end = c->h_row_end.data() + b.r0;
-    out.keep = c->h_keep.data();
+    out.n_items = i1 - i0;
+    out.items = rel_items.data();
     out.std = c->h_std[k].p;
     out.ext = ext ? c->h_ext[k].p : nullptr;
     if (sink(user, &out) != 0) rc = fail(c, NGSLD_ERR_SINK, "sink callback failed");

@@ -369,37 +369,53 @@ size_t ngsld_host_format_double(char *buf, size_t cap, double v, int decimals) {
 int ngsld_host_write_batch(const ngsld_batch *b, const ngsld_pos *pos, const double *pos_dist, const double *maf,
                            int n_threads, int fd) {
   if (b == nullptr || maf == nullptr) return NGSLD_ERR_INVALID;
-  const uint64_t rows = b->s1_end - b->s1_begin;
-  if (rows == 0 || b->n_pairs == 0) return NGSLD_OK;
+  if (b->n_items == 0 || b->n_pairs == 0) return NGSLD_OK;
   if (n_threads < 1) n_threads = 1;
-  if ((uint64_t)n_threads > rows) n_threads = (int)rows;
+  if ((uint64_t)n_threads > b->n_items) n_threads = (int)b->n_items;
   size_t max_label = 6;  // "(null)"
   if (pos)
     for (const auto &l : pos->labels) max_label = std::max(max_label, l.size());
   const size_t row_bytes = 2 * max_label + 1024;
-  // contiguous row ranges with equal pair counts; every thread formats into its own buffer
-  std::vector<uint64_t> cut(n_threads + 1, rows);
+  // contiguous item ranges with equal pair counts; every thread formats into its own buffer
+  std::vector<uint64_t> cut(n_threads + 1, b->n_items);
   cut[0] = 0;
   for (int t = 1; t < n_threads; ++t) {
     const uint64_t target = b->n_pairs * (uint64_t)t / (uint64_t)n_threads;
-    cut[t] = (uint64_t)(std::lower_bound(b->row_off, b->row_off + rows, target) - b->row_off);
-    if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    uint64_t lo = cut[t - 1], hi = b->n_items;
+    while (lo < hi) {  // first item whose first_record >= target
+      const uint64_t mid = (lo + hi) / 2;
+      if (b->items[mid].first_record < target) lo = mid + 1; else hi = mid;
+    }
+    cut[t] = lo;
   }
   std::vector<std::vector<char>> out(n_threads);
   auto work = [&](int t) {
-    const uint64_t r0 = cut[t], r1 = cut[t + 1];
-    const uint64_t np = b->row_off[r1] - b->row_off[r0];
+    const uint64_t i0 = cut[t], i1 = cut[t + 1];
+    if (i0 >= i1) return;
+    const uint64_t rec_end = i1 < b->n_items ? b->items[i1].first_record : b->n_pairs;
+    const uint64_t np = rec_end - b->items[i0].first_record;
     std::vector<char> &buf = out[t];
-    buf.resize(np * (b->ext ? 200 : 96) + np * 2 * max_label / 1 + row_bytes);
+    buf.resize(np * (b->ext ? 200 : 96) + np * 2 * max_label + row_bytes);
     char *p = buf.data();
-    for (uint64_t r = r0; r < r1; ++r) {
-      const uint64_t s1 = b->s1_begin + r;
-      uint64_t k = b->row_off[r];
+    uint64_t cur_s1 = UINT64_MAX, cur_s2 = 0;
+    double dist = 0;
+    for (uint64_t i = i0; i < i1; ++i) {
+      const ngsld_item &it = b->items[i];
+      const uint64_t s1 = it.s1;
+      if (s1 != cur_s1) {  // a new row: the reference's running sum starts over (ngsLD.cpp:233,241)
+        cur_s1 = s1;
+        cur_s2 = s1;
+        dist = 0;
+      }
       const char *l1 = pos ? pos->labels[s1].c_str() : nullptr;
-      double dist = 0;
-      for (uint64_t s2 = s1 + 1; s2 < b->row_end[r]; ++s2) {
-        dist += pos_dist ? pos_dist[s2] : INFINITY;  // the reference's running sum (ngsLD.cpp:241)
-        if (!b->keep[s2]) continue;
+      uint64_t k = it.first_record;
+      for (uint32_t cc = 0; cc < it.count; ++cc) {
+        const uint64_t s2 = (uint64_t)it.s2_begin + cc;
+        while (cur_s2 < s2) {  // dist accumulates over every site passed, kept or not
+          ++cur_s2;
+          dist += pos_dist ? pos_dist[cur_s2] : INFINITY;
+        }
+        if (!((it.mask >> cc) & 1ull)) continue;
         if ((size_t)(buf.data() + buf.size() - p) < row_bytes) {  // extreme values printed long: grow
           const size_t used = (size_t)(p - buf.data());
           buf.resize(buf.size() * 2 + row_bytes);

@@ -24,10 +24,8 @@ namespace ngsld {
 constexpr int kIterMax = 100;      // ITER_MAX, gen_func.hpp:18
 constexpr double kEpsilon = 1e-5;  // EPSILON,  gen_func.hpp:16
 
-// One unit of work: pairs (s1, s2) for s2 in [s2_begin, s2_begin + count).
-struct Item {
-  uint32_t s1, s2_begin, count, pad;
-};
+// One unit of work = ngsld_item: pairs (s1, s2_begin + c) for the bits c set in mask, records from first_record.
+typedef ngsld_item Item;
 
 struct PairArgs {
   const double *planes;  // [n_sites][3][np] normal-space normalised GLs, zero padded to np
@@ -37,12 +35,9 @@ struct PairArgs {
   const double *maf;     // [n_sites] est_maf
   const double *mean_e;  // [n_sites] mean expected genotype
   const double *rsx;     // [n_sites] 1 / sqrt(sum (e - mean)^2)  (inf for a constant site)
-  const uint8_t *keep;   // [n_sites] 0 where maf < min_maf
-  const uint32_t *cumkeep;  // [n_sites + 1] prefix count of keep
-  const uint64_t *row_off;  // [n_sites + 1] pairs before row s1
   const Item *items;
   uint64_t n_items;
-  uint64_t out_base;  // row_off of the first row of this launch
+  uint64_t out_base;  // global index of record 0 of the output buffers
   ngsld_rec_std *out_std;
   ngsld_rec_ext *out_ext;  // may be null
   int *status;             // set to NGSLD_ERR_MAF_RANGE when haplo_freq would error()
@@ -303,13 +298,13 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
   const double m1 = A.maf[s1];
   const double mean1 = A.mean_e[s1];
   const double rsx1 = A.rsx[s1];
-  const uint64_t row_base = A.row_off[s1] - A.out_base;
-  const uint32_t ck1 = A.cumkeep[s1 + 1];
+  const uint64_t rec0 = it.first_record - A.out_base;
   const double *pa = A.planes + (uint64_t)s1 * A.site_stride;
   const uint32_t i0 = (uint32_t)sub * (SLOTS * 64) + (uint32_t)lane;
 
-  for (uint32_t s2 = it.s2_begin; s2 < it.s2_begin + it.count; ++s2) {
-    if (!A.keep[s2]) continue;  // ngsLD.cpp:270-275
+  for (uint32_t c = 0; c < it.count; ++c) {
+    if (!((it.mask >> c) & 1ull)) continue;  // ngsLD.cpp:270-282: maf[s2] skip, random sub-sampling
+    const uint32_t s2 = it.s2_begin + c;
     double P[SLOTS][9];
     uint32_t vbits;
     double sxy;
@@ -336,7 +331,8 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
     const uint32_t n_iter =
         em_pair<SLOTS, WAVES, kCheckAll>(P, vbits, x, m1, A.maf[s2], f0, f1, f2, f3, xch, sub, lane, A.status);
     if (lane == 0 && sub == 0)
-      write_pair(A, row_base + (uint64_t)(A.cumkeep[s2] - ck1), f0, f1, f2, f3, sxy, rsx1, A.rsx[s2], x, n_iter);
+      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, A.rsx[s2], x,
+                 n_iter);
   }
 }
 
@@ -381,20 +377,19 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
   const double m1 = A.maf[s1];
   const double mean1 = A.mean_e[s1];
   const double rsx1 = A.rsx[s1];
-  const uint64_t row_base = A.row_off[s1] - A.out_base;
-  const uint32_t ck1 = A.cumkeep[s1 + 1];
+  const uint64_t rec0 = it.first_record - A.out_base;
   char *lds_a = smem;
   char *lds_b = smem + kSiteBytes * (1 + wave);
   uint32_t *claim = reinterpret_cast<uint32_t *>(smem + kSiteBytes * 5);
 
   // next unclaimed offset inside the item; offsets 0..3 are pre-assigned to the four wavefronts
   if (threadIdx.x == 0) *claim = 4;
-  auto claim_next = [&]() -> uint32_t {  // skips sites below min_maf (ngsLD.cpp:270-275)
+  auto claim_next = [&]() -> uint32_t {  // skips pairs dropped by the maf[s2] / sub-sampling filters (ngsLD.cpp:270-282)
     for (;;) {
       uint32_t c = 0;
       if (lane == 0) c = atomicAdd(claim, 1u);
       c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-      if (c >= it.count || A.keep[it.s2_begin + c]) return c;
+      if (c >= it.count || ((it.mask >> c) & 1ull)) return c;
     }
   };
   // Per-site scalars of the site a wavefront will work on are fetched when the site is CLAIMED, one pair
@@ -402,16 +397,14 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
   // copy too (vmcnt is in-order), which is exactly the stall this kernel exists to remove.
   struct SiteScalars {
     double maf, mean, rsx;
-    uint32_t ck;
   };
   auto load_scalars = [&](uint32_t c) -> SiteScalars {
-    SiteScalars v{0.0, 0.0, 0.0, 0u};
+    SiteScalars v{0.0, 0.0, 0.0};
     if (c < it.count) {
       const uint32_t s2 = it.s2_begin + c;
       v.maf = uniform(A.maf[s2]);
       v.mean = uniform(A.mean_e[s2]);
       v.rsx = uniform(A.rsx[s2]);
-      v.ck = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.cumkeep[s2]);
     }
     return v;
   };
@@ -420,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
   dma_site_to_lds<SLOTS>(A.planes + (uint64_t)s1 * A.site_stride, lds_a, lane, wave, 4);
   __syncthreads();  // claim counter initialised before anybody claims
   uint32_t c = (uint32_t)wave;
-  if (c < it.count && !A.keep[it.s2_begin + c]) c = claim_next();
+  if (c < it.count && !((it.mask >> c) & 1ull)) c = claim_next();
   SiteScalars cur = load_scalars(c);
   if (c < it.count) dma_site_to_lds<SLOTS>(A.planes + (uint64_t)(it.s2_begin + c) * A.site_stride, lds_b, lane, 0, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -444,7 +437,9 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
     double f0, f1, f2, f3;
     const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, x, m1, cur.maf, f0, f1, f2, f3,
                                                       (double (*)[1][4]) nullptr, 0, lane, A.status);
-    if (lane == 0) write_pair(A, row_base + (uint64_t)(cur.ck - ck1), f0, f1, f2, f3, sxy, rsx1, cur.rsx, x, n_iter);
+    if (lane == 0)
+      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, cur.rsx, x,
+                 n_iter);
     c = cn;
     cur = nxt;
   }

@@ -20,8 +20,23 @@ struct PrepArgs {
 };
 
 hipError_t launch_prep(const PrepArgs &a, hipStream_t stream);
-hipError_t launch_build_items(const uint32_t *row_end, const uint64_t *item_off, uint32_t n_sites, uint32_t ch,
-                              Item *items, hipStream_t stream);
+// Pair-space enumeration on the device, one thread per row s1 (the s2 walk of ngsLD.cpp:240-282 after the
+// distance/SNP cuts, which the host has already turned into row_end):
+//   count_only: row_count[s1] = number of candidates that survive the maf[s2] skip and, when rnd_sample < 1,
+//               the row's Tausworthe draws;  otherwise: write the row's items (mask + first_record).
+struct ItemArgs {
+  const uint32_t *row_end;    // [n_sites]
+  const uint8_t *keep;        // [n_sites] maf[s] >= min_maf
+  const uint64_t *row_seed;   // [n_sites] or null when not sampling
+  const uint64_t *row_off;    // [n_sites + 1] records before each row (fill pass)
+  const uint64_t *item_off;   // [n_sites + 1] items before each row (fill pass)
+  uint64_t *row_count;        // [n_sites] (count pass)
+  Item *items;
+  uint32_t n_sites, span;
+  double rnd_sample;
+  int count_only;
+};
+hipError_t launch_items(const ItemArgs &a, hipStream_t stream);
 hipError_t launch_selftest(const double *in, double *out, hipStream_t stream);
 
 }  // namespace ngsld

@@ -172,28 +172,62 @@ hipError_t launch_prep(const PrepArgs &a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// One thread per row: cut the row's s2 range [s1+1, row_end) into items of `ch` consecutive sites.
-__global__ void build_items_kernel(const uint32_t *row_end, const uint64_t *item_off, uint32_t n_sites, uint32_t ch,
-                                   Item *items) {
-  const uint32_t s1 = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s1 >= n_sites) return;
-  const uint32_t end = row_end[s1];
-  uint64_t k = item_off[s1];
-  for (uint32_t b = s1 + 1; b < end; b += ch) {
-    Item it;
-    it.s1 = s1;
-    it.s2_begin = b;
-    it.count = end - b < ch ? end - b : ch;
-    it.pad = 0;
-    items[k++] = it;
+// gsl_rng_taus (L'Ecuyer's 3-component Tausworthe generator; algorithm as published in GSL's rng/taus.c): the
+// per-row streams of the reference's random sub-sampling (ngsLD.cpp:165-166,277).
+struct Taus {
+  uint32_t s1, s2, s3;
+  __device__ __forceinline__ uint32_t get() {
+    s1 = ((s1 & 4294967294u) << 12) ^ (((s1 << 13) ^ s1) >> 19);
+    s2 = ((s2 & 4294967288u) << 4) ^ (((s2 << 2) ^ s2) >> 25);
+    s3 = ((s3 & 4294967280u) << 17) ^ (((s3 << 3) ^ s3) >> 11);
+    return s1 ^ s2 ^ s3;
   }
+  __device__ __forceinline__ void set(uint64_t seed) {
+    if (seed == 0) seed = 1;
+    s1 = (uint32_t)(69069ull * seed);
+    s2 = 69069u * s1;
+    s3 = 69069u * s2;
+    for (int k = 0; k < 6; ++k) get();
+  }
+  __device__ __forceinline__ double uniform() { return get() / 4294967296.0; }
+};
+
+__global__ void items_kernel(ItemArgs A) {
+  const uint32_t s1 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s1 >= A.n_sites) return;
+  const uint32_t end = A.row_end[s1];
+  const bool sampling = A.row_seed != nullptr;
+  Taus rng;
+  if (sampling) rng.set(A.row_seed[s1]);
+  uint64_t kept = 0;
+  uint64_t k = A.count_only ? 0 : A.item_off[s1];
+  const uint64_t base = A.count_only ? 0 : A.row_off[s1];
+  for (uint32_t b = s1 + 1; b < end; b += A.span) {
+    const uint32_t cnt = end - b < A.span ? end - b : A.span;
+    uint64_t mask = 0;
+    for (uint32_t c = 0; c < cnt; ++c) {
+      if (!A.keep[b + c]) continue;                                 // ngsLD.cpp:270-275
+      if (sampling && rng.uniform() > A.rnd_sample) continue;      // ngsLD.cpp:277-282, one draw per surviving pair
+      mask |= 1ull << c;
+    }
+    if (!A.count_only) {
+      Item it;
+      it.s1 = s1;
+      it.s2_begin = b;
+      it.count = cnt;
+      it.reserved = 0;
+      it.mask = mask;
+      it.first_record = base + kept;
+      A.items[k++] = it;
+    }
+    kept += (uint64_t)__popcll(mask);
+  }
+  if (A.count_only) A.row_count[s1] = kept;
 }
 
-hipError_t launch_build_items(const uint32_t *row_end, const uint64_t *item_off, uint32_t n_sites, uint32_t ch,
-                              Item *items, hipStream_t stream) {
-  if (n_sites == 0) return hipSuccess;
-  hipLaunchKernelGGL(build_items_kernel, dim3((n_sites + 255) / 256), dim3(256), 0, stream, row_end, item_off,
-                     n_sites, ch, items);
+hipError_t launch_items(const ItemArgs &a, hipStream_t stream) {
+  if (a.n_sites == 0) return hipSuccess;
+  hipLaunchKernelGGL(items_kernel, dim3((a.n_sites + 255) / 256), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -574,19 +574,81 @@ void orc_free_pos(orc_params *p) {
 }
 
 /* ------------------------------------------------------------------------------------------------
- * ngsLD.cpp:229-359 calc_pair_LD: the walk over s2 for one s1, filters in the reference's order:
- * dist (:252) -> snp dist (:258) -> maf[s1] (:264, break) -> maf[s2] (:270, skip).  The random
- * sub-sampling filter (:277) never rejects at the default --rnd_sample 1 and is not restated.
+ * gsl_rng_taus.  GSL is an external dependency of the reference (README.md:20) and is not installed
+ * here; this restates the published algorithm of GSL's rng/taus.c ("taus", not "taus2": no minimum
+ * values are forced on the state).  State s1,s2,s3 are 32-bit values;
+ *   TAUSWORTHE(s,a,b,c,d) = (((s & c) << d) & MASK) ^ ((((s << a) & MASK) ^ s) >> b)
+ *   s1 = T(s1,13,19,4294967294,12); s2 = T(s2,2,25,4294967288,4); s3 = T(s3,3,11,4294967280,17); out = s1^s2^s3
+ * seeding: s == 0 -> 1; s1 = LCG(s), s2 = LCG(s1), s3 = LCG(s2) with LCG(n) = (69069*n) & 0xffffffff, then six
+ * warm-up draws; uniform = get() / 4294967296.0.
  * ---------------------------------------------------------------------------------------------- */
+#define ORC_TAUS(s, a, b, c, d) (((((s) & (c)) << (d)) & 0xffffffffUL) ^ (((((s) << (a)) & 0xffffffffUL) ^ (s)) >> (b)))
+
+uint32_t orc_taus_get(orc_taus *r) {
+  unsigned long s1 = r->s1, s2 = r->s2, s3 = r->s3;
+  s1 = ORC_TAUS(s1, 13, 19, 4294967294UL, 12);
+  s2 = ORC_TAUS(s2, 2, 25, 4294967288UL, 4);
+  s3 = ORC_TAUS(s3, 3, 11, 4294967280UL, 17);
+  r->s1 = (uint32_t)s1;
+  r->s2 = (uint32_t)s2;
+  r->s3 = (uint32_t)s3;
+  return (uint32_t)(s1 ^ s2 ^ s3);
+}
+
+void orc_taus_set(orc_taus *r, unsigned long s) {
+  if (s == 0) s = 1;
+#define ORC_LCG(n) ((69069UL * (n)) & 0xffffffffUL)
+  unsigned long a = ORC_LCG(s), b = ORC_LCG(a), c = ORC_LCG(b);
+  r->s1 = (uint32_t)a;
+  r->s2 = (uint32_t)b;
+  r->s3 = (uint32_t)c;
+  for (int k = 0; k < 6; k++) orc_taus_get(r);
+}
+
+double orc_taus_uniform(orc_taus *r) { return orc_taus_get(r) / 4294967296.0; }
+
+/* ngsLD.cpp:69-70,165-166: master stream seeded with --seed; row s1's generator is seeded with
+ * (unsigned long) draw_rnd(master, 0, INF) = (unsigned long)(0 + uniform * (1e15 - 0)), drawn for s1 = 0,1,2,... */
+void orc_row_seeds(uint64_t seed, uint64_t n_sites, uint64_t *out) {
+  orc_taus m;
+  orc_taus_set(&m, (unsigned long)seed);
+  for (uint64_t s = 0; s < n_sites; s++) {
+    const uint64_t mn = 0, mx = (uint64_t)ORC_INF;
+    out[s] = (uint64_t)(unsigned long)(mn + orc_taus_uniform(&m) * (mx - mn));
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * ngsLD.cpp:229-359 calc_pair_LD: the walk over s2 for one s1, filters in the reference's order:
+ * dist (:252) -> snp dist (:258) -> maf[s1] (:264, break) -> maf[s2] (:270, skip) -> random
+ * sub-sampling (:277: one uniform draw from the row's own generator per pair that got this far; the
+ * pair is kept iff draw <= rnd_sample).  At the default --rnd_sample 1 nothing is ever rejected and
+ * the draws have no effect, so they are skipped.
+ * ---------------------------------------------------------------------------------------------- */
+static uint64_t orc_row_seed_of(const orc_params *p, uint64_t s1) {
+  /* row seeds are a serial stream over s1; recomputing the prefix is O(s1) -- fine for an oracle */
+  orc_taus m;
+  orc_taus_set(&m, (unsigned long)p->seed);
+  uint64_t v = 0;
+  for (uint64_t s = 0; s <= s1; s++) v = (uint64_t)(unsigned long)(0 + orc_taus_uniform(&m) * ((uint64_t)ORC_INF - 0));
+  return v;
+}
 uint64_t orc_row(const orc_params *p, uint64_t s1, orc_pair *out, uint64_t cap, int *err) {
   uint64_t s2 = s1 + 1, n_out = 0;
   double dist = 0;
+  const int sampling = p->rnd_sample > 0 && p->rnd_sample < 1;
+  orc_taus rng;
+  if (sampling) orc_taus_set(&rng, (unsigned long)orc_row_seed_of(p, s1));
   while (s2 < p->n_sites) {
     dist += p->pos_dist[s2];
     if (p->max_kb_dist > 0 && p->max_kb_dist * 1000 < dist) break;
     if (p->max_snp_dist > 0 && p->max_snp_dist < s2 - s1) break;
     if (p->maf[s1] < p->min_maf) break;
     if (p->maf[s2] < p->min_maf) {
+      s2++;
+      continue;
+    }
+    if (sampling && orc_taus_uniform(&rng) > p->rnd_sample) { /* ngsLD.cpp:277-282 */
       s2++;
       continue;
     }

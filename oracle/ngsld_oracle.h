@@ -47,6 +47,8 @@ typedef struct {
   int ignore_miss_data;
   int extend_out;
   int n_threads;
+  double rnd_sample; /* 1 = keep every pair (default, parse_args.cpp:22); < 1: per-pair Tausworthe draw */
+  uint64_t seed;     /* --seed: seeds the master stream (ngsLD.cpp:69-70) */
 
   double *geno_lkl;      /* [n_sites][n_ind][3]; log space after read, normal space after preprocess */
   double *maf;           /* [n_sites] */
@@ -101,6 +103,17 @@ void orc_preprocess(orc_params *p);
 /* read_dist + labels; allocates p->pos_dist, p->labels.  returns 0 ok */
 int orc_read_pos(orc_params *p, char *errbuf, size_t errlen);
 void orc_free_pos(orc_params *p);
+
+/* --- gsl_rng_taus (GSL is not in the reference tree): L'Ecuyer's 3-component Tausworthe generator restated from
+   GSL's published rng/taus.c; pinned by GSL's own self-test value (seed 1, 10000th output 2733957125) --- */
+typedef struct {
+  uint32_t s1, s2, s3;
+} orc_taus;
+void orc_taus_set(orc_taus *r, unsigned long seed);
+uint32_t orc_taus_get(orc_taus *r);
+double orc_taus_uniform(orc_taus *r);
+/* per-row seeds: for s1 = 0,1,2,... (unsigned long) draw_rnd(master, 0, INF)  (ngsLD.cpp:166, gen_func.cpp:117-119) */
+void orc_row_seeds(uint64_t seed, uint64_t n_sites, uint64_t *out);
 
 /* --- the hot path --- */
 /* number of pairs row s1 emits; when out != NULL the records are written there (capacity cap). */

@@ -30,6 +30,8 @@ int main(int argc, char **argv) {
   memset(&P, 0, sizeof(P));
   P.max_kb_dist = 100;
   P.n_threads = 1;
+  P.rnd_sample = 1;
+  P.seed = 12345; /* the reference defaults to time(NULL) + rand() % 1000 (parse_args.cpp:23): tests always pass --seed */
   const char *out = NULL, *dump = NULL;
   int verbose = 1, in_probs = 0, call_geno = 0;
   double rnd_sample = 1, N_thresh = 0, call_thresh = 0;
@@ -74,7 +76,7 @@ int main(int argc, char **argv) {
       case 'N': N_thresh = atof(optarg); call_geno = 1; break;
       case 'C': call_thresh = atof(optarg); call_geno = 1; break;
       case 'r': rnd_sample = atof(optarg); break;
-      case 'S': break;
+      case 'S': P.seed = (uint64_t)atoi(optarg); break;
       case 'x': P.extend_out = 1; break;
       case 'o': out = optarg; break;
       case 't': P.n_threads = atoi(optarg); break;
@@ -94,7 +96,7 @@ int main(int argc, char **argv) {
   if (rnd_sample <= 0 || rnd_sample > 1)
     die("parse_cmd_args", "proportion of comparisons to sample must be in ]0,1]!");
   if (P.n_threads < 1) die("parse_cmd_args", "number of threads cannot be less than 1!");
-  if (rnd_sample != 1) die("main", "oracle: --rnd_sample is outside the restated path");
+  P.rnd_sample = rnd_sample;
 
   struct stat st;
   if (stat(P.in_geno, &st) != 0) die("main", "cannot check GENO file size!");

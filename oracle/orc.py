@@ -23,7 +23,7 @@ class OrcParams(C.Structure):
         ("in_geno", C.c_char_p), ("in_logscale", C.c_int), ("n_ind", C.c_uint64), ("n_sites", C.c_uint64),
         ("in_pos", C.c_char_p), ("in_pos_header", C.c_int), ("max_kb_dist", C.c_uint64),
         ("max_snp_dist", C.c_uint64), ("min_maf", C.c_double), ("ignore_miss_data", C.c_int),
-        ("extend_out", C.c_int), ("n_threads", C.c_int),
+        ("extend_out", C.c_int), ("n_threads", C.c_int), ("rnd_sample", C.c_double), ("seed", C.c_uint64),
         ("geno_lkl", c_double_p), ("maf", c_double_p), ("expected_geno", c_double_p), ("pos_dist", c_double_p),
         ("labels", C.POINTER(C.c_char_p)),
     ]
@@ -93,6 +93,12 @@ def lib() -> C.CDLL:
         L.orc_run.restype = C.c_uint64
         L.orc_run.argtypes = [C.POINTER(OrcParams), C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64,
                               C.POINTER(C.c_int)]
+        L.orc_taus_set.restype = None
+        L.orc_taus_set.argtypes = [C.c_void_p, C.c_ulong]
+        L.orc_taus_get.restype = C.c_uint32
+        L.orc_taus_get.argtypes = [C.c_void_p]
+        L.orc_row_seeds.restype = None
+        L.orc_row_seeds.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
         L.orc_bench.restype = C.c_uint64
         L.orc_bench.argtypes = [C.POINTER(OrcParams), C.c_uint64, C.c_uint64, c_double_p, C.POINTER(C.c_uint64)]
         L.orc_row_end.restype = C.c_uint64
@@ -144,7 +150,8 @@ class Oracle:
 
     def __init__(self, raw_gl: np.ndarray, pos_dist: np.ndarray | None = None, log_scale: bool = False,
                  ignore_miss_data: bool = False, max_kb_dist: int = 0, max_snp_dist: int = 0, min_maf: float = 0.0,
-                 n_threads: int = 1, already_normalised_log: bool = False, call_geno: tuple | None = None):
+                 n_threads: int = 1, already_normalised_log: bool = False, call_geno: tuple | None = None,
+                 rnd_sample: float = 1.0, seed: int = 0):
         """raw_gl: what the binary reader would read, or (already_normalised_log) the log-normalised output of
         a reader.  call_geno = (N_thresh, call_thresh) applies ngsLD.cpp:92-98 before est_maf."""
         L = lib()
@@ -171,6 +178,7 @@ class Oracle:
         self.p.n_ind, self.p.n_sites = self.n_ind, self.n_sites
         self.p.max_kb_dist, self.p.max_snp_dist, self.p.min_maf = max_kb_dist, max_snp_dist, min_maf
         self.p.ignore_miss_data, self.p.n_threads = int(ignore_miss_data), n_threads
+        self.p.rnd_sample, self.p.seed = rnd_sample, seed
         self.p.geno_lkl, self.p.maf, self.p.expected_geno = dp(self.gl), dp(self.maf), dp(self.expg)
         self.p.pos_dist = dp(self.pos_dist)
         L.orc_preprocess(C.byref(self.p))  # gl -> normal space in place

@@ -80,7 +80,8 @@ def run_cli(raw, ptxt, flags, header=False, gtext=None):
 
 
 def make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max_kb=0, max_snp=0, min_maf=0.0,
-         extra_col=False, header=False, with_text=True, text_mode=None, call=None, geno_header=True):
+         extra_col=False, header=False, with_text=True, text_mode=None, call=None, geno_header=True,
+         rnd_sample=1.0, seed=0):
     """text_mode: None (binary GL file) | "probs" (text GL triples) | "called" (text genotypes, raw = [sites, ind]
     of {-1,0,1,2}); call = (N_thresh, call_thresh) adds --call_geno."""
     import gzip
@@ -133,10 +134,12 @@ def make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max
     # ---- oracle on the same input; must equal the reference wherever the reference can be built ----
     if text_mode is None:
         o = orc.Oracle(raw, pd, log_scale=log_scale, ignore_miss_data=ignore_miss, max_kb_dist=max_kb,
-                       max_snp_dist=max_snp, min_maf=min_maf, n_threads=4, call_geno=call)
+                       max_snp_dist=max_snp, min_maf=min_maf, n_threads=4, call_geno=call, rnd_sample=rnd_sample,
+                       seed=seed)
     else:
         o = orc.Oracle(gl_orc, pd, ignore_miss_data=ignore_miss, max_kb_dist=max_kb, max_snp_dist=max_snp,
-                       min_maf=min_maf, n_threads=4, already_normalised_log=True, call_geno=call)
+                       min_maf=min_maf, n_threads=4, already_normalised_log=True, call_geno=call,
+                       rnd_sample=rnd_sample, seed=seed)
     assert np.array_equal(o.gl_log, gl_log, equal_nan=True), "reader: oracle != reference"
     assert np.array_equal(o.maf, maf, equal_nan=True) and np.array_equal(o.gl, gl) and np.array_equal(o.expg, expg)
     if ref_pd is not None:
@@ -158,6 +161,7 @@ def make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max
         raw=raw, geno_text=np.array(gtext if gtext is not None else ""),
         text_mode=np.array(text_mode if text_mode is not None else ""),
         call_geno=np.array(list(call) if call is not None else [], dtype=np.float64),
+        rnd_sample=np.array(rnd_sample), seed=np.array(seed),
         ref_gl_log=gl_log if text_mode is not None else np.zeros(0),
         pos_text=np.array(ptxt if ptxt is not None else ""), has_pos=np.array(ptxt is not None),
         header=np.array(header), log_scale=np.array(log_scale), ignore_miss=np.array(ignore_miss),
@@ -177,6 +181,8 @@ def make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max
             flags.append("--ignore_miss_data")
         if text_mode == "probs" or call is not None:   # --call_geno needs --probs even for binary input (parse_args.cpp:178)
             flags.append("--probs")
+        if rnd_sample < 1:
+            flags += ["--rnd_sample", repr(rnd_sample), "--seed", str(seed)]
         if call is not None:
             flags += ["--call_geno", "--N_thresh", repr(float(call[0])), "--call_thresh", repr(float(call[1]))]
         for tag, extra in (("std", []), ("ext", ["--extend_out"])):
@@ -243,6 +249,12 @@ def main():
     chrs, pos = synth.make_positions(60, 83)
     make("f8_call_geno", raw, chrs, pos, call=(0.4, 0.9))
     make("f8_call_geno_default", raw, chrs, pos, call=(0.0, 0.0), ignore_miss=True)
+    # F9: --rnd_sample / --seed (per-row Tausworthe streams), alone and with the other filters
+    raw = synth.make_gl_numpy(80, 24, seed=91, depth=4.0)
+    chrs, pos = synth.make_positions(80, 91, n_chr=2)
+    make("f9_rnd_sample", raw, chrs, pos, rnd_sample=0.4, seed=7)
+    thr = float(np.round(np.quantile(orc.Oracle(raw).maf, 0.2), 3))
+    make("f9_rnd_sample_filters", raw, chrs, pos, rnd_sample=0.25, seed=123456789, max_kb=6, min_maf=thr)
     # F6/F7: the benchmark n_ind values (slot / multi-wavefront paths of the kernel)
     for name, ns, ni, seed in (("f7_n100", 128, 100, 7), ("f6_n500", 48, 500, 6), ("f6_n1000", 24, 1000, 8),
                                ("f6_n2000", 12, 2000, 9)):

@@ -23,7 +23,7 @@ def test_hip_matches_golden(engine, name, tmp_path):
     fx = Fixture(name)
     fx.engine_load(engine, str(tmp_path))
     assert np.all(close(engine.maf(), fx["ref_maf"], MAF_TOL)), "est_maf vs reference"
-    n = engine.plan(fx.max_kb, fx.max_snp, fx.min_maf, fx.ignore_miss, True)
+    n = engine.plan(fx.max_kb, fx.max_snp, fx.min_maf, fx.ignore_miss, True, fx.rnd_sample, fx.seed)
     assert n == len(fx["orc_s1"])
     s1, s2, std, ext = engine.run()
     assert np.array_equal(s1, fx["orc_s1"]) and np.array_equal(s2, fx["orc_s2"])

@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 
 
 def check_against_oracle(engine, raw, pos_dist=None, log_scale=False, ignore_miss=False, max_kb=0, max_snp=0,
-                         min_maf=0.0, via_lkl=False):
+                         min_maf=0.0, via_lkl=False, rnd_sample=1.0, seed=0):
     o = orc.Oracle(raw, pos_dist, log_scale=log_scale, ignore_miss_data=ignore_miss, max_kb_dist=max_kb,
-                   max_snp_dist=max_snp, min_maf=min_maf, n_threads=4)
+                   max_snp_dist=max_snp, min_maf=min_maf, n_threads=4, rnd_sample=rnd_sample, seed=seed)
     rec = o.run()
     if via_lkl:
         engine.set_geno_lkl(o.gl, o.maf)
@@ -25,7 +25,7 @@ def check_against_oracle(engine, raw, pos_dist=None, log_scale=False, ignore_mis
         engine.set_geno_raw(raw, log_scale=log_scale, ignore_miss_data=ignore_miss)
     engine.set_pos_dist(pos_dist)
     assert np.all(close(engine.maf(), o.maf, MAF_TOL)), "est_maf differs by more than 1e-12"
-    n = engine.plan(max_kb, max_snp, min_maf, ignore_miss, True)
+    n = engine.plan(max_kb, max_snp, min_maf, ignore_miss, True, rnd_sample, seed)
     assert n == len(rec), f"pair count {n} != oracle {len(rec)}"
     s1, s2, std, ext = engine.run()
     assert np.array_equal(s1, rec["s1"]) and np.array_equal(s2, rec["s2"])
@@ -129,3 +129,17 @@ def test_batched_run_matches_single_batch(engine):
     engine.set_tuning(pairs_per_item=16, batch_pairs=1 << 23)
     for x, y in zip(a, b):
         assert np.array_equal(x, y)     # bit-identical: the per-pair reduction order is fixed
+
+
+@pytest.mark.parametrize("rnd,seed", [(0.5, 1), (0.1, 99), (0.9, 4294967296 + 5), (1.0, 3)])
+def test_rnd_sample_streams(engine, rnd, seed):
+    """--rnd_sample / --seed: the same pairs survive as in the oracle's per-row Tausworthe streams."""
+    raw = synth.make_gl_numpy(150, 30, 33, depth=5.0)
+    chrs, pos = synth.make_positions(150, 33, n_chr=2)
+    pd = np.empty(150)
+    pd[0] = pos[0]
+    for s in range(1, 150):
+        pd[s] = np.inf if chrs[s] != chrs[s - 1] else pos[s] - pos[s - 1]
+    rec = check_against_oracle(engine, raw, pd, max_kb=8, rnd_sample=rnd, seed=seed)
+    full = check_against_oracle(engine, raw, pd, max_kb=8)
+    assert (len(rec) == len(full)) == (rnd == 1.0)

@@ -147,12 +147,7 @@ def test_write_batch_threads_reproduce_oracle_text(name, threads, tmp_path):
     ext = np.zeros(n, dtype=capi.REC_EXT)
     ext["hap"], ext["n_ind_data"], ext["n_iter"] = fx["ref_hap"], fx["ref_n_ind_data"], fx["ref_n_iter"]
     maf = np.ascontiguousarray(fx["ref_maf"])
-    keep = np.ascontiguousarray((~(maf < fx.min_maf)).astype(np.uint8))
-    row_end = np.ascontiguousarray(shard.row_ends(fx.pos_dist, fx.max_kb, fx.max_snp).astype(np.uint32))
-    row_end[maf < fx.min_maf] = np.arange(ns, dtype=np.uint32)[maf < fx.min_maf] + 1     # ngsLD.cpp:264: row empty
-    s1 = fx["orc_s1"].astype(np.int64)
-    row_off = np.zeros(ns + 1, dtype=np.uint64)
-    row_off[1:] = np.cumsum(np.bincount(s1, minlength=ns))
+    items = capi.items_from_pairs(fx["orc_s1"], fx["orc_s2"], span=7 if threads == 3 else 64)
     p = tmp_path / "in.pos"
     p.write_text(fx.pos_text)
     L = capi.lib()
@@ -160,8 +155,7 @@ def test_write_batch_threads_reproduce_oracle_text(name, threads, tmp_path):
     err = C.create_string_buffer(256)
     assert L.ngsld_host_read_pos(str(p).encode(), int(fx.header), ns, C.byref(h), err, 256) == 0
     pd = np.ascontiguousarray(fx.pos_dist)
-    b = capi.Batch(0, ns, n, row_off.ctypes.data_as(C.POINTER(C.c_uint64)), row_end.ctypes.data_as(C.POINTER(C.c_uint32)),
-                   keep.ctypes.data_as(C.POINTER(C.c_uint8)), std.ctypes.data, ext.ctypes.data)
+    b = capi.Batch(0, ns, n, len(items), items.ctypes.data, std.ctypes.data, ext.ctypes.data)
     out = tmp_path / "out.tsv"
     with open(out, "wb") as fh:
         rc = L.ngsld_host_write_batch(C.byref(b), h, pd.ctypes.data, maf.ctypes.data, threads, fh.fileno())

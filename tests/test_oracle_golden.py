@@ -78,3 +78,25 @@ def test_em_known_answers():
                           0.75, 0.25, n, 0, C.byref(e))
     # haplotypes: 10 ind x (0,0) -> h00, 10 ind x (1,1) -> h11, 20 ind x (1,0) -> h10
     assert np.allclose(hap, [0.25, 0.0, 0.5, 0.25], atol=1e-12) and nn.value == n and it <= 2 and e.value == 0
+
+
+def test_taus_known_answer_and_row_seeds():
+    """gsl_rng_taus restated from GSL's published algorithm (GSL is absent): GSL's own self-test value
+    (rng/test.c: seed 1, 10000th output 2733957125) pins the generator; row seeds are the serial master stream."""
+    import ctypes as C
+    L = orc.lib()
+    st = (C.c_uint32 * 3)()
+    L.orc_taus_set(st, 1)
+    v = 0
+    for _ in range(10000):
+        v = L.orc_taus_get(st)
+    assert v == 2733957125
+    L.orc_taus_set(st, 0)                      # seed 0 is replaced by 1
+    first0 = L.orc_taus_get(st)
+    L.orc_taus_set(st, 1)
+    assert first0 == L.orc_taus_get(st)
+    seeds = (C.c_uint64 * 5)()
+    L.orc_row_seeds(42, 5, seeds)
+    L.orc_taus_set(st, 42)
+    for k in range(5):
+        assert seeds[k] == int(L.orc_taus_get(st) / 4294967296.0 * 1e15)

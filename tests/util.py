@@ -33,6 +33,8 @@ class Fixture:
         self.geno_text = str(z["geno_text"]) if self.text_mode else None
         cg = z["call_geno"] if "call_geno" in z.files else np.zeros(0)
         self.call_geno = (float(cg[0]), float(cg[1])) if len(cg) == 2 else None
+        self.rnd_sample = float(z["rnd_sample"]) if "rnd_sample" in z.files else 1.0
+        self.seed = int(z["seed"]) if "seed" in z.files else 0
         if self.text_mode == "called":
             self.n_sites, self.n_ind = self.raw.shape
         self.pos_dist = z["ref_pos_dist"] if self.has_pos else None
@@ -44,7 +46,8 @@ class Fixture:
         import tempfile
         from oracle import orc
         kw = dict(ignore_miss_data=self.ignore_miss, max_kb_dist=self.max_kb, max_snp_dist=self.max_snp,
-                  min_maf=self.min_maf, n_threads=n_threads, call_geno=self.call_geno)
+                  min_maf=self.min_maf, n_threads=n_threads, call_geno=self.call_geno, rnd_sample=self.rnd_sample,
+                  seed=self.seed)
         if not self.text_mode:
             return orc.Oracle(self.raw, self.pos_dist, log_scale=self.log_scale, **kw)
         with tempfile.TemporaryDirectory() as d:
@@ -99,6 +102,8 @@ class Fixture:
             f.append("--ignore_miss_data")
         if self.text_mode == "probs" or self.call_geno:
             f.append("--probs")
+        if self.rnd_sample < 1:
+            f += ["--rnd_sample", repr(self.rnd_sample), "--seed", str(self.seed)]
         if self.call_geno:
             f += ["--call_geno", "--N_thresh", repr(self.call_geno[0]), "--call_thresh", repr(self.call_geno[1])]
         if extend:
