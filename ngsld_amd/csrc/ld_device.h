@@ -117,6 +117,14 @@ __device__ __forceinline__ double rcp_refined(double s) {
   return fma(r0, t, r0);
 }
 
+// Workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() would also
+// wait vmcnt(0), i.e. drain an asynchronous global->LDS site copy that is meant to fly through the whole EM loop.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // gen_func.cpp:862-868 miss_data with the reference's abs() macro semantics
 __device__ __forceinline__ bool miss_data(double g0, double g1, double g2) {
   double d01 = g0 - g1, d12 = g1 - g2;
@@ -128,22 +136,25 @@ __device__ __forceinline__ bool miss_data(double g0, double g1, double g2) {
 // ---------------------------------------------------------------------------------------------
 // Building blocks of the pair kernels
 // ---------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;        // operands of __builtin_amdgcn_global_load_lds
+typedef const __attribute__((address_space(1))) void glb_void_t;
 
 // Stage both sites of one pair: P = a (x) b for this lane's SLOTS individuals, their validity bits and the
 // Pearson cross moment.  pa / pb point at a site's three planes [3][np] -- in HBM/L2 (direct kernel) or in
 // LDS (prefetch kernel); after inlining the compiler knows which and emits global_load or ds_read.
 template <int SLOTS, bool MASKED>
-__device__ __forceinline__ void stage_pair(const double *pa, const double *pb, uint32_t np, uint32_t i0,
-                                           uint32_t n_ind, double mean1, double mean2, double (&P)[SLOTS][9],
-                                           uint32_t &vbits, double &sxy) {
+__device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint32_t ia0, const double *pb, uint32_t npb,
+                                           uint32_t ib0, uint32_t ind0, uint32_t n_ind, double mean1, double mean2,
+                                           double (&P)[SLOTS][9], uint32_t &vbits, double &sxy) {
+  // pa[g * npa + ia0 + 64 j] / pb[g * npb + ib0 + 64 j] hold genotype g of individual ind0 + 64 j (this lane, slot j)
   vbits = 0;
   sxy = 0.0;
 #pragma unroll
   for (int j = 0; j < SLOTS; ++j) {
-    const uint32_t i = i0 + (uint32_t)j * 64;
-    const double a0 = pa[i], a1 = pa[np + i], a2 = pa[2 * np + i];
-    const double b0 = pb[i], b1 = pb[np + i], b2 = pb[2 * np + i];
-    const bool inb = i < n_ind;
+    const uint32_t ia = ia0 + (uint32_t)j * 64, ib = ib0 + (uint32_t)j * 64;
+    const double a0 = pa[ia], a1 = pa[npa + ia], a2 = pa[2 * npa + ia];
+    const double b0 = pb[ib], b1 = pb[npb + ib], b2 = pb[2 * npb + ib];
+    const bool inb = ind0 + (uint32_t)j * 64 < n_ind;
     bool ok = inb;
     if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);  // gen_func.cpp:1089
     vbits |= (ok ? 1u : 0u) << j;
@@ -275,17 +286,23 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
 }
 
 // ---------------------------------------------------------------------------------------------
-// Direct kernel: site vectors read straight from HBM/L2 at every pair start.
+// Generic kernel: WAVES wavefronts share one pair (WAVES == 1: four independent wavefronts per 256-thread
+// workgroup, one item each).  Used for n_ind > 512; for WAVES == 1 it is the A/B baseline of the prefetch kernel.
 //   SLOTS  individuals per lane (compile time, P lives in 18*SLOTS VGPRs)
-//   WAVES  wavefronts sharing one pair (1: four independent wavefronts per 256-thread workgroup, one item each)
 //   MASKED --ignore_miss_data: individuals missing at either site are left out (gen_func.cpp:1089)
-// Used for n_ind > 512 (WAVES > 1); for WAVES == 1 it is the A/B baseline of the prefetch kernel below.
+//   PFB    prefetch the s2 vector: every wavefront only ever reads ITS slice of it (individuals sub*SLOTS*64 ...),
+//          so the slice of the NEXT pair is copied global->LDS asynchronously into a wave-private 1536*SLOTS-byte
+//          buffer while the EM loop of the current pair runs; the row vector (same for the whole item, L2/L1-hot)
+//          is still read directly.  No extra barrier is needed for the prefetch.
 // ---------------------------------------------------------------------------------------------
-template <int SLOTS, int WAVES, bool MASKED>
+template <int SLOTS, int WAVES, bool MASKED, bool PFB>
 __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
   constexpr bool kCheckAll = MASKED || WAVES > 1;  // otherwise only the last slot can hold padding
-  __shared__ double xch[2][WAVES][4];
-  __shared__ double xch0[WAVES][2];
+  constexpr int kWavesPerWg = WAVES == 1 ? 4 : WAVES;
+  constexpr int kSliceBytes = SLOTS * 64 * 3 * 8;
+  __shared__ __attribute__((aligned(16))) char smem[(PFB ? kWavesPerWg * kSliceBytes : 16) + WAVES * 96];
+  double (*xch)[WAVES][4] = reinterpret_cast<double (*)[WAVES][4]>(smem + (PFB ? kWavesPerWg * kSliceBytes : 16));
+  double (*xch0)[2] = reinterpret_cast<double (*)[2]>(smem + (PFB ? kWavesPerWg * kSliceBytes : 16) + WAVES * 64);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -301,15 +318,46 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
   const uint64_t rec0 = it.first_record - A.out_base;
   const double *pa = A.planes + (uint64_t)s1 * A.site_stride;
   const uint32_t i0 = (uint32_t)sub * (SLOTS * 64) + (uint32_t)lane;
+  char *lds_b = smem + wave * kSliceBytes;
 
-  for (uint32_t c = 0; c < it.count; ++c) {
-    if (!((it.mask >> c) & 1ull)) continue;  // ngsLD.cpp:270-282: maf[s2] skip, random sub-sampling
+  // copy this wavefront's slice of site s2 (three runs of SLOTS*512 B, one per genotype plane) into lds_b
+  auto dma_slice = [&](uint32_t s2) {
+    const char *g = reinterpret_cast<const char *>(A.planes + (uint64_t)s2 * A.site_stride + (uint32_t)sub * (SLOTS * 64)) +
+                    lane * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int k = 0; k < (SLOTS * 512 + 1023) / 1024; ++k)
+        if ((k + 1) * 1024 <= SLOTS * 512 || lane * 16 < SLOTS * 512 - k * 1024)
+          __builtin_amdgcn_global_load_lds((glb_void_t *)(g + (size_t)pl * A.np * 8 + k * 1024),
+                                           (lds_void_t *)(lds_b + pl * SLOTS * 512 + k * 1024), 16, 0, 0);
+  };
+  auto next_kept = [&](uint32_t c) -> uint32_t {  // first computed pair at or after c (ngsLD.cpp:270-282 filters)
+    while (c < it.count && !((it.mask >> c) & 1ull)) ++c;
+    return c;
+  };
+
+  uint32_t c = next_kept(0);
+  if (PFB && c < it.count) dma_slice(it.s2_begin + c);
+  while (c < it.count) {
     const uint32_t s2 = it.s2_begin + c;
+    const uint32_t cn = next_kept(c + 1);
+    // per-site scalars are fetched here, before the copy of the next site is started: an ordinary load waited
+    // for later would drain that copy too (vmcnt is in-order)
+    const double m2 = A.maf[s2], mean2 = A.mean_e[s2], rsx2 = A.rsx[s2];
     double P[SLOTS][9];
     uint32_t vbits;
     double sxy;
-    stage_pair<SLOTS, MASKED>(pa, A.planes + (uint64_t)s2 * A.site_stride, A.np, i0, A.n_ind, mean1, A.mean_e[s2], P,
-                              vbits, sxy);
+    if (PFB) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice copied during the previous pair has landed
+      stage_pair<SLOTS, MASKED>(pa, A.np, i0, reinterpret_cast<const double *>(lds_b), (uint32_t)(SLOTS * 64),
+                                (uint32_t)lane, i0, A.n_ind, mean1, mean2, P, vbits, sxy);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // a, b and the scalars are all consumed
+      if (cn < it.count) dma_slice(it.s2_begin + cn);
+    } else {
+      stage_pair<SLOTS, MASKED>(pa, A.np, i0, A.planes + (uint64_t)s2 * A.site_stride, A.np, i0, i0, A.n_ind, mean1,
+                                mean2, P, vbits, sxy);
+    }
     uint32_t x = count_valid<SLOTS>(vbits);
     sxy = wave_sum1(sxy);
     if (WAVES > 1) {
@@ -317,7 +365,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
         xch0[sub][0] = sxy;
         xch0[sub][1] = (double)x;
       }
-      __syncthreads();
+      lds_barrier();
       double sx = 0.0, xs = 0.0;
       for (int w = 0; w < WAVES; ++w) {
         sx += xch0[w][0];
@@ -325,14 +373,13 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
       }
       sxy = sx;
       x = (uint32_t)xs;
-      __syncthreads();
+      lds_barrier();
     }
     double f0, f1, f2, f3;
-    const uint32_t n_iter =
-        em_pair<SLOTS, WAVES, kCheckAll>(P, vbits, x, m1, A.maf[s2], f0, f1, f2, f3, xch, sub, lane, A.status);
+    const uint32_t n_iter = em_pair<SLOTS, WAVES, kCheckAll>(P, vbits, x, m1, m2, f0, f1, f2, f3, xch, sub, lane, A.status);
     if (lane == 0 && sub == 0)
-      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, A.rsx[s2], x,
-                 n_iter);
+      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, rsx2, x, n_iter);
+    c = cn;
   }
 }
 
@@ -345,9 +392,6 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
 // site it will work on NEXT -- the copy flies during the whole EM loop, so the ~2.5 us HBM/Infinity-Cache
 // latency that the direct kernel pays at every pair start is off the critical path.
 // ---------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void glb_void_t;
-
 // Asynchronous copy of one site's planes (SLOTS*1536 B, contiguous) into LDS, 1 KiB per wave-instruction
 // (lane l moves 16 B to lds_dst + k*1024 + l*16).  With `stride` > 1 only chunks k % stride == first are
 // issued (several wavefronts sharing one copy).  A trailing half chunk (odd SLOTS) is issued by lanes 0..31.
@@ -426,8 +470,9 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
     double P[SLOTS][9];
     uint32_t vbits;
     double sxy;
-    stage_pair<SLOTS, MASKED>(reinterpret_cast<const double *>(lds_a), reinterpret_cast<const double *>(lds_b), kNp,
-                              (uint32_t)lane, A.n_ind, mean1, cur.mean, P, vbits, sxy);
+    stage_pair<SLOTS, MASKED>(reinterpret_cast<const double *>(lds_a), kNp, (uint32_t)lane,
+                              reinterpret_cast<const double *>(lds_b), kNp, (uint32_t)lane, (uint32_t)lane, A.n_ind, mean1,
+                              cur.mean, P, vbits, sxy);
     // all ds_reads of the buffer are consumed (P is computed): start the copy of the next site over it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (cn < it.count)

@@ -27,18 +27,18 @@ static hipError_t launch_s(bool masked, bool prefetch, const PairArgs &a, hipStr
       hipLaunchKernelGGL((pair_ld_pf_kernel<SLOTS, false>), grid, block, 0, stream, a);
   } else {
     if (masked)
-      hipLaunchKernelGGL((pair_ld_kernel<SLOTS, 1, true>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((pair_ld_kernel<SLOTS, 1, true, false>), grid, block, 0, stream, a);
     else
-      hipLaunchKernelGGL((pair_ld_kernel<SLOTS, 1, false>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((pair_ld_kernel<SLOTS, 1, false, false>), grid, block, 0, stream, a);
   }
   return hipGetLastError();
 }
 
-hipError_t launch_pair_wn(int slots, int waves, bool masked, const PairArgs &a, hipStream_t stream);
+hipError_t launch_pair_wn(int slots, int waves, bool masked, bool prefetch, const PairArgs &a, hipStream_t stream);
 
 hipError_t launch_pair_kernel(int slots, int waves, bool masked, bool prefetch, const PairArgs &a,
                               hipStream_t stream) {
-  if (waves != 1) return launch_pair_wn(slots, waves, masked, a, stream);
+  if (waves != 1) return launch_pair_wn(slots, waves, masked, prefetch, a, stream);
   switch (slots) {
     case 1: return launch_s<1>(masked, prefetch, a, stream);
     case 2: return launch_s<2>(masked, prefetch, a, stream);
