@@ -69,7 +69,7 @@ struct ngsld_ctx {
   // data
   uint64_t n_sites = 0, n_ind = 0;
   uint32_t np = 0;
-  int slots = 0, waves = 0;
+  PairConfig cfg{};
   bool have_geno = false;
   DevBuf<double> d_planes, d_maf, d_mean, d_sxx, d_stage;
   DevBuf<int> d_status;
@@ -89,7 +89,8 @@ struct ngsld_ctx {
   uint64_t n_items = 0;
 
   // tuning
-  bool prefetch = true;  // n_ind <= 512: LDS-prefetch kernel (NGSLD_PAIR_KERNEL=direct selects the A/B baseline)
+  // kernel family selection for A/B runs: NGSLD_PAIR_KERNEL=direct (no prefetch anywhere) | wave (no row kernel)
+  bool prefetch = true, row_kernel = true;
   uint32_t pairs_per_item = 16;
   uint64_t batch_pairs = 1ull << 23;
 
@@ -134,17 +135,16 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   if (gl == nullptr || n_sites == 0 || n_ind == 0) return fail(c, NGSLD_ERR_INVALID, "empty genotype matrix");
   if (normalised && maf == nullptr) return fail(c, NGSLD_ERR_INVALID, "maf missing");
   if (n_sites >= 0xffffffffull) return fail(c, NGSLD_ERR_UNSUPPORTED, "n_sites must be below 2^32 - 1");
-  int slots, waves;
-  if (!pair_config(n_ind, &slots, &waves))
+  PairConfig cfg;
+  if (!pair_config(n_ind, c->prefetch, c->row_kernel, &cfg))
     return fail(c, NGSLD_ERR_UNSUPPORTED, "n_ind above 4096 is outside the built kernel set");
   HIP_TRY(c, hipSetDevice(c->device));
   c->have_geno = false;
   c->planned = false;
   c->n_sites = n_sites;
   c->n_ind = n_ind;
-  c->slots = slots;
-  c->waves = waves;
-  c->np = (uint32_t)(slots * waves * 64);
+  c->cfg = cfg;
+  c->np = cfg.np;
   const size_t plane_elems = (size_t)n_sites * 3 * c->np;
   HIP_TRY(c, c->d_planes.resize(plane_elems));
   HIP_TRY(c, c->d_maf.resize(n_sites));
@@ -269,7 +269,7 @@ hipError_t timed_launch(ngsld_ctx *c, const PairArgs &a, hipStream_t stream) {
   auto &ev = c->ev_pool[c->ev_used++];
   hipError_t r = hipEventRecord(ev.first, stream);
   if (r != hipSuccess) return r;
-  r = launch_pair_kernel(c->slots, c->waves, c->params.ignore_miss_data != 0, c->prefetch, a, stream);
+  r = launch_pair_kernel(c->cfg, c->params.ignore_miss_data != 0, a, stream);
   if (r != hipSuccess) return r;
   return hipEventRecord(ev.second, stream);
 }
@@ -332,7 +332,10 @@ int ngsld_create(int device, ngsld_ctx **out) {
   ngsld_ctx *c = new (std::nothrow) ngsld_ctx();
   if (c == nullptr) return NGSLD_ERR_NOMEM;
   c->device = device;
-  if (const char *k = std::getenv("NGSLD_PAIR_KERNEL")) c->prefetch = std::strcmp(k, "direct") != 0;
+  if (const char *k = std::getenv("NGSLD_PAIR_KERNEL")) {
+    c->prefetch = std::strcmp(k, "direct") != 0;
+    c->row_kernel = std::strcmp(k, "wave") != 0;
+  }
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
       (e = hipStreamCreate(&c->copy_stream)) != hipSuccess) {
     g_create_error = std::string("stream setup: ") + hipGetErrorString(e);
@@ -430,7 +433,7 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) {
   plan_rows(c->h_pos_dist, c->h_maf, *p, n, c->h_row_end);
   c->h_keep.resize(n);
   for (uint64_t s = 0; s < n; ++s) c->h_keep[s] = (c->h_maf[s] < p->min_maf) ? 0 : 1;  // ngsLD.cpp:270
-  const uint64_t ch = item_span(c->waves, c->prefetch, c->pairs_per_item);
+  const uint64_t ch = item_span(c->cfg, c->pairs_per_item);
   c->h_item_off.resize(n + 1);
   c->h_item_off[0] = 0;
   for (uint64_t s1 = 0; s1 < n; ++s1) {

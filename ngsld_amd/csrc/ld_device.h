@@ -490,13 +490,219 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row kernel (n_ind <= 128): a 16-lane DPP row owns one pair, so a wavefront runs FOUR pairs in lockstep and a
+// 256-thread workgroup sixteen, all of one row s1.  With few individuals the per-iteration bookkeeping
+// (f products, contraction, reduction, convergence test) outweighs the per-individual work; sharing each of
+// those instructions between four pairs is worth more than the lanes lost to lockstep (a row that has
+// converged idles until the slowest of its three neighbours has).
+//   lane = 16*row + r;  individual of (lane, slot j) = 16*j + r;  SLOTS = ceil(n_ind / 16) <= 8;  np = 16*SLOTS
+//   LDS: [row vector a, linear][per wavefront: next-site buffers of its 4 rows, interleaved in 256-byte pieces
+//        because global_load_lds writes wave-base + 16*lane: piece q of row rr sits at q*1024 + rr*256]
+// Values that are wavefront-uniform in the 64-lane kernels (f, the f products, eps) are row-uniform VGPR
+// values here; reductions are 4 DPP steps inside the row, in a fixed order.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v) { return v + dpp_mov<CTRL>(v); }
+
+__device__ __forceinline__ double row_sum(double v) {  // sum over the 16 lanes of a row, result in every lane
+  v = dpp_add<0x128>(v);  // row_ror:8
+  v = dpp_add<0x124>(v);  // row_ror:4
+  v = dpp_add<0x4E>(v);   // quad_perm:[2,3,0,1]
+  v = dpp_add<0xB1>(v);   // quad_perm:[1,0,3,2]
+  return v;
+}
+
+template <int SLOTS, bool MASKED>
+__global__ __launch_bounds__(256, 2) void pair_ld_row_kernel(PairArgs A) {
+  constexpr uint32_t kNp = SLOTS * 16;
+  constexpr int kSiteBytes = (int)kNp * 24;
+  constexpr int kPieces = (kSiteBytes + 255) / 256;         // 256-byte pieces of one site
+  constexpr int kABytes = ((kSiteBytes + 1023) / 1024) * 1024;
+  constexpr int kWaveBuf = kPieces * 1024;                  // four rows interleaved
+  __shared__ __attribute__((aligned(16))) char smem[kABytes + 4 * kWaveBuf + 16];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int row = lane >> 4, rl = lane & 15;
+  const Item it = A.items[blockIdx.x];
+  const uint32_t s1 = it.s1;
+  const double m1 = A.maf[s1];
+  const double mean1 = A.mean_e[s1];
+  const double rsx1 = A.rsx[s1];
+  const uint64_t rec0 = it.first_record - A.out_base;
+  char *lds_a = smem;
+  char *lds_w = smem + kABytes + wave * kWaveBuf;
+  uint32_t *claim = reinterpret_cast<uint32_t *>(smem + kABytes + 4 * kWaveBuf);
+
+  if (threadIdx.x == 0) *claim = 0;
+  // a row claims the next computed pair of the item (maf[s2] / sub-sampling filters live in the mask, ngsLD.cpp:270-282)
+  auto claim_row = [&]() -> uint32_t {
+    uint32_t c;
+    for (;;) {
+      c = 0;
+      if (rl == 0) c = atomicAdd(claim, 1u);
+      c = (uint32_t)__shfl((int)c, lane & 48);
+      if (c >= it.count || ((it.mask >> c) & 1ull)) break;
+    }
+    return c;
+  };
+  // byte offset of individual-slot j, genotype plane g of this lane's row inside the interleaved wave buffer
+  auto b_off = [&](int g, int j) -> uint32_t {
+    const uint32_t o = ((uint32_t)g * kNp + (uint32_t)j * 16u + (uint32_t)rl) * 8u;  // offset inside the site
+    return (o >> 8) * 1024u + (uint32_t)row * 256u + (o & 255u);
+  };
+  // start the copy of site (s2_begin + c) for every row whose c is inside the item: lane (row, rl) moves the
+  // 16 bytes [q*256 + rl*16, +16) of its row's site for q = 0 .. kPieces-1
+  auto dma_rows = [&](uint32_t c) {
+    const bool on = c < it.count;
+    const char *g = reinterpret_cast<const char *>(A.planes + (uint64_t)(it.s2_begin + (on ? c : 0u)) * A.site_stride) +
+                    rl * 16;
+#pragma unroll
+    for (int q = 0; q < kPieces; ++q)
+      if (on && q * 256 + rl * 16 < kSiteBytes)
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(g + q * 256), (lds_void_t *)(lds_w + q * 1024), 16, 0, 0);
+  };
+  struct SiteScalars {
+    double maf, mean, rsx;
+  };
+  auto load_scalars = [&](uint32_t c) -> SiteScalars {
+    SiteScalars v{0.5, 0.0, 0.0};
+    if (c < it.count) {
+      const uint32_t s2 = it.s2_begin + c;
+      v.maf = A.maf[s2];
+      v.mean = A.mean_e[s2];
+      v.rsx = A.rsx[s2];
+    }
+    return v;
+  };
+
+  // the row vector: linear copy, 1 KiB per wave-instruction, chunks dealt round-robin to the four wavefronts
+  {
+    const char *g = reinterpret_cast<const char *>(A.planes + (uint64_t)s1 * A.site_stride) + lane * 16;
+#pragma unroll
+    for (int k = 0; k < kABytes / 1024; ++k)
+      if ((k & 3) == wave && k * 1024 + lane * 16 < kSiteBytes)
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(g + k * 1024), (lds_void_t *)(lds_a + k * 1024), 16, 0, 0);
+  }
+  __syncthreads();  // claim counter initialised
+  uint32_t c = claim_row();
+  SiteScalars cur = load_scalars(c);
+  dma_rows(c);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // row vector complete in LDS
+
+  while (__any(c < it.count)) {
+    const bool active = c < it.count;
+    const uint32_t cn = active ? claim_row() : c;
+    const SiteScalars nxt = load_scalars(cn);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the four site copies issued a generation ago have landed
+
+    // ---- stage: P = a (x) b per lane, validity, Pearson cross moment (row sums) ----
+    double P[SLOTS][9];
+    uint32_t vbits = 0;
+    double sxy = 0.0;
+    const double *la = reinterpret_cast<const double *>(lds_a);
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+      const uint32_t i = (uint32_t)j * 16u + (uint32_t)rl;
+      const double a0 = la[i], a1 = la[kNp + i], a2 = la[2 * kNp + i];
+      const double b0 = *reinterpret_cast<const double *>(lds_w + b_off(0, j));
+      const double b1 = *reinterpret_cast<const double *>(lds_w + b_off(1, j));
+      const double b2 = *reinterpret_cast<const double *>(lds_w + b_off(2, j));
+      const bool inb = i < A.n_ind;
+      bool ok = inb && active;
+      if (MASKED) ok = ok && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);  // gen_func.cpp:1089
+      vbits |= (ok ? 1u : 0u) << j;
+      P[j][0] = a0 * b0; P[j][1] = a0 * b1; P[j][2] = a0 * b2;
+      P[j][3] = a1 * b0; P[j][4] = a1 * b1; P[j][5] = a1 * b2;
+      P[j][6] = a2 * b0; P[j][7] = a2 * b1; P[j][8] = a2 * b2;
+      const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;   // ngsLD.cpp:113, :290
+      const double c2 = inb ? fma(2.0, b2, b1) - cur.mean : 0.0;
+      sxy = fma(c1, c2, sxy);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // buffers consumed: start the next generation's copies
+    dma_rows(cn);
+    uint32_t x = 0;  // individuals with data in this row's pair (gen_func.cpp:1091), integer exact
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) x += (uint32_t)__popcll((__ballot((vbits >> j) & 1u) >> (row * 16)) & 0xffffull);
+    sxy = row_sum(sxy);
+
+    // ---- haplo_freq (gen_func.cpp:1027-1059), four pairs in lockstep ----
+    const double m2 = cur.maf;
+    double f0 = (1 - m1) * (1 - m2), f1 = (1 - m1) * m2, f2 = m1 * (1 - m2), f3 = m1 * m2;
+    if (active && (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1)) {
+      if (rl == 0) atomicExch(A.status, (int)NGSLD_ERR_MAF_RANGE);
+      f0 = f1 = f2 = f3 = __builtin_nan("");
+    }
+    const double inv_x = 1.0 / (double)x;
+    bool done = !active;
+    uint32_t n_iter = (uint32_t)kIterMax;
+    for (uint32_t itn = 0; itn < (uint32_t)kIterMax; ++itn) {
+      const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
+      const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
+      const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
+      double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
+#pragma unroll
+      for (int j = 0; j < SLOTS; ++j) {
+        if ((vbits >> j) & 1u) {
+          double s = p00 * P[j][0];
+          s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
+          s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
+          s = fma(p22, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(p33, P[j][8], s);
+          const double r = rcp_refined(s);
+          R0 = fma(P[j][0], r, R0); R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
+          R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
+          R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
+        }
+      }
+      const double t0 = row_sum(fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0))));
+      const double t1 = row_sum(fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1))));
+      const double t2 = row_sum(fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3))));
+      const double t3 = row_sum(fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4))));
+      const double n0 = t0 * inv_x, n1 = t1 * inv_x, n2 = t2 * inv_x, n3 = t3 * inv_x;
+      const double sn = (n0 + n1) + (n2 + n3);
+      const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
+      if (!done) {
+        if (!(sn < 2.0)) {  // the reference's all-NaN step: "converges" at this iteration (see em_pair)
+          f0 = f1 = f2 = f3 = __builtin_nan("");
+          done = true;
+          n_iter = itn;
+        } else {
+          f0 = n0; f1 = n1; f2 = n2; f3 = n3;
+          if (eps < kEpsilon) {  // gen_func.cpp:1054-1055
+            done = true;
+            n_iter = itn;
+          }
+        }
+      }
+      if (__all(done)) break;
+    }
+
+    if (active && rl == 0)
+      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, cur.rsx, x,
+                 n_iter);
+    c = cn;
+    cur = nxt;
+  }
+}
+
 // host-callable launchers, defined in ld_pair_w1.hip / ld_pair_wn.hip
-hipError_t launch_pair_kernel(int slots, int waves, bool masked, bool prefetch, const PairArgs &args,
-                              hipStream_t stream);
-bool pair_config(uint64_t n_ind, int *slots, int *waves);
-// s2 sites per work item: the prefetch kernel's item is shared by four wavefronts
-inline uint32_t item_span(int waves, bool prefetch, uint32_t pairs_per_item) {
-  return (waves == 1 && prefetch) ? 4u * pairs_per_item : pairs_per_item;
+// Kernel families: kRow = 16 lanes per pair (n_ind <= 128), kWave = one wavefront per pair with the row vector shared
+// in LDS (n_ind <= 512), kMulti = 2..8 wavefronts per pair; kDirect = kWave/kMulti shapes without any prefetch (A/B).
+enum PairKernel { kRow = 0, kWave = 1, kMulti = 2, kDirect = 3 };
+struct PairConfig {
+  int kernel;   // PairKernel
+  int slots;    // individuals per lane
+  int waves;    // wavefronts per pair
+  uint32_t np;  // padded individuals per genotype plane
+};
+bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg);
+hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs &args, hipStream_t stream);
+// candidate s2 sites per work item: kRow / kWave items are shared by the four wavefronts of a workgroup
+inline uint32_t item_span(const PairConfig &cfg, uint32_t pairs_per_item) {
+  const uint32_t span = (cfg.kernel == kRow || cfg.kernel == kWave) ? 4u * pairs_per_item : pairs_per_item;
+  return span > 64u ? 64u : span;
 }
 
 }  // namespace ngsld

@@ -3,24 +3,38 @@
 
 namespace ngsld {
 
-// n_ind -> (individuals per lane, wavefronts per pair).  One wavefront holds up to 8*64 = 512
-// individuals as 18*8 = 144 VGPRs of P; above that 2..8 wavefronts of a workgroup share the pair.
-bool pair_config(uint64_t n_ind, int *slots, int *waves) {
+// n_ind -> kernel family and shape.  16 lanes x 8 slots cover 128 individuals (row kernel); one wavefront
+// holds up to 8*64 = 512 individuals as 18*8 = 144 VGPRs of P; above that 2..8 wavefronts share the pair.
+bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg) {
   if (n_ind == 0 || n_ind > 4096) return false;  // 8 wavefronts x 8 slots x 64 lanes
+  if (allow_prefetch && allow_row && n_ind <= 128) {
+    cfg->kernel = kRow;
+    cfg->waves = 1;
+    cfg->slots = (int)((n_ind + 15) / 16);
+    cfg->np = (uint32_t)cfg->slots * 16u;
+    return true;
+  }
   int w = 1;
   while ((n_ind + 64ull * w - 1) / (64ull * w) > 8) w *= 2;
-  *waves = w;
-  *slots = (int)((n_ind + 64ull * w - 1) / (64ull * w));
+  cfg->waves = w;
+  cfg->slots = (int)((n_ind + 64ull * w - 1) / (64ull * w));
+  cfg->np = (uint32_t)(cfg->slots * w * 64);
+  cfg->kernel = !allow_prefetch ? kDirect : (w == 1 ? kWave : kMulti);
   return true;
 }
 
 template <int SLOTS>
-static hipError_t launch_s(bool masked, bool prefetch, const PairArgs &a, hipStream_t stream) {
-  const uint64_t blocks = prefetch ? a.n_items : (a.n_items + 3) / 4;
+static hipError_t launch_s(int kernel, bool masked, const PairArgs &a, hipStream_t stream) {
+  const uint64_t blocks = kernel == kDirect ? (a.n_items + 3) / 4 : a.n_items;
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   const dim3 grid((unsigned)blocks), block(256);
-  if (prefetch) {
+  if (kernel == kRow) {
+    if (masked)
+      hipLaunchKernelGGL((pair_ld_row_kernel<SLOTS, true>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((pair_ld_row_kernel<SLOTS, false>), grid, block, 0, stream, a);
+  } else if (kernel == kWave) {
     if (masked)
       hipLaunchKernelGGL((pair_ld_pf_kernel<SLOTS, true>), grid, block, 0, stream, a);
     else
@@ -36,18 +50,17 @@ static hipError_t launch_s(bool masked, bool prefetch, const PairArgs &a, hipStr
 
 hipError_t launch_pair_wn(int slots, int waves, bool masked, bool prefetch, const PairArgs &a, hipStream_t stream);
 
-hipError_t launch_pair_kernel(int slots, int waves, bool masked, bool prefetch, const PairArgs &a,
-                              hipStream_t stream) {
-  if (waves != 1) return launch_pair_wn(slots, waves, masked, prefetch, a, stream);
-  switch (slots) {
-    case 1: return launch_s<1>(masked, prefetch, a, stream);
-    case 2: return launch_s<2>(masked, prefetch, a, stream);
-    case 3: return launch_s<3>(masked, prefetch, a, stream);
-    case 4: return launch_s<4>(masked, prefetch, a, stream);
-    case 5: return launch_s<5>(masked, prefetch, a, stream);
-    case 6: return launch_s<6>(masked, prefetch, a, stream);
-    case 7: return launch_s<7>(masked, prefetch, a, stream);
-    case 8: return launch_s<8>(masked, prefetch, a, stream);
+hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs &a, hipStream_t stream) {
+  if (cfg.waves != 1) return launch_pair_wn(cfg.slots, cfg.waves, masked, cfg.kernel == kMulti, a, stream);
+  switch (cfg.slots) {
+    case 1: return launch_s<1>(cfg.kernel, masked, a, stream);
+    case 2: return launch_s<2>(cfg.kernel, masked, a, stream);
+    case 3: return launch_s<3>(cfg.kernel, masked, a, stream);
+    case 4: return launch_s<4>(cfg.kernel, masked, a, stream);
+    case 5: return launch_s<5>(cfg.kernel, masked, a, stream);
+    case 6: return launch_s<6>(cfg.kernel, masked, a, stream);
+    case 7: return launch_s<7>(cfg.kernel, masked, a, stream);
+    case 8: return launch_s<8>(cfg.kernel, masked, a, stream);
     default: return hipErrorInvalidValue;
   }
 }
