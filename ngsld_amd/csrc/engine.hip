@@ -280,6 +280,7 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
   a.site_stride = 3ull * c->np;
   a.np = c->np;
   a.n_ind = (uint32_t)c->n_ind;
+  a.inv_n = 1.0 / (double)c->n_ind;
   a.maf = c->d_maf.p;
   a.mean_e = c->d_mean.p;
   a.rsx = c->d_sxx.p;

@@ -32,6 +32,7 @@ struct PairArgs {
   uint64_t site_stride;  // 3 * np
   uint32_t np;
   uint32_t n_ind;
+  double inv_n;          // 1.0 / n_ind (the EM's 1/x when every individual has data)
   const double *maf;     // [n_sites] est_maf
   const double *mean_e;  // [n_sites] mean expected genotype
   const double *rsx;     // [n_sites] 1 / sqrt(sum (e - mean)^2)  (inf for a constant site)
@@ -142,7 +143,7 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // Stage both sites of one pair: P = a (x) b for this lane's SLOTS individuals, their validity bits and the
 // Pearson cross moment.  pa / pb point at a site's three planes [3][np] -- in HBM/L2 (direct kernel) or in
 // LDS (prefetch kernel); after inlining the compiler knows which and emits global_load or ds_read.
-template <int SLOTS, bool MASKED>
+template <int SLOTS, bool MASKED, bool ONLY_LAST = false>  // ONLY_LAST: only the last slot can hold padding lanes
 __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint32_t ia0, const double *pb, uint32_t npb,
                                            uint32_t ib0, uint32_t ind0, uint32_t n_ind, double mean1, double mean2,
                                            double (&P)[SLOTS][9], uint32_t &vbits, double &sxy) {
@@ -154,7 +155,7 @@ __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint3
     const uint32_t ia = ia0 + (uint32_t)j * 64, ib = ib0 + (uint32_t)j * 64;
     const double a0 = pa[ia], a1 = pa[npa + ia], a2 = pa[2 * npa + ia];
     const double b0 = pb[ib], b1 = pb[npb + ib], b2 = pb[2 * npb + ib];
-    const bool inb = ind0 + (uint32_t)j * 64 < n_ind;
+    const bool inb = (ONLY_LAST && j < SLOTS - 1) ? true : ind0 + (uint32_t)j * 64 < n_ind;
     bool ok = inb;
     if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);  // gen_func.cpp:1089
     vbits |= (ok ? 1u : 0u) << j;
@@ -181,7 +182,7 @@ __device__ __forceinline__ uint32_t count_valid(uint32_t vbits) {
 //   CHECK_ALL: every slot may hold padding / missing individuals (otherwise only the last one can)
 //   WAVES > 1: the pair is spread over WAVES wavefronts, partial sums meet in xch (LDS, double buffered)
 template <int SLOTS, int WAVES, bool CHECK_ALL>
-__device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_t vbits, uint32_t x, double m1,
+__device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_t vbits, double inv_x, double m1,
                                             double m2, double &f0, double &f1, double &f2, double &f3,
                                             double (*xch)[WAVES][4], int sub, int lane, int *status) {
   f0 = (1 - m1) * (1 - m2); f1 = (1 - m1) * m2; f2 = m1 * (1 - m2); f3 = m1 * m2;  // gen_func.cpp:1034-1037
@@ -191,8 +192,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   }
   // f = ff/(2x) (gen_func.cpp:1108-1109).  The renormalisation that follows there (:1112-1113) divides
   // by sum_k ff_k/(2x) = (1/x) sum_i s_i/s_i = 1 up to rounding, and the EM map does not depend on the
-  // scale of f, so it is not repeated per iteration.  x == 0 gives 0 * inf = NaN like the reference's 0/0.
-  const double inv_x = 1.0 / (double)x;
+  // scale of f, so it is not repeated per iteration.  inv_x = 1/x; x == 0 gives 0 * inf = NaN like the reference's 0/0.
   bool bad = false;
   uint32_t n_iter = 0;
   for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
@@ -376,7 +376,8 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
       lds_barrier();
     }
     double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair<SLOTS, WAVES, kCheckAll>(P, vbits, x, m1, m2, f0, f1, f2, f3, xch, sub, lane, A.status);
+    const uint32_t n_iter = em_pair<SLOTS, WAVES, kCheckAll>(P, vbits, 1.0 / (double)x, m1, m2, f0, f1, f2, f3, xch, sub,
+                                                             lane, A.status);
     if (lane == 0 && sub == 0)
       write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, rsx2, x, n_iter);
     c = cn;
@@ -470,17 +471,19 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
     double P[SLOTS][9];
     uint32_t vbits;
     double sxy;
-    stage_pair<SLOTS, MASKED>(reinterpret_cast<const double *>(lds_a), kNp, (uint32_t)lane,
-                              reinterpret_cast<const double *>(lds_b), kNp, (uint32_t)lane, (uint32_t)lane, A.n_ind, mean1,
-                              cur.mean, P, vbits, sxy);
+    stage_pair<SLOTS, MASKED, !MASKED>(reinterpret_cast<const double *>(lds_a), kNp, (uint32_t)lane,
+                                       reinterpret_cast<const double *>(lds_b), kNp, (uint32_t)lane, (uint32_t)lane,
+                                       A.n_ind, mean1, cur.mean, P, vbits, sxy);
     // all ds_reads of the buffer are consumed (P is computed): start the copy of the next site over it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (cn < it.count)
       dma_site_to_lds<SLOTS>(A.planes + (uint64_t)(it.s2_begin + cn) * A.site_stride, lds_b, lane, 0, 1);
-    const uint32_t x = count_valid<SLOTS>(vbits);
+    // without --ignore_miss_data every individual counts: x = n_ind, 1/x comes precomputed (same IEEE quotient)
+    const uint32_t x = MASKED ? count_valid<SLOTS>(vbits) : A.n_ind;
+    const double inv_x = MASKED ? 1.0 / (double)x : A.inv_n;
     sxy = wave_sum1(sxy);
     double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, x, m1, cur.maf, f0, f1, f2, f3,
+    const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, inv_x, m1, cur.maf, f0, f1, f2, f3,
                                                       (double (*)[1][4]) nullptr, 0, lane, A.status);
     if (lane == 0)
       write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, cur.rsx, x,

@@ -143,3 +143,31 @@ def test_rnd_sample_streams(engine, rnd, seed):
     rec = check_against_oracle(engine, raw, pd, max_kb=8, rnd_sample=rnd, seed=seed)
     full = check_against_oracle(engine, raw, pd, max_kb=8)
     assert (len(rec) == len(full)) == (rnd == 1.0)
+
+
+@pytest.mark.parametrize("n_sites,n_ind,seed", [
+    (2, 1, 201), (3, 2, 202), (1, 40, 203),            # degenerate sizes (one site: no pair at all)
+    (30, 16, 204), (30, 17, 205),                      # row kernel: one full slot / one lane into the second
+    (20, 128, 206), (20, 129, 207),                    # last shape of the row kernel / first of the wavefront kernel
+    (40, 130, 208), (16, 448, 209),                    # wavefront kernel, partial last slot
+])
+def test_kernel_family_boundaries(engine, n_sites, n_ind, seed):
+    raw = synth.make_gl_numpy(n_sites, n_ind, seed, depth=6.0)
+    rec = check_against_oracle(engine, raw)
+    assert len(rec) == n_sites * (n_sites - 1) // 2
+
+
+def test_long_rows_and_many_items(engine):
+    """All pairs of 3000 sites x 20 ind: rows of up to 2999 candidates = 47 items each, claimed dynamically."""
+    raw = synth.make_gl_numpy(3000, 20, 211, depth=3.0)
+    engine.set_geno_raw(raw)
+    engine.set_pos_dist(None)
+    n = engine.plan(extend_out=True)
+    assert n == 3000 * 2999 // 2
+    s1, s2, std, ext = engine.run()
+    o = orc.Oracle(raw[[5, 2990]], None)           # spot-check two far-apart sites against the oracle
+    r = o.run()[0]
+    k = int(np.flatnonzero((s1 == 5) & (s2 == 2990))[0])
+    assert ext["n_iter"][k] == r["n_iter"] and np.all(close(ext["hap"][k], r["hap"]))
+    assert np.all(close([std["D"][k], std["r2"][k], std["r2_ExpG"][k]], [r["D"], r["r2"], r["r2pear"]]))
+    assert float(np.abs(ext["hap"].sum(axis=1) - 1).max()) < 1e-12
