@@ -53,8 +53,10 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(raw_head: np.ndarray, pos_dist_head: np.ndarray, max_kb: int, target_s: float) -> dict:
-    """Oracle (kind 'port') on every host core, rows [0, R) of the bench matrix with R sized for ~target_s."""
+def cpu_baseline(raw_head: np.ndarray, pos_dist_head: np.ndarray, max_kb: int, target_s: float, gpu_rows=None) -> dict:
+    """Oracle (kind 'port') on every host core, rows [0, R) of the bench matrix with R sized for ~target_s.
+    gpu_rows(R) -> (#pairs, sum of finite r2, sum of executed EM iterations) of the GPU records of the same rows:
+    a whole-sample parity check (the iteration totals must be EQUAL, i.e. no convergence-threshold flip)."""
     from oracle import orc
     cores = os.cpu_count() or 1
     n_have = raw_head.shape[0]
@@ -70,9 +72,16 @@ def cpu_baseline(raw_head: np.ndarray, pos_dist_head: np.ndarray, max_kb: int, t
     t0 = time.perf_counter()
     n, chk, iters = o.bench(0, rows)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"rows 0..{rows} of the same matrix ({n} pairs, {dt:.1f} s, mean executed EM iterations "
-                      f"{iters / max(n, 1):.2f}); oracle/liborc.so, {cores} pthreads"}
+    out = {"value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+           "sample": f"rows 0..{rows} of the same matrix ({n} pairs, {dt:.1f} s, mean executed EM iterations "
+                     f"{iters / max(n, 1):.2f}); oracle/liborc.so, {cores} pthreads"}
+    if gpu_rows is not None:
+        gn, gsum, giters = gpu_rows(rows)
+        out["parity_on_sample"] = {"pairs": int(gn), "pairs_equal": bool(gn == n),
+                                   "executed_iterations_cpu": int(iters), "executed_iterations_gpu": int(giters),
+                                   "executed_iterations_equal": bool(giters == iters),
+                                   "abs_diff_sum_r2": abs(gsum - chk), "sum_r2_cpu": chk}
+    return out
 
 
 def main():
@@ -240,8 +249,14 @@ def main():
                                                "(FMA counted as 2 flop); the binding roofline"}},
         }
         if raw_head is not None:
+            def gpu_rows(rows):
+                k = int(row_off[rows] - row_off[0])
+                r2 = d_std.view(torch.float64).view(-1, 4)[:k, 3]
+                it = ext_i32[:k, 9].to(torch.int64)
+                fin = torch.isfinite(r2)
+                return k, float(r2[fin].sum()), int(torch.clamp(it + 1, max=100).sum())
             out["cpu_baseline"] = cpu_baseline(raw_head, pos_dist[:raw_head.shape[0]].copy(), args.max_kb,
-                                               args.cpu_seconds)
+                                               args.cpu_seconds, gpu_rows)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
