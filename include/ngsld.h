@@ -41,7 +41,7 @@ enum {
   NGSLD_ERR_NAN = -4,        /* "NaN found! Is the file format correct?" (read_data.cpp:42-45) */
   NGSLD_ERR_MAF_RANGE = -5,  /* "invalid allele frequencies" (gen_func.cpp:1030-1031) */
   NGSLD_ERR_SINK = -6,       /* the sink callback returned non-zero */
-  NGSLD_ERR_UNSUPPORTED = -7 /* problem shape outside the built kernel set (n_ind > 4096) */
+  NGSLD_ERR_UNSUPPORTED = -7 /* problem shape outside the supported range (n_sites or n_ind >= 2^32 - 64) */
 };
 
 /* The fields of `params` (ngsLD.hpp:11-44) that calc_pair_LD reads. */

@@ -137,7 +137,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   if (n_sites >= 0xffffffffull) return fail(c, NGSLD_ERR_UNSUPPORTED, "n_sites must be below 2^32 - 1");
   PairConfig cfg;
   if (!pair_config(n_ind, c->prefetch, c->row_kernel, &cfg))
-    return fail(c, NGSLD_ERR_UNSUPPORTED, "n_ind above 4096 is outside the built kernel set");
+    return fail(c, NGSLD_ERR_UNSUPPORTED, "n_ind is outside the supported range");
   HIP_TRY(c, hipSetDevice(c->device));
   c->have_geno = false;
   c->planned = false;

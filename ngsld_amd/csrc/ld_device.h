@@ -690,10 +690,128 @@ __global__ __launch_bounds__(256, 2) void pair_ld_row_kernel(PairArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming kernel (n_ind > 4096): no limit on the number of individuals.  One 256-thread workgroup per pair at a
+// time; wavefront w takes the 64-individual blocks w, w+4, w+8, ...  P does not fit in registers any more, so
+// every EM iteration re-reads both site vectors (from L2: a pair's two vectors are 48*n_ind bytes) and forms
+//   s = sum_g1 a[g1] * (sum_g2 W[g1][g2] b[g2]),   R[g1][g2] += (r a[g1]) * b[g2]
+// on the fly: 24 f64 VALU + rcp + 6 loads per individual and iteration instead of 21 + rcp from registers.
+// Same reduction order rules as the other kernels (fixed, deterministic).
+// ---------------------------------------------------------------------------------------------
+template <bool MASKED>
+__global__ __launch_bounds__(256, 2) void pair_ld_stream_kernel(PairArgs A) {
+  __shared__ double xch[2][4][4];
+  __shared__ double xch0[4][2];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const Item it = A.items[blockIdx.x];
+  const uint32_t s1 = it.s1;
+  const double m1 = A.maf[s1];
+  const double mean1 = A.mean_e[s1];
+  const double rsx1 = A.rsx[s1];
+  const uint64_t rec0 = it.first_record - A.out_base;
+  const double *pa = A.planes + (uint64_t)s1 * A.site_stride;
+  const uint32_t np = A.np;
+  const uint32_t n_blocks = np / 64;
+
+  for (uint32_t c = 0; c < it.count; ++c) {
+    if (!((it.mask >> c) & 1ull)) continue;  // ngsLD.cpp:270-282
+    const uint32_t s2 = it.s2_begin + c;
+    const double *pb = A.planes + (uint64_t)s2 * A.site_stride;
+    const double m2 = A.maf[s2], mean2 = A.mean_e[s2], rsx2 = A.rsx[s2];
+
+    // ---- pass 0: individuals with data, Pearson cross moment ----
+    uint32_t x = 0;
+    double sxy = 0.0;
+    for (uint32_t b = (uint32_t)wave; b < n_blocks; b += 4) {
+      const uint32_t i = b * 64 + (uint32_t)lane;
+      const double a0 = pa[i], a1 = pa[np + i], a2 = pa[2 * np + i];
+      const double b0 = pb[i], b1 = pb[np + i], b2 = pb[2 * np + i];
+      const bool inb = i < A.n_ind;
+      bool ok = inb;
+      if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);
+      x += (uint32_t)__popcll(__ballot(ok));
+      const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;
+      const double c2 = inb ? fma(2.0, b2, b1) - mean2 : 0.0;
+      sxy = fma(c1, c2, sxy);
+    }
+    sxy = wave_sum1(sxy);
+    if (lane == 0) {
+      xch0[wave][0] = sxy;
+      xch0[wave][1] = (double)x;
+    }
+    __syncthreads();
+    sxy = ((xch0[0][0] + xch0[1][0]) + xch0[2][0]) + xch0[3][0];
+    x = (uint32_t)(((xch0[0][1] + xch0[1][1]) + xch0[2][1]) + xch0[3][1]);
+    __syncthreads();
+
+    // ---- haplo_freq (gen_func.cpp:1027-1059) ----
+    double f0 = (1 - m1) * (1 - m2), f1 = (1 - m1) * m2, f2 = m1 * (1 - m2), f3 = m1 * m2;
+    if (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1) {
+      if (threadIdx.x == 0) atomicExch(A.status, (int)NGSLD_ERR_MAF_RANGE);
+      f0 = f1 = f2 = f3 = __builtin_nan("");
+    }
+    const double inv_x = 1.0 / (double)x;
+    bool bad = false;
+    uint32_t n_iter = 0;
+    for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
+      const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
+      const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
+      const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
+      double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
+      for (uint32_t b = (uint32_t)wave; b < n_blocks; b += 4) {
+        const uint32_t i = b * 64 + (uint32_t)lane;
+        const double a0 = pa[i], a1 = pa[np + i], a2 = pa[2 * np + i];
+        const double b0 = pb[i], b1 = pb[np + i], b2 = pb[2 * np + i];
+        bool ok = i < A.n_ind;
+        if (MASKED) ok = ok && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);
+        if (ok) {
+          const double v0 = fma(p11, b2, fma(w1, b1, p00 * b0));  // sum_g2 W[0][g2] b[g2]
+          const double v1 = fma(w5, b2, fma(w4, b1, w3 * b0));
+          const double v2 = fma(p33, b2, fma(w7, b1, p22 * b0));
+          const double s = fma(a2, v2, fma(a1, v1, a0 * v0));
+          const double r = rcp_refined(s);
+          const double r0 = r * a0, r1 = r * a1, r2 = r * a2;
+          R0 = fma(r0, b0, R0); R1 = fma(r0, b1, R1); R2 = fma(r0, b2, R2);
+          R3 = fma(r1, b0, R3); R4 = fma(r1, b1, R4); R5 = fma(r1, b2, R5);
+          R6 = fma(r2, b0, R6); R7 = fma(r2, b1, R7); R8 = fma(r2, b2, R8);
+        }
+      }
+      double t0 = fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0)));
+      double t1 = fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1)));
+      double t2 = fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3)));
+      double t3 = fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4)));
+      wave_sum4(t0, t1, t2, t3);
+      const int par = (int)(n_iter & 1u);
+      if (lane == 0) {
+        xch[par][wave][0] = t0; xch[par][wave][1] = t1; xch[par][wave][2] = t2; xch[par][wave][3] = t3;
+      }
+      __syncthreads();
+      t0 = ((xch[par][0][0] + xch[par][1][0]) + xch[par][2][0]) + xch[par][3][0];
+      t1 = ((xch[par][0][1] + xch[par][1][1]) + xch[par][2][1]) + xch[par][3][1];
+      t2 = ((xch[par][0][2] + xch[par][1][2]) + xch[par][2][2]) + xch[par][3][2];
+      t3 = ((xch[par][0][3] + xch[par][1][3]) + xch[par][2][3]) + xch[par][3][3];
+      const double n0 = t0 * inv_x, n1 = t1 * inv_x, n2 = t2 * inv_x, n3 = t3 * inv_x;
+      const double sn = (n0 + n1) + (n2 + n3);
+      if (__builtin_amdgcn_readfirstlane((int)!(sn < 2.0))) {  // the reference's all-NaN step (see em_pair)
+        bad = true;
+        break;
+      }
+      const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
+      f0 = n0; f1 = n1; f2 = n2; f3 = n3;
+      if (__builtin_amdgcn_readfirstlane((int)(eps < kEpsilon))) break;
+    }
+    if (bad) f0 = f1 = f2 = f3 = __builtin_nan("");
+    if (threadIdx.x == 0)
+      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, rsx2, x, n_iter);
+  }
+}
+
 // host-callable launchers, defined in ld_pair_w1.hip / ld_pair_wn.hip
 // Kernel families: kRow = 16 lanes per pair (n_ind <= 128), kWave = one wavefront per pair with the row vector shared
-// in LDS (n_ind <= 512), kMulti = 2..8 wavefronts per pair; kDirect = kWave/kMulti shapes without any prefetch (A/B).
-enum PairKernel { kRow = 0, kWave = 1, kMulti = 2, kDirect = 3 };
+// in LDS (n_ind <= 512), kMulti = 2..8 wavefronts per pair (n_ind <= 4096), kStream = any n_ind, vectors re-read every
+// iteration; kDirect = kWave/kMulti shapes without any prefetch (A/B).
+enum PairKernel { kRow = 0, kWave = 1, kMulti = 2, kDirect = 3, kStream = 4 };
 struct PairConfig {
   int kernel;   // PairKernel
   int slots;    // individuals per lane

@@ -6,7 +6,14 @@ namespace ngsld {
 // n_ind -> kernel family and shape.  16 lanes x 8 slots cover 128 individuals (row kernel); one wavefront
 // holds up to 8*64 = 512 individuals as 18*8 = 144 VGPRs of P; above that 2..8 wavefronts share the pair.
 bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg) {
-  if (n_ind == 0 || n_ind > 4096) return false;  // 8 wavefronts x 8 slots x 64 lanes
+  if (n_ind == 0 || n_ind >= 0xffffffc0ull) return false;
+  if (n_ind > 4096) {  // beyond 8 wavefronts x 8 slots x 64 lanes: streaming kernel, one workgroup per pair
+    cfg->kernel = kStream;
+    cfg->waves = 4;
+    cfg->slots = 0;
+    cfg->np = (uint32_t)((n_ind + 63) / 64 * 64);
+    return true;
+  }
   if (allow_prefetch && allow_row && n_ind <= 128) {
     cfg->kernel = kRow;
     cfg->waves = 1;
@@ -51,6 +58,15 @@ static hipError_t launch_s(int kernel, bool masked, const PairArgs &a, hipStream
 hipError_t launch_pair_wn(int slots, int waves, bool masked, bool prefetch, const PairArgs &a, hipStream_t stream);
 
 hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs &a, hipStream_t stream) {
+  if (cfg.kernel == kStream) {
+    if (a.n_items == 0) return hipSuccess;
+    if (a.n_items > 0x7fffffffull) return hipErrorInvalidValue;
+    if (masked)
+      hipLaunchKernelGGL((pair_ld_stream_kernel<true>), dim3((unsigned)a.n_items), dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL((pair_ld_stream_kernel<false>), dim3((unsigned)a.n_items), dim3(256), 0, stream, a);
+    return hipGetLastError();
+  }
   if (cfg.waves != 1) return launch_pair_wn(cfg.slots, cfg.waves, masked, cfg.kernel == kMulti, a, stream);
   switch (cfg.slots) {
     case 1: return launch_s<1>(cfg.kernel, masked, a, stream);

@@ -171,3 +171,45 @@ def test_long_rows_and_many_items(engine):
     assert ext["n_iter"][k] == r["n_iter"] and np.all(close(ext["hap"][k], r["hap"]))
     assert np.all(close([std["D"][k], std["r2"][k], std["r2_ExpG"][k]], [r["D"], r["r2"], r["r2pear"]]))
     assert float(np.abs(ext["hap"].sum(axis=1) - 1).max()) < 1e-12
+
+
+@pytest.mark.parametrize("n_sites,n_ind,seed,ignore", [(6, 4097, 301, False), (5, 5000, 302, True), (4, 9001, 303, False)])
+def test_streaming_kernel_large_cohorts(engine, n_sites, n_ind, seed, ignore):
+    """n_ind > 4096: the streaming kernel (site vectors re-read every EM iteration)."""
+    raw = synth.make_gl_numpy(n_sites, n_ind, seed, depth=8.0)
+    if ignore:
+        raw[np.random.default_rng(seed).random((n_sites, n_ind)) < 0.05] = 1.0 / 3.0
+    check_against_oracle(engine, raw, ignore_miss=ignore)
+
+
+def test_api_error_paths(engine):
+    from ngsld_amd import capi
+    raw = synth.make_gl_numpy(8, 10, 401, depth=4.0)
+    fresh = capi.Engine(0)
+    try:
+        with pytest.raises(capi.NgsldError) as e:
+            fresh.plan()
+        assert e.value.code == capi.ERR_INVALID
+        bad = raw.copy()
+        bad[2, 3, :] = -1.0
+        with pytest.raises(capi.NgsldError) as e:
+            fresh.set_geno_raw(bad)
+        assert e.value.code == capi.ERR_NAN and "NaN found" in e.value.msg
+        fresh.set_geno_raw(raw)
+        with pytest.raises(capi.NgsldError) as e:
+            fresh.plan(max_kb_dist=5)                       # distance filter without positions (parse_args.cpp:174)
+        assert "position file necessary" in e.value.msg
+        with pytest.raises(capi.NgsldError) as e:
+            fresh.plan(min_maf=1.5)
+        assert "minimum allele frequency" in e.value.msg
+        with pytest.raises(capi.NgsldError) as e:
+            fresh.set_geno_raw(raw, call_geno=(0.9, 0.1))   # gen_func.cpp:887
+        assert "missing data threshold" in e.value.msg
+        fresh.set_geno_raw(raw)
+        fresh.set_pos_dist(None)
+        assert fresh.plan() == 28
+        with pytest.raises(capi.NgsldError) as e:
+            fresh.run(0, 99)
+        assert e.value.code == capi.ERR_INVALID
+    finally:
+        fresh.close()
