@@ -53,6 +53,9 @@ typedef struct {
   int32_t extend_out;        /* also produce ngsld_rec_ext */
   double rnd_sample;         /* ngsLD.cpp:277: keep a pair iff its Tausworthe draw <= rnd_sample; 0 or 1 = keep all */
   uint64_t seed;             /* --seed of the master gsl_rng_taus stream (ngsLD.cpp:69-70); used iff rnd_sample < 1 */
+  uint64_t first_row;        /* global index of this context's site 0 when it holds a slab of a larger matrix (multi-GPU
+                                row sharding): that many draws of the master stream are skipped so that every row gets
+                                the seed it has in the single-process run (ngsLD.cpp:165-166).  0 otherwise. */
 } ngsld_params;
 
 /* Standard columns computed per pair (ngsLD.cpp:290-306): 32 bytes. */

@@ -34,6 +34,8 @@ int ngsld_host_read_pos(const char *path, int header, uint64_t n_sites, ngsld_po
 const double *ngsld_host_pos_dist(const ngsld_pos *p);
 const char *ngsld_host_label(const ngsld_pos *p, uint64_t site);
 void ngsld_host_free_pos(ngsld_pos *p);
+/* Copy of sites [begin, end) (a rank's slab in a multi-GPU run): labels and pos_dist re-indexed from 0. */
+ngsld_pos *ngsld_host_pos_slice(const ngsld_pos *p, uint64_t begin, uint64_t end);
 
 /* n_sites == file_size / 8 / n_ind / 3 with the reference's integer divisions (ngsLD.cpp:55). */
 int ngsld_host_geno_size_ok(uint64_t file_size, uint64_t n_ind, uint64_t n_sites);

@@ -22,7 +22,7 @@ OK, ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_NAN, ERR_MAF_RANGE, ERR_SINK, ERR_UN
 class Params(C.Structure):
     _fields_ = [("max_kb_dist", C.c_uint64), ("max_snp_dist", C.c_uint64), ("min_maf", C.c_double),
                 ("ignore_miss_data", C.c_int32), ("extend_out", C.c_int32), ("rnd_sample", C.c_double),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("first_row", C.c_uint64)]
 
 
 class GenoOpts(C.Structure):
@@ -79,7 +79,7 @@ SYMBOLS = [
     "ngsld_set_geno_raw_opts", "ngsld_set_geno_lkl",
     "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device",
     "ngsld_last_kernel_time", "ngsld_set_tuning", "ngsld_selftest",
-    "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos",
+    "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos", "ngsld_host_pos_slice",
     "ngsld_host_geno_size_ok", "ngsld_host_read_geno_bin", "ngsld_host_read_geno_text", "ngsld_host_format_header", "ngsld_host_format_pair",
     "ngsld_host_format_double", "ngsld_host_write_batch",
 ]
@@ -136,6 +136,8 @@ def lib() -> C.CDLL:
         L.ngsld_host_label.restype = C.c_char_p
         L.ngsld_host_free_pos.argtypes = [vp]
         L.ngsld_host_free_pos.restype = None
+        L.ngsld_host_pos_slice.argtypes = [vp, u64, u64]
+        L.ngsld_host_pos_slice.restype = vp
         L.ngsld_host_geno_size_ok.argtypes = [u64, u64, u64]
         L.ngsld_host_read_geno_bin.argtypes = [C.c_char_p, u64, u64, vp, C.c_char_p, C.c_size_t]
         L.ngsld_host_read_geno_text.argtypes = [C.c_char_p, C.c_int, C.c_int, u64, u64, vp, C.POINTER(C.c_int),
@@ -287,8 +289,9 @@ class Engine:
         self._check(self._L.ngsld_set_tuning(self._h, pairs_per_item, batch_pairs))
 
     def plan(self, max_kb_dist: int = 0, max_snp_dist: int = 0, min_maf: float = 0.0, ignore_miss_data: bool = False,
-             extend_out: bool = True, rnd_sample: float = 1.0, seed: int = 0) -> int:
-        p = Params(max_kb_dist, max_snp_dist, min_maf, int(ignore_miss_data), int(extend_out), rnd_sample, seed)
+             extend_out: bool = True, rnd_sample: float = 1.0, seed: int = 0, first_row: int = 0) -> int:
+        p = Params(max_kb_dist, max_snp_dist, min_maf, int(ignore_miss_data), int(extend_out), rnd_sample, seed,
+                   first_row)
         n = C.c_uint64()
         self._check(self._L.ngsld_plan(self._h, C.byref(p), C.byref(n)))
         self.extend_out = extend_out
@@ -328,6 +331,21 @@ class Engine:
         cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)
         return (cat(s1s, np.uint64), cat(s2s, np.uint64), cat(stds, REC_STD),
                 cat(exts, REC_EXT) if self.extend_out else None)
+
+    def run_to_fd(self, s1_begin: int, s1_end: int, fd: int, pos_handle, pos_dist: np.ndarray | None, maf: np.ndarray,
+                  n_threads: int) -> int:
+        """Rows [s1_begin, s1_end) -> TSV rows on file descriptor fd (ngsld_run + ngsld_host_write_batch)."""
+        maf = np.ascontiguousarray(maf, dtype=np.float64)
+        pd_ptr = None if pos_dist is None else np.ascontiguousarray(pos_dist, dtype=np.float64).ctypes.data
+        total, rc_box = [0], [0]
+
+        def sink(_user, bp):
+            total[0] += bp.contents.n_pairs
+            rc_box[0] = self._L.ngsld_host_write_batch(bp, pos_handle, pd_ptr, maf.ctypes.data, n_threads, fd)
+            return 0 if rc_box[0] == OK else 1
+
+        self._check(self._L.ngsld_run(self._h, s1_begin, s1_end, SINK_FN(sink), None))
+        return total[0]
 
     def run_discard(self, s1_begin: int = 0, s1_end: int | None = None) -> int:
         """Run through the sink path (kernel + D2H of every record into pinned host memory) and only count the

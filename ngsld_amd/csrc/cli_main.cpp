@@ -236,6 +236,7 @@ int main(int argc, char **argv) {
   lp.extend_out = pars.extend_out ? 1 : 0;
   lp.rnd_sample = pars.rnd_sample;
   lp.seed = pars.seed;
+  lp.first_row = 0;
   uint64_t n_pairs = 0;
   if (ngsld_plan(ctx, &lp, &n_pairs) != NGSLD_OK) error("ngsld_plan", ngsld_last_error(ctx));
   if (pars.verbose >= 1) fprintf(stderr, "==> Waiting for all threads to finish...\n");

@@ -471,6 +471,7 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) {
     m.s2 = 69069u * m.s1;
     m.s3 = 69069u * m.s2;
     for (int k = 0; k < 6; ++k) m.get();
+    for (uint64_t k = 0; k < p->first_row; ++k) m.get();  // rows that live on other GPUs
     for (uint64_t s = 0; s < n; ++s) seeds[s] = (uint64_t)(0 + (m.get() / 4294967296.0) * (double)1000000000000000ull);
     HIP_TRY(c, c->d_row_seed.resize(n));
     HIP_TRY(c, hipMemcpyAsync(c->d_row_seed.p, seeds.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));

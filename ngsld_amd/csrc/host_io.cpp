@@ -248,6 +248,13 @@ const char *ngsld_host_label(const ngsld_pos *p, uint64_t site) {
   return (p && site < p->labels.size()) ? p->labels[site].c_str() : nullptr;
 }
 void ngsld_host_free_pos(ngsld_pos *p) { delete p; }
+ngsld_pos *ngsld_host_pos_slice(const ngsld_pos *p, uint64_t begin, uint64_t end) {
+  if (p == nullptr || begin > end || end > p->labels.size()) return nullptr;
+  ngsld_pos *q = new ngsld_pos();
+  q->pos_dist.assign(p->pos_dist.begin() + (ptrdiff_t)begin, p->pos_dist.begin() + (ptrdiff_t)end);
+  q->labels.assign(p->labels.begin() + (ptrdiff_t)begin, p->labels.begin() + (ptrdiff_t)end);
+  return q;
+}
 
 int ngsld_host_geno_size_ok(uint64_t file_size, uint64_t n_ind, uint64_t n_sites) {
   if (n_ind == 0) return 0;

@@ -1,0 +1,152 @@
+"""Multi-GPU front end: the ngsLD command line over the GPUs of one node, one process per GPU.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m ngsld_amd.multi \\
+        --geno in.glf --n_ind 500 --n_sites 100000 --pos in.pos --max_kb_dist 100 --extend_out --out out.ld
+
+Every SNP pair is independent given the read-only GL matrix (the reference exploits this per s1,
+ngsLD.cpp:159-186), so the design of SURVEY §8(e) is: rank 0 reads the genotype file, ONE collective (a
+broadcast over RCCL/xGMI) hands the raw matrix to every GPU, ranks take contiguous row ranges balanced by pair
+count and hold only their slab (rows + window halo), and each rank writes its own shard `<out>.rank<k>` in
+(site1, site2) order; rank 0's shard carries the header, so `cat out.rank0 out.rank1 ...` is the single-GPU
+output.  Flags are the reference's (parse_args.cpp:35-59) plus --device-base.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser(prog="ngsld_amd.multi", allow_abbrev=False)
+    ap.add_argument("--geno", required=True)
+    ap.add_argument("--probs", action="store_true")
+    ap.add_argument("--log_scale", action="store_true")
+    ap.add_argument("--n_ind", type=int, required=True)
+    ap.add_argument("--n_sites", type=int, required=True)
+    ap.add_argument("--pos")
+    ap.add_argument("--posH")
+    ap.add_argument("--max_kb_dist", type=int, default=100)
+    ap.add_argument("--max_snp_dist", type=int, default=0)
+    ap.add_argument("--min_maf", type=float, default=0.0)
+    ap.add_argument("--ignore_miss_data", action="store_true")
+    ap.add_argument("--call_geno", action="store_true")
+    ap.add_argument("--N_thresh", type=float)
+    ap.add_argument("--call_thresh", type=float)
+    ap.add_argument("--rnd_sample", type=float, default=1.0)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--extend_out", action="store_true")
+    ap.add_argument("--out", required=True, help="shards are written to <out>.rank<k>")
+    ap.add_argument("--n_threads", type=int, default=1)
+    ap.add_argument("--verbose", type=int, default=1)
+    ap.add_argument("--device-base", type=int, default=0)
+    return ap.parse_args(argv)
+
+
+def main(argv=None) -> int:
+    a = parse(argv)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import torch.distributed as dist
+
+    from . import capi, shard
+
+    one_dev = os.environ.get("NGSLD_BENCH_ONE_DEVICE") == "1"      # debug: all ranks on GPU 0 over gloo
+    dev_index = a.device_base + (0 if one_dev else local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if one_dev else "nccl", rank=rank, world_size=world,
+                                **({} if one_dev else {"device_id": dev}))
+    pos_path, pos_header = (a.posH, True) if a.posH else (a.pos, False)
+    if pos_path is None and a.max_kb_dist > 0:
+        raise SystemExit("position file necessary in order to filter by maximum distance!")
+    call = None
+    if a.call_geno or a.N_thresh is not None or a.call_thresh is not None:
+        call = (a.N_thresh or 0.0, a.call_thresh or 0.0)
+    binary = not a.geno.endswith(".gz")
+    if a.log_scale:
+        a.probs = True
+    if binary:
+        a.probs = True
+    if call is not None and not a.probs:
+        raise SystemExit("can only call genotypes from likelihoods/probabilities!")
+    seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(4), "little")
+
+    # ---- rank 0 reads; one broadcast distributes the raw matrix (+ the seed when it was not given) ----
+    n_sites, n_ind = a.n_sites, a.n_ind
+    meta = torch.zeros(2, dtype=torch.int64, device=dev)
+    if rank == 0:
+        if binary:
+            if not capi.lib().ngsld_host_geno_size_ok(os.path.getsize(a.geno), n_ind, n_sites):
+                raise SystemExit("invalid/corrupt genotype input file!")
+            raw_h, is_log = capi.read_geno_bin(a.geno, n_ind, n_sites), a.log_scale
+        else:
+            raw_h, is_log = capi.read_geno_text(a.geno, a.probs, a.log_scale, n_ind, n_sites)
+        raw = torch.from_numpy(raw_h).to(dev)
+        meta[0], meta[1] = int(is_log), seed
+    else:
+        raw = torch.empty((n_sites, n_ind, 3), dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.broadcast(meta, src=0)
+    shard.broadcast_matrix(raw, src=0)
+    is_log, seed = bool(meta[0].item()), int(meta[1].item())
+
+    # ---- rows of this rank (balanced by candidate pairs), its slab, its engine ----
+    L = capi.lib()
+    import ctypes as C
+    pos_h = C.c_void_p()
+    pos_dist = None
+    if pos_path:
+        err = C.create_string_buffer(512)
+        if L.ngsld_host_read_pos(pos_path.encode(), int(pos_header), n_sites, C.byref(pos_h), err, len(err)) != capi.OK:
+            raise SystemExit(f"read_dist: {err.value.decode()}")
+        pos_dist = np.ctypeslib.as_array(L.ngsld_host_pos_dist(pos_h), shape=(n_sites,)).copy()
+    pd_plan = pos_dist if pos_dist is not None else np.full(n_sites, np.inf)
+    row_end = shard.row_ends(pd_plan, a.max_kb_dist, a.max_snp_dist)
+    counts = row_end - (np.arange(n_sites, dtype=np.int64) + 1)
+    lo, hi = shard.split_rows(counts, world)[rank]
+    slab_lo, slab_hi = shard.slab_for_rows(row_end, lo, hi)
+    total = 0
+    with open(f"{a.out}.rank{rank}", "wb") as fh:
+        if rank == 0:
+            fh.write(capi.format_header(a.extend_out).encode())
+            fh.flush()
+        if hi > lo:
+            eng = capi.Engine(dev_index)
+            slab = raw[slab_lo:slab_hi]
+            eng.set_geno_raw(slab.data_ptr(), n_sites=slab_hi - slab_lo, n_ind=n_ind, log_scale=is_log,
+                             ignore_miss_data=a.ignore_miss_data, text=not binary, call_geno=call)
+            del slab, raw
+            local_pd = None if pos_dist is None else pos_dist[slab_lo:slab_hi].copy()
+            eng.set_pos_dist(local_pd)
+            eng.plan(a.max_kb_dist, a.max_snp_dist, a.min_maf, a.ignore_miss_data, a.extend_out, a.rnd_sample, seed,
+                     first_row=slab_lo)
+            maf = eng.maf()
+            slab_pos = L.ngsld_host_pos_slice(pos_h, slab_lo, slab_hi) if pos_path else None
+            total = eng.run_to_fd(0, hi - lo, fh.fileno(), slab_pos, local_pd, maf, a.n_threads)
+            if slab_pos:
+                L.ngsld_host_free_pos(slab_pos)
+            eng.close()
+    if pos_path:
+        L.ngsld_host_free_pos(pos_h)
+    if world > 1:
+        t = torch.tensor([total], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        total = int(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and a.verbose >= 1:
+        print(f"ngsld_amd.multi: {total} pairs on {world} GPU(s); shards {a.out}.rank0 .. rank{world - 1}", file=sys.stderr)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
