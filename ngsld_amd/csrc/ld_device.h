@@ -79,8 +79,10 @@ __device__ __forceinline__ double fold16(double x, double y) {
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  // old = 0 with bound_ctrl: every lane has a source for the controls used here (row_ror, quad_perm), and this form
+  // lets the compiler write a fresh register instead of first copying `old` into the destination
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 
@@ -193,6 +195,8 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   // f = ff/(2x) (gen_func.cpp:1108-1109).  The renormalisation that follows there (:1112-1113) divides
   // by sum_k ff_k/(2x) = (1/x) sum_i s_i/s_i = 1 up to rounding, and the EM map does not depend on the
   // scale of f, so it is not repeated per iteration.  inv_x = 1/x; x == 0 gives 0 * inf = NaN like the reference's 0/0.
+  // (held in a VGPR: the four products t_k * inv_x below take t_k from SGPRs, and a VALU op reads one SGPR at most)
+  asm("" : "+v"(inv_x));
   bool bad = false;
   uint32_t n_iter = 0;
   for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
@@ -237,13 +241,13 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     // NaN difference never raises eps (gen_func.cpp:1049-1053), "convergence" at this iteration.  Here
     // s == 0 poisons every R with inf/NaN, so a sum that is not a sane ~1 <=> the reference is all NaN.
     const double sn = (n0 + n1) + (n2 + n3);
-    if (__builtin_amdgcn_readfirstlane((int)!(sn < 2.0))) {
+    if (__builtin_amdgcn_ballot_w64(!(sn < 2.0))) {  // wave-uniform values: the ballot is all-or-nothing
       bad = true;
       break;
     }
     const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
     f0 = n0; f1 = n1; f2 = n2; f3 = n3;
-    if (__builtin_amdgcn_readfirstlane((int)(eps < kEpsilon))) break;  // gen_func.cpp:1054-1055
+    if (__builtin_amdgcn_ballot_w64(eps < kEpsilon)) break;  // gen_func.cpp:1054-1055
   }
   if (bad) f0 = f1 = f2 = f3 = __builtin_nan("");
   return n_iter;
