@@ -652,7 +652,9 @@ __global__ __launch_bounds__(256, 2) void pair_ld_row_kernel(PairArgs A) {
       double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
 #pragma unroll
       for (int j = 0; j < SLOTS; ++j) {
-        if ((vbits >> j) & 1u) {
+        // without --ignore_miss_data only the last slot can hold padding lanes; a row without a pair computes
+        // on stale buffers there, which is harmless (it is `done` from the start and never written)
+        if ((!MASKED && j < SLOTS - 1) || ((vbits >> j) & 1u)) {
           double s = p00 * P[j][0];
           s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
           s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
