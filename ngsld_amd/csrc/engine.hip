@@ -71,7 +71,7 @@ struct ngsld_ctx {
   uint32_t np = 0;
   PairConfig cfg{};
   bool have_geno = false;
-  DevBuf<double> d_planes, d_maf, d_mean, d_sxx, d_stage;
+  DevBuf<double> d_planes, d_maf, d_mean, d_rsx, d_stage;
   DevBuf<int> d_status;
   std::vector<double> h_maf, h_pos_dist;
 
@@ -149,7 +149,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   HIP_TRY(c, c->d_planes.resize(plane_elems));
   HIP_TRY(c, c->d_maf.resize(n_sites));
   HIP_TRY(c, c->d_mean.resize(n_sites));
-  HIP_TRY(c, c->d_sxx.resize(n_sites));
+  HIP_TRY(c, c->d_rsx.resize(n_sites));
   HIP_TRY(c, c->d_status.resize(1));
   HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, sizeof(int), c->stream));
 
@@ -188,7 +188,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   a.call_thresh = o.call_thresh;
   a.maf = c->d_maf.p;
   a.mean_e = c->d_mean.p;
-  a.rsx = c->d_sxx.p;
+  a.rsx = c->d_rsx.p;
   a.status = c->d_status.p;
   HIP_TRY(c, launch_prep(a, c->stream));
   c->h_maf.resize(n_sites);
@@ -283,7 +283,7 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
   a.inv_n = 1.0 / (double)c->n_ind;
   a.maf = c->d_maf.p;
   a.mean_e = c->d_mean.p;
-  a.rsx = c->d_sxx.p;
+  a.rsx = c->d_rsx.p;
   a.items = c->d_items.p + c->h_item_off[r0];
   a.n_items = c->h_item_off[r1] - c->h_item_off[r0];
   a.out_base = c->h_row_off[r0];
@@ -355,7 +355,7 @@ void ngsld_destroy(ngsld_ctx *c) {
   if (c == nullptr) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_sxx.release(); c->d_stage.release();
+  c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_rsx.release(); c->d_stage.release();
   c->d_status.release(); c->d_row_off.release(); c->d_item_off.release(); c->d_row_end.release();
   c->d_row_seed.release(); c->d_row_count.release(); c->d_keep.release(); c->d_items.release();
   for (int k = 0; k < 2; ++k) {
