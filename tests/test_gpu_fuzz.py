@@ -1,0 +1,57 @@
+"""GPU: seeded random sweep over shapes and flag combinations, HIP path vs oracle.  Every kernel family (row,
+wavefront, multi-wavefront, streaming), both mask modes, every filter, depths from 0.5 (many capped EMs) to 30."""
+import numpy as np
+import pytest
+
+from ngsld_amd import shard, synth
+from oracle import orc
+from util import MAF_TOL, check_records, close
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(k):
+    rng = np.random.default_rng(1000 + k)
+    n_ind = int(rng.choice([1, 3, 15, 16, 17, 33, 64, 100, 128, 129, 200, 257, 500, 513, 777, 1100, 2100, 4100]))
+    n_sites = int(rng.integers(3, 60 if n_ind <= 600 else 14))
+    depth = float(rng.choice([0.5, 1.0, 2.0, 5.0, 10.0, 30.0]))
+    raw = synth.make_gl_numpy(n_sites, n_ind, 5000 + k, depth=depth)
+    miss = rng.random((n_sites, n_ind)) < rng.choice([0.0, 0.05, 0.4])
+    raw[miss] = rng.choice([1.0 / 3.0, 0.5, 1e-3])
+    if rng.random() < 0.3:                                       # some hard-called individuals / a monomorphic site
+        hc = rng.random((n_sites, n_ind)) < 0.2
+        raw[hc] = np.eye(3)[rng.integers(0, 3, size=int(hc.sum()))]
+    if rng.random() < 0.2:
+        raw[int(rng.integers(0, n_sites))] = np.array([1.0, 0.0, 0.0])
+    log_scale = bool(rng.random() < 0.25)
+    if log_scale:
+        with np.errstate(divide="ignore"):
+            raw = np.log(raw)
+    chrs, pos = synth.make_positions(n_sites, 7000 + k, max_gap=int(rng.choice([5, 200, 3000])),
+                                     n_chr=int(rng.integers(1, 4)))
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    kw = dict(log_scale=log_scale, ignore_miss_data=bool(rng.random() < 0.5),
+              max_kb_dist=int(rng.choice([0, 0, 1, 5, 50])), max_snp_dist=int(rng.choice([0, 0, 3, 11])),
+              rnd_sample=float(rng.choice([1.0, 1.0, 0.5, 0.15])), seed=int(rng.integers(0, 2 ** 40)))
+    call = None if rng.random() < 0.8 else tuple(sorted(rng.random(2)))
+    return raw, pd, kw, call
+
+
+@pytest.mark.parametrize("k", range(48))
+def test_random_configuration(engine, k):
+    raw, pd, kw, call = _case(k)
+    o0 = orc.Oracle(raw, pd, log_scale=kw["log_scale"], call_geno=call)
+    min_maf = 0.0
+    if k % 3 == 0 and np.isfinite(o0.maf).any():
+        min_maf = float(np.round(np.nanquantile(o0.maf, 0.3), 3))
+    o = orc.Oracle(raw, pd, min_maf=min_maf, n_threads=4, call_geno=call, **kw)
+    rec = o.run()
+    engine.set_geno_raw(raw, log_scale=kw["log_scale"], ignore_miss_data=kw["ignore_miss_data"], call_geno=call)
+    engine.set_pos_dist(pd)
+    assert np.all(close(engine.maf(), o.maf, MAF_TOL))
+    n = engine.plan(kw["max_kb_dist"], kw["max_snp_dist"], min_maf, kw["ignore_miss_data"], True, kw["rnd_sample"],
+                    kw["seed"])
+    assert n == len(rec)
+    s1, s2, std, ext = engine.run()
+    assert np.array_equal(s1, rec["s1"]) and np.array_equal(s2, rec["s2"])
+    check_records(std, ext, rec)

@@ -134,11 +134,23 @@ def check_records(std, ext, want: dict, tol=TOL):
     bad = np.flatnonzero(ext["n_iter"] != want["n_iter"])
     assert len(bad) == 0, f"nIter differs on {len(bad)} pairs, first {bad[:5]}"
     degen = degenerate_rows(want["hap_maf"])
+    # D' and r2 divide by products of hap_maf = 1 - (f0 + f1), which keeps an ABSOLUTE accuracy of ~1e-16: with a
+    # hap-derived allele frequency q the reference's own D' and r2 carry a relative error of ~1e-16 / q.  Two correct
+    # implementations therefore agree to 1e-9 only where q >~ 1e-6; the tolerance grows as 100 ulp / q below that
+    # (DESIGN.md "conditioning of D' and r2").  hap, D, nIter and sample_size are held to the plain bars.
+    hm = np.asarray(want["hap_maf"], dtype=np.float64)
+    import warnings
+    with np.errstate(invalid="ignore", divide="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)       # all-NaN rows (NaN hap): nanmin warns, q stays NaN
+        q = np.nanmin(np.stack([hm[:, 0], 1 - hm[:, 0], hm[:, 1], 1 - hm[:, 1]]), axis=0)
+        cond_tol = tol + 100 * 2.2e-16 / np.maximum(np.abs(q), 1e-300)
     for name, got, exp in (("hap", ext["hap"], want["hap"]), ("D", std["D"], want["D"]), ("Dp", std["Dp"], want["Dp"]),
                            ("r2", std["r2"], want["r2"]), ("r2_ExpG", std["r2_ExpG"], want["r2pear"])):
         ok = close(got, exp, tol)
         if name in ("Dp", "r2"):
             g = np.asarray(got)
+            with np.errstate(invalid="ignore"):
+                ok = ok | (np.abs(g - np.asarray(exp)) <= cond_tol)
             ok = ok | (degen & (np.isnan(g) | np.isinf(g) | (g == 0)))
         assert np.all(ok), (f"{name}: {np.count_nonzero(~ok)} of {ok.size} outside {tol}; got "
                             f"{np.asarray(got)[~ok][:3]} want {np.asarray(exp)[~ok][:3]}")
