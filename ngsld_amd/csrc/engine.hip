@@ -500,9 +500,7 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) {
   // pass 2: the items (same draws again), and a host copy for the sink
   ia.count_only = 0;
   HIP_TRY(c, launch_items(ia, c->stream));
-  c->h_items.resize(c->n_items);
-  if (c->n_items)
-    HIP_TRY(c, hipMemcpyAsync(c->h_items.data(), c->d_items.p, c->n_items * sizeof(Item), hipMemcpyDeviceToHost, c->stream));
+  c->h_items.clear();  // the host copy is fetched on demand by ngsld_run (the sink needs it, ngsld_run_device does not)
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->planned = true;
   if (n_pairs) *n_pairs = c->h_row_off[n];
@@ -555,6 +553,11 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   c->timed_stream = c->stream;
   c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
 
+  if (c->h_items.size() != c->n_items) {
+    c->h_items.resize(c->n_items);
+    if (c->n_items)
+      HIP_TRY(c, hipMemcpy(c->h_items.data(), c->d_items.p, c->n_items * sizeof(Item), hipMemcpyDeviceToHost));
+  }
   struct Batch {
     uint64_t r0, r1, n;
   };
