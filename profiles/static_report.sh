@@ -1,0 +1,29 @@
+#!/usr/bin/env bash
+# Static evidence for DESIGN.md §4: resource usage of the shipped pair kernels and the instruction mix of the
+# headline kernel's EM loop (hipcc cross-compiles; no GPU needed).  Usage: profiles/static_report.sh > profiles/r01/static_report.txt
+set -euo pipefail
+R=$(cd "$(dirname "$0")/.." && pwd)
+T=$(mktemp -d)
+cat > $T/k.hip <<EOT
+#include "$R/ngsld_amd/csrc/ld_device.h"
+template __global__ void ngsld::pair_ld_pf_kernel<8,false>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_pf_kernel<8,true>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_row_kernel<7,false>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_kernel<8,2,false,true>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_kernel<8,4,false,true>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_stream_kernel<false>(ngsld::PairArgs);
+EOT
+cd $T
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -c k.hip -o k.o -save-temps \
+  -Rpass-analysis=kernel-resource-usage 2> res.txt || true
+echo "== kernel resources (hipcc -Rpass-analysis=kernel-resource-usage, gfx950) =="
+grep -E "Function Name|VGPRs:|AGPRs|ScratchSize|Occupancy|LDS Size|SGPRs:" res.txt | sed 's/remark:[^:]*:[0-9]*:[0-9]*: *//; s/ \[-Rpass-analysis=kernel-resource-usage\]//' \
+  | sed 's/_ZN5ngsld//; s/EvNS_8PairArgsE//'
+S=k-hip-amdgcn-amd-amdhsa-gfx950.s
+awk '/^_ZN5ngsld17pair_ld_pf_kernelILi8ELb0EEEvNS_8PairArgsE:/,/s_endpgm/' $S > pf.s
+L=$(grep -n "Inner Loop Header: Depth=2" pf.s | tail -1 | cut -d: -f1)
+E=$(awk -v s=$L 'NR>s && /^\.LBB0_[0-9]+:.*Depth=1$/ {print NR; exit}' pf.s)
+echo
+echo "== pair_ld_pf_kernel<8,false>: instruction mix of the EM loop body (ISA lines $L..$E of the kernel) =="
+sed -n "${L},${E}p" pf.s | grep -v "^\s*;" | grep -v "^\." | awk '{print $1}' | sort | uniq -c | sort -rn
+rm -rf $T
