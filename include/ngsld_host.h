@@ -28,6 +28,10 @@ extern "C" {
 
 typedef struct ngsld_pos ngsld_pos;
 
+/* Number of host threads the readers below may use (text parsing); the TSV writer takes its own argument.
+ * Process-wide, default 1 (the reference's --n_threads default, parse_args.cpp:27). */
+void ngsld_host_set_threads(int n_threads);
+
 /* Read a position file (chr TAB pos [TAB ...]); `header` != 0 skips one line (--posH).
  * Returns NGSLD_OK or NGSLD_ERR_INVALID with the reference's message text in err. */
 int ngsld_host_read_pos(const char *path, int header, uint64_t n_sites, ngsld_pos **out, char *err, size_t errlen);

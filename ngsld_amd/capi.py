@@ -79,7 +79,7 @@ SYMBOLS = [
     "ngsld_set_geno_raw_opts", "ngsld_set_geno_lkl",
     "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device",
     "ngsld_last_kernel_time", "ngsld_set_tuning", "ngsld_selftest",
-    "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos", "ngsld_host_pos_slice",
+    "ngsld_host_set_threads", "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos", "ngsld_host_pos_slice",
     "ngsld_host_geno_size_ok", "ngsld_host_read_geno_bin", "ngsld_host_read_geno_text", "ngsld_host_format_header", "ngsld_host_format_pair",
     "ngsld_host_format_double", "ngsld_host_write_batch",
 ]
@@ -129,6 +129,8 @@ def lib() -> C.CDLL:
         L.ngsld_last_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
         L.ngsld_set_tuning.argtypes = [vp, C.c_uint32, u64]
         L.ngsld_selftest.argtypes = [vp]
+        L.ngsld_host_set_threads.argtypes = [C.c_int]
+        L.ngsld_host_set_threads.restype = None
         L.ngsld_host_read_pos.argtypes = [C.c_char_p, C.c_int, u64, C.POINTER(vp), C.c_char_p, C.c_size_t]
         L.ngsld_host_pos_dist.argtypes = [vp]
         L.ngsld_host_pos_dist.restype = C.POINTER(dbl)

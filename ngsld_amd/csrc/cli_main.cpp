@@ -178,6 +178,8 @@ int main(int argc, char **argv) {
   fwrite(hdr, 1, hn, pars.out_fh);
   fflush(pars.out_fh);
 
+  ngsld_host_set_threads((int)pars.n_threads);
+
   // ---- device ----
   ngsld_ctx *ctx = nullptr;
   if (ngsld_create(pars.device, &ctx) != NGSLD_OK) error("ngsld_create", ngsld_last_error(nullptr));

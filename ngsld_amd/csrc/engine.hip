@@ -71,7 +71,7 @@ struct ngsld_ctx {
   uint32_t np = 0;
   PairConfig cfg{};
   bool have_geno = false;
-  DevBuf<double> d_planes, d_maf, d_mean, d_rsx, d_stage;
+  DevBuf<double> d_planes, d_maf, d_mean, d_rsx;
   DevBuf<int> d_status;
   std::vector<double> h_maf, h_pos_dist;
 
@@ -153,30 +153,12 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   HIP_TRY(c, c->d_status.resize(1));
   HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, sizeof(int), c->stream));
 
-  const double *d_raw = gl;
-  DevBuf<double> d_maf_in;
-  const size_t raw_elems = (size_t)n_sites * n_ind * 3;
-  if (!on_device) {
-    HIP_TRY(c, c->d_stage.resize(raw_elems));
-    HIP_TRY(c, hipMemcpyAsync(c->d_stage.p, gl, raw_elems * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    d_raw = c->d_stage.p;
-  }
-  const double *d_maf_src = nullptr;
-  if (normalised) {
-    if (on_device) {
-      d_maf_src = maf;
-    } else {
-      HIP_TRY(c, d_maf_in.resize(n_sites));
-      HIP_TRY(c, hipMemcpyAsync(d_maf_in.p, maf, n_sites * sizeof(double), hipMemcpyHostToDevice, c->stream));
-      d_maf_src = d_maf_in.p;
-    }
-  }
+  // Host matrices are ingested in chunks of sites through two staging buffers: the H2D copy of chunk k+1 overlaps
+  // the prep kernel of chunk k, and the device never holds more than planes + 2 chunks (a 48 GB matrix does not need
+  // a second 48 GB on the device).  Device-resident input is prepped in place in one launch.
   PrepArgs a{};
-  a.raw = d_raw;
-  a.maf_in = d_maf_src;
   a.planes = c->d_planes.p;
   a.site_stride = 3ull * c->np;
-  a.n_sites = n_sites;
   a.np = c->np;
   a.n_ind = (uint32_t)n_ind;
   a.log_scale = log_scale;
@@ -190,14 +172,60 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   a.mean_e = c->d_mean.p;
   a.rsx = c->d_rsx.p;
   a.status = c->d_status.p;
-  HIP_TRY(c, launch_prep(a, c->stream));
+  if (on_device) {
+    a.raw = gl;
+    a.maf_in = maf;
+    a.site0 = 0;
+    a.n_sites = n_sites;
+    HIP_TRY(c, launch_prep(a, c->stream));
+  } else {
+    const uint64_t site_bytes = n_ind * 3 * sizeof(double);
+    uint64_t stage_bytes = 256ull << 20;
+    if (const char *e = std::getenv("NGSLD_STAGE_BYTES")) stage_bytes = std::strtoull(e, nullptr, 10);  // tests: force many chunks
+    uint64_t chunk = stage_bytes / site_bytes;
+    if (chunk < 1) chunk = 1;
+    if (chunk > n_sites) chunk = n_sites;
+    DevBuf<double> stage[2], maf_stage[2];
+    hipEvent_t prepped[2] = {nullptr, nullptr};
+    for (int k = 0; k < 2; ++k) {
+      HIP_TRY(c, stage[k].resize(chunk * n_ind * 3));
+      if (normalised) HIP_TRY(c, maf_stage[k].resize(chunk));
+      HIP_TRY(c, hipEventCreateWithFlags(&prepped[k], hipEventDisableTiming));
+    }
+    int rc = NGSLD_OK;
+    uint64_t k = 0;
+    for (uint64_t s0 = 0; s0 < n_sites && rc == NGSLD_OK; s0 += chunk, ++k) {
+      const int b = (int)(k & 1);
+      const uint64_t m = std::min(chunk, n_sites - s0);
+      hipError_t e = hipSuccess;
+      if (k >= 2) e = hipEventSynchronize(prepped[b]);  // the prep kernel that last read this buffer is done
+      if (e == hipSuccess)
+        e = hipMemcpyAsync(stage[b].p, gl + s0 * n_ind * 3, m * site_bytes, hipMemcpyHostToDevice, c->copy_stream);
+      if (e == hipSuccess && normalised)
+        e = hipMemcpyAsync(maf_stage[b].p, maf + s0, m * sizeof(double), hipMemcpyHostToDevice, c->copy_stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
+      a.raw = stage[b].p;
+      a.maf_in = normalised ? maf_stage[b].p : nullptr;
+      a.site0 = s0;
+      a.n_sites = m;
+      if (e == hipSuccess) e = launch_prep(a, c->stream);
+      if (e == hipSuccess) e = hipEventRecord(prepped[b], c->stream);
+      if (e != hipSuccess) rc = hip_fail(c, e, "chunked genotype upload");
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    for (int q = 0; q < 2; ++q) {
+      stage[q].release();
+      maf_stage[q].release();
+      if (prepped[q]) (void)hipEventDestroy(prepped[q]);
+    }
+    if (rc != NGSLD_OK) return rc;
+    if (e != hipSuccess) return hip_fail(c, e, "chunked genotype upload");
+  }
   c->h_maf.resize(n_sites);
   int status = 0;
   HIP_TRY(c, hipMemcpyAsync(c->h_maf.data(), c->d_maf.p, n_sites * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(&status, c->d_status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  d_maf_in.release();
-  c->d_stage.release();
   if (status == NGSLD_ERR_NAN) return fail(c, NGSLD_ERR_NAN, "NaN found! Is the file format correct?");
   c->have_geno = true;
   return NGSLD_OK;
@@ -355,7 +383,7 @@ void ngsld_destroy(ngsld_ctx *c) {
   if (c == nullptr) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_rsx.release(); c->d_stage.release();
+  c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_rsx.release();
   c->d_status.release(); c->d_row_off.release(); c->d_item_off.release(); c->d_row_end.release();
   c->d_row_seed.release(); c->d_row_count.release(); c->d_keep.release(); c->d_items.release();
   for (int k = 0; k < 2; ++k) {

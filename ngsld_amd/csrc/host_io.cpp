@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -21,6 +22,8 @@ struct ngsld_pos {
 };
 
 namespace {
+
+std::atomic<int> g_host_threads{1};
 
 int set_err(char *err, size_t errlen, const char *msg) {
   if (err && errlen) std::snprintf(err, errlen, "%s", msg);
@@ -291,6 +294,8 @@ int ngsld_host_read_geno_bin(const char *path, uint64_t n_ind, uint64_t n_sites,
   return NGSLD_OK;
 }
 
+void ngsld_host_set_threads(int n_threads) { g_host_threads.store(n_threads < 1 ? 1 : n_threads); }
+
 int ngsld_host_read_geno_text(const char *path, int in_probs, int log_scale, uint64_t n_ind, uint64_t n_sites,
                               double *out_raw, int *out_log_scale, char *err, size_t errlen) {
   if (path == nullptr || out_raw == nullptr || out_log_scale == nullptr) return set_err(err, errlen, "invalid argument");
@@ -298,58 +303,90 @@ int ngsld_host_read_geno_text(const char *path, int in_probs, int log_scale, uin
   if (!slurp(path, text)) return set_err(err, errlen, "cannot open GENO file!");
   *out_log_scale = in_probs ? (log_scale ? 1 : 0) : 1;
   const uint64_t need = n_ind * (in_probs ? 3 : 1);
-  std::vector<double> vals;
-  size_t b = 0;
-  uint64_t s = 0;
-  while (s < n_sites) {
-    if (b >= text.size())
-      return set_err(err, errlen, "GENO file at premature EOF. Check GENO file and number of sites!");
+
+  // numeric fields of one line (split(char*, sep, double**), gen_func.cpp:381-410: a token counts iff strtod eats
+  // all of it); tokens are bounded by blanks / TABs, strtod never runs past one because those stop it
+  auto numeric_fields = [&](size_t b, size_t len, std::vector<double> &vals) {
+    vals.clear();
+    const char *base = text.c_str();  // NUL-terminated: a last token touching the end of the buffer is safe
+    size_t p = b;
+    const size_t end = b + len;
+    while (p < end) {
+      size_t q = p;
+      while (q < end && base[q] != ' ' && base[q] != '\t') ++q;
+      if (q > p) {
+        char *stop = nullptr;
+        const double v = std::strtod(base + p, &stop);
+        if (stop == base + q) vals.push_back(v);
+      }
+      p = q + 1;
+    }
+  };
+  // one data line -> one site row; returns an error text or nullptr
+  auto fill_site = [&](const std::vector<double> &vals, uint64_t s) -> const char * {
+    if (vals.size() < need) return "wrong GENO file format. Less fields than expected!";
+    const double *ptr = vals.data() + (vals.size() - need);  // last n_ind*n_geno columns (read_data.cpp:80-81)
+    double *row = out_raw + s * n_ind * 3;
+    if (in_probs) {
+      std::memcpy(row, ptr, need * sizeof(double));
+      return nullptr;
+    }
+    for (uint64_t i = 0; i < n_ind; ++i) {
+      const int g = (int)ptr[i];
+      double *t = row + 3 * i;
+      if (g >= 0) {
+        if (g > 2) return "wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !";
+        t[0] = t[1] = t[2] = -1e15;  // init_ptr(..., -INF), read_data.cpp:21
+        t[g] = 0.0;                  // log(1), :92
+      } else {
+        t[0] = t[1] = t[2] = std::log(1.0 / 3.0);  // :94
+      }
+    }
+    return nullptr;
+  };
+
+  // line index: (begin, length) after chomp; an empty line is an error (see the header of this file's section)
+  std::vector<std::pair<size_t, size_t>> lines;
+  for (size_t b = 0; b < text.size();) {
     size_t e = text.find('\n', b);
     if (e == std::string::npos) e = text.size();
     size_t len = e - b;
     if (e == text.size() && len > 0 && text[b + len - 1] == '\r') --len;
     if (len == 0) return set_err(err, errlen, "empty line in GENO file");
-    // numeric fields only (split(char*, sep, double**), gen_func.cpp:381-410: a token counts iff strtod eats all of it)
-    vals.clear();
-    size_t p = b;
-    const size_t end = b + len;
-    while (p < end) {
-      size_t q = p;
-      while (q < end && text[q] != ' ' && text[q] != '\t') ++q;
-      if (q > p) {
-        const char save = text[q == text.size() ? q - 1 : q];
-        char *stop = nullptr;
-        if (q < text.size()) text[q] = '\0';
-        const double v = std::strtod(text.c_str() + p, &stop);
-        const bool whole = stop == text.c_str() + q;
-        if (q < text.size()) text[q] = save;
-        if (whole) vals.push_back(v);
-      }
-      p = q + 1;
-    }
+    lines.emplace_back(b, len);
     b = e + 1;
-    if (vals.empty() || (s == 0 && vals.size() < need)) continue;  // header line (read_data.cpp:64-72)
-    if (vals.size() < need) return set_err(err, errlen, "wrong GENO file format. Less fields than expected!");
-    const double *ptr = vals.data() + (vals.size() - need);  // last n_ind*n_geno columns (read_data.cpp:80-81)
-    double *row = out_raw + s * n_ind * 3;
-    if (in_probs) {
-      std::memcpy(row, ptr, need * sizeof(double));
-    } else {
-      for (uint64_t i = 0; i < n_ind; ++i) {
-        const int g = (int)ptr[i];
-        double *t = row + 3 * i;
-        if (g >= 0) {
-          if (g > 2) return set_err(err, errlen, "wrong GENO file format. Genotypes must be coded as {-1,0,1,2} !");
-          t[0] = t[1] = t[2] = -1e15;  // init_ptr(..., -INF), read_data.cpp:21
-          t[g] = 0.0;                  // log(1), :92
-        } else {
-          t[0] = t[1] = t[2] = std::log(1.0 / 3.0);  // :94
-        }
-      }
-    }
-    ++s;
   }
-  if (b < text.size()) return set_err(err, errlen, "GENO file not at EOF. Check GENO file and number of sites!");
+  // header lines at the top: no numeric field at all, or (first line only) fewer than needed (read_data.cpp:64-72)
+  size_t first = 0;
+  std::vector<double> vals;
+  while (first < lines.size()) {
+    numeric_fields(lines[first].first, lines[first].second, vals);
+    if (vals.empty() || (first == 0 && vals.size() < need)) ++first; else break;
+  }
+  if (lines.size() - first < n_sites)
+    return set_err(err, errlen, "GENO file at premature EOF. Check GENO file and number of sites!");
+  if (lines.size() - first > n_sites)
+    return set_err(err, errlen, "GENO file not at EOF. Check GENO file and number of sites!");
+
+  const int nt = (int)std::min<uint64_t>((uint64_t)g_host_threads.load(), n_sites ? n_sites : 1);
+  std::vector<const char *> errors(nt, nullptr);
+  auto work = [&](int t) {
+    std::vector<double> v;
+    for (uint64_t s = (uint64_t)t; s < n_sites && errors[t] == nullptr; s += (uint64_t)nt) {
+      numeric_fields(lines[first + s].first, lines[first + s].second, v);
+      if (v.empty()) {  // a line without numbers further down is skipped as a header by the reference (:64)
+        errors[t] = "wrong GENO file format. Less fields than expected!";
+        break;
+      }
+      errors[t] = fill_site(v, s);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto &x : th) x.join();
+  for (int t = 0; t < nt; ++t)
+    if (errors[t]) return set_err(err, errlen, errors[t]);
   return NGSLD_OK;
 }
 

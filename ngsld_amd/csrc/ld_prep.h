@@ -6,7 +6,8 @@
 namespace ngsld {
 
 struct PrepArgs {
-  const double *raw;     // [n_sites][n_ind][3] as on disk (or already normalised, normal space)
+  const double *raw;     // [n_sites][n_ind][3] as on disk (or already normalised, normal space); a chunk of sites
+  uint64_t site0;        // global index of the chunk's first site: outputs go to site0 + k
   const double *maf_in;  // only with normalised_input
   double *planes;        // [n_sites][3][np]
   uint64_t site_stride;  // 3 * np

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
   __shared__ double sh1[4][1];
   for (uint64_t site = blockIdx.x; site < A.n_sites; site += gridDim.x) {
     const double *raw = A.raw + site * (uint64_t)A.n_ind * 3;
-    double *pl = A.planes + site * A.site_stride;
+    double *pl = A.planes + (A.site0 + site) * A.site_stride;
     double acc[3] = {0.0, 0.0, 0.0};  // num, den (est_maf), sum of expected genotypes
     bool nan_seen = false;
     for (uint32_t i = threadIdx.x; i < A.np; i += 256) {
@@ -157,9 +157,9 @@ __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
     }
     block_sum<1>(sq, sh1);
     if (threadIdx.x == 0) {
-      A.maf[site] = A.normalised_input ? A.maf_in[site] : acc[0] / acc[1];
-      A.mean_e[site] = mean;
-      A.rsx[site] = 1.0 / sqrt(sq[0]);
+      A.maf[A.site0 + site] = A.normalised_input ? A.maf_in[site] : acc[0] / acc[1];
+      A.mean_e[A.site0 + site] = mean;
+      A.rsx[A.site0 + site] = 1.0 / sqrt(sq[0]);
     }
     if (nan_seen) atomicExch(A.status, (int)NGSLD_ERR_NAN);
   }

@@ -82,6 +82,7 @@ def main(argv=None) -> int:
 
     # ---- rank 0 reads; one broadcast distributes the raw matrix (+ the seed when it was not given) ----
     n_sites, n_ind = a.n_sites, a.n_ind
+    capi.lib().ngsld_host_set_threads(a.n_threads)
     meta = torch.zeros(2, dtype=torch.int64, device=dev)
     if rank == 0:
         if binary:

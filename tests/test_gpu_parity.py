@@ -213,3 +213,30 @@ def test_api_error_paths(engine):
         assert e.value.code == capi.ERR_INVALID
     finally:
         fresh.close()
+
+
+def test_chunked_host_ingestion(monkeypatch):
+    """Host matrices enter the device in chunks of sites through two staging buffers; forced here to 3 sites per
+    chunk (NGSLD_STAGE_BYTES) so that 50 sites take 17 chunks -- results must equal the one-chunk run bit for bit."""
+    from ngsld_amd import capi
+    raw = synth.make_gl_numpy(50, 70, 501, depth=5.0)
+    outs = []
+    for stage in (None, str(3 * 70 * 24), "1"):
+        if stage is None:
+            monkeypatch.delenv("NGSLD_STAGE_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("NGSLD_STAGE_BYTES", stage)
+        eng = capi.Engine(0)
+        try:
+            eng.set_geno_raw(raw)
+            maf = eng.maf()
+            eng.set_pos_dist(None)
+            eng.plan(extend_out=True)
+            outs.append((maf,) + eng.run())
+        finally:
+            eng.close()
+    for other in outs[1:]:
+        for x, y in zip(outs[0], other):
+            assert np.array_equal(x, y)
+    o = orc.Oracle(raw)
+    assert np.all(close(outs[0][0], o.maf, MAF_TOL))

@@ -205,3 +205,15 @@ def test_read_geno_text_errors(tmp_path):
     with pytest.raises(capi.NgsldError) as e:
         capi.read_geno_text(str(p), False, False, 3, 1)
     assert "not at EOF" in e.value.msg
+
+
+def test_read_geno_text_threads_agree(tmp_path):
+    fx = Fixture("f8_text_probs")
+    g, _ = fx.write_inputs(str(tmp_path))
+    L = capi.lib()
+    L.ngsld_host_set_threads(1)
+    a, la = capi.read_geno_text(g, True, False, fx.n_ind, fx.n_sites)
+    L.ngsld_host_set_threads(7)
+    b, lb = capi.read_geno_text(g, True, False, fx.n_ind, fx.n_sites)
+    L.ngsld_host_set_threads(1)
+    assert la == lb and np.array_equal(a, b, equal_nan=True)
