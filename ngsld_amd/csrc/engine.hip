@@ -16,6 +16,7 @@
 #include "../../include/ngsld.h"
 #include "ld_device.h"
 #include "ld_prep.h"
+#include "taus.h"
 
 using namespace ngsld;
 
@@ -485,22 +486,10 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) {
     // ngsLD.cpp:69-70,165-166: one master gsl_rng_taus stream, row s1's seed = (unsigned long)(uniform * 1e15),
     // drawn for s1 = 0, 1, 2, ... (serial by construction; n_sites draws)
     seeds.resize(n);
-    struct {
-      uint32_t s1, s2, s3;
-      uint32_t get() {
-        s1 = ((s1 & 4294967294u) << 12) ^ (((s1 << 13) ^ s1) >> 19);
-        s2 = ((s2 & 4294967288u) << 4) ^ (((s2 << 2) ^ s2) >> 25);
-        s3 = ((s3 & 4294967280u) << 17) ^ (((s3 << 3) ^ s3) >> 11);
-        return s1 ^ s2 ^ s3;
-      }
-    } m;
-    uint64_t sd = p->seed ? p->seed : 1;
-    m.s1 = (uint32_t)(69069ull * sd);
-    m.s2 = 69069u * m.s1;
-    m.s3 = 69069u * m.s2;
-    for (int k = 0; k < 6; ++k) m.get();
-    for (uint64_t k = 0; k < p->first_row; ++k) m.get();  // rows that live on other GPUs
-    for (uint64_t s = 0; s < n; ++s) seeds[s] = (uint64_t)(0 + (m.get() / 4294967296.0) * (double)1000000000000000ull);
+    Taus master;
+    master.set(p->seed);
+    for (uint64_t k = 0; k < p->first_row; ++k) master.get();  // rows that live on other GPUs
+    for (uint64_t s = 0; s < n; ++s) seeds[s] = master.row_seed();
     HIP_TRY(c, c->d_row_seed.resize(n));
     HIP_TRY(c, hipMemcpyAsync(c->d_row_seed.p, seeds.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
   }

@@ -6,6 +6,7 @@
 //   exp -> planes [site][geno][np] (+ mean and centred second moment of the expected genotypes, which
 //   is everything pearson_r needs per site).
 #include "ld_prep.h"
+#include "taus.h"
 
 namespace ngsld {
 
@@ -171,26 +172,6 @@ hipError_t launch_prep(const PrepArgs &a, hipStream_t stream) {
   hipLaunchKernelGGL(prep_sites_kernel, dim3(grid), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
-
-// gsl_rng_taus (L'Ecuyer's 3-component Tausworthe generator; algorithm as published in GSL's rng/taus.c): the
-// per-row streams of the reference's random sub-sampling (ngsLD.cpp:165-166,277).
-struct Taus {
-  uint32_t s1, s2, s3;
-  __device__ __forceinline__ uint32_t get() {
-    s1 = ((s1 & 4294967294u) << 12) ^ (((s1 << 13) ^ s1) >> 19);
-    s2 = ((s2 & 4294967288u) << 4) ^ (((s2 << 2) ^ s2) >> 25);
-    s3 = ((s3 & 4294967280u) << 17) ^ (((s3 << 3) ^ s3) >> 11);
-    return s1 ^ s2 ^ s3;
-  }
-  __device__ __forceinline__ void set(uint64_t seed) {
-    if (seed == 0) seed = 1;
-    s1 = (uint32_t)(69069ull * seed);
-    s2 = 69069u * s1;
-    s3 = 69069u * s2;
-    for (int k = 0; k < 6; ++k) get();
-  }
-  __device__ __forceinline__ double uniform() { return get() / 4294967296.0; }
-};
 
 __global__ void items_kernel(ItemArgs A) {
   const uint32_t s1 = blockIdx.x * blockDim.x + threadIdx.x;
