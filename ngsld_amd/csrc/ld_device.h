@@ -21,6 +21,10 @@
 
 namespace ngsld {
 
+#ifndef NGSLD_PAIR_RCP
+#define NGSLD_PAIR_RCP 1  // build-time A/B switch of the paired-reciprocal trick in em_pair (0 = one rcp per individual)
+#endif
+constexpr bool kPairRcp = NGSLD_PAIR_RCP != 0;
 constexpr int kIterMax = 100;      // ITER_MAX, gen_func.hpp:18
 constexpr double kEpsilon = 1e-5;  // EPSILON,  gen_func.hpp:16
 
@@ -139,6 +143,8 @@ __device__ __forceinline__ bool miss_data(double g0, double g1, double g2) {
 // ---------------------------------------------------------------------------------------------
 // Building blocks of the pair kernels
 // ---------------------------------------------------------------------------------------------
+struct PairedTag { static constexpr bool value = true; };   // compile-time selectors of em_pair's reciprocal scheme
+struct SingleTag { static constexpr bool value = false; };
 typedef __attribute__((address_space(3))) void lds_void_t;        // operands of __builtin_amdgcn_global_load_lds
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
@@ -199,25 +205,43 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   asm("" : "+v"(inv_x));
   bool bad = false;
   uint32_t n_iter = 0;
-  for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
+  // Slots known to be full (no padding / missing lanes) take their reciprocals two at a time:
+  //   r = 1/(s_a s_b),  1/s_a = s_b r,  1/s_b = s_a r      -- one 16-cycle v_rcp_f64 + 3 mul instead of two rcp chains.
+  // s lies in (0, 1]; the product can only underflow when both factors are below 1e-154, and that -- like any other
+  // non-finite outcome -- is caught by the sanity test on the new frequencies, after which the iteration is redone
+  // with one reciprocal per individual before anything is concluded from it.
+  constexpr int kPaired = CHECK_ALL ? 0 : (SLOTS - 1) / 2;
+  auto em_step = [&](auto paired_tag, double &n0, double &n1, double &n2, double &n3) {
+    constexpr bool kPair = decltype(paired_tag)::value;
     // products f_k f_h: they build the two-locus genotype weights W (s = sum_G W[G] P[G] is the
     // reference's 16-term `sum`, gen_func.cpp:1093-1096) and are reused by the t_k contraction below
     const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
     const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
     const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
     double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
+    auto slot_s = [&](int j) -> double {
+      double s = p00 * P[j][0];
+      s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
+      s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
+      s = fma(p22, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(p33, P[j][8], s);
+      return s;
+    };
+    auto slot_acc = [&](int j, double r) {
+      R0 = fma(P[j][0], r, R0); R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
+      R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
+      R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
+    };
+    constexpr int kFirstSingle = kPair ? 2 * kPaired : 0;
 #pragma unroll
-    for (int j = 0; j < SLOTS; ++j) {
-      if ((!CHECK_ALL && j < SLOTS - 1) || ((vbits >> j) & 1u)) {
-        double s = p00 * P[j][0];
-        s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
-        s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
-        s = fma(p22, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(p33, P[j][8], s);
-        const double r = rcp_refined(s);
-        R0 = fma(P[j][0], r, R0); R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
-        R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
-        R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
-      }
+    for (int q = 0; q < (kPair ? kPaired : 0); ++q) {
+      const double sa = slot_s(2 * q), sb = slot_s(2 * q + 1);
+      const double r = rcp_refined(sa * sb);
+      slot_acc(2 * q, sb * r);
+      slot_acc(2 * q + 1, sa * r);
+    }
+#pragma unroll
+    for (int j = kFirstSingle; j < SLOTS; ++j) {
+      if ((!CHECK_ALL && j < SLOTS - 1) || ((vbits >> j) & 1u)) slot_acc(j, rcp_refined(slot_s(j)));
     }
     // t_k = sum_h f_k f_h R[G(k,h)]  (= this lane's share of ff_k / 2, gen_func.cpp:1098-1104)
     double t0 = fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0)));
@@ -230,20 +254,33 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
       if (lane == 0) {
         xch[par][sub][0] = t0; xch[par][sub][1] = t1; xch[par][sub][2] = t2; xch[par][sub][3] = t3;
       }
-      __syncthreads();
+      lds_barrier();
       t0 = t1 = t2 = t3 = 0.0;
       for (int w = 0; w < WAVES; ++w) {
         t0 += xch[par][w][0]; t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
       }
     }
-    const double n0 = t0 * inv_x, n1 = t1 * inv_x, n2 = t2 * inv_x, n3 = t3 * inv_x;
+    n0 = t0 * inv_x; n1 = t1 * inv_x; n2 = t2 * inv_x; n3 = t3 * inv_x;
+  };
+  for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
+    double n0, n1, n2, n3;
+    if (kPaired > 0 && kPairRcp)
+      em_step(PairedTag(), n0, n1, n2, n3);
+    else
+      em_step(SingleTag(), n0, n1, n2, n3);
     // Any individual with s == 0 makes every tmp/sum NaN in the reference, hence all four f NaN and, as a
     // NaN difference never raises eps (gen_func.cpp:1049-1053), "convergence" at this iteration.  Here
     // s == 0 poisons every R with inf/NaN, so a sum that is not a sane ~1 <=> the reference is all NaN.
-    const double sn = (n0 + n1) + (n2 + n3);
+    double sn = (n0 + n1) + (n2 + n3);
     if (__builtin_amdgcn_ballot_w64(!(sn < 2.0))) {  // wave-uniform values: the ballot is all-or-nothing
-      bad = true;
-      break;
+      if (kPaired > 0 && kPairRcp) {  // rule out an underflowed reciprocal product before concluding anything
+        em_step(SingleTag(), n0, n1, n2, n3);
+        sn = (n0 + n1) + (n2 + n3);
+      }
+      if (__builtin_amdgcn_ballot_w64(!(sn < 2.0))) {
+        bad = true;
+        break;
+      }
     }
     const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
     f0 = n0; f1 = n1; f2 = n2; f3 = n3;
