@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--pairs-per-item", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--ignore-miss", action="store_true", help="run the --ignore_miss_data kernels (not the headline config)")
     ap.add_argument("--sink", action="store_true", help="also time ngsld_run (records copied to pinned host memory)")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "hbm_traffic.json"))
     return ap.parse_args()
@@ -140,14 +141,15 @@ def main():
     slab = raw[slab_lo:slab_hi]
     torch.cuda.synchronize()
     t_prep = time.perf_counter()
-    eng.set_geno_raw(slab.data_ptr(), n_sites=slab_hi - slab_lo, n_ind=n_ind)   # per-site prep kernel (one-off)
+    eng.set_geno_raw(slab.data_ptr(), n_sites=slab_hi - slab_lo, n_ind=n_ind,
+                     ignore_miss_data=args.ignore_miss)                          # per-site prep kernel (one-off)
     t_prep = time.perf_counter() - t_prep
     local_pd = pos_dist[slab_lo:slab_hi].copy()
     eng.set_pos_dist(local_pd)
     if args.pairs_per_item:
         eng.set_tuning(pairs_per_item=args.pairs_per_item)
     t_plan = time.perf_counter()
-    eng.plan(max_kb_dist=args.max_kb, extend_out=True)                            # pair-space plan (one-off)
+    eng.plan(max_kb_dist=args.max_kb, extend_out=True, ignore_miss_data=args.ignore_miss)   # pair-space plan (one-off)
     t_plan = time.perf_counter() - t_plan
     row_off, _ = eng.plan_rows()
     n_rows = hi - lo
@@ -155,7 +157,7 @@ def main():
     assert n_pairs == int(counts[lo:hi].sum()), "engine plan and host mirror disagree on the pair count"
 
     raw_head = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and not args.ignore_miss:
         head = min(n_sites, 12_000)
         raw_head = raw[:head].cpu().numpy()
     del slab, raw
