@@ -24,6 +24,23 @@ with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
     synth.write_pos(p, chrs, pos)
     n_pairs = int(shard.row_pair_counts(shard.pos_dist_from_positions(chrs, pos), 100, 0).sum())
     del raw
+    if os.environ.get("E2E_MD5") == "1":      # content check: thread count must not change a single byte
+        import hashlib
+        sums = []
+        for t in (1, threads):
+            o = os.path.join(d, f"out{t}.ld")
+            r = subprocess.run([capi.CLI_PATH, "--geno", g, "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--pos", p,
+                                "--max_kb_dist", "100", "--extend_out", "--n_threads", str(t), "--verbose", "0",
+                                "--out", o], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            h = hashlib.md5()
+            with open(o, "rb") as fh:
+                for blk in iter(lambda: fh.read(1 << 24), b""):
+                    h.update(blk)
+            sums.append((h.hexdigest(), os.path.getsize(o)))
+            os.unlink(o)
+        print("md5/size per thread count:", sums, "IDENTICAL" if sums[0] == sums[1] else "DIFFERENT")
+        assert sums[0] == sums[1]
     for t in (1, threads):
         t0 = time.perf_counter()
         r = subprocess.run([capi.CLI_PATH, "--geno", g, "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--pos", p,
