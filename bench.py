@@ -247,8 +247,10 @@ def main():
                        "host_handoff_pairs_per_s_rank0": sink_rate},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("pair_ld_row_kernel" if n_ind <= 128 else "pair_ld_pf_kernel" if n_ind <= 512
-                                    else "pair_ld_kernel (multi-wavefront)"),
+                         "kernel": ("pair_ld_group_kernel" if n_ind <= 128 or (n_ind <= 256 and ((n_ind + 31) // 32) % 2)
+                                    else "pair_ld_pf_kernel" if n_ind <= 512
+                                    else "pair_ld_kernel (multi-wavefront)" if n_ind <= 4096
+                                    else "pair_ld_stream_kernel"),
                          "kernel_ms_per_launch": launch_s * 1e3,
                          "algorithmic_bytes_per_pair": bytes_pair,
                          "fp64_valu": {"achieved": fp64_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -535,40 +535,45 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row kernel (n_ind <= 128): a 16-lane DPP row owns one pair, so a wavefront runs FOUR pairs in lockstep and a
-// 256-thread workgroup sixteen, all of one row s1.  With few individuals the per-iteration bookkeeping
-// (f products, contraction, reduction, convergence test) outweighs the per-individual work; sharing each of
-// those instructions between four pairs is worth more than the lanes lost to lockstep (a row that has
-// converged idles until the slowest of its three neighbours has).
-//   lane = 16*row + r;  individual of (lane, slot j) = 16*j + r;  SLOTS = ceil(n_ind / 16) <= 8;  np = 16*SLOTS
-//   LDS: [row vector a, linear][per wavefront: next-site buffers of its 4 rows, interleaved in 256-byte pieces
-//        because global_load_lds writes wave-base + 16*lane: piece q of row rr sits at q*1024 + rr*256]
-// Values that are wavefront-uniform in the 64-lane kernels (f, the f products, eps) are row-uniform VGPR
-// values here; reductions are 4 DPP steps inside the row, in a fixed order.
+// Group kernel (n_ind <= 256): a group of G = 8, 16 or 32 lanes owns one pair, so a wavefront runs 8, 4 or 2 pairs in
+// lockstep, all of one row s1.  With few individuals the per-iteration bookkeeping (f products, contraction,
+// reduction, convergence test) outweighs the per-individual work; sharing each of those instructions between the
+// pairs of a wavefront is worth more than the lanes lost to lockstep (a group that has converged idles until the
+// slowest group of its wavefront has).
+//   lane = G*grp + r;  individual of (lane, slot j) = G*j + r;  SLOTS = ceil(n_ind / G) <= 8;  np = G*SLOTS
+//   LDS: [row vector a, linear][per wavefront: next-site buffers of its 64/G groups, interleaved in pieces of 16*G
+//        bytes because global_load_lds writes wave-base + 16*lane: piece q of group gg sits at q*1024 + gg*16*G]
+// Values that are wavefront-uniform in the 64-lane kernels (f, the f products, eps) are group-uniform VGPR values
+// here; reductions are DPP steps inside the group, in a fixed order.
 // ---------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ double dpp_add(double v) { return v + dpp_mov<CTRL>(v); }
 
-__device__ __forceinline__ double row_sum(double v) {  // sum over the 16 lanes of a row, result in every lane
-  v = dpp_add<0x128>(v);  // row_ror:8
-  v = dpp_add<0x124>(v);  // row_ror:4
-  v = dpp_add<0x4E>(v);   // quad_perm:[2,3,0,1]
-  v = dpp_add<0xB1>(v);   // quad_perm:[1,0,3,2]
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {  // sum over the G lanes of a group, result in every lane of it
+  v = dpp_add<0xB1>(v);               // quad_perm:[1,0,3,2]
+  v = dpp_add<0x4E>(v);               // quad_perm:[2,3,0,1]
+  if (G == 8) return dpp_add<0x141>(v);  // row_half_mirror: lane l <-> 7 - l inside each 8-lane half row
+  v = dpp_add<0x124>(v);              // row_ror:4
+  v = dpp_add<0x128>(v);              // row_ror:8
+  if (G == 32) v = fold16(v, v);      // odd rows trade places with even rows of the copy: row0+row1 | row2+row3
   return v;
 }
 
-template <int SLOTS, bool MASKED>
-__global__ __launch_bounds__(256, 2) void pair_ld_row_kernel(PairArgs A) {
-  constexpr uint32_t kNp = SLOTS * 16;
+template <int G, int SLOTS, bool MASKED>
+__global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
+  constexpr uint32_t kNp = SLOTS * G;
   constexpr int kSiteBytes = (int)kNp * 24;
-  constexpr int kPieces = (kSiteBytes + 255) / 256;         // 256-byte pieces of one site
+  constexpr int kPiece = G * 16;                             // bytes one group moves per copy instruction
+  constexpr int kPieces = (kSiteBytes + kPiece - 1) / kPiece;
   constexpr int kABytes = ((kSiteBytes + 1023) / 1024) * 1024;
-  constexpr int kWaveBuf = kPieces * 1024;                  // four rows interleaved
+  constexpr int kWaveBuf = kPieces * 1024;                   // the 64/G groups of a wavefront, interleaved
+  constexpr unsigned long long kGroupMask = G == 32 ? 0xffffffffull : ((1ull << G) - 1ull);
   __shared__ __attribute__((aligned(16))) char smem[kABytes + 4 * kWaveBuf + 16];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int row = lane >> 4, rl = lane & 15;
+  const int grp = lane / G, gl = lane % G;
   const Item it = A.items[blockIdx.x];
   const uint32_t s1 = it.s1;
   const double m1 = A.maf[s1];
@@ -580,32 +585,32 @@ __global__ __launch_bounds__(256, 2) void pair_ld_row_kernel(PairArgs A) {
   uint32_t *claim = reinterpret_cast<uint32_t *>(smem + kABytes + 4 * kWaveBuf);
 
   if (threadIdx.x == 0) *claim = 0;
-  // a row claims the next computed pair of the item (maf[s2] / sub-sampling filters live in the mask, ngsLD.cpp:270-282)
-  auto claim_row = [&]() -> uint32_t {
+  // a group claims the next computed pair of the item (maf[s2] / sub-sampling filters live in the mask, ngsLD.cpp:270-282)
+  auto claim_group = [&]() -> uint32_t {
     uint32_t c;
     for (;;) {
       c = 0;
-      if (rl == 0) c = atomicAdd(claim, 1u);
-      c = (uint32_t)__shfl((int)c, lane & 48);
+      if (gl == 0) c = atomicAdd(claim, 1u);
+      c = (uint32_t)__shfl((int)c, lane & ~(G - 1));
       if (c >= it.count || ((it.mask >> c) & 1ull)) break;
     }
     return c;
   };
-  // byte offset of individual-slot j, genotype plane g of this lane's row inside the interleaved wave buffer
+  // byte offset of individual-slot j, genotype plane g of this lane's group inside the interleaved wave buffer
   auto b_off = [&](int g, int j) -> uint32_t {
-    const uint32_t o = ((uint32_t)g * kNp + (uint32_t)j * 16u + (uint32_t)rl) * 8u;  // offset inside the site
-    return (o >> 8) * 1024u + (uint32_t)row * 256u + (o & 255u);
+    const uint32_t o = ((uint32_t)g * kNp + (uint32_t)j * (uint32_t)G + (uint32_t)gl) * 8u;  // offset inside the site
+    return (o / (uint32_t)kPiece) * 1024u + (uint32_t)grp * (uint32_t)kPiece + (o % (uint32_t)kPiece);
   };
-  // start the copy of site (s2_begin + c) for every row whose c is inside the item: lane (row, rl) moves the
-  // 16 bytes [q*256 + rl*16, +16) of its row's site for q = 0 .. kPieces-1
-  auto dma_rows = [&](uint32_t c) {
+  // start the copy of site (s2_begin + c) for every group whose c is inside the item: lane (grp, r) moves the
+  // 16 bytes [q*kPiece + r*16, +16) of its group's site for q = 0 .. kPieces-1
+  auto dma_groups = [&](uint32_t c) {
     const bool on = c < it.count;
     const char *g = reinterpret_cast<const char *>(A.planes + (uint64_t)(it.s2_begin + (on ? c : 0u)) * A.site_stride) +
-                    rl * 16;
+                    gl * 16;
 #pragma unroll
     for (int q = 0; q < kPieces; ++q)
-      if (on && q * 256 + rl * 16 < kSiteBytes)
-        __builtin_amdgcn_global_load_lds((glb_void_t *)(g + q * 256), (lds_void_t *)(lds_w + q * 1024), 16, 0, 0);
+      if (on && q * kPiece + gl * 16 < kSiteBytes)
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(g + q * kPiece), (lds_void_t *)(lds_w + q * 1024), 16, 0, 0);
   };
   struct SiteScalars {
     double maf, mean, rsx;
@@ -630,26 +635,26 @@ __global__ __launch_bounds__(256, 2) void pair_ld_row_kernel(PairArgs A) {
         __builtin_amdgcn_global_load_lds((glb_void_t *)(g + k * 1024), (lds_void_t *)(lds_a + k * 1024), 16, 0, 0);
   }
   __syncthreads();  // claim counter initialised
-  uint32_t c = claim_row();
+  uint32_t c = claim_group();
   SiteScalars cur = load_scalars(c);
-  dma_rows(c);
+  dma_groups(c);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // row vector complete in LDS
 
   while (__any(c < it.count)) {
     const bool active = c < it.count;
-    const uint32_t cn = active ? claim_row() : c;
+    const uint32_t cn = active ? claim_group() : c;
     const SiteScalars nxt = load_scalars(cn);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the four site copies issued a generation ago have landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the site copies issued a generation ago have landed
 
-    // ---- stage: P = a (x) b per lane, validity, Pearson cross moment (row sums) ----
+    // ---- stage: P = a (x) b per lane, validity, Pearson cross moment (group sums) ----
     double P[SLOTS][9];
     uint32_t vbits = 0;
     double sxy = 0.0;
     const double *la = reinterpret_cast<const double *>(lds_a);
 #pragma unroll
     for (int j = 0; j < SLOTS; ++j) {
-      const uint32_t i = (uint32_t)j * 16u + (uint32_t)rl;
+      const uint32_t i = (uint32_t)j * (uint32_t)G + (uint32_t)gl;
       const double a0 = la[i], a1 = la[kNp + i], a2 = la[2 * kNp + i];
       const double b0 = *reinterpret_cast<const double *>(lds_w + b_off(0, j));
       const double b1 = *reinterpret_cast<const double *>(lds_w + b_off(1, j));
@@ -666,17 +671,18 @@ __global__ __launch_bounds__(256, 2) void pair_ld_row_kernel(PairArgs A) {
       sxy = fma(c1, c2, sxy);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // buffers consumed: start the next generation's copies
-    dma_rows(cn);
-    uint32_t x = 0;  // individuals with data in this row's pair (gen_func.cpp:1091), integer exact
+    dma_groups(cn);
+    uint32_t x = 0;  // individuals with data in this group's pair (gen_func.cpp:1091), integer exact
 #pragma unroll
-    for (int j = 0; j < SLOTS; ++j) x += (uint32_t)__popcll((__ballot((vbits >> j) & 1u) >> (row * 16)) & 0xffffull);
-    sxy = row_sum(sxy);
+    for (int j = 0; j < SLOTS; ++j)
+      x += (uint32_t)__popcll((__ballot((vbits >> j) & 1u) >> (grp * G)) & kGroupMask);
+    sxy = group_sum<G>(sxy);
 
-    // ---- haplo_freq (gen_func.cpp:1027-1059), four pairs in lockstep ----
+    // ---- haplo_freq (gen_func.cpp:1027-1059), 64/G pairs in lockstep ----
     const double m2 = cur.maf;
     double f0 = (1 - m1) * (1 - m2), f1 = (1 - m1) * m2, f2 = m1 * (1 - m2), f3 = m1 * m2;
     if (active && (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1)) {
-      if (rl == 0) atomicExch(A.status, (int)NGSLD_ERR_MAF_RANGE);
+      if (gl == 0) atomicExch(A.status, (int)NGSLD_ERR_MAF_RANGE);
       f0 = f1 = f2 = f3 = __builtin_nan("");
     }
     const double inv_x = 1.0 / (double)x;
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_row_kernel(PairArgs A) {
       double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
 #pragma unroll
       for (int j = 0; j < SLOTS; ++j) {
-        // without --ignore_miss_data only the last slot can hold padding lanes; a row without a pair computes
+        // without --ignore_miss_data only the last slot can hold padding lanes; a group without a pair computes
         // on stale buffers there, which is harmless (it is `done` from the start and never written)
         if ((!MASKED && j < SLOTS - 1) || ((vbits >> j) & 1u)) {
           double s = p00 * P[j][0];
@@ -702,10 +708,10 @@ __global__ __launch_bounds__(256, 2) void pair_ld_row_kernel(PairArgs A) {
           R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
         }
       }
-      const double t0 = row_sum(fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0))));
-      const double t1 = row_sum(fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1))));
-      const double t2 = row_sum(fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3))));
-      const double t3 = row_sum(fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4))));
+      const double t0 = group_sum<G>(fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0))));
+      const double t1 = group_sum<G>(fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1))));
+      const double t2 = group_sum<G>(fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3))));
+      const double t3 = group_sum<G>(fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4))));
       const double n0 = t0 * inv_x, n1 = t1 * inv_x, n2 = t2 * inv_x, n3 = t3 * inv_x;
       const double sn = (n0 + n1) + (n2 + n3);
       const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_row_kernel(PairArgs A) {
       if (__all(done)) break;
     }
 
-    if (active && rl == 0)
+    if (active && gl == 0)
       write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, cur.rsx, x,
                  n_iter);
     c = cn;
@@ -851,21 +857,22 @@ __global__ __launch_bounds__(256, 2) void pair_ld_stream_kernel(PairArgs A) {
 }
 
 // host-callable launchers, defined in ld_pair_w1.hip / ld_pair_wn.hip
-// Kernel families: kRow = 16 lanes per pair (n_ind <= 128), kWave = one wavefront per pair with the row vector shared
+// Kernel families: kGroup = 8/16/32 lanes per pair (n_ind <= 256), kWave = one wavefront per pair with the row vector shared
 // in LDS (n_ind <= 512), kMulti = 2..8 wavefronts per pair (n_ind <= 4096), kStream = any n_ind, vectors re-read every
 // iteration; kDirect = kWave/kMulti shapes without any prefetch (A/B).
-enum PairKernel { kRow = 0, kWave = 1, kMulti = 2, kDirect = 3, kStream = 4 };
+enum PairKernel { kGroup = 0, kWave = 1, kMulti = 2, kDirect = 3, kStream = 4 };
 struct PairConfig {
   int kernel;   // PairKernel
+  int group;    // kGroup: lanes per pair (8, 16 or 32); 64 otherwise
   int slots;    // individuals per lane
   int waves;    // wavefronts per pair
   uint32_t np;  // padded individuals per genotype plane
 };
 bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg);
 hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs &args, hipStream_t stream);
-// candidate s2 sites per work item: kRow / kWave items are shared by the four wavefronts of a workgroup
+// candidate s2 sites per work item: kGroup / kWave items are shared by the four wavefronts of a workgroup
 inline uint32_t item_span(const PairConfig &cfg, uint32_t pairs_per_item) {
-  const uint32_t span = (cfg.kernel == kRow || cfg.kernel == kWave) ? 4u * pairs_per_item : pairs_per_item;
+  const uint32_t span = (cfg.kernel == kGroup || cfg.kernel == kWave) ? 4u * pairs_per_item : pairs_per_item;
   return span > 64u ? 64u : span;
 }
 

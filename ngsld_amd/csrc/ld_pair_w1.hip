@@ -3,10 +3,12 @@
 
 namespace ngsld {
 
-// n_ind -> kernel family and shape.  16 lanes x 8 slots cover 128 individuals (row kernel); one wavefront
-// holds up to 8*64 = 512 individuals as 18*8 = 144 VGPRs of P; above that 2..8 wavefronts share the pair.
+// n_ind -> kernel family and shape.  Lane groups of 8 / 16 / 32 lanes x 8 slots cover 64 / 128 / 256 individuals
+// (group kernel); one wavefront holds up to 8*64 = 512 individuals as 18*8 = 144 VGPRs of P; above that 2..8
+// wavefronts share the pair, and beyond 4096 the streaming kernel takes over.
 bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg) {
   if (n_ind == 0 || n_ind >= 0xffffffc0ull) return false;
+  cfg->group = 64;
   if (n_ind > 4096) {  // beyond 8 wavefronts x 8 slots x 64 lanes: streaming kernel, one workgroup per pair
     cfg->kernel = kStream;
     cfg->waves = 4;
@@ -14,11 +16,15 @@ bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig
     cfg->np = (uint32_t)((n_ind + 63) / 64 * 64);
     return true;
   }
-  if (allow_prefetch && allow_row && n_ind <= 128) {
-    cfg->kernel = kRow;
+  // 32-lane groups pay only where they pad less than 64 lanes do (an odd number of 32-individual slots: measured
+  // +6..8 % at n_ind 160 / 200, -3 % at 250 where both shapes hold 256 individuals and lockstep is a pure loss)
+  const bool g32 = n_ind > 128 && n_ind <= 256 && (((n_ind + 31) / 32) & 1ull);
+  if (allow_prefetch && allow_row && (n_ind <= 128 || g32)) {
+    cfg->kernel = kGroup;
     cfg->waves = 1;
-    cfg->slots = (int)((n_ind + 15) / 16);
-    cfg->np = (uint32_t)cfg->slots * 16u;
+    cfg->group = n_ind <= 64 ? 8 : (n_ind <= 128 ? 16 : 32);
+    cfg->slots = (int)((n_ind + (uint64_t)cfg->group - 1) / (uint64_t)cfg->group);
+    cfg->np = (uint32_t)(cfg->slots * cfg->group);
     return true;
   }
   int w = 1;
@@ -30,18 +36,40 @@ bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig
   return true;
 }
 
+template <int G, int SLOTS>
+static hipError_t launch_g(bool masked, const PairArgs &a, hipStream_t stream) {
+  if (a.n_items == 0) return hipSuccess;
+  if (a.n_items > 0x7fffffffull) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)a.n_items), block(256);
+  if (masked)
+    hipLaunchKernelGGL((pair_ld_group_kernel<G, SLOTS, true>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((pair_ld_group_kernel<G, SLOTS, false>), grid, block, 0, stream, a);
+  return hipGetLastError();
+}
+
+template <int G>
+static hipError_t launch_group(int slots, bool masked, const PairArgs &a, hipStream_t stream) {
+  switch (slots) {
+    case 1: return launch_g<G, 1>(masked, a, stream);
+    case 2: return launch_g<G, 2>(masked, a, stream);
+    case 3: return launch_g<G, 3>(masked, a, stream);
+    case 4: return launch_g<G, 4>(masked, a, stream);
+    case 5: return launch_g<G, 5>(masked, a, stream);
+    case 6: return launch_g<G, 6>(masked, a, stream);
+    case 7: return launch_g<G, 7>(masked, a, stream);
+    case 8: return launch_g<G, 8>(masked, a, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 template <int SLOTS>
 static hipError_t launch_s(int kernel, bool masked, const PairArgs &a, hipStream_t stream) {
   const uint64_t blocks = kernel == kDirect ? (a.n_items + 3) / 4 : a.n_items;
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   const dim3 grid((unsigned)blocks), block(256);
-  if (kernel == kRow) {
-    if (masked)
-      hipLaunchKernelGGL((pair_ld_row_kernel<SLOTS, true>), grid, block, 0, stream, a);
-    else
-      hipLaunchKernelGGL((pair_ld_row_kernel<SLOTS, false>), grid, block, 0, stream, a);
-  } else if (kernel == kWave) {
+  if (kernel == kWave) {
     if (masked)
       hipLaunchKernelGGL((pair_ld_pf_kernel<SLOTS, true>), grid, block, 0, stream, a);
     else
@@ -66,6 +94,11 @@ hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs
     else
       hipLaunchKernelGGL((pair_ld_stream_kernel<false>), dim3((unsigned)a.n_items), dim3(256), 0, stream, a);
     return hipGetLastError();
+  }
+  if (cfg.kernel == kGroup) {
+    if (cfg.group == 8) return launch_group<8>(cfg.slots, masked, a, stream);
+    if (cfg.group == 16) return launch_group<16>(cfg.slots, masked, a, stream);
+    return launch_group<32>(cfg.slots, masked, a, stream);
   }
   if (cfg.waves != 1) return launch_pair_wn(cfg.slots, cfg.waves, masked, cfg.kernel == kMulti, a, stream);
   switch (cfg.slots) {

@@ -39,7 +39,7 @@ def test_selftest(engine):
 
 @pytest.mark.parametrize("n_sites,n_ind,depth,seed", [
     (100, 24, 2.0, 1),      # C1 shape, slow convergence incl. nIter == 100
-    (128, 100, 5.0, 7),     # 2 slots, padded last slot
+    (128, 100, 5.0, 7),     # 16-lane groups, padded last slot
     (64, 500, 10.0, 6),     # headline n_ind, 8 slots
     (48, 64, 10.0, 11),     # exactly one full slot
     (40, 65, 10.0, 12),     # one individual in the second slot
@@ -147,9 +147,13 @@ def test_rnd_sample_streams(engine, rnd, seed):
 
 @pytest.mark.parametrize("n_sites,n_ind,seed", [
     (2, 1, 201), (3, 2, 202), (1, 40, 203),            # degenerate sizes (one site: no pair at all)
-    (30, 16, 204), (30, 17, 205),                      # row kernel: one full slot / one lane into the second
-    (20, 128, 206), (20, 129, 207),                    # last shape of the row kernel / first of the wavefront kernel
-    (40, 130, 208), (16, 448, 209),                    # wavefront kernel, partial last slot
+    (40, 7, 210), (40, 8, 211), (40, 9, 212),          # 8-lane groups: partial / full first slot, one lane into the second
+    (30, 16, 204), (30, 17, 205), (30, 63, 213),       # 8-lane groups, up to 8 slots
+    (30, 64, 214), (30, 65, 215),                      # last shape of the 8-lane groups / first of the 16-lane groups
+    (20, 128, 206), (20, 129, 207),                    # last shape of the 16-lane groups / first of the 32-lane groups
+    (40, 130, 208), (24, 160, 216), (24, 161, 217),    # 32-lane groups (5 slots) / wavefront kernel (161..192)
+    (24, 193, 218), (24, 224, 219), (24, 225, 220),    # 32-lane groups (7 slots) / wavefront kernel again
+    (16, 448, 209),                                    # wavefront kernel, partial last slot
 ])
 def test_kernel_family_boundaries(engine, n_sites, n_ind, seed):
     raw = synth.make_gl_numpy(n_sites, n_ind, seed, depth=6.0)
