@@ -165,6 +165,47 @@ int ngsld_set_tuning(ngsld_ctx *ctx, uint32_t pairs_per_item, uint64_t batch_pai
  * reduction, refined reciprocal).  Returns NGSLD_OK or NGSLD_ERR_DEVICE with a message. */
 int ngsld_selftest(ngsld_ctx *ctx);
 
+/* ---- Streaming: matrices larger than the device budget (windowed runs only) ------------------------------
+ * The reference keeps the whole matrix in host memory (twice during the transpose, ngsLD.cpp:87-89).  Here a
+ * windowed run (max_kb_dist and/or max_snp_dist > 0) can be cut into slabs of rows: slab k holds the sites
+ * [row_begin, site_end) = its rows plus the halo their windows reach into, and computes the rows
+ * [row_begin, row_end).  Two contexts on the same device alternate, so the file read + upload + prep of slab
+ * k+1 overlap the pair kernels of slab k; neither the host nor the device ever holds more than two slabs. */
+typedef struct {
+  uint64_t row_begin, row_end; /* rows (s1) this slab computes */
+  uint64_t site_end;           /* one past the last site any of those rows pairs with */
+} ngsld_slab;
+
+/* Upper end of the s2 walk of every row from the distance / SNP-count limits alone (ngsLD.cpp:240-262):
+ * row s1 pairs with sites (s1, row_end[s1]).  Host only, no device needed; pos_dist NULL = all INFINITY. */
+int ngsld_window_ends(const double *pos_dist, uint64_t n_sites, const ngsld_params *params, uint32_t *row_end);
+
+/* Cut rows [0, n_sites) into slabs of at most max_slab_sites sites (rows + halo).  slabs has room for `cap`
+ * entries (n_sites always suffices).  NGSLD_ERR_NOMEM when a single row's window does not fit. Host only. */
+int ngsld_plan_slabs(const double *pos_dist, uint64_t n_sites, const ngsld_params *params, uint64_t max_slab_sites,
+                     ngsld_slab *slabs, uint64_t cap, uint64_t *n_slabs);
+
+/* How many sites of n_ind individuals fit a slab when `budget_bytes` of device memory may be used in total
+ * (both contexts, their record buffers included); 0 when the budget is too small for any. */
+uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes);
+
+/* Free and total memory of HIP device `device`, in bytes. */
+int ngsld_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
+
+/* Fill dst with the raw values ([site][ind][3] doubles, as ngsld_set_geno_raw_opts takes them) of sites
+ * [site_begin, site_begin + n_sites).  Called on a library thread, never concurrently.  Non-zero = failure. */
+typedef int (*ngsld_read_sites_fn)(void *user, uint64_t site_begin, uint64_t n_sites, double *dst);
+
+/* The whole job, slab by slab: create two contexts on `device`, and for every slab read -> ngsld_set_geno_raw_opts
+ * -> ngsld_set_pos_dist -> ngsld_plan (first_row = row_begin) -> ngsld_run.  The sink sees the batches of all
+ * slabs in global (s1, s2) order with GLOBAL site indices in ngsld_batch and ngsld_item.  maf_out (n_sites
+ * doubles, may be NULL) receives est_maf of every site; entries are final before the first batch that refers to
+ * them is handed to the sink.  pos_dist: n_sites doubles or NULL.  err (may be NULL) receives the message. */
+int ngsld_run_streamed(int device, uint64_t n_sites, uint64_t n_ind, const double *pos_dist,
+                       const ngsld_params *params, const ngsld_geno_opts *opts, uint64_t max_slab_sites,
+                       ngsld_read_sites_fn read, void *read_user, double *maf_out, ngsld_sink_fn sink,
+                       void *sink_user, uint64_t *n_pairs, uint64_t *n_slabs, char *err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

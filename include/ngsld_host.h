@@ -46,6 +46,10 @@ int ngsld_host_geno_size_ok(uint64_t file_size, uint64_t n_ind, uint64_t n_sites
 /* Read n_sites*n_ind*3 raw doubles (plain or gzip-compressed file, like gzread) and require EOF after them. */
 int ngsld_host_read_geno_bin(const char *path, uint64_t n_ind, uint64_t n_sites, double *out_raw, char *err,
                              size_t errlen);
+/* The raw doubles of sites [site_begin, site_begin + n_sites) of the same file (a slab of a streamed run,
+ * ngsld_run_streamed): pread for a plain file, gzseek for a compressed one.  No EOF requirement. */
+int ngsld_host_read_geno_bin_range(const char *path, uint64_t n_ind, uint64_t site_begin, uint64_t n_sites,
+                                   double *out_raw, char *err, size_t errlen);
 
 /* Text genotype input (plain or .gz), the text branch of read_geno (read_data.cpp:48-104): one line per site,
  * fields split on blanks and TABs, only fully numeric fields count and the LAST n_ind*3 (in_probs: GL or

@@ -72,6 +72,8 @@ def items_from_pairs(s1: np.ndarray, s2: np.ndarray, span: int = 64) -> np.ndarr
 
 
 SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Batch))
+READ_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p)
+SLAB = np.dtype([("row_begin", "<u8"), ("row_end", "<u8"), ("site_end", "<u8")])
 
 # every symbol the two headers declare (checked by tests/test_abi.py against the headers' text)
 SYMBOLS = [
@@ -79,6 +81,8 @@ SYMBOLS = [
     "ngsld_set_geno_raw_opts", "ngsld_set_geno_lkl",
     "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device",
     "ngsld_last_kernel_time", "ngsld_set_tuning", "ngsld_selftest",
+    "ngsld_window_ends", "ngsld_plan_slabs", "ngsld_slab_sites_for_budget", "ngsld_device_memory", "ngsld_run_streamed",
+    "ngsld_host_read_geno_bin_range",
     "ngsld_host_set_threads", "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos", "ngsld_host_pos_slice",
     "ngsld_host_geno_size_ok", "ngsld_host_read_geno_bin", "ngsld_host_read_geno_text", "ngsld_host_format_header", "ngsld_host_format_pair",
     "ngsld_host_format_double", "ngsld_host_write_batch",
@@ -129,6 +133,14 @@ def lib() -> C.CDLL:
         L.ngsld_last_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
         L.ngsld_set_tuning.argtypes = [vp, C.c_uint32, u64]
         L.ngsld_selftest.argtypes = [vp]
+        L.ngsld_window_ends.argtypes = [vp, u64, C.POINTER(Params), vp]
+        L.ngsld_plan_slabs.argtypes = [vp, u64, C.POINTER(Params), u64, vp, u64, C.POINTER(u64)]
+        L.ngsld_slab_sites_for_budget.argtypes = [u64, u64]
+        L.ngsld_slab_sites_for_budget.restype = u64
+        L.ngsld_device_memory.argtypes = [C.c_int, C.POINTER(u64), C.POINTER(u64)]
+        L.ngsld_run_streamed.argtypes = [C.c_int, u64, u64, vp, C.POINTER(Params), C.POINTER(GenoOpts), u64, READ_FN, vp,
+                                         vp, SINK_FN, vp, C.POINTER(u64), C.POINTER(u64), C.c_char_p, C.c_size_t]
+        L.ngsld_host_read_geno_bin_range.argtypes = [C.c_char_p, u64, u64, u64, vp, C.c_char_p, C.c_size_t]
         L.ngsld_host_set_threads.argtypes = [C.c_int]
         L.ngsld_host_set_threads.restype = None
         L.ngsld_host_read_pos.argtypes = [C.c_char_p, C.c_int, u64, C.POINTER(vp), C.c_char_p, C.c_size_t]
@@ -181,6 +193,108 @@ def read_geno_bin(path: str, n_ind: int, n_sites: int) -> np.ndarray:
     if rc != OK:
         raise NgsldError(rc, err.value.decode())
     return out
+
+
+def read_geno_bin_range(path: str, n_ind: int, site_begin: int, n_sites: int) -> np.ndarray:
+    L = lib()
+    out = np.empty((n_sites, n_ind, 3), dtype=np.float64)
+    err = C.create_string_buffer(512)
+    rc = L.ngsld_host_read_geno_bin_range(path.encode(), n_ind, site_begin, n_sites, out.ctypes.data, err, len(err))
+    if rc != OK:
+        raise NgsldError(rc, err.value.decode())
+    return out
+
+
+def _params(max_kb_dist=0, max_snp_dist=0, min_maf=0.0, ignore_miss_data=False, extend_out=True, rnd_sample=1.0, seed=0,
+            first_row=0) -> Params:
+    return Params(max_kb_dist, max_snp_dist, min_maf, int(ignore_miss_data), int(extend_out), rnd_sample, seed, first_row)
+
+
+def window_ends(pos_dist: np.ndarray | None, n_sites: int, **kw) -> np.ndarray:
+    """row_end[s1] from the distance / SNP-count limits alone (host only)."""
+    pd = None if pos_dist is None else np.ascontiguousarray(pos_dist, dtype=np.float64)
+    out = np.empty(n_sites, dtype=np.uint32)
+    p = _params(**kw)
+    rc = lib().ngsld_window_ends(None if pd is None else pd.ctypes.data, n_sites, C.byref(p), out.ctypes.data)
+    if rc != OK:
+        raise NgsldError(rc, "ngsld_window_ends")
+    return out
+
+
+def plan_slabs(pos_dist: np.ndarray | None, n_sites: int, max_slab_sites: int, **kw) -> np.ndarray:
+    """Slabs (row_begin, row_end, site_end) of a streamed run (host only)."""
+    pd = None if pos_dist is None else np.ascontiguousarray(pos_dist, dtype=np.float64)
+    out = np.zeros(n_sites, dtype=SLAB)
+    n = C.c_uint64()
+    p = _params(**kw)
+    rc = lib().ngsld_plan_slabs(None if pd is None else pd.ctypes.data, n_sites, C.byref(p), max_slab_sites,
+                                out.ctypes.data, n_sites, C.byref(n))
+    if rc != OK:
+        raise NgsldError(rc, "the window of a single site does not fit the slab" if rc == ERR_NOMEM else "ngsld_plan_slabs")
+    return out[:n.value].copy()
+
+
+def slab_sites_for_budget(n_ind: int, budget_bytes: int) -> int:
+    return int(lib().ngsld_slab_sites_for_budget(n_ind, budget_bytes))
+
+
+def device_memory(device: int = 0) -> tuple[int, int]:
+    f, t = C.c_uint64(), C.c_uint64()
+    rc = lib().ngsld_device_memory(device, C.byref(f), C.byref(t))
+    if rc != OK:
+        raise NgsldError(rc, "ngsld_device_memory")
+    return f.value, t.value
+
+
+def run_streamed(read_sites, n_sites: int, n_ind: int, pos_dist: np.ndarray | None, max_slab_sites: int, device: int = 0,
+                 log_scale: bool = False, call_geno: tuple[float, float] | None = None, **kw):
+    """The whole job slab by slab (ngsld_run_streamed).  read_sites(site_begin, n) -> array [n, n_ind, 3] of raw values.
+    Returns (s1, s2, std, ext, maf, n_slabs) with global site indices."""
+    L = lib()
+    pd = None if pos_dist is None else np.ascontiguousarray(pos_dist, dtype=np.float64)
+    p = _params(**kw)
+    o = GenoOpts(int(log_scale), p.ignore_miss_data, 0, 0, int(call_geno is not None), 0,
+                 call_geno[0] if call_geno else 0.0, call_geno[1] if call_geno else 0.0)
+    s1s, s2s, stds, exts = [], [], [], []
+
+    def reader(_user, site_begin, n, dst):
+        try:
+            a = np.ascontiguousarray(read_sites(int(site_begin), int(n)), dtype=np.float64)
+            assert a.size == n * n_ind * 3
+            C.memmove(dst, a.ctypes.data, a.nbytes)
+            return 0
+        except Exception:  # noqa: BLE001 -- reported through the return code
+            return 1
+
+    def sink(_user, bp):
+        b = bp.contents
+        n = b.n_pairs
+        if n:
+            stds.append(np.frombuffer(C.string_at(b.std, n * REC_STD.itemsize), dtype=REC_STD).copy())
+            if b.ext:
+                exts.append(np.frombuffer(C.string_at(b.ext, n * REC_EXT.itemsize), dtype=REC_EXT).copy())
+        items = np.frombuffer(C.string_at(b.items, b.n_items * ITEM.itemsize), dtype=ITEM) if b.n_items else \
+            np.zeros(0, dtype=ITEM)
+        a, bb = items_to_pairs(items)
+        assert len(a) == n and (n == 0 or (a.min() >= b.s1_begin and a.max() < b.s1_end))
+        s1s.append(a)
+        s2s.append(bb)
+        return 0
+
+    maf = np.full(n_sites, np.nan)
+    n_pairs, n_slabs = C.c_uint64(), C.c_uint64()
+    err = C.create_string_buffer(512)
+    rcb, scb = READ_FN(reader), SINK_FN(sink)
+    rc = L.ngsld_run_streamed(device, n_sites, n_ind, None if pd is None else pd.ctypes.data, C.byref(p), C.byref(o),
+                              max_slab_sites, rcb, None, maf.ctypes.data, scb, None, C.byref(n_pairs), C.byref(n_slabs),
+                              err, len(err))
+    if rc != OK:
+        raise NgsldError(rc, err.value.decode())
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)
+    s1 = cat(s1s, np.uint64)
+    assert len(s1) == n_pairs.value
+    return (s1, cat(s2s, np.uint64), cat(stds, REC_STD), cat(exts, REC_EXT) if p.extend_out else None, maf,
+            int(n_slabs.value))
 
 
 def read_geno_text(path: str, in_probs: bool, log_scale: bool, n_ind: int, n_sites: int) -> tuple[np.ndarray, bool]:

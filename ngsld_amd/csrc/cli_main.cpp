@@ -4,7 +4,8 @@
 //
 // Differences a user can see (all listed in DESIGN.md):
 //   * rows are written in (site1, site2) order (the reference's order is arbitrary for --n_threads > 1);
-//   * --n_threads sets the number of host threads that format the TSV; --device N (new) picks the GPU;
+//   * --n_threads sets the number of host threads that format the TSV; --device N (new) picks the GPU, --max_gpu_mem GB (new)
+//     caps the device memory: a windowed run on binary input that does not fit is streamed slab by slab;
 #include <getopt.h>
 #include <sys/stat.h>
 
@@ -14,6 +15,7 @@
 #include <cstring>
 #include <ctime>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/ngsld.h"
@@ -39,6 +41,7 @@ struct Params {  // ngsLD.hpp:11-44
   FILE *out_fh = stdout;
   unsigned n_threads = 1, verbose = 1;
   int device = 0;
+  double max_gpu_mem = 0;  // GB of device memory the run may use; 0 = what is free on the device
 };
 
 [[noreturn]] void error(const char *func, const char *msg) {  // gen_func.cpp:12-18
@@ -72,6 +75,7 @@ void parse_cmd_args(Params *pars, int argc, char **argv) {
                                          {"n_threads", required_argument, NULL, 't'},
                                          {"verbose", required_argument, NULL, 'V'},
                                          {"device", required_argument, NULL, 1001},
+                                         {"max_gpu_mem", required_argument, NULL, 1002},
                                          {0, 0, 0, 0}};
   pars->seed = (uint64_t)(time(NULL) + rand() % 1000);  // parse_args.cpp:23
   int c = 0;
@@ -98,6 +102,7 @@ void parse_cmd_args(Params *pars, int argc, char **argv) {
       case 't': pars->n_threads = (unsigned)atoi(optarg); break;
       case 'V': pars->verbose = (unsigned)atoi(optarg); break;
       case 1001: pars->device = atoi(optarg); break;
+      case 1002: pars->max_gpu_mem = atof(optarg); break;
       default: exit(-1);  // unknown flags and --outH (declared, no case: parse_args.cpp:55,130)
     }
 
@@ -150,6 +155,79 @@ int write_batch(void *user, const ngsld_batch *b) {
                                 fileno(st->pars->out_fh)) == NGSLD_OK ? 0 : 1;
 }
 
+
+struct ReadState {
+  const Params *pars;
+  char err[512];
+};
+
+int read_slab(void *user, uint64_t site_begin, uint64_t n_sites, double *dst) {
+  ReadState *r = static_cast<ReadState *>(user);
+  return ngsld_host_read_geno_bin_range(r->pars->in_geno, r->pars->n_ind, site_begin, n_sites, dst, r->err,
+                                        sizeof(r->err)) == NGSLD_OK ? 0 : 1;
+}
+
+void fill_run_params(const Params &pars, ngsld_params *lp, ngsld_geno_opts *go) {
+  lp->max_kb_dist = pars.max_kb_dist;
+  lp->max_snp_dist = pars.max_snp_dist;
+  lp->min_maf = pars.min_maf;
+  lp->ignore_miss_data = pars.ignore_miss_data ? 1 : 0;
+  lp->extend_out = pars.extend_out ? 1 : 0;
+  lp->rnd_sample = pars.rnd_sample;
+  lp->seed = pars.seed;
+  lp->first_row = 0;
+  memset(go, 0, sizeof(*go));
+  go->log_scale = pars.in_logscale ? 1 : 0;
+  go->ignore_miss_data = pars.ignore_miss_data ? 1 : 0;
+  go->call_geno = pars.call_geno ? 1 : 0;
+  go->N_thresh = pars.N_thresh;
+  go->call_thresh = pars.call_thresh;
+}
+
+// The out-of-core path (no counterpart in the reference): the same TSV, the matrix read slab by slab.
+// Returns false (nothing written yet) when may_fall_back and the slabs cannot hold a window.
+bool run_streamed(Params &pars, uint64_t slab_sites, bool may_fall_back) {
+  char err[512];
+  ngsld_pos *pos = nullptr;
+  if (pars.verbose >= 1) fprintf(stderr, "==> Getting sites coordinates\n");
+  if (pars.in_pos &&
+      ngsld_host_read_pos(pars.in_pos, pars.in_pos_header ? 1 : 0, pars.n_sites, &pos, err, sizeof(err)) != NGSLD_OK)
+    error("read_dist", err);
+  ngsld_params lp;
+  ngsld_geno_opts go;
+  fill_run_params(pars, &lp, &go);
+  std::vector<double> maf(pars.n_sites);
+  SinkState sink;
+  sink.pars = &pars;
+  sink.pos = pos;
+  sink.pos_dist = pos ? ngsld_host_pos_dist(pos) : nullptr;
+  sink.maf = &maf;
+  ReadState rs;
+  rs.pars = &pars;
+  rs.err[0] = 0;
+  uint64_t n_pairs = 0, n_slabs = 0;
+  if (may_fall_back) {
+    std::vector<ngsld_slab> probe(pars.n_sites);
+    uint64_t n = 0;
+    if (ngsld_plan_slabs(sink.pos_dist, pars.n_sites, &lp, slab_sites, probe.data(), probe.size(), &n) != NGSLD_OK) {
+      ngsld_host_free_pos(pos);
+      return false;
+    }
+  }
+  if (pars.verbose >= 1)
+    fprintf(stderr, "==> Streaming the genotype matrix in slabs of up to %lu sites\n", (unsigned long)slab_sites);
+  const int rc = ngsld_run_streamed(pars.device, pars.n_sites, pars.n_ind, sink.pos_dist, &lp, &go, slab_sites,
+                                    read_slab, &rs, maf.data(), write_batch, &sink, &n_pairs, &n_slabs, err, sizeof(err));
+  if (rc == NGSLD_ERR_NAN) error("read_geno", err);
+  if (rc == NGSLD_ERR_MAF_RANGE) error("haplo_freq", err);
+  if (rc != NGSLD_OK) error("ngsld_run_streamed", rs.err[0] ? rs.err : err);
+  if (pars.verbose >= 1) fprintf(stderr, "==> Freeing memory...\n");
+  fclose(pars.out_fh);
+  ngsld_host_free_pos(pos);
+  if (pars.verbose >= 1) fprintf(stderr, "Done!\n");
+  return true;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -184,9 +262,41 @@ int main(int argc, char **argv) {
   ngsld_ctx *ctx = nullptr;
   if (ngsld_create(pars.device, &ctx) != NGSLD_OK) error("ngsld_create", ngsld_last_error(nullptr));
 
+  char err[512];
+  // ---- does the matrix fit the device?  If not, a windowed run on binary input is streamed slab by slab ----
+  uint64_t budget = 0;
+  {
+    uint64_t free_b = 0, total_b = 0;
+    if (ngsld_device_memory(pars.device, &free_b, &total_b) != NGSLD_OK)
+      error("ngsld_device_memory", "cannot query the device memory");
+    budget = (uint64_t)(0.9 * (double)free_b);
+    if (pars.max_gpu_mem > 0 && pars.max_gpu_mem * 1e9 < (double)budget) budget = (uint64_t)(pars.max_gpu_mem * 1e9);
+  }
+  // resident = one context holding every site; ngsld_slab_sites_for_budget prices two, so ask with twice the budget
+  const bool fits = ngsld_slab_sites_for_budget(pars.n_ind, 2 * budget) >= pars.n_sites;
+  uint64_t slab_sites = 0;  // > 0: run slab by slab
+  if (const char *e = getenv("NGSLD_SLAB_SITES")) {  // tests: stream a small file in slabs of n sites
+    if (pars.in_bin) slab_sites = strtoull(e, nullptr, 10);
+  } else if (!fits) {
+    if (!pars.in_bin)
+      error(__FUNCTION__, "the genotype matrix does not fit the device memory budget (only binary input is streamed)");
+    slab_sites = ngsld_slab_sites_for_budget(pars.n_ind, budget);
+    if (slab_sites < 2) error(__FUNCTION__, "the device memory budget is too small for this number of individuals");
+  } else if (pars.in_bin && (pars.max_kb_dist > 0 || pars.max_snp_dist > 0) && (uint64_t)st.st_size >= (1ull << 30) &&
+             !(getenv("NGSLD_PIPELINE") && strcmp(getenv("NGSLD_PIPELINE"), "0") == 0)) {
+    // a large windowed job that fits is still cut into about six slabs, only to overlap the file read and the
+    // upload of one part with the pair kernels of the previous one (same output; falls back when a window is too wide)
+    slab_sites = std::min<uint64_t>(ngsld_slab_sites_for_budget(pars.n_ind, budget), (pars.n_sites + 5) / 6);
+  }
+  if (slab_sites > 0) {
+    ngsld_destroy(ctx);
+    ctx = nullptr;
+    if (run_streamed(pars, slab_sites, /*may_fall_back=*/fits)) return 0;
+    if (ngsld_create(pars.device, &ctx) != NGSLD_OK) error("ngsld_create", ngsld_last_error(nullptr));
+  }
+
   // ---- read input data (ngsLD.cpp:85-114; the arithmetic runs on the device) ----
   if (pars.verbose >= 1) fprintf(stderr, "> Reading data from file...\n");
-  char err[512];
   std::vector<double> raw((size_t)pars.n_sites * pars.n_ind * 3);
   ngsld_geno_opts go;
   memset(&go, 0, sizeof(go));

@@ -708,4 +708,40 @@ int ngsld_selftest(ngsld_ctx *c) {
   return NGSLD_OK;
 }
 
+int ngsld_window_ends(const double *pos_dist, uint64_t n_sites, const ngsld_params *p, uint32_t *row_end) {
+  if (p == nullptr || row_end == nullptr || n_sites == 0 || n_sites >= 0xffffffffull) return NGSLD_ERR_INVALID;
+  std::vector<double> pd;
+  if (pos_dist == nullptr)
+    pd.assign(n_sites, std::numeric_limits<double>::infinity());
+  else
+    pd.assign(pos_dist, pos_dist + n_sites);
+  ngsld_params q = *p;
+  q.min_maf = 0.0;  // the maf filters can only shorten a row
+  const std::vector<double> maf(n_sites, 0.5);
+  std::vector<uint32_t> ends;
+  plan_rows(pd, maf, q, n_sites, ends);
+  std::memcpy(row_end, ends.data(), n_sites * sizeof(uint32_t));
+  return NGSLD_OK;
+}
+
+uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes) {
+  PairConfig cfg;
+  if (!pair_config(n_ind, true, true, &cfg)) return 0;
+  // per context: planes (24*np per site) + maf/mean/rsx + row tables (~64 B per site), two record slots of
+  // batch_pairs records, two staging chunks of 256 MiB, items; the fixed part is rounded up generously
+  const uint64_t fixed = (2ull * (1ull << 23) * (sizeof(ngsld_rec_std) + sizeof(ngsld_rec_ext))) + (768ull << 20);
+  const uint64_t per_ctx = budget_bytes / 2;
+  if (per_ctx <= fixed) return 0;
+  return (per_ctx - fixed) / (24ull * cfg.np + 64ull);
+}
+
+int ngsld_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
+  if (hipSetDevice(device) != hipSuccess) return NGSLD_ERR_DEVICE;
+  size_t f = 0, t = 0;
+  if (hipMemGetInfo(&f, &t) != hipSuccess) return NGSLD_ERR_DEVICE;
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return NGSLD_OK;
+}
+
 }  // extern "C"

@@ -1,6 +1,7 @@
 // host_io.cpp -- host-side readers and TSV writer of the drop-in (declared in include/ngsld_host.h).
 // Pure C++17 + zlib, no device code: this is the part of the reference's L0/L4 layers
 // (shared/read_data.cpp, shared/gen_func.cpp read_file, ngsLD.cpp fprintf) the new engine keeps on the host.
+#include <fcntl.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -291,6 +292,42 @@ int ngsld_host_read_geno_bin(const char *path, uint64_t n_ind, uint64_t n_sites,
   const bool at_eof = gzeof(fh);
   gzclose(fh);
   if (!at_eof) return set_err(err, errlen, "GENO file not at EOF. Check GENO file and number of sites!");
+  return NGSLD_OK;
+}
+
+int ngsld_host_read_geno_bin_range(const char *path, uint64_t n_ind, uint64_t site_begin, uint64_t n_sites,
+                                   double *out_raw, char *err, size_t errlen) {
+  if (path == nullptr || out_raw == nullptr) return set_err(err, errlen, "invalid argument");
+  const uint64_t site_bytes = n_ind * 3 * sizeof(double);
+  const uint64_t off = site_begin * site_bytes, total = n_sites * site_bytes;
+  char *dst = reinterpret_cast<char *>(out_raw);
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return set_err(err, errlen, "cannot open GENO file!");
+  unsigned char magic[2] = {0, 0};
+  const bool gz = pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+  uint64_t got = 0;
+  if (!gz) {  // plain file: positioned reads, nothing before the slab is touched
+    while (got < total) {
+      const ssize_t n = pread(fd, dst + got, (size_t)std::min<uint64_t>(total - got, 1u << 30), (off_t)(off + got));
+      if (n <= 0) break;
+      got += (uint64_t)n;
+    }
+    close(fd);
+  } else {  // compressed: zlib has to inflate its way to the slab
+    close(fd);
+    gzFile fh = gzopen(path, "rb");
+    if (fh == nullptr) return set_err(err, errlen, "cannot open GENO file!");
+    gzbuffer(fh, 1 << 22);
+    if (gzseek(fh, (z_off_t)off, SEEK_SET) == (z_off_t)off)
+      while (got < total) {
+        const int n = gzread(fh, dst + got, (unsigned)std::min<uint64_t>(total - got, 1u << 30));
+        if (n <= 0) break;
+        got += (uint64_t)n;
+      }
+    gzclose(fh);
+  }
+  if (got != total)
+    return set_err(err, errlen, "GENO file at premature EOF. Check GENO file and number of sites!");
   return NGSLD_OK;
 }
 

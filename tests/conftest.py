@@ -13,6 +13,14 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 
+# torch carries its own HIP runtime; libngsld.so links the one under /opt/rocm.  Whichever is loaded first serves
+# both, and torch does not find the device through the other one, so tests that use both fix the order here.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 

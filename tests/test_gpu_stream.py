@@ -1,0 +1,121 @@
+"""Streamed (out-of-core) runs, BASELINE configs[4]'s mode: the matrix is cut into row slabs with halos and two
+contexts alternate on the device.  The records must be those of the resident run, bit for bit."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ngsld_amd import capi, shard, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _resident(engine, raw, pd, **kw):
+    engine.set_geno_raw(raw, ignore_miss_data=kw.get("ignore_miss_data", False))
+    engine.set_pos_dist(pd)
+    engine.plan(**kw)
+    return engine.run() + (engine.maf(),)
+
+
+def _same(a, b):
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[2].tobytes() == b[2].tobytes()
+    if a[3] is None:
+        assert b[3] is None
+    else:
+        assert a[3].tobytes() == b[3].tobytes()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(max_kb_dist=2),
+    dict(max_kb_dist=2, extend_out=False),
+    dict(max_kb_dist=3, max_snp_dist=9, min_maf=0.15),
+    dict(max_snp_dist=25),
+    dict(max_kb_dist=2, rnd_sample=0.4, seed=77),
+    dict(max_kb_dist=2, ignore_miss_data=True),
+])
+@pytest.mark.parametrize("slab", [64, 150, 100000])
+def test_streamed_equals_resident(engine, kw, slab):
+    n_sites, n_ind = 900, 30
+    raw = synth.make_gl_numpy(n_sites, n_ind, 41, depth=4.0)
+    if kw.get("ignore_miss_data"):
+        rng = np.random.default_rng(8)
+        raw[rng.random((n_sites, n_ind)) < 0.2] = 1.0
+    chrs, pos = synth.make_positions(n_sites, 41, n_chr=2)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    want = _resident(engine, raw, pd, **kw)
+    calls = []
+
+    def read(b, m):
+        calls.append((b, m))
+        return raw[b:b + m]
+
+    got = capi.run_streamed(read, n_sites, n_ind, pd, slab, **kw)
+    _same(got, want)
+    assert np.array_equal(got[4], want[4])                      # est_maf of every site, slab-independent
+    slabs = capi.plan_slabs(pd, n_sites, slab, **{k: v for k, v in kw.items() if k in ("max_kb_dist", "max_snp_dist")})
+    assert got[5] == len(slabs) == len(calls)
+    assert calls == [(int(s["row_begin"]), int(s["site_end"] - s["row_begin"])) for s in slabs]
+    assert (len(slabs) == 1) == (slab >= n_sites)
+
+
+def test_streamed_multi_wavefront_cohort(engine):
+    """n_ind = 2000 (configs[4]'s cohort, 4 wavefronts per pair), 500 kb window over ~1 kb gaps."""
+    torch = pytest.importorskip("torch")
+    n_sites, n_ind = 6000, 2000
+    raw = synth.make_gl_torch(n_sites, n_ind, 5, torch.device("cuda:0")).cpu().numpy()
+    chrs, pos = synth.make_positions(n_sites, 5, max_gap=2000)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    want = _resident(engine, raw, pd, max_kb_dist=500)
+    got = capi.run_streamed(lambda b, m: raw[b:b + m], n_sites, n_ind, pd, 1500, max_kb_dist=500)
+    assert got[5] >= 5 and len(got[0]) > 2_000_000
+    _same(got, want)
+
+
+def test_streamed_errors(engine):
+    n_sites, n_ind = 300, 12
+    raw = synth.make_gl_numpy(n_sites, n_ind, 43, depth=4.0)
+    chrs, pos = synth.make_positions(n_sites, 43)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    with pytest.raises(capi.NgsldError) as e:                  # the window does not fit the slab
+        capi.run_streamed(lambda b, m: raw[b:b + m], n_sites, n_ind, pd, 8, max_kb_dist=2)
+    assert e.value.code == capi.ERR_NOMEM and "does not fit" in str(e.value)
+
+    def failing(b, m):
+        if b > 0:
+            raise IOError("disk gone")
+        return raw[b:b + m]
+
+    with pytest.raises(capi.NgsldError) as e:                  # a reader failure on the second slab stops the job
+        capi.run_streamed(failing, n_sites, n_ind, pd, 64, max_kb_dist=2)
+    assert "cannot read" in str(e.value)
+    bad = raw.copy()
+    bad[250, 3, :] = -1.0                                       # log(-1): the NaN check of read_geno (read_data.cpp:42-45)
+    with pytest.raises(capi.NgsldError) as e:
+        capi.run_streamed(lambda b, m: bad[b:b + m], n_sites, n_ind, pd, 64, max_kb_dist=2)
+    assert e.value.code == capi.ERR_NAN
+
+
+@pytest.mark.parametrize("flags", [["--max_kb_dist", "3", "--extend_out"],
+                                   ["--max_kb_dist", "3", "--rnd_sample", "0.5", "--seed", "9", "--min_maf", "0.1"]])
+def test_cli_streamed_output_is_identical(tmp_path, flags):
+    """The drop-in binary forced to stream (NGSLD_SLAB_SITES) writes the same bytes as the resident run."""
+    n_sites, n_ind = 1500, 40
+    raw = synth.make_gl_numpy(n_sites, n_ind, 47, depth=5.0)
+    chrs, pos = synth.make_positions(n_sites, 47, n_chr=2)
+    g, p = str(tmp_path / "in.glf"), str(tmp_path / "in.pos")
+    raw.tofile(g)
+    synth.write_pos(p, chrs, pos)
+    cmd = [capi.CLI_PATH, "--geno", g, "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--pos", p, "--verbose", "0",
+           "--n_threads", "4"] + flags
+    a = subprocess.run(cmd, capture_output=True)
+    b = subprocess.run(cmd, capture_output=True, env=dict(os.environ, NGSLD_SLAB_SITES="100"))
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
+    assert a.stdout == b.stdout and a.stdout.count(b"\n") > 1000
+    # all pairs cannot be cut into slabs: a job that fits the device falls back to the resident run
+    ap = cmd[:-len(flags)] + ["--max_kb_dist", "0", "--max_snp_dist", "30"]
+    c = subprocess.run(ap[:-1] + ["0"], capture_output=True, env=dict(os.environ, NGSLD_SLAB_SITES="100"))
+    d = subprocess.run(ap[:-1] + ["0"], capture_output=True)
+    assert c.returncode == 0 and d.returncode == 0 and c.stdout == d.stdout
+    assert c.stdout.count(b"\n") == 1 + n_sites * (n_sites - 1) // 2

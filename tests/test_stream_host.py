@@ -1,0 +1,97 @@
+"""Host side of the streamed (out-of-core) run: window ends, slab planning, ranged binary reads.  No device."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+from ngsld_amd import capi, shard, synth
+
+
+def _pos_dist(n, seed, two_chr=False, max_gap=200):
+    rng = np.random.default_rng(seed)
+    pd = rng.integers(1, max_gap + 1, size=n).astype(np.float64)
+    if two_chr:
+        pd[n // 3] = np.inf
+        pd[n // 2] = np.inf
+    return pd
+
+
+@pytest.mark.parametrize("kb,snp,two_chr", [(1, 0, False), (2, 0, True), (0, 7, False), (3, 11, True), (0, 0, False)])
+def test_window_ends_match_the_literal_walk(kb, snp, two_chr):
+    """ngsld_window_ends == the running-sum walk of ngsLD.cpp:240-262 (restated here literally)."""
+    n = 700
+    pd = _pos_dist(n, 3, two_chr)
+    got = capi.window_ends(pd, n, max_kb_dist=kb, max_snp_dist=snp)
+    want = np.empty(n, dtype=np.uint32)
+    for s1 in range(n):
+        dist, e = 0.0, s1 + 1
+        while e < n:
+            dist += pd[e]
+            if kb > 0 and dist > kb * 1000:
+                break
+            if snp > 0 and e - s1 > snp:
+                break
+            e += 1
+        want[s1] = e
+    assert np.array_equal(got, want)
+    assert np.array_equal(got, shard.row_ends(pd, max_kb_dist=kb, max_snp_dist=snp))
+    assert np.array_equal(capi.window_ends(None, 5, max_kb_dist=0), np.full(5, 5, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("cap", [40, 64, 200, 5000])
+def test_slabs_cover_every_row_once_and_hold_its_window(cap):
+    n = 3000
+    pd = _pos_dist(n, 5, two_chr=True)
+    ends = capi.window_ends(pd, n, max_kb_dist=2)
+    assert int((ends - np.arange(n)).max()) <= 40          # the widest window fits the smallest cap tried
+    slabs = capi.plan_slabs(pd, n, cap, max_kb_dist=2)
+    assert slabs["row_begin"][0] == 0 and slabs["row_end"][-1] == n
+    assert np.array_equal(slabs["row_begin"][1:], slabs["row_end"][:-1])
+    for sl in slabs:
+        r0, r1, hi = int(sl["row_begin"]), int(sl["row_end"]), int(sl["site_end"])
+        assert r1 > r0 and hi - r0 <= cap and hi <= n
+        assert int(ends[r0:r1].max()) <= hi
+        # greedy: one more row would not have fitted
+        assert r1 == n or max(hi, int(ends[r1])) - r0 > cap
+    if cap >= n:
+        assert len(slabs) == 1
+
+
+def test_slab_planning_errors():
+    n = 500
+    pd = _pos_dist(n, 6)
+    with pytest.raises(capi.NgsldError) as e:
+        capi.plan_slabs(pd, n, 5, max_kb_dist=2)             # windows of ~20 sites cannot fit 5
+    assert e.value.code == capi.ERR_NOMEM
+    with pytest.raises(capi.NgsldError) as e:
+        capi.plan_slabs(None, n, n - 1, max_kb_dist=0)       # all pairs: row 0 needs every site
+    assert e.value.code == capi.ERR_NOMEM
+    assert len(capi.plan_slabs(None, n, n, max_kb_dist=0)) == 1
+    assert len(capi.plan_slabs(None, n, 60, max_snp_dist=10)) > 1
+
+
+def test_slab_budget_is_monotone_and_zero_when_too_small():
+    assert capi.slab_sites_for_budget(500, 1 << 30) == 0
+    a, b = capi.slab_sites_for_budget(500, 16 << 30), capi.slab_sites_for_budget(500, 64 << 30)
+    assert 0 < a < b
+    assert capi.slab_sites_for_budget(2000, 64 << 30) < b
+    # two contexts, each planes of 24 * np bytes per site: a 64 GiB budget holds < 32 GiB of planes per slab
+    assert b * 24 * 512 < 32 << 30
+
+
+@pytest.mark.parametrize("compressed", [False, True])
+def test_ranged_binary_read(tmp_path, compressed):
+    raw = synth.make_gl_numpy(50, 7, 11, depth=4.0)
+    path = str(tmp_path / ("g.glf" if not compressed else "g.glf.bgz"))
+    if compressed:
+        with gzip.open(path, "wb") as fh:
+            fh.write(raw.tobytes())
+    else:
+        raw.tofile(path)
+    for b, m in [(0, 50), (0, 1), (13, 20), (49, 1)]:
+        assert np.array_equal(capi.read_geno_bin_range(path, 7, b, m), raw[b:b + m])
+    with pytest.raises(capi.NgsldError):
+        capi.read_geno_bin_range(path, 7, 40, 11)             # runs past the end
+    with pytest.raises(capi.NgsldError):
+        capi.read_geno_bin_range(os.path.join(str(tmp_path), "missing"), 7, 0, 1)
