@@ -21,10 +21,10 @@ def _run_device(eng, n_rows, n_pairs, dev):
     return std, ext[:, :4], meta[:, 0], meta[:, 1]
 
 
-def _sample_check(raw_t, pos_dist, row_off, row_end, std, hap, n_data, n_iter, n_sample, seed, max_kb):
+def _sample_check(raw_t, pos_dist, row_off, row_end, std, hap, n_data, n_iter, n_sample, seed, max_kb, n_rows=None):
     rng = np.random.default_rng(seed)
     n_sites = raw_t.shape[0]
-    rows = rng.integers(0, n_sites - 1, size=n_sample)
+    rows = rng.integers(0, (n_rows or n_sites) - 1, size=n_sample)
     for s1 in rows:
         span = int(row_end[s1]) - (s1 + 1)
         if span <= 0:
@@ -114,5 +114,84 @@ def test_c3_windowed_100000x500():
         finally:
             eng2.close()
         _sample_check(raw, pd, row_off, row_end, std, hap, n_data, n_iter, 200, 7, max_kb)
+    finally:
+        eng.close()
+
+
+def test_c4_all_pairs_50000x1000_in_rank_shards():
+    """configs[3]: 50,000 sites x 1,000 ind, all 1,249,975,000 pairs, computed as the 8 row shards of an 8-GPU run
+    (shard.split_rows: equal pair counts), one after the other on this GPU; 2 wavefronts per pair."""
+    dev = torch.device("cuda", 0)
+    n_sites, n_ind, world = 50_000, 1000, 8
+    raw = synth.make_gl_torch(n_sites, n_ind, 4, dev, depth=10.0)
+    eng = capi.Engine(0)
+    try:
+        eng.set_geno_raw(raw.data_ptr(), n_sites=n_sites, n_ind=n_ind)
+        eng.set_pos_dist(None)
+        n = eng.plan(extend_out=True)
+        assert n == n_sites * (n_sites - 1) // 2 == 1_249_975_000
+        row_off, row_end = eng.plan_rows()
+        bounds = shard.split_rows(np.diff(row_off.astype(np.int64)), world)
+        assert bounds[0][0] == 0 and bounds[-1][1] == n_sites
+        total, it_sum = 0, 0
+        for rank, (lo, hi) in enumerate(bounds):
+            m = int(row_off[hi] - row_off[lo])
+            assert abs(m - n / world) < 2 * n_sites                           # balanced to within a row or two
+            d_std = torch.empty(m * 32, dtype=torch.uint8, device=dev)
+            d_ext = torch.empty(m * 40, dtype=torch.uint8, device=dev)
+            eng.run_device(lo, hi, d_std.data_ptr(), d_ext.data_ptr(), None)
+            std = d_std.view(torch.float64).view(-1, 4)
+            hap = d_ext.view(torch.float64).view(-1, 5)[:, :4]
+            meta = d_ext.view(torch.int32).view(-1, 10)[:, 8:10]
+            assert bool(torch.all(meta[:, 0] == n_ind)) and bool(torch.all((meta[:, 1] >= 0) & (meta[:, 1] <= 100)))
+            assert float((hap.sum(dim=1) - 1).abs().max()) < 1e-12 and float(hap.min()) >= 0.0
+            assert float(std[:, 3].min()) >= 0.0 and float(std[:, 3].max()) <= 1.0 + 1e-9
+            assert float(std[:, 2].abs().max()) <= 1.0 + 1e-9
+            total += m
+            it_sum += int(meta[:, 1].sum(dtype=torch.int64))
+            if rank in (0, 5):                                                 # sampled pairs of this shard vs the oracle
+                rng = np.random.default_rng(rank)
+                for s1 in rng.integers(lo, hi, size=40):
+                    s2 = int(rng.integers(s1 + 1, n_sites)) if s1 + 1 < n_sites else None
+                    if s2 is None:
+                        continue
+                    k = int(row_off[s1] - row_off[lo]) + (s2 - int(s1) - 1)
+                    r = orc.Oracle(raw[[int(s1), s2]].cpu().numpy(), None).run()[0]
+                    assert int(meta[k, 1]) == r["n_iter"], (s1, s2)
+                    assert np.all(close(hap[k].cpu().numpy(), r["hap"])) and np.all(
+                        close(std[k].cpu().numpy(), [r["r2pear"], r["D"], r["Dp"], r["r2"]])), (s1, s2)
+            del std, hap, meta, d_std, d_ext
+        assert total == n
+        assert 8.0 < it_sum / n < 12.0                                         # depth-10 data: ~9.5 iterations per pair
+    finally:
+        eng.close()
+
+
+def test_c5_rank_slab_125000x2000_windowed():
+    """configs[4]: 1,000,000 sites x 2,000 ind, --max_kb_dist 500 over ~1 kb gaps, 8 ranks: one rank's slab
+    (125,000 rows + halo, 6 GB of GLs, 4 wavefronts per pair) at full size."""
+    dev = torch.device("cuda", 0)
+    n_sites, n_ind, max_kb = 125_600, 2000, 500
+    chrs, pos = synth.make_positions(n_sites, 5, max_gap=2000)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    ends = shard.row_ends(pd, max_kb, 0)
+    n_rows = 125_000
+    assert int(ends[:n_rows].max()) <= n_sites                                # the halo covers the last row's window
+    raw = synth.make_gl_torch(n_sites, n_ind, 5, dev, depth=10.0)
+    eng = capi.Engine(0)
+    try:
+        eng.set_geno_raw(raw.data_ptr(), n_sites=n_sites, n_ind=n_ind)
+        eng.set_pos_dist(pd)
+        eng.plan(max_kb_dist=max_kb, extend_out=True)
+        row_off, row_end = eng.plan_rows()
+        assert np.array_equal(row_end.astype(np.int64), ends)
+        m = int(row_off[n_rows])
+        assert 5.5e7 < m < 7.0e7                                               # ~500 partners per site
+        std, hap, n_data, n_iter = _run_device(eng, n_rows, m, dev)
+        assert bool(torch.all(n_data == n_ind)) and bool(torch.all((n_iter >= 0) & (n_iter <= 100)))
+        assert float((hap.sum(dim=1) - 1).abs().max()) < 1e-12 and float(hap.min()) >= 0.0
+        assert float(std[:, 3].min()) >= 0.0 and float(std[:, 3].max()) <= 1.0 + 1e-9
+        assert float(std[:, 0].min()) >= 0.0 and float(std[:, 0].max()) <= 1.0 + 1e-12
+        _sample_check(raw, pd, row_off, row_end, std, hap, n_data, n_iter, 60, 9, max_kb, n_rows=n_rows)
     finally:
         eng.close()
