@@ -22,9 +22,11 @@
 namespace ngsld {
 
 #ifndef NGSLD_PAIR_RCP
-#define NGSLD_PAIR_RCP 1  // build-time A/B switch of the paired-reciprocal trick in em_pair (0 = one rcp per individual)
+#define NGSLD_PAIR_RCP 2  // build-time A/B switch of em_pair's reciprocals: 0 = one v_rcp_f64 per individual,
+                         // 1 = one per two individuals, 2 = one per lane (product tree over all slots)
 #endif
 constexpr bool kPairRcp = NGSLD_PAIR_RCP != 0;
+constexpr bool kTreeRcp = NGSLD_PAIR_RCP == 2;
 constexpr int kIterMax = 100;      // ITER_MAX, gen_func.hpp:18
 constexpr double kEpsilon = 1e-5;  // EPSILON,  gen_func.hpp:16
 
@@ -143,6 +145,27 @@ __device__ __forceinline__ bool miss_data(double g0, double g1, double g2) {
 // ---------------------------------------------------------------------------------------------
 // Building blocks of the pair kernels
 // ---------------------------------------------------------------------------------------------
+// Reciprocals of N positive numbers from ONE reciprocal: products up a binary tree (N - 1 multiplies), 1/root, then
+// down again -- the inverse of a node is the parent's inverse times the sibling's product (2 multiplies per inner
+// node).  N = 8: 21 multiplies + one refined v_rcp_f64 instead of 8 (or 4, taken in pairs) of the 16-cycle kind.
+template <int N>
+struct RcpTree {
+  static constexpr int L = N / 2;
+  static __device__ __forceinline__ double prod(const double *s) {
+    return RcpTree<L>::prod(s) * RcpTree<N - L>::prod(s + L);
+  }
+  static __device__ __forceinline__ void down(const double *s, double inv, double *r) {
+    const double pl = RcpTree<L>::prod(s), pr = RcpTree<N - L>::prod(s + L);  // same expressions as in prod(): CSE'd
+    RcpTree<L>::down(s, inv * pr, r);
+    RcpTree<N - L>::down(s + L, inv * pl, r + L);
+  }
+};
+template <>
+struct RcpTree<1> {
+  static __device__ __forceinline__ double prod(const double *s) { return s[0]; }
+  static __device__ __forceinline__ void down(const double *, double inv, double *r) { r[0] = inv; }
+};
+
 struct PairedTag { static constexpr bool value = true; };   // compile-time selectors of em_pair's reciprocal scheme
 struct SingleTag { static constexpr bool value = false; };
 typedef __attribute__((address_space(3))) void lds_void_t;        // operands of __builtin_amdgcn_global_load_lds
@@ -189,7 +212,9 @@ __device__ __forceinline__ uint32_t count_valid(uint32_t vbits) {
 // haplo_freq (gen_func.cpp:1027-1059) on the staged pair.  Returns n_iter; f0..f3 hold hap_freq on exit.
 //   CHECK_ALL: every slot may hold padding / missing individuals (otherwise only the last one can)
 //   WAVES > 1: the pair is spread over WAVES wavefronts, partial sums meet in xch (LDS, double buffered)
-template <int SLOTS, int WAVES, bool CHECK_ALL>
+//   TREE_DYN:  CHECK_ALL kernels without --ignore_miss_data (several wavefronts per pair): a wavefront whose lanes are
+//              all full up to the last slot -- every one but the pair's last -- still takes the one-reciprocal path
+template <int SLOTS, int WAVES, bool CHECK_ALL, bool TREE_DYN = false>
 __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_t vbits, double inv_x, double m1,
                                             double m2, double &f0, double &f1, double &f2, double &f3,
                                             double (*xch)[WAVES][4], int sub, int lane, int *status) {
@@ -210,7 +235,18 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   // s lies in (0, 1]; the product can only underflow when both factors are below 1e-154, and that -- like any other
   // non-finite outcome -- is caught by the sanity test on the new frequencies, after which the iteration is redone
   // with one reciprocal per individual before anything is concluded from it.
+  // kTree: ALL slots of the lane share one reciprocal (RcpTree).  Padding lanes of the last slot hold P == 0 (the prep
+  // kernel zero-fills the planes beyond n_ind); `pad` = 1 there makes their s exactly 1, so they neither disturb the
+  // product nor add anything to R.  The product of SLOTS values underflows sooner than a pair's (all below ~1e-38 for
+  // eight slots); the same redo-with-single-reciprocals rule covers it.
   constexpr int kPaired = CHECK_ALL ? 0 : (SLOTS - 1) / 2;
+  constexpr bool kTree = kTreeRcp && (!CHECK_ALL || TREE_DYN) && SLOTS > 1;
+  const double pad = ((vbits >> (SLOTS - 1)) & 1u) ? 0.0 : 1.0;
+  bool tree_ok = true;  // wavefront-uniform
+  if (CHECK_ALL && kTree) {
+    constexpr uint32_t kNeed = (1u << (SLOTS - 1)) - 1u;  // padding (P == 0, no missing data here) in the last slot only
+    tree_ok = !__builtin_amdgcn_ballot_w64((vbits & kNeed) != kNeed);
+  }
   auto em_step = [&](auto paired_tag, double &n0, double &n1, double &n2, double &n3) {
     constexpr bool kPair = decltype(paired_tag)::value;
     // products f_k f_h: they build the two-locus genotype weights W (s = sum_G W[G] P[G] is the
@@ -231,9 +267,18 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
       R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
       R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
     };
-    constexpr int kFirstSingle = kPair ? 2 * kPaired : 0;
+    constexpr int kFirstSingle = kPair ? (kTree ? SLOTS : 2 * kPaired) : 0;
+    if constexpr (kPair && kTree) {
+      double sv[SLOTS], rv[SLOTS];
 #pragma unroll
-    for (int q = 0; q < (kPair ? kPaired : 0); ++q) {
+      for (int j = 0; j < SLOTS; ++j) sv[j] = slot_s(j);
+      sv[SLOTS - 1] += pad;
+      RcpTree<SLOTS>::down(sv, rcp_refined(RcpTree<SLOTS>::prod(sv)), rv);
+#pragma unroll
+      for (int j = 0; j < SLOTS; ++j) slot_acc(j, rv[j]);
+    }
+#pragma unroll
+    for (int q = 0; q < (kPair && !kTree ? kPaired : 0); ++q) {
       const double sa = slot_s(2 * q), sb = slot_s(2 * q + 1);
       const double r = rcp_refined(sa * sb);
       slot_acc(2 * q, sb * r);
@@ -264,7 +309,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   };
   for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
     double n0, n1, n2, n3;
-    if (kPaired > 0 && kPairRcp)
+    if ((kPaired > 0 || kTree) && kPairRcp && tree_ok)
       em_step(PairedTag(), n0, n1, n2, n3);
     else
       em_step(SingleTag(), n0, n1, n2, n3);
@@ -273,7 +318,8 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     // s == 0 poisons every R with inf/NaN, so a sum that is not a sane ~1 <=> the reference is all NaN.
     double sn = (n0 + n1) + (n2 + n3);
     if (__builtin_amdgcn_ballot_w64(!(sn < 2.0))) {  // wave-uniform values: the ballot is all-or-nothing
-      if (kPaired > 0 && kPairRcp) {  // rule out an underflowed reciprocal product before concluding anything
+      if ((kPaired > 0 || kTree) && kPairRcp) {  // rule out an underflowed reciprocal product before concluding anything
+        if (WAVES > 1) lds_barrier();  // sn is the same in every wavefront: all redo, none still reads the exchange buffer
         em_step(SingleTag(), n0, n1, n2, n3);
         sn = (n0 + n1) + (n2 + n3);
       }
@@ -417,7 +463,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
       lds_barrier();
     }
     double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair<SLOTS, WAVES, kCheckAll>(P, vbits, 1.0 / (double)x, m1, m2, f0, f1, f2, f3, xch, sub,
+    const uint32_t n_iter = em_pair<SLOTS, WAVES, kCheckAll, (WAVES > 1 && !MASKED)>(P, vbits, 1.0 / (double)x, m1, m2, f0, f1, f2, f3, xch, sub,
                                                              lane, A.status);
     if (lane == 0 && sub == 0)
       write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, rsx2, x, n_iter);
@@ -686,34 +732,62 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       f0 = f1 = f2 = f3 = __builtin_nan("");
     }
     const double inv_x = 1.0 / (double)x;
-    bool done = !active;
-    uint32_t n_iter = (uint32_t)kIterMax;
-    for (uint32_t itn = 0; itn < (uint32_t)kIterMax; ++itn) {
+    // one reciprocal per lane and iteration (RcpTree) when only the last slot can hold padding, see em_pair
+    constexpr bool kTree = kTreeRcp && !MASKED && SLOTS > 1;
+    const double pad = ((vbits >> (SLOTS - 1)) & 1u) ? 0.0 : 1.0;
+    auto em_step = [&](auto tree_tag, double &n0, double &n1, double &n2, double &n3) {
+      constexpr bool kT = decltype(tree_tag)::value;
       const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
       const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
       const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
       double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
+      auto slot_s = [&](int j) -> double {
+        double s = p00 * P[j][0];
+        s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
+        s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
+        s = fma(p22, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(p33, P[j][8], s);
+        return s;
+      };
+      auto slot_acc = [&](int j, double r) {
+        R0 = fma(P[j][0], r, R0); R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
+        R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
+        R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
+      };
+      if constexpr (kT) {
+        double sv[SLOTS], rv[SLOTS];
 #pragma unroll
-      for (int j = 0; j < SLOTS; ++j) {
-        // without --ignore_miss_data only the last slot can hold padding lanes; a group without a pair computes
-        // on stale buffers there, which is harmless (it is `done` from the start and never written)
-        if ((!MASKED && j < SLOTS - 1) || ((vbits >> j) & 1u)) {
-          double s = p00 * P[j][0];
-          s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
-          s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
-          s = fma(p22, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(p33, P[j][8], s);
-          const double r = rcp_refined(s);
-          R0 = fma(P[j][0], r, R0); R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
-          R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
-          R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
+        for (int j = 0; j < SLOTS; ++j) sv[j] = slot_s(j);
+        sv[SLOTS - 1] += pad;
+        RcpTree<SLOTS>::down(sv, rcp_refined(RcpTree<SLOTS>::prod(sv)), rv);
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) slot_acc(j, rv[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < SLOTS; ++j) {
+          // without --ignore_miss_data only the last slot can hold padding lanes; a group without a pair computes
+          // on stale buffers there, which is harmless (it is `done` from the start and never written)
+          if ((!MASKED && j < SLOTS - 1) || ((vbits >> j) & 1u)) slot_acc(j, rcp_refined(slot_s(j)));
         }
       }
       const double t0 = group_sum<G>(fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0))));
       const double t1 = group_sum<G>(fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1))));
       const double t2 = group_sum<G>(fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3))));
       const double t3 = group_sum<G>(fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4))));
-      const double n0 = t0 * inv_x, n1 = t1 * inv_x, n2 = t2 * inv_x, n3 = t3 * inv_x;
-      const double sn = (n0 + n1) + (n2 + n3);
+      n0 = t0 * inv_x; n1 = t1 * inv_x; n2 = t2 * inv_x; n3 = t3 * inv_x;
+    };
+    bool done = !active;
+    uint32_t n_iter = (uint32_t)kIterMax;
+    for (uint32_t itn = 0; itn < (uint32_t)kIterMax; ++itn) {
+      double n0, n1, n2, n3;
+      if (kTree)
+        em_step(PairedTag(), n0, n1, n2, n3);
+      else
+        em_step(SingleTag(), n0, n1, n2, n3);
+      double sn = (n0 + n1) + (n2 + n3);
+      if (kTree && __any(!done && !(sn < 2.0))) {  // a live group's step is not sane: rule out an underflowed product
+        em_step(SingleTag(), n0, n1, n2, n3);
+        sn = (n0 + n1) + (n2 + n3);
+      }
       const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
       if (!done) {
         if (!(sn < 2.0)) {  // the reference's all-NaN step: "converges" at this iteration (see em_pair)
