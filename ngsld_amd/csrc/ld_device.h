@@ -496,11 +496,19 @@ __device__ __forceinline__ void dma_site_to_lds(const double *site, char *lds_ds
   }
 }
 
+// What the EM leaves behind for one pair.  The derived statistics (write_pair: ~100 wavefront-uniform f64
+// instructions with two divisions and a square root) are not computed by the wavefront that ran the EM -- there they
+// would cost a full instruction issue each for ONE pair -- but once per work item, one LANE per pair.
+struct PairResult {
+  double f[4], sxy, rsx2;
+  uint32_t x, n_iter;
+};
+
 template <int SLOTS, bool MASKED>
 __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
   constexpr int kSiteBytes = SLOTS * 64 * 3 * 8;
   constexpr uint32_t kNp = SLOTS * 64;
-  __shared__ __attribute__((aligned(16))) char smem[kSiteBytes * 5 + 16];
+  __shared__ __attribute__((aligned(16))) char smem[kSiteBytes * 5 + 16 + 64 * sizeof(PairResult)];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -513,6 +521,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
   char *lds_a = smem;
   char *lds_b = smem + kSiteBytes * (1 + wave);
   uint32_t *claim = reinterpret_cast<uint32_t *>(smem + kSiteBytes * 5);
+  PairResult *res = reinterpret_cast<PairResult *>(smem + kSiteBytes * 5 + 16);  // one per candidate of the item
 
   // next unclaimed offset inside the item; offsets 0..3 are pre-assigned to the four wavefronts
   if (threadIdx.x == 0) *claim = 4;
@@ -572,11 +581,24 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
     double f0, f1, f2, f3;
     const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, inv_x, m1, cur.maf, f0, f1, f2, f3,
                                                       (double (*)[1][4]) nullptr, 0, lane, A.status);
-    if (lane == 0)
-      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, cur.rsx, x,
-                 n_iter);
+    if (lane == 0) {
+      PairResult &r = res[c];
+      r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;
+      r.sxy = sxy;
+      r.rsx2 = cur.rsx;
+      r.x = x;
+      r.n_iter = n_iter;
+    }
     c = cn;
     cur = nxt;
+  }
+  // the item is done: thread t derives and writes the record of candidate t (consecutive records: coalesced stores)
+  __syncthreads();
+  const uint32_t t = threadIdx.x;
+  if (t < it.count && ((it.mask >> t) & 1ull)) {
+    const PairResult r = res[t];
+    write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << t) - 1ull)), r.f[0], r.f[1], r.f[2], r.f[3], r.sxy, rsx1,
+               r.rsx2, r.x, r.n_iter);
   }
 }
 
