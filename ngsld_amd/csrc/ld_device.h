@@ -372,6 +372,14 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
   }
 }
 
+// What the EM leaves behind for one pair.  The derived statistics (write_pair: ~100 wavefront-uniform f64
+// instructions with two divisions and a square root) are not computed by the wavefront that ran the EM -- there they
+// would cost a full instruction issue each for ONE pair -- but once per work item, one LANE per pair.
+struct PairResult {
+  double f[4], sxy, rsx2;
+  uint32_t x, n_iter;
+};
+
 // ---------------------------------------------------------------------------------------------
 // Generic kernel: WAVES wavefronts share one pair (WAVES == 1: four independent wavefronts per 256-thread
 // workgroup, one item each).  Used for n_ind > 512; for WAVES == 1 it is the A/B baseline of the prefetch kernel.
@@ -387,7 +395,9 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
   constexpr bool kCheckAll = MASKED || WAVES > 1;  // otherwise only the last slot can hold padding
   constexpr int kWavesPerWg = WAVES == 1 ? 4 : WAVES;
   constexpr int kSliceBytes = SLOTS * 64 * 3 * 8;
-  __shared__ __attribute__((aligned(16))) char smem[(PFB ? kWavesPerWg * kSliceBytes : 16) + WAVES * 96];
+  constexpr int kXchBase = PFB ? kWavesPerWg * kSliceBytes : 16;
+  __shared__ __attribute__((aligned(16))) char smem[kXchBase + WAVES * 96 + (WAVES > 1 ? 64 * sizeof(PairResult) : 0)];
+  PairResult *res = reinterpret_cast<PairResult *>(smem + kXchBase + WAVES * 96);  // WAVES > 1: one per candidate
   double (*xch)[WAVES][4] = reinterpret_cast<double (*)[WAVES][4]>(smem + (PFB ? kWavesPerWg * kSliceBytes : 16));
   double (*xch0)[2] = reinterpret_cast<double (*)[2]>(smem + (PFB ? kWavesPerWg * kSliceBytes : 16) + WAVES * 64);
 
@@ -465,9 +475,27 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
     double f0, f1, f2, f3;
     const uint32_t n_iter = em_pair<SLOTS, WAVES, kCheckAll, (WAVES > 1 && !MASKED)>(P, vbits, 1.0 / (double)x, m1, m2, f0, f1, f2, f3, xch, sub,
                                                              lane, A.status);
-    if (lane == 0 && sub == 0)
-      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, rsx2, x, n_iter);
+    if (WAVES == 1) {
+      if (lane == 0)
+        write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, rsx2, x, n_iter);
+    } else if (lane == 0 && sub == 0) {
+      PairResult &r = res[c];
+      r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;
+      r.sxy = sxy;
+      r.rsx2 = rsx2;
+      r.x = x;
+      r.n_iter = n_iter;
+    }
     c = cn;
+  }
+  if (WAVES > 1) {  // the whole workgroup shares the item: thread t derives and writes the record of candidate t
+    __syncthreads();
+    const uint32_t t = threadIdx.x;
+    if (t < it.count && ((it.mask >> t) & 1ull)) {
+      const PairResult r = res[t];
+      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << t) - 1ull)), r.f[0], r.f[1], r.f[2], r.f[3], r.sxy, rsx1,
+                 r.rsx2, r.x, r.n_iter);
+    }
   }
 }
 
@@ -495,14 +523,6 @@ __device__ __forceinline__ void dma_site_to_lds(const double *site, char *lds_ds
       __builtin_amdgcn_global_load_lds((glb_void_t *)(g + k * 1024), (lds_void_t *)(lds_dst + k * 1024), 16, 0, 0);
   }
 }
-
-// What the EM leaves behind for one pair.  The derived statistics (write_pair: ~100 wavefront-uniform f64
-// instructions with two divisions and a square root) are not computed by the wavefront that ran the EM -- there they
-// would cost a full instruction issue each for ONE pair -- but once per work item, one LANE per pair.
-struct PairResult {
-  double f[4], sxy, rsx2;
-  uint32_t x, n_iter;
-};
 
 template <int SLOTS, bool MASKED>
 __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
@@ -637,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
   constexpr int kABytes = ((kSiteBytes + 1023) / 1024) * 1024;
   constexpr int kWaveBuf = kPieces * 1024;                   // the 64/G groups of a wavefront, interleaved
   constexpr unsigned long long kGroupMask = G == 32 ? 0xffffffffull : ((1ull << G) - 1ull);
-  __shared__ __attribute__((aligned(16))) char smem[kABytes + 4 * kWaveBuf + 16];
+  __shared__ __attribute__((aligned(16))) char smem[kABytes + 4 * kWaveBuf + 16 + 64 * sizeof(PairResult)];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -651,6 +671,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
   char *lds_a = smem;
   char *lds_w = smem + kABytes + wave * kWaveBuf;
   uint32_t *claim = reinterpret_cast<uint32_t *>(smem + kABytes + 4 * kWaveBuf);
+  PairResult *res = reinterpret_cast<PairResult *>(smem + kABytes + 4 * kWaveBuf + 16);  // one per candidate of the item
 
   if (threadIdx.x == 0) *claim = 0;
   // a group claims the next computed pair of the item (maf[s2] / sub-sampling filters live in the mask, ngsLD.cpp:270-282)
@@ -827,11 +848,24 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       if (__all(done)) break;
     }
 
-    if (active && gl == 0)
-      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, cur.rsx, x,
-                 n_iter);
+    if (active && gl == 0) {
+      PairResult &r = res[c];
+      r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;
+      r.sxy = sxy;
+      r.rsx2 = cur.rsx;
+      r.x = x;
+      r.n_iter = n_iter;
+    }
     c = cn;
     cur = nxt;
+  }
+  // the item is done: thread t derives and writes the record of candidate t (see pair_ld_pf_kernel)
+  __syncthreads();
+  const uint32_t t = threadIdx.x;
+  if (t < it.count && ((it.mask >> t) & 1ull)) {
+    const PairResult r = res[t];
+    write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << t) - 1ull)), r.f[0], r.f[1], r.f[2], r.f[3], r.sxy, rsx1,
+               r.rsx2, r.x, r.n_iter);
   }
 }
 
