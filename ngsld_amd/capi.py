@@ -13,7 +13,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "libngsld.so")
+LIB_PATH = os.environ.get("NGSLD_LIB") or os.path.join(PKG_DIR, "libngsld.so")  # NGSLD_LIB: A/B builds of the same C-ABI
 CLI_PATH = os.path.join(PKG_DIR, "bin", "ngsLD")
 
 OK, ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_NAN, ERR_MAF_RANGE, ERR_SINK, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7

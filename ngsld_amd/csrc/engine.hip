@@ -72,7 +72,7 @@ struct ngsld_ctx {
   uint32_t np = 0;
   PairConfig cfg{};
   bool have_geno = false;
-  DevBuf<double> d_planes, d_maf, d_mean, d_rsx;
+  DevBuf<double> d_planes, d_maf, d_mean, d_rsx, d_sc4;
   DevBuf<int> d_status;
   std::vector<double> h_maf, h_pos_dist;
 
@@ -83,6 +83,8 @@ struct ngsld_ctx {
   std::vector<uint32_t> h_row_end;
   std::vector<uint8_t> h_keep;
   std::vector<Item> h_items;  // host copy for the sink (which pairs each record belongs to)
+  std::vector<uint64_t> h_run_off;  // run kernel: runs before each row
+  DevBuf<Run> d_runs;
   DevBuf<uint64_t> d_row_off, d_item_off, d_row_seed, d_row_count;
   DevBuf<uint32_t> d_row_end;
   DevBuf<uint8_t> d_keep;
@@ -91,7 +93,7 @@ struct ngsld_ctx {
 
   // tuning
   // kernel family selection for A/B runs: NGSLD_PAIR_KERNEL=direct (no prefetch anywhere) | wave (no row kernel)
-  bool prefetch = true, row_kernel = true;
+  bool prefetch = true, row_kernel = true, run_kernel = true;
   uint32_t pairs_per_item = 16;
   uint64_t batch_pairs = 1ull << 23;
 
@@ -137,7 +139,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   if (normalised && maf == nullptr) return fail(c, NGSLD_ERR_INVALID, "maf missing");
   if (n_sites >= 0xffffffffull) return fail(c, NGSLD_ERR_UNSUPPORTED, "n_sites must be below 2^32 - 1");
   PairConfig cfg;
-  if (!pair_config(n_ind, c->prefetch, c->row_kernel, &cfg))
+  if (!pair_config(n_ind, c->prefetch, c->row_kernel, &cfg, c->run_kernel))
     return fail(c, NGSLD_ERR_UNSUPPORTED, "n_ind is outside the supported range");
   HIP_TRY(c, hipSetDevice(c->device));
   c->have_geno = false;
@@ -151,6 +153,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   HIP_TRY(c, c->d_maf.resize(n_sites));
   HIP_TRY(c, c->d_mean.resize(n_sites));
   HIP_TRY(c, c->d_rsx.resize(n_sites));
+  HIP_TRY(c, c->d_sc4.resize(4 * n_sites));
   HIP_TRY(c, c->d_status.resize(1));
   HIP_TRY(c, hipMemsetAsync(c->d_status.p, 0, sizeof(int), c->stream));
 
@@ -222,6 +225,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
     if (rc != NGSLD_OK) return rc;
     if (e != hipSuccess) return hip_fail(c, e, "chunked genotype upload");
   }
+  HIP_TRY(c, launch_pack_scalars(c->d_maf.p, c->d_mean.p, c->d_rsx.p, c->d_sc4.p, n_sites, c->stream));
   c->h_maf.resize(n_sites);
   int status = 0;
   HIP_TRY(c, hipMemcpyAsync(c->h_maf.data(), c->d_maf.p, n_sites * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -315,6 +319,12 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
   a.rsx = c->d_rsx.p;
   a.items = c->d_items.p + c->h_item_off[r0];
   a.n_items = c->h_item_off[r1] - c->h_item_off[r0];
+  if (c->cfg.kernel == kRun) {
+    a.runs = c->d_runs.p + c->h_run_off[r0];
+    a.n_runs = c->h_run_off[r1] - c->h_run_off[r0];
+  }
+  a.items_all = c->d_items.p;
+  a.sc4 = c->d_sc4.p;
   a.out_base = c->h_row_off[r0];
   a.out_std = d_std;
   a.out_ext = d_ext;
@@ -365,6 +375,7 @@ int ngsld_create(int device, ngsld_ctx **out) {
   if (const char *k = std::getenv("NGSLD_PAIR_KERNEL")) {
     c->prefetch = std::strcmp(k, "direct") != 0;
     c->row_kernel = std::strcmp(k, "wave") != 0;
+    c->run_kernel = std::strcmp(k, "item") != 0;  // "item": one workgroup per item (pair_ld_pf_kernel), the run kernel's baseline
   }
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
       (e = hipStreamCreate(&c->copy_stream)) != hipSuccess) {
@@ -384,7 +395,7 @@ void ngsld_destroy(ngsld_ctx *c) {
   if (c == nullptr) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_rsx.release();
+  c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_rsx.release(); c->d_sc4.release(); c->d_runs.release();
   c->d_status.release(); c->d_row_off.release(); c->d_item_off.release(); c->d_row_end.release();
   c->d_row_seed.release(); c->d_row_count.release(); c->d_keep.release(); c->d_items.release();
   for (int k = 0; k < 2; ++k) {
@@ -472,6 +483,24 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) {
     c->h_item_off[s1 + 1] = c->h_item_off[s1] + (span + ch - 1) / ch;
   }
   c->n_items = c->h_item_off[n];
+  if (c->cfg.kernel == kRun) {
+    // runs: a row's items cut into ceil(items / kRunItems) runs of near-equal length (one workgroup each)
+    std::vector<Run> runs;
+    c->h_run_off.assign(n + 1, 0);
+    for (uint64_t s1 = 0; s1 < n; ++s1) {
+      const uint64_t i0 = c->h_item_off[s1], m = c->h_item_off[s1 + 1] - i0;
+      const uint64_t parts = (m + kRunItems - 1) / kRunItems;
+      for (uint64_t q = 0; q < parts; ++q) {
+        const uint64_t b = i0 + m * q / parts, e = i0 + m * (q + 1) / parts;
+        runs.push_back(Run{(uint32_t)b, (uint32_t)(e - b)});
+      }
+      c->h_run_off[s1 + 1] = runs.size();
+    }
+    if (c->n_items > 0xffffffffull) return fail(c, NGSLD_ERR_UNSUPPORTED, "more than 2^32 work items in one plan");
+    HIP_TRY(c, c->d_runs.resize(runs.empty() ? 1 : runs.size()));
+    if (!runs.empty())
+      HIP_TRY(c, hipMemcpy(c->d_runs.p, runs.data(), runs.size() * sizeof(Run), hipMemcpyHostToDevice));
+  }
   HIP_TRY(c, c->d_row_end.resize(n));
   HIP_TRY(c, c->d_keep.resize(n));
   HIP_TRY(c, c->d_row_off.resize(n + 1));

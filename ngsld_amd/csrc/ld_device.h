@@ -25,6 +25,10 @@ namespace ngsld {
 #define NGSLD_PAIR_RCP 2  // build-time A/B switch of em_pair's reciprocals: 0 = one v_rcp_f64 per individual,
                          // 1 = one per two individuals, 2 = one per lane (product tree over all slots)
 #endif
+#ifndef NGSLD_DROP0
+#define NGSLD_DROP0 1     // build-time A/B switch: 1 = hap_freq[0] is recovered from sum_k f_k = 1 instead of being accumulated
+#endif
+constexpr bool kDrop0 = NGSLD_DROP0 != 0;
 constexpr bool kPairRcp = NGSLD_PAIR_RCP != 0;
 constexpr bool kTreeRcp = NGSLD_PAIR_RCP == 2;
 constexpr int kIterMax = 100;      // ITER_MAX, gen_func.hpp:18
@@ -32,6 +36,12 @@ constexpr double kEpsilon = 1e-5;  // EPSILON,  gen_func.hpp:16
 
 // One unit of work = ngsld_item: pairs (s1, s2_begin + c) for the bits c set in mask, records from first_record.
 typedef ngsld_item Item;
+
+// A run = up to kRunItems consecutive work items of ONE row: what one workgroup of the run kernel works through.
+struct Run {
+  uint32_t first_item, n_items;
+};
+constexpr uint32_t kRunItems = 8;
 
 struct PairArgs {
   const double *planes;  // [n_sites][3][np] normal-space normalised GLs, zero padded to np
@@ -44,6 +54,10 @@ struct PairArgs {
   const double *rsx;     // [n_sites] 1 / sqrt(sum (e - mean)^2)  (inf for a constant site)
   const Item *items;
   uint64_t n_items;
+  const struct Run *runs;  // run kernel: this launch's runs (consecutive items of one row each), indices into items_all
+  uint64_t n_runs;
+  const Item *items_all;   // the whole plan's item array
+  const double *sc4;       // [n_sites][4] packed per-site scalars {maf, mean_e, rsx, 0}: one 32-byte copy per site
   uint64_t out_base;  // global index of record 0 of the output buffers
   ngsld_rec_std *out_std;
   ngsld_rec_ext *out_ext;  // may be null
@@ -107,6 +121,20 @@ __device__ __forceinline__ void wave_sum4(double &t0, double &t1, double &t2, do
   t2 = read_lane(w, 16);
   t1 = read_lane(w, 32);
   t3 = read_lane(w, 48);
+}
+
+// Three values: same scheme, the third one folded with itself (rows 1 and 3 both end up holding its sum).
+__device__ __forceinline__ void wave_sum3(double &t1, double &t2, double &t3) {
+  double z12 = fold32(t1, t2);
+  double z33 = fold32(t3, t3);
+  double w = fold16(z12, z33);  // row0: t1, row1: t3, row2: t2, row3: t3
+  w += dpp_mov<0x128>(w);
+  w += dpp_mov<0x124>(w);
+  w += dpp_mov<0x4E>(w);
+  w += dpp_mov<0xB1>(w);
+  t1 = read_lane(w, 0);
+  t3 = read_lane(w, 16);
+  t2 = read_lane(w, 32);
 }
 
 __device__ __forceinline__ double wave_sum1(double v) {
@@ -228,6 +256,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   // scale of f, so it is not repeated per iteration.  inv_x = 1/x; x == 0 gives 0 * inf = NaN like the reference's 0/0.
   // (held in a VGPR: the four products t_k * inv_x below take t_k from SGPRs, and a VALU op reads one SGPR at most)
   asm("" : "+v"(inv_x));
+  const double keep0 = f0 == 0.0 ? 0.0 : 1.0;
   bool bad = false;
   uint32_t n_iter = 0;
   // Slots known to be full (no padding / missing lanes) take their reciprocals two at a time:
@@ -263,7 +292,8 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
       return s;
     };
     auto slot_acc = [&](int j, double r) {
-      R0 = fma(P[j][0], r, R0); R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
+      if (!kDrop0) R0 = fma(P[j][0], r, R0);
+      R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
       R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
       R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
     };
@@ -289,23 +319,32 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
       if ((!CHECK_ALL && j < SLOTS - 1) || ((vbits >> j) & 1u)) slot_acc(j, rcp_refined(slot_s(j)));
     }
     // t_k = sum_h f_k f_h R[G(k,h)]  (= this lane's share of ff_k / 2, gen_func.cpp:1098-1104)
-    double t0 = fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0)));
+    double t0 = kDrop0 ? 0.0 : fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0)));
     double t1 = fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1)));
     double t2 = fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3)));
     double t3 = fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4)));
-    wave_sum4(t0, t1, t2, t3);
+    if (kDrop0)
+      wave_sum3(t1, t2, t3);
+    else
+      wave_sum4(t0, t1, t2, t3);
     if (WAVES > 1) {
       const int par = (int)(n_iter & 1u);
       if (lane == 0) {
-        xch[par][sub][0] = t0; xch[par][sub][1] = t1; xch[par][sub][2] = t2; xch[par][sub][3] = t3;
+        if (!kDrop0) xch[par][sub][0] = t0;
+        xch[par][sub][1] = t1; xch[par][sub][2] = t2; xch[par][sub][3] = t3;
       }
       lds_barrier();
       t0 = t1 = t2 = t3 = 0.0;
       for (int w = 0; w < WAVES; ++w) {
-        t0 += xch[par][w][0]; t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
+        if (!kDrop0) t0 += xch[par][w][0];
+        t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
       }
     }
-    n0 = t0 * inv_x; n1 = t1 * inv_x; n2 = t2 * inv_x; n3 = t3 * inv_x;
+    n1 = t1 * inv_x; n2 = t2 * inv_x; n3 = t3 * inv_x;
+    // sum_k ff_k / (2x) = 1 (every individual's four posterior weights add up to one): with kDrop0 the first frequency
+    // is what the other three leave, R[0] is never accumulated and three values go through the reduction instead of
+    // four.  keep0 = 0 keeps an exact zero exact (f0 = 0 is a fixed point of the reference's step: tmp_0 = f0 * ...).
+    n0 = kDrop0 ? keep0 * (1.0 - ((n1 + n2) + n3)) : t0 * inv_x;
   };
   for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
     double n0, n1, n2, n3;
@@ -316,12 +355,13 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     // Any individual with s == 0 makes every tmp/sum NaN in the reference, hence all four f NaN and, as a
     // NaN difference never raises eps (gen_func.cpp:1049-1053), "convergence" at this iteration.  Here
     // s == 0 poisons every R with inf/NaN, so a sum that is not a sane ~1 <=> the reference is all NaN.
-    double sn = (n0 + n1) + (n2 + n3);
+    // (one NaN reciprocal poisons EVERY R -- fma(P, NaN, R) -- so with kDrop0 any one accumulated frequency tells)
+    double sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);
     if (__builtin_amdgcn_ballot_w64(!(sn < 2.0))) {  // wave-uniform values: the ballot is all-or-nothing
       if ((kPaired > 0 || kTree) && kPairRcp) {  // rule out an underflowed reciprocal product before concluding anything
         if (WAVES > 1) lds_barrier();  // sn is the same in every wavefront: all redo, none still reads the exchange buffer
         em_step(SingleTag(), n0, n1, n2, n3);
-        sn = (n0 + n1) + (n2 + n3);
+        sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);
       }
       if (__builtin_amdgcn_ballot_w64(!(sn < 2.0))) {
         bad = true;
@@ -529,6 +569,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
   constexpr int kSiteBytes = SLOTS * 64 * 3 * 8;
   constexpr uint32_t kNp = SLOTS * 64;
   __shared__ __attribute__((aligned(16))) char smem[kSiteBytes * 5 + 16 + 64 * sizeof(PairResult)];
+  __shared__ double site_sc[3][64];  // maf, mean_e, rsx of the item's candidate sites
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -553,26 +594,32 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
       if (c >= it.count || ((it.mask >> c) & 1ull)) return c;
     }
   };
-  // Per-site scalars of the site a wavefront will work on are fetched when the site is CLAIMED, one pair
-  // ahead, and parked in SGPRs: an ordinary load waited for while a site copy is in flight would drain the
-  // copy too (vmcnt is in-order), which is exactly the stall this kernel exists to remove.
+  // Per-site scalars of all candidate sites of the item are brought into LDS once, by one coalesced load per
+  // array: inside the pair loop there is no ordinary global load left to wait for -- a load waited for while a
+  // site copy is in flight would drain the copy too (vmcnt is in-order), and its ~2 us round trip per pair was
+  // 13 % of the wavefronts' time when the scalars were still fetched pair by pair.
   struct SiteScalars {
     double maf, mean, rsx;
   };
   auto load_scalars = [&](uint32_t c) -> SiteScalars {
     SiteScalars v{0.0, 0.0, 0.0};
     if (c < it.count) {
-      const uint32_t s2 = it.s2_begin + c;
-      v.maf = uniform(A.maf[s2]);
-      v.mean = uniform(A.mean_e[s2]);
-      v.rsx = uniform(A.rsx[s2]);
+      v.maf = uniform(site_sc[0][c]);
+      v.mean = uniform(site_sc[1][c]);
+      v.rsx = uniform(site_sc[2][c]);
     }
     return v;
   };
+  if (threadIdx.x < it.count) {
+    const uint32_t s2 = it.s2_begin + threadIdx.x;
+    site_sc[0][threadIdx.x] = A.maf[s2];
+    site_sc[1][threadIdx.x] = A.mean_e[s2];
+    site_sc[2][threadIdx.x] = A.rsx[s2];
+  }
 
   // the row vector: every wavefront copies a quarter of it
   dma_site_to_lds<SLOTS>(A.planes + (uint64_t)s1 * A.site_stride, lds_a, lane, wave, 4);
-  __syncthreads();  // claim counter initialised before anybody claims
+  __syncthreads();  // claim counter initialised before anybody claims, candidate scalars in place
   uint32_t c = (uint32_t)wave;
   if (c < it.count && !((it.mask >> c) & 1ull)) c = claim_next();
   SiteScalars cur = load_scalars(c);
@@ -620,6 +667,134 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
     write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << t) - 1ull)), r.f[0], r.f[1], r.f[2], r.f[3], r.sxy, rsx1,
                r.rsx2, r.x, r.n_iter);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Run kernel (n_ind <= 512, the headline shape): pair_ld_pf_kernel's pair pipeline without its per-item costs.
+// A workgroup works through a RUN of up to kRunItems consecutive items of one row (512 candidate sites) instead of
+// one item: the row vector is brought into LDS once per run, the four wavefronts claim candidates from one LDS
+// counter for the whole run, and NOTHING inside the run synchronises them -- no barrier at item boundaries, no
+// workgroup turnover every 64 pairs (with one item per workgroup the SIMDs held 1.8 of 2 wavefronts on average:
+// launch, the barrier at the item's end and the wait for its slowest wavefront).
+//   * item headers of the run sit in LDS (claims need mask / count / first_record; a global load per claim would be
+//     a ~2 us round trip on the critical path);
+//   * a site's scalars {maf, mean_e, rsx} travel with its planes: one more 32-byte global->LDS copy behind the site
+//     copy, so the pair loop has no ordinary global load to wait for at all;
+//   * results collect in a wave-private LDS ring and are turned into records 32 at a time, one LANE per pair
+//     (write_pair is ~100 wavefront-uniform f64 instructions: issued per pair they would cost 4 % of the kernel).
+//   LDS: [row vector][4 x (site buffer + 32 B scalars)][4 x ring of 32 results][item headers][claim counter]
+// ---------------------------------------------------------------------------------------------
+struct RunResult {
+  double f[4], sxy, rsx2;
+  uint32_t x, n_iter;
+  uint64_t rec;
+};
+
+template <int SLOTS, bool MASKED>
+__global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
+  constexpr int kSiteBytes = SLOTS * 64 * 3 * 8;
+  constexpr int kBuf = kSiteBytes + 32;
+  constexpr uint32_t kNp = SLOTS * 64;
+  constexpr uint32_t kRing = 32;
+  constexpr int kRingOff = kSiteBytes + 4 * kBuf;
+  constexpr int kItemOff = kRingOff + 4 * (int)(kRing * sizeof(RunResult));
+  constexpr int kClaimOff = kItemOff + (int)(kRunItems * sizeof(Item));
+  __shared__ __attribute__((aligned(16))) char smem[kClaimOff + 16];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const Run run = A.runs[blockIdx.x];
+  const Item *g_items = A.items_all + run.first_item;
+  const uint32_t s1 = g_items[0].s1;
+  const double m1 = A.sc4[4 * (uint64_t)s1], mean1 = A.sc4[4 * (uint64_t)s1 + 1], rsx1 = A.sc4[4 * (uint64_t)s1 + 2];
+  char *lds_a = smem;
+  char *lds_b = smem + kSiteBytes + wave * kBuf;
+  RunResult *ring = reinterpret_cast<RunResult *>(smem + kRingOff) + wave * kRing;
+  const Item *l_items = reinterpret_cast<const Item *>(smem + kItemOff);
+  uint32_t *claim = reinterpret_cast<uint32_t *>(smem + kClaimOff);
+
+  if (threadIdx.x < run.n_items * 2)  // item headers, 16 bytes per thread
+    reinterpret_cast<uint4 *>(smem + kItemOff)[threadIdx.x] = reinterpret_cast<const uint4 *>(g_items)[threadIdx.x];
+  if (threadIdx.x == 0) *claim = 0;
+  dma_site_to_lds<SLOTS>(A.planes + (uint64_t)s1 * A.site_stride, lds_a, lane, wave, 4);  // a quarter per wavefront
+  __syncthreads();  // (waits for this wavefront's copies first) row vector, headers and counter in place
+
+  // one candidate of the run: item k, offset c inside it -> site and record index
+  struct Cand {
+    uint32_t s2;
+    uint64_t rec;
+    bool ok;
+  };
+  auto claim_next = [&]() -> Cand {  // pairs dropped by the maf[s2] / sub-sampling filters are skipped (ngsLD.cpp:270-282)
+    for (;;) {
+      uint32_t q = 0;
+      if (lane == 0) q = atomicAdd(claim, 1u);
+      q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+      const uint32_t k = q >> 6, c = q & 63u;  // items of a run span 64 candidates (the row's last one may hold fewer)
+      if (k >= run.n_items) return Cand{0u, 0ull, false};
+      const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)l_items[k].count);
+      const uint64_t mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(l_items[k].mask >> 32)) << 32) |
+                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)l_items[k].mask);
+      if (c < cnt && ((mask >> c) & 1ull)) {
+        const uint32_t s2b = (uint32_t)__builtin_amdgcn_readfirstlane((int)l_items[k].s2_begin);
+        const uint64_t fr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(l_items[k].first_record >> 32)) << 32) |
+                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)l_items[k].first_record);
+        return Cand{s2b + c, fr - A.out_base + (uint64_t)__popcll(mask & ((1ull << c) - 1ull)), true};
+      }
+    }
+  };
+  auto dma_site = [&](uint32_t s2) {
+    dma_site_to_lds<SLOTS>(A.planes + (uint64_t)s2 * A.site_stride, lds_b, lane, 0, 1);
+    if (lane < 2)
+      __builtin_amdgcn_global_load_lds((glb_void_t *)(reinterpret_cast<const char *>(A.sc4 + 4 * (uint64_t)s2) + lane * 16),
+                                       (lds_void_t *)(lds_b + kSiteBytes), 16, 0, 0);
+  };
+  auto flush = [&](uint32_t n) {  // lane t derives and writes the record of ring entry t
+    if ((uint32_t)lane < n) {
+      const RunResult r = ring[lane];
+      write_pair(A, r.rec, r.f[0], r.f[1], r.f[2], r.f[3], r.sxy, rsx1, r.rsx2, r.x, r.n_iter);
+    }
+  };
+
+  Cand cur = claim_next();
+  if (cur.ok) dma_site(cur.s2);
+  uint32_t held = 0;
+  while (cur.ok) {
+    const Cand nxt = claim_next();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's site copy (issued a pair ago) has landed
+    const double *sc = reinterpret_cast<const double *>(lds_b + kSiteBytes);
+    const double m2 = uniform(sc[0]), mean2 = uniform(sc[1]), rsx2 = uniform(sc[2]);
+    double P[SLOTS][9];
+    uint32_t vbits;
+    double sxy;
+    stage_pair<SLOTS, MASKED, !MASKED>(reinterpret_cast<const double *>(lds_a), kNp, (uint32_t)lane,
+                                       reinterpret_cast<const double *>(lds_b), kNp, (uint32_t)lane, (uint32_t)lane,
+                                       A.n_ind, mean1, mean2, P, vbits, sxy);
+    // all ds_reads of the buffer are consumed (P is computed): start the copy of the next site over it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (nxt.ok) dma_site(nxt.s2);
+    const uint32_t x = MASKED ? count_valid<SLOTS>(vbits) : A.n_ind;
+    const double inv_x = MASKED ? 1.0 / (double)x : A.inv_n;
+    sxy = wave_sum1(sxy);
+    double f0, f1, f2, f3;
+    const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, inv_x, m1, m2, f0, f1, f2, f3,
+                                                      (double (*)[1][4]) nullptr, 0, lane, A.status);
+    if (lane == 0) {
+      RunResult &r = ring[held];
+      r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;
+      r.sxy = sxy;
+      r.rsx2 = rsx2;
+      r.x = x;
+      r.n_iter = n_iter;
+      r.rec = cur.rec;
+    }
+    if (++held == kRing) {
+      flush(held);
+      held = 0;
+    }
+    cur = nxt;
+  }
+  flush(held);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -989,8 +1164,9 @@ __global__ __launch_bounds__(256, 2) void pair_ld_stream_kernel(PairArgs A) {
 // host-callable launchers, defined in ld_pair_w1.hip / ld_pair_wn.hip
 // Kernel families: kGroup = 8/16/32 lanes per pair (n_ind <= 256), kWave = one wavefront per pair with the row vector shared
 // in LDS (n_ind <= 512), kMulti = 2..8 wavefronts per pair (n_ind <= 4096), kStream = any n_ind, vectors re-read every
-// iteration; kDirect = kWave/kMulti shapes without any prefetch (A/B).
-enum PairKernel { kGroup = 0, kWave = 1, kMulti = 2, kDirect = 3, kStream = 4 };
+// iteration; kDirect = kWave/kMulti shapes without any prefetch (A/B); kRun = kWave's pipeline over runs of items
+// (the default for n_ind 257..512; kWave remains as its per-item A/B baseline).
+enum PairKernel { kGroup = 0, kWave = 1, kMulti = 2, kDirect = 3, kStream = 4, kRun = 5 };
 struct PairConfig {
   int kernel;   // PairKernel
   int group;    // kGroup: lanes per pair (8, 16 or 32); 64 otherwise
@@ -998,10 +1174,11 @@ struct PairConfig {
   int waves;    // wavefronts per pair
   uint32_t np;  // padded individuals per genotype plane
 };
-bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg);
+bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg, bool allow_run = true);
 hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs &args, hipStream_t stream);
 // candidate s2 sites per work item: kGroup / kWave items are shared by the four wavefronts of a workgroup
 inline uint32_t item_span(const PairConfig &cfg, uint32_t pairs_per_item) {
+  if (cfg.kernel == kRun) return 64u;  // the run kernel addresses candidates as 64 * item + offset
   const uint32_t span = (cfg.kernel == kGroup || cfg.kernel == kWave) ? 4u * pairs_per_item : pairs_per_item;
   return span > 64u ? 64u : span;
 }

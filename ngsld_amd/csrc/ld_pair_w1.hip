@@ -6,7 +6,7 @@ namespace ngsld {
 // n_ind -> kernel family and shape.  Lane groups of 8 / 16 / 32 lanes x 8 slots cover 64 / 128 / 256 individuals
 // (group kernel); one wavefront holds up to 8*64 = 512 individuals as 18*8 = 144 VGPRs of P; above that 2..8
 // wavefronts share the pair, and beyond 4096 the streaming kernel takes over.
-bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg) {
+bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg, bool allow_run) {
   if (n_ind == 0 || n_ind >= 0xffffffc0ull) return false;
   cfg->group = 64;
   if (n_ind > 4096) {  // beyond 8 wavefronts x 8 slots x 64 lanes: streaming kernel, one workgroup per pair
@@ -32,7 +32,7 @@ bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig
   cfg->waves = w;
   cfg->slots = (int)((n_ind + 64ull * w - 1) / (64ull * w));
   cfg->np = (uint32_t)(cfg->slots * w * 64);
-  cfg->kernel = !allow_prefetch ? kDirect : (w == 1 ? kWave : kMulti);
+  cfg->kernel = !allow_prefetch ? kDirect : (w == 1 ? (allow_run ? kRun : kWave) : kMulti);
   return true;
 }
 
@@ -65,11 +65,16 @@ static hipError_t launch_group(int slots, bool masked, const PairArgs &a, hipStr
 
 template <int SLOTS>
 static hipError_t launch_s(int kernel, bool masked, const PairArgs &a, hipStream_t stream) {
-  const uint64_t blocks = kernel == kDirect ? (a.n_items + 3) / 4 : a.n_items;
+  const uint64_t blocks = kernel == kDirect ? (a.n_items + 3) / 4 : (kernel == kRun ? a.n_runs : a.n_items);
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   const dim3 grid((unsigned)blocks), block(256);
-  if (kernel == kWave) {
+  if (kernel == kRun) {
+    if (masked)
+      hipLaunchKernelGGL((pair_ld_run_kernel<SLOTS, true>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((pair_ld_run_kernel<SLOTS, false>), grid, block, 0, stream, a);
+  } else if (kernel == kWave) {
     if (masked)
       hipLaunchKernelGGL((pair_ld_pf_kernel<SLOTS, true>), grid, block, 0, stream, a);
     else

@@ -38,6 +38,8 @@ struct ItemArgs {
   int count_only;
 };
 hipError_t launch_items(const ItemArgs &a, hipStream_t stream);
+hipError_t launch_pack_scalars(const double *maf, const double *mean_e, const double *rsx, double *sc4, uint64_t n,
+                               hipStream_t stream);
 hipError_t launch_selftest(const double *in, double *out, hipStream_t stream);
 
 }  // namespace ngsld

@@ -173,6 +173,23 @@ hipError_t launch_prep(const PrepArgs &a, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// {maf, mean_e, rsx, 0} of every site side by side: the run kernel fetches a site's scalars with one 32-byte copy.
+__global__ void pack_scalars_kernel(const double *maf, const double *mean_e, const double *rsx, double *sc4, uint64_t n) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  sc4[4 * s] = maf[s];
+  sc4[4 * s + 1] = mean_e[s];
+  sc4[4 * s + 2] = rsx[s];
+  sc4[4 * s + 3] = 0.0;
+}
+
+hipError_t launch_pack_scalars(const double *maf, const double *mean_e, const double *rsx, double *sc4, uint64_t n,
+                               hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_scalars_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, maf, mean_e, rsx, sc4, n);
+  return hipGetLastError();
+}
+
 __global__ void items_kernel(ItemArgs A) {
   const uint32_t s1 = blockIdx.x * blockDim.x + threadIdx.x;
   if (s1 >= A.n_sites) return;
