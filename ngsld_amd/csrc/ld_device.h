@@ -271,6 +271,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   constexpr int kPaired = CHECK_ALL ? 0 : (SLOTS - 1) / 2;
   constexpr bool kTree = kTreeRcp && (!CHECK_ALL || TREE_DYN) && SLOTS > 1;
   const double pad = ((vbits >> (SLOTS - 1)) & 1u) ? 0.0 : 1.0;
+  constexpr bool kScaled = kDrop0 && WAVES == 1;  // (several wavefronts per pair: partial sums are scaled after they met)
   bool tree_ok = true;  // wavefront-uniform
   if (CHECK_ALL && kTree) {
     constexpr uint32_t kNeed = (1u << (SLOTS - 1)) - 1u;  // padding (P == 0, no missing data here) in the last slot only
@@ -284,8 +285,8 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
     const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
     double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
-    auto slot_s = [&](int j) -> double {
-      double s = p00 * P[j][0];
+    auto slot_s = [&](int j, bool padded = false) -> double {
+      double s = padded ? fma(p00, P[j][0], pad) : p00 * P[j][0];  // padded: see kTree above (pad = 1 where P == 0)
       s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
       s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
       s = fma(p22, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(p33, P[j][8], s);
@@ -301,9 +302,11 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     if constexpr (kPair && kTree) {
       double sv[SLOTS], rv[SLOTS];
 #pragma unroll
-      for (int j = 0; j < SLOTS; ++j) sv[j] = slot_s(j);
-      sv[SLOTS - 1] += pad;
-      RcpTree<SLOTS>::down(sv, rcp_refined(RcpTree<SLOTS>::prod(sv)), rv);
+      for (int j = 0; j < SLOTS; ++j) sv[j] = slot_s(j, j == SLOTS - 1);
+      // kScaled: 1/x rides on the root inverse, so every R -- and with them the three t_k -- come out divided by x
+      double inv = rcp_refined(RcpTree<SLOTS>::prod(sv));
+      if (kScaled) inv *= inv_x;
+      RcpTree<SLOTS>::down(sv, inv, rv);
 #pragma unroll
       for (int j = 0; j < SLOTS; ++j) slot_acc(j, rv[j]);
     }
@@ -340,11 +343,15 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
         t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
       }
     }
-    n1 = t1 * inv_x; n2 = t2 * inv_x; n3 = t3 * inv_x;
+    if (kPair && kTree && kScaled) {
+      n1 = t1; n2 = t2; n3 = t3;
+    } else {
+      n1 = t1 * inv_x; n2 = t2 * inv_x; n3 = t3 * inv_x;
+    }
     // sum_k ff_k / (2x) = 1 (every individual's four posterior weights add up to one): with kDrop0 the first frequency
     // is what the other three leave, R[0] is never accumulated and three values go through the reduction instead of
     // four.  keep0 = 0 keeps an exact zero exact (f0 = 0 is a fixed point of the reference's step: tmp_0 = f0 * ...).
-    n0 = kDrop0 ? keep0 * (1.0 - ((n1 + n2) + n3)) : t0 * inv_x;
+    n0 = kDrop0 ? fma(-keep0, (n1 + n2) + n3, keep0) : t0 * inv_x;
   };
   for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
     double n0, n1, n2, n3;
@@ -950,6 +957,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       f0 = f1 = f2 = f3 = __builtin_nan("");
     }
     const double inv_x = 1.0 / (double)x;
+    const double keep0 = f0 == 0.0 ? 0.0 : 1.0;  // an exact zero stays exact (see em_pair)
     // one reciprocal per lane and iteration (RcpTree) when only the last slot can hold padding, see em_pair
     constexpr bool kTree = kTreeRcp && !MASKED && SLOTS > 1;
     const double pad = ((vbits >> (SLOTS - 1)) & 1u) ? 0.0 : 1.0;
@@ -967,7 +975,8 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
         return s;
       };
       auto slot_acc = [&](int j, double r) {
-        R0 = fma(P[j][0], r, R0); R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
+        if (!kDrop0) R0 = fma(P[j][0], r, R0);
+        R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
         R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
         R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
       };
@@ -987,11 +996,16 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
           if ((!MASKED && j < SLOTS - 1) || ((vbits >> j) & 1u)) slot_acc(j, rcp_refined(slot_s(j)));
         }
       }
-      const double t0 = group_sum<G>(fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0))));
       const double t1 = group_sum<G>(fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1))));
       const double t2 = group_sum<G>(fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3))));
       const double t3 = group_sum<G>(fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4))));
-      n0 = t0 * inv_x; n1 = t1 * inv_x; n2 = t2 * inv_x; n3 = t3 * inv_x;
+      n1 = t1 * inv_x; n2 = t2 * inv_x; n3 = t3 * inv_x;
+      if (kDrop0) {  // the first frequency is what the other three leave (see em_pair)
+        n0 = fma(-keep0, (n1 + n2) + n3, keep0);
+      } else {
+        const double t0 = group_sum<G>(fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0))));
+        n0 = t0 * inv_x;
+      }
     };
     bool done = !active;
     uint32_t n_iter = (uint32_t)kIterMax;
@@ -1001,10 +1015,10 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
         em_step(PairedTag(), n0, n1, n2, n3);
       else
         em_step(SingleTag(), n0, n1, n2, n3);
-      double sn = (n0 + n1) + (n2 + n3);
+      double sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);  // one NaN reciprocal poisons every R (see em_pair)
       if (kTree && __any(!done && !(sn < 2.0))) {  // a live group's step is not sane: rule out an underflowed product
         em_step(SingleTag(), n0, n1, n2, n3);
-        sn = (n0 + n1) + (n2 + n3);
+        sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);
       }
       const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
       if (!done) {
