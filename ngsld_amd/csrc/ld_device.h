@@ -563,11 +563,27 @@ __device__ __forceinline__ void dma_site_to_lds(const double *site, char *lds_ds
   constexpr int kBytes = SLOTS * 64 * 3 * 8;
   constexpr int kChunks = (kBytes + 1023) / 1024;
   const char *g = reinterpret_cast<const char *>(site) + lane * 16;
+  // The instruction's immediate offset applies to the global AND the LDS address, and the copy is contiguous on both
+  // sides: four chunks share one address pair (offsets 0 .. 3072 fit the 12-bit field) instead of one 64-bit add and
+  // one M0 write per chunk.
 #pragma unroll
-  for (int k = 0; k < kChunks; ++k) {
-    if (stride != 1 && (k % stride) != first) continue;
-    if ((k + 1) * 1024 <= kBytes || lane * 16 < kBytes - k * 1024)
-      __builtin_amdgcn_global_load_lds((glb_void_t *)(g + k * 1024), (lds_void_t *)(lds_dst + k * 1024), 16, 0, 0);
+  for (int k0 = 0; k0 < kChunks; k0 += 4) {
+    glb_void_t *gb = (glb_void_t *)(g + k0 * 1024);
+    lds_void_t *lb = (lds_void_t *)(lds_dst + k0 * 1024);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = k0 + kk;
+      if (k >= kChunks) break;
+      if (stride != 1 && (k % stride) != first) continue;
+      if ((k + 1) * 1024 <= kBytes || lane * 16 < kBytes - k * 1024) {
+        switch (kk) {
+          case 0: __builtin_amdgcn_global_load_lds(gb, lb, 16, 0, 0); break;
+          case 1: __builtin_amdgcn_global_load_lds(gb, lb, 16, 1024, 0); break;
+          case 2: __builtin_amdgcn_global_load_lds(gb, lb, 16, 2048, 0); break;
+          default: __builtin_amdgcn_global_load_lds(gb, lb, 16, 3072, 0); break;
+        }
+      }
+    }
   }
 }
 
