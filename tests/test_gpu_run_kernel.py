@@ -1,0 +1,86 @@
+"""GPU: the run kernel (n_ind 257..512, one workgroup per run of up to 8 items of a row) against the oracle and
+against its per-item baseline kernel.
+
+What is specific to it and therefore tested here: rows longer than one run (claims that cross item and run
+boundaries), items whose mask drops candidates (maf[s2] skip, --rnd_sample), the row's short last item, records
+written from the wave-private result rings (every 32 pairs and at the end of the run), site scalars that travel with
+the site copy."""
+import numpy as np
+import pytest
+
+from ngsld_amd import capi, shard, synth
+from oracle import orc
+from util import MAF_TOL, check_records, close
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(engine, raw, pd, **kw):
+    ignore = kw.get("ignore_miss_data", False)
+    o = orc.Oracle(raw, pd, n_threads=16, **kw)
+    rec = o.run()
+    engine.set_geno_raw(raw, ignore_miss_data=ignore)
+    engine.set_pos_dist(pd)
+    assert np.all(close(engine.maf(), o.maf, MAF_TOL))
+    n = engine.plan(kw.get("max_kb_dist", 0), kw.get("max_snp_dist", 0), kw.get("min_maf", 0.0), ignore, True,
+                    kw.get("rnd_sample", 1.0), kw.get("seed", 0))
+    assert n == len(rec)
+    s1, s2, std, ext = engine.run()
+    assert np.array_equal(s1, rec["s1"]) and np.array_equal(s2, rec["s2"])
+    check_records(std, ext, rec)
+    return rec
+
+
+def test_rows_longer_than_a_run(engine):
+    """All pairs of 700 sites x 300 ind: row 0 has 699 candidates = 11 items = 2 runs; rows shrink to one short item."""
+    raw = synth.make_gl_numpy(700, 300, 901, depth=4.0)
+    rec = _check(engine, raw, None)
+    assert len(rec) == 700 * 699 // 2
+
+
+def test_filters_inside_runs(engine):
+    """maf[s2] skips and a Tausworthe sub-sample punch holes into the items' masks; some rows lose every pair."""
+    raw = synth.make_gl_numpy(640, 260, 902, depth=6.0)
+    o0 = orc.Oracle(raw, None)
+    min_maf = float(np.round(np.nanquantile(o0.maf, 0.25), 3))
+    rec = _check(engine, raw, None, min_maf=min_maf, rnd_sample=0.6, seed=12345)
+    assert 0 < len(rec) < 640 * 639 // 2
+
+
+def test_ignore_miss_data_in_runs(engine):
+    """--ignore_miss_data (the masked variant of the run kernel): sample_size varies per pair and stays bit-exact."""
+    raw = synth.make_gl_numpy(600, 400, 903, depth=5.0)
+    miss = np.random.default_rng(903).random((600, 400)) < 0.1
+    raw[miss] = 1.0 / 3.0
+    rec = _check(engine, raw, None, ignore_miss_data=True)
+    assert rec["n_ind_data"].min() < rec["n_ind_data"].max() <= 400
+
+
+def test_windowed_rows_split_into_equal_runs(engine):
+    """A 60 kb window over 3,000 sites x 512 ind (no padding lane): ~600 candidates per row = 10 items = 2 runs of 5."""
+    n_sites = 3000
+    raw = synth.make_gl_numpy(n_sites, 512, 904, depth=10.0)
+    chrs, pos = synth.make_positions(n_sites, 904, max_gap=200, n_chr=2)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    rec = _check(engine, raw[:900], pd[:900], max_kb_dist=60)       # oracle-sized head: full comparison
+    assert len(rec) > 200_000
+    # the whole matrix: records of the run kernel and of its per-item baseline are the same BITS
+    out = []
+    import os
+    for kernel in ("", "item"):
+        if kernel:
+            os.environ["NGSLD_PAIR_KERNEL"] = kernel
+        try:
+            eng = capi.Engine(0)
+        finally:
+            if kernel:
+                del os.environ["NGSLD_PAIR_KERNEL"]
+        try:
+            eng.set_geno_raw(raw)
+            eng.set_pos_dist(pd)
+            eng.plan(60, 0, 0.0, False, True)
+            out.append(eng.run())
+        finally:
+            eng.close()
+    for a, b in zip(*out):
+        assert a.tobytes() == b.tobytes()
