@@ -41,7 +41,10 @@ typedef ngsld_item Item;
 struct Run {
   uint32_t first_item, n_items;
 };
-constexpr uint32_t kRunItems = 8;
+#ifndef NGSLD_RUN_ITEMS
+#define NGSLD_RUN_ITEMS 16  // build-time tuning knob: 4 / 8 / 16 / 32 measured 503 / 507 / 498 / 498 ms on the bench
+#endif
+constexpr uint32_t kRunItems = NGSLD_RUN_ITEMS;
 
 struct PairArgs {
   const double *planes;  // [n_sites][3][np] normal-space normalised GLs, zero padded to np
