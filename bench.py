@@ -221,8 +221,8 @@ def main():
         launch_s = (kernel_ms / max(launches, 1)) / 1e3
         pairs_per_launch = n_pairs * args.steps / max(launches, 1)
         achieved = bytes_pair * pairs_per_launch / launch_s / 1e9
-        # FP64 view: per individual and executed iteration 9 FMA (s) + 4 FMA (Newton) + 9 FMA (R) + 1 rcp
-        dp_ops = pairs_per_launch * n_ind * mean_exec * 23.0
+        # FP64 view: per individual and executed iteration 9 FMA (s) + 8 FMA (R) + 3 of the shared-reciprocal tree
+        dp_ops = pairs_per_launch * n_ind * mean_exec * 20.0
         fp64_tflops = 2.0 * dp_ops / launch_s / 1e12
         traffic = None
         try:
@@ -248,14 +248,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": ("pair_ld_group_kernel" if n_ind <= 128 or (n_ind <= 256 and ((n_ind + 31) // 32) % 2)
-                                    else "pair_ld_pf_kernel" if n_ind <= 512
+                                    else "pair_ld_run_kernel" if n_ind <= 512
                                     else "pair_ld_kernel (multi-wavefront)" if n_ind <= 4096
                                     else "pair_ld_stream_kernel"),
                          "kernel_ms_per_launch": launch_s * 1e3,
                          "algorithmic_bytes_per_pair": bytes_pair,
                          "fp64_valu": {"achieved": fp64_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                        "frac": fp64_tflops / FP64_PEAK_TFLOPS,
-                                       "note": "23 f64 VALU ops per individual per executed EM iteration "
+                                       "note": "20 f64 VALU ops per individual per executed EM iteration "
                                                "(FMA counted as 2 flop); the binding roofline"}},
         }
         if raw_head is not None:

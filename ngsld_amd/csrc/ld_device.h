@@ -729,6 +729,8 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // (An XCD-aware order -- each XCD taking 64 consecutive runs of every 512 -- was measured and dropped: neighbouring
+  // rows drift apart by more pairs than the 4 MB L2 bridges, L2-miss traffic rose 35 % and the kernel lost 0.7 %.)
   const Run run = A.runs[blockIdx.x];
   const Item *g_items = A.items_all + run.first_item;
   const uint32_t s1 = g_items[0].s1;
