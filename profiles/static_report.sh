@@ -6,8 +6,9 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
 cat > $T/k.hip <<EOT
 #include "$R/ngsld_amd/csrc/ld_device.h"
+template __global__ void ngsld::pair_ld_run_kernel<8,false>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_run_kernel<8,true>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_pf_kernel<8,false>(ngsld::PairArgs);
-template __global__ void ngsld::pair_ld_pf_kernel<8,true>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_group_kernel<8,3,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_group_kernel<16,7,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_group_kernel<32,7,false>(ngsld::PairArgs);
@@ -22,10 +23,16 @@ echo "== kernel resources (hipcc -Rpass-analysis=kernel-resource-usage, gfx950) 
 grep -E "Function Name|VGPRs:|AGPRs|ScratchSize|Occupancy|LDS Size|SGPRs:" res.txt | sed 's/remark:[^:]*:[0-9]*:[0-9]*: *//; s/ \[-Rpass-analysis=kernel-resource-usage\]//' \
   | sed 's/_ZN5ngsld//; s/EvNS_8PairArgsE//'
 S=k-hip-amdgcn-amd-amdhsa-gfx950.s
-awk '/^_ZN5ngsld17pair_ld_pf_kernelILi8ELb0EEEvNS_8PairArgsE:/,/s_endpgm/' $S > pf.s
+awk '/^_ZN5ngsld18pair_ld_run_kernelILi8ELb0EEEvNS_8PairArgsE:/,/s_endpgm/' $S > pf.s
 L=$(grep -n "Inner Loop Header: Depth=2" pf.s | tail -1 | cut -d: -f1)
-E=$(awk -v s=$L 'NR>s && /^\.LBB0_[0-9]+:.*Depth=1$/ {print NR; exit}' pf.s)
+# the hot path of one EM iteration = the loop header block up to its first branch (the shared-reciprocal step and its
+# reduction); what follows in the loop is the single-reciprocal redo path and the convergence bookkeeping
+E=$(awk -v s=$L 'NR>s && /s_cbranch/ {print NR; exit}' pf.s)
+X=$(awk -v s=$L 'NR>s && /^\.LBB0_[0-9]+:.*Depth=1$/ {print NR; exit}' pf.s)
 echo
-echo "== pair_ld_pf_kernel<8,false>: instruction mix of the EM loop body (ISA lines $L..$E of the kernel) =="
+echo "== pair_ld_run_kernel<8,false>: instruction mix of the hot block of one EM iteration (ISA lines $L..$E) =="
 sed -n "${L},${E}p" pf.s | grep -v "^\s*;" | grep -v "^\." | awk '{print $1}' | sort | uniq -c | sort -rn
+echo
+echo "== same kernel: whole EM loop incl. the redo path and the convergence test (ISA lines $L..$X) =="
+sed -n "${L},${X}p" pf.s | grep -v "^\s*;" | grep -v "^\." | awk '{print $1}' | sort | uniq -c | sort -rn
 rm -rf $T
