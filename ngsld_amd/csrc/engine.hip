@@ -319,7 +319,7 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
   a.rsx = c->d_rsx.p;
   a.items = c->d_items.p + c->h_item_off[r0];
   a.n_items = c->h_item_off[r1] - c->h_item_off[r0];
-  if (c->cfg.kernel == kRun) {
+  if (c->cfg.kernel == kRun || c->cfg.kernel == kGroup) {
     a.runs = c->d_runs.p + c->h_run_off[r0];
     a.n_runs = c->h_run_off[r1] - c->h_run_off[r0];
   }
@@ -483,7 +483,7 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) {
     c->h_item_off[s1 + 1] = c->h_item_off[s1] + (span + ch - 1) / ch;
   }
   c->n_items = c->h_item_off[n];
-  if (c->cfg.kernel == kRun) {
+  if (c->cfg.kernel == kRun || c->cfg.kernel == kGroup) {
     // runs: a row's items cut into ceil(items / kRunItems) runs of near-equal length (one workgroup each)
     std::vector<Run> runs;
     c->h_run_off.assign(n + 1, 0);

@@ -858,64 +858,71 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
   constexpr int kPiece = G * 16;                             // bytes one group moves per copy instruction
   constexpr int kPieces = (kSiteBytes + kPiece - 1) / kPiece;
   constexpr int kABytes = ((kSiteBytes + 1023) / 1024) * 1024;
-  constexpr int kWaveBuf = kPieces * 1024;                   // the 64/G groups of a wavefront, interleaved
+  constexpr int kWaveBuf = (kPieces + 1) * 1024;             // the 64/G groups of a wavefront, interleaved, + their scalars
+  constexpr int kGroups = 64 / G;
+  constexpr uint32_t kRing = 32;
+  constexpr int kRingOff = kABytes + 4 * kWaveBuf;
+  constexpr int kItemOff = kRingOff + 4 * (int)(kRing * sizeof(RunResult));
+  constexpr int kClaimOff = kItemOff + (int)(kRunItems * sizeof(Item));
   constexpr unsigned long long kGroupMask = G == 32 ? 0xffffffffull : ((1ull << G) - 1ull);
-  __shared__ __attribute__((aligned(16))) char smem[kABytes + 4 * kWaveBuf + 16 + 64 * sizeof(PairResult)];
+  __shared__ __attribute__((aligned(16))) char smem[kClaimOff + 16];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int grp = lane / G, gl = lane % G;
-  const Item it = A.items[blockIdx.x];
-  const uint32_t s1 = it.s1;
-  const double m1 = A.maf[s1];
-  const double mean1 = A.mean_e[s1];
-  const double rsx1 = A.rsx[s1];
-  const uint64_t rec0 = it.first_record - A.out_base;
+  // Run form (see pair_ld_run_kernel): the workgroup works through up to kRunItems consecutive items of one row; the row
+  // vector is loaded once, groups claim candidates from one counter for the whole run, item headers sit in LDS, a site's
+  // scalars travel with its planes, results go through a wave-private ring.  With a pair costing a few microseconds at
+  // these cohort sizes, one workgroup per 64-candidate item meant a workgroup turnover every ~10 us.
+  const Run run = A.runs[blockIdx.x];
+  const Item *g_items = A.items_all + run.first_item;
+  const uint32_t s1 = g_items[0].s1;
+  const double m1 = A.sc4[4 * (uint64_t)s1], mean1 = A.sc4[4 * (uint64_t)s1 + 1], rsx1 = A.sc4[4 * (uint64_t)s1 + 2];
   char *lds_a = smem;
   char *lds_w = smem + kABytes + wave * kWaveBuf;
-  uint32_t *claim = reinterpret_cast<uint32_t *>(smem + kABytes + 4 * kWaveBuf);
-  PairResult *res = reinterpret_cast<PairResult *>(smem + kABytes + 4 * kWaveBuf + 16);  // one per candidate of the item
+  RunResult *ring = reinterpret_cast<RunResult *>(smem + kRingOff) + wave * kRing;
+  const Item *l_items = reinterpret_cast<const Item *>(smem + kItemOff);
+  uint32_t *claim = reinterpret_cast<uint32_t *>(smem + kClaimOff);
 
+  if (threadIdx.x < run.n_items * 2)  // item headers, 16 bytes per thread
+    reinterpret_cast<uint4 *>(smem + kItemOff)[threadIdx.x] = reinterpret_cast<const uint4 *>(g_items)[threadIdx.x];
   if (threadIdx.x == 0) *claim = 0;
-  // a group claims the next computed pair of the item (maf[s2] / sub-sampling filters live in the mask, ngsLD.cpp:270-282)
-  auto claim_group = [&]() -> uint32_t {
-    uint32_t c;
+
+  // one candidate of the run per group: site and record index (group-uniform values)
+  struct Cand {
+    uint32_t s2;
+    uint64_t rec;
+    bool ok;
+  };
+  // a group claims the next computed pair of the run (maf[s2] / sub-sampling filters live in the masks, ngsLD.cpp:270-282)
+  auto claim_group = [&]() -> Cand {
     for (;;) {
-      c = 0;
-      if (gl == 0) c = atomicAdd(claim, 1u);
-      c = (uint32_t)__shfl((int)c, lane & ~(G - 1));
-      if (c >= it.count || ((it.mask >> c) & 1ull)) break;
+      uint32_t q = 0;
+      if (gl == 0) q = atomicAdd(claim, 1u);
+      q = (uint32_t)__shfl((int)q, lane & ~(G - 1));
+      const uint32_t k = q >> 6, c = q & 63u;  // items of a run span 64 candidates (the row's last one may hold fewer)
+      if (k >= run.n_items) return Cand{0u, 0ull, false};
+      const Item h = l_items[k];
+      if (c < h.count && ((h.mask >> c) & 1ull))
+        return Cand{h.s2_begin + c, h.first_record - A.out_base + (uint64_t)__popcll(h.mask & ((1ull << c) - 1ull)), true};
     }
-    return c;
   };
   // byte offset of individual-slot j, genotype plane g of this lane's group inside the interleaved wave buffer
   auto b_off = [&](int g, int j) -> uint32_t {
     const uint32_t o = ((uint32_t)g * kNp + (uint32_t)j * (uint32_t)G + (uint32_t)gl) * 8u;  // offset inside the site
     return (o / (uint32_t)kPiece) * 1024u + (uint32_t)grp * (uint32_t)kPiece + (o % (uint32_t)kPiece);
   };
-  // start the copy of site (s2_begin + c) for every group whose c is inside the item: lane (grp, r) moves the
-  // 16 bytes [q*kPiece + r*16, +16) of its group's site for q = 0 .. kPieces-1
-  auto dma_groups = [&](uint32_t c) {
-    const bool on = c < it.count;
-    const char *g = reinterpret_cast<const char *>(A.planes + (uint64_t)(it.s2_begin + (on ? c : 0u)) * A.site_stride) +
-                    gl * 16;
+  // start the copy of every group's next site: lane (grp, r) moves the 16 bytes [q*kPiece + r*16, +16) of its group's
+  // site for q = 0 .. kPieces-1; lanes r = 0, 1 then move the site's 32 bytes of scalars {maf, mean_e, rsx, 0}
+  auto dma_groups = [&](const Cand &cd) {
+    const char *g = reinterpret_cast<const char *>(A.planes + (uint64_t)(cd.ok ? cd.s2 : 0u) * A.site_stride) + gl * 16;
 #pragma unroll
     for (int q = 0; q < kPieces; ++q)
-      if (on && q * kPiece + gl * 16 < kSiteBytes)
+      if (cd.ok && q * kPiece + gl * 16 < kSiteBytes)
         __builtin_amdgcn_global_load_lds((glb_void_t *)(g + q * kPiece), (lds_void_t *)(lds_w + q * 1024), 16, 0, 0);
-  };
-  struct SiteScalars {
-    double maf, mean, rsx;
-  };
-  auto load_scalars = [&](uint32_t c) -> SiteScalars {
-    SiteScalars v{0.5, 0.0, 0.0};
-    if (c < it.count) {
-      const uint32_t s2 = it.s2_begin + c;
-      v.maf = A.maf[s2];
-      v.mean = A.mean_e[s2];
-      v.rsx = A.rsx[s2];
-    }
-    return v;
+    if (cd.ok && gl < 2)
+      __builtin_amdgcn_global_load_lds((glb_void_t *)(reinterpret_cast<const char *>(A.sc4 + 4 * (uint64_t)cd.s2) + gl * 16),
+                                       (lds_void_t *)(lds_w + kPieces * 1024), 16, 0, 0);
   };
 
   // the row vector: linear copy, 1 KiB per wave-instruction, chunks dealt round-robin to the four wavefronts
@@ -926,18 +933,24 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       if ((k & 3) == wave && k * 1024 + lane * 16 < kSiteBytes)
         __builtin_amdgcn_global_load_lds((glb_void_t *)(g + k * 1024), (lds_void_t *)(lds_a + k * 1024), 16, 0, 0);
   }
-  __syncthreads();  // claim counter initialised
-  uint32_t c = claim_group();
-  SiteScalars cur = load_scalars(c);
-  dma_groups(c);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // row vector complete in LDS
+  __syncthreads();  // (waits for this wavefront's copies first) row vector, headers and counter in place
+  Cand cur = claim_group();
+  dma_groups(cur);
+  uint32_t held = 0;
+  auto flush = [&](uint32_t n) {  // lane t derives and writes the record of ring entry t (holes: groups without a pair)
+    if ((uint32_t)lane < n) {
+      const RunResult r = ring[lane];
+      if (r.rec != ~0ull) write_pair(A, r.rec, r.f[0], r.f[1], r.f[2], r.f[3], r.sxy, rsx1, r.rsx2, r.x, r.n_iter);
+    }
+  };
 
-  while (__any(c < it.count)) {
-    const bool active = c < it.count;
-    const uint32_t cn = active ? claim_group() : c;
-    const SiteScalars nxt = load_scalars(cn);
+  while (__any(cur.ok)) {
+    const bool active = cur.ok;
+    Cand nxt = cur;
+    if (active) nxt = claim_group();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the site copies issued a generation ago have landed
+    const double *sc = reinterpret_cast<const double *>(lds_w + kPieces * 1024 + grp * kPiece);
+    const double m2 = active ? sc[0] : 0.5, mean2 = active ? sc[1] : 0.0, rsx2 = active ? sc[2] : 0.0;
 
     // ---- stage: P = a (x) b per lane, validity, Pearson cross moment (group sums) ----
     double P[SLOTS][9];
@@ -959,11 +972,11 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       P[j][3] = a1 * b0; P[j][4] = a1 * b1; P[j][5] = a1 * b2;
       P[j][6] = a2 * b0; P[j][7] = a2 * b1; P[j][8] = a2 * b2;
       const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;   // ngsLD.cpp:113, :290
-      const double c2 = inb ? fma(2.0, b2, b1) - cur.mean : 0.0;
+      const double c2 = inb ? fma(2.0, b2, b1) - mean2 : 0.0;
       sxy = fma(c1, c2, sxy);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // buffers consumed: start the next generation's copies
-    dma_groups(cn);
+    dma_groups(nxt);
     uint32_t x = 0;  // individuals with data in this group's pair (gen_func.cpp:1091), integer exact
 #pragma unroll
     for (int j = 0; j < SLOTS; ++j)
@@ -971,7 +984,6 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
     sxy = group_sum<G>(sxy);
 
     // ---- haplo_freq (gen_func.cpp:1027-1059), 64/G pairs in lockstep ----
-    const double m2 = cur.maf;
     double f0 = (1 - m1) * (1 - m2), f1 = (1 - m1) * m2, f2 = m1 * (1 - m2), f3 = m1 * m2;
     if (active && (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1)) {
       if (gl == 0) atomicExch(A.status, (int)NGSLD_ERR_MAF_RANGE);
@@ -1058,25 +1070,23 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       if (__all(done)) break;
     }
 
-    if (active && gl == 0) {
-      PairResult &r = res[c];
+    if (gl == 0) {  // one ring entry per group and generation; a group without a pair leaves a hole
+      RunResult &r = ring[held + (uint32_t)grp];
       r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;
       r.sxy = sxy;
-      r.rsx2 = cur.rsx;
+      r.rsx2 = rsx2;
       r.x = x;
       r.n_iter = n_iter;
+      r.rec = active ? cur.rec : ~0ull;
     }
-    c = cn;
+    held += (uint32_t)kGroups;
+    if (held + (uint32_t)kGroups > kRing) {
+      flush(held);
+      held = 0;
+    }
     cur = nxt;
   }
-  // the item is done: thread t derives and writes the record of candidate t (see pair_ld_pf_kernel)
-  __syncthreads();
-  const uint32_t t = threadIdx.x;
-  if (t < it.count && ((it.mask >> t) & 1ull)) {
-    const PairResult r = res[t];
-    write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << t) - 1ull)), r.f[0], r.f[1], r.f[2], r.f[3], r.sxy, rsx1,
-               r.rsx2, r.x, r.n_iter);
-  }
+  flush(held);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1213,7 +1223,7 @@ bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig
 hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs &args, hipStream_t stream);
 // candidate s2 sites per work item: kGroup / kWave items are shared by the four wavefronts of a workgroup
 inline uint32_t item_span(const PairConfig &cfg, uint32_t pairs_per_item) {
-  if (cfg.kernel == kRun) return 64u;  // the run kernel addresses candidates as 64 * item + offset
+  if (cfg.kernel == kRun || cfg.kernel == kGroup) return 64u;  // run form: candidates are addressed as 64 * item + offset
   const uint32_t span = (cfg.kernel == kGroup || cfg.kernel == kWave) ? 4u * pairs_per_item : pairs_per_item;
   return span > 64u ? 64u : span;
 }

@@ -38,9 +38,9 @@ bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig
 
 template <int G, int SLOTS>
 static hipError_t launch_g(bool masked, const PairArgs &a, hipStream_t stream) {
-  if (a.n_items == 0) return hipSuccess;
-  if (a.n_items > 0x7fffffffull) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)a.n_items), block(256);
+  if (a.n_runs == 0) return hipSuccess;
+  if (a.n_runs > 0x7fffffffull) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)a.n_runs), block(256);
   if (masked)
     hipLaunchKernelGGL((pair_ld_group_kernel<G, SLOTS, true>), grid, block, 0, stream, a);
   else
