@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--ignore-miss", action="store_true", help="run the --ignore_miss_data kernels (not the headline config)")
+    ap.add_argument("--rnd-sample", type=float, default=1.0, help="--rnd_sample of the plan (not the headline config)")
     ap.add_argument("--sink", action="store_true", help="also time ngsld_run (records copied to pinned host memory)")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "hbm_traffic.json"))
     return ap.parse_args()
@@ -149,15 +150,16 @@ def main():
     if args.pairs_per_item:
         eng.set_tuning(pairs_per_item=args.pairs_per_item)
     t_plan = time.perf_counter()
-    eng.plan(max_kb_dist=args.max_kb, extend_out=True, ignore_miss_data=args.ignore_miss)   # pair-space plan (one-off)
+    eng.plan(max_kb_dist=args.max_kb, extend_out=True, ignore_miss_data=args.ignore_miss,
+             rnd_sample=args.rnd_sample, seed=12345)                                # pair-space plan (one-off)
     t_plan = time.perf_counter() - t_plan
     row_off, _ = eng.plan_rows()
     n_rows = hi - lo
     n_pairs = int(row_off[n_rows] - row_off[0])
-    assert n_pairs == int(counts[lo:hi].sum()), "engine plan and host mirror disagree on the pair count"
+    assert args.rnd_sample < 1.0 or n_pairs == int(counts[lo:hi].sum()), "engine plan and host mirror disagree on the pair count"
 
     raw_head = None
-    if rank == 0 and world == 1 and not args.no_cpu and not args.ignore_miss:
+    if rank == 0 and world == 1 and not args.no_cpu and not args.ignore_miss and args.rnd_sample >= 1.0:
         head = min(n_sites, 12_000)
         raw_head = raw[:head].cpu().numpy()
     del slab, raw

@@ -716,6 +716,43 @@ struct RunResult {
   uint64_t rec;
 };
 
+// The computed pairs of a run, as a list: cand[j] = candidate index (64 * item + offset = s2 - s2 of the run's first
+// candidate) of the run's j-th computed pair, in increasing s2 -- so its record is simply the run's first record + j.
+// Built once per run from the items' masks by the whole workgroup; a claim is then one LDS atomic and one 2-byte read
+// whatever the masks look like.  (Claiming candidate by candidate and skipping the masked-out ones cost a dependent LDS
+// round trip per dropped candidate: -11 % at --rnd_sample 0.1, -49 % at 0.02.)
+struct RunList {
+  uint16_t cand[kRunItems * 64];
+  uint32_t base[kRunItems + 1];  // computed pairs before each item; base[n_items] = all of the run's
+  uint32_t claim;
+  uint32_t pad[2];
+  Item items[kRunItems];         // the run's item headers
+};
+
+// Called by all 256 threads; ends with a barrier (which also completes whatever global->LDS copies the callers issued
+// before it: __syncthreads waits for the wavefront's own memory operations first).
+__device__ __forceinline__ void build_run_list(RunList *L, const Item *g_items, uint32_t n_items) {
+  if (threadIdx.x < n_items * 2)  // item headers, 16 bytes per thread
+    reinterpret_cast<uint4 *>(L->items)[threadIdx.x] = reinterpret_cast<const uint4 *>(g_items)[threadIdx.x];
+  if (threadIdx.x == 0) L->claim = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (uint32_t k = 0; k < n_items; ++k) {
+      L->base[k] = acc;
+      acc += (uint32_t)__popcll(L->items[k].mask);  // bits at or beyond `count` are never set (items_kernel)
+    }
+    L->base[n_items] = acc;
+  }
+  __syncthreads();
+  for (uint32_t idx = threadIdx.x; idx < n_items * 64; idx += 256) {
+    const uint32_t k = idx >> 6, c = idx & 63u;
+    const unsigned long long m = L->items[k].mask;
+    if ((m >> c) & 1ull) L->cand[L->base[k] + (uint32_t)__popcll(m & ((1ull << c) - 1ull))] = (uint16_t)idx;
+  }
+  __syncthreads();
+}
+
 template <int SLOTS, bool MASKED>
 __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
   constexpr int kSiteBytes = SLOTS * 64 * 3 * 8;
@@ -723,9 +760,8 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
   constexpr uint32_t kNp = SLOTS * 64;
   constexpr uint32_t kRing = 32;
   constexpr int kRingOff = kSiteBytes + 4 * kBuf;
-  constexpr int kItemOff = kRingOff + 4 * (int)(kRing * sizeof(RunResult));
-  constexpr int kClaimOff = kItemOff + (int)(kRunItems * sizeof(Item));
-  __shared__ __attribute__((aligned(16))) char smem[kClaimOff + 16];
+  constexpr int kListOff = kRingOff + 4 * (int)(kRing * sizeof(RunResult));
+  __shared__ __attribute__((aligned(16))) char smem[kListOff + sizeof(RunList)];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -738,38 +774,27 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
   char *lds_a = smem;
   char *lds_b = smem + kSiteBytes + wave * kBuf;
   RunResult *ring = reinterpret_cast<RunResult *>(smem + kRingOff) + wave * kRing;
-  const Item *l_items = reinterpret_cast<const Item *>(smem + kItemOff);
-  uint32_t *claim = reinterpret_cast<uint32_t *>(smem + kClaimOff);
+  RunList *L = reinterpret_cast<RunList *>(smem + kListOff);
 
-  if (threadIdx.x < run.n_items * 2)  // item headers, 16 bytes per thread
-    reinterpret_cast<uint4 *>(smem + kItemOff)[threadIdx.x] = reinterpret_cast<const uint4 *>(g_items)[threadIdx.x];
-  if (threadIdx.x == 0) *claim = 0;
   dma_site_to_lds<SLOTS>(A.planes + (uint64_t)s1 * A.site_stride, lds_a, lane, wave, 4);  // a quarter per wavefront
-  __syncthreads();  // (waits for this wavefront's copies first) row vector, headers and counter in place
+  build_run_list(L, g_items, run.n_items);  // its last barrier: row vector and list in place
+  const uint32_t n_kept = (uint32_t)__builtin_amdgcn_readfirstlane((int)L->base[run.n_items]);
+  const uint32_t s2_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)L->items[0].s2_begin);
+  const uint64_t rec_base = g_items[0].first_record - A.out_base;
 
-  // one candidate of the run: item k, offset c inside it -> site and record index
+  // one computed pair of the run: site and record index
   struct Cand {
     uint32_t s2;
     uint64_t rec;
     bool ok;
   };
-  auto claim_next = [&]() -> Cand {  // pairs dropped by the maf[s2] / sub-sampling filters are skipped (ngsLD.cpp:270-282)
-    for (;;) {
-      uint32_t q = 0;
-      if (lane == 0) q = atomicAdd(claim, 1u);
-      q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
-      const uint32_t k = q >> 6, c = q & 63u;  // items of a run span 64 candidates (the row's last one may hold fewer)
-      if (k >= run.n_items) return Cand{0u, 0ull, false};
-      const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)l_items[k].count);
-      const uint64_t mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(l_items[k].mask >> 32)) << 32) |
-                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)l_items[k].mask);
-      if (c < cnt && ((mask >> c) & 1ull)) {
-        const uint32_t s2b = (uint32_t)__builtin_amdgcn_readfirstlane((int)l_items[k].s2_begin);
-        const uint64_t fr = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(l_items[k].first_record >> 32)) << 32) |
-                            (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)l_items[k].first_record);
-        return Cand{s2b + c, fr - A.out_base + (uint64_t)__popcll(mask & ((1ull << c) - 1ull)), true};
-      }
-    }
+  auto claim_next = [&]() -> Cand {  // (the maf[s2] / sub-sampling filters, ngsLD.cpp:270-282, already shaped the list)
+    uint32_t j = 0;
+    if (lane == 0) j = atomicAdd(&L->claim, 1u);
+    j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+    if (j >= n_kept) return Cand{0u, 0ull, false};
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)L->cand[j]);
+    return Cand{s2_base + off, rec_base + j, true};
   };
   auto dma_site = [&](uint32_t s2) {
     dma_site_to_lds<SLOTS>(A.planes + (uint64_t)s2 * A.site_stride, lds_b, lane, 0, 1);
@@ -862,10 +887,9 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
   constexpr int kGroups = 64 / G;
   constexpr uint32_t kRing = 32;
   constexpr int kRingOff = kABytes + 4 * kWaveBuf;
-  constexpr int kItemOff = kRingOff + 4 * (int)(kRing * sizeof(RunResult));
-  constexpr int kClaimOff = kItemOff + (int)(kRunItems * sizeof(Item));
+  constexpr int kListOff = kRingOff + 4 * (int)(kRing * sizeof(RunResult));
   constexpr unsigned long long kGroupMask = G == 32 ? 0xffffffffull : ((1ull << G) - 1ull);
-  __shared__ __attribute__((aligned(16))) char smem[kClaimOff + 16];
+  __shared__ __attribute__((aligned(16))) char smem[kListOff + sizeof(RunList)];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -881,31 +905,23 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
   char *lds_a = smem;
   char *lds_w = smem + kABytes + wave * kWaveBuf;
   RunResult *ring = reinterpret_cast<RunResult *>(smem + kRingOff) + wave * kRing;
-  const Item *l_items = reinterpret_cast<const Item *>(smem + kItemOff);
-  uint32_t *claim = reinterpret_cast<uint32_t *>(smem + kClaimOff);
+  RunList *L = reinterpret_cast<RunList *>(smem + kListOff);
 
-  if (threadIdx.x < run.n_items * 2)  // item headers, 16 bytes per thread
-    reinterpret_cast<uint4 *>(smem + kItemOff)[threadIdx.x] = reinterpret_cast<const uint4 *>(g_items)[threadIdx.x];
-  if (threadIdx.x == 0) *claim = 0;
-
-  // one candidate of the run per group: site and record index (group-uniform values)
+  // one computed pair of the run per group: site and record index (group-uniform values)
   struct Cand {
     uint32_t s2;
     uint64_t rec;
     bool ok;
   };
-  // a group claims the next computed pair of the run (maf[s2] / sub-sampling filters live in the masks, ngsLD.cpp:270-282)
+  uint32_t n_kept = 0, s2_base = 0;   // set once the run's list is built
+  uint64_t rec_base = 0;
+  // a group claims the next computed pair of the run (the maf[s2] / sub-sampling filters, ngsLD.cpp:270-282, shaped the list)
   auto claim_group = [&]() -> Cand {
-    for (;;) {
-      uint32_t q = 0;
-      if (gl == 0) q = atomicAdd(claim, 1u);
-      q = (uint32_t)__shfl((int)q, lane & ~(G - 1));
-      const uint32_t k = q >> 6, c = q & 63u;  // items of a run span 64 candidates (the row's last one may hold fewer)
-      if (k >= run.n_items) return Cand{0u, 0ull, false};
-      const Item h = l_items[k];
-      if (c < h.count && ((h.mask >> c) & 1ull))
-        return Cand{h.s2_begin + c, h.first_record - A.out_base + (uint64_t)__popcll(h.mask & ((1ull << c) - 1ull)), true};
-    }
+    uint32_t j = 0;
+    if (gl == 0) j = atomicAdd(&L->claim, 1u);
+    j = (uint32_t)__shfl((int)j, lane & ~(G - 1));
+    if (j >= n_kept) return Cand{0u, 0ull, false};
+    return Cand{s2_base + (uint32_t)L->cand[j], rec_base + j, true};
   };
   // byte offset of individual-slot j, genotype plane g of this lane's group inside the interleaved wave buffer
   auto b_off = [&](int g, int j) -> uint32_t {
@@ -933,7 +949,10 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       if ((k & 3) == wave && k * 1024 + lane * 16 < kSiteBytes)
         __builtin_amdgcn_global_load_lds((glb_void_t *)(g + k * 1024), (lds_void_t *)(lds_a + k * 1024), 16, 0, 0);
   }
-  __syncthreads();  // (waits for this wavefront's copies first) row vector, headers and counter in place
+  build_run_list(L, g_items, run.n_items);  // its last barrier: row vector and list in place
+  n_kept = L->base[run.n_items];
+  s2_base = L->items[0].s2_begin;
+  rec_base = g_items[0].first_record - A.out_base;
   Cand cur = claim_group();
   dma_groups(cur);
   uint32_t held = 0;
