@@ -466,6 +466,18 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
   const double *pa = A.planes + (uint64_t)s1 * A.site_stride;
   const uint32_t i0 = (uint32_t)sub * (SLOTS * 64) + (uint32_t)lane;
   char *lds_b = smem + wave * kSliceBytes;
+  // WAVES > 1: the scalars of the item's candidate sites come into LDS once, by one coalesced load per array, so the pair
+  // loop waits for no ordinary global load (a ~2 us round trip per pair, and it would drain the slice copy in flight)
+  __shared__ double site_sc[WAVES > 1 ? 3 : 1][64];
+  if (WAVES > 1) {
+    if (threadIdx.x < it.count) {
+      const uint32_t s2 = it.s2_begin + threadIdx.x;
+      site_sc[0][threadIdx.x] = A.maf[s2];
+      site_sc[WAVES > 1 ? 1 : 0][threadIdx.x] = A.mean_e[s2];
+      site_sc[WAVES > 1 ? 2 : 0][threadIdx.x] = A.rsx[s2];
+    }
+    __syncthreads();
+  }
 
   // copy this wavefront's slice of site s2 (three runs of SLOTS*512 B, one per genotype plane) into lds_b
   auto dma_slice = [&](uint32_t s2) {
@@ -489,9 +501,11 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
   while (c < it.count) {
     const uint32_t s2 = it.s2_begin + c;
     const uint32_t cn = next_kept(c + 1);
-    // per-site scalars are fetched here, before the copy of the next site is started: an ordinary load waited
-    // for later would drain that copy too (vmcnt is in-order)
-    const double m2 = A.maf[s2], mean2 = A.mean_e[s2], rsx2 = A.rsx[s2];
+    // (one wavefront per pair: per-site scalars are fetched here, before the copy of the next site is started: an
+    // ordinary load waited for later would drain that copy too, vmcnt is in-order)
+    const double m2 = WAVES > 1 ? site_sc[0][c] : A.maf[s2];
+    const double mean2 = WAVES > 1 ? site_sc[WAVES > 1 ? 1 : 0][c] : A.mean_e[s2];
+    const double rsx2 = WAVES > 1 ? site_sc[WAVES > 1 ? 2 : 0][c] : A.rsx[s2];
     double P[SLOTS][9];
     uint32_t vbits;
     double sxy;
