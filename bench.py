@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--ind", type=int, default=500)
     ap.add_argument("--max-kb", type=int, default=100)
     ap.add_argument("--depth", type=float, default=10.0)
+    ap.add_argument("--max-gap", type=int, default=200, help="site gaps ~ UniformInt[1, max-gap] (SURVEY 8d: 2000 for configs[4])")
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--pairs-per-item", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample")
@@ -117,7 +118,7 @@ def main():
     n_ind = args.ind
 
     # ---- positions (host, identical on every rank) and the row shards ----
-    chrs, pos = synth.make_positions(n_sites, args.seed, max_gap=200, n_chr=1)
+    chrs, pos = synth.make_positions(n_sites, args.seed, max_gap=args.max_gap, n_chr=1)
     pos_dist = shard.pos_dist_from_positions(chrs, pos)
     row_end = shard.row_ends(pos_dist, args.max_kb, 0)
     counts = row_end - (np.arange(n_sites, dtype=np.int64) + 1)
@@ -240,7 +241,8 @@ def main():
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic binary GL, {args.sites} sites/GPU x {n_ind} ind, depth {args.depth:g}, "
-                                   f"--max_kb_dist {args.max_kb} windowed, --extend_out (BASELINE configs[2])",
+                                   f"--max_kb_dist {args.max_kb} {'windowed' if args.max_kb else 'all pairs'}, --extend_out"
+                                   + (" (BASELINE configs[2])" if (args.sites, n_ind, args.max_kb, args.max_gap) == (100_000, 500, 100, 200) else ""),
                        "n_sites_total": n_sites, "pairs_per_step": total_pairs,
                        "mean_executed_em_iterations": round(mean_exec, 3),
                        "parallelism": f"rows sharded by pair count over {world} GPU(s), no data-path collective",
