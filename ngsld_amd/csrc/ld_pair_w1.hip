@@ -1,4 +1,6 @@
 // ld_pair_w1.hip -- instantiations of the one-wavefront-per-pair kernel (n_ind <= 512) and the launcher.
+#include <cstdlib>
+
 #include "ld_device.h"
 
 namespace ngsld {
@@ -90,7 +92,39 @@ static hipError_t launch_s(int kernel, bool masked, const PairArgs &a, hipStream
 
 hipError_t launch_pair_wn(int slots, int waves, bool masked, bool prefetch, const PairArgs &a, hipStream_t stream);
 
+static hipError_t launch_pair_chunk(const PairConfig &cfg, bool masked, const PairArgs &a, hipStream_t stream);
+
+// HIP addresses the threads of a launch with 32 bits per dimension: gridDim.x * blockDim.x has to stay below 2^32, and a
+// grid beyond that is not refused -- it silently wraps (50,000 x 1,000 all pairs on ONE device is 7.8e7 items of the
+// multi-wavefront kernel x 128 threads = 1.0e10: only the first 14 % of the items ran).  Workgroups have at most 512
+// threads, so one launch takes at most 2^22 of them; longer item / run lists go out as consecutive launches on the
+// same stream.  NGSLD_MAX_BLOCKS lowers the cap (tests).
 hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs &a, hipStream_t stream) {
+  uint64_t max_blocks = 1ull << 22;
+  if (const char *e = std::getenv("NGSLD_MAX_BLOCKS")) {
+    const uint64_t u = std::strtoull(e, nullptr, 10);
+    if (u >= 1 && u < max_blocks) max_blocks = u;
+  }
+  const bool by_runs = cfg.kernel == kRun || cfg.kernel == kGroup;
+  const uint64_t total = by_runs ? a.n_runs : a.n_items;
+  const uint64_t per = max_blocks * ((cfg.kernel == kDirect && cfg.waves == 1) ? 4u : 1u);  // kDirect: 4 items per block
+  for (uint64_t off = 0; off < total; off += per) {
+    PairArgs b = a;
+    const uint64_t n = total - off < per ? total - off : per;
+    if (by_runs) {
+      b.runs = a.runs + off;
+      b.n_runs = n;
+    } else {
+      b.items = a.items + off;
+      b.n_items = n;
+    }
+    const hipError_t e = launch_pair_chunk(cfg, masked, b, stream);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+static hipError_t launch_pair_chunk(const PairConfig &cfg, bool masked, const PairArgs &a, hipStream_t stream) {
   if (cfg.kernel == kStream) {
     if (a.n_items == 0) return hipSuccess;
     if (a.n_items > 0x7fffffffull) return hipErrorInvalidValue;

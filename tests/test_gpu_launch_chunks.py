@@ -1,0 +1,56 @@
+"""GPU: long item / run lists go out as several launches (HIP addresses a launch's threads with 32 bits per dimension;
+a grid beyond 2^32 threads silently wraps -- 50,000 x 1,000 all pairs on one device once computed 14 % of its pairs)."""
+import os
+
+import numpy as np
+import pytest
+
+from ngsld_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.mark.parametrize("n_sites,n_ind,seed", [(300, 20, 1), (260, 100, 2), (200, 300, 3), (90, 600, 4), (24, 4200, 5)])
+def test_chunked_launches_are_bit_identical(engine, n_sites, n_ind, seed):
+    """Every kernel family with the cap forced down to 5 workgroups per launch: same records, bit for bit."""
+    raw = synth.make_gl_numpy(n_sites, n_ind, seed, depth=5.0)
+    out = []
+    for cap in (None, "5"):
+        if cap:
+            os.environ["NGSLD_MAX_BLOCKS"] = cap
+        try:
+            engine.set_geno_raw(raw)
+            engine.set_pos_dist(None)
+            engine.plan(extend_out=True, rnd_sample=0.7, seed=99)
+            out.append(engine.run())
+        finally:
+            os.environ.pop("NGSLD_MAX_BLOCKS", None)
+    assert len(out[0][0]) > 0
+    for a, b in zip(*out):
+        assert a.tobytes() == b.tobytes()
+
+
+def test_more_than_2_to_32_threads_in_one_plan():
+    """40,000 x 513 all pairs = 8e8 candidates = 5e7 items of the two-wavefront kernel (6.4e9 threads), thinned to ~1.6e6
+    computed pairs by --rnd_sample: every record of the plan must have been written."""
+    dev = torch.device("cuda", 0)
+    n_sites, n_ind = 40_000, 513
+    raw = synth.make_gl_torch(n_sites, n_ind, 11, dev, depth=8.0)
+    eng = capi.Engine(0)
+    try:
+        eng.set_geno_raw(raw.data_ptr(), n_sites=n_sites, n_ind=n_ind)
+        del raw
+        eng.set_pos_dist(None)
+        n = eng.plan(extend_out=True, rnd_sample=0.002, seed=7)
+        assert 1.2e6 < n < 2.0e6
+        d_std = torch.full((n * 4,), float("nan"), dtype=torch.float64, device=dev)
+        d_ext = torch.full((n * 10,), -1, dtype=torch.int32, device=dev)          # n_iter = -1: "never written"
+        eng.run_device(0, n_sites, d_std.data_ptr(), d_ext.data_ptr(), None)
+        meta = d_ext.view(-1, 10)[:, 8:10]
+        assert bool(torch.all(meta[:, 0] == n_ind)) and bool(torch.all((meta[:, 1] >= 0) & (meta[:, 1] <= 100)))
+        hap = d_ext.view(torch.float64).view(-1, 5)[:, :4]
+        assert float((hap.sum(dim=1) - 1).abs().max()) < 1e-12
+        assert bool(torch.all(torch.isfinite(d_std.view(-1, 4)[:, 1])))           # D of every pair
+    finally:
+        eng.close()
