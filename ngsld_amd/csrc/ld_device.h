@@ -140,6 +140,25 @@ __device__ __forceinline__ void wave_sum3(double &t1, double &t2, double &t3) {
   t2 = read_lane(w, 32);
 }
 
+// One value, no permlane swaps (each costs ~14 cycles of issue): four DPP levels inside the rows, then the GFX9 row
+// broadcasts -- lane 15 of rows 0 / 2 into rows 1 / 3, lane 31 into rows 2 and 3 -- leave the total in row 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_rows(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);  // rows outside ROW_MASK keep old = 0
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum1_bcast(double v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm:[1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm:[2,3,0,1]
+  v += dpp_mov<0x124>(v);  // row_ror:4
+  v += dpp_mov<0x128>(v);  // row_ror:8
+  v += dpp_mov_rows<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_mov_rows<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return read_lane(v, 63);
+}
+
 __device__ __forceinline__ double wave_sum1(double v) {
   double a = v, b = 0.0, c = 0.0, d = 0.0;
   wave_sum4(a, b, c, d);
@@ -205,7 +224,9 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // Stage both sites of one pair: P = a (x) b for this lane's SLOTS individuals, their validity bits and the
 // Pearson cross moment.  pa / pb point at a site's three planes [3][np] -- in HBM/L2 (direct kernel) or in
 // LDS (prefetch kernel); after inlining the compiler knows which and emits global_load or ds_read.
-template <int SLOTS, bool MASKED, bool ONLY_LAST = false>  // ONLY_LAST: only the last slot can hold padding lanes
+//   CROSS_FROM_P: sxy comes back as the UNCENTRED cross moment sum e1 e2 = sum (P4 + 2 (P5 + P7) + 4 P8) -- padding lanes hold
+//   P == 0, so no bounds test -- and the caller subtracts n * mean1 * mean2 once per pair
+template <int SLOTS, bool MASKED, bool ONLY_LAST = false, bool CROSS_FROM_P = false>  // ONLY_LAST: only the last slot can hold padding lanes
 __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint32_t ia0, const double *pb, uint32_t npb,
                                            uint32_t ib0, uint32_t ind0, uint32_t n_ind, double mean1, double mean2,
                                            double (&P)[SLOTS][9], uint32_t &vbits, double &sxy) {
@@ -225,9 +246,13 @@ __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint3
     P[j][3] = a1 * b0; P[j][4] = a1 * b1; P[j][5] = a1 * b2;
     P[j][6] = a2 * b0; P[j][7] = a2 * b1; P[j][8] = a2 * b2;
     // expected genotypes p1 + 2*p2 (ngsLD.cpp:113); pearson_r runs over ALL individuals (ngsLD.cpp:290)
-    const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;
-    const double c2 = inb ? fma(2.0, b2, b1) - mean2 : 0.0;
-    sxy = fma(c1, c2, sxy);
+    if (CROSS_FROM_P) {  // (a1 + 2 a2)(b1 + 2 b2) = P4 + 2 P5 + 2 P7 + 4 P8
+      sxy += fma(4.0, P[j][8], fma(2.0, P[j][5] + P[j][7], P[j][4]));
+    } else {
+      const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;
+      const double c2 = inb ? fma(2.0, b2, b1) - mean2 : 0.0;
+      sxy = fma(c1, c2, sxy);
+    }
   }
 }
 
@@ -406,7 +431,9 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
   const double den = D < 0 ? -(q00 <= q11 ? q00 : q11) : (q01 <= q10 ? q01 : q10);
   const double Dp = D / den;
   const double rr = D / sqrt(hm0 * hm1 * (1 - hm0) * (1 - hm1));
-  const double r = sxy * rsx1 * rsx2;  // 0 * inf = NaN for a constant site, like the 0/0 there
+  // a constant site (rsx = 1/sqrt(0) = inf) is 0/0 = NaN in gsl_stats_correlation; said explicitly because a cross
+  // moment centred after the fact (run kernel) is only ~0 there, not exactly 0
+  const double r = (rsx1 == __builtin_inf() || rsx2 == __builtin_inf()) ? __builtin_nan("") : sxy * rsx1 * rsx2;
   ngsld_rec_std o;
   o.r2_ExpG = r * r;
   o.D = D;
@@ -674,9 +701,9 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
     double P[SLOTS][9];
     uint32_t vbits;
     double sxy;
-    stage_pair<SLOTS, MASKED, !MASKED>(reinterpret_cast<const double *>(lds_a), kNp, (uint32_t)lane,
-                                       reinterpret_cast<const double *>(lds_b), kNp, (uint32_t)lane, (uint32_t)lane,
-                                       A.n_ind, mean1, cur.mean, P, vbits, sxy);
+    stage_pair<SLOTS, MASKED, !MASKED, true>(reinterpret_cast<const double *>(lds_a), kNp, (uint32_t)lane,
+                                             reinterpret_cast<const double *>(lds_b), kNp, (uint32_t)lane, (uint32_t)lane,
+                                             A.n_ind, mean1, cur.mean, P, vbits, sxy);
     // all ds_reads of the buffer are consumed (P is computed): start the copy of the next site over it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (cn < it.count)
@@ -684,7 +711,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
     // without --ignore_miss_data every individual counts: x = n_ind, 1/x comes precomputed (same IEEE quotient)
     const uint32_t x = MASKED ? count_valid<SLOTS>(vbits) : A.n_ind;
     const double inv_x = MASKED ? 1.0 / (double)x : A.inv_n;
-    sxy = wave_sum1(sxy);
+    sxy = fma(-(double)A.n_ind * mean1, cur.mean, wave_sum1_bcast(sxy));  // centred: sum e1 e2 - n mean1 mean2 (as the run kernel)
     double f0, f1, f2, f3;
     const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, inv_x, m1, cur.maf, f0, f1, f2, f3,
                                                       (double (*)[1][4]) nullptr, 0, lane, A.status);
@@ -823,6 +850,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
     }
   };
 
+  const double n_mean1 = (double)A.n_ind * mean1;
   Cand cur = claim_next();
   if (cur.ok) dma_site(cur.s2);
   uint32_t held = 0;
@@ -834,15 +862,15 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
     double P[SLOTS][9];
     uint32_t vbits;
     double sxy;
-    stage_pair<SLOTS, MASKED, !MASKED>(reinterpret_cast<const double *>(lds_a), kNp, (uint32_t)lane,
-                                       reinterpret_cast<const double *>(lds_b), kNp, (uint32_t)lane, (uint32_t)lane,
-                                       A.n_ind, mean1, mean2, P, vbits, sxy);
+    stage_pair<SLOTS, MASKED, !MASKED, true>(reinterpret_cast<const double *>(lds_a), kNp, (uint32_t)lane,
+                                             reinterpret_cast<const double *>(lds_b), kNp, (uint32_t)lane, (uint32_t)lane,
+                                             A.n_ind, mean1, mean2, P, vbits, sxy);
     // all ds_reads of the buffer are consumed (P is computed): start the copy of the next site over it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (nxt.ok) dma_site(nxt.s2);
     const uint32_t x = MASKED ? count_valid<SLOTS>(vbits) : A.n_ind;
     const double inv_x = MASKED ? 1.0 / (double)x : A.inv_n;
-    sxy = wave_sum1(sxy);
+    sxy = fma(-n_mean1, mean2, wave_sum1_bcast(sxy));  // centred: sum e1 e2 - n mean1 mean2
     double f0, f1, f2, f3;
     const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, inv_x, m1, m2, f0, f1, f2, f3,
                                                       (double (*)[1][4]) nullptr, 0, lane, A.status);
