@@ -224,12 +224,15 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // Stage both sites of one pair: P = a (x) b for this lane's SLOTS individuals, their validity bits and the
 // Pearson cross moment.  pa / pb point at a site's three planes [3][np] -- in HBM/L2 (direct kernel) or in
 // LDS (prefetch kernel); after inlining the compiler knows which and emits global_load or ds_read.
-//   CROSS_FROM_P: sxy comes back as the UNCENTRED cross moment sum e1 e2 = sum (P4 + 2 (P5 + P7) + 4 P8) -- padding lanes hold
-//   P == 0, so no bounds test -- and the caller subtracts n * mean1 * mean2 once per pair
-template <int SLOTS, bool MASKED, bool ONLY_LAST = false, bool CROSS_FROM_P = false>  // ONLY_LAST: only the last slot can hold padding lanes
+//   UNCENTRED: sxy comes back as the uncentred cross moment sum e1 e2 -- padding lanes hold a == b == 0, so no bounds
+//   test -- and the caller subtracts n * mean1 * mean2 once per pair
+//   pads (MASKED only, may be null): P of an individual WITHOUT data is zeroed and pads[j] = 1 there (0 elsewhere), so
+//   that em_pair can run its one-reciprocal-per-lane step over all slots: such an individual's s is exactly 1 and it
+//   adds nothing to R (the same device that neutralises the padding lanes of the last slot)
+template <int SLOTS, bool MASKED, bool ONLY_LAST = false, bool UNCENTRED = false>  // ONLY_LAST: only the last slot can hold padding lanes
 __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint32_t ia0, const double *pb, uint32_t npb,
                                            uint32_t ib0, uint32_t ind0, uint32_t n_ind, double mean1, double mean2,
-                                           double (&P)[SLOTS][9], uint32_t &vbits, double &sxy) {
+                                           double (&P)[SLOTS][9], uint32_t &vbits, double &sxy, double *pads = nullptr) {
   // pa[g * npa + ia0 + 64 j] / pb[g * npb + ib0 + 64 j] hold genotype g of individual ind0 + 64 j (this lane, slot j)
   vbits = 0;
   sxy = 0.0;
@@ -242,12 +245,20 @@ __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint3
     bool ok = inb;
     if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);  // gen_func.cpp:1089
     vbits |= (ok ? 1u : 0u) << j;
-    P[j][0] = a0 * b0; P[j][1] = a0 * b1; P[j][2] = a0 * b2;
-    P[j][3] = a1 * b0; P[j][4] = a1 * b1; P[j][5] = a1 * b2;
-    P[j][6] = a2 * b0; P[j][7] = a2 * b1; P[j][8] = a2 * b2;
+    double z0 = a0, z1 = a1, z2 = a2;
+    if (MASKED && pads != nullptr) {
+      const double keep = ok ? 1.0 : 0.0;
+      z0 = a0 * keep; z1 = a1 * keep; z2 = a2 * keep;
+      pads[j] = 1.0 - keep;
+    }
+    P[j][0] = z0 * b0; P[j][1] = z0 * b1; P[j][2] = z0 * b2;
+    P[j][3] = z1 * b0; P[j][4] = z1 * b1; P[j][5] = z1 * b2;
+    P[j][6] = z2 * b0; P[j][7] = z2 * b1; P[j][8] = z2 * b2;
     // expected genotypes p1 + 2*p2 (ngsLD.cpp:113); pearson_r runs over ALL individuals (ngsLD.cpp:290)
-    if (CROSS_FROM_P) {  // (a1 + 2 a2)(b1 + 2 b2) = P4 + 2 P5 + 2 P7 + 4 P8
+    if (UNCENTRED && !MASKED) {  // (a1 + 2 a2)(b1 + 2 b2) = P4 + 2 P5 + 2 P7 + 4 P8 (measured 0.3 % faster than from a, b)
       sxy += fma(4.0, P[j][8], fma(2.0, P[j][5] + P[j][7], P[j][4]));
+    } else if (UNCENTRED) {      // P of individuals without data is zeroed: take the moment from a and b
+      sxy = fma(fma(2.0, a2, a1), fma(2.0, b2, b1), sxy);
     } else {
       const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;
       const double c2 = inb ? fma(2.0, b2, b1) - mean2 : 0.0;
@@ -270,10 +281,13 @@ __device__ __forceinline__ uint32_t count_valid(uint32_t vbits) {
 //   WAVES > 1: the pair is spread over WAVES wavefronts, partial sums meet in xch (LDS, double buffered)
 //   TREE_DYN:  CHECK_ALL kernels without --ignore_miss_data (several wavefronts per pair): a wavefront whose lanes are
 //              all full up to the last slot -- every one but the pair's last -- still takes the one-reciprocal path
+//   pads:      (CHECK_ALL, one wavefront per pair) per-slot 0 / 1 from stage_pair: individuals without data have P == 0 and
+//              pad 1, so the one-reciprocal step runs over all slots although any of them may be empty
 template <int SLOTS, int WAVES, bool CHECK_ALL, bool TREE_DYN = false>
 __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_t vbits, double inv_x, double m1,
                                             double m2, double &f0, double &f1, double &f2, double &f3,
-                                            double (*xch)[WAVES][4], int sub, int lane, int *status) {
+                                            double (*xch)[WAVES][4], int sub, int lane, int *status,
+                                            const double *pads = nullptr) {
   f0 = (1 - m1) * (1 - m2); f1 = (1 - m1) * m2; f2 = m1 * (1 - m2); f3 = m1 * m2;  // gen_func.cpp:1034-1037
   if (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1) {  // error() in the reference (:1030); reported through status
     if (lane == 0 && sub == 0) atomicExch(status, (int)NGSLD_ERR_MAF_RANGE);
@@ -297,13 +311,14 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   // product nor add anything to R.  The product of SLOTS values underflows sooner than a pair's (all below ~1e-38 for
   // eight slots); the same redo-with-single-reciprocals rule covers it.
   constexpr int kPaired = CHECK_ALL ? 0 : (SLOTS - 1) / 2;
-  constexpr bool kTree = kTreeRcp && (!CHECK_ALL || TREE_DYN) && SLOTS > 1;
+  const bool mask_tree = CHECK_ALL && !TREE_DYN && WAVES == 1 && pads != nullptr;  // compile-time after inlining
+  constexpr bool kTree = kTreeRcp && (!CHECK_ALL || TREE_DYN || WAVES == 1) && SLOTS > 1;
   const double pad = ((vbits >> (SLOTS - 1)) & 1u) ? 0.0 : 1.0;
   constexpr bool kScaled = kDrop0 && WAVES == 1;  // (several wavefronts per pair: partial sums are scaled after they met)
   bool tree_ok = true;  // wavefront-uniform
-  if (CHECK_ALL && kTree) {
+  if (CHECK_ALL && kTree && !mask_tree) {
     constexpr uint32_t kNeed = (1u << (SLOTS - 1)) - 1u;  // padding (P == 0, no missing data here) in the last slot only
-    tree_ok = !__builtin_amdgcn_ballot_w64((vbits & kNeed) != kNeed);
+    tree_ok = TREE_DYN ? !__builtin_amdgcn_ballot_w64((vbits & kNeed) != kNeed) : false;
   }
   auto em_step = [&](auto paired_tag, double &n0, double &n1, double &n2, double &n3) {
     constexpr bool kPair = decltype(paired_tag)::value;
@@ -314,7 +329,8 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
     double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
     auto slot_s = [&](int j, bool padded = false) -> double {
-      double s = padded ? fma(p00, P[j][0], pad) : p00 * P[j][0];  // padded: see kTree above (pad = 1 where P == 0)
+      // padded: see kTree above (pad = 1 where P == 0); mask_tree: every slot has its own pad
+      double s = padded ? fma(p00, P[j][0], mask_tree ? pads[j] : pad) : p00 * P[j][0];
       s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
       s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
       s = fma(p22, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(p33, P[j][8], s);
@@ -330,7 +346,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     if constexpr (kPair && kTree) {
       double sv[SLOTS], rv[SLOTS];
 #pragma unroll
-      for (int j = 0; j < SLOTS; ++j) sv[j] = slot_s(j, j == SLOTS - 1);
+      for (int j = 0; j < SLOTS; ++j) sv[j] = slot_s(j, mask_tree || j == SLOTS - 1);
       // kScaled: 1/x rides on the root inverse, so every R -- and with them the three t_k -- come out divided by x
       double inv = rcp_refined(RcpTree<SLOTS>::prod(sv));
       if (kScaled) inv *= inv_x;
@@ -393,7 +409,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     // (one NaN reciprocal poisons EVERY R -- fma(P, NaN, R) -- so with kDrop0 any one accumulated frequency tells)
     double sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);
     if (__builtin_amdgcn_ballot_w64(!(sn < 2.0))) {  // wave-uniform values: the ballot is all-or-nothing
-      if ((kPaired > 0 || kTree) && kPairRcp) {  // rule out an underflowed reciprocal product before concluding anything
+      if ((kPaired > 0 || kTree) && kPairRcp && tree_ok) {  // rule out an underflowed reciprocal product before concluding anything
         if (WAVES > 1) lds_barrier();  // sn is the same in every wavefront: all redo, none still reads the exchange buffer
         em_step(SingleTag(), n0, n1, n2, n3);
         sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);
@@ -701,9 +717,10 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
     double P[SLOTS][9];
     uint32_t vbits;
     double sxy;
+    double pads[SLOTS];  // --ignore_miss_data: 1 where the individual has no data at either site
     stage_pair<SLOTS, MASKED, !MASKED, true>(reinterpret_cast<const double *>(lds_a), kNp, (uint32_t)lane,
                                              reinterpret_cast<const double *>(lds_b), kNp, (uint32_t)lane, (uint32_t)lane,
-                                             A.n_ind, mean1, cur.mean, P, vbits, sxy);
+                                             A.n_ind, mean1, cur.mean, P, vbits, sxy, MASKED ? pads : nullptr);
     // all ds_reads of the buffer are consumed (P is computed): start the copy of the next site over it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (cn < it.count)
@@ -714,7 +731,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
     sxy = fma(-(double)A.n_ind * mean1, cur.mean, wave_sum1_bcast(sxy));  // centred: sum e1 e2 - n mean1 mean2 (as the run kernel)
     double f0, f1, f2, f3;
     const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, inv_x, m1, cur.maf, f0, f1, f2, f3,
-                                                      (double (*)[1][4]) nullptr, 0, lane, A.status);
+                                                      (double (*)[1][4]) nullptr, 0, lane, A.status, MASKED ? pads : nullptr);
     if (lane == 0) {
       PairResult &r = res[c];
       r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;
@@ -862,9 +879,10 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
     double P[SLOTS][9];
     uint32_t vbits;
     double sxy;
+    double pads[SLOTS];  // --ignore_miss_data: 1 where the individual has no data at either site
     stage_pair<SLOTS, MASKED, !MASKED, true>(reinterpret_cast<const double *>(lds_a), kNp, (uint32_t)lane,
                                              reinterpret_cast<const double *>(lds_b), kNp, (uint32_t)lane, (uint32_t)lane,
-                                             A.n_ind, mean1, mean2, P, vbits, sxy);
+                                             A.n_ind, mean1, mean2, P, vbits, sxy, MASKED ? pads : nullptr);
     // all ds_reads of the buffer are consumed (P is computed): start the copy of the next site over it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (nxt.ok) dma_site(nxt.s2);
@@ -873,7 +891,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
     sxy = fma(-n_mean1, mean2, wave_sum1_bcast(sxy));  // centred: sum e1 e2 - n mean1 mean2
     double f0, f1, f2, f3;
     const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, inv_x, m1, m2, f0, f1, f2, f3,
-                                                      (double (*)[1][4]) nullptr, 0, lane, A.status);
+                                                      (double (*)[1][4]) nullptr, 0, lane, A.status, MASKED ? pads : nullptr);
     if (lane == 0) {
       RunResult &r = ring[held];
       r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;
