@@ -1033,6 +1033,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
 
     // ---- stage: P = a (x) b per lane, validity, Pearson cross moment (group sums) ----
     double P[SLOTS][9];
+    double pads[MASKED ? SLOTS : 1];
     uint32_t vbits = 0;
     double sxy = 0.0;
     const double *la = reinterpret_cast<const double *>(lds_a);
@@ -1047,9 +1048,15 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       bool ok = inb && active;
       if (MASKED) ok = ok && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);  // gen_func.cpp:1089
       vbits |= (ok ? 1u : 0u) << j;
-      P[j][0] = a0 * b0; P[j][1] = a0 * b1; P[j][2] = a0 * b2;
-      P[j][3] = a1 * b0; P[j][4] = a1 * b1; P[j][5] = a1 * b2;
-      P[j][6] = a2 * b0; P[j][7] = a2 * b1; P[j][8] = a2 * b2;
+      double z0 = a0, z1 = a1, z2 = a2;
+      if (MASKED) {  // an individual without data: P = 0 and pad 1, so the one-reciprocal step can run over all slots
+        const double keep = ok ? 1.0 : 0.0;
+        z0 = a0 * keep; z1 = a1 * keep; z2 = a2 * keep;
+        pads[j] = 1.0 - keep;
+      }
+      P[j][0] = z0 * b0; P[j][1] = z0 * b1; P[j][2] = z0 * b2;
+      P[j][3] = z1 * b0; P[j][4] = z1 * b1; P[j][5] = z1 * b2;
+      P[j][6] = z2 * b0; P[j][7] = z2 * b1; P[j][8] = z2 * b2;
       const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;   // ngsLD.cpp:113, :290
       const double c2 = inb ? fma(2.0, b2, b1) - mean2 : 0.0;
       sxy = fma(c1, c2, sxy);
@@ -1071,7 +1078,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
     const double inv_x = 1.0 / (double)x;
     const double keep0 = f0 == 0.0 ? 0.0 : 1.0;  // an exact zero stays exact (see em_pair)
     // one reciprocal per lane and iteration (RcpTree) when only the last slot can hold padding, see em_pair
-    constexpr bool kTree = kTreeRcp && !MASKED && SLOTS > 1;
+    constexpr bool kTree = kTreeRcp && SLOTS > 1;
     const double pad = ((vbits >> (SLOTS - 1)) & 1u) ? 0.0 : 1.0;
     auto em_step = [&](auto tree_tag, double &n0, double &n1, double &n2, double &n3) {
       constexpr bool kT = decltype(tree_tag)::value;
@@ -1079,8 +1086,8 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
       const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
       double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
-      auto slot_s = [&](int j) -> double {
-        double s = p00 * P[j][0];
+      auto slot_s = [&](int j, bool padded = false) -> double {
+        double s = padded ? fma(p00, P[j][0], MASKED ? pads[MASKED ? j : 0] : pad) : p00 * P[j][0];
         s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
         s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
         s = fma(p22, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(p33, P[j][8], s);
@@ -1095,8 +1102,8 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       if constexpr (kT) {
         double sv[SLOTS], rv[SLOTS];
 #pragma unroll
-        for (int j = 0; j < SLOTS; ++j) sv[j] = slot_s(j);
-        sv[SLOTS - 1] += pad;
+        for (int j = 0; j < SLOTS; ++j) sv[j] = slot_s(j, MASKED);
+        if (!MASKED) sv[SLOTS - 1] += pad;  // (kept as a separate add here: folding it into the first FMA costs registers)
         RcpTree<SLOTS>::down(sv, rcp_refined(RcpTree<SLOTS>::prod(sv)), rv);
 #pragma unroll
         for (int j = 0; j < SLOTS; ++j) slot_acc(j, rv[j]);
