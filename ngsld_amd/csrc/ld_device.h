@@ -29,6 +29,12 @@ namespace ngsld {
 #define NGSLD_DROP0 1     // build-time A/B switch: 1 = hap_freq[0] is recovered from sum_k f_k = 1 instead of being accumulated
 #endif
 constexpr bool kDrop0 = NGSLD_DROP0 != 0;
+#ifndef NGSLD_PRIO_S  // issue priority per stretch of an EM iteration (swept on the bench: differences of +-0.5 %)
+#define NGSLD_PRIO_S 0
+#define NGSLD_PRIO_TREE 3
+#define NGSLD_PRIO_R 1
+#define NGSLD_PRIO_SERIAL 3
+#endif
 #ifndef NGSLD_SETPRIO
 #define NGSLD_SETPRIO 1  // build-time A/B switch: issue priority raised through the serial phases of an EM iteration
 #endif
@@ -331,7 +337,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
     const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
     double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
-    if (NGSLD_SETPRIO && kPair && kTree) __builtin_amdgcn_s_setprio(0);  // the dense s sums start here
+    if (NGSLD_SETPRIO && kPair && kTree) __builtin_amdgcn_s_setprio(NGSLD_PRIO_S);  // the dense s sums start here
     auto slot_s = [&](int j, bool padded = false) -> double {
       // padded: see kTree above (pad = 1 where P == 0); mask_tree: every slot has its own pad
       double s = padded ? fma(p00, P[j][0], mask_tree ? pads[j] : pad) : p00 * P[j][0];
@@ -355,15 +361,15 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
       // reduction, convergence test and the next f products) has one instruction ready at a time and every cycle it
       // waits for the issue slot lengthens its critical path; the one inside a dense stretch (the s and R sums) has
       // dozens ready.  Priority goes to the former.
-      if (NGSLD_SETPRIO) __builtin_amdgcn_s_setprio(3);
+      if (NGSLD_SETPRIO) __builtin_amdgcn_s_setprio(NGSLD_PRIO_TREE);
       // kScaled: 1/x rides on the root inverse, so every R -- and with them the three t_k -- come out divided by x
       double inv = rcp_refined(RcpTree<SLOTS>::prod(sv));
       if (kScaled) inv *= inv_x;
       RcpTree<SLOTS>::down(sv, inv, rv);
-      if (NGSLD_SETPRIO) __builtin_amdgcn_s_setprio(0);
+      if (NGSLD_SETPRIO) __builtin_amdgcn_s_setprio(NGSLD_PRIO_R);
 #pragma unroll
       for (int j = 0; j < SLOTS; ++j) slot_acc(j, rv[j]);
-      if (NGSLD_SETPRIO) __builtin_amdgcn_s_setprio(3);
+      if (NGSLD_SETPRIO) __builtin_amdgcn_s_setprio(NGSLD_PRIO_SERIAL);
     }
 #pragma unroll
     for (int q = 0; q < (kPair && !kTree ? kPaired : 0); ++q) {
