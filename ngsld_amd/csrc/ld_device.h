@@ -414,31 +414,50 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     // four.  keep0 = 0 keeps an exact zero exact (f0 = 0 is a fixed point of the reference's step: tmp_0 = f0 * ...).
     n0 = kDrop0 ? fma(-keep0, (n1 + n2) + n3, keep0) : t0 * inv_x;
   };
-  for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
+  // Any individual with s == 0 makes every tmp/sum NaN in the reference, hence all four f NaN and, as a
+  // NaN difference never raises eps (gen_func.cpp:1049-1053), "convergence" at this iteration.  Here
+  // s == 0 poisons every R with inf/NaN, so a sum that is not a sane ~1 <=> the reference is all NaN.
+  // (one NaN reciprocal poisons EVERY R -- fma(P, NaN, R) -- so with kDrop0 any one accumulated frequency tells)
+  // The hot loop holds the one-reciprocal step and nothing else: a step that does not look sane leaves it, is redone
+  // with one reciprocal per individual (an underflowed product has to be ruled out before anything is concluded), and
+  // the loop is entered again -- with a single definition of the new frequencies per trip the compiler carries them
+  // from one iteration to the next without register copies.
+  constexpr bool kFast = (kPaired > 0 || kTree) && kPairRcp;
+  bool done = false;
+  while (!done && n_iter < (uint32_t)kIterMax) {
+    bool odd_step = false;
+    if (kFast && tree_ok) {
+      for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
+        double n0, n1, n2, n3;
+        em_step(PairedTag(), n0, n1, n2, n3);
+        const double sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);
+        if (__builtin_amdgcn_ballot_w64(!(sn < 2.0))) {  // wave-uniform values: the ballot is all-or-nothing
+          odd_step = true;
+          break;
+        }
+        const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
+        f0 = n0; f1 = n1; f2 = n2; f3 = n3;
+        if (__builtin_amdgcn_ballot_w64(eps < kEpsilon)) {  // gen_func.cpp:1054-1055
+          done = true;
+          break;
+        }
+      }
+      if (!odd_step) break;  // converged, or ITER_MAX iterations done
+      if (WAVES > 1) lds_barrier();  // sn is the same in every wavefront: all redo, none still reads the exchange buffer
+    }
+    // one iteration with one reciprocal per individual: the kernels' only path where any slot may be empty, the
+    // second opinion on an odd step elsewhere
     double n0, n1, n2, n3;
-    if ((kPaired > 0 || kTree) && kPairRcp && tree_ok)
-      em_step(PairedTag(), n0, n1, n2, n3);
-    else
-      em_step(SingleTag(), n0, n1, n2, n3);
-    // Any individual with s == 0 makes every tmp/sum NaN in the reference, hence all four f NaN and, as a
-    // NaN difference never raises eps (gen_func.cpp:1049-1053), "convergence" at this iteration.  Here
-    // s == 0 poisons every R with inf/NaN, so a sum that is not a sane ~1 <=> the reference is all NaN.
-    // (one NaN reciprocal poisons EVERY R -- fma(P, NaN, R) -- so with kDrop0 any one accumulated frequency tells)
-    double sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);
-    if (__builtin_amdgcn_ballot_w64(!(sn < 2.0))) {  // wave-uniform values: the ballot is all-or-nothing
-      if ((kPaired > 0 || kTree) && kPairRcp && tree_ok) {  // rule out an underflowed reciprocal product before concluding anything
-        if (WAVES > 1) lds_barrier();  // sn is the same in every wavefront: all redo, none still reads the exchange buffer
-        em_step(SingleTag(), n0, n1, n2, n3);
-        sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);
-      }
-      if (__builtin_amdgcn_ballot_w64(!(sn < 2.0))) {
-        bad = true;
-        break;
-      }
+    em_step(SingleTag(), n0, n1, n2, n3);
+    const double sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);
+    if (__builtin_amdgcn_ballot_w64(!(sn < 2.0))) {
+      bad = true;
+      break;
     }
     const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
     f0 = n0; f1 = n1; f2 = n2; f3 = n3;
-    if (__builtin_amdgcn_ballot_w64(eps < kEpsilon)) break;  // gen_func.cpp:1054-1055
+    if (__builtin_amdgcn_ballot_w64(eps < kEpsilon)) break;
+    ++n_iter;
   }
   if (bad) f0 = f1 = f2 = f3 = __builtin_nan("");
   return n_iter;
