@@ -1168,17 +1168,35 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
     };
     bool done = !active;
     uint32_t n_iter = (uint32_t)kIterMax;
-    for (uint32_t itn = 0; itn < (uint32_t)kIterMax; ++itn) {
-      double n0, n1, n2, n3;
-      if (kTree)
-        em_step(PairedTag(), n0, n1, n2, n3);
-      else
-        em_step(SingleTag(), n0, n1, n2, n3);
-      double sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);  // one NaN reciprocal poisons every R (see em_pair)
-      if (kTree && __any(!done && !(sn < 2.0))) {  // a live group's step is not sane: rule out an underflowed product
-        em_step(SingleTag(), n0, n1, n2, n3);
-        sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);
+    // As in em_pair the hot loop holds the one-reciprocal step only; a step that is not sane in some live group leaves it
+    // for one iteration with a reciprocal per individual (an underflowed product has to be ruled out first).
+    uint32_t itn = 0;
+    while (itn < (uint32_t)kIterMax) {
+      if (kTree) {
+        bool odd_step = false;
+        for (; itn < (uint32_t)kIterMax; ++itn) {
+          double n0, n1, n2, n3;
+          em_step(PairedTag(), n0, n1, n2, n3);
+          const double sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);  // one NaN reciprocal poisons every R (see em_pair)
+          if (__any(!done && !(sn < 2.0))) {
+            odd_step = true;
+            break;
+          }
+          const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
+          if (!done) {
+            f0 = n0; f1 = n1; f2 = n2; f3 = n3;
+            if (eps < kEpsilon) {  // gen_func.cpp:1054-1055
+              done = true;
+              n_iter = itn;
+            }
+          }
+          if (__all(done)) break;
+        }
+        if (!odd_step) break;
       }
+      double n0, n1, n2, n3;
+      em_step(SingleTag(), n0, n1, n2, n3);
+      const double sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);
       const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
       if (!done) {
         if (!(sn < 2.0)) {  // the reference's all-NaN step: "converges" at this iteration (see em_pair)
@@ -1187,13 +1205,14 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
           n_iter = itn;
         } else {
           f0 = n0; f1 = n1; f2 = n2; f3 = n3;
-          if (eps < kEpsilon) {  // gen_func.cpp:1054-1055
+          if (eps < kEpsilon) {
             done = true;
             n_iter = itn;
           }
         }
       }
       if (__all(done)) break;
+      ++itn;
     }
 
     if (gl == 0) {  // one ring entry per group and generation; a group without a pair leaves a hole
