@@ -320,8 +320,8 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   // product nor add anything to R.  The product of SLOTS values underflows sooner than a pair's (all below ~1e-38 for
   // eight slots); the same redo-with-single-reciprocals rule covers it.
   constexpr int kPaired = CHECK_ALL ? 0 : (SLOTS - 1) / 2;
-  const bool mask_tree = CHECK_ALL && !TREE_DYN && WAVES == 1 && pads != nullptr;  // compile-time after inlining
-  constexpr bool kTree = kTreeRcp && (!CHECK_ALL || TREE_DYN || WAVES == 1) && SLOTS > 1;
+  const bool mask_tree = CHECK_ALL && !TREE_DYN && pads != nullptr;  // compile-time after inlining
+  constexpr bool kTree = kTreeRcp && SLOTS > 1;
   const double pad = ((vbits >> (SLOTS - 1)) & 1u) ? 0.0 : 1.0;
   constexpr bool kScaled = kDrop0 && WAVES == 1;  // (several wavefronts per pair: partial sums are scaled after they met)
   bool tree_ok = true;  // wavefront-uniform
@@ -588,15 +588,16 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
     double P[SLOTS][9];
     uint32_t vbits;
     double sxy;
+    double pads[SLOTS];  // --ignore_miss_data: 1 where the individual has no data at either site (see stage_pair)
     if (PFB) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice copied during the previous pair has landed
       stage_pair<SLOTS, MASKED>(pa, A.np, i0, reinterpret_cast<const double *>(lds_b), (uint32_t)(SLOTS * 64),
-                                (uint32_t)lane, i0, A.n_ind, mean1, mean2, P, vbits, sxy);
+                                (uint32_t)lane, i0, A.n_ind, mean1, mean2, P, vbits, sxy, MASKED ? pads : nullptr);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // a, b and the scalars are all consumed
       if (cn < it.count) dma_slice(it.s2_begin + cn);
     } else {
       stage_pair<SLOTS, MASKED>(pa, A.np, i0, A.planes + (uint64_t)s2 * A.site_stride, A.np, i0, i0, A.n_ind, mean1,
-                                mean2, P, vbits, sxy);
+                                mean2, P, vbits, sxy, MASKED ? pads : nullptr);
     }
     uint32_t x = count_valid<SLOTS>(vbits);
     sxy = wave_sum1(sxy);
@@ -617,7 +618,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
     }
     double f0, f1, f2, f3;
     const uint32_t n_iter = em_pair<SLOTS, WAVES, kCheckAll, (WAVES > 1 && !MASKED)>(P, vbits, 1.0 / (double)x, m1, m2, f0, f1, f2, f3, xch, sub,
-                                                             lane, A.status);
+                                                             lane, A.status, MASKED ? pads : nullptr);
     if (WAVES == 1) {
       if (lane == 0)
         write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, rsx2, x, n_iter);
