@@ -11,6 +11,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -111,6 +112,29 @@ inline char *put_fixed(char *p, double v) {
   }
   return p + 6;
 }
+
+// malloc'd, never zero-filled, grown with the first `keep` bytes preserved
+struct RawBuf {
+  char *p = nullptr;
+  size_t cap = 0;
+  RawBuf() = default;
+  RawBuf(const RawBuf &) = delete;
+  RawBuf &operator=(const RawBuf &) = delete;
+  RawBuf(RawBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+  ~RawBuf() { std::free(p); }
+  char *data() const { return p; }
+  size_t size() const { return cap; }
+  bool reserve(size_t n, size_t keep) {
+    if (n <= cap) return true;
+    char *q = (char *)std::malloc(n);
+    if (q == nullptr) return false;
+    if (keep) std::memcpy(q, p, keep);
+    std::free(p);
+    p = q;
+    cap = n;
+    return true;
+  }
+};
 
 inline char *put_str(char *p, const char *s) {
   const size_t n = std::strlen(s);
@@ -469,14 +493,24 @@ int ngsld_host_write_batch(const ngsld_batch *b, const ngsld_pos *pos, const dou
     }
     cut[t] = lo;
   }
-  std::vector<std::vector<char>> out(n_threads);
+  // The threads' text buffers live across calls (a batch is ~1-2 GB of text: allocating, zero-filling and page-faulting
+  // that afresh for every batch cost more than the formatting itself); they are plain malloc'd memory, grown on demand.
+  static std::mutex cache_mutex;
+  static std::vector<RawBuf> cache;
+  std::lock_guard<std::mutex> cache_lock(cache_mutex);
+  if (cache.size() < (size_t)n_threads) cache.resize((size_t)n_threads);
+  std::vector<size_t> out_len((size_t)n_threads, 0);
+  std::vector<int> out_err((size_t)n_threads, 0);
   auto work = [&](int t) {
     const uint64_t i0 = cut[t], i1 = cut[t + 1];
     if (i0 >= i1) return;
     const uint64_t rec_end = i1 < b->n_items ? b->items[i1].first_record : b->n_pairs;
     const uint64_t np = rec_end - b->items[i0].first_record;
-    std::vector<char> &buf = out[t];
-    buf.resize(np * (b->ext ? 200 : 96) + np * 2 * max_label + row_bytes);
+    RawBuf &buf = cache[(size_t)t];
+    if (!buf.reserve(np * (b->ext ? 200 : 96) + np * 2 * max_label + row_bytes, 0)) {
+      out_err[(size_t)t] = 1;
+      return;
+    }
     char *p = buf.data();
     uint64_t cur_s1 = UINT64_MAX, cur_s2 = 0;
     double dist = 0;
@@ -499,7 +533,10 @@ int ngsld_host_write_batch(const ngsld_batch *b, const ngsld_pos *pos, const dou
         if (!((it.mask >> cc) & 1ull)) continue;
         if ((size_t)(buf.data() + buf.size() - p) < row_bytes) {  // extreme values printed long: grow
           const size_t used = (size_t)(p - buf.data());
-          buf.resize(buf.size() * 2 + row_bytes);
+          if (!buf.reserve(buf.size() * 2 + row_bytes, used)) {
+            out_err[(size_t)t] = 1;
+            return;
+          }
           p = buf.data() + used;
         }
         p = format_row(p, l1, pos ? pos->labels[s2].c_str() : nullptr, dist, &b->std[k], b->ext ? &b->ext[k] : nullptr,
@@ -507,15 +544,17 @@ int ngsld_host_write_batch(const ngsld_batch *b, const ngsld_pos *pos, const dou
         ++k;
       }
     }
-    buf.resize((size_t)(p - buf.data()));
+    out_len[(size_t)t] = (size_t)(p - buf.data());
   };
   std::vector<std::thread> th;
   for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
   work(0);
   for (auto &x : th) x.join();
+  for (int t = 0; t < n_threads; ++t)
+    if (out_err[(size_t)t]) return NGSLD_ERR_NOMEM;
   for (int t = 0; t < n_threads; ++t) {
-    const char *q = out[t].data();
-    size_t left = out[t].size();
+    const char *q = cache[(size_t)t].data();
+    size_t left = out_len[(size_t)t];
     while (left) {
       const ssize_t w = ::write(fd, q, left);
       if (w <= 0) return NGSLD_ERR_INVALID;
