@@ -92,6 +92,12 @@ typedef struct {
   const ngsld_item *items;   /* [n_items] */
   const ngsld_rec_std *std;  /* [n_pairs] */
   const ngsld_rec_ext *ext;  /* [n_pairs] or NULL when extend_out == 0 */
+  /* Only after ngsld_set_text_output(..., 1): the batch's TSV rows, formatted on the device -- byte for byte what
+   * ngsld_host_write_batch writes for this batch (ngsLD.cpp:314-351).  When text != NULL, items / std / ext are NULL
+   * (the records were not copied to the host).  A batch the device formatter cannot take (a value beyond its
+   * fast path) arrives as records, text == NULL, as without text output. */
+  const char *text;
+  uint64_t text_len;
 } ngsld_batch;
 
 typedef int (*ngsld_sink_fn)(void *user, const ngsld_batch *batch);
@@ -147,6 +153,13 @@ int ngsld_plan_rows(ngsld_ctx *ctx, const uint64_t **row_off, const uint32_t **r
 
 /* Compute every pair of rows [s1_begin, s1_end) and hand the records to `sink`, batch by batch. */
 int ngsld_run(ngsld_ctx *ctx, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user);
+
+/* Device-side TSV for ngsld_run (replaces the fprintf block of calc_pair_LD, ngsLD.cpp:310-352, at kernel rates):
+ * labels = n_sites C strings as they appear in the first two columns (ngsLD.cpp:127-132), or NULL for the
+ * reference's no --pos output "(null)".  enable != 0: ngsld_run hands over text (ngsld_batch.text) instead of records.
+ * Call after ngsld_set_geno_* (the labels belong to that matrix); the dist column comes from ngsld_set_pos_dist and
+ * needs its finite gaps to be integers (as read_dist produces them), otherwise batches arrive as records. */
+int ngsld_set_text_output(ngsld_ctx *ctx, const char *const *labels, int enable);
 
 /* Same computation with the records left in caller-owned DEVICE memory (no host transfer):
  * d_std holds ngsld_rec_std[n], d_ext ngsld_rec_ext[n] (may be NULL), n = row_off[s1_end] -

@@ -41,7 +41,8 @@ ITEM = np.dtype([("s1", "<u4"), ("s2_begin", "<u4"), ("count", "<u4"), ("reserve
 
 class Batch(C.Structure):
     _fields_ = [("s1_begin", C.c_uint64), ("s1_end", C.c_uint64), ("n_pairs", C.c_uint64), ("n_items", C.c_uint64),
-                ("items", C.c_void_p), ("std", C.c_void_p), ("ext", C.c_void_p)]
+                ("items", C.c_void_p), ("std", C.c_void_p), ("ext", C.c_void_p), ("text", C.c_void_p),
+                ("text_len", C.c_uint64)]
 
 
 def items_to_pairs(items: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
@@ -79,7 +80,7 @@ SLAB = np.dtype([("row_begin", "<u8"), ("row_end", "<u8"), ("site_end", "<u8")])
 SYMBOLS = [
     "ngsld_version", "ngsld_create", "ngsld_destroy", "ngsld_last_error", "ngsld_set_geno_raw",
     "ngsld_set_geno_raw_opts", "ngsld_set_geno_lkl",
-    "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device",
+    "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device", "ngsld_set_text_output",
     "ngsld_last_kernel_time", "ngsld_set_tuning", "ngsld_selftest",
     "ngsld_window_ends", "ngsld_plan_slabs", "ngsld_slab_sites_for_budget", "ngsld_device_memory", "ngsld_run_streamed",
     "ngsld_host_read_geno_bin_range",
@@ -130,6 +131,7 @@ def lib() -> C.CDLL:
         L.ngsld_plan_rows.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint32))]
         L.ngsld_run.argtypes = [vp, u64, u64, SINK_FN, vp]
         L.ngsld_run_device.argtypes = [vp, u64, u64, vp, vp, vp]
+        L.ngsld_set_text_output.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int]
         L.ngsld_last_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
         L.ngsld_set_tuning.argtypes = [vp, C.c_uint32, u64]
         L.ngsld_selftest.argtypes = [vp]
@@ -462,6 +464,30 @@ class Engine:
 
         self._check(self._L.ngsld_run(self._h, s1_begin, s1_end, SINK_FN(sink), None))
         return total[0]
+
+    def set_text_output(self, labels: list[str] | None, enable: bool = True) -> None:
+        """Device-side TSV: ngsld_run then hands over text instead of records (labels None = "(null)")."""
+        arr = None
+        if labels is not None:
+            arr = (C.c_char_p * len(labels))(*[l.encode() for l in labels])
+        self._check(self._L.ngsld_set_text_output(self._h, arr, int(enable)))
+
+    def run_text(self, s1_begin: int = 0, s1_end: int | None = None) -> tuple[bytes, int]:
+        """Run through the sink path with device-side TSV on; returns (text of all batches, batches that arrived
+        as records instead)."""
+        s1_end = self.n_sites if s1_end is None else s1_end
+        parts, fallbacks = [], [0]
+
+        def sink(_user, bp):
+            b = bp.contents
+            if b.text:
+                parts.append(C.string_at(b.text, b.text_len))
+            else:
+                fallbacks[0] += 1
+            return 0
+
+        self._check(self._L.ngsld_run(self._h, s1_begin, s1_end, SINK_FN(sink), None))
+        return b"".join(parts), fallbacks[0]
 
     def run_discard(self, s1_begin: int = 0, s1_end: int | None = None) -> int:
         """Run through the sink path (kernel + D2H of every record into pinned host memory) and only count the

@@ -8,6 +8,7 @@
 //     caps the device memory: a windowed run on binary input that does not fit is streamed slab by slab;
 #include <getopt.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdio>
@@ -156,8 +157,20 @@ int write_batch(void *user, const ngsld_batch *b) {
   SinkState *st = static_cast<SinkState *>(user);
   const auto t0 = std::chrono::steady_clock::now();
   fflush(st->pars->out_fh);
-  const int rc = ngsld_host_write_batch(b, st->pos, st->pos_dist, st->maf->data(), (int)st->pars->n_threads,
-                                        fileno(st->pars->out_fh)) == NGSLD_OK ? 0 : 1;
+  int rc = 0;
+  if (b->text != nullptr) {  // rows formatted on the device (ngsld_set_text_output): only bytes to write
+    const char *q = b->text;
+    uint64_t left = b->text_len;
+    const int fd = fileno(st->pars->out_fh);
+    while (left && rc == 0) {
+      const ssize_t w = ::write(fd, q, left > (1ull << 30) ? (size_t)(1ull << 30) : (size_t)left);
+      if (w <= 0) rc = 1;
+      else { q += w; left -= (uint64_t)w; }
+    }
+  } else {
+    rc = ngsld_host_write_batch(b, st->pos, st->pos_dist, st->maf->data(), (int)st->pars->n_threads,
+                                fileno(st->pars->out_fh)) == NGSLD_OK ? 0 : 1;
+  }
   g_sink_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   ++g_sink_batches;
   return rc;
@@ -372,6 +385,18 @@ int main(int argc, char **argv) {
   lp.first_row = 0;
   uint64_t n_pairs = 0;
   if (ngsld_plan(ctx, &lp, &n_pairs) != NGSLD_OK) error("ngsld_plan", ngsld_last_error(ctx));
+  // The rows are formatted on the device (the fprintf block of calc_pair_LD, ngsLD.cpp:310-352, at kernel rates); a
+  // batch the device formatter cannot take arrives as records and goes through the --n_threads host formatter as
+  // before.  NGSLD_HOST_TEXT=1 keeps everything on the host formatter (A/B, tests).
+  if (!(getenv("NGSLD_HOST_TEXT") && strcmp(getenv("NGSLD_HOST_TEXT"), "1") == 0)) {
+    std::vector<const char *> lab;
+    if (pos) {
+      lab.resize(pars.n_sites);
+      for (uint64_t s = 0; s < pars.n_sites; s++) lab[s] = ngsld_host_label(pos, s);
+    }
+    if (ngsld_set_text_output(ctx, pos ? lab.data() : nullptr, 1) != NGSLD_OK)
+      error("ngsld_set_text_output", ngsld_last_error(ctx));
+  }
   if (pars.verbose >= 1) fprintf(stderr, "==> Waiting for all threads to finish...\n");
   SinkState sink;
   sink.pars = &pars;

@@ -16,6 +16,7 @@
 #include "../../include/ngsld.h"
 #include "ld_device.h"
 #include "ld_prep.h"
+#include "ld_text.h"
 #include "taus.h"
 
 using namespace ngsld;
@@ -104,6 +105,16 @@ struct ngsld_ctx {
   PinBuf<ngsld_rec_ext> h_ext[2];
   hipEvent_t ev_kernel_done[2] = {nullptr, nullptr}, ev_copy_done[2] = {nullptr, nullptr};
 
+  // device-side TSV (ngsld_set_text_output)
+  bool text_mode = false, have_labels = false;
+  uint64_t max_label = 6;  // "(null)"
+  DevBuf<char> d_labels, d_text[2], d_scan_tmp;
+  DevBuf<uint64_t> d_label_off, d_lens[2], d_offs[2], d_text_meta[2];  // meta: {total bytes, needs_host}
+  DevBuf<double> d_cum;
+  DevBuf<uint32_t> d_infc;
+  PinBuf<char> h_text[2];
+  PinBuf<uint64_t> h_text_meta[2];
+
   // timing of pair-kernel launches
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
@@ -144,6 +155,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   HIP_TRY(c, hipSetDevice(c->device));
   c->have_geno = false;
   c->planned = false;
+  c->text_mode = false;  // labels belong to a matrix
   c->n_sites = n_sites;
   c->n_ind = n_ind;
   c->cfg = cfg;
@@ -377,6 +389,10 @@ int ngsld_create(int device, ngsld_ctx **out) {
     c->row_kernel = std::strcmp(k, "wave") != 0;
     c->run_kernel = std::strcmp(k, "item") != 0;  // "item": one workgroup per item (pair_ld_pf_kernel), the run kernel's baseline
   }
+  if (const char *k = std::getenv("NGSLD_BATCH_PAIRS")) {  // tests: many small batches through ngsld_run
+    const uint64_t v = std::strtoull(k, nullptr, 10);
+    if (v > 0) c->batch_pairs = v;
+  }
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
       (e = hipStreamCreate(&c->copy_stream)) != hipSuccess) {
     g_create_error = std::string("stream setup: ") + hipGetErrorString(e);
@@ -396,6 +412,11 @@ void ngsld_destroy(ngsld_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_rsx.release(); c->d_sc4.release(); c->d_runs.release();
+  c->d_labels.release(); c->d_scan_tmp.release(); c->d_label_off.release(); c->d_cum.release(); c->d_infc.release();
+  for (int k = 0; k < 2; ++k) {
+    c->d_text[k].release(); c->d_lens[k].release(); c->d_offs[k].release(); c->d_text_meta[k].release();
+    c->h_text[k].release(); c->h_text_meta[k].release();
+  }
   c->d_status.release(); c->d_row_off.release(); c->d_item_off.release(); c->d_row_end.release();
   c->d_row_seed.release(); c->d_row_count.release(); c->d_keep.release(); c->d_items.release();
   for (int k = 0; k < 2; ++k) {
@@ -561,6 +582,33 @@ int ngsld_plan_rows(ngsld_ctx *c, const uint64_t **row_off, const uint32_t **row
   return NGSLD_OK;
 }
 
+int ngsld_set_text_output(ngsld_ctx *c, const char *const *labels, int enable) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "set the genotype data before the labels");
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->text_mode = false;
+  if (!enable) return NGSLD_OK;
+  c->have_labels = labels != nullptr;
+  c->max_label = 6;
+  if (labels != nullptr) {
+    std::vector<uint64_t> off(c->n_sites + 1, 0);
+    for (uint64_t s = 0; s < c->n_sites; ++s) {
+      if (labels[s] == nullptr) return fail(c, NGSLD_ERR_INVALID, "a label is NULL");
+      const uint64_t n = std::strlen(labels[s]);
+      off[s + 1] = off[s] + n;
+      c->max_label = std::max<uint64_t>(c->max_label, n);
+    }
+    std::vector<char> blob(off[c->n_sites] ? off[c->n_sites] : 1);
+    for (uint64_t s = 0; s < c->n_sites; ++s) std::memcpy(blob.data() + off[s], labels[s], off[s + 1] - off[s]);
+    HIP_TRY(c, c->d_labels.resize(blob.size()));
+    HIP_TRY(c, c->d_label_off.resize(c->n_sites + 1));
+    HIP_TRY(c, hipMemcpy(c->d_labels.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_label_off.p, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
+  c->text_mode = true;
+  return NGSLD_OK;
+}
+
 int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_std, void *d_ext, void *hip_stream) {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   if (!c->planned) return fail(c, NGSLD_ERR_INVALID, "ngsld_plan has not been called");
@@ -599,10 +647,44 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   c->timed_stream = c->stream;
   c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
 
-  if (c->h_items.size() != c->n_items) {
-    c->h_items.resize(c->n_items);
-    if (c->n_items)
-      HIP_TRY(c, hipMemcpy(c->h_items.data(), c->d_items.p, c->n_items * sizeof(Item), hipMemcpyDeviceToHost));
+  // Device-side TSV: the dist column needs prefix sums of pos_dist that are EXACT (the host writer adds the gaps one
+  // by one, ngsLD.cpp:241), i.e. integer gaps as read_dist produces them; otherwise the batches go out as records.
+  bool text = c->text_mode;
+  if (text) {
+    const uint64_t n = c->n_sites;
+    std::vector<double> cum(n);
+    std::vector<uint32_t> infc(n);
+    double run = 0.0;
+    uint32_t ic = 0;
+    for (uint64_t s = 0; s < n && text; ++s) {
+      const double g = c->h_pos_dist[s];
+      if (std::isinf(g) && g > 0) {
+        ++ic;
+      } else {
+        if (!(g >= 0.0) || g != std::floor(g) || run + g > 9.0e15) text = false;
+        run += g;
+      }
+      cum[s] = run;
+      infc[s] = ic;
+    }
+    if (text) {
+      HIP_TRY(c, c->d_cum.resize(n));
+      HIP_TRY(c, c->d_infc.resize(n));
+      HIP_TRY(c, hipMemcpy(c->d_cum.p, cum.data(), n * sizeof(double), hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(c->d_infc.p, infc.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+  }
+  auto need_host_items = [&]() -> int {  // the host copy of the plan's items, fetched on first use
+    if (c->h_items.size() != c->n_items) {
+      c->h_items.resize(c->n_items);
+      if (c->n_items)
+        HIP_TRY(c, hipMemcpy(c->h_items.data(), c->d_items.p, c->n_items * sizeof(Item), hipMemcpyDeviceToHost));
+    }
+    return NGSLD_OK;
+  };
+  if (!text) {
+    const int rc0 = need_host_items();
+    if (rc0 != NGSLD_OK) return rc0;
   }
   struct Batch {
     uint64_t r0, r1, n;
@@ -618,18 +700,57 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   for (auto &b : batches) cap = std::max(cap, b.n);
   for (int k = 0; k < 2; ++k) {
     HIP_TRY(c, c->d_std[k].resize(cap));
-    HIP_TRY(c, c->h_std[k].resize(cap));
-    if (ext) {
-      HIP_TRY(c, c->d_ext[k].resize(cap));
-      HIP_TRY(c, c->h_ext[k].resize(cap));
+    if (ext) HIP_TRY(c, c->d_ext[k].resize(cap));
+    if (text) {
+      HIP_TRY(c, c->d_lens[k].resize(cap));
+      HIP_TRY(c, c->d_offs[k].resize(cap));
+      HIP_TRY(c, c->d_text_meta[k].resize(2));
+      HIP_TRY(c, c->h_text_meta[k].resize(2));
+    } else {
+      HIP_TRY(c, c->h_std[k].resize(cap));
+      if (ext) HIP_TRY(c, c->h_ext[k].resize(cap));
     }
   }
+  size_t scan_bytes = 0;
+  if (text) {
+    scan_bytes = text_scan_temp_bytes(cap);
+    HIP_TRY(c, c->d_scan_tmp.resize(scan_bytes ? scan_bytes : 1));
+  }
+  auto text_args = [&](const Batch &b, int k) -> TextArgs {
+    TextArgs t{};
+    t.items = c->d_items.p + c->h_item_off[b.r0];
+    t.n_items = c->h_item_off[b.r1] - c->h_item_off[b.r0];
+    t.out_base = c->h_row_off[b.r0];
+    t.n_pairs = b.n;
+    t.std_rec = c->d_std[k].p;
+    t.ext_rec = ext ? c->d_ext[k].p : nullptr;
+    t.maf = c->d_maf.p;
+    t.cum = c->d_cum.p;
+    t.infc = c->d_infc.p;
+    t.labels = c->have_labels ? c->d_labels.p : nullptr;
+    t.label_off = c->d_label_off.p;
+    t.lens = c->d_lens[k].p;
+    t.offs = c->d_offs[k].p;
+    t.text = c->d_text[k].p;
+    t.needs_host = reinterpret_cast<int *>(c->d_text_meta[k].p + 1);
+    return t;
+  };
   std::vector<Item> rel_items;
   auto issue = [&](size_t bi) -> int {  // kernel on `stream`, D2H on `copy_stream`
     const int k = (int)(bi & 1);
     const Batch &b = batches[bi];
     PairArgs a = make_args(c, b.r0, b.r1, c->d_std[k].p, ext ? c->d_ext[k].p : nullptr);
     HIP_TRY(c, timed_launch(c, a, c->stream));
+    if (text) {  // row lengths and their prefix sums right behind the pair kernel; the rows are written at consume time
+      HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), c->stream));
+      const TextArgs t = text_args(b, k);
+      HIP_TRY(c, launch_text_lengths(t, c->stream));
+      HIP_TRY(c, text_scan(c->d_scan_tmp.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n, c->d_text_meta[k].p, c->stream));
+      HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                c->stream));
+      HIP_TRY(c, hipEventRecord(c->ev_kernel_done[k], c->stream));
+      return NGSLD_OK;
+    }
     HIP_TRY(c, hipEventRecord(c->ev_kernel_done[k], c->stream));
     HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_kernel_done[k], 0));
     if (b.n) {
@@ -651,19 +772,56 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       rc = issue(bi + 1);
       if (rc != NGSLD_OK) break;
     }
-    HIP_TRY(c, hipEventSynchronize(c->ev_copy_done[k]));
     const Batch &b = batches[bi];
     const uint64_t i0 = c->h_item_off[b.r0], i1 = c->h_item_off[b.r1];
-    rel_items.assign(c->h_items.begin() + (ptrdiff_t)i0, c->h_items.begin() + (ptrdiff_t)i1);
-    for (auto &it : rel_items) it.first_record -= c->h_row_off[b.r0];
     ngsld_batch out{};
     out.s1_begin = b.r0;
     out.s1_end = b.r1;
     out.n_pairs = b.n;
-    out.n_items = i1 - i0;
-    out.items = rel_items.data();
-    out.std = c->h_std[k].p;
-    out.ext = ext ? c->h_ext[k].p : nullptr;
+    bool as_records = !text;
+    if (text) {
+      // the batch's text: its length is known now; the rows are written and copied on the copy stream while the pair
+      // kernel of the next batch (already enqueued) runs on the compute stream
+      HIP_TRY(c, hipEventSynchronize(c->ev_kernel_done[k]));
+      const uint64_t total = c->h_text_meta[k].p[0];
+      const bool needs_host = (c->h_text_meta[k].p[1] & 0xffffffffull) != 0;
+      if (needs_host) {
+        as_records = true;  // a value beyond the device formatter's fast path: this batch goes out as records
+        HIP_TRY(c, c->h_std[k].resize(cap));
+        if (ext) HIP_TRY(c, c->h_ext[k].resize(cap));
+        if (b.n) {
+          HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, c->d_std[k].p, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost,
+                                    c->copy_stream));
+          if (ext)
+            HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, c->d_ext[k].p, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost,
+                                      c->copy_stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+        const int rc1 = need_host_items();
+        if (rc1 != NGSLD_OK) return rc1;
+      } else {
+        if (total > c->d_text[k].n) HIP_TRY(c, c->d_text[k].resize(total + total / 8));
+        if (total > c->h_text[k].n) HIP_TRY(c, c->h_text[k].resize(total + total / 8));
+        if (total) {
+          const TextArgs t = text_args(b, k);
+          HIP_TRY(c, launch_text_write(t, c->copy_stream));
+          HIP_TRY(c, hipMemcpyAsync(c->h_text[k].p, c->d_text[k].p, total, hipMemcpyDeviceToHost, c->copy_stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+        out.text = c->h_text[k].p;
+        out.text_len = total;
+      }
+    } else {
+      HIP_TRY(c, hipEventSynchronize(c->ev_copy_done[k]));
+    }
+    if (as_records) {
+      rel_items.assign(c->h_items.begin() + (ptrdiff_t)i0, c->h_items.begin() + (ptrdiff_t)i1);
+      for (auto &it : rel_items) it.first_record -= c->h_row_off[b.r0];
+      out.n_items = i1 - i0;
+      out.items = rel_items.data();
+      out.std = c->h_std[k].p;
+      out.ext = ext ? c->h_ext[k].p : nullptr;
+    }
     if (sink(user, &out) != 0) rc = fail(c, NGSLD_ERR_SINK, "sink callback failed");
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));

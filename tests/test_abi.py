@@ -42,7 +42,7 @@ def test_binding_lists_nothing_extra():
 def test_record_layouts_match_header():
     assert capi.REC_STD.itemsize == 32 and capi.REC_EXT.itemsize == 40      # sizes stated in ngsld.h
     assert capi.REC_EXT.fields["n_ind_data"][1] == 32 and capi.REC_EXT.fields["n_iter"][1] == 36
-    assert C.sizeof(capi.Params) == 56 and capi.ITEM.itemsize == 32 and C.sizeof(capi.Batch) == 56
+    assert C.sizeof(capi.Params) == 56 and capi.ITEM.itemsize == 32 and C.sizeof(capi.Batch) == 72
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful where no GPU is present")

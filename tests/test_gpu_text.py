@@ -1,0 +1,76 @@
+"""GPU: TSV rows formatted on the device (ngsld_set_text_output) are byte for byte the host writer's
+(ngsld_host_write_batch / ngsld_host_format_pair, themselves pinned to the oracle's text by the golden md5 tests)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ngsld_amd import capi, shard, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cli(args, env_extra):
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([capi.CLI_PATH] + args, capture_output=True, env=env)
+    assert r.returncode == 0, r.stderr.decode()
+    return r.stdout
+
+
+@pytest.mark.parametrize("case", ["std", "ext", "ext_filters", "nopos", "degenerate", "many_batches", "n1000"])
+def test_cli_device_text_equals_host_text(tmp_path, case):
+    n_sites, n_ind = (400, 60) if case != "n1000" else (120, 1000)
+    raw = synth.make_gl_numpy(n_sites, n_ind, 77, depth=3.0)
+    if case == "degenerate":
+        raw[5] = np.array([1.0, 0.0, 0.0])                        # monomorphic: -nan columns
+        raw[9] = 1.0 / 3.0                                          # no information at all
+        raw[11] = np.eye(3)[np.random.default_rng(1).integers(0, 3, size=n_ind)]   # hard calls
+    g = str(tmp_path / "in.glf")
+    raw.tofile(g)
+    chrs, pos = synth.make_positions(n_sites, 77, max_gap=300, n_chr=3)
+    p = str(tmp_path / "in.pos")
+    synth.write_pos(p, chrs, pos, extra_col=(case == "ext_filters"))
+    args = ["--geno", g, "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--verbose", "0", "--n_threads", "3"]
+    if case == "nopos":
+        args += ["--max_kb_dist", "0", "--extend_out"]
+    else:
+        args += ["--pos", p, "--max_kb_dist", "0" if case in ("degenerate", "n1000") else "20"]
+    if case in ("ext", "ext_filters", "degenerate", "many_batches", "n1000"):
+        args += ["--extend_out"]
+    if case == "ext_filters":
+        args += ["--min_maf", "0.1", "--rnd_sample", "0.5", "--seed", "42", "--ignore_miss_data"]
+    env = {"NGSLD_BATCH_PAIRS": "700"} if case == "many_batches" else {}
+    host = _cli(args, dict(env, NGSLD_HOST_TEXT="1"))
+    dev = _cli(args, env)
+    assert len(host) > 1000 and host.count(b"\n") > 10
+    assert dev == host
+
+
+def test_api_text_rows(engine):
+    """ngsld_run with text output against ngsld_host_format_pair row by row (labels with TABs, long labels)."""
+    n_sites, n_ind = 150, 40
+    raw = synth.make_gl_numpy(n_sites, n_ind, 5, depth=2.0)
+    chrs, pos = synth.make_positions(n_sites, 5, n_chr=2)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    labels = [f"{c}:{q}" + ("\tid%d" % k if k % 7 == 0 else "") + ("x" * 40 if k == 13 else "") for k, (c, q) in
+              enumerate(zip(chrs, pos))]
+    engine.set_geno_raw(raw)
+    engine.set_pos_dist(pd)
+    engine.plan(max_kb_dist=10, extend_out=True)
+    maf = engine.maf()
+    s1, s2, std, ext = engine.run()
+    engine.set_text_output(labels)
+    try:
+        text, fallbacks = engine.run_text()
+    finally:
+        engine.set_text_output(None, enable=False)
+    assert fallbacks == 0
+    rows = text.split(b"\n")
+    assert rows[-1] == b"" and len(rows) - 1 == len(s1)
+    for k in np.random.default_rng(3).choice(len(s1), size=min(400, len(s1)), replace=False):
+        a, b = int(s1[k]), int(s2[k])
+        dist = float(np.sum(pd[a + 1:b + 1]))
+        want = capi.format_pair(labels[a], labels[b], dist, std[k], ext[k], maf[a], maf[b]).encode()
+        assert rows[k] + b"\n" == want, (k, rows[k], want)
