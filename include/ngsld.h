@@ -219,6 +219,14 @@ int ngsld_run_streamed(int device, uint64_t n_sites, uint64_t n_ind, const doubl
                        ngsld_read_sites_fn read, void *read_user, double *maf_out, ngsld_sink_fn sink,
                        void *sink_user, uint64_t *n_pairs, uint64_t *n_slabs, char *err, size_t errlen);
 
+/* The same with device-side TSV (ngsld_set_text_output on every slab): labels = n_sites C strings or NULL ("(null)"),
+ * text_output != 0 makes the sink receive text batches (ngsld_batch.text), in global (s1, s2) order. */
+int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const double *pos_dist,
+                            const ngsld_params *params, const ngsld_geno_opts *opts, uint64_t max_slab_sites,
+                            ngsld_read_sites_fn read, void *read_user, double *maf_out, ngsld_sink_fn sink,
+                            void *sink_user, uint64_t *n_pairs, uint64_t *n_slabs, char *err, size_t errlen,
+                            const char *const *labels, int text_output);
+
 #ifdef __cplusplus
 }
 #endif

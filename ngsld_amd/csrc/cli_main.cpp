@@ -248,8 +248,15 @@ bool run_streamed(Params &pars, uint64_t slab_sites, bool may_fall_back) {
   }
   if (pars.verbose >= 1)
     fprintf(stderr, "==> Streaming the genotype matrix in slabs of up to %lu sites\n", (unsigned long)slab_sites);
-  const int rc = ngsld_run_streamed(pars.device, pars.n_sites, pars.n_ind, sink.pos_dist, &lp, &go, slab_sites,
-                                    read_slab, &rs, maf.data(), write_batch, &sink, &n_pairs, &n_slabs, err, sizeof(err));
+  const bool dev_text = !(getenv("NGSLD_HOST_TEXT") && strcmp(getenv("NGSLD_HOST_TEXT"), "1") == 0);
+  std::vector<const char *> lab;
+  if (pos && dev_text) {
+    lab.resize(pars.n_sites);
+    for (uint64_t s = 0; s < pars.n_sites; s++) lab[s] = ngsld_host_label(pos, s);
+  }
+  const int rc = ngsld_run_streamed_text(pars.device, pars.n_sites, pars.n_ind, sink.pos_dist, &lp, &go, slab_sites,
+                                         read_slab, &rs, maf.data(), write_batch, &sink, &n_pairs, &n_slabs, err,
+                                         sizeof(err), pos && dev_text ? lab.data() : nullptr, dev_text ? 1 : 0);
   if (rc == NGSLD_ERR_NAN) error("read_geno", err);
   if (rc == NGSLD_ERR_MAF_RANGE) error("haplo_freq", err);
   if (rc != NGSLD_OK) error("ngsld_run_streamed", rs.err[0] ? rs.err : err);

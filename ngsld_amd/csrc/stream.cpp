@@ -81,6 +81,15 @@ int ngsld_run_streamed(int device, uint64_t n_sites, uint64_t n_ind, const doubl
                        const ngsld_params *params, const ngsld_geno_opts *opts, uint64_t max_slab_sites,
                        ngsld_read_sites_fn read, void *read_user, double *maf_out, ngsld_sink_fn sink,
                        void *sink_user, uint64_t *n_pairs, uint64_t *n_slabs_out, char *err, size_t errlen) {
+  return ngsld_run_streamed_text(device, n_sites, n_ind, pos_dist, params, opts, max_slab_sites, read, read_user, maf_out,
+                                 sink, sink_user, n_pairs, n_slabs_out, err, errlen, nullptr, 0);
+}
+
+int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const double *pos_dist,
+                            const ngsld_params *params, const ngsld_geno_opts *opts, uint64_t max_slab_sites,
+                            ngsld_read_sites_fn read, void *read_user, double *maf_out, ngsld_sink_fn sink,
+                            void *sink_user, uint64_t *n_pairs, uint64_t *n_slabs_out, char *err, size_t errlen,
+                            const char *const *labels, int text_output) {
   if (params == nullptr || opts == nullptr || read == nullptr || sink == nullptr || n_sites == 0 || n_ind == 0) {
     set_err(err, errlen, "invalid argument");
     return NGSLD_ERR_INVALID;
@@ -173,6 +182,8 @@ int ngsld_run_streamed(int device, uint64_t n_sites, uint64_t n_ind, const doubl
           const uint64_t *row_off = nullptr;
           if (r == NGSLD_OK) r = ngsld_plan_rows(ctx[b], &row_off, nullptr);
           if (r == NGSLD_OK) slab_pairs[k] = row_off[sl.row_end - sl.row_begin];
+          // device-side TSV: the slab's sites carry their own labels (set after the matrix, which resets it)
+          if (r == NGSLD_OK && text_output) r = ngsld_set_text_output(ctx[b], labels ? labels + sl.row_begin : nullptr, 1);
         }
         if (r != NGSLD_OK) msg = ngsld_last_error(ctx[b]);
       }
