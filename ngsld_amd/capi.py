@@ -452,13 +452,27 @@ class Engine:
 
     def run_to_fd(self, s1_begin: int, s1_end: int, fd: int, pos_handle, pos_dist: np.ndarray | None, maf: np.ndarray,
                   n_threads: int) -> int:
-        """Rows [s1_begin, s1_end) -> TSV rows on file descriptor fd (ngsld_run + ngsld_host_write_batch)."""
+        """Rows [s1_begin, s1_end) -> TSV rows on file descriptor fd: text batches (after set_text_output) are written
+        as they come, record batches go through ngsld_host_write_batch."""
         maf = np.ascontiguousarray(maf, dtype=np.float64)
         pd_ptr = None if pos_dist is None else np.ascontiguousarray(pos_dist, dtype=np.float64).ctypes.data
         total, rc_box = [0], [0]
 
+        libc = C.CDLL(None, use_errno=True)
+        libc.write.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+        libc.write.restype = C.c_ssize_t
+
         def sink(_user, bp):
-            total[0] += bp.contents.n_pairs
+            b = bp.contents
+            total[0] += b.n_pairs
+            if b.text:                                   # rows formatted on the device (set_text_output): only bytes to write
+                off = 0
+                while off < b.text_len:
+                    w = libc.write(fd, b.text + off, min(b.text_len - off, 1 << 30))
+                    if w <= 0:
+                        return 1
+                    off += w
+                return 0
             rc_box[0] = self._L.ngsld_host_write_batch(bp, pos_handle, pd_ptr, maf.ctypes.data, n_threads, fd)
             return 0 if rc_box[0] == OK else 1
 

@@ -132,6 +132,9 @@ def main(argv=None) -> int:
                      first_row=slab_lo)
             maf = eng.maf()
             slab_pos = L.ngsld_host_pos_slice(pos_h, slab_lo, slab_hi) if pos_path else None
+            if os.environ.get("NGSLD_HOST_TEXT") != "1":       # rows formatted on the device; records only as fallback
+                eng.set_text_output([L.ngsld_host_label(slab_pos, s).decode() for s in range(slab_hi - slab_lo)]
+                                    if pos_path else None)
             total = eng.run_to_fd(0, hi - lo, fh.fileno(), slab_pos, local_pd, maf, a.n_threads)
             if slab_pos:
                 L.ngsld_host_free_pos(slab_pos)
