@@ -788,7 +788,11 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       // kernel of the next batch (already enqueued) runs on the compute stream
       HIP_TRY(c, hipEventSynchronize(c->ev_kernel_done[k]));
       const uint64_t total = c->h_text_meta[k].p[0];
-      const bool needs_host = (c->h_text_meta[k].p[1] & 0xffffffffull) != 0;
+      bool needs_host = (c->h_text_meta[k].p[1] & 0xffffffffull) != 0;
+      if (const char *e = std::getenv("NGSLD_TEXT_FALLBACK_EVERY")) {  // tests: every n-th batch takes the record path
+        const uint64_t every = std::strtoull(e, nullptr, 10);
+        if (every > 0 && bi % every == every - 1) needs_host = true;
+      }
       if (needs_host) {
         as_records = true;  // a value beyond the device formatter's fast path: this batch goes out as records
         HIP_TRY(c, c->h_std[k].resize(cap));

@@ -19,7 +19,7 @@ def _cli(args, env_extra):
     return r.stdout
 
 
-@pytest.mark.parametrize("case", ["std", "ext", "ext_filters", "nopos", "degenerate", "many_batches", "n1000", "slabs"])
+@pytest.mark.parametrize("case", ["std", "ext", "ext_filters", "nopos", "degenerate", "many_batches", "n1000", "slabs", "mixed"])
 def test_cli_device_text_equals_host_text(tmp_path, case):
     n_sites, n_ind = (400, 60) if case != "n1000" else (120, 1000)
     raw = synth.make_gl_numpy(n_sites, n_ind, 77, depth=3.0)
@@ -37,11 +37,13 @@ def test_cli_device_text_equals_host_text(tmp_path, case):
         args += ["--max_kb_dist", "0", "--extend_out"]
     else:
         args += ["--pos", p, "--max_kb_dist", "0" if case in ("degenerate", "n1000") else "20"]
-    if case in ("ext", "ext_filters", "degenerate", "many_batches", "n1000", "slabs"):
+    if case in ("ext", "ext_filters", "degenerate", "many_batches", "n1000", "slabs", "mixed"):
         args += ["--extend_out"]
     if case == "ext_filters":
         args += ["--min_maf", "0.1", "--rnd_sample", "0.5", "--seed", "42", "--ignore_miss_data"]
     env = {"NGSLD_BATCH_PAIRS": "700"} if case == "many_batches" else {}
+    if case == "mixed":                                             # every third batch falls back to records + host formatter
+        env = {"NGSLD_BATCH_PAIRS": "500", "NGSLD_TEXT_FALLBACK_EVERY": "3"}
     if case == "slabs":                                             # the streamed path: slabs of 150 sites, text per slab
         env = {"NGSLD_SLAB_SITES": "150", "NGSLD_BATCH_PAIRS": "900"}
     host = _cli(args, dict(env, NGSLD_HOST_TEXT="1"))
