@@ -131,7 +131,8 @@ def lib() -> C.CDLL:
         L.ngsld_plan_rows.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint32))]
         L.ngsld_run.argtypes = [vp, u64, u64, SINK_FN, vp]
         L.ngsld_run_device.argtypes = [vp, u64, u64, vp, vp, vp]
-        L.ngsld_set_text_output.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int]
+        if hasattr(L, "ngsld_set_text_output"):  # (absent only from older A/B builds loaded through NGSLD_LIB)
+            L.ngsld_set_text_output.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int]
         L.ngsld_last_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
         L.ngsld_set_tuning.argtypes = [vp, C.c_uint32, u64]
         L.ngsld_selftest.argtypes = [vp]

@@ -230,6 +230,38 @@ struct SingleTag { static constexpr bool value = false; };
 typedef __attribute__((address_space(3))) void lds_void_t;        // operands of __builtin_amdgcn_global_load_lds
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
+// Allele relabelling (with kDrop0).  The frequency recovered from the other three carries an ABSOLUTE error of ~1e-16.
+// That is harmless for the largest of the four and ruinous for a tiny one: with both sites nearly monomorphic the
+// denominators of D' and r2 are products of two small margins (1e-14, say), and 1e-16 in a hap00 of 1e-15 moved D' in
+// the third decimal.  So each site's alleles are labelled such that its estimated frequency is <= 1/2 -- a site with
+// maf > 1/2 has its genotype planes 0 and 2 read in each other's place -- which makes hap 0 (initially (1-m1)(1-m2) >=
+// 1/4) the common-common haplotype, the one that tends to 1 exactly where the conditioning is bad.  The EM is equivariant
+// under the relabelling; the frequencies are put back in the caller's order afterwards (k = 2 * allele1 + allele2).
+struct Relabel {
+  bool flip1, flip2;
+  double m1, m2, mean1, mean2;  // frequencies and mean expected genotypes under the new labels
+};
+__device__ __forceinline__ Relabel relabel(double m1, double m2, double mean1, double mean2) {
+  Relabel r;
+  r.flip1 = kDrop0 && m1 > 0.5;
+  r.flip2 = kDrop0 && m2 > 0.5;
+  r.m1 = r.flip1 ? 1.0 - m1 : m1;
+  r.m2 = r.flip2 ? 1.0 - m2 : m2;
+  r.mean1 = r.flip1 ? 2.0 - mean1 : mean1;  // expected genotype p1 + 2 p2 of a normalised triple becomes 2 - e
+  r.mean2 = r.flip2 ? 2.0 - mean2 : mean2;
+  return r;
+}
+__device__ __forceinline__ void unrelabel(bool flip1, bool flip2, double &f0, double &f1, double &f2, double &f3) {
+  if (flip1) {  // allele at site 1: haplotypes k <-> k ^ 2
+    double t = f0; f0 = f2; f2 = t;
+    t = f1; f1 = f3; f3 = t;
+  }
+  if (flip2) {  // allele at site 2: k <-> k ^ 1
+    double t = f0; f0 = f1; f1 = t;
+    t = f2; f2 = f3; f3 = t;
+  }
+}
+
 // Stage both sites of one pair: P = a (x) b for this lane's SLOTS individuals, their validity bits and the
 // Pearson cross moment.  pa / pb point at a site's three planes [3][np] -- in HBM/L2 (direct kernel) or in
 // LDS (prefetch kernel); after inlining the compiler knows which and emits global_load or ds_read.
@@ -241,15 +273,19 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 template <int SLOTS, bool MASKED, bool ONLY_LAST = false, bool UNCENTRED = false>  // ONLY_LAST: only the last slot can hold padding lanes
 __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint32_t ia0, const double *pb, uint32_t npb,
                                            uint32_t ib0, uint32_t ind0, uint32_t n_ind, double mean1, double mean2,
-                                           double (&P)[SLOTS][9], uint32_t &vbits, double &sxy, double *pads = nullptr) {
-  // pa[g * npa + ia0 + 64 j] / pb[g * npb + ib0 + 64 j] hold genotype g of individual ind0 + 64 j (this lane, slot j)
+                                           double (&P)[SLOTS][9], uint32_t &vbits, double &sxy, double *pads = nullptr,
+                                           bool flip_a = false, bool flip_b = false) {
+  // pa[g * npa + ia0 + 64 j] / pb[g * npb + ib0 + 64 j] hold genotype g of individual ind0 + 64 j (this lane, slot j);
+  // flip_a / flip_b (wavefront-uniform) relabel the alleles of a site: genotype planes 0 and 2 trade places (see Relabel)
   vbits = 0;
   sxy = 0.0;
+  const double *pa0 = pa + (flip_a ? 2 * npa : 0u), *pa2 = pa + (flip_a ? 0u : 2 * npa);
+  const double *pb0 = pb + (flip_b ? 2 * npb : 0u), *pb2 = pb + (flip_b ? 0u : 2 * npb);
 #pragma unroll
   for (int j = 0; j < SLOTS; ++j) {
     const uint32_t ia = ia0 + (uint32_t)j * 64, ib = ib0 + (uint32_t)j * 64;
-    const double a0 = pa[ia], a1 = pa[npa + ia], a2 = pa[2 * npa + ia];
-    const double b0 = pb[ib], b1 = pb[npb + ib], b2 = pb[2 * npb + ib];
+    const double a0 = pa0[ia], a1 = pa[npa + ia], a2 = pa2[ia];
+    const double b0 = pb0[ib], b1 = pb[npb + ib], b2 = pb2[ib];
     const bool inb = (ONLY_LAST && j < SLOTS - 1) ? true : ind0 + (uint32_t)j * 64 < n_ind;
     bool ok = inb;
     if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);  // gen_func.cpp:1089
@@ -307,7 +343,6 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   // scale of f, so it is not repeated per iteration.  inv_x = 1/x; x == 0 gives 0 * inf = NaN like the reference's 0/0.
   // (held in a VGPR: the four products t_k * inv_x below take t_k from SGPRs, and a VALU op reads one SGPR at most)
   asm("" : "+v"(inv_x));
-  const double keep0 = f0 == 0.0 ? 0.0 : 1.0;
   bool bad = false;
   uint32_t n_iter = 0;
   // Slots known to be full (no padding / missing lanes) take their reciprocals two at a time:
@@ -329,8 +364,13 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     constexpr uint32_t kNeed = (1u << (SLOTS - 1)) - 1u;  // padding (P == 0, no missing data here) in the last slot only
     tree_ok = TREE_DYN ? !__builtin_amdgcn_ballot_w64((vbits & kNeed) != kNeed) : false;
   }
-  auto em_step = [&](auto paired_tag, double &n0, double &n1, double &n2, double &n3) {
+  // drop_tag: the step in its three-value form (hap 0 recovered from the sum) or in the full four-value form.  The
+  // shared-reciprocal step only exists in the three-value form; the step with one reciprocal per individual, which
+  // only ever runs outside the hot loop, in the full form -- and, where several wavefronts share a pair, in the
+  // three-value form too (all of them have to exchange the same values, and some take this step in every iteration).
+  auto em_step = [&](auto paired_tag, auto drop_tag, double &n0, double &n1, double &n2, double &n3) {
     constexpr bool kPair = decltype(paired_tag)::value;
+    constexpr bool kDrop = kDrop0 && decltype(drop_tag)::value;
     // products f_k f_h: they build the two-locus genotype weights W (s = sum_G W[G] P[G] is the
     // reference's 16-term `sum`, gen_func.cpp:1093-1096) and are reused by the t_k contraction below
     const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
@@ -347,7 +387,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
       return s;
     };
     auto slot_acc = [&](int j, double r) {
-      if (!kDrop0) R0 = fma(P[j][0], r, R0);
+      if (!kDrop) R0 = fma(P[j][0], r, R0);
       R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
       R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
       R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
@@ -383,74 +423,83 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
       if ((!CHECK_ALL && j < SLOTS - 1) || ((vbits >> j) & 1u)) slot_acc(j, rcp_refined(slot_s(j)));
     }
     // t_k = sum_h f_k f_h R[G(k,h)]  (= this lane's share of ff_k / 2, gen_func.cpp:1098-1104)
-    double t0 = kDrop0 ? 0.0 : fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0)));
+    double t0 = kDrop ? 0.0 : fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0)));
     double t1 = fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1)));
     double t2 = fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3)));
     double t3 = fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4)));
-    if (kDrop0)
+    if (kDrop)
       wave_sum3(t1, t2, t3);
     else
       wave_sum4(t0, t1, t2, t3);
     if (WAVES > 1) {
       const int par = (int)(n_iter & 1u);
       if (lane == 0) {
-        if (!kDrop0) xch[par][sub][0] = t0;
+        if (!kDrop) xch[par][sub][0] = t0;
         xch[par][sub][1] = t1; xch[par][sub][2] = t2; xch[par][sub][3] = t3;
       }
       lds_barrier();
       t0 = t1 = t2 = t3 = 0.0;
       for (int w = 0; w < WAVES; ++w) {
-        if (!kDrop0) t0 += xch[par][w][0];
+        if (!kDrop) t0 += xch[par][w][0];
         t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
       }
     }
-    if (kPair && kTree && kScaled) {
-      n1 = t1; n2 = t2; n3 = t3;
-    } else {
-      n1 = t1 * inv_x; n2 = t2 * inv_x; n3 = t3 * inv_x;
-    }
-    // sum_k ff_k / (2x) = 1 (every individual's four posterior weights add up to one): with kDrop0 the first frequency
-    // is what the other three leave, R[0] is never accumulated and three values go through the reduction instead of
-    // four.  keep0 = 0 keeps an exact zero exact (f0 = 0 is a fixed point of the reference's step: tmp_0 = f0 * ...).
-    n0 = kDrop0 ? fma(-keep0, (n1 + n2) + n3, keep0) : t0 * inv_x;
+    const bool scaled = kPair && kTree && kScaled;
+    n1 = scaled ? t1 : t1 * inv_x; n2 = scaled ? t2 : t2 * inv_x; n3 = scaled ? t3 : t3 * inv_x;
+    // sum_k ff_k / (2x) = 1 (every individual's four posterior weights add up to one): in the three-value form the first
+    // frequency is what the other three leave, R[0] is never accumulated and three values go through the reduction
+    // instead of four
+    n0 = kDrop ? 1.0 - ((n1 + n2) + n3) : (scaled ? t0 : t0 * inv_x);
   };
   // Any individual with s == 0 makes every tmp/sum NaN in the reference, hence all four f NaN and, as a
   // NaN difference never raises eps (gen_func.cpp:1049-1053), "convergence" at this iteration.  Here
-  // s == 0 poisons every R with inf/NaN, so a sum that is not a sane ~1 <=> the reference is all NaN.
-  // (one NaN reciprocal poisons EVERY R -- fma(P, NaN, R) -- so with kDrop0 any one accumulated frequency tells)
-  // The hot loop holds the one-reciprocal step and nothing else: a step that does not look sane leaves it, is redone
-  // with one reciprocal per individual (an underflowed product has to be ruled out before anything is concluded), and
-  // the loop is entered again -- with a single definition of the new frequencies per trip the compiler carries them
-  // from one iteration to the next without register copies.
+  // s == 0 poisons every R with inf/NaN -- fma(P, NaN, R) -- so any one accumulated frequency that is not a sane
+  // value below 2 <=> the reference is all NaN.
+  // The hot loops hold the one-reciprocal step and nothing else: a step that does not look sane leaves its loop, is
+  // redone with one reciprocal per individual (an underflowed product has to be ruled out before anything is
+  // concluded), and the loop is entered again -- with a single definition of the new frequencies per trip the compiler
+  // carries them from one iteration to the next without register copies.
+  // Two forms of the step.  The three-value form leaves hap 0 with an ABSOLUTE error of ~1e-16, which is nothing while
+  // hap 0 is a sizeable frequency (the allele relabelling makes it the common-common haplotype) and too much once it is
+  // tiny: its update is multiplicative, so a relative error stays for good, and the denominators of D' and r2 can be
+  // products of two small margins.  Below kFullBelow the pair therefore leaves the hot loop for good and finishes in
+  // the full four-value form (one reciprocal per individual: slower, and rare): hap 0 then keeps the relative accuracy
+  // it had at the switch (1e-16 / kFullBelow ~ 1e-13).
+  constexpr double kFullBelow = 0x1p-10;
   constexpr bool kFast = (kPaired > 0 || kTree) && kPairRcp;
+  bool full = kDrop0 && __builtin_amdgcn_ballot_w64(f0 < kFullBelow) != 0;  // wave-uniform (f is)
   bool done = false;
   while (!done && n_iter < (uint32_t)kIterMax) {
-    bool odd_step = false;
-    if (kFast && tree_ok) {
+    if (kFast && tree_ok && !full) {
       for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
         double n0, n1, n2, n3;
-        em_step(PairedTag(), n0, n1, n2, n3);
-        const double sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);
-        if (__builtin_amdgcn_ballot_w64(!(sn < 2.0))) {  // wave-uniform values: the ballot is all-or-nothing
-          odd_step = true;
-          break;
-        }
+        em_step(PairedTag(), PairedTag(), n0, n1, n2, n3);  // (the tags double as true / false)
+        if (__builtin_amdgcn_ballot_w64(!(n1 < 2.0))) break;  // an odd step (wave-uniform values: all-or-nothing)
         const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
         f0 = n0; f1 = n1; f2 = n2; f3 = n3;
         if (__builtin_amdgcn_ballot_w64(eps < kEpsilon)) {  // gen_func.cpp:1054-1055
           done = true;
           break;
         }
+        if (kDrop0 && __builtin_amdgcn_ballot_w64(n0 < kFullBelow)) {
+          full = true;
+          ++n_iter;  // this iteration is complete
+          break;
+        }
       }
-      if (!odd_step) break;  // converged, or ITER_MAX iterations done
-      if (WAVES > 1) lds_barrier();  // sn is the same in every wavefront: all redo, none still reads the exchange buffer
+      if (done || n_iter >= (uint32_t)kIterMax) break;
+      if (full) continue;
+      // an odd step: on to the second opinion
+      if (WAVES > 1) lds_barrier();  // n1 is the same in every wavefront: all redo, none still reads the exchange buffer
     }
-    // one iteration with one reciprocal per individual: the kernels' only path where any slot may be empty, the
-    // second opinion on an odd step elsewhere
+    // one iteration with one reciprocal per individual, four-value form: the kernels' only path where any slot may be
+    // empty, the second opinion on an odd step, and how a pair with a tiny hap 0 finishes
     double n0, n1, n2, n3;
-    em_step(SingleTag(), n0, n1, n2, n3);
-    const double sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);
-    if (__builtin_amdgcn_ballot_w64(!(sn < 2.0))) {
+    if (WAVES == 1 || full)
+      em_step(SingleTag(), SingleTag(), n0, n1, n2, n3);
+    else
+      em_step(SingleTag(), PairedTag(), n0, n1, n2, n3);
+    if (__builtin_amdgcn_ballot_w64(!(n1 < 2.0))) {
       bad = true;
       break;
     }
@@ -458,6 +507,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     f0 = n0; f1 = n1; f2 = n2; f3 = n3;
     if (__builtin_amdgcn_ballot_w64(eps < kEpsilon)) break;
     ++n_iter;
+    if (kDrop0 && !full && __builtin_amdgcn_ballot_w64(f0 < kFullBelow)) full = true;  // (wavefronts without a hot loop)
   }
   if (bad) f0 = f1 = f2 = f3 = __builtin_nan("");
   return n_iter;
@@ -589,15 +639,17 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
     uint32_t vbits;
     double sxy;
     double pads[SLOTS];  // --ignore_miss_data: 1 where the individual has no data at either site (see stage_pair)
+    const Relabel rl = relabel(m1, m2, mean1, mean2);
     if (PFB) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice copied during the previous pair has landed
       stage_pair<SLOTS, MASKED>(pa, A.np, i0, reinterpret_cast<const double *>(lds_b), (uint32_t)(SLOTS * 64),
-                                (uint32_t)lane, i0, A.n_ind, mean1, mean2, P, vbits, sxy, MASKED ? pads : nullptr);
+                                (uint32_t)lane, i0, A.n_ind, rl.mean1, rl.mean2, P, vbits, sxy, MASKED ? pads : nullptr,
+                                rl.flip1, rl.flip2);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // a, b and the scalars are all consumed
       if (cn < it.count) dma_slice(it.s2_begin + cn);
     } else {
-      stage_pair<SLOTS, MASKED>(pa, A.np, i0, A.planes + (uint64_t)s2 * A.site_stride, A.np, i0, i0, A.n_ind, mean1,
-                                mean2, P, vbits, sxy, MASKED ? pads : nullptr);
+      stage_pair<SLOTS, MASKED>(pa, A.np, i0, A.planes + (uint64_t)s2 * A.site_stride, A.np, i0, i0, A.n_ind, rl.mean1,
+                                rl.mean2, P, vbits, sxy, MASKED ? pads : nullptr, rl.flip1, rl.flip2);
     }
     uint32_t x = count_valid<SLOTS>(vbits);
     sxy = wave_sum1(sxy);
@@ -617,8 +669,9 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
       lds_barrier();
     }
     double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair<SLOTS, WAVES, kCheckAll, (WAVES > 1 && !MASKED)>(P, vbits, 1.0 / (double)x, m1, m2, f0, f1, f2, f3, xch, sub,
+    const uint32_t n_iter = em_pair<SLOTS, WAVES, kCheckAll, (WAVES > 1 && !MASKED)>(P, vbits, 1.0 / (double)x, rl.m1, rl.m2, f0, f1, f2, f3, xch, sub,
                                                              lane, A.status, MASKED ? pads : nullptr);
+    unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
     if (WAVES == 1) {
       if (lane == 0)
         write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, rsx2, x, n_iter);
@@ -755,9 +808,11 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
     uint32_t vbits;
     double sxy;
     double pads[SLOTS];  // --ignore_miss_data: 1 where the individual has no data at either site
+    const Relabel rl = relabel(m1, cur.maf, mean1, cur.mean);
     stage_pair<SLOTS, MASKED, !MASKED, true>(reinterpret_cast<const double *>(lds_a), kNp, (uint32_t)lane,
                                              reinterpret_cast<const double *>(lds_b), kNp, (uint32_t)lane, (uint32_t)lane,
-                                             A.n_ind, mean1, cur.mean, P, vbits, sxy, MASKED ? pads : nullptr);
+                                             A.n_ind, rl.mean1, rl.mean2, P, vbits, sxy, MASKED ? pads : nullptr, rl.flip1,
+                                             rl.flip2);
     // all ds_reads of the buffer are consumed (P is computed): start the copy of the next site over it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (cn < it.count)
@@ -765,10 +820,11 @@ __global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
     // without --ignore_miss_data every individual counts: x = n_ind, 1/x comes precomputed (same IEEE quotient)
     const uint32_t x = MASKED ? count_valid<SLOTS>(vbits) : A.n_ind;
     const double inv_x = MASKED ? 1.0 / (double)x : A.inv_n;
-    sxy = fma(-(double)A.n_ind * mean1, cur.mean, wave_sum1_bcast(sxy));  // centred: sum e1 e2 - n mean1 mean2 (as the run kernel)
+    sxy = fma(-(double)A.n_ind * rl.mean1, rl.mean2, wave_sum1_bcast(sxy));  // centred: sum e1 e2 - n mean1 mean2 (as the run kernel)
     double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, inv_x, m1, cur.maf, f0, f1, f2, f3,
+    const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, inv_x, rl.m1, rl.m2, f0, f1, f2, f3,
                                                       (double (*)[1][4]) nullptr, 0, lane, A.status, MASKED ? pads : nullptr);
+    unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
     if (lane == 0) {
       PairResult &r = res[c];
       r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;
@@ -904,7 +960,6 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
     }
   };
 
-  const double n_mean1 = (double)A.n_ind * mean1;
   Cand cur = claim_next();
   if (cur.ok) dma_site(cur.s2);
   uint32_t held = 0;
@@ -917,18 +972,21 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
     uint32_t vbits;
     double sxy;
     double pads[SLOTS];  // --ignore_miss_data: 1 where the individual has no data at either site
+    const Relabel rl = relabel(m1, m2, mean1, mean2);
     stage_pair<SLOTS, MASKED, !MASKED, true>(reinterpret_cast<const double *>(lds_a), kNp, (uint32_t)lane,
                                              reinterpret_cast<const double *>(lds_b), kNp, (uint32_t)lane, (uint32_t)lane,
-                                             A.n_ind, mean1, mean2, P, vbits, sxy, MASKED ? pads : nullptr);
+                                             A.n_ind, rl.mean1, rl.mean2, P, vbits, sxy, MASKED ? pads : nullptr, rl.flip1,
+                                             rl.flip2);
     // all ds_reads of the buffer are consumed (P is computed): start the copy of the next site over it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (nxt.ok) dma_site(nxt.s2);
     const uint32_t x = MASKED ? count_valid<SLOTS>(vbits) : A.n_ind;
     const double inv_x = MASKED ? 1.0 / (double)x : A.inv_n;
-    sxy = fma(-n_mean1, mean2, wave_sum1_bcast(sxy));  // centred: sum e1 e2 - n mean1 mean2
+    sxy = fma(-(double)A.n_ind * rl.mean1, rl.mean2, wave_sum1_bcast(sxy));  // centred: sum e1 e2 - n mean1 mean2
     double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, inv_x, m1, m2, f0, f1, f2, f3,
+    const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, inv_x, rl.m1, rl.m2, f0, f1, f2, f3,
                                                       (double (*)[1][4]) nullptr, 0, lane, A.status, MASKED ? pads : nullptr);
+    unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
     if (lane == 0) {
       RunResult &r = ring[held];
       r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;
@@ -998,7 +1056,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
   const Run run = A.runs[blockIdx.x];
   const Item *g_items = A.items_all + run.first_item;
   const uint32_t s1 = g_items[0].s1;
-  const double m1 = A.sc4[4 * (uint64_t)s1], mean1 = A.sc4[4 * (uint64_t)s1 + 1], rsx1 = A.sc4[4 * (uint64_t)s1 + 2];
+  const double m1_in = A.sc4[4 * (uint64_t)s1], mean1_in = A.sc4[4 * (uint64_t)s1 + 1], rsx1 = A.sc4[4 * (uint64_t)s1 + 2];
   char *lds_a = smem;
   char *lds_w = smem + kABytes + wave * kWaveBuf;
   RunResult *ring = reinterpret_cast<RunResult *>(smem + kRingOff) + wave * kRing;
@@ -1066,7 +1124,11 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
     if (active) nxt = claim_group();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the site copies issued a generation ago have landed
     const double *sc = reinterpret_cast<const double *>(lds_w + kPieces * 1024 + grp * kPiece);
-    const double m2 = active ? sc[0] : 0.5, mean2 = active ? sc[1] : 0.0, rsx2 = active ? sc[2] : 0.0;
+    const double m2_in = active ? sc[0] : 0.5, mean2_in = active ? sc[1] : 0.0, rsx2 = active ? sc[2] : 0.0;
+    // allele relabelling (see Relabel): site 1's is the same for the whole run, site 2's differs from group to group
+    const Relabel rl = relabel(m1_in, m2_in, mean1_in, mean2_in);
+    const double m1 = rl.m1, m2 = rl.m2, mean1 = rl.mean1, mean2 = rl.mean2;
+    const int gb0 = rl.flip2 ? 2 : 0, gb2 = rl.flip2 ? 0 : 2;
 
     // ---- stage: P = a (x) b per lane, validity, Pearson cross moment (group sums) ----
     double P[SLOTS][9];
@@ -1074,13 +1136,14 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
     uint32_t vbits = 0;
     double sxy = 0.0;
     const double *la = reinterpret_cast<const double *>(lds_a);
+    const double *la0 = la + (rl.flip1 ? 2 * kNp : 0u), *la2 = la + (rl.flip1 ? 0u : 2 * kNp);
 #pragma unroll
     for (int j = 0; j < SLOTS; ++j) {
       const uint32_t i = (uint32_t)j * (uint32_t)G + (uint32_t)gl;
-      const double a0 = la[i], a1 = la[kNp + i], a2 = la[2 * kNp + i];
-      const double b0 = *reinterpret_cast<const double *>(lds_w + b_off(0, j));
+      const double a0 = la0[i], a1 = la[kNp + i], a2 = la2[i];
+      const double b0 = *reinterpret_cast<const double *>(lds_w + b_off(gb0, j));
       const double b1 = *reinterpret_cast<const double *>(lds_w + b_off(1, j));
-      const double b2 = *reinterpret_cast<const double *>(lds_w + b_off(2, j));
+      const double b2 = *reinterpret_cast<const double *>(lds_w + b_off(gb2, j));
       const bool inb = i < A.n_ind;
       bool ok = inb && active;
       if (MASKED) ok = ok && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);  // gen_func.cpp:1089
@@ -1113,12 +1176,12 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       f0 = f1 = f2 = f3 = __builtin_nan("");
     }
     const double inv_x = 1.0 / (double)x;
-    const double keep0 = f0 == 0.0 ? 0.0 : 1.0;  // an exact zero stays exact (see em_pair)
     // one reciprocal per lane and iteration (RcpTree) when only the last slot can hold padding, see em_pair
     constexpr bool kTree = kTreeRcp && SLOTS > 1;
     const double pad = ((vbits >> (SLOTS - 1)) & 1u) ? 0.0 : 1.0;
     auto em_step = [&](auto tree_tag, double &n0, double &n1, double &n2, double &n3) {
       constexpr bool kT = decltype(tree_tag)::value;
+      constexpr bool kDrop = kDrop0 && kT;  // shared-reciprocal step: three-value form; the other one: full (see em_pair)
       const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
       const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
       const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
@@ -1131,7 +1194,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
         return s;
       };
       auto slot_acc = [&](int j, double r) {
-        if (!kDrop0) R0 = fma(P[j][0], r, R0);
+        if (!kDrop) R0 = fma(P[j][0], r, R0);
         R1 = fma(P[j][1], r, R1); R2 = fma(P[j][2], r, R2);
         R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
         R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
@@ -1160,8 +1223,8 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       const double t2 = group_sum<G>(fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3))));
       const double t3 = group_sum<G>(fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4))));
       n1 = t1 * inv_x; n2 = t2 * inv_x; n3 = t3 * inv_x;
-      if (kDrop0) {  // the first frequency is what the other three leave (see em_pair)
-        n0 = fma(-keep0, (n1 + n2) + n3, keep0);
+      if (kDrop) {  // the first frequency is what the other three leave (see em_pair)
+        n0 = 1.0 - ((n1 + n2) + n3);
       } else {
         const double t0 = group_sum<G>(fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0))));
         n0 = t0 * inv_x;
@@ -1169,20 +1232,19 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
     };
     bool done = !active;
     uint32_t n_iter = (uint32_t)kIterMax;
-    // As in em_pair the hot loop holds the one-reciprocal step only; a step that is not sane in some live group leaves it
-    // for one iteration with a reciprocal per individual (an underflowed product has to be ruled out first).
+    // As in em_pair: the hot loop holds the shared-reciprocal step in its three-value form only; a step that is not sane
+    // in some live group leaves it for one iteration with a reciprocal per individual, and as soon as hap 0 of any live
+    // group falls below kFullBelow the wavefront leaves it for good and finishes in the full four-value form.
+    constexpr double kFullBelow = 0x1p-10;
+    bool full = kDrop0 && __any(!done && f0 < kFullBelow);
     uint32_t itn = 0;
     while (itn < (uint32_t)kIterMax) {
-      if (kTree) {
-        bool odd_step = false;
+      if (kTree && !full) {
+        bool all_done = false;
         for (; itn < (uint32_t)kIterMax; ++itn) {
           double n0, n1, n2, n3;
           em_step(PairedTag(), n0, n1, n2, n3);
-          const double sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);  // one NaN reciprocal poisons every R (see em_pair)
-          if (__any(!done && !(sn < 2.0))) {
-            odd_step = true;
-            break;
-          }
+          if (__any(!done && !(n1 < 2.0))) break;  // an odd step (one NaN reciprocal poisons every R, see em_pair)
           const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
           if (!done) {
             f0 = n0; f1 = n1; f2 = n2; f3 = n3;
@@ -1191,16 +1253,24 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
               n_iter = itn;
             }
           }
-          if (__all(done)) break;
+          if (__all(done)) {
+            all_done = true;
+            break;
+          }
+          if (kDrop0 && __any(!done && f0 < kFullBelow)) {
+            full = true;
+            ++itn;  // this iteration is complete
+            break;
+          }
         }
-        if (!odd_step) break;
+        if (all_done || itn >= (uint32_t)kIterMax) break;
+        if (full) continue;
       }
       double n0, n1, n2, n3;
       em_step(SingleTag(), n0, n1, n2, n3);
-      const double sn = kDrop0 ? n1 : (n0 + n1) + (n2 + n3);
       const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
       if (!done) {
-        if (!(sn < 2.0)) {  // the reference's all-NaN step: "converges" at this iteration (see em_pair)
+        if (!(n1 < 2.0)) {  // the reference's all-NaN step: "converges" at this iteration (see em_pair)
           f0 = f1 = f2 = f3 = __builtin_nan("");
           done = true;
           n_iter = itn;
@@ -1216,6 +1286,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       ++itn;
     }
 
+    unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
     if (gl == 0) {  // one ring entry per group and generation; a group without a pair leaves a hole
       RunResult &r = ring[held + (uint32_t)grp];
       r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;
