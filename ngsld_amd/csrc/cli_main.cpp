@@ -176,8 +176,15 @@ int write_batch(void *user, const ngsld_batch *b) {
   return rc;
 }
 
-struct TimingReport {  // NGSLD_TIMING=1: wall time since start and the sink's share, on stderr
-  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+struct TimingReport {  // NGSLD_TIMING=1: wall time since start, per phase, and the sink's share, on stderr
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+  bool on = getenv("NGSLD_TIMING") && strcmp(getenv("NGSLD_TIMING"), "1") == 0;
+  void mark(const char *what) {
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[timing] %-28s %.3f s\n", what, std::chrono::duration<double>(now - last).count());
+    last = now;
+  }
   ~TimingReport() {
     if (const char *e = getenv("NGSLD_TIMING"))
       if (strcmp(e, "1") == 0)
@@ -297,11 +304,13 @@ int main(int argc, char **argv) {
   fflush(pars.out_fh);
 
   ngsld_host_set_threads((int)pars.n_threads);
+  timing_report.mark("arguments, output header");
 
   // ---- device ----
   ngsld_ctx *ctx = nullptr;
   if (ngsld_create(pars.device, &ctx) != NGSLD_OK) error("ngsld_create", ngsld_last_error(nullptr));
 
+  timing_report.mark("ngsld_create");
   char err[512];
   // ---- does the matrix fit the device?  If not, a windowed run on binary input is streamed slab by slab ----
   uint64_t budget = 0;
@@ -357,12 +366,14 @@ int main(int argc, char **argv) {
     go.log_scale = is_log;
     go.text_semantics = 1;
   }
+  timing_report.mark("read genotype file");
   if (pars.call_geno && pars.verbose >= 1) fprintf(stderr, "> Calling genotypes...\n");
   if (pars.verbose >= 1) fprintf(stderr, "==> Calculating MAF for all sites...\n");
   int rc = ngsld_set_geno_raw_opts(ctx, raw.data(), pars.n_sites, pars.n_ind, &go);
   if (rc == NGSLD_ERR_NAN) error("read_geno", ngsld_last_error(ctx));
   if (rc == NGSLD_ERR_INVALID && pars.call_geno) error("call_geno", ngsld_last_error(ctx));
   if (rc != NGSLD_OK) error("ngsld_set_geno_raw", ngsld_last_error(ctx));
+  timing_report.mark("upload + per-site prep");
   std::vector<double>().swap(raw);
   std::vector<double> maf(pars.n_sites);
   if (ngsld_get_maf(ctx, maf.data()) != NGSLD_OK) error("ngsld_get_maf", ngsld_last_error(ctx));
@@ -391,7 +402,9 @@ int main(int argc, char **argv) {
   lp.seed = pars.seed;
   lp.first_row = 0;
   uint64_t n_pairs = 0;
+  timing_report.mark("positions");
   if (ngsld_plan(ctx, &lp, &n_pairs) != NGSLD_OK) error("ngsld_plan", ngsld_last_error(ctx));
+  timing_report.mark("plan");
   // The rows are formatted on the device (the fprintf block of calc_pair_LD, ngsLD.cpp:310-352, at kernel rates); a
   // batch the device formatter cannot take arrives as records and goes through the --n_threads host formatter as
   // before.  NGSLD_HOST_TEXT=1 keeps everything on the host formatter (A/B, tests).
@@ -410,7 +423,9 @@ int main(int argc, char **argv) {
   sink.pos = pos;
   sink.pos_dist = pos ? ngsld_host_pos_dist(pos) : nullptr;
   sink.maf = &maf;
+  timing_report.mark("labels to the device");
   rc = ngsld_run(ctx, 0, pars.n_sites, write_batch, &sink);
+  timing_report.mark("pair kernels + text + write");
   if (rc == NGSLD_ERR_MAF_RANGE) error("haplo_freq", ngsld_last_error(ctx));
   if (rc != NGSLD_OK) error("ngsld_run", ngsld_last_error(ctx));
 
@@ -419,6 +434,7 @@ int main(int argc, char **argv) {
   fclose(pars.out_fh);
   ngsld_host_free_pos(pos);
   ngsld_destroy(ctx);
+  timing_report.mark("free");
   if (pars.verbose >= 1) fprintf(stderr, "Done!\n");
   return 0;
 }

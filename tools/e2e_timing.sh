@@ -12,8 +12,8 @@ synth.make_gl_torch(100000, 500, 3, torch.device("cuda", 0)).cpu().numpy().tofil
 chrs, pos = synth.make_positions(100000, 3)
 synth.write_pos(os.path.join(d, "in.pos"), chrs, pos)
 PY
-for t in 8 32 256; do for pipe in 1 0; do
+for t in 8 256; do for pipe in 0; do
   echo "--n_threads $t NGSLD_PIPELINE=$pipe"
-  NGSLD_TIMING=1 NGSLD_PIPELINE=$pipe ngsld_amd/bin/ngsLD --geno $D/in.glf --n_ind 500 --n_sites 100000 --pos $D/in.pos --max_kb_dist 100 --extend_out --n_threads $t --verbose 0 --out /dev/null 2>&1 | tail -1
+  NGSLD_TIMING=1 NGSLD_PIPELINE=$pipe ngsld_amd/bin/ngsLD --geno $D/in.glf --n_ind 500 --n_sites 100000 --pos $D/in.pos --max_kb_dist 100 --extend_out --n_threads $t --verbose 0 --out /dev/null 2>&1 | tail -12
 done; done
 rm -rf $D
