@@ -2,6 +2,7 @@
 // Pure C++17 + zlib, no device code: this is the part of the reference's L0/L4 layers
 // (shared/read_data.cpp, shared/gen_func.cpp read_file, ngsLD.cpp fprintf) the new engine keeps on the host.
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
 
@@ -292,10 +293,52 @@ int ngsld_host_geno_size_ok(uint64_t file_size, uint64_t n_ind, uint64_t n_sites
 int ngsld_host_read_geno_bin(const char *path, uint64_t n_ind, uint64_t n_sites, double *out_raw, char *err,
                              size_t errlen) {
   if (path == nullptr || out_raw == nullptr) return set_err(err, errlen, "invalid argument");
+  const uint64_t total = n_sites * n_ind * 3 * sizeof(double);
+  // A plain (not gzip-compressed) regular file is read with pread by the host threads (ngsld_host_set_threads) straight
+  // into the caller's buffer -- gzread's transparent mode is one thread and one more copy; same error texts.
+  if (std::strcmp(path, "-") != 0) {
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return set_err(err, errlen, "cannot open GENO file!");
+    struct stat st;
+    unsigned char magic[2] = {0, 0};
+    const bool regular = ::fstat(fd, &st) == 0 && S_ISREG(st.st_mode);
+    const bool gz = ::pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    if (regular && !gz) {
+      if ((uint64_t)st.st_size < total) {
+        ::close(fd);
+        return set_err(err, errlen, "GENO file at premature EOF. Check GENO file and number of sites!");
+      }
+      if ((uint64_t)st.st_size > total) {
+        ::close(fd);
+        return set_err(err, errlen, "GENO file not at EOF. Check GENO file and number of sites!");
+      }
+      const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(1, g_host_threads.load()), total >> 24));
+      std::atomic<int> failed{0};
+      auto work = [&](int t) {
+        uint64_t lo = total * (uint64_t)t / (uint64_t)nt, hi = total * (uint64_t)(t + 1) / (uint64_t)nt;
+        char *dst = reinterpret_cast<char *>(out_raw);
+        while (lo < hi) {
+          const ssize_t n = ::pread(fd, dst + lo, (size_t)std::min<uint64_t>(hi - lo, 1u << 30), (off_t)lo);
+          if (n <= 0) {
+            failed = 1;
+            return;
+          }
+          lo += (uint64_t)n;
+        }
+      };
+      std::vector<std::thread> th;
+      for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+      work(0);
+      for (auto &x : th) x.join();
+      ::close(fd);
+      if (failed) return set_err(err, errlen, "cannot read binary GENO file. Check GENO file and number of sites!");
+      return NGSLD_OK;
+    }
+    ::close(fd);
+  }
   gzFile fh = std::strcmp(path, "-") == 0 ? gzdopen(0, "rb") : gzopen(path, "rb");
   if (fh == nullptr) return set_err(err, errlen, "cannot open GENO file!");
   gzbuffer(fh, 1 << 22);
-  const uint64_t total = n_sites * n_ind * 3 * sizeof(double);
   uint64_t got = 0;
   char *dst = reinterpret_cast<char *>(out_raw);
   while (got < total) {
