@@ -140,6 +140,20 @@ int hip_fail(ngsld_ctx *c, hipError_t e, const char *what) {
     if (e_ != hipSuccess) return hip_fail(c, e_, #call); \
   } while (0)
 
+// No exception crosses the C-ABI (include/ngsld.h): every entry point that allocates host memory is a function-try-block
+// ending in this handler.  Work still in flight is waited for, so that buffers the caller owns are quiet on return.
+int caught(ngsld_ctx *c, bool nomem) {
+  if (c) {
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    c->planned = false;
+  }
+  return nomem ? fail(c, NGSLD_ERR_NOMEM, "out of host memory") : fail(c, NGSLD_ERR_INVALID, "unexpected C++ exception");
+}
+#define NGSLD_CATCH(ctx)                                        \
+  catch (const std::bad_alloc &) { return caught(ctx, true); }  \
+  catch (...) { return caught(ctx, false); }
+
 int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t n_sites, uint64_t n_ind,
                     const ngsld_geno_opts &o, bool normalised) {
   if (c == nullptr) return NGSLD_ERR_INVALID;
@@ -436,35 +450,35 @@ void ngsld_destroy(ngsld_ctx *c) {
 const char *ngsld_last_error(const ngsld_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
 int ngsld_set_geno_raw(ngsld_ctx *c, const double *gl_raw, uint64_t n_sites, uint64_t n_ind, int log_scale,
-                       int ignore_miss_data, int on_device) {
+                       int ignore_miss_data, int on_device) try {
   ngsld_geno_opts o{};
   o.log_scale = log_scale;
   o.ignore_miss_data = ignore_miss_data;
   o.on_device = on_device;
   return set_geno_common(c, gl_raw, nullptr, n_sites, n_ind, o, false);
-}
+} NGSLD_CATCH(c)
 
 int ngsld_set_geno_raw_opts(ngsld_ctx *c, const double *gl_raw, uint64_t n_sites, uint64_t n_ind,
-                            const ngsld_geno_opts *opts) {
+                            const ngsld_geno_opts *opts) try {
   if (opts == nullptr) return c ? fail(c, NGSLD_ERR_INVALID, "opts is NULL") : NGSLD_ERR_INVALID;
   return set_geno_common(c, gl_raw, nullptr, n_sites, n_ind, *opts, false);
-}
+} NGSLD_CATCH(c)
 
 int ngsld_set_geno_lkl(ngsld_ctx *c, const double *geno_lkl, const double *maf, uint64_t n_sites, uint64_t n_ind,
-                       int on_device) {
+                       int on_device) try {
   ngsld_geno_opts o{};
   o.on_device = on_device;
   return set_geno_common(c, geno_lkl, maf, n_sites, n_ind, o, true);
-}
+} NGSLD_CATCH(c)
 
-int ngsld_get_maf(ngsld_ctx *c, double *maf_out) {
+int ngsld_get_maf(ngsld_ctx *c, double *maf_out) try {
   if (c == nullptr || maf_out == nullptr) return NGSLD_ERR_INVALID;
   if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "no genotype data set");
   std::memcpy(maf_out, c->h_maf.data(), c->n_sites * sizeof(double));
   return NGSLD_OK;
-}
+} NGSLD_CATCH(c)
 
-int ngsld_set_pos_dist(ngsld_ctx *c, const double *pos_dist) {
+int ngsld_set_pos_dist(ngsld_ctx *c, const double *pos_dist) try {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "set the genotype data before the positions");
   c->planned = false;
@@ -473,9 +487,9 @@ int ngsld_set_pos_dist(ngsld_ctx *c, const double *pos_dist) {
   else
     c->h_pos_dist.assign(pos_dist, pos_dist + c->n_sites);
   return NGSLD_OK;
-}
+} NGSLD_CATCH(c)
 
-int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) {
+int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
   if (c == nullptr || p == nullptr) return NGSLD_ERR_INVALID;
   if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "no genotype data set");
   if (c->h_pos_dist.size() != c->n_sites) {
@@ -572,7 +586,7 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) {
   c->planned = true;
   if (n_pairs) *n_pairs = c->h_row_off[n];
   return NGSLD_OK;
-}
+} NGSLD_CATCH(c)
 
 int ngsld_plan_rows(ngsld_ctx *c, const uint64_t **row_off, const uint32_t **row_end) {
   if (c == nullptr) return NGSLD_ERR_INVALID;
@@ -582,7 +596,7 @@ int ngsld_plan_rows(ngsld_ctx *c, const uint64_t **row_off, const uint32_t **row
   return NGSLD_OK;
 }
 
-int ngsld_set_text_output(ngsld_ctx *c, const char *const *labels, int enable) {
+int ngsld_set_text_output(ngsld_ctx *c, const char *const *labels, int enable) try {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "set the genotype data before the labels");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -607,9 +621,9 @@ int ngsld_set_text_output(ngsld_ctx *c, const char *const *labels, int enable) {
   }
   c->text_mode = true;
   return NGSLD_OK;
-}
+} NGSLD_CATCH(c)
 
-int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_std, void *d_ext, void *hip_stream) {
+int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_std, void *d_ext, void *hip_stream) try {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   if (!c->planned) return fail(c, NGSLD_ERR_INVALID, "ngsld_plan has not been called");
   if (s1_begin > s1_end || s1_end > c->n_sites) return fail(c, NGSLD_ERR_INVALID, "row range out of bounds");
@@ -635,9 +649,9 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
     return check_status(c);
   }
   return NGSLD_OK;
-}
+} NGSLD_CATCH(c)
 
-int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user) {
+int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user) try {
   if (c == nullptr || sink == nullptr) return NGSLD_ERR_INVALID;
   if (!c->planned) return fail(c, NGSLD_ERR_INVALID, "ngsld_plan has not been called");
   if (s1_begin > s1_end || s1_end > c->n_sites) return fail(c, NGSLD_ERR_INVALID, "row range out of bounds");
@@ -836,7 +850,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
   if (rc != NGSLD_OK) return rc;
   return check_status(c);
-}
+} NGSLD_CATCH(c)
 
 int ngsld_last_kernel_time(ngsld_ctx *c, double *total_ms, uint64_t *n_launches, uint64_t *n_pairs) {
   if (c == nullptr) return NGSLD_ERR_INVALID;
@@ -864,7 +878,7 @@ int ngsld_set_tuning(ngsld_ctx *c, uint32_t pairs_per_item, uint64_t batch_pairs
   return NGSLD_OK;
 }
 
-int ngsld_selftest(ngsld_ctx *c) {
+int ngsld_selftest(ngsld_ctx *c) try {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   std::vector<double> in(320), out(68, 0.0);
@@ -901,9 +915,9 @@ int ngsld_selftest(ngsld_ctx *c) {
     }
   }
   return NGSLD_OK;
-}
+} NGSLD_CATCH(c)
 
-int ngsld_window_ends(const double *pos_dist, uint64_t n_sites, const ngsld_params *p, uint32_t *row_end) {
+int ngsld_window_ends(const double *pos_dist, uint64_t n_sites, const ngsld_params *p, uint32_t *row_end) try {
   if (p == nullptr || row_end == nullptr || n_sites == 0 || n_sites >= 0xffffffffull) return NGSLD_ERR_INVALID;
   std::vector<double> pd;
   if (pos_dist == nullptr)
@@ -917,7 +931,7 @@ int ngsld_window_ends(const double *pos_dist, uint64_t n_sites, const ngsld_para
   plan_rows(pd, maf, q, n_sites, ends);
   std::memcpy(row_end, ends.data(), n_sites * sizeof(uint32_t));
   return NGSLD_OK;
-}
+} NGSLD_CATCH((ngsld_ctx *)nullptr)
 
 uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes) {
   PairConfig cfg;

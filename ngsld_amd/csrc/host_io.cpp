@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -191,9 +192,14 @@ inline char *format_row(char *p, const char *label1, const char *label2, double 
 
 }  // namespace
 
+// No exception crosses the C-ABI: host-side out-of-memory comes back as an error code and text.
+#define NGSLD_HOST_CATCH                                                              \
+  catch (const std::bad_alloc &) { return set_err(err, errlen, "out of host memory"); } \
+  catch (...) { return set_err(err, errlen, "unexpected C++ exception"); }
+
 extern "C" {
 
-int ngsld_host_read_pos(const char *path, int header, uint64_t n_sites, ngsld_pos **out, char *err, size_t errlen) {
+int ngsld_host_read_pos(const char *path, int header, uint64_t n_sites, ngsld_pos **out, char *err, size_t errlen) try {
   if (path == nullptr || out == nullptr) return set_err(err, errlen, "invalid argument");
   *out = nullptr;
   std::string text;
@@ -270,7 +276,7 @@ int ngsld_host_read_pos(const char *path, int header, uint64_t n_sites, ngsld_po
   }
   *out = p;
   return NGSLD_OK;
-}
+} NGSLD_HOST_CATCH
 
 const double *ngsld_host_pos_dist(const ngsld_pos *p) { return p ? p->pos_dist.data() : nullptr; }
 const char *ngsld_host_label(const ngsld_pos *p, uint64_t site) {
@@ -291,7 +297,7 @@ int ngsld_host_geno_size_ok(uint64_t file_size, uint64_t n_ind, uint64_t n_sites
 }
 
 int ngsld_host_read_geno_bin(const char *path, uint64_t n_ind, uint64_t n_sites, double *out_raw, char *err,
-                             size_t errlen) {
+                             size_t errlen) try {
   if (path == nullptr || out_raw == nullptr) return set_err(err, errlen, "invalid argument");
   const uint64_t total = n_sites * n_ind * 3 * sizeof(double);
   // A plain (not gzip-compressed) regular file is read with pread by the host threads (ngsld_host_set_threads) straight
@@ -360,10 +366,10 @@ int ngsld_host_read_geno_bin(const char *path, uint64_t n_ind, uint64_t n_sites,
   gzclose(fh);
   if (!at_eof) return set_err(err, errlen, "GENO file not at EOF. Check GENO file and number of sites!");
   return NGSLD_OK;
-}
+} NGSLD_HOST_CATCH
 
 int ngsld_host_read_geno_bin_range(const char *path, uint64_t n_ind, uint64_t site_begin, uint64_t n_sites,
-                                   double *out_raw, char *err, size_t errlen) {
+                                   double *out_raw, char *err, size_t errlen) try {
   if (path == nullptr || out_raw == nullptr) return set_err(err, errlen, "invalid argument");
   const uint64_t site_bytes = n_ind * 3 * sizeof(double);
   const uint64_t off = site_begin * site_bytes, total = n_sites * site_bytes;
@@ -396,12 +402,12 @@ int ngsld_host_read_geno_bin_range(const char *path, uint64_t n_ind, uint64_t si
   if (got != total)
     return set_err(err, errlen, "GENO file at premature EOF. Check GENO file and number of sites!");
   return NGSLD_OK;
-}
+} NGSLD_HOST_CATCH
 
 void ngsld_host_set_threads(int n_threads) { g_host_threads.store(n_threads < 1 ? 1 : n_threads); }
 
 int ngsld_host_read_geno_text(const char *path, int in_probs, int log_scale, uint64_t n_ind, uint64_t n_sites,
-                              double *out_raw, int *out_log_scale, char *err, size_t errlen) {
+                              double *out_raw, int *out_log_scale, char *err, size_t errlen) try {
   if (path == nullptr || out_raw == nullptr || out_log_scale == nullptr) return set_err(err, errlen, "invalid argument");
   std::string text;
   if (!slurp(path, text)) return set_err(err, errlen, "cannot open GENO file!");
@@ -492,7 +498,7 @@ int ngsld_host_read_geno_text(const char *path, int in_probs, int log_scale, uin
   for (int t = 0; t < nt; ++t)
     if (errors[t]) return set_err(err, errlen, errors[t]);
   return NGSLD_OK;
-}
+} NGSLD_HOST_CATCH
 
 size_t ngsld_host_format_header(char *buf, size_t cap, int extend_out) {
   const int n = std::snprintf(
@@ -515,7 +521,7 @@ size_t ngsld_host_format_double(char *buf, size_t cap, double v, int decimals) {
 }
 
 int ngsld_host_write_batch(const ngsld_batch *b, const ngsld_pos *pos, const double *pos_dist, const double *maf,
-                           int n_threads, int fd) {
+                           int n_threads, int fd) try {
   if (b == nullptr || maf == nullptr) return NGSLD_ERR_INVALID;
   if (b->n_items == 0 || b->n_pairs == 0) return NGSLD_OK;
   if (n_threads < 1) n_threads = 1;
@@ -590,7 +596,14 @@ int ngsld_host_write_batch(const ngsld_batch *b, const ngsld_pos *pos, const dou
     out_len[(size_t)t] = (size_t)(p - buf.data());
   };
   std::vector<std::thread> th;
-  for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+  th.reserve((size_t)n_threads);
+  for (int t = 1; t < n_threads; ++t) {
+    try {
+      th.emplace_back(work, t);
+    } catch (...) {  // no more threads to be had: this share is formatted by the caller
+      work(t);
+    }
+  }
   work(0);
   for (auto &x : th) x.join();
   for (int t = 0; t < n_threads; ++t)
@@ -606,6 +619,8 @@ int ngsld_host_write_batch(const ngsld_batch *b, const ngsld_pos *pos, const dou
     }
   }
   return NGSLD_OK;
+} catch (...) {
+  return NGSLD_ERR_NOMEM;
 }
 
 }  // extern "C"

@@ -56,7 +56,12 @@ int ngsld_plan_slabs(const double *pos_dist, uint64_t n_sites, const ngsld_param
                      ngsld_slab *slabs, uint64_t cap, uint64_t *n_slabs) {
   if (params == nullptr || slabs == nullptr || n_slabs == nullptr || n_sites == 0 || max_slab_sites == 0)
     return NGSLD_ERR_INVALID;
-  std::vector<uint32_t> row_end(n_sites);
+  std::vector<uint32_t> row_end;
+  try {
+    row_end.resize(n_sites);
+  } catch (const std::bad_alloc &) {
+    return NGSLD_ERR_NOMEM;
+  }
   const int rc = ngsld_window_ends(pos_dist, n_sites, params, row_end.data());
   if (rc != NGSLD_OK) return rc;
   uint64_t k = 0, r0 = 0;
@@ -98,7 +103,14 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
     set_err(err, errlen, "a streamed run reads host memory");
     return NGSLD_ERR_INVALID;
   }
-  std::vector<ngsld_slab> slabs(n_sites);
+  std::vector<ngsld_slab> slabs;
+  std::vector<uint64_t> slab_pairs;
+  try {
+    slabs.resize(n_sites);
+  } catch (const std::bad_alloc &) {
+    set_err(err, errlen, "cannot allocate the slab table");
+    return NGSLD_ERR_NOMEM;
+  }
   uint64_t n_slabs = 0;
   int rc = ngsld_plan_slabs(pos_dist, n_sites, params, max_slab_sites, slabs.data(), slabs.size(), &n_slabs);
   if (rc == NGSLD_ERR_NOMEM) {
@@ -142,7 +154,7 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
   bool stop = false;
   int load_rc = NGSLD_OK;
   std::string load_msg;
-  std::vector<uint64_t> slab_pairs(n_slabs, 0);
+  slab_pairs.assign(n_slabs, 0);  // (n_slabs <= n_sites words: not guarded separately)
 
   std::thread loader([&]() {
     uint64_t maf_done = 0;  // maf_out[0, maf_done) is final
@@ -157,6 +169,7 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
       const uint64_t m = sl.site_end - sl.row_begin;
       int r = NGSLD_OK;
       std::string msg;
+      try {  // host allocations below: an exception must not leave this thread
       if (read(read_user, sl.row_begin, m, host[b].data()) != 0) {
         r = NGSLD_ERR_INVALID;
         msg = "cannot read the genotype data of a slab";
@@ -186,6 +199,10 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
           if (r == NGSLD_OK && text_output) r = ngsld_set_text_output(ctx[b], labels ? labels + sl.row_begin : nullptr, 1);
         }
         if (r != NGSLD_OK) msg = ngsld_last_error(ctx[b]);
+      }
+      } catch (...) {
+        r = NGSLD_ERR_NOMEM;
+        msg = "out of host memory while loading a slab";
       }
       std::lock_guard<std::mutex> lk(mu);
       if (r != NGSLD_OK) {
