@@ -881,7 +881,7 @@ int ngsld_set_tuning(ngsld_ctx *c, uint32_t pairs_per_item, uint64_t batch_pairs
 int ngsld_selftest(ngsld_ctx *c) try {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
-  std::vector<double> in(320), out(68, 0.0);
+  std::vector<double> in(320), out(71, 0.0);
   uint64_t st = 0x9E3779B97F4A7C15ull;
   for (auto &v : in) {
     st = st * 6364136223846793005ull + 1442695040888963407ull;
@@ -897,12 +897,14 @@ int ngsld_selftest(ngsld_ctx *c) try {
   HIP_TRY(c, hipMemcpy(out.data(), d_out.p, out.size() * sizeof(double), hipMemcpyDeviceToHost));
   d_in.release();
   d_out.release();
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < 7; ++k) {  // 0..3: wave_sum4, 4..6: wave_sum3 (the matrix-pipe reduction of the EM loop)
+    const int v = k < 4 ? k : k - 4;
+    const double got = k < 4 ? out[k] : out[68 + v];
     long double ref = 0;
-    for (int l = 0; l < 64; ++l) ref += in[k * 64 + l];
-    if (std::fabs((double)(out[k] - ref)) > 1e-12 * std::fabs((double)ref)) {
+    for (int l = 0; l < 64; ++l) ref += in[v * 64 + l];
+    if (!(std::fabs((double)(got - ref)) <= 1e-14 * std::fabs((double)ref))) {
       char buf[160];
-      std::snprintf(buf, sizeof(buf), "wave_sum4 value %d: got %.17g expected %.17Lg", k, out[k], ref);
+      std::snprintf(buf, sizeof(buf), "%s value %d: got %.17g expected %.17Lg", k < 4 ? "wave_sum4" : "wave_sum3", v, got, ref);
       return fail(c, NGSLD_ERR_DEVICE, buf);
     }
   }

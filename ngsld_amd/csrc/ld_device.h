@@ -135,8 +135,59 @@ __device__ __forceinline__ void wave_sum4(double &t0, double &t1, double &t2, do
   t3 = read_lane(w, 48);
 }
 
+// Three values through the MATRIX pipe -- built, measured, NOT used (NGSLD_MFMA_REDUCE = 0).  v_mfma_f64_4x4x4_4b is a
+// cross-lane adder: D_b[i][j] = sum_k A_b[i][k] B_b[k][j] with (measured, tools/probe_mfma_f64.hip)
+//   block b = (lane / 4) % 4;   A: i = lane % 4, k = lane / 16;   B: j = lane % 4, k = lane / 16;   D: i = lane / 16, j = lane % 4
+// i.e. it sums over the four 16-lane ROWS and hands the A operand's position-in-quad (lane % 4) to the output ROW.
+//   stage 1  e_v = mfma(t_v, ones): lane l holds sum_rows t_v[(l / 16) + 4 b + 16 k] -- 16 column sums, spread over
+//            (row, b), the same in the four lanes of a quad
+//   stage 2  (1) p = sum_v mfma(e_v, sel_v) chained through C, sel_v[k][j] = (j == v): lane l holds the sum of value
+//            (l % 4)'s four column sums of quad b;  (2) the e_v packed by lane % 4 with selects, one mfma(w, ones): row v
+//            holds value v's quad sums
+//   stage 3  the four quads of a row: two DPP levels (row_ror:4, row_ror:8) on the ONE packed register
+// On paper 6 (or 4) MFMA issues + 4 DPP moves + 2 adds + 6 v_readlane replace 6 v_permlane*_swap (~14 cycles of issue
+// each) + 2 moves + 8 DPP moves + 7 adds + 6 v_readlane.  Same-box A/B on the bench (tools/ab.sh): variant 1 -2.3 %,
+// variant 2 -1.7 % against the swap / DPP reduction: the f64 matrix peak of gfx950 EQUALS its f64 vector peak, and the
+// measurement says why -- an f64 MFMA is not free issue beside the f64 VALU stream, a 4-pass one costs more than the
+// ~14-cycle swap it replaces.  Kept as a build-time switch with its self test (ngsld_selftest covers wave_sum3).
+#ifndef NGSLD_MFMA_REDUCE
+#define NGSLD_MFMA_REDUCE 0  // build-time A/B switch: 0 = the permlane-swap / DPP reduction below, 1 / 2 = the variants above
+#endif
+__device__ __forceinline__ void wave_sum3_mfma(double &t1, double &t2, double &t3) {
+  const unsigned q = threadIdx.x & 3u;  // lane % 4 (a wavefront starts at a multiple of 64)
+  const double one = 1.0;
+  const double sel0 = q == 0u ? 1.0 : 0.0, sel1 = q == 1u ? 1.0 : 0.0, sel2 = q == 2u ? 1.0 : 0.0;
+  const double e1 = __builtin_amdgcn_mfma_f64_4x4x4f64(t1, one, 0.0, 0, 0, 0);
+  const double e2 = __builtin_amdgcn_mfma_f64_4x4x4f64(t2, one, 0.0, 0, 0, 0);
+  const double e3 = __builtin_amdgcn_mfma_f64_4x4x4f64(t3, one, 0.0, 0, 0, 0);
+  double p;
+  if (NGSLD_MFMA_REDUCE == 2) {  // variant: the three stage-1 results packed by lane % 4 with selects, ONE stage-2 MFMA
+    const double w = q == 0u ? e1 : (q == 1u ? e2 : e3);
+    // as the A operand, position-in-quad i' = lane % 4 goes to the output ROW: row v ends up with value v's quad sums
+    p = __builtin_amdgcn_mfma_f64_4x4x4f64(w, one, 0.0, 0, 0, 0);
+    p += dpp_mov<0x124>(p);
+    p += dpp_mov<0x128>(p);
+    t1 = read_lane(p, 0);
+    t2 = read_lane(p, 16);
+    t3 = read_lane(p, 32);
+    return;
+  }
+  p = __builtin_amdgcn_mfma_f64_4x4x4f64(e1, sel0, 0.0, 0, 0, 0);
+  p = __builtin_amdgcn_mfma_f64_4x4x4f64(e2, sel1, p, 0, 0, 0);
+  p = __builtin_amdgcn_mfma_f64_4x4x4f64(e3, sel2, p, 0, 0, 0);
+  p += dpp_mov<0x124>(p);  // row_ror:4
+  p += dpp_mov<0x128>(p);  // row_ror:8
+  t1 = read_lane(p, 0);
+  t2 = read_lane(p, 1);
+  t3 = read_lane(p, 2);
+}
+
 // Three values: same scheme, the third one folded with itself (rows 1 and 3 both end up holding its sum).
 __device__ __forceinline__ void wave_sum3(double &t1, double &t2, double &t3) {
+  if (NGSLD_MFMA_REDUCE) {
+    wave_sum3_mfma(t1, t2, t3);
+    return;
+  }
   double z12 = fold32(t1, t2);
   double z33 = fold32(t3, t3);
   double w = fold16(z12, z33);  // row0: t1, row1: t3, row2: t2, row3: t3

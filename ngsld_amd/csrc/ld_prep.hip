@@ -229,7 +229,8 @@ hipError_t launch_items(const ItemArgs &a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// Self test: out[0..3] = wave_sum4 of in[k*64 + lane]; out[4 + lane] = rcp_refined(in[256 + lane]).
+// Self test: out[0..3] = wave_sum4 of in[k*64 + lane]; out[4 + lane] = rcp_refined(in[256 + lane]);
+// out[68..70] = wave_sum3 of in[k*64 + lane], k = 0..2.
 __global__ void selftest_kernel(const double *in, double *out) {
   const int lane = threadIdx.x;
   double t0 = in[lane], t1 = in[64 + lane], t2 = in[128 + lane], t3 = in[192 + lane];
@@ -241,6 +242,13 @@ __global__ void selftest_kernel(const double *in, double *out) {
     out[3] = t3;
   }
   out[4 + lane] = rcp_refined(in[256 + lane]);
+  double u1 = in[lane], u2 = in[64 + lane], u3 = in[128 + lane];
+  wave_sum3(u1, u2, u3);
+  if (lane == 0) {
+    out[68] = u1;
+    out[69] = u2;
+    out[70] = u3;
+  }
 }
 
 hipError_t launch_selftest(const double *in, double *out, hipStream_t stream) {
