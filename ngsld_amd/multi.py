@@ -4,10 +4,11 @@
         --geno in.glf --n_ind 500 --n_sites 100000 --pos in.pos --max_kb_dist 100 --extend_out --out out.ld
 
 Every SNP pair is independent given the read-only GL matrix (the reference exploits this per s1,
-ngsLD.cpp:159-186), so the design of SURVEY §8(e) is: rank 0 reads the genotype file, ONE collective (a
-broadcast over RCCL/xGMI) hands the raw matrix to every GPU, ranks take contiguous row ranges balanced by pair
-count and hold only their slab (rows + window halo), and each rank writes its own shard `<out>.rank<k>` in
-(site1, site2) order; rank 0's shard carries the header, so `cat out.rank0 out.rank1 ...` is the single-GPU
+ngsLD.cpp:159-186), so the design of SURVEY §8(e) is: ranks take contiguous row ranges balanced by pair count and
+hold only their slab (rows + window halo).  All-pairs runs (every rank needs every site): rank 0 reads the genotype
+file and ONE collective (a broadcast over RCCL/xGMI) hands the raw matrix to every GPU.  Windowed runs on a binary
+file: every rank reads its own slab straight from the file, no collective and no rank with the whole matrix.
+Each rank writes its own shard `<out>.rank<k>` in (site1, site2) order; rank 0's shard carries the header, so `cat out.rank0 out.rank1 ...` is the single-GPU
 output.  Flags are the reference's (parse_args.cpp:35-59) plus --device-base.
 """
 from __future__ import annotations
@@ -80,29 +81,12 @@ def main(argv=None) -> int:
         raise SystemExit("can only call genotypes from likelihoods/probabilities!")
     seed = a.seed if a.seed is not None else int.from_bytes(os.urandom(4), "little")
 
-    # ---- rank 0 reads; one broadcast distributes the raw matrix (+ the seed when it was not given) ----
     n_sites, n_ind = a.n_sites, a.n_ind
-    capi.lib().ngsld_host_set_threads(a.n_threads)
-    meta = torch.zeros(2, dtype=torch.int64, device=dev)
-    if rank == 0:
-        if binary:
-            if not capi.lib().ngsld_host_geno_size_ok(os.path.getsize(a.geno), n_ind, n_sites):
-                raise SystemExit("invalid/corrupt genotype input file!")
-            raw_h, is_log = capi.read_geno_bin(a.geno, n_ind, n_sites), a.log_scale
-        else:
-            raw_h, is_log = capi.read_geno_text(a.geno, a.probs, a.log_scale, n_ind, n_sites)
-        raw = torch.from_numpy(raw_h).to(dev)
-        meta[0], meta[1] = int(is_log), seed
-    else:
-        raw = torch.empty((n_sites, n_ind, 3), dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.broadcast(meta, src=0)
-    shard.broadcast_matrix(raw, src=0)
-    is_log, seed = bool(meta[0].item()), int(meta[1].item())
-
-    # ---- rows of this rank (balanced by candidate pairs), its slab, its engine ----
     L = capi.lib()
     import ctypes as C
+    L.ngsld_host_set_threads(a.n_threads)
+
+    # ---- rows of this rank (balanced by candidate pairs) and its slab: rows + window halo ----
     pos_h = C.c_void_p()
     pos_dist = None
     if pos_path:
@@ -115,6 +99,44 @@ def main(argv=None) -> int:
     counts = row_end - (np.arange(n_sites, dtype=np.int64) + 1)
     lo, hi = shard.split_rows(counts, world)[rank]
     slab_lo, slab_hi = shard.slab_for_rows(row_end, lo, hi)
+
+    # ---- the genotype data ----
+    # Windowed run on a plain binary file (BASELINE configs[2] / configs[4]): every rank reads ITS slab straight
+    # from the file (pread on [slab_lo, slab_hi), the ranks' reads run side by side) and uploads it over its own PCIe link:
+    # no rank ever holds the whole matrix (1,000,000 x 2,000 is 48 GB; a rank's slab of it 6 GB) and there is no collective.
+    # Anything else (all pairs: every rank needs every site; text or stdin input: one reader) is read by rank 0 and handed
+    # to every GPU by ONE broadcast over RCCL / xGMI.
+    slab_read = binary and a.geno != "-" and world > 1 and (a.max_kb_dist > 0 or a.max_snp_dist > 0)
+    expect = os.environ.get("NGSLD_MULTI_EXPECT")                  # tests: which distribution path must be taken
+    if expect and expect != ("slab" if slab_read else "broadcast"):
+        raise SystemExit(f"ngsld_amd.multi: expected the {expect} path")
+    meta = torch.zeros(2, dtype=torch.int64, device=dev)
+    raw = None
+    if slab_read:
+        if not L.ngsld_host_geno_size_ok(os.path.getsize(a.geno), n_ind, n_sites):
+            raise SystemExit("invalid/corrupt genotype input file!")
+        meta[0], meta[1] = int(a.log_scale), seed
+        if world > 1:
+            dist.broadcast(meta, src=0)       # (the seed, when it was drawn here rather than given)
+        slab = capi.read_geno_bin_range(a.geno, n_ind, slab_lo, slab_hi - slab_lo) if hi > lo else None
+    else:
+        if rank == 0:
+            if binary:
+                if not L.ngsld_host_geno_size_ok(os.path.getsize(a.geno), n_ind, n_sites):
+                    raise SystemExit("invalid/corrupt genotype input file!")
+                raw_h, is_log = capi.read_geno_bin(a.geno, n_ind, n_sites), a.log_scale
+            else:
+                raw_h, is_log = capi.read_geno_text(a.geno, a.probs, a.log_scale, n_ind, n_sites)
+            raw = torch.from_numpy(raw_h).to(dev)
+            meta[0], meta[1] = int(is_log), seed
+        else:
+            raw = torch.empty((n_sites, n_ind, 3), dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.broadcast(meta, src=0)
+        shard.broadcast_matrix(raw, src=0)
+        slab = raw[slab_lo:slab_hi]
+    is_log, seed = bool(meta[0].item()), int(meta[1].item())
+
     total = 0
     with open(f"{a.out}.rank{rank}", "wb") as fh:
         if rank == 0:
@@ -122,8 +144,7 @@ def main(argv=None) -> int:
             fh.flush()
         if hi > lo:
             eng = capi.Engine(dev_index)
-            slab = raw[slab_lo:slab_hi]
-            eng.set_geno_raw(slab.data_ptr(), n_sites=slab_hi - slab_lo, n_ind=n_ind, log_scale=is_log,
+            eng.set_geno_raw(slab if slab_read else slab.data_ptr(), n_sites=slab_hi - slab_lo, n_ind=n_ind, log_scale=is_log,
                              ignore_miss_data=a.ignore_miss_data, text=not binary, call_geno=call)
             del slab, raw
             local_pd = None if pos_dist is None else pos_dist[slab_lo:slab_hi].copy()
@@ -148,7 +169,8 @@ def main(argv=None) -> int:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and a.verbose >= 1:
-        print(f"ngsld_amd.multi: {total} pairs on {world} GPU(s); shards {a.out}.rank0 .. rank{world - 1}", file=sys.stderr)
+        print(f"ngsld_amd.multi: {total} pairs on {world} GPU(s), {'per-rank slab reads' if slab_read else 'one broadcast'}; "
+              f"shards {a.out}.rank0 .. rank{world - 1}", file=sys.stderr)
     return 0
 
 
