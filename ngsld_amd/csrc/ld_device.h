@@ -38,6 +38,9 @@ constexpr bool kDrop0 = NGSLD_DROP0 != 0;
 #ifndef NGSLD_SETPRIO
 #define NGSLD_SETPRIO 1  // build-time A/B switch: issue priority raised through the serial phases of an EM iteration
 #endif
+#ifndef NGSLD_WN_ROWS
+#define NGSLD_WN_ROWS 1  // build-time A/B switch: several wavefronts per pair post their partial sums without v_readlane
+#endif
 #ifndef NGSLD_EARLY_EPS
 #define NGSLD_EARLY_EPS 1  // build-time A/B switch: the convergence test looks at one change first (see em_pair)
 #endif
@@ -201,6 +204,20 @@ __device__ __forceinline__ void wave_sum3(double &t1, double &t2, double &t3) {
   t1 = read_lane(w, 0);
   t3 = read_lane(w, 16);
   t2 = read_lane(w, 32);
+}
+
+// The same reduction stopped before the v_readlane: every lane of row 0 holds the sum of t1, row 1 (and 3) that of t3,
+// row 2 that of t2.  For the kernels where several wavefronts share a pair: lanes 0 / 16 / 32 post their row's total
+// straight to the exchange buffer.
+__device__ __forceinline__ double wave_sum3_rows(double t1, double t2, double t3) {
+  double z12 = fold32(t1, t2);
+  double z33 = fold32(t3, t3);
+  double w = fold16(z12, z33);
+  w += dpp_mov<0x128>(w);
+  w += dpp_mov<0x124>(w);
+  w += dpp_mov<0x4E>(w);
+  w += dpp_mov<0xB1>(w);
+  return w;
 }
 
 // One value, no permlane swaps (each costs ~14 cycles of issue): four DPP levels inside the rows, then the GFX9 row
@@ -481,21 +498,36 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     double t1 = fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1)));
     double t2 = fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3)));
     double t3 = fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4)));
-    if (kDrop)
-      wave_sum3(t1, t2, t3);
-    else
-      wave_sum4(t0, t1, t2, t3);
-    if (WAVES > 1) {
+    if (NGSLD_WN_ROWS && WAVES > 1 && kDrop && !NGSLD_MFMA_REDUCE) {
+      // several wavefronts per pair, three-value form: the row totals go to the exchange buffer from the lanes that hold
+      // them (no v_readlane, no copies back to VGPRs), and every wavefront adds the partials up in the same order -- the
+      // new frequencies must be the same bit pattern in all of them, they decide together when to leave the loop
+      const double w = wave_sum3_rows(t1, t2, t3);
       const int par = (int)(n_iter & 1u);
-      if (lane == 0) {
-        if (!kDrop) xch[par][sub][0] = t0;
-        xch[par][sub][1] = t1; xch[par][sub][2] = t2; xch[par][sub][3] = t3;
-      }
+      const int row = lane >> 4;
+      if ((lane & 15) == 0 && row < 3) xch[par][sub][row == 0 ? 1 : (row == 1 ? 3 : 2)] = w;
       lds_barrier();
-      t0 = t1 = t2 = t3 = 0.0;
-      for (int w = 0; w < WAVES; ++w) {
-        if (!kDrop) t0 += xch[par][w][0];
-        t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
+      t1 = xch[par][0][1]; t2 = xch[par][0][2]; t3 = xch[par][0][3];
+      for (int v = 1; v < WAVES; ++v) {
+        t1 += xch[par][v][1]; t2 += xch[par][v][2]; t3 += xch[par][v][3];
+      }
+    } else {
+      if (kDrop)
+        wave_sum3(t1, t2, t3);
+      else
+        wave_sum4(t0, t1, t2, t3);
+      if (WAVES > 1) {
+        const int par = (int)(n_iter & 1u);
+        if (lane == 0) {
+          if (!kDrop) xch[par][sub][0] = t0;
+          xch[par][sub][1] = t1; xch[par][sub][2] = t2; xch[par][sub][3] = t3;
+        }
+        lds_barrier();
+        t0 = t1 = t2 = t3 = 0.0;
+        for (int w = 0; w < WAVES; ++w) {
+          if (!kDrop) t0 += xch[par][w][0];
+          t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
+        }
       }
     }
     const bool scaled = kPair && kTree && kScaled;
