@@ -1337,13 +1337,18 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
           double n0, n1, n2, n3;
           em_step(PairedTag(), n0, n1, n2, n3);
           if (__any(!done && !(n1 < 2.0))) break;  // an odd step (one NaN reciprocal poisons every R, see em_pair)
-          const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
-          if (!done) {
-            f0 = n0; f1 = n1; f2 = n2; f3 = n3;
-            if (eps < kEpsilon) {  // gen_func.cpp:1054-1055
+          // as in em_pair: eps is at least the change of hap 1, and while that alone is above EPSILON in every live
+          // group the other three differences are not formed
+          if (!NGSLD_EARLY_EPS || __any(!done && fabs(n1 - f1) < kEpsilon)) {
+            const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
+            if (!done && eps < kEpsilon) {  // gen_func.cpp:1054-1055
               done = true;
               n_iter = itn;
+              f0 = n0; f1 = n1; f2 = n2; f3 = n3;
             }
+          }
+          if (!done) {
+            f0 = n0; f1 = n1; f2 = n2; f3 = n3;
           }
           if (__all(done)) {
             all_done = true;
