@@ -1298,7 +1298,8 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
         for (int j = 0; j < SLOTS; ++j) sv[j] = slot_s(j, MASKED);
         if (NGSLD_SETPRIO) __builtin_amdgcn_s_setprio(3);
         if (!MASKED) sv[SLOTS - 1] += pad;  // (kept as a separate add here: folding it into the first FMA costs registers)
-        RcpTree<SLOTS>::down(sv, rcp_refined(RcpTree<SLOTS>::prod(sv)), rv);
+        // 1/x rides on the root inverse (as in em_pair): every R, and with them the three t_k, come out divided by x
+        RcpTree<SLOTS>::down(sv, rcp_refined(RcpTree<SLOTS>::prod(sv)) * inv_x, rv);
         if (NGSLD_SETPRIO) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
         for (int j = 0; j < SLOTS; ++j) slot_acc(j, rv[j]);
@@ -1314,12 +1315,16 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       const double t1 = group_sum<G>(fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1))));
       const double t2 = group_sum<G>(fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3))));
       const double t3 = group_sum<G>(fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4))));
-      n1 = t1 * inv_x; n2 = t2 * inv_x; n3 = t3 * inv_x;
+      if (kT) {
+        n1 = t1; n2 = t2; n3 = t3;  // already divided by x
+      } else {
+        n1 = t1 * inv_x; n2 = t2 * inv_x; n3 = t3 * inv_x;
+      }
       if (kDrop) {  // the first frequency is what the other three leave (see em_pair)
         n0 = 1.0 - ((n1 + n2) + n3);
       } else {
         const double t0 = group_sum<G>(fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0))));
-        n0 = t0 * inv_x;
+        n0 = kT ? t0 : t0 * inv_x;
       }
     };
     bool done = !active;
