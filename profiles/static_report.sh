@@ -24,15 +24,28 @@ grep -E "Function Name|VGPRs:|AGPRs|ScratchSize|Occupancy|LDS Size|SGPRs:" res.t
   | sed 's/_ZN5ngsld//; s/EvNS_8PairArgsE//'
 S=k-hip-amdgcn-amd-amdhsa-gfx950.s
 awk '/^_ZN5ngsld18pair_ld_run_kernelILi8ELb0EEEvNS_8PairArgsE:/,/s_endpgm/' $S > pf.s
-L=$(grep -n "Inner Loop Header: Depth=2" pf.s | tail -1 | cut -d: -f1)
-# the hot path of one EM iteration = the loop header block up to its first branch (the shared-reciprocal step and its
-# reduction); what follows in the loop is the single-reciprocal redo path and the convergence bookkeeping
-E=$(awk -v s=$L 'NR>s && /s_cbranch/ {print NR; exit}' pf.s)
-X=$(awk -v s=$L 'NR>s && /^\.LBB0_[0-9]+:.*Depth=1$/ {print NR; exit}' pf.s)
 echo
-echo "== pair_ld_run_kernel<8,false>: instruction mix of the hot block of one EM iteration (ISA lines $L..$E) =="
-sed -n "${L},${E}p" pf.s | grep -v "^\s*;" | grep -v "^\." | awk '{print $1}' | sort | uniq -c | sort -rn
-echo
-echo "== same kernel: whole EM loop incl. the redo path and the convergence test (ISA lines $L..$X) =="
-sed -n "${L},${X}p" pf.s | grep -v "^\s*;" | grep -v "^\." | awk '{print $1}' | sort | uniq -c | sort -rn
+echo "== pair_ld_run_kernel<8,false>: instruction mix of the hot block of one EM iteration =="
+echo "   (the basic block with the most f64 FMAs: the shared-reciprocal step and its reduction, up to the sanity branch;"
+echo "    the convergence test that follows is another ~12 VALU instructions on its common path)"
+python3 - pf.s <<'PY'
+import re, sys
+from collections import Counter
+blocks, cur = [], []
+for l in open(sys.argv[1]):
+    if re.match(r'^\.LBB', l) or 's_cbranch' in l or 's_branch' in l:
+        if cur:
+            blocks.append(cur)
+        cur = []
+    else:
+        t = l.strip()
+        if t and not t.startswith(';') and not t.startswith('.'):
+            cur.append(t.split()[0])
+if cur:
+    blocks.append(cur)
+hot = max(blocks, key=lambda b: sum(1 for x in b if x.startswith('v_fma')))
+for k, v in sorted(Counter(hot).items(), key=lambda kv: -kv[1]):
+    print(f"{v:7d} {k}")
+print(f"{len(hot):7d} instructions in the block")
+PY
 rm -rf $T
