@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--ignore-miss", action="store_true", help="run the --ignore_miss_data kernels (not the headline config)")
     ap.add_argument("--rnd-sample", type=float, default=1.0, help="--rnd_sample of the plan (not the headline config)")
     ap.add_argument("--sink", action="store_true", help="also time ngsld_run (records copied to pinned host memory)")
+    ap.add_argument("--hard-calls", action="store_true",
+                    help="hard-call the synthetic likelihoods (argmax -> 1/0/0 triples): the genotype-combination kernel (not the headline config)")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "hbm_traffic.json"))
     return ap.parse_args()
 
@@ -131,6 +133,8 @@ def main():
         raw = synth.make_gl_torch(n_sites, n_ind, args.seed, dev, depth=args.depth)
     else:
         raw = torch.empty((n_sites, n_ind, 3), dtype=torch.float64, device=dev)
+    if args.hard_calls and rank == 0:
+        raw = torch.nn.functional.one_hot(raw.argmax(dim=2), 3).to(torch.float64).contiguous()
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
     t_bc = time.perf_counter()
@@ -160,6 +164,7 @@ def main():
     assert args.rnd_sample < 1.0 or n_pairs == int(counts[lo:hi].sum()), "engine plan and host mirror disagree on the pair count"
 
     raw_head = None
+    family = eng.pair_kernel()
     if rank == 0 and world == 1 and not args.no_cpu and not args.ignore_miss and args.rnd_sample >= 1.0:
         head = min(n_sites, 12_000)
         raw_head = raw[:head].cpu().numpy()
@@ -242,7 +247,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic binary GL, {args.sites} sites/GPU x {n_ind} ind, depth {args.depth:g}, "
                                    f"--max_kb_dist {args.max_kb} {'windowed' if args.max_kb else 'all pairs'}, --extend_out"
-                                   + (" (BASELINE configs[2])" if (args.sites, n_ind, args.max_kb, args.max_gap) == (100_000, 500, 100, 200) else ""),
+                                   + (", hard-called" if args.hard_calls else "")
+                                   + (" (BASELINE configs[2])" if (args.sites, n_ind, args.max_kb, args.max_gap, args.hard_calls) == (100_000, 500, 100, 200, False) else ""),
                        "n_sites_total": n_sites, "pairs_per_step": total_pairs,
                        "mean_executed_em_iterations": round(mean_exec, 3),
                        "parallelism": f"rows sharded by pair count over {world} GPU(s), no data-path collective",
@@ -251,10 +257,10 @@ def main():
                        "host_handoff_pairs_per_s_rank0": sink_rate},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("pair_ld_group_kernel" if n_ind <= 128 or (n_ind <= 256 and ((n_ind + 31) // 32) % 2)
-                                    else "pair_ld_run_kernel" if n_ind <= 512
-                                    else "pair_ld_kernel (multi-wavefront)" if n_ind <= 4096
-                                    else "pair_ld_stream_kernel"),
+                         "kernel": {"group": "pair_ld_group_kernel", "run": "pair_ld_run_kernel", "wave": "pair_ld_pf_kernel",
+                                    "multi": "pair_ld_kernel (multi-wavefront)", "stream": "pair_ld_stream_kernel",
+                                    "direct": "pair_ld_kernel (no prefetch)",
+                                    "hard": "pair_ld_hard_kernel (genotype-combination counts)"}.get(family, family),
                          "kernel_ms_per_launch": launch_s * 1e3,
                          "algorithmic_bytes_per_pair": bytes_pair,
                          "fp64_valu": {"achieved": fp64_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

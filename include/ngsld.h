@@ -171,6 +171,12 @@ int ngsld_run_device(ngsld_ctx *ctx, uint64_t s1_begin, uint64_t s1_end, void *d
  * HIP events on the stream they ran on (synchronises that stream).  Any pointer may be NULL. */
 int ngsld_last_kernel_time(ngsld_ctx *ctx, double *total_ms, uint64_t *n_launches, uint64_t *n_pairs);
 
+/* Which pair kernel family the genotype data set last will run on: "group" (8 / 16 / 32 lanes per pair), "run" / "wave"
+ * (one wavefront per pair), "multi" (several wavefronts per pair), "stream", "direct" (A/B baseline), or "hard" -- every
+ * likelihood triple is a called genotype or "no data" (text genotypes, --call_geno: ngsLD.cpp:92-98,
+ * read_data.cpp:83-99), the pairs run on their 16 genotype-combination counts.  "" before any data is set. */
+const char *ngsld_pair_kernel(const ngsld_ctx *ctx);
+
 /* Tuning knobs (optional): pairs per work item, max pairs per batch of ngsld_run. 0 keeps the default. */
 int ngsld_set_tuning(ngsld_ctx *ctx, uint32_t pairs_per_item, uint64_t batch_pairs);
 

@@ -81,7 +81,7 @@ SYMBOLS = [
     "ngsld_version", "ngsld_create", "ngsld_destroy", "ngsld_last_error", "ngsld_set_geno_raw",
     "ngsld_set_geno_raw_opts", "ngsld_set_geno_lkl",
     "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device", "ngsld_set_text_output",
-    "ngsld_last_kernel_time", "ngsld_set_tuning", "ngsld_selftest",
+    "ngsld_last_kernel_time", "ngsld_pair_kernel", "ngsld_set_tuning", "ngsld_selftest",
     "ngsld_window_ends", "ngsld_plan_slabs", "ngsld_slab_sites_for_budget", "ngsld_device_memory", "ngsld_run_streamed", "ngsld_run_streamed_text",
     "ngsld_host_read_geno_bin_range",
     "ngsld_host_set_threads", "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos", "ngsld_host_pos_slice",
@@ -135,6 +135,9 @@ def lib() -> C.CDLL:
             L.ngsld_set_text_output.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int]
         L.ngsld_last_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
         L.ngsld_set_tuning.argtypes = [vp, C.c_uint32, u64]
+        if hasattr(L, "ngsld_pair_kernel"):
+            L.ngsld_pair_kernel.argtypes = [vp]
+            L.ngsld_pair_kernel.restype = C.c_char_p
         L.ngsld_selftest.argtypes = [vp]
         L.ngsld_window_ends.argtypes = [vp, u64, C.POINTER(Params), vp]
         L.ngsld_plan_slabs.argtypes = [vp, u64, C.POINTER(Params), u64, vp, u64, C.POINTER(u64)]
@@ -519,6 +522,10 @@ class Engine:
 
     def run_device(self, s1_begin: int, s1_end: int, d_std: int, d_ext: int | None, stream: int | None = None) -> None:
         self._check(self._L.ngsld_run_device(self._h, s1_begin, s1_end, d_std, d_ext, stream))
+
+    def pair_kernel(self) -> str:
+        """Kernel family of the data set last: group / run / wave / multi / stream / direct / hard."""
+        return self._L.ngsld_pair_kernel(self._h).decode()
 
     def last_kernel_time(self) -> tuple[float, int, int]:
         ms, nl, npairs = C.c_double(), C.c_uint64(), C.c_uint64()

@@ -76,6 +76,11 @@ struct ngsld_ctx {
   DevBuf<double> d_planes, d_maf, d_mean, d_rsx, d_sc4;
   DevBuf<int> d_status;
   std::vector<double> h_maf, h_pos_dist;
+  // hard-called matrices (kHard): per-site genotype bit sets
+  DevBuf<uint64_t> d_hard_masks;
+  DevBuf<double> d_hard_u;
+  DevBuf<int> d_all_hard;
+  uint32_t mask_words = 0;
 
   // plan
   bool planned = false;
@@ -252,12 +257,37 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
     if (e != hipSuccess) return hip_fail(c, e, "chunked genotype upload");
   }
   HIP_TRY(c, launch_pack_scalars(c->d_maf.p, c->d_mean.p, c->d_rsx.p, c->d_sc4.p, n_sites, c->stream));
+  // Is every likelihood triple a called genotype or "no data" (text genotypes, --call_geno)?  Then the pairs run on the
+  // 16 genotype-combination counts instead of the individuals (ld_pair_hard.hip).  NGSLD_HARD_KERNEL=0: never (A/B, tests).
+  int all_hard = 0;
+  const char *hk = std::getenv("NGSLD_HARD_KERNEL");
+  const bool try_hard = c->prefetch && n_ind <= kHardMaxInd && !(hk != nullptr && std::strcmp(hk, "0") == 0);
+  if (try_hard) {
+    c->mask_words = (uint32_t)((n_ind + 63) / 64);
+    HIP_TRY(c, c->d_hard_masks.resize((size_t)n_sites * 4 * c->mask_words));
+    HIP_TRY(c, c->d_hard_u.resize(n_sites));
+    HIP_TRY(c, c->d_all_hard.resize(1));
+    all_hard = 1;
+    HIP_TRY(c, hipMemcpyAsync(c->d_all_hard.p, &all_hard, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, launch_classify_hard(c->d_planes.p, 3ull * c->np, c->np, (uint32_t)n_ind, n_sites, c->d_hard_masks.p,
+                                    c->d_hard_u.p, c->d_all_hard.p, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&all_hard, c->d_all_hard.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  }
   c->h_maf.resize(n_sites);
   int status = 0;
   HIP_TRY(c, hipMemcpyAsync(c->h_maf.data(), c->d_maf.p, n_sites * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(&status, c->d_status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (status == NGSLD_ERR_NAN) return fail(c, NGSLD_ERR_NAN, "NaN found! Is the file format correct?");
+  if (try_hard && all_hard) {
+    c->cfg.kernel = kHard;
+    c->cfg.group = 16;
+    c->cfg.slots = 1;
+    c->cfg.waves = 1;
+  } else {
+    c->d_hard_masks.release();
+    c->d_hard_u.release();
+  }
   c->have_geno = true;
   return NGSLD_OK;
 }
@@ -345,10 +375,13 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
   a.rsx = c->d_rsx.p;
   a.items = c->d_items.p + c->h_item_off[r0];
   a.n_items = c->h_item_off[r1] - c->h_item_off[r0];
-  if (c->cfg.kernel == kRun || c->cfg.kernel == kGroup) {
+  if (c->cfg.kernel == kRun || c->cfg.kernel == kGroup || c->cfg.kernel == kHard) {
     a.runs = c->d_runs.p + c->h_run_off[r0];
     a.n_runs = c->h_run_off[r1] - c->h_run_off[r0];
   }
+  a.hard_masks = c->d_hard_masks.p;
+  a.hard_u = c->d_hard_u.p;
+  a.mask_words = c->mask_words;
   a.items_all = c->d_items.p;
   a.sc4 = c->d_sc4.p;
   a.out_base = c->h_row_off[r0];
@@ -426,6 +459,7 @@ void ngsld_destroy(ngsld_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_rsx.release(); c->d_sc4.release(); c->d_runs.release();
+  c->d_hard_masks.release(); c->d_hard_u.release(); c->d_all_hard.release();
   c->d_labels.release(); c->d_scan_tmp.release(); c->d_label_off.release(); c->d_cum.release(); c->d_infc.release();
   for (int k = 0; k < 2; ++k) {
     c->d_text[k].release(); c->d_lens[k].release(); c->d_offs[k].release(); c->d_text_meta[k].release();
@@ -518,7 +552,7 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
     c->h_item_off[s1 + 1] = c->h_item_off[s1] + (span + ch - 1) / ch;
   }
   c->n_items = c->h_item_off[n];
-  if (c->cfg.kernel == kRun || c->cfg.kernel == kGroup) {
+  if (c->cfg.kernel == kRun || c->cfg.kernel == kGroup || c->cfg.kernel == kHard) {
     // runs: a row's items cut into ceil(items / kRunItems) runs of near-equal length (one workgroup each)
     std::vector<Run> runs;
     c->h_run_off.assign(n + 1, 0);
@@ -866,6 +900,20 @@ int ngsld_last_kernel_time(ngsld_ctx *c, double *total_ms, uint64_t *n_launches,
   if (n_launches) *n_launches = c->ev_used;
   if (n_pairs) *n_pairs = c->timed_pairs;
   return NGSLD_OK;
+}
+
+const char *ngsld_pair_kernel(const ngsld_ctx *c) {
+  if (c == nullptr || !c->have_geno) return "";
+  switch (c->cfg.kernel) {
+    case kGroup: return "group";
+    case kWave: return "wave";
+    case kMulti: return "multi";
+    case kDirect: return "direct";
+    case kStream: return "stream";
+    case kRun: return "run";
+    case kHard: return "hard";
+    default: return "";
+  }
 }
 
 int ngsld_set_tuning(ngsld_ctx *c, uint32_t pairs_per_item, uint64_t batch_pairs) {

@@ -80,6 +80,10 @@ struct PairArgs {
   ngsld_rec_std *out_std;
   ngsld_rec_ext *out_ext;  // may be null
   int *status;             // set to NGSLD_ERR_MAF_RANGE when haplo_freq would error()
+  // hard-called matrices (pair_ld_hard_kernel): per site four bit sets over the individuals -- genotype 0, 1, 2, no data
+  const uint64_t *hard_masks;  // [n_sites][4][mask_words]
+  const double *hard_u;        // [n_sites] the value of the three equal likelihoods of an individual without data
+  uint32_t mask_words;         // ceil(n_ind / 64)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1565,7 +1569,11 @@ __global__ __launch_bounds__(256, 2) void pair_ld_stream_kernel(PairArgs A) {
 // in LDS (n_ind <= 512), kMulti = 2..8 wavefronts per pair (n_ind <= 4096), kStream = any n_ind, vectors re-read every
 // iteration; kDirect = kWave/kMulti shapes without any prefetch (A/B); kRun = kWave's pipeline over runs of items
 // (the default for n_ind 257..512; kWave remains as its per-item A/B baseline).
-enum PairKernel { kGroup = 0, kWave = 1, kMulti = 2, kDirect = 3, kStream = 4, kRun = 5 };
+// kHard = every likelihood triple of the matrix is a called genotype or "no data": the pairs' 16 genotype-combination
+// counts replace the individuals (any n_ind up to kHardMaxInd).
+enum PairKernel { kGroup = 0, kWave = 1, kMulti = 2, kDirect = 3, kStream = 4, kRun = 5, kHard = 6 };
+constexpr uint32_t kHardMaxWords = 512;                 // row bit sets in LDS: 4 x 512 x 8 B = 16 KB
+constexpr uint64_t kHardMaxInd = 64ull * kHardMaxWords;
 struct PairConfig {
   int kernel;   // PairKernel
   int group;    // kGroup: lanes per pair (8, 16 or 32); 64 otherwise
@@ -1575,9 +1583,14 @@ struct PairConfig {
 };
 bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg, bool allow_run = true);
 hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs &args, hipStream_t stream);
+hipError_t launch_pair_hard(bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_hard.hip
+// Per-site classification behind kHard (ld_pair_hard.hip): masks / u as in PairArgs; *all_hard (device int, preset to 1) is
+// cleared when any triple is neither a called genotype (1,0,0) / (0,1,0) / (0,0,1) nor three equal values
+hipError_t launch_classify_hard(const double *planes, uint64_t site_stride, uint32_t np, uint32_t n_ind, uint64_t n_sites,
+                                uint64_t *masks, double *u, int *all_hard, hipStream_t stream);
 // candidate s2 sites per work item: kGroup / kWave items are shared by the four wavefronts of a workgroup
 inline uint32_t item_span(const PairConfig &cfg, uint32_t pairs_per_item) {
-  if (cfg.kernel == kRun || cfg.kernel == kGroup) return 64u;  // run form: candidates are addressed as 64 * item + offset
+  if (cfg.kernel == kRun || cfg.kernel == kGroup || cfg.kernel == kHard) return 64u;  // run form: candidates are addressed as 64 * item + offset
   const uint32_t span = (cfg.kernel == kGroup || cfg.kernel == kWave) ? 4u * pairs_per_item : pairs_per_item;
   return span > 64u ? 64u : span;
 }

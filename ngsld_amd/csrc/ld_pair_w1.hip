@@ -105,7 +105,7 @@ hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs
     const uint64_t u = std::strtoull(e, nullptr, 10);
     if (u >= 1 && u < max_blocks) max_blocks = u;
   }
-  const bool by_runs = cfg.kernel == kRun || cfg.kernel == kGroup;
+  const bool by_runs = cfg.kernel == kRun || cfg.kernel == kGroup || cfg.kernel == kHard;
   const uint64_t total = by_runs ? a.n_runs : a.n_items;
   const uint64_t per = max_blocks * ((cfg.kernel == kDirect && cfg.waves == 1) ? 4u : 1u);  // kDirect: 4 items per block
   for (uint64_t off = 0; off < total; off += per) {
@@ -134,6 +134,7 @@ static hipError_t launch_pair_chunk(const PairConfig &cfg, bool masked, const Pa
       hipLaunchKernelGGL((pair_ld_stream_kernel<false>), dim3((unsigned)a.n_items), dim3(256), 0, stream, a);
     return hipGetLastError();
   }
+  if (cfg.kernel == kHard) return launch_pair_hard(masked, a, stream);
   if (cfg.kernel == kGroup) {
     if (cfg.group == 8) return launch_group<8>(cfg.slots, masked, a, stream);
     if (cfg.group == 16) return launch_group<16>(cfg.slots, masked, a, stream);

@@ -36,8 +36,51 @@ def test_hard_calls_and_rare_variants(engine, case, n_sites, n_ind, mode, ignore
     rec = o.run()
     engine.set_geno_raw(raw, ignore_miss_data=ignore)
     engine.set_pos_dist(None)
+    # called genotypes (with or without missing data) take the genotype-combination kernel, everything else the
+    # per-individual kernels
+    assert (engine.pair_kernel() == "hard") == mode.startswith("called")
     assert np.all(close(engine.maf(), o.maf, MAF_TOL))
     n = engine.plan(0, 0, 0.0, ignore, True)
     assert n == len(rec) == n_sites * (n_sites - 1) // 2
     s1, s2, std, ext = engine.run()
     check_records(std, ext, rec, pearson_tol=pearson_tolerance(o.gl, s1, s2))
+
+
+@pytest.mark.parametrize("case,n_sites,n_ind,miss,ignore", [
+    (0, 500, 24, 0.0, False), (1, 400, 500, 0.2, False), (2, 400, 500, 0.2, True), (3, 300, 2000, 0.05, True),
+    (4, 200, 5000, 0.1, False), (5, 300, 64, 0.5, True), (6, 300, 129, 0.0, False)])
+def test_called_genotypes_on_both_kernel_paths(case, n_sites, n_ind, miss, ignore, monkeypatch):
+    """Hard-called matrices against the oracle twice: on the genotype-combination kernel (ld_pair_hard.hip) and, with
+    NGSLD_HARD_KERNEL=0, on the per-individual kernels; the two paths agree with each other far inside the tolerance."""
+    from ngsld_amd import capi
+    rng = np.random.default_rng(700 + case)
+    raw = np.eye(3)[synth.make_gl_numpy(n_sites, n_ind, 700 + case, depth=4.0).argmax(axis=2)]
+    if miss:
+        raw[rng.random((n_sites, n_ind)) < miss] = 1.0 / 3.0
+        raw[5, :] = 1.0 / 3.0                                    # a site nobody has data for
+    raw[7] = np.eye(3)[0]                                        # a monomorphic site
+    chrs, pos = synth.make_positions(n_sites, 700 + case, n_chr=2)
+    from ngsld_amd import shard
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    o = orc.Oracle(raw, pd, ignore_miss_data=ignore, max_kb_dist=8, min_maf=0.02, n_threads=32)
+    rec = o.run()
+    got = {}
+    for path in ("hard", "generic"):
+        if path == "generic":
+            monkeypatch.setenv("NGSLD_HARD_KERNEL", "0")
+        eng = capi.Engine(0)
+        try:
+            eng.set_geno_raw(raw, ignore_miss_data=ignore)
+            assert (eng.pair_kernel() == "hard") == (path == "hard")
+            eng.set_pos_dist(pd)
+            assert np.all(close(eng.maf(), o.maf, MAF_TOL))
+            n = eng.plan(8, 0, 0.02, ignore, True)
+            assert n == len(rec)
+            s1, s2, std, ext = eng.run()
+        finally:
+            eng.close()
+        assert np.array_equal(s1, rec["s1"]) and np.array_equal(s2, rec["s2"])
+        check_records(std, ext, rec, pearson_tol=pearson_tolerance(o.gl, s1, s2))
+        got[path] = (std, ext)
+    assert np.array_equal(got["hard"][1]["n_iter"], got["generic"][1]["n_iter"])
+    assert np.all(close(got["hard"][1]["hap"], got["generic"][1]["hap"], 1e-12))
