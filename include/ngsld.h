@@ -121,14 +121,17 @@ int ngsld_set_geno_raw(ngsld_ctx *ctx, const double *gl_raw, uint64_t n_sites, u
  *   text_semantics  the values came from a text (.gz) genotype file: plain log() with no -inf -> -1e15
  *                   replacement and no NaN check, as the text branch of read_geno (read_data.cpp:83-99)
  *   call_geno       harden the likelihoods first (ngsLD.cpp:92-98 -> call_geno, gen_func.cpp:886-914):
- *                   best genotype below N_thresh -> missing, at or above call_thresh -> called */
+ *                   best genotype below N_thresh -> missing, at or above call_thresh -> called
+ *   per_individual_only  never switch to the genotype-combination kernel (ngsld_pair_kernel): a caller that computes
+ *                   parts of one matrix in several contexts sets it unless ALL parts qualify, so that every part
+ *                   runs the same arithmetic */
 typedef struct {
   int32_t log_scale;
   int32_t ignore_miss_data;
   int32_t on_device;
   int32_t text_semantics;
   int32_t call_geno;
-  int32_t reserved;
+  int32_t per_individual_only;
   double N_thresh;
   double call_thresh;
 } ngsld_geno_opts;

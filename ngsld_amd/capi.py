@@ -27,7 +27,7 @@ class Params(C.Structure):
 
 class GenoOpts(C.Structure):
     _fields_ = [("log_scale", C.c_int32), ("ignore_miss_data", C.c_int32), ("on_device", C.c_int32),
-                ("text_semantics", C.c_int32), ("call_geno", C.c_int32), ("reserved", C.c_int32),
+                ("text_semantics", C.c_int32), ("call_geno", C.c_int32), ("per_individual_only", C.c_int32),
                 ("N_thresh", C.c_double), ("call_thresh", C.c_double)]
 
 
@@ -374,7 +374,8 @@ class Engine:
         self._check(self._L.ngsld_selftest(self._h))
 
     def set_geno_raw(self, gl, n_sites: int | None = None, n_ind: int | None = None, log_scale: bool = False,
-                     ignore_miss_data: bool = False, text: bool = False, call_geno: tuple | None = None) -> None:
+                     ignore_miss_data: bool = False, text: bool = False, call_geno: tuple | None = None,
+                     per_individual_only: bool = False) -> None:
         """gl: numpy float64 [n_sites, n_ind, 3] (host) or an int device pointer with explicit sizes.
         text: values come from a text genotype file (read_geno_text); call_geno = (N_thresh, call_thresh)."""
         if isinstance(gl, np.ndarray):
@@ -383,7 +384,7 @@ class Engine:
             ptr, on_dev = gl.ctypes.data, 0
         else:
             ptr, on_dev = int(gl), 1
-        o = GenoOpts(int(log_scale), int(ignore_miss_data), on_dev, int(text), int(call_geno is not None), 0,
+        o = GenoOpts(int(log_scale), int(ignore_miss_data), on_dev, int(text), int(call_geno is not None), int(per_individual_only),
                      float(call_geno[0]) if call_geno else 0.0, float(call_geno[1]) if call_geno else 0.0)
         self._check(self._L.ngsld_set_geno_raw_opts(self._h, ptr, n_sites, n_ind, C.byref(o)))
         self.n_sites, self.n_ind = n_sites, n_ind

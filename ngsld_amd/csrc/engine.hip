@@ -261,7 +261,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   // 16 genotype-combination counts instead of the individuals (ld_pair_hard.hip).  NGSLD_HARD_KERNEL=0: never (A/B, tests).
   int all_hard = 0;
   const char *hk = std::getenv("NGSLD_HARD_KERNEL");
-  const bool try_hard = c->prefetch && n_ind <= kHardMaxInd && !(hk != nullptr && std::strcmp(hk, "0") == 0);
+  const bool try_hard = c->prefetch && n_ind <= kHardMaxInd && !o.per_individual_only && !(hk != nullptr && std::strcmp(hk, "0") == 0);
   if (try_hard) {
     c->mask_words = (uint32_t)((n_ind + 63) / 64);
     HIP_TRY(c, c->d_hard_masks.resize((size_t)n_sites * 4 * c->mask_words));

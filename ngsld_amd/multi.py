@@ -138,14 +138,24 @@ def main(argv=None) -> int:
     is_log, seed = bool(meta[0].item()), int(meta[1].item())
 
     total = 0
+    eng = None
+    if hi > lo:
+        eng = capi.Engine(dev_index)
+        geno_kw = dict(n_sites=slab_hi - slab_lo, n_ind=n_ind, log_scale=is_log, ignore_miss_data=a.ignore_miss_data,
+                       text=not binary, call_geno=call)
+        eng.set_geno_raw(slab if slab_read else slab.data_ptr(), **geno_kw)
+    # every rank must run the same arithmetic: the genotype-combination kernel of called matrices only if ALL slabs
+    # qualify (a slab can consist of called genotypes where the whole matrix does not); ranks without rows agree to anything
+    hard = torch.tensor([1 if eng is None else int(eng.pair_kernel() == "hard")], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(hard, op=dist.ReduceOp.MIN)
+    if eng is not None and eng.pair_kernel() == "hard" and not int(hard.item()):
+        eng.set_geno_raw(slab if slab_read else slab.data_ptr(), per_individual_only=True, **geno_kw)
     with open(f"{a.out}.rank{rank}", "wb") as fh:
         if rank == 0:
             fh.write(capi.format_header(a.extend_out).encode())
             fh.flush()
-        if hi > lo:
-            eng = capi.Engine(dev_index)
-            eng.set_geno_raw(slab if slab_read else slab.data_ptr(), n_sites=slab_hi - slab_lo, n_ind=n_ind, log_scale=is_log,
-                             ignore_miss_data=a.ignore_miss_data, text=not binary, call_geno=call)
+        if eng is not None:
             del slab, raw
             local_pd = None if pos_dist is None else pos_dist[slab_lo:slab_hi].copy()
             eng.set_pos_dist(local_pd)

@@ -66,3 +66,36 @@ def test_slab_reads_on_a_larger_windowed_run(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     merged = "".join(open(f"{out}.rank{k}").read() for k in range(3))
     assert merged.count("\n") > 100_000 and merged == single.stdout
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_called_genotypes_across_ranks(mixed, tmp_path):
+    """Called genotypes over three ranks.  All sites called: every rank runs the genotype-combination kernel, as the single
+    process does.  Mixed (the last third of the sites keep their likelihoods): rank 0's slab is all called genotypes, the
+    matrix is not -- the ranks agree on the per-individual kernels, the shards still concatenate to the single-GPU text."""
+    import numpy as np
+    from ngsld_amd import synth
+    n_sites, n_ind = 900, 60
+    raw = synth.make_gl_numpy(n_sites, n_ind, seed=31, depth=5.0)
+    called = np.eye(3)[raw.argmax(axis=2)]
+    called[np.random.default_rng(31).random((n_sites, n_ind)) < 0.1] = 1.0 / 3.0
+    if mixed:
+        called[600:] = raw[600:] / raw[600:].sum(axis=2, keepdims=True)
+    chrs, pos = synth.make_positions(n_sites, 31)
+    g, p = str(tmp_path / "c.glf"), str(tmp_path / "c.pos")
+    called.tofile(g)
+    synth.write_pos(p, chrs, pos)
+    flags = ["--max_kb_dist", "4", "--extend_out", "--ignore_miss_data"]
+    single = subprocess.run([capi.CLI_PATH, "--geno", g, "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--verbose", "0",
+                             "--pos", p] + flags, capture_output=True, text=True)
+    assert single.returncode == 0, single.stderr
+    out = str(tmp_path / "multi.ld")
+    env = dict(os.environ, NGSLD_BENCH_ONE_DEVICE="1", PYTHONPATH=capi.REPO_DIR, NGSLD_MULTI_EXPECT="slab")
+    port = 29600 + ((os.getpid() + 13 + int(mixed)) % 300)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "ngsld_amd.multi",
+                        "--geno", g, "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--verbose", "0", "--pos", p,
+                        "--out", out] + flags, capture_output=True, text=True, env=env, cwd=capi.REPO_DIR, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    merged = "".join(open(f"{out}.rank{k}").read() for k in range(3))
+    assert merged.count("\n") > 10_000 and merged == single.stdout
