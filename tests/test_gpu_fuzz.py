@@ -43,13 +43,27 @@ def _case(k):
 REGRESSION_SEEDS = [270, 330, 334, 441, 450, 465, 520, 530, 542, 638, 728, 754]
 
 
+def pick_min_maf(maf: np.ndarray, k: int) -> float:
+    """Every third case filters by allele frequency: the 0.3 quantile of the sites' own frequencies, to three decimals.
+    A threshold that EQUALS a site's frequency to the last bits is stepped aside: there `maf < min_maf` is decided by the
+    rounding noise of the reference's sequential est_maf sums (gen_func.cpp:995-996), which a differently ordered sum cannot
+    reproduce (deviations: found by tools/fuzz_soak.py, case 5178, where discrete likelihood values made a
+    frequency of exactly 0.185)."""
+    if k % 3 != 0 or not np.isfinite(maf).any():
+        return 0.0
+    m0 = float(np.round(np.nanquantile(maf[np.isfinite(maf)], 0.3), 3))
+    for step in range(40):
+        m = float(np.round(m0 + 0.0007 * ((step + 1) // 2) * (1 if step % 2 else -1), 4)) if step else m0
+        if 0.0 <= m <= 1.0 and not np.any(np.abs(maf[np.isfinite(maf)] - m) < 1e-9):
+            return m
+    return m0
+
+
 @pytest.mark.parametrize("k", list(range(240)) + REGRESSION_SEEDS)
 def test_random_configuration(engine, k):
     raw, pd, kw, call = _case(k)
     o0 = orc.Oracle(raw, pd, log_scale=kw["log_scale"], call_geno=call)
-    min_maf = 0.0
-    if k % 3 == 0 and np.isfinite(o0.maf).any():
-        min_maf = float(np.round(np.nanquantile(o0.maf, 0.3), 3))
+    min_maf = pick_min_maf(o0.maf, k)
     o = orc.Oracle(raw, pd, min_maf=min_maf, n_threads=4, call_geno=call, **kw)
     rec = o.run()
     engine.set_geno_raw(raw, log_scale=kw["log_scale"], ignore_miss_data=kw["ignore_miss_data"], call_geno=call)

@@ -6,13 +6,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch  # noqa: F401
 from ngsld_amd import capi
 from oracle import orc
-from test_gpu_fuzz import _case
+from test_gpu_fuzz import _case, pick_min_maf
 k = int(sys.argv[1])
 raw, pd, kw, call = _case(k)
 o0 = orc.Oracle(raw, pd, log_scale=kw["log_scale"], call_geno=call)
-min_maf = 0.0
-if k % 3 == 0 and np.isfinite(o0.maf).any():
-    min_maf = float(np.round(np.nanquantile(o0.maf, 0.3), 3))
+min_maf = pick_min_maf(o0.maf, k)
 o = orc.Oracle(raw, pd, min_maf=min_maf, n_threads=4, call_geno=call, **kw)
 rec = o.run()
 eng = capi.Engine(0)

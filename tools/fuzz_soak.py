@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch  # noqa: F401  (HIP runtime load order, see tests/conftest.py)
 from ngsld_amd import capi
 from oracle import orc
-from test_gpu_fuzz import _case
+from test_gpu_fuzz import _case, pick_min_maf
 from util import MAF_TOL, check_records, close, pearson_tolerance
 
 first, last = int(sys.argv[1]) if len(sys.argv) > 1 else 48, int(sys.argv[2]) if len(sys.argv) > 2 else 400
@@ -17,9 +17,7 @@ pairs = 0
 for k in range(first, last):
     raw, pd, kw, call = _case(k)
     o0 = orc.Oracle(raw, pd, log_scale=kw["log_scale"], call_geno=call)
-    min_maf = 0.0
-    if k % 3 == 0 and np.isfinite(o0.maf).any():
-        min_maf = float(np.round(np.nanquantile(o0.maf, 0.3), 3))
+    min_maf = pick_min_maf(o0.maf, k)
     o = orc.Oracle(raw, pd, min_maf=min_maf, n_threads=16, call_geno=call, **kw)
     rec = o.run()
     try:
@@ -32,7 +30,7 @@ for k in range(first, last):
         assert np.array_equal(s1, rec["s1"]) and np.array_equal(s2, rec["s2"])
         check_records(std, ext, rec, pearson_tol=pearson_tolerance(o.gl, s1, s2))
         pairs += n
-    except AssertionError as e:
+    except (AssertionError, capi.NgsldError) as e:
         bad += 1
         print(f"case {k}: n_ind {raw.shape[1]} n_sites {raw.shape[0]} FAILED: {str(e)[:300]}")
 print(f"fuzz soak: cases {first}..{last - 1}, {pairs} pairs compared, {bad} failing cases")
