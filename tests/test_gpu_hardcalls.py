@@ -84,3 +84,25 @@ def test_called_genotypes_on_both_kernel_paths(case, n_sites, n_ind, miss, ignor
         got[path] = (std, ext)
     assert np.array_equal(got["hard"][1]["n_iter"], got["generic"][1]["n_iter"])
     assert np.all(close(got["hard"][1]["hap"], got["generic"][1]["hap"], 1e-12))
+
+
+@pytest.mark.parametrize("case,n_sites,n_ind,miss,ignore", [
+    (0, 400, 100, 0.0, False), (1, 400, 100, 0.1, False), (2, 400, 100, 0.1, True), (3, 300, 37, 0.3, False),
+    (4, 200, 2000, 0.2, True), (5, 300, 10, 0.5, False)])
+def test_maf_is_bit_identical_on_called_genotypes(engine, case, n_sites, n_ind, miss, ignore):
+    """est_maf of called genotypes (with missing data) equals the oracle's BIT FOR BIT -- its terms are 0, 1, 2, the sums are
+    exact whatever their order -- so a round --min_maf (0.05 with 100 individuals: a frequency many sites have exactly)
+    keeps and drops the same sites as the reference (deviations)."""
+    rng = np.random.default_rng(case)
+    raw = np.eye(3)[synth.make_gl_numpy(n_sites, n_ind, 50 + case, depth=3.0).argmax(axis=2)]
+    raw[rng.random((n_sites, n_ind)) < miss] = 1.0 / 3.0
+    o = orc.Oracle(raw, None, ignore_miss_data=ignore)
+    engine.set_geno_raw(raw, ignore_miss_data=ignore)
+    m = engine.maf()
+    assert np.all((m == o.maf) | (np.isnan(m) & np.isnan(o.maf)))
+    if not ignore:                                       # a threshold that IS the frequency of some sites resolves alike
+        thr = float(np.sort(o.maf[np.isfinite(o.maf)])[n_sites // 3])
+        assert np.count_nonzero(o.maf == thr) >= 1
+        o2 = orc.Oracle(raw, None, min_maf=thr)
+        engine.set_pos_dist(None)
+        assert engine.plan(0, 0, thr, False, True) == o2.count()
