@@ -102,6 +102,10 @@ typedef struct {
 
 typedef int (*ngsld_sink_fn)(void *user, const ngsld_batch *batch);
 
+/* Fill dst with the raw values ([site][ind][3] doubles, as ngsld_set_geno_raw_opts takes them) of sites
+ * [site_begin, site_begin + n_sites).  Called on a library thread, never concurrently.  Non-zero = failure. */
+typedef int (*ngsld_read_sites_fn)(void *user, uint64_t site_begin, uint64_t n_sites, double *dst);
+
 const char *ngsld_version(void);
 
 /* Bind to HIP device `device` (must be gfx950).  Fails with NGSLD_ERR_DEVICE when there is no GPU:
@@ -164,11 +168,41 @@ int ngsld_run(ngsld_ctx *ctx, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn 
  * needs its finite gaps to be integers (as read_dist produces them), otherwise batches arrive as records. */
 int ngsld_set_text_output(ngsld_ctx *ctx, const char *const *labels, int enable);
 
+/* ---- Exact-order replay ------------------------------------------------------------------------------------
+ * The kernels evaluate every pair with reordered arithmetic (tree sums, fused multiply-adds), which agrees with the
+ * reference to ~1e-15 wherever the outcome is well conditioned.  A few outcomes are decided by the reference's own
+ * rounding noise: D' and r2 of a pair with a site (nearly) monomorphic in the estimated haplotypes (0/0-type
+ * quotients, ngsLD.cpp:296-306: -nan, 0.000000 or inf), nIter when eps lands within 1e-12 of EPSILON
+ * (gen_func.cpp:1054), the maf < min_maf tests when a frequency ties --min_maf (ngsLD.cpp:264-275), r2_ExpG at a
+ * site whose expected genotypes are constant up to rounding (ngsLD.cpp:365-367).  The kernels flag those pairs and
+ * the engine re-evaluates them on the host in the reference's operation order (sequential sums over individuals,
+ * the sequential renormalisation, no fused multiply-add: ngsld_host_replay_pair in ngsld_host.h) and overwrites
+ * their records -- before a batch reaches the sink, before it is formatted on the device, before ngsld_run_device
+ * returns.  On by default.
+ *
+ * The replay needs the two sites' values again.  ngsld_set_replay_source registers where to get them: `read` fills
+ * dst with the RAW values of sites [site_begin, site_begin + n) of this context ([site][ind][3], exactly what
+ * ngsld_set_geno_raw_opts / ngsld_set_geno_lkl was given) and may be called from several library threads, one call
+ * at a time.  With a source the replayed records are the reference's own bits (same libm).  Without one the
+ * library reads its prepped planes back from the device: same operation order, inputs that differ from the
+ * reference's by the device's exp/log rounding (exact for ngsld_set_geno_lkl), and --min_maf ties are left to the
+ * device's est_maf.  Call after ngsld_set_geno_* (the source belongs to that matrix), before ngsld_plan. */
+int ngsld_set_replay_source(ngsld_ctx *ctx, ngsld_read_sites_fn read, void *user);
+/* enable == 0: no replay, every record is the kernels' own value. */
+int ngsld_set_replay(ngsld_ctx *ctx, int enable);
+/* Pairs replayed by the last ngsld_run / ngsld_run_device (+ ngsld_finish_device) and sites re-evaluated by the last
+ * ngsld_plan and run.  Either pointer may be NULL. */
+int ngsld_replay_stats(ngsld_ctx *ctx, uint64_t *pairs, uint64_t *sites);
+
 /* Same computation with the records left in caller-owned DEVICE memory (no host transfer):
  * d_std holds ngsld_rec_std[n], d_ext ngsld_rec_ext[n] (may be NULL), n = row_off[s1_end] -
  * row_off[s1_begin], record k = global pair index - row_off[s1_begin].  `hip_stream` is a hipStream_t
  * (NULL = the ctx's own stream); the call returns after enqueueing when a stream is given. */
 int ngsld_run_device(ngsld_ctx *ctx, uint64_t s1_begin, uint64_t s1_end, void *d_std, void *d_ext, void *hip_stream);
+/* After ngsld_run_device on a caller's stream: waits for that stream, replays the flagged pairs and patches the device
+ * records (exact-order replay, above).  Without this call the flagged records keep the kernels' own values.  A no-op
+ * after a run on the ctx's own stream (hip_stream == NULL does all of it before returning). */
+int ngsld_finish_device(ngsld_ctx *ctx);
 
 /* Timing of the pair kernel launches issued by the last ngsld_run / ngsld_run_device, measured with
  * HIP events on the stream they ran on (synchronises that stream).  Any pointer may be NULL. */
@@ -214,9 +248,6 @@ uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes);
 /* Free and total memory of HIP device `device`, in bytes. */
 int ngsld_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 
-/* Fill dst with the raw values ([site][ind][3] doubles, as ngsld_set_geno_raw_opts takes them) of sites
- * [site_begin, site_begin + n_sites).  Called on a library thread, never concurrently.  Non-zero = failure. */
-typedef int (*ngsld_read_sites_fn)(void *user, uint64_t site_begin, uint64_t n_sites, double *dst);
 
 /* The whole job, slab by slab: create two contexts on `device`, and for every slab read -> ngsld_set_geno_raw_opts
  * -> ngsld_set_pos_dist -> ngsld_plan (first_row = row_begin) -> ngsld_run.  The sink sees the batches of all

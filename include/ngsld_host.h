@@ -13,6 +13,8 @@
  *   ngsLD.cpp:77,314-351          TSV header/rows => ngsld_host_format_header / ngsld_host_format_pair
  *   ngsLD.cpp:296-298,328-333     hap_maf, chi2   => inside ngsld_host_format_pair (float chi2)
  *   ngsLD.cpp:310-352             fprintf under the mutex => ngsld_host_write_batch (threads format, one ordered write)
+ *   ngsLD.cpp:290-306 + gen_func.cpp:1027-1119   one pair in the reference's own operation order
+ *                                                 => ngsld_host_replay_pair (the engine's exact-order replay, see ngsld.h)
  */
 #ifndef NGSLD_HOST_H
 #define NGSLD_HOST_H
@@ -75,6 +77,15 @@ size_t ngsld_host_format_double(char *buf, size_t cap, double v, int decimals);
  * "(null)"), pos_dist NULL = all INFINITY; maf = per-site allele frequencies (ngsld_get_maf). */
 int ngsld_host_write_batch(const ngsld_batch *b, const ngsld_pos *pos, const double *pos_dist, const double *maf,
                            int n_threads, int fd);
+
+/* One pair evaluated on the host in the reference's own operation order: read_geno's arithmetic on the two sites' raw
+ * values ([n_ind][3] each, as ngsld_set_geno_raw_opts takes them; opts->on_device is ignored), call_geno, est_maf
+ * (sequential, gen_func.cpp:974-1009), exp, pearson_r, haplo_freq (gen_func.cpp:1027-1119: sequential sums, the
+ * sequential renormalisation, no fused multiply-add) and D / D' / r2 (ngsLD.cpp:296-306).  This is the arithmetic the
+ * engine replays for the pairs whose outcome the reference's own rounding decides (ngsld_set_replay_source).
+ * ext_rec and maf_out (2 doubles) may be NULL.  Returns NGSLD_OK, or NGSLD_ERR_MAF_RANGE where haplo_freq calls error(). */
+int ngsld_host_replay_pair(const double *raw1, const double *raw2, uint64_t n_ind, const ngsld_geno_opts *opts,
+                           ngsld_rec_std *std_rec, ngsld_rec_ext *ext_rec, double *maf_out);
 
 #ifdef __cplusplus
 }

@@ -81,12 +81,13 @@ SYMBOLS = [
     "ngsld_version", "ngsld_create", "ngsld_destroy", "ngsld_last_error", "ngsld_set_geno_raw",
     "ngsld_set_geno_raw_opts", "ngsld_set_geno_lkl",
     "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device", "ngsld_set_text_output",
+    "ngsld_set_replay_source", "ngsld_set_replay", "ngsld_replay_stats", "ngsld_finish_device",
     "ngsld_last_kernel_time", "ngsld_pair_kernel", "ngsld_set_tuning", "ngsld_selftest",
     "ngsld_window_ends", "ngsld_plan_slabs", "ngsld_slab_sites_for_budget", "ngsld_device_memory", "ngsld_run_streamed", "ngsld_run_streamed_text",
     "ngsld_host_read_geno_bin_range",
     "ngsld_host_set_threads", "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos", "ngsld_host_pos_slice",
     "ngsld_host_geno_size_ok", "ngsld_host_read_geno_bin", "ngsld_host_read_geno_text", "ngsld_host_format_header", "ngsld_host_format_pair",
-    "ngsld_host_format_double", "ngsld_host_write_batch",
+    "ngsld_host_format_double", "ngsld_host_write_batch", "ngsld_host_replay_pair",
 ]
 
 
@@ -131,6 +132,11 @@ def lib() -> C.CDLL:
         L.ngsld_plan_rows.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint64)), C.POINTER(C.POINTER(C.c_uint32))]
         L.ngsld_run.argtypes = [vp, u64, u64, SINK_FN, vp]
         L.ngsld_run_device.argtypes = [vp, u64, u64, vp, vp, vp]
+        if hasattr(L, "ngsld_set_replay_source"):  # (absent only from older A/B builds loaded through NGSLD_LIB)
+            L.ngsld_set_replay_source.argtypes = [vp, READ_FN, vp]
+            L.ngsld_set_replay.argtypes = [vp, C.c_int]
+            L.ngsld_replay_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+            L.ngsld_finish_device.argtypes = [vp]
         if hasattr(L, "ngsld_set_text_output"):  # (absent only from older A/B builds loaded through NGSLD_LIB)
             L.ngsld_set_text_output.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int]
         L.ngsld_last_kernel_time.argtypes = [vp, C.POINTER(dbl), C.POINTER(u64), C.POINTER(u64)]
@@ -169,6 +175,7 @@ def lib() -> C.CDLL:
         L.ngsld_host_format_double.argtypes = [C.c_char_p, C.c_size_t, dbl, C.c_int]
         L.ngsld_host_format_double.restype = C.c_size_t
         L.ngsld_host_write_batch.argtypes = [C.POINTER(Batch), vp, vp, vp, C.c_int, C.c_int]
+        L.ngsld_host_replay_pair.argtypes = [vp, vp, u64, C.POINTER(GenoOpts), vp, vp, vp]
         _lib = L
     return _lib
 
@@ -316,6 +323,22 @@ def read_geno_text(path: str, in_probs: bool, log_scale: bool, n_ind: int, n_sit
     return out, bool(is_log.value)
 
 
+def replay_pair(raw1: np.ndarray, raw2: np.ndarray, log_scale: bool = False, ignore_miss_data: bool = False,
+                text: bool = False, call_geno: tuple | None = None):
+    """One pair in the reference's own operation order on the host (ngsld_host_replay_pair).
+    raw1, raw2: [n_ind, 3] raw values of the two sites.  Returns (std record, ext record, (maf1, maf2))."""
+    a = np.ascontiguousarray(raw1, dtype=np.float64)
+    b = np.ascontiguousarray(raw2, dtype=np.float64)
+    o = GenoOpts(int(log_scale), int(ignore_miss_data), 0, int(text), int(call_geno is not None), 0,
+                 float(call_geno[0]) if call_geno else 0.0, float(call_geno[1]) if call_geno else 0.0)
+    s, e, m = np.zeros(1, dtype=REC_STD), np.zeros(1, dtype=REC_EXT), np.zeros(2)
+    rc = lib().ngsld_host_replay_pair(a.ctypes.data, b.ctypes.data, a.shape[0], C.byref(o), s.ctypes.data, e.ctypes.data,
+                                      m.ctypes.data)
+    if rc not in (OK, ERR_MAF_RANGE):
+        raise NgsldError(rc, "ngsld_host_replay_pair")
+    return s[0], e[0], (float(m[0]), float(m[1]))
+
+
 def format_double(v: float, decimals: int = 6) -> str:
     buf = C.create_string_buffer(512)
     n = lib().ngsld_host_format_double(buf, len(buf), v, decimals)
@@ -354,6 +377,7 @@ class Engine:
             raise NgsldError(rc, self._L.ngsld_last_error(None).decode())
         self.n_sites = self.n_ind = 0
         self.extend_out = False
+        self._source = None
 
     def close(self) -> None:
         if self._h:
@@ -375,7 +399,7 @@ class Engine:
 
     def set_geno_raw(self, gl, n_sites: int | None = None, n_ind: int | None = None, log_scale: bool = False,
                      ignore_miss_data: bool = False, text: bool = False, call_geno: tuple | None = None,
-                     per_individual_only: bool = False) -> None:
+                     per_individual_only: bool = False, replay_source: bool = True) -> None:
         """gl: numpy float64 [n_sites, n_ind, 3] (host) or an int device pointer with explicit sizes.
         text: values come from a text genotype file (read_geno_text); call_geno = (N_thresh, call_thresh)."""
         if isinstance(gl, np.ndarray):
@@ -388,12 +412,51 @@ class Engine:
                      float(call_geno[0]) if call_geno else 0.0, float(call_geno[1]) if call_geno else 0.0)
         self._check(self._L.ngsld_set_geno_raw_opts(self._h, ptr, n_sites, n_ind, C.byref(o)))
         self.n_sites, self.n_ind = n_sites, n_ind
+        self._source = None
+        if isinstance(gl, np.ndarray) and replay_source:
+            self.set_replay_source(gl)
 
-    def set_geno_lkl(self, geno_lkl: np.ndarray, maf: np.ndarray) -> None:
+    def set_geno_lkl(self, geno_lkl: np.ndarray, maf: np.ndarray, replay_source: bool = True) -> None:
         g = np.ascontiguousarray(geno_lkl, dtype=np.float64)
         m = np.ascontiguousarray(maf, dtype=np.float64)
         self._check(self._L.ngsld_set_geno_lkl(self._h, g.ctypes.data, m.ctypes.data, g.shape[0], g.shape[1], 0))
         self.n_sites, self.n_ind = g.shape[0], g.shape[1]
+        self._source = None
+        if replay_source:
+            self.set_replay_source(g)
+
+    def set_replay_source(self, values: np.ndarray | None) -> None:
+        """The matrix the exact-order replay reads the flagged pairs' sites from again: the array given to set_geno_raw /
+        set_geno_lkl (kept alive by this object).  None: the library reads its own planes back from the device."""
+        if values is None or not hasattr(self._L, "ngsld_set_replay_source"):
+            self._source = None
+            if hasattr(self._L, "ngsld_set_replay_source"):
+                self._check(self._L.ngsld_set_replay_source(self._h, READ_FN(0), None))
+            return
+        arr = np.ascontiguousarray(values, dtype=np.float64).reshape(self.n_sites, -1)
+        row = arr.shape[1] * 8
+
+        def reader(_user, site_begin, n, dst):
+            if site_begin + n > arr.shape[0]:
+                return 1
+            C.memmove(dst, arr.ctypes.data + int(site_begin) * row, int(n) * row)
+            return 0
+
+        cb = READ_FN(reader)
+        self._source = (arr, cb)
+        self._check(self._L.ngsld_set_replay_source(self._h, cb, None))
+
+    def set_replay(self, enable: bool) -> None:
+        self._check(self._L.ngsld_set_replay(self._h, int(enable)))
+
+    def replay_stats(self) -> tuple[int, int]:
+        """(pairs replayed by the last run, sites re-evaluated by the last plan + run)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._L.ngsld_replay_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def finish_device(self) -> None:
+        self._check(self._L.ngsld_finish_device(self._h))
 
     def maf(self) -> np.ndarray:
         out = np.empty(self.n_sites, dtype=np.float64)

@@ -380,9 +380,22 @@ int main(int argc, char **argv) {
   if (rc == NGSLD_ERR_INVALID && pars.call_geno) error("call_geno", ngsld_last_error(ctx));
   if (rc != NGSLD_OK) error("ngsld_set_geno_raw", ngsld_last_error(ctx));
   timing_report.mark("upload + per-site prep");
-  raw.reset();
-  std::vector<double> maf(pars.n_sites);
-  if (ngsld_get_maf(ctx, maf.data()) != NGSLD_OK) error("ngsld_get_maf", ngsld_last_error(ctx));
+  // The matrix stays in host memory for the run (the reference holds it throughout, ngsLD.cpp:86-89): the pairs whose
+  // outcome the reference's own rounding decides are replayed from it in the reference's operation order.
+  struct RawSource {
+    const double *raw;
+    uint64_t n_sites, n_ind;
+  } raw_src{raw.get(), pars.n_sites, pars.n_ind};
+  auto read_raw = [](void *user, uint64_t site_begin, uint64_t n, double *dst) -> int {
+    const RawSource *r = static_cast<const RawSource *>(user);
+    if (site_begin + n > r->n_sites) return 1;
+    memcpy(dst, r->raw + site_begin * r->n_ind * 3, n * r->n_ind * 3 * sizeof(double));
+    return 0;
+  };
+  if (getenv("NGSLD_REPLAY_SOURCE") && strcmp(getenv("NGSLD_REPLAY_SOURCE"), "0") == 0)
+    raw.reset();  // (tests: replay from the device's own planes)
+  else if (ngsld_set_replay_source(ctx, read_raw, &raw_src) != NGSLD_OK)
+    error("ngsld_set_replay_source", ngsld_last_error(ctx));
 
   if (pars.verbose >= 1) fprintf(stderr, "==> Getting sites coordinates\n");
   ngsld_pos *pos = nullptr;
@@ -410,6 +423,8 @@ int main(int argc, char **argv) {
   uint64_t n_pairs = 0;
   timing_report.mark("positions");
   if (ngsld_plan(ctx, &lp, &n_pairs) != NGSLD_OK) error("ngsld_plan", ngsld_last_error(ctx));
+  std::vector<double> maf(pars.n_sites);  // (after the plan: a frequency that ties --min_maf has been settled by then)
+  if (ngsld_get_maf(ctx, maf.data()) != NGSLD_OK) error("ngsld_get_maf", ngsld_last_error(ctx));
   timing_report.mark("plan");
   // The rows are formatted on the device (the fprintf block of calc_pair_LD, ngsLD.cpp:310-352, at kernel rates); a
   // batch the device formatter cannot take arrives as records and goes through the --n_threads host formatter as
@@ -434,6 +449,12 @@ int main(int argc, char **argv) {
   timing_report.mark("pair kernels + text + write");
   if (rc == NGSLD_ERR_MAF_RANGE) error("haplo_freq", ngsld_last_error(ctx));
   if (rc != NGSLD_OK) error("ngsld_run", ngsld_last_error(ctx));
+  if (pars.verbose >= 2) {
+    uint64_t rp = 0, rsites = 0;
+    ngsld_replay_stats(ctx, &rp, &rsites);
+    fprintf(stderr, "==> %lu of %lu pairs replayed in the reference's operation order\n", (unsigned long)rp,
+            (unsigned long)n_pairs);
+  }
 
   // ---- free memory (ngsLD.cpp:205-222) ----
   if (pars.verbose >= 1) fprintf(stderr, "==> Freeing memory...\n");

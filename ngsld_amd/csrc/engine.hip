@@ -9,14 +9,18 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ngsld.h"
 #include "ld_device.h"
 #include "ld_prep.h"
 #include "ld_text.h"
+#include "replay.h"
 #include "taus.h"
 
 using namespace ngsld;
@@ -24,10 +28,15 @@ using namespace ngsld;
 namespace {
 thread_local std::string g_create_error;
 
+// (both buffers free themselves: an early return from a function that holds one as a local leaks nothing)
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
   hipError_t resize(size_t count) {
     if (count <= n && p != nullptr) return hipSuccess;
     release();
@@ -47,6 +56,10 @@ template <typename T>
 struct PinBuf {
   T *p = nullptr;
   size_t n = 0;
+  PinBuf() = default;
+  PinBuf(const PinBuf &) = delete;
+  PinBuf &operator=(const PinBuf &) = delete;
+  ~PinBuf() { release(); }
   hipError_t resize(size_t count) {
     if (count <= n && p != nullptr) return hipSuccess;
     release();
@@ -120,6 +133,30 @@ struct ngsld_ctx {
   PinBuf<char> h_text[2];
   PinBuf<uint64_t> h_text_meta[2];
 
+  // exact-order replay of the pairs the kernels flag (replay.h)
+  bool replay_on = true;
+  ngsld_read_sites_fn replay_read = nullptr;  // the caller's raw values again (null: the device's planes are read back)
+  void *replay_user = nullptr;
+  std::mutex replay_mu;                       // serialises the source callback / the plane read-back
+  hipStream_t replay_stream = nullptr;        // non-blocking: read-backs must not wait for the next batch's kernel
+  ngsld_geno_opts gopts{};
+  bool normalised = false;                    // data came through ngsld_set_geno_lkl
+  DevBuf<uint32_t> d_flags[2], d_flags_dev;   // [count, pad, one bit per record ...] per pipeline slot / for ngsld_run_device
+  PinBuf<uint32_t> h_flag_count[2];
+  DevBuf<uint64_t> d_patch_idx;
+  DevBuf<ngsld_rec_std> d_patch_std;
+  DevBuf<ngsld_rec_ext> d_patch_ext;
+  DevBuf<char> d_scan_tmp2;                   // text lengths re-derived after a patch, beside the next batch's scan
+  uint64_t replayed_pairs = 0, replayed_sites = 0;
+  int replay_threads = 0;                     // 0 = min(8, hardware threads)
+  struct {
+    bool pending = false;
+    uint64_t s1_begin = 0, s1_end = 0;
+    ngsld_rec_std *d_std = nullptr;
+    ngsld_rec_ext *d_ext = nullptr;
+    hipStream_t st = nullptr;
+  } dev_run;                                  // the last ngsld_run_device, until ngsld_finish_device has looked at its flags
+
   // timing of pair-kernel launches
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
@@ -175,6 +212,11 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   c->have_geno = false;
   c->planned = false;
   c->text_mode = false;  // labels belong to a matrix
+  c->replay_read = nullptr;  // and so does the replay source
+  c->replay_user = nullptr;
+  c->dev_run.pending = false;
+  c->gopts = o;
+  c->normalised = normalised;
   c->n_sites = n_sites;
   c->n_ind = n_ind;
   c->cfg = cfg;
@@ -363,8 +405,11 @@ hipError_t timed_launch(ngsld_ctx *c, const PairArgs &a, hipStream_t stream) {
   return hipEventRecord(ev.second, stream);
 }
 
-PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext) {
+PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext,
+                   uint32_t *d_flags = nullptr) {
   PairArgs a{};
+  a.flags = d_flags;
+  a.flag_text = 1;
   a.planes = c->d_planes.p;
   a.site_stride = 3ull * c->np;
   a.np = c->np;
@@ -396,6 +441,203 @@ int check_status(ngsld_ctx *c) {
   HIP_TRY(c, hipMemcpy(&status, c->d_status.p, sizeof(int), hipMemcpyDeviceToHost));
   if (status == NGSLD_ERR_MAF_RANGE) return fail(c, NGSLD_ERR_MAF_RANGE, "invalid allele frequencies");
   return NGSLD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Exact-order replay (replay.h): the pairs the kernels flagged are re-evaluated on the host in the reference's own
+// operation order and their records overwritten -- in the host buffers of a record batch, or on the device (text
+// batches, ngsld_run_device) through a small scatter kernel.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void patch_records_kernel(const uint64_t *idx, uint64_t n, const ngsld_rec_std *src_std,
+                                     const ngsld_rec_ext *src_ext, ngsld_rec_std *dst_std, ngsld_rec_ext *dst_ext) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  dst_std[idx[k]] = src_std[k];
+  if (dst_ext != nullptr) dst_ext[idx[k]] = src_ext[k];
+}
+
+int ensure_host_items(ngsld_ctx *c) {  // the host copy of the plan's items, fetched on first use
+  if (c->h_items.size() != c->n_items) {
+    c->h_items.resize(c->n_items);
+    if (c->n_items)
+      HIP_TRY(c, hipMemcpy(c->h_items.data(), c->d_items.p, c->n_items * sizeof(Item), hipMemcpyDeviceToHost));
+  }
+  return NGSLD_OK;
+}
+
+// (s1, s2) of the plan's record `rec` (h_items must be present)
+bool locate_record(const ngsld_ctx *c, uint64_t rec, uint32_t *s1, uint32_t *s2) {
+  const auto &off = c->h_row_off;
+  const uint64_t row = (uint64_t)(std::upper_bound(off.begin(), off.end(), rec) - off.begin()) - 1;
+  if (row >= c->n_sites) return false;
+  uint64_t lo = c->h_item_off[row], hi = c->h_item_off[row + 1];
+  while (lo + 1 < hi) {  // last item of the row whose first record is <= rec
+    const uint64_t mid = (lo + hi) / 2;
+    if (c->h_items[mid].first_record <= rec) lo = mid; else hi = mid;
+  }
+  if (lo >= hi) return false;
+  const Item &it = c->h_items[lo];
+  uint64_t k = rec - it.first_record, m = it.mask;
+  if (k >= (uint64_t)__builtin_popcountll(m)) return false;
+  while (k--) m &= m - 1;  // drop the k lowest set bits
+  *s1 = it.s1;
+  *s2 = it.s2_begin + (uint32_t)__builtin_ctzll(m);
+  return true;
+}
+
+// One site in the reference's arithmetic: from the caller's raw values when a source is registered, otherwise from the
+// device's own planes (already normalised normal-space values; exact for ngsld_set_geno_lkl input).
+int fetch_replay_site(ngsld_ctx *c, uint64_t s, std::vector<double> &tmp, ReplaySite *out) {
+  const uint64_t n = c->n_ind;
+  if (c->replay_read != nullptr) {
+    tmp.resize(3 * n);
+    {
+      std::lock_guard<std::mutex> g(c->replay_mu);
+      if (c->replay_read(c->replay_user, s, 1, tmp.data()) != 0) return NGSLD_ERR_SINK;
+    }
+    if (c->normalised)
+      replay_site_from_lkl(tmp.data(), c->h_maf[s], n, out);
+    else
+      replay_site_from_raw(tmp.data(), n, c->gopts, out);
+    return NGSLD_OK;
+  }
+  tmp.resize(3ull * c->np + 3 * n);
+  double *planes = tmp.data(), *lkl = tmp.data() + 3ull * c->np;
+  {
+    std::lock_guard<std::mutex> g(c->replay_mu);
+    if (hipSetDevice(c->device) != hipSuccess ||
+        hipMemcpyAsync(planes, c->d_planes.p + s * 3ull * c->np, 3ull * c->np * sizeof(double), hipMemcpyDeviceToHost,
+                       c->replay_stream) != hipSuccess ||
+        hipStreamSynchronize(c->replay_stream) != hipSuccess)
+      return NGSLD_ERR_DEVICE;
+  }
+  for (uint64_t i = 0; i < n; ++i)
+    for (int g = 0; g < 3; ++g) lkl[3 * i + g] = planes[(uint64_t)g * c->np + i];
+  replay_site_from_lkl(lkl, c->h_maf[s], n, out);
+  return NGSLD_OK;
+}
+
+// Records [0, n) of a launch whose record 0 is the plan's record `base`: every flagged one is replayed; the new records go
+// to h_std / h_ext (host buffers of the batch) or, when those are null, to d_std / d_ext on stream st (synchronised).
+int replay_flagged(ngsld_ctx *c, const uint32_t *d_flags, uint64_t base, uint64_t n, ngsld_rec_std *h_std,
+                   ngsld_rec_ext *h_ext, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext, hipStream_t st) {
+  const uint64_t words = (n + 31) / 32;
+  std::vector<uint32_t> bits(words);
+  HIP_TRY(c, hipMemcpyAsync(bits.data(), d_flags + 2, words * sizeof(uint32_t), hipMemcpyDeviceToHost, c->replay_stream));
+  HIP_TRY(c, hipStreamSynchronize(c->replay_stream));
+  std::vector<uint64_t> recs;
+  for (uint64_t w = 0; w < words; ++w)
+    for (uint32_t m = bits[w]; m; m &= m - 1) {
+      const uint64_t r = w * 32 + (uint64_t)__builtin_ctz(m);
+      if (r < n) recs.push_back(r);
+    }
+  if (recs.empty()) return NGSLD_OK;
+  const int rc0 = ensure_host_items(c);
+  if (rc0 != NGSLD_OK) return rc0;
+  const bool ext = (h_std != nullptr ? (void *)h_ext : (void *)d_ext) != nullptr;
+  const bool ign = c->params.ignore_miss_data != 0;
+  std::vector<ngsld_rec_std> out_std(recs.size());
+  std::vector<ngsld_rec_ext> out_ext(ext ? recs.size() : 0);
+  unsigned hw = std::thread::hardware_concurrency();
+  int T = c->replay_threads > 0 ? c->replay_threads : (int)std::min<unsigned>(8u, hw ? hw : 1u);
+  if ((uint64_t)T > (recs.size() + 15) / 16) T = (int)((recs.size() + 15) / 16);
+  std::vector<int> rcs((size_t)T, NGSLD_OK), stats((size_t)T, NGSLD_OK);
+  std::vector<uint64_t> sites_done((size_t)T, 0);
+  auto work = [&](int t) {
+    const size_t k0 = recs.size() * (size_t)t / (size_t)T, k1 = recs.size() * (size_t)(t + 1) / (size_t)T;
+    // records come in (s1, s2) order: the row's site is kept, the partners go through a bounded cache
+    const size_t cache_cap = std::max<size_t>(64, (256ull << 20) / (32 * c->n_ind + 64));
+    std::unordered_map<uint32_t, ReplaySite> cache;
+    std::vector<double> tmp;
+    ReplaySite row;
+    uint32_t row_site = 0xffffffffu;
+    try {
+      for (size_t k = k0; k < k1; ++k) {
+        uint32_t s1 = 0, s2 = 0;
+        if (!locate_record(c, base + recs[k], &s1, &s2)) {
+          rcs[(size_t)t] = NGSLD_ERR_INVALID;
+          return;
+        }
+        if (s1 != row_site) {
+          const int rc = fetch_replay_site(c, s1, tmp, &row);
+          if (rc != NGSLD_OK) { rcs[(size_t)t] = rc; return; }
+          row_site = s1;
+          ++sites_done[(size_t)t];
+        }
+        auto hit = cache.find(s2);
+        if (hit == cache.end()) {
+          if (cache.size() >= cache_cap) cache.clear();
+          hit = cache.emplace(s2, ReplaySite()).first;
+          const int rc = fetch_replay_site(c, s2, tmp, &hit->second);
+          if (rc != NGSLD_OK) { rcs[(size_t)t] = rc; return; }
+          ++sites_done[(size_t)t];
+        }
+        replay_pair(row, hit->second, c->n_ind, ign, &out_std[k], ext ? &out_ext[k] : nullptr, &stats[(size_t)t]);
+      }
+    } catch (...) {
+      rcs[(size_t)t] = NGSLD_ERR_NOMEM;
+    }
+  };
+  if (T <= 1) {
+    T = 1;
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+  }
+  for (int t = 0; t < T; ++t) {
+    if (rcs[(size_t)t] != NGSLD_OK)
+      return fail(c, rcs[(size_t)t], rcs[(size_t)t] == NGSLD_ERR_SINK ? "the replay source callback failed"
+                                                                      : "exact-order replay failed");
+    if (stats[(size_t)t] == NGSLD_ERR_MAF_RANGE) {
+      const int v = NGSLD_ERR_MAF_RANGE;
+      HIP_TRY(c, hipMemcpy(c->d_status.p, &v, sizeof(int), hipMemcpyHostToDevice));
+    }
+    c->replayed_sites += sites_done[(size_t)t];
+  }
+  c->replayed_pairs += recs.size();
+  if (h_std != nullptr) {
+    for (size_t k = 0; k < recs.size(); ++k) {
+      h_std[recs[k]] = out_std[k];
+      if (ext && h_ext != nullptr) h_ext[recs[k]] = out_ext[k];
+    }
+    return NGSLD_OK;
+  }
+  HIP_TRY(c, c->d_patch_idx.resize(recs.size()));
+  HIP_TRY(c, c->d_patch_std.resize(recs.size()));
+  if (ext) HIP_TRY(c, c->d_patch_ext.resize(recs.size()));
+  HIP_TRY(c, hipMemcpyAsync(c->d_patch_idx.p, recs.data(), recs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(c->d_patch_std.p, out_std.data(), recs.size() * sizeof(ngsld_rec_std), hipMemcpyHostToDevice, st));
+  if (ext)
+    HIP_TRY(c, hipMemcpyAsync(c->d_patch_ext.p, out_ext.data(), recs.size() * sizeof(ngsld_rec_ext), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(patch_records_kernel, dim3((unsigned)((recs.size() + 255) / 256)), dim3(256), 0, st, c->d_patch_idx.p,
+                     (uint64_t)recs.size(), c->d_patch_std.p, ext ? c->d_patch_ext.p : nullptr, d_std, ext ? d_ext : nullptr);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(st));  // the pageable source vectors go out of scope
+  return NGSLD_OK;
+}
+
+// A flag buffer for n records, zeroed on `stream`.
+int reset_flags(ngsld_ctx *c, DevBuf<uint32_t> &buf, uint64_t n, hipStream_t stream) {
+  const size_t words = 2 + (size_t)((n + 31) / 32);
+  HIP_TRY(c, buf.resize(words));
+  HIP_TRY(c, hipMemsetAsync(buf.p, 0, words * sizeof(uint32_t), stream));
+  return NGSLD_OK;
+}
+
+int finish_device_run(ngsld_ctx *c) {
+  if (!c->dev_run.pending) return NGSLD_OK;
+  c->dev_run.pending = false;
+  HIP_TRY(c, hipStreamSynchronize(c->dev_run.st));
+  if (!c->replay_on || c->d_flags_dev.p == nullptr) return NGSLD_OK;
+  uint32_t count = 0;
+  HIP_TRY(c, hipMemcpyAsync(&count, c->d_flags_dev.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->replay_stream));
+  HIP_TRY(c, hipStreamSynchronize(c->replay_stream));
+  if (count == 0) return NGSLD_OK;
+  const uint64_t base = c->h_row_off[c->dev_run.s1_begin], n = c->h_row_off[c->dev_run.s1_end] - base;
+  return replay_flagged(c, c->d_flags_dev.p, base, n, nullptr, nullptr, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st);
 }
 
 }  // namespace
@@ -440,8 +682,11 @@ int ngsld_create(int device, ngsld_ctx **out) {
     const uint64_t v = std::strtoull(k, nullptr, 10);
     if (v > 0) c->batch_pairs = v;
   }
+  if (const char *k = std::getenv("NGSLD_REPLAY")) c->replay_on = std::strcmp(k, "0") != 0;  // A/B, tests
+  if (const char *k = std::getenv("NGSLD_REPLAY_THREADS")) c->replay_threads = std::atoi(k);
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
-      (e = hipStreamCreate(&c->copy_stream)) != hipSuccess) {
+      (e = hipStreamCreate(&c->copy_stream)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&c->replay_stream, hipStreamNonBlocking)) != hipSuccess) {
     g_create_error = std::string("stream setup: ") + hipGetErrorString(e);
     delete c;
     return NGSLD_ERR_DEVICE;
@@ -478,6 +723,7 @@ void ngsld_destroy(ngsld_ctx *c) {
   }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->replay_stream) (void)hipStreamDestroy(c->replay_stream);
   delete c;
 }
 
@@ -540,6 +786,34 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
   if (!(p->rnd_sample >= 0 && p->rnd_sample <= 1))  // parse_args.cpp:180-181 (0 is taken as "off" here)
     return fail(c, NGSLD_ERR_INVALID, "proportion of comparisons to sample must be in ]0,1]!");
   const bool sampling = p->rnd_sample > 0 && p->rnd_sample < 1;
+  c->replayed_sites = 0;
+  c->dev_run.pending = false;
+  if (c->replay_on && c->replay_read != nullptr && !c->normalised) {
+    // A frequency that ties --min_maf to the last bits falls on either side of `maf < min_maf` (ngsLD.cpp:264-275)
+    // depending on the order est_maf adds its terms up in (the prep kernel block-reduces them), and one that sits on a
+    // rounding point of the sixth decimal prints a different last digit (maf1 / maf2, ngsLD.cpp:338-339).  Such sites get
+    // the reference's own sequential est_maf from the caller's raw values, and keep it for everything downstream.
+    bool changed = false;
+    std::vector<double> tmp;
+    ReplaySite site;
+    for (uint64_t s = 0; s < n; ++s) {
+      const double m = c->h_maf[s], t = std::fabs(m) * 1e6;
+      const bool tie = p->min_maf > 0 && std::fabs(m - p->min_maf) <= 1e-12;
+      const bool edge = p->extend_out && std::fabs((t - std::floor(t)) - 0.5) < 1e-6;  // within 1e-12 of a rounding point
+      if (!tie && !edge) continue;
+      const int rcs = fetch_replay_site(c, s, tmp, &site);
+      if (rcs != NGSLD_OK) return fail(c, rcs, "the replay source callback failed");
+      ++c->replayed_sites;
+      if (site.maf != m && !(site.maf != site.maf && m != m)) {
+        c->h_maf[s] = site.maf;
+        changed = true;
+      }
+    }
+    if (changed) {
+      HIP_TRY(c, hipMemcpy(c->d_maf.p, c->h_maf.data(), n * sizeof(double), hipMemcpyHostToDevice));
+      HIP_TRY(c, launch_pack_scalars(c->d_maf.p, c->d_mean.p, c->d_rsx.p, c->d_sc4.p, n, c->stream));
+    }
+  }
   plan_rows(c->h_pos_dist, c->h_maf, *p, n, c->h_row_end);
   c->h_keep.resize(n);
   for (uint64_t s = 0; s < n; ++s) c->h_keep[s] = (c->h_maf[s] < p->min_maf) ? 0 : 1;  // ngsLD.cpp:270
@@ -657,6 +931,37 @@ int ngsld_set_text_output(ngsld_ctx *c, const char *const *labels, int enable) t
   return NGSLD_OK;
 } NGSLD_CATCH(c)
 
+int ngsld_set_replay_source(ngsld_ctx *c, ngsld_read_sites_fn read, void *user) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "set the genotype data before its replay source");
+  c->replay_read = read;
+  c->replay_user = user;
+  c->planned = false;  // a --min_maf tie is settled at plan time
+  return NGSLD_OK;
+}
+
+int ngsld_set_replay(ngsld_ctx *c, int enable) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  c->replay_on = enable != 0;
+  c->planned = false;
+  return NGSLD_OK;
+}
+
+int ngsld_replay_stats(ngsld_ctx *c, uint64_t *pairs, uint64_t *sites) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (pairs) *pairs = c->replayed_pairs;
+  if (sites) *sites = c->replayed_sites;
+  return NGSLD_OK;
+}
+
+int ngsld_finish_device(ngsld_ctx *c) try {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int rc = finish_device_run(c);
+  if (rc != NGSLD_OK) return rc;
+  return check_status(c);
+} NGSLD_CATCH(c)
+
 int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_std, void *d_ext, void *hip_stream) try {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   if (!c->planned) return fail(c, NGSLD_ERR_INVALID, "ngsld_plan has not been called");
@@ -667,22 +972,35 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
   c->ev_used = 0;
   c->timed_stream = st;
   c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
+  c->replayed_pairs = 0;
+  if (c->replay_on) {
+    const int rcf = reset_flags(c, c->d_flags_dev, c->timed_pairs, st);
+    if (rcf != NGSLD_OK) return rcf;
+  }
   // one launch per <= 2^31-1 workgroups; rows are cut so that each launch's grid fits
   const uint64_t max_items = 0x7ffffff0ull;
   uint64_t r0 = s1_begin;
   while (r0 < s1_end) {
     uint64_t r1 = r0 + 1;
     while (r1 < s1_end && c->h_item_off[r1 + 1] - c->h_item_off[r0] <= max_items) ++r1;
-    PairArgs a = make_args(c, r0, r1, (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext);
+    PairArgs a = make_args(c, r0, r1, (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, c->replay_on ? c->d_flags_dev.p : nullptr);
     a.out_base = c->h_row_off[s1_begin];
+    a.flag_text = 0;  // these records stay on the device: only numerically ill-conditioned pairs are replayed
     HIP_TRY(c, timed_launch(c, a, st));
     r0 = r1;
   }
+  c->dev_run.pending = true;
+  c->dev_run.s1_begin = s1_begin;
+  c->dev_run.s1_end = s1_end;
+  c->dev_run.d_std = (ngsld_rec_std *)d_std;
+  c->dev_run.d_ext = (ngsld_rec_ext *)d_ext;
+  c->dev_run.st = st;
   if (hip_stream == nullptr) {
-    HIP_TRY(c, hipStreamSynchronize(st));
+    const int rcd = finish_device_run(c);  // waits for the kernels, replays what they flagged
+    if (rcd != NGSLD_OK) return rcd;
     return check_status(c);
   }
-  return NGSLD_OK;
+  return NGSLD_OK;  // (the caller's stream: the records are final after ngsld_finish_device)
 } NGSLD_CATCH(c)
 
 int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user) try {
@@ -694,6 +1012,9 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   c->ev_used = 0;
   c->timed_stream = c->stream;
   c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
+  c->replayed_pairs = 0;
+  c->dev_run.pending = false;
+  const bool replay = c->replay_on;
 
   // Device-side TSV: the dist column needs prefix sums of pos_dist that are EXACT (the host writer adds the gaps one
   // by one, ngsLD.cpp:241), i.e. integer gaps as read_dist produces them; otherwise the batches go out as records.
@@ -722,14 +1043,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       HIP_TRY(c, hipMemcpy(c->d_infc.p, infc.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
   }
-  auto need_host_items = [&]() -> int {  // the host copy of the plan's items, fetched on first use
-    if (c->h_items.size() != c->n_items) {
-      c->h_items.resize(c->n_items);
-      if (c->n_items)
-        HIP_TRY(c, hipMemcpy(c->h_items.data(), c->d_items.p, c->n_items * sizeof(Item), hipMemcpyDeviceToHost));
-    }
-    return NGSLD_OK;
-  };
+  auto need_host_items = [&]() -> int { return ensure_host_items(c); };
   if (!text) {
     const int rc0 = need_host_items();
     if (rc0 != NGSLD_OK) return rc0;
@@ -762,11 +1076,16 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       HIP_TRY(c, c->h_std[k].resize(cap));
       if (ext) HIP_TRY(c, c->h_ext[k].resize(cap));
     }
+    if (replay) {
+      HIP_TRY(c, c->d_flags[k].resize(2 + (size_t)((cap + 31) / 32)));
+      HIP_TRY(c, c->h_flag_count[k].resize(2));
+    }
   }
   size_t scan_bytes = 0;
   if (text) {
     scan_bytes = text_scan_temp_bytes(cap);
     HIP_TRY(c, c->d_scan_tmp.resize(scan_bytes ? scan_bytes : 1));
+    if (replay) HIP_TRY(c, c->d_scan_tmp2.resize(scan_bytes ? scan_bytes : 1));
   }
   auto text_args = [&](const Batch &b, int k) -> TextArgs {
     TextArgs t{};
@@ -791,8 +1110,14 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   auto issue = [&](size_t bi) -> int {  // kernel on `stream`, D2H on `copy_stream`
     const int k = (int)(bi & 1);
     const Batch &b = batches[bi];
-    PairArgs a = make_args(c, b.r0, b.r1, c->d_std[k].p, ext ? c->d_ext[k].p : nullptr);
+    if (replay) {
+      const int rcf = reset_flags(c, c->d_flags[k], b.n, c->stream);
+      if (rcf != NGSLD_OK) return rcf;
+    }
+    PairArgs a = make_args(c, b.r0, b.r1, c->d_std[k].p, ext ? c->d_ext[k].p : nullptr, replay ? c->d_flags[k].p : nullptr);
     HIP_TRY(c, timed_launch(c, a, c->stream));
+    if (replay)  // how many pairs the kernel flagged for the exact-order replay: known to the host with the batch
+      HIP_TRY(c, hipMemcpyAsync(c->h_flag_count[k].p, c->d_flags[k].p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     if (text) {  // row lengths and their prefix sums right behind the pair kernel; the rows are written at consume time
       HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), c->stream));
       const TextArgs t = text_args(b, k);
@@ -835,6 +1160,20 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       // the batch's text: its length is known now; the rows are written and copied on the copy stream while the pair
       // kernel of the next batch (already enqueued) runs on the compute stream
       HIP_TRY(c, hipEventSynchronize(c->ev_kernel_done[k]));
+      if (replay && c->h_flag_count[k].p[0] != 0) {
+        // flagged pairs: replayed on the host, patched into the device records, and the row lengths derived again --
+        // all on the copy stream, beside the next batch's pair kernel
+        const int rcr = replay_flagged(c, c->d_flags[k].p, c->h_row_off[b.r0], b.n, nullptr, nullptr, c->d_std[k].p,
+                                       ext ? c->d_ext[k].p : nullptr, c->copy_stream);
+        if (rcr != NGSLD_OK) return rcr;
+        HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), c->copy_stream));
+        const TextArgs t = text_args(b, k);
+        HIP_TRY(c, launch_text_lengths(t, c->copy_stream));
+        HIP_TRY(c, text_scan(c->d_scan_tmp2.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n, c->d_text_meta[k].p, c->copy_stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                  c->copy_stream));
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+      }
       const uint64_t total = c->h_text_meta[k].p[0];
       bool needs_host = (c->h_text_meta[k].p[1] & 0xffffffffull) != 0;
       if (const char *e = std::getenv("NGSLD_TEXT_FALLBACK_EVERY")) {  // tests: every n-th batch takes the record path
@@ -869,6 +1208,11 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       }
     } else {
       HIP_TRY(c, hipEventSynchronize(c->ev_copy_done[k]));
+      if (replay && c->h_flag_count[k].p[0] != 0) {  // flagged pairs: replayed on the host, patched into the batch's buffers
+        const int rcr = replay_flagged(c, c->d_flags[k].p, c->h_row_off[b.r0], b.n, c->h_std[k].p, ext ? c->h_ext[k].p : nullptr,
+                                       nullptr, nullptr, nullptr);
+        if (rcr != NGSLD_OK) return rcr;
+      }
     }
     if (as_records) {
       rel_items.assign(c->h_items.begin() + (ptrdiff_t)i0, c->h_items.begin() + (ptrdiff_t)i1);

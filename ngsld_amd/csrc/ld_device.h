@@ -49,6 +49,20 @@ constexpr bool kTreeRcp = NGSLD_PAIR_RCP == 2;
 constexpr int kIterMax = 100;      // ITER_MAX, gen_func.hpp:18
 constexpr double kEpsilon = 1e-5;  // EPSILON,  gen_func.hpp:16
 
+// Exact-order replay (replay.h): the kernels FLAG the pairs whose outcome the reference's own rounding decides and the
+// engine re-evaluates those on the host in the reference's operation order.  A pair is flagged when
+//   * a hap-derived allele frequency 1 - (f0 + f1) / 1 - (f0 + f2) (ngsLD.cpp:297-298) is within kReplayBelow of 0 or 1:
+//     it carries ~1e-16 of ABSOLUTE rounding noise in the reference, so D' and r2 (quotients by products of these
+//     margins) are only reproducible to 1e-16 / q -- below 2^-18 that is no longer safely inside 1e-9, and at q ~ 1e-16
+//     the noise alone decides between nan, 0 and inf -- or any frequency is NaN;
+//   * eps came within kTieMargin of EPSILON in some iteration (gen_func.cpp:1054: nIter could differ by one);
+//   * one of its sites has expected genotypes that are constant up to rounding (negative rsx, see prep_sites_kernel):
+//     gsl_stats_correlation is then a 0/0-type quotient of its own accumulation noise (ngsLD.cpp:365-367).
+constexpr double kReplayBelow = 0x1p-18;
+constexpr double kTieMargin = 1e-12;
+constexpr double kEpsilonTie = kEpsilon + kTieMargin;
+constexpr uint32_t kTieBit = 0x80000000u;  // rides on n_iter (<= 100) from the EM loop to write_pair
+
 // One unit of work = ngsld_item: pairs (s1, s2_begin + c) for the bits c set in mask, records from first_record.
 typedef ngsld_item Item;
 
@@ -84,6 +98,10 @@ struct PairArgs {
   const uint64_t *hard_masks;  // [n_sites][4][mask_words]
   const double *hard_u;        // [n_sites] the value of the three equal likelihoods of an individual without data
   uint32_t mask_words;         // ceil(n_ind / 64)
+  // exact-order replay: flags[0] counts the flagged pairs, bit r of flags[2 + r / 32] marks record r of the output
+  // buffers (null: no flagging)
+  uint32_t *flags;
+  uint32_t flag_text;  // also flag the pairs whose printed digits (six decimals) rounding noise could change
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -418,7 +436,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   // scale of f, so it is not repeated per iteration.  inv_x = 1/x; x == 0 gives 0 * inf = NaN like the reference's 0/0.
   // (held in a VGPR: the four products t_k * inv_x below take t_k from SGPRs, and a VALU op reads one SGPR at most)
   asm("" : "+v"(inv_x));
-  bool bad = false;
+  bool bad = false, tie = false;
   uint32_t n_iter = 0;
   // Slots known to be full (no padding / missing lanes) take their reciprocals two at a time:
   //   r = 1/(s_a s_b),  1/s_a = s_b r,  1/s_b = s_a r      -- one 16-cycle v_rcp_f64 + 3 mul instead of two rcp chains.
@@ -568,9 +586,10 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
         // eps = the largest of the four changes (gen_func.cpp:1049-1053) is at least the change of hap 1: while that one
         // alone is above EPSILON -- nine iterations in ten -- the other three differences are not formed
         bool conv = false;
-        if (!NGSLD_EARLY_EPS || __builtin_amdgcn_ballot_w64(fabs(n1 - f1) < kEpsilon)) {
+        if (!NGSLD_EARLY_EPS || __builtin_amdgcn_ballot_w64(fabs(n1 - f1) < kEpsilonTie)) {
           const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
           conv = __builtin_amdgcn_ballot_w64(eps < kEpsilon) != 0;  // gen_func.cpp:1054-1055
+          tie |= __builtin_amdgcn_ballot_w64(fabs(eps - kEpsilon) < kTieMargin) != 0;  // too close to call: replayed
         }
         f0 = n0; f1 = n1; f2 = n2; f3 = n3;
         if (conv) {
@@ -601,28 +620,30 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     }
     const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
     f0 = n0; f1 = n1; f2 = n2; f3 = n3;
+    tie |= __builtin_amdgcn_ballot_w64(fabs(eps - kEpsilon) < kTieMargin) != 0;
     if (__builtin_amdgcn_ballot_w64(eps < kEpsilon)) break;
     ++n_iter;
     if (kDrop0 && !full && __builtin_amdgcn_ballot_w64(f0 < kFullBelow)) full = true;  // (wavefronts without a hot loop)
   }
   if (bad) f0 = f1 = f2 = f3 = __builtin_nan("");
-  return n_iter;
+  return n_iter | (tie ? kTieBit : 0u);
 }
 
-// ngsLD.cpp:296-306 (hap-derived maf, D, D', r2) + pearson_r, one record per pair.
+// Is v closer than d to a point where "%f" (six decimals) rounds the other way?  NaN / inf: no.
+__device__ __forceinline__ bool near_rounding(double v, double d) {
+  const double t = fabs(v) * 1e6;
+  return fabs((t - floor(t)) - 0.5) < d * 1e6;
+}
+
+// ngsLD.cpp:296-306 (hap-derived maf, D, D', r2) + pearson_r, one record per pair; pairs whose outcome the reference's
+// rounding decides are flagged for the exact-order replay (see kReplayBelow).
 __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, double f0, double f1, double f2,
                                            double f3, double sxy, double rsx1, double rsx2, uint32_t x,
                                            uint32_t n_iter) {
-  // 1 - (f0 + f1) carries ~1e-16 of rounding noise; at a monomorphic site that noise alone decides in
-  // the reference whether D' and r2 come out as 0/0 = NaN or 0/1e-16 = 0.  Noise-sized values are
-  // snapped to the exact 0 / 1 they stand for, which is the reference's outcome whenever its own
-  // rounding happens to cancel (DESIGN.md "degenerate pairs").
-  double hm0 = 1 - (f0 + f1);
-  double hm1 = 1 - (f0 + f2);
-  if (fabs(hm0) < 1e-15) hm0 = 0.0;
-  if (fabs(1 - hm0) < 1e-15) hm0 = 1.0;
-  if (fabs(hm1) < 1e-15) hm1 = 0.0;
-  if (fabs(1 - hm1) < 1e-15) hm1 = 1.0;
+  const bool tie = (n_iter & kTieBit) != 0;
+  n_iter &= ~kTieBit;
+  const double hm0 = 1 - (f0 + f1);
+  const double hm1 = 1 - (f0 + f2);
   const double D = f0 * f3 - f1 * f2;
   const double q00 = hm0 * hm1, q11 = (1 - hm0) * (1 - hm1);
   const double q01 = hm0 * (1 - hm1), q10 = (1 - hm0) * hm1;
@@ -630,8 +651,10 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
   const double Dp = D / den;
   const double rr = D / sqrt(hm0 * hm1 * (1 - hm0) * (1 - hm1));
   // a constant site (rsx = 1/sqrt(0) = inf) is 0/0 = NaN in gsl_stats_correlation; said explicitly because a cross
-  // moment centred after the fact (run kernel) is only ~0 there, not exactly 0
-  const double r = (rsx1 == __builtin_inf() || rsx2 == __builtin_inf()) ? __builtin_nan("") : sxy * rsx1 * rsx2;
+  // moment centred after the fact (run kernel) is only ~0 there, not exactly 0.  The sign of rsx is the prep kernel's
+  // "constant up to rounding" mark.
+  const double a1 = fabs(rsx1), a2 = fabs(rsx2);
+  const double r = (a1 == __builtin_inf() || a2 == __builtin_inf()) ? __builtin_nan("") : sxy * a1 * a2;
   ngsld_rec_std o;
   o.r2_ExpG = r * r;
   o.D = D;
@@ -644,6 +667,31 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
     e.n_ind_data = x;
     e.n_iter = n_iter;
     A.out_ext[slot] = e;
+  }
+  if (A.flags != nullptr) {
+    const double q0 = fabs(hm0) <= fabs(1 - hm0) ? fabs(hm0) : fabs(1 - hm0);
+    const double q1 = fabs(hm1) <= fabs(1 - hm1) ? fabs(hm1) : fabs(1 - hm1);
+    // (NaN frequencies fail both comparisons)
+    bool flag = tie || !(q0 >= kReplayBelow) || !(q1 >= kReplayBelow) || rsx1 < 0 || rsx2 < 0;
+    // The TSV prints six decimals (ngsLD.cpp:314-349).  A value that sits on a rounding point of the sixth decimal --
+    // closer to it than this kernel and the reference can differ -- would print a different last digit, and a D within
+    // rounding noise of zero a different sign ("-0.000000"): those pairs are replayed too, so that the text is the
+    // reference's byte for byte.  Error bounds: hap, hap_maf and D are absolute (a few ulp of 1); D' and r2 divide by
+    // products of the margins q (relative error ~ulp / q); r2_ExpG carries ~ulp * n * rsx1 * rsx2 of cancellation.
+    // (flag_text: only where the records may become text -- ngsld_run; ngsld_run_device leaves them on the device)
+    constexpr double kUlp = 0x1p-52;
+    const double d_abs = A.flag_text ? 32 * kUlp : -1.0;  // (negative: near_rounding is never true)
+    const double amp = A.flag_text ? 1.0 / q0 + 1.0 / q1 : 0.0;
+    flag = flag || fabs(D) < 2 * d_abs || near_rounding(D, d_abs) || near_rounding(Dp, 2 * d_abs * (1.0 + fabs(Dp) * amp)) ||
+           near_rounding(o.r2, 2 * d_abs * (1.0 + o.r2 * amp)) ||
+           near_rounding(o.r2_ExpG, 0.5 * d_abs * (1.0 + 4.0 * (double)A.n_ind * a1 * a2));
+    if (A.out_ext != nullptr)
+      flag = flag || near_rounding(f0, d_abs) || near_rounding(f1, d_abs) || near_rounding(f2, d_abs) ||
+             near_rounding(f3, d_abs) || near_rounding(hm0, d_abs) || near_rounding(hm1, d_abs);
+    if (flag) {
+      atomicOr(&A.flags[2 + (slot >> 5)], 1u << (slot & 31u));
+      atomicAdd(&A.flags[0], 1u);
+    }
   }
 }
 
@@ -1366,7 +1414,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
         n0 = kT ? t0 : t0 * inv_x;
       }
     };
-    bool done = !active;
+    bool done = !active, tie = false;
     uint32_t n_iter = (uint32_t)kIterMax;
     // As in em_pair: the hot loop holds the shared-reciprocal step in its three-value form only; a step that is not sane
     // in some live group leaves it for one iteration with a reciprocal per individual, and as soon as hap 0 of any live
@@ -1383,8 +1431,9 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
           if (__any(!done && !(n1 < 2.0))) break;  // an odd step (one NaN reciprocal poisons every R, see em_pair)
           // as in em_pair: eps is at least the change of hap 1, and while that alone is above EPSILON in every live
           // group the other three differences are not formed
-          if (!NGSLD_EARLY_EPS || __any(!done && fabs(n1 - f1) < kEpsilon)) {
+          if (!NGSLD_EARLY_EPS || __any(!done && fabs(n1 - f1) < kEpsilonTie)) {
             const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
+            if (!done && fabs(eps - kEpsilon) < kTieMargin) tie = true;  // too close to call: replayed
             if (!done && eps < kEpsilon) {  // gen_func.cpp:1054-1055
               done = true;
               n_iter = itn;
@@ -1417,6 +1466,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
           n_iter = itn;
         } else {
           f0 = n0; f1 = n1; f2 = n2; f3 = n3;
+          if (fabs(eps - kEpsilon) < kTieMargin) tie = true;
           if (eps < kEpsilon) {
             done = true;
             n_iter = itn;
@@ -1434,7 +1484,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       r.sxy = sxy;
       r.rsx2 = rsx2;
       r.x = x;
-      r.n_iter = n_iter;
+      r.n_iter = n_iter | (tie ? kTieBit : 0u);
       r.rec = active ? cur.rec : ~0ull;
     }
     held += (uint32_t)kGroups;
@@ -1509,7 +1559,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_stream_kernel(PairArgs A) {
       f0 = f1 = f2 = f3 = __builtin_nan("");
     }
     const double inv_x = 1.0 / (double)x;
-    bool bad = false;
+    bool bad = false, tie = false;
     uint32_t n_iter = 0;
     for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
       const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
@@ -1556,11 +1606,13 @@ __global__ __launch_bounds__(256, 2) void pair_ld_stream_kernel(PairArgs A) {
       }
       const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
       f0 = n0; f1 = n1; f2 = n2; f3 = n3;
+      if (fabs(eps - kEpsilon) < kTieMargin) tie = true;
       if (__builtin_amdgcn_readfirstlane((int)(eps < kEpsilon))) break;
     }
     if (bad) f0 = f1 = f2 = f3 = __builtin_nan("");
     if (threadIdx.x == 0)
-      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, rsx2, x, n_iter);
+      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, rsx2, x,
+                 n_iter | (tie ? kTieBit : 0u));
   }
 }
 

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 4) void pair_ld_hard_kernel(PairArgs A) {
       if (gl == 0) atomicExch(A.status, (int)NGSLD_ERR_MAF_RANGE);
       f0 = f1 = f2 = f3 = __builtin_nan("");
     }
-    bool done = !active;
+    bool done = !active, tie = false;
     uint32_t n_iter = (uint32_t)kIterMax;
     for (uint32_t itn = 0; itn < (uint32_t)kIterMax; ++itn) {
       const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256, 4) void pair_ld_hard_kernel(PairArgs A) {
         } else {
           const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
           f0 = n0; f1 = n1; f2 = n2; f3 = n3;
+          if (fabs(eps - kEpsilon) < kTieMargin) tie = true;  // too close to call: replayed in the reference's order
           if (eps < kEpsilon) {  // gen_func.cpp:1054-1055
             done = true;
             n_iter = itn;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256, 4) void pair_ld_hard_kernel(PairArgs A) {
       r.sxy = sxy;
       r.rsx2 = rsx2;
       r.x = x;
-      r.n_iter = n_iter;
+      r.n_iter = n_iter | (tie ? kTieBit : 0u);
       r.rec = active ? cur.rec : ~0ull;
     }
     held += 4;

@@ -160,7 +160,14 @@ __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
     if (threadIdx.x == 0) {
       A.maf[A.site0 + site] = A.normalised_input ? A.maf_in[site] : acc[0] / acc[1];
       A.mean_e[A.site0 + site] = mean;
-      A.rsx[A.site0 + site] = 1.0 / sqrt(sq[0]);
+      // A site whose expected genotypes are constant UP TO ROUNDING (spread below 1/500 of their size: nobody carries
+      // information) leaves gsl_stats_correlation a quotient of its own accumulation noise; such a site is marked by a
+      // NEGATIVE rsx and its pairs go through the exact-order replay (ld_device.h, kReplayBelow).  An exactly constant
+      // site (rsx = +inf) is NaN on every path and needs no replay.
+      double rs = 1.0 / sqrt(sq[0]);
+      const double size = fabs(mean) > 1.0 ? fabs(mean) : 1.0;
+      if (rs != __builtin_inf() && sqrt((double)A.n_ind) * size * rs > 500.0) rs = -rs;
+      A.rsx[A.site0 + site] = rs;
     }
     if (nan_seen) atomicExch(A.status, (int)NGSLD_ERR_NAN);
   }

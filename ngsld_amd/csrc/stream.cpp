@@ -48,6 +48,19 @@ int rebase_sink(void *user, const ngsld_batch *b) {
   return r->sink(r->user, &g);
 }
 
+// Replay source of one slab (ngsld_set_replay_source): its raw values as they sit in the host slab buffer.
+struct SlabSource {
+  const double *raw;
+  uint64_t n_sites, n_ind;
+};
+
+int read_slab_copy(void *user, uint64_t site_begin, uint64_t n, double *dst) {
+  const SlabSource *s = static_cast<const SlabSource *>(user);
+  if (site_begin + n > s->n_sites) return 1;
+  std::memcpy(dst, s->raw + site_begin * s->n_ind * 3, n * s->n_ind * 3 * sizeof(double));
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -156,6 +169,7 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
   std::string load_msg;
   slab_pairs.assign(n_slabs, 0);  // (n_slabs <= n_sites words: not guarded separately)
 
+  SlabSource src[2] = {};
   std::thread loader([&]() {
     uint64_t maf_done = 0;  // maf_out[0, maf_done) is final
     for (uint64_t k = 0; k < n_slabs; ++k) {
@@ -175,23 +189,32 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
         msg = "cannot read the genotype data of a slab";
       }
       if (r == NGSLD_OK) {
-        r = ngsld_set_geno_raw_opts(ctx[b], host[b].data(), m, n_ind, opts);
-        if (r == NGSLD_OK && maf_out != nullptr && sl.site_end > maf_done) {
-          // only the sites no earlier slab delivered: entries a sink may be reading are never rewritten
-          std::vector<double> maf(m);
-          r = ngsld_get_maf(ctx[b], maf.data());
-          if (r == NGSLD_OK) {
-            const uint64_t from = std::max(maf_done, sl.row_begin);
-            std::memcpy(maf_out + from, maf.data() + (from - sl.row_begin), (sl.site_end - from) * sizeof(double));
-            maf_done = sl.site_end;
-          }
-        }
+        // One kernel family for the whole job: a slab that happens to hold only called genotypes must not switch to the
+        // genotype-combination kernel while its neighbours run the per-individual one (same values to 1e-12, not the
+        // same bits).
+        ngsld_geno_opts so = *opts;
+        so.per_individual_only = 1;
+        r = ngsld_set_geno_raw_opts(ctx[b], host[b].data(), m, n_ind, &so);
+        // exact-order replay: the slab's raw values stay in host[b] until its run is over
+        src[b] = SlabSource{host[b].data(), m, n_ind};
+        if (r == NGSLD_OK) r = ngsld_set_replay_source(ctx[b], read_slab_copy, &src[b]);
         if (r == NGSLD_OK) r = ngsld_set_pos_dist(ctx[b], pos_dist ? pos_dist + sl.row_begin : nullptr);
         if (r == NGSLD_OK) {
           ngsld_params p = *params;
           p.first_row = params->first_row + sl.row_begin;
           uint64_t all_rows = 0;  // includes the halo rows, which the next slab computes
           r = ngsld_plan(ctx[b], &p, &all_rows);
+          if (r == NGSLD_OK && maf_out != nullptr && sl.site_end > maf_done) {
+            // (after the plan: a frequency that ties --min_maf has been settled by then.)  Only the sites no earlier slab
+            // delivered: entries a sink may be reading are never rewritten
+            std::vector<double> maf(m);
+            r = ngsld_get_maf(ctx[b], maf.data());
+            if (r == NGSLD_OK) {
+              const uint64_t from = std::max(maf_done, sl.row_begin);
+              std::memcpy(maf_out + from, maf.data() + (from - sl.row_begin), (sl.site_end - from) * sizeof(double));
+              maf_done = sl.site_end;
+            }
+          }
           const uint64_t *row_off = nullptr;
           if (r == NGSLD_OK) r = ngsld_plan_rows(ctx[b], &row_off, nullptr);
           if (r == NGSLD_OK) slab_pairs[k] = row_off[sl.row_end - sl.row_begin];

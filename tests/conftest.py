@@ -44,3 +44,16 @@ def engine():
     eng = capi.Engine(0)
     yield eng
     eng.close()
+
+
+def pytest_terminal_summary(terminalreporter):
+    """How many pairs the parity checks compared, and how many of them needed more than the 1e-9 bar (expected: none --
+    the ill-conditioned ones are replayed in the reference's operation order)."""
+    try:
+        from util import REPORT
+    except ImportError:
+        from tests.util import REPORT
+    if REPORT["pairs"]:
+        terminalreporter.write_line(
+            f"parity: {REPORT['pairs']} pairs compared with the oracle, {REPORT['over_tol']} beyond 1e-9, "
+            f"{REPORT['degenerate']} degenerate pairs held to bit equality, largest difference {REPORT['max_diff']:.3e}")

@@ -44,19 +44,18 @@ REGRESSION_SEEDS = [270, 330, 334, 441, 450, 465, 520, 530, 542, 638, 728, 754]
 
 
 def pick_min_maf(maf: np.ndarray, k: int) -> float:
-    """Every third case filters by allele frequency: the 0.3 quantile of the sites' own frequencies, to three decimals.
-    A threshold that EQUALS a site's frequency to the last bits is stepped aside: there `maf < min_maf` is decided by the
-    rounding noise of the reference's sequential est_maf sums (gen_func.cpp:995-996), which a differently ordered sum cannot
-    reproduce (deviations: found by tools/fuzz_soak.py, case 5178, where discrete likelihood values made a
-    frequency of exactly 0.185)."""
-    if k % 3 != 0 or not np.isfinite(maf).any():
+    """Every third case filters by allele frequency: the 0.3 quantile of the sites' own frequencies, to three decimals
+    -- and every sixth uses a site's frequency ITSELF as the threshold: `maf < min_maf` (ngsLD.cpp:264-275) is then
+    decided by the last bits of the reference's sequential est_maf sums (gen_func.cpp:995-996), which the engine
+    reproduces by re-evaluating tied sites in that order (round 1 stepped such thresholds aside: tools/fuzz_soak.py
+    case 5178, where discrete likelihood values made a frequency of exactly 0.185)."""
+    ok = np.isfinite(maf)
+    if k % 3 != 0 or not ok.any():
         return 0.0
-    m0 = float(np.round(np.nanquantile(maf[np.isfinite(maf)], 0.3), 3))
-    for step in range(40):
-        m = float(np.round(m0 + 0.0007 * ((step + 1) // 2) * (1 if step % 2 else -1), 4)) if step else m0
-        if 0.0 <= m <= 1.0 and not np.any(np.abs(maf[np.isfinite(maf)] - m) < 1e-9):
-            return m
-    return m0
+    if k % 6 == 0:
+        cand = np.sort(maf[ok])
+        return float(cand[int(0.3 * (len(cand) - 1))])
+    return float(np.round(np.nanquantile(maf[ok], 0.3), 3))
 
 
 @pytest.mark.parametrize("k", list(range(240)) + REGRESSION_SEEDS)

@@ -1,0 +1,83 @@
+"""The product's exact-order replay (ngsld_amd/csrc/replay.cpp, C door ngsld_host_replay_pair) against the oracle:
+BIT-identical records -- hap, nIter, sample_size, D, D', r2, r2_ExpG, maf -- on every pair of the small fixtures,
+the degenerate ones (monomorphic / all-missing sites: -nan, 0, inf outcomes) included.  No GPU needed."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from ngsld_amd import capi, synth
+from tests.util import Fixture, fixtures
+
+
+def bits(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64)).view(np.uint64)
+
+
+def same_bits(a, b):
+    """Equal bit patterns, any NaN equal to any NaN (the sign of a NaN is not part of the record contract)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return bool(np.all((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))))
+
+
+def check_against_oracle(raw, want, orc_maf, max_pairs=400, **kw):
+    idx = np.arange(len(want))
+    if len(idx) > max_pairs:
+        idx = np.random.default_rng(0).choice(idx, max_pairs, replace=False)
+    for k in idx:
+        w = want[k]
+        s, e, maf = capi.replay_pair(raw[int(w["s1"])], raw[int(w["s2"])], **kw)
+        assert same_bits(maf, [orc_maf[int(w["s1"])], orc_maf[int(w["s2"])]]), ("maf", k)
+        assert int(e["n_iter"]) == int(w["n_iter"]) and int(e["n_ind_data"]) == int(w["n_ind_data"]), ("counts", k)
+        assert same_bits(e["hap"], w["hap"]), ("hap", k, e["hap"], w["hap"])
+        for mine, theirs in (("D", "D"), ("Dp", "Dp"), ("r2", "r2"), ("r2_ExpG", "r2pear")):
+            assert same_bits(s[mine], w[theirs]), (mine, k, s[mine], w[theirs])
+
+
+@pytest.mark.parametrize("name", [n for n in fixtures() if not n.startswith("f8_text")])
+def test_replay_is_bit_identical_to_the_oracle_on_fixture(name):
+    fx = Fixture(name)
+    o = fx.oracle()
+    want = o.run()
+    check_against_oracle(fx.raw, want, o.maf, log_scale=fx.log_scale, ignore_miss_data=fx.ignore_miss,
+                         call_geno=fx.call_geno)
+
+
+@pytest.mark.parametrize("name", [n for n in fixtures() if n.startswith("f8_text")])
+def test_replay_is_bit_identical_on_text_input(name, tmp_path):
+    fx = Fixture(name)
+    o = fx.oracle()
+    want = o.run()
+    g, _ = fx.write_inputs(str(tmp_path))
+    raw, is_log = capi.read_geno_text(g, fx.text_mode == "probs", fx.log_scale, fx.n_ind, fx.n_sites)
+    check_against_oracle(raw, want, o.maf, log_scale=is_log, ignore_miss_data=fx.ignore_miss, text=True,
+                         call_geno=fx.call_geno)
+
+
+def test_replay_on_a_monomorphic_and_a_missing_site():
+    """Hard calls with a monomorphic site, an all-missing site and a site that is constant up to rounding: the 0/0-type
+    outcomes (nan / 0 / inf) are whatever the reference's own rounding makes them -- the replay gives the same bits."""
+    from oracle import orc
+    rng = np.random.default_rng(7)
+    n_ind, n_sites = 37, 14
+    g = rng.integers(0, 3, size=(n_sites, n_ind))
+    raw = np.zeros((n_sites, n_ind, 3))
+    for s in range(n_sites):
+        raw[s, np.arange(n_ind), g[s]] = 1.0
+    raw[3] = 0.0
+    raw[3, :, 0] = 1.0                      # monomorphic
+    raw[5] = 1.0 / 3.0                      # no data at all
+    raw[7, :, :] = [0.2, 0.3, 0.5]          # the same uninformative triple everywhere: spread of e is rounding-sized
+    raw[9, ::2] = 1.0 / 3.0                 # half missing
+    for ign in (False, True):
+        o = orc.Oracle(raw, ignore_miss_data=ign)
+        want = o.run()
+        check_against_oracle(raw, want, o.maf, ignore_miss_data=ign)
+
+
+def test_replay_at_benchmark_cohort_sizes():
+    from oracle import orc
+    for n_ind, seed in ((500, 2), (1000, 3)):
+        raw = synth.make_gl_numpy(12, n_ind, seed=seed, depth=10.0)
+        o = orc.Oracle(raw)
+        check_against_oracle(raw, o.run(), o.maf)
