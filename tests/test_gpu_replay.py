@@ -12,7 +12,7 @@ from util import check_records, same_bits
 pytestmark = pytest.mark.gpu
 
 
-def degenerate_matrix(n_ind=37, n_sites=14, seed=7):
+def degenerate_matrix(n_ind=37, n_sites=14, seed=7, all_called=False):
     rng = np.random.default_rng(seed)
     g = rng.integers(0, 3, size=(n_sites, n_ind))
     raw = np.zeros((n_sites, n_ind, 3))
@@ -21,7 +21,11 @@ def degenerate_matrix(n_ind=37, n_sites=14, seed=7):
     raw[3] = 0.0
     raw[3, :, 0] = 1.0                      # monomorphic
     raw[5] = 1.0 / 3.0                      # no data at all
-    raw[7, :, :] = [0.2, 0.3, 0.5]          # the same uninformative triple everywhere
+    if all_called:
+        raw[7] = 0.0
+        raw[7, :, 2] = 1.0                  # monomorphic for the other allele
+    else:
+        raw[7, :, :] = [0.2, 0.3, 0.5]      # the same uninformative triple everywhere
     raw[9, ::2] = 1.0 / 3.0                 # half missing
     return raw
 
@@ -47,10 +51,10 @@ def all_bits_equal(std, ext, want):
 @pytest.mark.parametrize("ign", [False, True])
 @pytest.mark.parametrize("hard_kernel", [True, False])
 def test_degenerate_pairs_are_the_reference_bits(engine, ign, hard_kernel):
-    raw = degenerate_matrix()
+    raw = degenerate_matrix(all_called=hard_kernel)
     o = orc.Oracle(raw, ignore_miss_data=ign)
     want = o.run()
-    engine.set_geno_raw(raw, ignore_miss_data=ign, per_individual_only=not hard_kernel)
+    engine.set_geno_raw(raw, ignore_miss_data=ign)
     assert (engine.pair_kernel() == "hard") == hard_kernel
     engine.set_pos_dist(None)
     assert engine.plan(ignore_miss_data=ign) == len(want)
@@ -131,7 +135,9 @@ def test_device_records_are_patched(engine):
         std = d_std.cpu().numpy().view(capi.REC_STD)
         ext = d_ext.cpu().numpy().view(capi.REC_EXT)
         check_records(std, ext, want)
-        flagged = np.isin(want["s1"], [4, 11, 17, 23]) | np.isin(want["s2"], [4, 11, 17, 23])
+        # (records that stay on the device are replayed where the NUMBERS are ill-conditioned -- the monomorphic sites --
+        # not where only a printed digit or the sign of a rounded zero is at stake)
+        flagged = np.isin(want["s1"], [4, 17]) | np.isin(want["s2"], [4, 17])
         all_bits_equal(std[flagged], ext[flagged], want[flagged])
 
 
