@@ -1,28 +1,40 @@
 #!/usr/bin/env python
 """bench.py -- SNP-pair EM-LD computations per second on MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json configs[2], the n_ind = 500 configuration the metric is quoted on):
+Default workload = BASELINE.json configs[2], the n_ind = 500 configuration the metric is quoted on:
 synthetic binary GL, 100,000 sites x 500 individuals PER GPU, depth-10 generator, positions with gaps
-~ UniformInt[1,200] on one chromosome, --max_kb_dist 100 windowed, --extend_out records.  A "step" is one
-pass of the pair kernel over every pair of the rank's rows, inputs already resident in HBM, results
-left in HBM (ngsld_run_device).  N GPUs: the site axis is N x 100,000 long (weak scaling), rank 0
-generates the matrix and broadcasts it once over RCCL (outside the timed region), ranks take contiguous
-row ranges balanced by pair count and never communicate on the compute path.
+~ UniformInt[1,200] on one chromosome, --max_kb_dist 100 windowed, --extend_out records.  A "step" is one pass of the
+pair kernels over every pair of the rank's rows, inputs already resident in HBM, records left in HBM
+(ngsld_run_device + ngsld_finish_device: the exact-order replay of whatever the kernels flagged is inside the step).
+N GPUs: rank 0 generates the matrix and broadcasts it once over RCCL (outside the timed region), ranks take
+contiguous row ranges balanced by pair count and never communicate on the compute path.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with two extra objects:
-  roofline      HBM roofline of the pair kernel on ALGORITHMIC bytes: (48*n_ind + 72) B per pair
-                (both sites' GL vectors + the 32 B standard and 40 B extended record) / kernel time from
-                HIP events on the launch stream, against 8 TB/s.  Also carries the FP64-VALU view, which
-                is the bound that actually binds this kernel.
-  cpu_baseline  the CPU oracle (bit-checked restatement of the reference) on all host cores, on a
-                bounded sample of the same workload (first rows of the same matrix).
+--config picks another BASELINE configuration (same code path, same JSON line):
+  c1  configs[1]   5,000 x 100 all pairs                       weak (each GPU its own 5,000 sites)
+  c2  configs[2]   100,000 x 500, 100 kb window (default)      weak (N x 100,000 sites)
+  c3  configs[3]   50,000 x 1,000 all pairs, 1.25e9 pairs      STRONG: the fixed problem sharded over N GPUs
+  c4  configs[4]   1,000,000 x 2,000, 500 kb window, 1 kb gaps STRONG (48 GB matrix; --sites scales it down)
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  Beside the contract's fields:
+  value_host_resident  SURVEY §8(d)'s metric to the letter: pairs / wall time from the first kernel launch to the last
+                       record resident in HOST memory (ngsld_run: kernel || D2H into pinned buffers || sink), all ranks
+  e2e_file_to_tsv_s    N = 1, configs[2]: the drop-in binary, binary GL file in -> TSV text out (to /dev/null)
+  roofline             the pair kernel against the HBM roofline on ALGORITHMIC bytes ((48 n_ind + 72) B per pair, as
+                       if every pair streamed both sites from HBM), kernel time from HIP events on the launch stream;
+                       `traffic` is the HBM traffic measured with rocprofv3 PMC counters in a separate profiling run
+                       (profiles/), not in this run; `fp64_valu` is the roofline that actually binds the kernel
+  cpu_baseline         the host: `port` = the oracle restatement (whole per-pair path), `reference` = the reference's
+                       own compiled haplo_freq (oracle/_ref; the EM only, an upper bound on the reference's rate),
+                       each on the threads this process may really use and on one thread
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -34,59 +46,167 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X FP64 vector peak
 STD_BYTES, EXT_BYTES = 32, 40
 
+CONFIGS = {  # sites (per GPU when weak, total when strong), ind, max_kb, max_gap, scaling, steps, warmup
+    "c1": dict(sites=5_000, ind=100, max_kb=0, max_gap=200, scaling="weak", steps=5, warmup=2,
+               name="BASELINE configs[1]"),
+    "c2": dict(sites=100_000, ind=500, max_kb=100, max_gap=200, scaling="weak", steps=3, warmup=1,
+               name="BASELINE configs[2]"),
+    "c3": dict(sites=50_000, ind=1_000, max_kb=0, max_gap=200, scaling="strong", steps=1, warmup=0,
+               name="BASELINE configs[3]"),
+    "c4": dict(sites=1_000_000, ind=2_000, max_kb=500, max_gap=2000, scaling="strong", steps=1, warmup=0,
+               name="BASELINE configs[4]"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--sites", type=int, default=100_000, help="sites per GPU")
-    ap.add_argument("--ind", type=int, default=500)
-    ap.add_argument("--max-kb", type=int, default=100)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--sites", type=int, default=None, help="sites per GPU (weak) / in total (strong)")
+    ap.add_argument("--ind", type=int, default=None)
+    ap.add_argument("--max-kb", type=int, default=None)
     ap.add_argument("--depth", type=float, default=10.0)
-    ap.add_argument("--max-gap", type=int, default=200, help="site gaps ~ UniformInt[1, max-gap] (SURVEY 8d: 2000 for configs[4])")
+    ap.add_argument("--max-gap", type=int, default=None, help="site gaps ~ UniformInt[1, max-gap]")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--pairs-per-item", type=int, default=0)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of each cpu_baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-sink", action="store_true", help="skip the host-resident leg (value_host_resident)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file -> TSV leg of the drop-in binary")
     ap.add_argument("--ignore-miss", action="store_true", help="run the --ignore_miss_data kernels (not the headline config)")
     ap.add_argument("--rnd-sample", type=float, default=1.0, help="--rnd_sample of the plan (not the headline config)")
-    ap.add_argument("--sink", action="store_true", help="also time ngsld_run (records copied to pinned host memory)")
     ap.add_argument("--hard-calls", action="store_true",
                     help="hard-call the synthetic likelihoods (argmax -> 1/0/0 triples): the genotype-combination kernel (not the headline config)")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "hbm_traffic.json"))
-    return ap.parse_args()
+    a = ap.parse_args()
+    preset = CONFIGS[a.config]
+    a.custom = any(getattr(a, k) is not None for k in ("sites", "ind", "max_kb", "max_gap", "scaling"))
+    for k in ("steps", "warmup", "sites", "ind", "max_kb", "max_gap", "scaling"):
+        if getattr(a, k) is None:
+            setattr(a, k, preset[k])
+    return a
+
+
+def host_cpus() -> dict:
+    """The threads this process can really run on: the affinity mask, cut by the cgroup CPU quota when there is one
+    (os.cpu_count() reports the machine, not the lease)."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    usable = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return {"os_cpu_count": os.cpu_count(), "sched_affinity": aff, "cgroup_cpu_quota": quota, "threads_used": usable}
 
 
 def cpu_baseline(raw_head: np.ndarray, pos_dist_head: np.ndarray, max_kb: int, target_s: float, gpu_rows=None) -> dict:
-    """Oracle (kind 'port') on every host core, rows [0, R) of the bench matrix with R sized for ~target_s.
+    """Rows [0, R) of the bench matrix on the host, R sized for ~target_s per leg.
     gpu_rows(R) -> (#pairs, sum of finite r2, sum of executed EM iterations) of the GPU records of the same rows:
     a whole-sample parity check (the iteration totals must be EQUAL, i.e. no convergence-threshold flip)."""
     from oracle import orc
-    cores = os.cpu_count() or 1
+    cpus = host_cpus()
+    nt = cpus["threads_used"]
     n_have = raw_head.shape[0]
-    o = orc.Oracle(raw_head, pos_dist_head, max_kb_dist=max_kb, n_threads=cores)
+    o = orc.Oracle(raw_head, pos_dist_head, max_kb_dist=max_kb, n_threads=nt)
     ends = o.row_ends().astype(np.int64)
     halo = int((ends - np.arange(n_have)).max())
     usable = max(1, n_have - halo)                      # rows whose whole window lies inside the sample
-    cal_rows = min(usable, max(cores, 64))
-    t0 = time.perf_counter()
-    n_cal, _, _ = o.bench(0, cal_rows)
-    t_cal = max(time.perf_counter() - t0, 1e-6)
-    rows = int(min(usable, max(cal_rows, cal_rows * target_s / t_cal)))
-    t0 = time.perf_counter()
-    n, chk, iters = o.bench(0, rows)
-    dt = time.perf_counter() - t0
-    out = {"value": n / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+    if max_kb == 0:                                     # all pairs: the sample is the sub-matrix's own pair space
+        usable, gpu_rows = n_have - 1, None
+
+    def timed(fn, threads, seconds):
+        cal_rows = min(usable, max(threads, 16))
+        t0 = time.perf_counter()
+        fn(cal_rows, threads)
+        t_cal = max(time.perf_counter() - t0, 1e-6)
+        rows = int(min(usable, max(cal_rows, cal_rows * seconds / t_cal)))
+        t0 = time.perf_counter()
+        res = fn(rows, threads)
+        return rows, res, time.perf_counter() - t0
+
+    def port(rows, threads):
+        o.p.n_threads = threads
+        return o.bench(0, rows)                          # (#pairs, checksum, executed iterations)
+
+    rows, (n, chk, iters), dt = timed(port, nt, target_s)
+    out = {"value": n / dt, "unit": "pairs/s", "cores": nt, "kind": "port",
            "sample": f"rows 0..{rows} of the same matrix ({n} pairs, {dt:.1f} s, mean executed EM iterations "
-                     f"{iters / max(n, 1):.2f}); oracle/liborc.so, {cores} pthreads"}
+                     f"{iters / max(n, 1):.2f}); oracle/liborc.so (the whole per-pair path: pearson_r, haplo_freq, D/D'/r2), "
+                     f"{nt} pthreads",
+           "host": cpus}
+    rows1, (n1, _, _), dt1 = timed(port, 1, target_s / 3)
+    out["one_thread"] = {"value": n1 / dt1, "pairs": int(n1), "seconds": round(dt1, 2)}
+    out["threads_x_one_thread"] = nt * n1 / dt1          # what perfect scaling of the 1-thread rate would give
     if gpu_rows is not None:
         gn, gsum, giters = gpu_rows(rows)
         out["parity_on_sample"] = {"pairs": int(gn), "pairs_equal": bool(gn == n),
                                    "executed_iterations_cpu": int(iters), "executed_iterations_gpu": int(giters),
                                    "executed_iterations_equal": bool(giters == iters),
                                    "abs_diff_sum_r2": abs(gsum - chk), "sum_r2_cpu": chk}
+    if o.bench_reference(0, 1, 1) is not None:          # the reference's own compiled EM (oracle/_ref travelled here)
+        def ref(rows, threads):
+            return o.bench_reference(0, rows, threads)
+        rrows, (rn, rit, _), rdt = timed(ref, nt, target_s)
+        r1rows, (rn1, _, _), rdt1 = timed(ref, 1, target_s / 3)
+        out["reference"] = {"value": rn / rdt, "unit": "pairs/s", "cores": nt, "kind": "reference-subset",
+                            "sample": f"rows 0..{rrows} of the same matrix ({rn} pairs, {rdt:.1f} s, mean executed EM "
+                                      f"iterations {rit / max(rn, 1):.2f}): the reference's own haplo_freq "
+                                      f"(shared/gen_func.cpp:1027, compiled from /root/reference into oracle/_ref) on {nt} "
+                                      "pthreads, rows dealt round-robin as its thread pool deals calc_pair_LD jobs; pearson_r "
+                                      "(GSL) and the fprintf are not in it, so this bounds the reference's rate from above",
+                            "one_thread": {"value": rn1 / rdt1, "pairs": int(rn1), "seconds": round(rdt1, 2)},
+                            "executed_iterations_equal_port": bool(rrows != rows or rit == iters)}
+    else:
+        out["reference"] = None
     return out
+
+
+def e2e_file_to_tsv(raw_dev, n_sites: int, n_ind: int, chrs, pos, max_kb: int, threads: int) -> dict | None:
+    """The drop-in binary end to end: binary GL file + pos file in, extended TSV out (to /dev/null)."""
+    from ngsld_amd import capi, synth
+    if not os.path.exists(capi.CLI_PATH):
+        return None
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    need = n_sites * n_ind * 24
+    try:
+        st = os.statvfs(base or tempfile.gettempdir())
+        if st.f_bavail * st.f_frsize < need * 1.2:
+            return {"skipped": "not enough scratch space for the input file"}
+    except OSError:
+        pass
+    with tempfile.TemporaryDirectory(dir=base) as d:
+        g, p = os.path.join(d, "in.glf"), os.path.join(d, "in.pos")
+        with open(g, "wb") as fh:
+            step = max(1, (256 << 20) // (n_ind * 24))
+            for lo in range(0, n_sites, step):
+                fh.write(raw_dev[lo:lo + step].cpu().numpy().tobytes())
+        synth.write_pos(p, chrs, pos)
+        cmd = [capi.CLI_PATH, "--geno", g, "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--pos", p,
+               "--max_kb_dist", str(max_kb), "--extend_out", "--n_threads", str(threads), "--verbose", "0",
+               "--out", "/dev/null"]
+        best = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            dt = time.perf_counter() - t0
+            if r.returncode != 0:
+                return {"error": r.stderr[-300:]}
+            best = dt if best is None else min(best, dt)
+    return {"seconds": best, "n_threads": threads, "what": "ngsld_amd/bin/ngsLD: file read, H2D, per-site prep, plan, pair "
+            "kernels, device-side TSV, D2H of the text, write to /dev/null (best of 2)"}
 
 
 def main():
@@ -116,7 +236,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    n_sites = args.sites * world
+    strong = args.scaling == "strong"
+    n_sites = args.sites if strong else args.sites * world
     n_ind = args.ind
 
     # ---- positions (host, identical on every rank) and the row shards ----
@@ -150,6 +271,11 @@ def main():
     eng.set_geno_raw(slab.data_ptr(), n_sites=slab_hi - slab_lo, n_ind=n_ind,
                      ignore_miss_data=args.ignore_miss)                          # per-site prep kernel (one-off)
     t_prep = time.perf_counter() - t_prep
+    # the exact-order replay reads flagged pairs' sites from host memory (as the drop-in binary does); a slab too large to
+    # mirror on the host is read back from the device's planes instead
+    if slab.numel() * 8 <= (8 << 30):
+        slab_host = slab.cpu().numpy()
+        eng.set_replay_source(slab_host)
     local_pd = pos_dist[slab_lo:slab_hi].copy()
     eng.set_pos_dist(local_pd)
     if args.pairs_per_item:
@@ -163,20 +289,28 @@ def main():
     n_pairs = int(row_off[n_rows] - row_off[0])
     assert args.rnd_sample < 1.0 or n_pairs == int(counts[lo:hi].sum()), "engine plan and host mirror disagree on the pair count"
 
+    headline = world == 1 and not args.ignore_miss and args.rnd_sample >= 1.0 and not args.hard_calls
     raw_head = None
     family = eng.pair_kernel()
-    if rank == 0 and world == 1 and not args.no_cpu and not args.ignore_miss and args.rnd_sample >= 1.0:
-        head = min(n_sites, 12_000)
+    if rank == 0 and headline and not args.no_cpu:
+        head = min(n_sites, 12_000 if n_ind <= 500 else 6_000)
         raw_head = raw[:head].cpu().numpy()
+    e2e = None
+    if rank == 0 and headline and not args.no_e2e and args.config == "c2" and not args.custom:
+        torch.cuda.synchronize()
+        e2e = e2e_file_to_tsv(raw, n_sites, n_ind, chrs, pos, args.max_kb, host_cpus()["threads_used"])
     del slab, raw
     torch.cuda.empty_cache()
 
     d_std = torch.empty(max(n_pairs, 1) * STD_BYTES, dtype=torch.uint8, device=dev)
     d_ext = torch.empty(max(n_pairs, 1) * EXT_BYTES, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
+    replayed = [0]
 
     def step():
         eng.run_device(0, n_rows, d_std.data_ptr(), d_ext.data_ptr(), stream)
+        eng.finish_device()              # waits for the kernels; exact-order replay of the pairs they flagged
+        replayed[0] = eng.replay_stats()[0]
 
     def barrier():
         if world > 1:
@@ -191,7 +325,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        ms, nl, _ = eng.last_kernel_time()   # HIP events on the launch stream (waits for that step's kernels)
+        ms, nl, _ = eng.last_kernel_time()   # HIP events on the launch stream
         kernel_ms += ms
         launches += nl
     torch.cuda.synchronize()
@@ -199,24 +333,32 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    sink_rate = None
-    if args.sink:                       # PCIe-inclusive hand-off; reported beside, never as `value`
-        eng.run_discard(0, n_rows)
+    # ---- SURVEY §8(d)'s metric to the letter: last record resident in HOST memory (kernel || D2H || sink) ----
+    sink_elapsed = 0.0
+    if not args.no_sink:
+        eng.run_discard(0, n_rows)                               # warm-up pass: pinned buffers, host copy of the plan
+        torch.cuda.synchronize()
+        barrier()
         t1 = time.perf_counter()
         got = eng.run_discard(0, n_rows)
-        sink_rate = got / (time.perf_counter() - t1)
+        torch.cuda.synchronize()
+        barrier()
+        sink_elapsed = time.perf_counter() - t1
         assert got == n_pairs
 
     # ---- aggregate over ranks: MAX time, SUM pairs ----
-    stats = torch.tensor([elapsed, kernel_ms / max(launches, 1), float(n_pairs)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([elapsed, kernel_ms / max(launches, 1), float(n_pairs), sink_elapsed, -elapsed, -float(n_pairs)],
+                         dtype=torch.float64, device=dev)
     if world > 1:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone()
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed_max, total_pairs = float(mx[0]), int(sm[2])
+        elapsed_max, total_pairs, sink_max = float(mx[0]), int(sm[2]), float(mx[3])
+        elapsed_min, pairs_min, pairs_max = -float(mx[4]), int(-float(mx[5])), int(mx[2])
     else:
-        elapsed_max, total_pairs = elapsed, n_pairs
+        elapsed_max, total_pairs, sink_max = elapsed, n_pairs, sink_elapsed
+        elapsed_min, pairs_min, pairs_max = elapsed, n_pairs, n_pairs
 
     # mean executed EM iterations (n_iter is the 0-based index of the converging iteration; 100 = cap)
     ext_i32 = d_ext.view(torch.int32).view(-1, EXT_BYTES // 4)
@@ -232,31 +374,45 @@ def main():
         # FP64 view: per individual and executed iteration 9 FMA (s) + 8 FMA (R) + 3 of the shared-reciprocal tree
         dp_ops = pairs_per_launch * n_ind * mean_exec * 20.0
         fp64_tflops = 2.0 * dp_ops / launch_s / 1e12
-        traffic = None
+        traffic, traffic_src = None, None
         try:
             with open(args.traffic_json) as fh:
                 tj = json.load(fh)
             if tj.get("workload") == f"{args.sites}x{n_ind}@{args.max_kb}kb":
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_src = ("from_profile: rocprofv3 PMC passes of an earlier run of this workload (" +
+                               os.path.relpath(args.traffic_json, REPO) + "), not measured in this run")
         except (OSError, ValueError):
             pass
+        preset = CONFIGS[args.config]
+        is_preset = not args.custom and not args.hard_calls
         out = {
-            "metric": "SNP-pair EM-LD computations/sec @ n_ind=500", "value": value, "unit": "pairs/s",
+            "metric": f"SNP-pair EM-LD computations/sec @ n_ind={n_ind}", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic binary GL, {args.sites} sites/GPU x {n_ind} ind, depth {args.depth:g}, "
+            "config": {"workload": f"synthetic binary GL, {args.sites} sites{'' if strong else '/GPU'} x {n_ind} ind, depth {args.depth:g}, "
                                    f"--max_kb_dist {args.max_kb} {'windowed' if args.max_kb else 'all pairs'}, --extend_out"
                                    + (", hard-called" if args.hard_calls else "")
-                                   + (" (BASELINE configs[2])" if (args.sites, n_ind, args.max_kb, args.max_gap, args.hard_calls) == (100_000, 500, 100, 200, False) else ""),
+                                   + (f" ({preset['name']})" if is_preset else ""),
                        "n_sites_total": n_sites, "pairs_per_step": total_pairs,
                        "mean_executed_em_iterations": round(mean_exec, 3),
                        "parallelism": f"rows sharded by pair count over {world} GPU(s), no data-path collective",
+                       "pairs_per_rank_min_max": [pairs_min, pairs_max],
+                       "rank_seconds_min_max": [elapsed_min, elapsed_max],
+                       "pairs_replayed_exact_order_rank0_last_step": replayed[0],
                        "gl_generate_s": round(t_gen, 3), "gl_broadcast_s": round(t_bc, 3),
-                       "one_off_prep_ms_rank0": round(t_prep * 1e3, 2), "one_off_plan_ms_rank0": round(t_plan * 1e3, 2),
-                       "host_handoff_pairs_per_s_rank0": sink_rate},
+                       "one_off_prep_ms_rank0": round(t_prep * 1e3, 2), "one_off_plan_ms_rank0": round(t_plan * 1e3, 2)},
+            "value_host_resident": (total_pairs / sink_max) if sink_max > 0 else None,
+            "host_resident_note": "SURVEY 8(d): pairs / wall time from the first kernel launch to the last record resident "
+                                  "in host memory (ngsld_run: 72 B per pair over PCIe into pinned buffers, double-buffered "
+                                  "against the kernels); one pass, all ranks, MAX over ranks",
+            "e2e_file_to_tsv_s": e2e,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac_is": "algorithmic bytes per pair x pairs per launch / kernel time, over the HBM peak -- NOT the "
+                                    "HBM utilisation: the row vector is shared through LDS and the window is re-read from L2 / "
+                                    "Infinity Cache (`traffic`); the binding roofline is fp64_valu",
                          "kernel": {"group": "pair_ld_group_kernel", "run": "pair_ld_run_kernel", "wave": "pair_ld_pf_kernel",
                                     "multi": "pair_ld_kernel (multi-wavefront)", "stream": "pair_ld_stream_kernel",
                                     "direct": "pair_ld_kernel (no prefetch)",

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -142,7 +143,8 @@ struct ngsld_ctx {
   ngsld_geno_opts gopts{};
   bool normalised = false;                    // data came through ngsld_set_geno_lkl
   DevBuf<uint32_t> d_flags[2], d_flags_dev;   // [count, pad, one bit per record ...] per pipeline slot / for ngsld_run_device
-  PinBuf<uint32_t> h_flag_count[2];
+  PinBuf<uint32_t> h_flags[2], h_flags_dev;   // host copies: they travel with the batch's records / text meta
+  PinBuf<double> h_site_stage;                // plane read-back of one site (no source registered)
   DevBuf<uint64_t> d_patch_idx;
   DevBuf<ngsld_rec_std> d_patch_std;
   DevBuf<ngsld_rec_ext> d_patch_ext;
@@ -501,30 +503,33 @@ int fetch_replay_site(ngsld_ctx *c, uint64_t s, std::vector<double> &tmp, Replay
       replay_site_from_raw(tmp.data(), n, c->gopts, out);
     return NGSLD_OK;
   }
-  tmp.resize(3ull * c->np + 3 * n);
-  double *planes = tmp.data(), *lkl = tmp.data() + 3ull * c->np;
+  // (pinned staging: a pageable copy would be staged by the runtime; while a pair kernel of the next batch has the device
+  // this read-back can still wait for it -- callers that care register a source)
+  tmp.resize(3 * n);
+  double *lkl = tmp.data();
   {
     std::lock_guard<std::mutex> g(c->replay_mu);
-    if (hipSetDevice(c->device) != hipSuccess ||
-        hipMemcpyAsync(planes, c->d_planes.p + s * 3ull * c->np, 3ull * c->np * sizeof(double), hipMemcpyDeviceToHost,
-                       c->replay_stream) != hipSuccess ||
+    if (hipSetDevice(c->device) != hipSuccess || c->h_site_stage.resize(3ull * c->np) != hipSuccess ||
+        hipMemcpyAsync(c->h_site_stage.p, c->d_planes.p + s * 3ull * c->np, 3ull * c->np * sizeof(double),
+                       hipMemcpyDeviceToHost, c->replay_stream) != hipSuccess ||
         hipStreamSynchronize(c->replay_stream) != hipSuccess)
       return NGSLD_ERR_DEVICE;
+    const double *planes = c->h_site_stage.p;
+    for (uint64_t i = 0; i < n; ++i)
+      for (int g = 0; g < 3; ++g) lkl[3 * i + g] = planes[(uint64_t)g * c->np + i];
   }
-  for (uint64_t i = 0; i < n; ++i)
-    for (int g = 0; g < 3; ++g) lkl[3 * i + g] = planes[(uint64_t)g * c->np + i];
   replay_site_from_lkl(lkl, c->h_maf[s], n, out);
   return NGSLD_OK;
 }
 
 // Records [0, n) of a launch whose record 0 is the plan's record `base`: every flagged one is replayed; the new records go
 // to h_std / h_ext (host buffers of the batch) or, when those are null, to d_std / d_ext on stream st (synchronised).
-int replay_flagged(ngsld_ctx *c, const uint32_t *d_flags, uint64_t base, uint64_t n, ngsld_rec_std *h_std,
+// h_flags: the launch's flag buffer ([count, pad, bits ...]) in host memory.  (It travels with the batch: a copy issued
+// at this point, while the next batch's pair kernel has the device, can wait for that kernel -- measured 43 ms.)
+int replay_flagged(ngsld_ctx *c, const uint32_t *h_flags, uint64_t base, uint64_t n, ngsld_rec_std *h_std,
                    ngsld_rec_ext *h_ext, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext, hipStream_t st) {
   const uint64_t words = (n + 31) / 32;
-  std::vector<uint32_t> bits(words);
-  HIP_TRY(c, hipMemcpyAsync(bits.data(), d_flags + 2, words * sizeof(uint32_t), hipMemcpyDeviceToHost, c->replay_stream));
-  HIP_TRY(c, hipStreamSynchronize(c->replay_stream));
+  const uint32_t *bits = h_flags + 2;
   std::vector<uint64_t> recs;
   for (uint64_t w = 0; w < words; ++w)
     for (uint32_t m = bits[w]; m; m &= m - 1) {
@@ -632,12 +637,16 @@ int finish_device_run(ngsld_ctx *c) {
   c->dev_run.pending = false;
   HIP_TRY(c, hipStreamSynchronize(c->dev_run.st));
   if (!c->replay_on || c->d_flags_dev.p == nullptr) return NGSLD_OK;
-  uint32_t count = 0;
-  HIP_TRY(c, hipMemcpyAsync(&count, c->d_flags_dev.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->replay_stream));
-  HIP_TRY(c, hipStreamSynchronize(c->replay_stream));
-  if (count == 0) return NGSLD_OK;
   const uint64_t base = c->h_row_off[c->dev_run.s1_begin], n = c->h_row_off[c->dev_run.s1_end] - base;
-  return replay_flagged(c, c->d_flags_dev.p, base, n, nullptr, nullptr, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st);
+  HIP_TRY(c, c->h_flags_dev.resize(2));
+  HIP_TRY(c, hipMemcpyAsync(c->h_flags_dev.p, c->d_flags_dev.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->dev_run.st));
+  HIP_TRY(c, hipStreamSynchronize(c->dev_run.st));
+  if (c->h_flags_dev.p[0] == 0) return NGSLD_OK;
+  const size_t words = 2 + (size_t)((n + 31) / 32);
+  HIP_TRY(c, c->h_flags_dev.resize(words));
+  HIP_TRY(c, hipMemcpyAsync(c->h_flags_dev.p, c->d_flags_dev.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, c->dev_run.st));
+  HIP_TRY(c, hipStreamSynchronize(c->dev_run.st));
+  return replay_flagged(c, c->h_flags_dev.p, base, n, nullptr, nullptr, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st);
 }
 
 }  // namespace
@@ -1078,7 +1087,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     }
     if (replay) {
       HIP_TRY(c, c->d_flags[k].resize(2 + (size_t)((cap + 31) / 32)));
-      HIP_TRY(c, c->h_flag_count[k].resize(2));
+      HIP_TRY(c, c->h_flags[k].resize(2 + (size_t)((cap + 31) / 32)));
     }
   }
   size_t scan_bytes = 0;
@@ -1116,8 +1125,9 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     }
     PairArgs a = make_args(c, b.r0, b.r1, c->d_std[k].p, ext ? c->d_ext[k].p : nullptr, replay ? c->d_flags[k].p : nullptr);
     HIP_TRY(c, timed_launch(c, a, c->stream));
-    if (replay)  // how many pairs the kernel flagged for the exact-order replay: known to the host with the batch
-      HIP_TRY(c, hipMemcpyAsync(c->h_flag_count[k].p, c->d_flags[k].p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    const size_t flag_bytes = (2 + (size_t)((b.n + 31) / 32)) * sizeof(uint32_t);
+    if (replay && text)  // which pairs the kernel flagged for the exact-order replay: known to the host with the batch
+      HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, flag_bytes, hipMemcpyDeviceToHost, c->stream));
     if (text) {  // row lengths and their prefix sums right behind the pair kernel; the rows are written at consume time
       HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), c->stream));
       const TextArgs t = text_args(b, k);
@@ -1137,18 +1147,25 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
         HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, c->d_ext[k].p, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost,
                                   c->copy_stream));
     }
+    if (replay)  // the flags travel with the records
+      HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, flag_bytes, hipMemcpyDeviceToHost, c->copy_stream));
     HIP_TRY(c, hipEventRecord(c->ev_copy_done[k], c->copy_stream));
     return NGSLD_OK;
   };
   int rc = NGSLD_OK;
+  const bool trace = std::getenv("NGSLD_TRACE") != nullptr;  // dev: per-batch host timeline on stderr
+  const auto t_run = std::chrono::steady_clock::now();
+  auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run).count(); };
   if (!batches.empty()) rc = issue(0);
   for (size_t bi = 0; rc == NGSLD_OK && bi < batches.size(); ++bi) {
     const int k = (int)(bi & 1);
+    const double t_a = now_ms();
     if (bi + 1 < batches.size()) {
       // slot of batch bi+1 was last used by batch bi-1, whose sink call has already returned
       rc = issue(bi + 1);
       if (rc != NGSLD_OK) break;
     }
+    const double t_b = now_ms();
     const Batch &b = batches[bi];
     const uint64_t i0 = c->h_item_off[b.r0], i1 = c->h_item_off[b.r1];
     ngsld_batch out{};
@@ -1160,10 +1177,10 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       // the batch's text: its length is known now; the rows are written and copied on the copy stream while the pair
       // kernel of the next batch (already enqueued) runs on the compute stream
       HIP_TRY(c, hipEventSynchronize(c->ev_kernel_done[k]));
-      if (replay && c->h_flag_count[k].p[0] != 0) {
+      if (replay && c->h_flags[k].p[0] != 0) {
         // flagged pairs: replayed on the host, patched into the device records, and the row lengths derived again --
         // all on the copy stream, beside the next batch's pair kernel
-        const int rcr = replay_flagged(c, c->d_flags[k].p, c->h_row_off[b.r0], b.n, nullptr, nullptr, c->d_std[k].p,
+        const int rcr = replay_flagged(c, c->h_flags[k].p, c->h_row_off[b.r0], b.n, nullptr, nullptr, c->d_std[k].p,
                                        ext ? c->d_ext[k].p : nullptr, c->copy_stream);
         if (rcr != NGSLD_OK) return rcr;
         HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), c->copy_stream));
@@ -1208,8 +1225,9 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       }
     } else {
       HIP_TRY(c, hipEventSynchronize(c->ev_copy_done[k]));
-      if (replay && c->h_flag_count[k].p[0] != 0) {  // flagged pairs: replayed on the host, patched into the batch's buffers
-        const int rcr = replay_flagged(c, c->d_flags[k].p, c->h_row_off[b.r0], b.n, c->h_std[k].p, ext ? c->h_ext[k].p : nullptr,
+      if (trace) std::fprintf(stderr, "[trace] batch %zu: issue next %.2f..%.2f, copy done %.2f, flagged %u\n", bi, t_a, t_b, now_ms(), replay ? c->h_flags[k].p[0] : 0u);
+      if (replay && c->h_flags[k].p[0] != 0) {  // flagged pairs: replayed on the host, patched into the batch's buffers
+        const int rcr = replay_flagged(c, c->h_flags[k].p, c->h_row_off[b.r0], b.n, c->h_std[k].p, ext ? c->h_ext[k].p : nullptr,
                                        nullptr, nullptr, nullptr);
         if (rcr != NGSLD_OK) return rcr;
       }
@@ -1222,6 +1240,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       out.std = c->h_std[k].p;
       out.ext = ext ? c->h_ext[k].p : nullptr;
     }
+    if (trace) std::fprintf(stderr, "[trace] batch %zu: replay done %.2f\n", bi, now_ms());
     if (sink(user, &out) != 0) rc = fail(c, NGSLD_ERR_SINK, "sink callback failed");
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));

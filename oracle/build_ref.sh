@@ -49,6 +49,6 @@ drop_gsl_cpp() {   # source: no self-include, no draw_rnd definition (signature 
   drop_gsl_cpp "$REF/shared/read_data.cpp"
   echo '#line 1 "oracle/ref_shim.cpp"'
   cat "$HERE/ref_shim.cpp"
-} | g++ -x c++ -O3 -w -fPIC -shared -ffp-contract=off -o "$HERE/_ref/libngsld_ref.so" - -lz
+} | g++ -x c++ -O3 -w -fPIC -shared -ffp-contract=off -o "$HERE/_ref/libngsld_ref.so" - -lz -lpthread
 
 echo "built $HERE/_ref/libngsld_ref.so"

@@ -136,6 +136,11 @@ def ref():
         R.ref_read_dist.argtypes = [C.c_char_p, C.c_int, C.c_uint64, c_double_p]
         R.ref_read_labels.restype = C.c_uint64
         R.ref_read_labels.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_uint64, C.c_uint64]
+        if hasattr(R, "ref_bench_haplo_freq"):
+            R.ref_bench_haplo_freq.restype = C.c_uint64
+            R.ref_bench_haplo_freq.argtypes = [c_double_p, c_double_p, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64,
+                                               C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_uint64),
+                                               c_double_p]
         _ref = R
     return _ref
 
@@ -204,5 +209,20 @@ class Oracle:
         n = lib().orc_bench(C.byref(self.p), s1_begin, s1_end, C.byref(chk), C.byref(it))
         return n, chk.value, it.value
 
+    def bench_reference(self, s1_begin: int, s1_end: int, n_threads: int) -> tuple[int, int, float] | None:
+        """The REFERENCE's own compiled haplo_freq (oracle/_ref) over the pairs of rows [s1_begin, s1_end) of this
+        matrix: (#pairs, executed EM iterations, sum of hap[0]).  None when oracle/_ref is not there."""
+        R = ref()
+        if R is None or not hasattr(R, "ref_bench_haplo_freq"):
+            return None
+        ends = np.ascontiguousarray(self.row_ends(), dtype=np.uint64)
+        it, chk = C.c_uint64(0), C.c_double(0.0)
+        n = R.ref_bench_haplo_freq(dp(self.gl), dp(self.maf), ends.ctypes.data_as(C.POINTER(C.c_uint64)), self.n_ind,
+                                   self.n_sites, s1_begin, s1_end, int(self.p.ignore_miss_data), n_threads, C.byref(it),
+                                   C.byref(chk))
+        return int(n), int(it.value), float(chk.value)
+
     def row_ends(self) -> np.ndarray:
-        return np.array([lib().orc_row_end(C.byref(self.p), s) for s in range(self.n_sites)], dtype=np.uint64)
+        if getattr(self, "_row_ends", None) is None:
+            self._row_ends = np.array([lib().orc_row_end(C.byref(self.p), s) for s in range(self.n_sites)], dtype=np.uint64)
+        return self._row_ends

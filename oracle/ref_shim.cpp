@@ -9,8 +9,9 @@
  * in main() and cannot be compiled without GSL.
  *
  * NB: the reference headers define abs/min/max as MACROS (gen_func.hpp:21-23); do not use those
- * names here and do not include further standard headers.
+ * names here and do not include further C++ standard headers (pthread.h is plain C and untouched by them).
  */
+#include <pthread.h>
 
 static double **ref_rows(const double *flat, uint64_t n) {
   double **p = new double *[n];
@@ -111,6 +112,66 @@ uint64_t ref_read_labels(const char *path, int header, char *out, uint64_t strid
     out[s * stride + stride - 1] = '\0';
   }
   return n;
+}
+
+/* Timing door (bench.py cpu_baseline, kind "reference-subset"): the reference's OWN compiled haplo_freq
+ * (gen_func.cpp:1027, the EM that dominates calc_pair_LD) over every pair (s1, s2) with s1 in [s1_begin, s1_end),
+ * s2 in (s1, row_end[s1]), rows dealt round-robin to n_threads pthreads -- the granularity of the reference's own
+ * thread pool (one calc_pair_LD job per s1, ngsLD.cpp:159-186).  gl: normal-space [site][ind][3] as calc_pair_LD sees
+ * it; the jagged row pointers haplo_freq wants are built once per site.  pearson_r (GSL) and the fprintf are not
+ * part of it: this is a SUBSET of the reference's per-pair work, hence an upper bound on its pairs/s. */
+struct ref_bench_job {
+  double ***rows;
+  const double *maf;
+  const uint64_t *row_end;
+  uint64_t n_ind, s1_begin, s1_end, pairs, iters;
+  int tid, n_threads, ignore_miss;
+  double sum;
+};
+
+static void *ref_bench_worker(void *arg) {
+  ref_bench_job *j = (ref_bench_job *)arg;
+  for (uint64_t s1 = j->s1_begin + (uint64_t)j->tid; s1 < j->s1_end; s1 += (uint64_t)j->n_threads)
+    for (uint64_t s2 = s1 + 1; s2 < j->row_end[s1]; s2++) {
+      double hap[4], loglkl = 0;
+      uint64_t n = 0;
+      uint64_t it = haplo_freq(hap, &loglkl, &n, j->rows[s1], j->rows[s2], j->maf[s1], j->maf[s2], j->n_ind,
+                               j->ignore_miss != 0, false);
+      j->sum += hap[0];
+      j->iters += it < ITER_MAX ? it + 1 : ITER_MAX;
+      j->pairs++;
+    }
+  return NULL;
+}
+
+uint64_t ref_bench_haplo_freq(const double *gl, const double *maf, const uint64_t *row_end, uint64_t n_ind,
+                              uint64_t n_sites, uint64_t s1_begin, uint64_t s1_end, int ignore_miss, int n_threads,
+                              uint64_t *iters, double *checksum) {
+  if (n_threads < 1) n_threads = 1;
+  double ***rows = new double **[n_sites];
+  for (uint64_t s = 0; s < n_sites; s++) rows[s] = ref_rows(gl + s * n_ind * 3, n_ind);
+  pthread_t *th = new pthread_t[n_threads];
+  ref_bench_job *jobs = new ref_bench_job[n_threads];
+  for (int t = 0; t < n_threads; t++) {
+    ref_bench_job q = {rows, maf, row_end, n_ind, s1_begin, s1_end, 0, 0, t, n_threads, ignore_miss, 0.0};
+    jobs[t] = q;
+    pthread_create(&th[t], NULL, ref_bench_worker, &jobs[t]);
+  }
+  uint64_t pairs = 0, it = 0;
+  double sum = 0;
+  for (int t = 0; t < n_threads; t++) {
+    pthread_join(th[t], NULL);
+    pairs += jobs[t].pairs;
+    it += jobs[t].iters;
+    sum += jobs[t].sum;
+  }
+  if (iters) *iters = it;
+  if (checksum) *checksum = sum;
+  for (uint64_t s = 0; s < n_sites; s++) delete[] rows[s];
+  delete[] rows;
+  delete[] th;
+  delete[] jobs;
+  return pairs;
 }
 
 } /* extern "C" */
