@@ -113,7 +113,7 @@ struct ngsld_ctx {
 
   // tuning
   // kernel family selection for A/B runs: NGSLD_PAIR_KERNEL=direct (no prefetch anywhere) | wave (no row kernel)
-  bool prefetch = true, row_kernel = true, run_kernel = true;
+  bool prefetch = true, row_kernel = true, run_kernel = true, ab_kernel = false;
   uint32_t pairs_per_item = 16;
   uint64_t batch_pairs = 1ull << 23;
 
@@ -208,7 +208,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   if (normalised && maf == nullptr) return fail(c, NGSLD_ERR_INVALID, "maf missing");
   if (n_sites >= 0xffffffffull) return fail(c, NGSLD_ERR_UNSUPPORTED, "n_sites must be below 2^32 - 1");
   PairConfig cfg;
-  if (!pair_config(n_ind, c->prefetch, c->row_kernel, &cfg, c->run_kernel))
+  if (!pair_config(n_ind, c->prefetch, c->row_kernel, &cfg, c->run_kernel, c->ab_kernel))
     return fail(c, NGSLD_ERR_UNSUPPORTED, "n_ind is outside the supported range");
   HIP_TRY(c, hipSetDevice(c->device));
   c->have_geno = false;
@@ -422,7 +422,7 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
   a.rsx = c->d_rsx.p;
   a.items = c->d_items.p + c->h_item_off[r0];
   a.n_items = c->h_item_off[r1] - c->h_item_off[r0];
-  if (c->cfg.kernel == kRun || c->cfg.kernel == kGroup || c->cfg.kernel == kHard) {
+  if (uses_runs(c->cfg.kernel)) {
     a.runs = c->d_runs.p + c->h_run_off[r0];
     a.n_runs = c->h_run_off[r1] - c->h_run_off[r0];
   }
@@ -686,6 +686,8 @@ int ngsld_create(int device, ngsld_ctx **out) {
     c->prefetch = std::strcmp(k, "direct") != 0;
     c->row_kernel = std::strcmp(k, "wave") != 0;
     c->run_kernel = std::strcmp(k, "item") != 0;  // "item": one workgroup per item (pair_ld_pf_kernel), the run kernel's baseline
+    c->ab_kernel = std::strcmp(k, "ab") == 0;  // "ab": 513..1024 individuals on ONE wavefront per pair, EM step in its a/b form
+                                               // (ld_pair_ab.hip: built, measured against the two-wavefront kernel, not the default)
   }
   if (const char *k = std::getenv("NGSLD_BATCH_PAIRS")) {  // tests: many small batches through ngsld_run
     const uint64_t v = std::strtoull(k, nullptr, 10);
@@ -835,7 +837,7 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
     c->h_item_off[s1 + 1] = c->h_item_off[s1] + (span + ch - 1) / ch;
   }
   c->n_items = c->h_item_off[n];
-  if (c->cfg.kernel == kRun || c->cfg.kernel == kGroup || c->cfg.kernel == kHard) {
+  if (uses_runs(c->cfg.kernel)) {
     // runs: a row's items cut into ceil(items / kRunItems) runs of near-equal length (one workgroup each)
     std::vector<Run> runs;
     c->h_run_off.assign(n + 1, 0);
@@ -1275,6 +1277,7 @@ const char *ngsld_pair_kernel(const ngsld_ctx *c) {
     case kStream: return "stream";
     case kRun: return "run";
     case kHard: return "hard";
+    case kRunAB: return "ab";
     default: return "";
   }
 }

@@ -1623,7 +1623,10 @@ __global__ __launch_bounds__(256, 2) void pair_ld_stream_kernel(PairArgs A) {
 // (the default for n_ind 257..512; kWave remains as its per-item A/B baseline).
 // kHard = every likelihood triple of the matrix is a called genotype or "no data": the pairs' 16 genotype-combination
 // counts replace the individuals (any n_ind up to kHardMaxInd).
-enum PairKernel { kGroup = 0, kWave = 1, kMulti = 2, kDirect = 3, kStream = 4, kRun = 5, kHard = 6 };
+// kRunAB = one wavefront per pair for 513..1024 individuals, EM step in its a/b form, run pipeline (ld_pair_ab.hip).
+enum PairKernel { kGroup = 0, kWave = 1, kMulti = 2, kDirect = 3, kStream = 4, kRun = 5, kHard = 6, kRunAB = 7 };
+// kernels launched over runs of items (one workgroup per run, candidates addressed as 64 * item + offset)
+inline bool uses_runs(int kernel) { return kernel == kRun || kernel == kGroup || kernel == kHard || kernel == kRunAB; }
 constexpr uint32_t kHardMaxWords = 512;                 // row bit sets in LDS: 4 x 512 x 8 B = 16 KB
 constexpr uint64_t kHardMaxInd = 64ull * kHardMaxWords;
 struct PairConfig {
@@ -1633,16 +1636,18 @@ struct PairConfig {
   int waves;    // wavefronts per pair
   uint32_t np;  // padded individuals per genotype plane
 };
-bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg, bool allow_run = true);
+bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg, bool allow_run = true,
+                 bool allow_ab = true);
 hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs &args, hipStream_t stream);
 hipError_t launch_pair_hard(bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_hard.hip
+hipError_t launch_pair_ab(int slots, bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_ab.hip
 // Per-site classification behind kHard (ld_pair_hard.hip): masks / u as in PairArgs; *all_hard (device int, preset to 1) is
 // cleared when any triple is neither a called genotype (1,0,0) / (0,1,0) / (0,0,1) nor three equal values
 hipError_t launch_classify_hard(const double *planes, uint64_t site_stride, uint32_t np, uint32_t n_ind, uint64_t n_sites,
                                 uint64_t *masks, double *u, int *all_hard, hipStream_t stream);
 // candidate s2 sites per work item: kGroup / kWave items are shared by the four wavefronts of a workgroup
 inline uint32_t item_span(const PairConfig &cfg, uint32_t pairs_per_item) {
-  if (cfg.kernel == kRun || cfg.kernel == kGroup || cfg.kernel == kHard) return 64u;  // run form: candidates are addressed as 64 * item + offset
+  if (uses_runs(cfg.kernel)) return 64u;  // run form: candidates are addressed as 64 * item + offset
   const uint32_t span = (cfg.kernel == kGroup || cfg.kernel == kWave) ? 4u * pairs_per_item : pairs_per_item;
   return span > 64u ? 64u : span;
 }

@@ -8,7 +8,7 @@ namespace ngsld {
 // n_ind -> kernel family and shape.  Lane groups of 8 / 16 / 32 lanes x 8 slots cover 64 / 128 / 256 individuals
 // (group kernel); one wavefront holds up to 8*64 = 512 individuals as 18*8 = 144 VGPRs of P; above that 2..8
 // wavefronts share the pair, and beyond 4096 the streaming kernel takes over.
-bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg, bool allow_run) {
+bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg, bool allow_run, bool allow_ab) {
   if (n_ind == 0 || n_ind >= 0xffffffc0ull) return false;
   cfg->group = 64;
   if (n_ind > 4096) {  // beyond 8 wavefronts x 8 slots x 64 lanes: streaming kernel, one workgroup per pair
@@ -27,6 +27,14 @@ bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig
     cfg->group = n_ind <= 64 ? 8 : (n_ind <= 128 ? 16 : 32);
     cfg->slots = (int)((n_ind + (uint64_t)cfg->group - 1) / (uint64_t)cfg->group);
     cfg->np = (uint32_t)(cfg->slots * cfg->group);
+    return true;
+  }
+  if (allow_prefetch && allow_row && allow_run && allow_ab && n_ind > 512 && n_ind <= 1024) {
+    // one wavefront per pair, 9..16 individuals per lane, EM step in its a/b form (ld_pair_ab.hip)
+    cfg->kernel = kRunAB;
+    cfg->waves = 1;
+    cfg->slots = (int)((n_ind + 63) / 64);
+    cfg->np = (uint32_t)(cfg->slots * 64);
     return true;
   }
   int w = 1;
@@ -105,7 +113,7 @@ hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs
     const uint64_t u = std::strtoull(e, nullptr, 10);
     if (u >= 1 && u < max_blocks) max_blocks = u;
   }
-  const bool by_runs = cfg.kernel == kRun || cfg.kernel == kGroup || cfg.kernel == kHard;
+  const bool by_runs = uses_runs(cfg.kernel);
   const uint64_t total = by_runs ? a.n_runs : a.n_items;
   const uint64_t per = max_blocks * ((cfg.kernel == kDirect && cfg.waves == 1) ? 4u : 1u);  // kDirect: 4 items per block
   for (uint64_t off = 0; off < total; off += per) {
@@ -135,6 +143,7 @@ static hipError_t launch_pair_chunk(const PairConfig &cfg, bool masked, const Pa
     return hipGetLastError();
   }
   if (cfg.kernel == kHard) return launch_pair_hard(masked, a, stream);
+  if (cfg.kernel == kRunAB) return launch_pair_ab(cfg.slots, masked, a, stream);
   if (cfg.kernel == kGroup) {
     if (cfg.group == 8) return launch_group<8>(cfg.slots, masked, a, stream);
     if (cfg.group == 16) return launch_group<16>(cfg.slots, masked, a, stream);

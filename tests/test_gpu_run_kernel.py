@@ -84,3 +84,30 @@ def test_windowed_rows_split_into_equal_runs(engine):
             eng.close()
     for a, b in zip(*out):
         assert a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("n_ind,ignore_miss", [(513, False), (640, True), (777, False), (1000, False), (1024, True)])
+def test_ab_form_kernel_matches_the_oracle(n_ind, ignore_miss):
+    """NGSLD_PAIR_KERNEL=ab: one wavefront per pair for 513..1024 individuals, EM step in its a/b form (ld_pair_ab.hip;
+    measured against the two-wavefront kernel and not the default).  Held to the same bars as every kernel."""
+    import os
+    from oracle import orc
+    from util import check_records
+    raw = synth.make_gl_numpy(30, n_ind, 905 + n_ind, depth=3.0)
+    raw[5] = [1.0, 0.0, 0.0]
+    raw[9, ::3] = 1.0 / 3.0
+    want = orc.Oracle(raw, ignore_miss_data=ignore_miss, n_threads=4).run()
+    os.environ["NGSLD_PAIR_KERNEL"] = "ab"
+    try:
+        eng = capi.Engine(0)
+    finally:
+        del os.environ["NGSLD_PAIR_KERNEL"]
+    try:
+        eng.set_geno_raw(raw, ignore_miss_data=ignore_miss)
+        assert eng.pair_kernel() == "ab"
+        eng.set_pos_dist(None)
+        assert eng.plan(ignore_miss_data=ignore_miss) == len(want)
+        s1, s2, std, ext = eng.run()
+        check_records(std, ext, want)
+    finally:
+        eng.close()
