@@ -267,6 +267,32 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
                             void *sink_user, uint64_t *n_pairs, uint64_t *n_slabs, char *err, size_t errlen,
                             const char *const *labels, int text_output);
 
+/* ---- Several GPUs of one node, one process (replaces the thread-pool section of the reference's main(),
+ * ngsLD.cpp:153-198, at the scale of devices) ----------------------------------------------------------------------
+ * The rows are cut into n_devices contiguous parts with equal candidate-pair counts; part k runs on devices[k] from its
+ * own host thread and holds only the sites its rows pair with.  Pairs are independent, so nothing is exchanged while
+ * computing; the records of the parts, in part order, are the single-device run bit for bit. */
+
+/* Cut rows [0, n_sites) into n_parts parts: parts[k] = {row_begin, row_end, site_end} -- part k computes the rows
+ * [row_begin, row_end) and needs the sites [row_begin, site_end).  Host only. */
+int ngsld_plan_parts(const double *pos_dist, uint64_t n_sites, const ngsld_params *params, int n_parts, ngsld_slab *parts);
+
+/* Sink of a multi-device run: called on part `part`'s own thread -- the batches of one part arrive in (s1, s2) order,
+ * different parts call concurrently.  Site indices in the batch are global. */
+typedef int (*ngsld_multi_sink_fn)(void *user, int part, const ngsld_batch *batch);
+
+/* The whole job: gl_raw = the matrix in host memory ([site][ind][3], as ngsld_set_geno_raw_opts takes it), or NULL and
+ * `read` delivers the raw values of any site range (it is called from several threads at once).  A windowed run uploads
+ * every part's slab from host memory over the part's own PCIe link; an all-pairs run on >= 2 distinct devices puts the
+ * matrix on the first device once and hands it to the others with ONE ncclBroadcast (RCCL over xGMI, loaded on demand).
+ * maf_out (n_sites doubles, may be NULL) receives est_maf; it is complete before the first batch reaches the sink.
+ * labels / text_output as in ngsld_run_streamed_text.  pairs_per_part (n_devices entries, may be NULL) receives the
+ * pairs each part computed.  Every part must fit its device (a job that does not is for ngsld_run_streamed). */
+int ngsld_run_multi(const int *devices, int n_devices, uint64_t n_sites, uint64_t n_ind, const double *pos_dist,
+                    const ngsld_params *params, const ngsld_geno_opts *opts, const double *gl_raw,
+                    ngsld_read_sites_fn read, void *read_user, double *maf_out, ngsld_multi_sink_fn sink, void *sink_user,
+                    const char *const *labels, int text_output, uint64_t *pairs_per_part, char *err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,7 @@ def items_from_pairs(s1: np.ndarray, s2: np.ndarray, span: int = 64) -> np.ndarr
 
 
 SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Batch))
+MULTI_SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(Batch))
 READ_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p)
 SLAB = np.dtype([("row_begin", "<u8"), ("row_end", "<u8"), ("site_end", "<u8")])
 
@@ -82,6 +83,7 @@ SYMBOLS = [
     "ngsld_set_geno_raw_opts", "ngsld_set_geno_lkl",
     "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device", "ngsld_set_text_output",
     "ngsld_set_replay_source", "ngsld_set_replay", "ngsld_replay_stats", "ngsld_finish_device",
+    "ngsld_plan_parts", "ngsld_run_multi",
     "ngsld_last_kernel_time", "ngsld_pair_kernel", "ngsld_set_tuning", "ngsld_selftest",
     "ngsld_window_ends", "ngsld_plan_slabs", "ngsld_slab_sites_for_budget", "ngsld_device_memory", "ngsld_run_streamed", "ngsld_run_streamed_text",
     "ngsld_host_read_geno_bin_range",
@@ -152,6 +154,11 @@ def lib() -> C.CDLL:
         L.ngsld_device_memory.argtypes = [C.c_int, C.POINTER(u64), C.POINTER(u64)]
         L.ngsld_run_streamed.argtypes = [C.c_int, u64, u64, vp, C.POINTER(Params), C.POINTER(GenoOpts), u64, READ_FN, vp,
                                          vp, SINK_FN, vp, C.POINTER(u64), C.POINTER(u64), C.c_char_p, C.c_size_t]
+        if hasattr(L, "ngsld_run_multi"):
+            L.ngsld_plan_parts.argtypes = [vp, u64, C.POINTER(Params), C.c_int, vp]
+            L.ngsld_run_multi.argtypes = [C.POINTER(C.c_int), C.c_int, u64, u64, vp, C.POINTER(Params), C.POINTER(GenoOpts),
+                                          vp, READ_FN, vp, vp, MULTI_SINK_FN, vp, C.POINTER(C.c_char_p), C.c_int,
+                                          C.POINTER(u64), C.c_char_p, C.c_size_t]
         L.ngsld_host_read_geno_bin_range.argtypes = [C.c_char_p, u64, u64, u64, vp, C.c_char_p, C.c_size_t]
         L.ngsld_host_set_threads.argtypes = [C.c_int]
         L.ngsld_host_set_threads.restype = None
@@ -308,6 +315,74 @@ def run_streamed(read_sites, n_sites: int, n_ind: int, pos_dist: np.ndarray | No
     assert len(s1) == n_pairs.value
     return (s1, cat(s2s, np.uint64), cat(stds, REC_STD), cat(exts, REC_EXT) if p.extend_out else None, maf,
             int(n_slabs.value))
+
+
+def plan_parts(pos_dist: np.ndarray | None, n_sites: int, n_parts: int, **kw) -> np.ndarray:
+    """Row parts (row_begin, row_end, site_end) of a multi-device run (host only)."""
+    pd = None if pos_dist is None else np.ascontiguousarray(pos_dist, dtype=np.float64)
+    out = np.zeros(n_parts, dtype=SLAB)
+    p = _params(**kw)
+    rc = lib().ngsld_plan_parts(None if pd is None else pd.ctypes.data, n_sites, C.byref(p), n_parts, out.ctypes.data)
+    if rc != OK:
+        raise NgsldError(rc, "ngsld_plan_parts")
+    return out
+
+
+def run_multi(raw: np.ndarray, pos_dist: np.ndarray | None, devices: list[int], log_scale: bool = False,
+              call_geno: tuple[float, float] | None = None, text: bool = False, labels: list[str] | None = None,
+              text_output: bool = False, **kw):
+    """One job over several devices in this process (ngsld_run_multi).  Returns per part a tuple
+    (s1, s2, std, ext) -- or the part's TSV bytes with text_output -- plus the maf vector and the pairs per part."""
+    L = lib()
+    raw = np.ascontiguousarray(raw, dtype=np.float64)
+    n_sites, n_ind = raw.shape[0], raw.shape[1]
+    pd = None if pos_dist is None else np.ascontiguousarray(pos_dist, dtype=np.float64)
+    p = _params(**kw)
+    o = GenoOpts(int(log_scale), p.ignore_miss_data, 0, int(text), int(call_geno is not None), 0,
+                 call_geno[0] if call_geno else 0.0, call_geno[1] if call_geno else 0.0)
+    n = len(devices)
+    acc = [dict(s1=[], s2=[], std=[], ext=[], text=[]) for _ in range(n)]
+
+    def sink(_user, part, bp):
+        b = bp.contents
+        a = acc[part]
+        if b.text:
+            a["text"].append(C.string_at(b.text, b.text_len))
+            return 0
+        k = b.n_pairs
+        if k:
+            a["std"].append(np.frombuffer(C.string_at(b.std, k * REC_STD.itemsize), dtype=REC_STD).copy())
+            if b.ext:
+                a["ext"].append(np.frombuffer(C.string_at(b.ext, k * REC_EXT.itemsize), dtype=REC_EXT).copy())
+        items = np.frombuffer(C.string_at(b.items, b.n_items * ITEM.itemsize), dtype=ITEM) if b.n_items else \
+            np.zeros(0, dtype=ITEM)
+        x, y = items_to_pairs(items)
+        a["s1"].append(x)
+        a["s2"].append(y)
+        return 0
+
+    maf = np.full(n_sites, np.nan)
+    per = (C.c_uint64 * n)()
+    err = C.create_string_buffer(512)
+    devs = (C.c_int * n)(*devices)
+    lab = None
+    if labels is not None:
+        lab = (C.c_char_p * len(labels))(*[l.encode() for l in labels])
+    cb = MULTI_SINK_FN(sink)
+    rc = L.ngsld_run_multi(devs, n, n_sites, n_ind, None if pd is None else pd.ctypes.data, C.byref(p), C.byref(o),
+                           raw.ctypes.data, READ_FN(0), None, maf.ctypes.data, cb, None, lab, int(text_output), per, err,
+                           len(err))
+    if rc != OK:
+        raise NgsldError(rc, err.value.decode())
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dtype=dt)
+    out = []
+    for a in acc:
+        if text_output:
+            out.append(b"".join(a["text"]))
+        else:
+            out.append((cat(a["s1"], np.uint64), cat(a["s2"], np.uint64), cat(a["std"], REC_STD),
+                        cat(a["ext"], REC_EXT) if p.extend_out else None))
+    return out, maf, [int(v) for v in per]
 
 
 def read_geno_text(path: str, in_probs: bool, log_scale: bool, n_ind: int, n_sites: int) -> tuple[np.ndarray, bool]:

@@ -6,6 +6,8 @@
 //   * rows are written in (site1, site2) order (the reference's order is arbitrary for --n_threads > 1);
 //   * --n_threads sets the number of host threads that format the TSV; --device N (new) picks the GPU, --max_gpu_mem GB (new)
 //     caps the device memory: a windowed run on binary input that does not fit is streamed slab by slab;
+//   * --devices 0-7 (or 0,2,5; new) runs the job on several GPUs of the node from this one process (ngsld_run_multi):
+//     the rows are cut into one part per device, the output is the single-device output;
 #include <getopt.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -45,7 +47,30 @@ struct Params {  // ngsLD.hpp:11-44
   unsigned n_threads = 1, verbose = 1;
   int device = 0;
   double max_gpu_mem = 0;  // GB of device memory the run may use; 0 = what is free on the device
+  std::vector<int> devices;  // --devices: more than one entry = one part of the rows per device
 };
+
+// "0-3", "0,2,5", "1" -> device indices; empty on a malformed list
+std::vector<int> parse_devices(const char *txt) {
+  std::vector<int> out;
+  const char *p = txt;
+  while (*p) {
+    char *end = nullptr;
+    const long a = strtol(p, &end, 10);
+    if (end == p || a < 0) return {};
+    long b = a;
+    p = end;
+    if (*p == '-') {
+      b = strtol(p + 1, &end, 10);
+      if (end == p + 1 || b < a) return {};
+      p = end;
+    }
+    for (long d = a; d <= b; ++d) out.push_back((int)d);
+    if (*p == ',') ++p;
+    else if (*p) return {};
+  }
+  return out;
+}
 
 [[noreturn]] void error(const char *func, const char *msg) {  // gen_func.cpp:12-18
   fflush(stdout);
@@ -79,6 +104,7 @@ void parse_cmd_args(Params *pars, int argc, char **argv) {
                                          {"verbose", required_argument, NULL, 'V'},
                                          {"device", required_argument, NULL, 1001},
                                          {"max_gpu_mem", required_argument, NULL, 1002},
+                                         {"devices", required_argument, NULL, 1003},
                                          {0, 0, 0, 0}};
   pars->seed = (uint64_t)(time(NULL) + rand() % 1000);  // parse_args.cpp:23
   int c = 0;
@@ -106,6 +132,11 @@ void parse_cmd_args(Params *pars, int argc, char **argv) {
       case 'V': pars->verbose = (unsigned)atoi(optarg); break;
       case 1001: pars->device = atoi(optarg); break;
       case 1002: pars->max_gpu_mem = atof(optarg); break;
+      case 1003:
+        pars->devices = parse_devices(optarg);
+        if (pars->devices.empty()) error(__FUNCTION__, "--devices takes a list like 0-7 or 0,2,5");
+        pars->device = pars->devices[0];
+        break;
       default: exit(-1);  // unknown flags and --outH (declared, no case: parse_args.cpp:55,130)
     }
 
@@ -140,6 +171,9 @@ void parse_cmd_args(Params *pars, int argc, char **argv) {
   if (pars->rnd_sample <= 0 || pars->rnd_sample > 1)
     error(__FUNCTION__, "proportion of comparisons to sample must be in ]0,1]!");
   if (pars->n_threads < 1) error(__FUNCTION__, "number of threads cannot be less than 1!");
+  // (n_threads is unsigned in the reference too, ngsLD.hpp:33: a negative value passes the test above as 4 billion and
+  // its thread pool then fails to start; here it would only ask for that many formatter threads)
+  if (pars->n_threads > 4096) pars->n_threads = 4096;
 }
 
 struct SinkState {
@@ -275,6 +309,107 @@ bool run_streamed(Params &pars, uint64_t slab_sites, bool may_fall_back) {
   return true;
 }
 
+// ---- several devices, one process (ngsld_run_multi): part 0 writes straight to the output, the other parts spool their
+// rows to <out>.part<k> (a temporary file when the output is stdout) and are appended in order at the end ----
+struct MultiSink {
+  const Params *pars;
+  const ngsld_pos *pos;
+  const double *pos_dist;
+  const double *maf;
+  std::vector<FILE *> fh;  // one per part
+  int n_threads;           // formatter threads per part
+};
+
+int write_part_batch(void *user, int part, const ngsld_batch *b) {
+  MultiSink *m = static_cast<MultiSink *>(user);
+  FILE *fh = m->fh[(size_t)part];
+  fflush(fh);
+  const int fd = fileno(fh);
+  if (b->text != nullptr) {
+    const char *q = b->text;
+    uint64_t left = b->text_len;
+    while (left) {
+      const ssize_t w = ::write(fd, q, left > (1ull << 30) ? (size_t)(1ull << 30) : (size_t)left);
+      if (w <= 0) return 1;
+      q += w;
+      left -= (uint64_t)w;
+    }
+    return 0;
+  }
+  return ngsld_host_write_batch(b, m->pos, m->pos_dist, m->maf, m->n_threads, fd) == NGSLD_OK ? 0 : 1;
+}
+
+void run_multi(Params &pars, const double *raw, int text_semantics, int log_scale) {
+  char err[512];
+  const int n = (int)pars.devices.size();
+  ngsld_pos *pos = nullptr;
+  if (pars.verbose >= 1) fprintf(stderr, "==> Getting sites coordinates\n");
+  if (pars.in_pos &&
+      ngsld_host_read_pos(pars.in_pos, pars.in_pos_header ? 1 : 0, pars.n_sites, &pos, err, sizeof(err)) != NGSLD_OK)
+    error("read_dist", err);
+  ngsld_params lp;
+  ngsld_geno_opts go;
+  fill_run_params(pars, &lp, &go);
+  go.text_semantics = text_semantics;
+  go.log_scale = log_scale;
+  std::vector<double> maf(pars.n_sites);
+  MultiSink ms;
+  ms.pars = &pars;
+  ms.pos = pos;
+  ms.pos_dist = pos ? ngsld_host_pos_dist(pos) : nullptr;
+  ms.maf = maf.data();
+  ms.n_threads = (int)std::max<unsigned>(1u, pars.n_threads / (unsigned)n);
+  std::vector<std::string> part_names((size_t)n);
+  ms.fh.assign((size_t)n, nullptr);
+  ms.fh[0] = pars.out_fh;
+  for (int k = 1; k < n; ++k) {
+    if (pars.out != NULL) {
+      part_names[(size_t)k] = std::string(pars.out) + ".part" + std::to_string(k);
+      ms.fh[(size_t)k] = fopen(part_names[(size_t)k].c_str(), "w+");
+    } else {
+      ms.fh[(size_t)k] = tmpfile();
+    }
+    if (ms.fh[(size_t)k] == nullptr) error(__FUNCTION__, "cannot open a part file next to the output");
+  }
+  ReadState rs;
+  rs.pars = &pars;
+  rs.err[0] = 0;
+  const bool dev_text = !(getenv("NGSLD_HOST_TEXT") && strcmp(getenv("NGSLD_HOST_TEXT"), "1") == 0);
+  std::vector<const char *> lab;
+  if (pos && dev_text) {
+    lab.resize(pars.n_sites);
+    for (uint64_t s = 0; s < pars.n_sites; s++) lab[s] = ngsld_host_label(pos, s);
+  }
+  if (pars.verbose >= 1) fprintf(stderr, "==> Launching %d device threads...\n", n);
+  std::vector<uint64_t> per((size_t)n, 0);
+  const int rc = ngsld_run_multi(pars.devices.data(), n, pars.n_sites, pars.n_ind, ms.pos_dist, &lp, &go, raw,
+                                 raw ? nullptr : read_slab, raw ? nullptr : &rs, maf.data(), write_part_batch, &ms,
+                                 pos && dev_text ? lab.data() : nullptr, dev_text ? 1 : 0, per.data(), err, sizeof(err));
+  if (rc == NGSLD_ERR_NAN) error("read_geno", err);
+  if (rc == NGSLD_ERR_MAF_RANGE) error("haplo_freq", err);
+  if (rc != NGSLD_OK) error("ngsld_run_multi", rs.err[0] ? rs.err : err);
+  if (pars.verbose >= 2)
+    for (int k = 0; k < n; ++k)
+      fprintf(stderr, "\tdevice %d: %lu pairs\n", pars.devices[(size_t)k], (unsigned long)per[(size_t)k]);
+  // append the spooled parts in order
+  fflush(pars.out_fh);
+  std::vector<char> buf(8u << 20);
+  for (int k = 1; k < n; ++k) {
+    FILE *fh = ms.fh[(size_t)k];
+    fflush(fh);
+    rewind(fh);
+    size_t got;
+    while ((got = fread(buf.data(), 1, buf.size(), fh)) > 0)
+      if (fwrite(buf.data(), 1, got, pars.out_fh) != got) error(__FUNCTION__, "cannot append a part to the output");
+    fclose(fh);
+    if (!part_names[(size_t)k].empty()) unlink(part_names[(size_t)k].c_str());
+  }
+  if (pars.verbose >= 1) fprintf(stderr, "==> Freeing memory...\n");
+  fclose(pars.out_fh);
+  ngsld_host_free_pos(pos);
+  if (pars.verbose >= 1) fprintf(stderr, "Done!\n");
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -306,6 +441,13 @@ int main(int argc, char **argv) {
 
   ngsld_host_set_threads((int)pars.n_threads);
   timing_report.mark("arguments, output header");
+
+  // ---- several devices: a windowed run on binary input lets every part read its own slab from the file ----
+  if (pars.devices.size() > 1 && pars.in_bin && (pars.max_kb_dist > 0 || pars.max_snp_dist > 0)) {
+    if (pars.verbose >= 1) fprintf(stderr, "> Reading data from file...\n");
+    run_multi(pars, nullptr, 0, pars.in_logscale ? 1 : 0);
+    return 0;
+  }
 
   // ---- device ----
   ngsld_ctx *ctx = nullptr;
@@ -373,6 +515,13 @@ int main(int argc, char **argv) {
     go.text_semantics = 1;
   }
   timing_report.mark("read genotype file");
+  if (pars.devices.size() > 1) {  // all pairs (or text input) on several devices: the matrix is in host memory once
+    ngsld_destroy(ctx);
+    if (pars.call_geno && pars.verbose >= 1) fprintf(stderr, "> Calling genotypes...\n");
+    if (pars.verbose >= 1) fprintf(stderr, "==> Calculating MAF for all sites...\n");
+    run_multi(pars, raw.get(), go.text_semantics, go.log_scale);
+    return 0;
+  }
   if (pars.call_geno && pars.verbose >= 1) fprintf(stderr, "> Calling genotypes...\n");
   if (pars.verbose >= 1) fprintf(stderr, "==> Calculating MAF for all sites...\n");
   int rc = ngsld_set_geno_raw_opts(ctx, raw.get(), pars.n_sites, pars.n_ind, &go);

@@ -95,3 +95,24 @@ def test_two_rank_gloo_shards_equal_single_process(max_kb):
     assert len(rec) == len(want)
     for col in ("s1", "s2", "dist", "hap", "n_iter", "n_ind_data", "r2", "D", "Dp", "r2pear"):
         assert np.array_equal(rec[col], want[col], equal_nan=True), col
+
+
+def test_plan_parts_covers_the_rows_and_balances_the_pairs():
+    """ngsld_plan_parts (host only): contiguous parts, every row once, halo = the furthest site a row pairs with,
+    candidate pairs within a few rows of equal."""
+    from ngsld_amd import capi
+    n_sites = 5000
+    chrs, pos = synth.make_positions(n_sites, 9, max_gap=200, n_chr=3)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    for kw in (dict(max_kb_dist=20), dict(max_kb_dist=0), dict(max_snp_dist=50)):
+        ends = capi.window_ends(pd if kw.get("max_kb_dist", 0) else pd, n_sites, **kw).astype(np.int64)
+        counts = np.maximum(ends - (np.arange(n_sites) + 1), 0)
+        for n_parts in (1, 2, 8):
+            parts = capi.plan_parts(pd, n_sites, n_parts, **kw)
+            assert parts["row_begin"][0] == 0 and parts["row_end"][-1] == n_sites
+            assert np.array_equal(parts["row_begin"][1:], parts["row_end"][:-1])
+            per = [int(counts[a:b].sum()) for a, b in zip(parts["row_begin"], parts["row_end"])]
+            assert sum(per) == int(counts.sum())
+            assert max(per) - min(per) <= 2 * int(counts.max()) + 1
+            for a, b, e in zip(parts["row_begin"], parts["row_end"], parts["site_end"]):
+                assert e == (max(int(ends[a:b].max()), b) if b > a else b)
