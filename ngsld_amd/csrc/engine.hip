@@ -2,6 +2,7 @@
 // batched replacement of the reference's per-s1 thread-pool dispatch, ngsLD.cpp:153-198) and the
 // batch pipeline kernel -> async D2H -> sink.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -28,6 +29,43 @@ using namespace ngsld;
 
 namespace {
 thread_local std::string g_create_error;
+
+// roctx ranges around the phases of a run (upload / prep / plan / pair kernels / D2H / replay / sink), so that a
+// `rocprofv3 --marker-trace --kernel-trace` timeline reads as phases.  The marker library (rocprofiler-sdk-roctx, or the
+// older libroctx64) is resolved on first use and is not a link-time dependency: without it the ranges are no-ops.
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    if (const char *e = std::getenv("NGSLD_ROCTX"))
+      if (std::strcmp(e, "0") == 0) return;
+    for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+      void *lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);  // only if the profiler (or the caller) already loaded it
+      if (lib == nullptr && std::getenv("NGSLD_ROCTX") != nullptr) lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib == nullptr) continue;
+      push = reinterpret_cast<int (*)(const char *)>(dlsym(lib, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+      if (push && pop) return;
+      push = nullptr;
+      pop = nullptr;
+    }
+  }
+};
+Roctx &roctx() {
+  static Roctx r;
+  return r;
+}
+struct Range {  // scope = one named phase
+  bool on;
+  explicit Range(const char *name) : on(roctx().push != nullptr) {
+    if (on) roctx().push(name);
+  }
+  ~Range() {
+    if (on) roctx().pop();
+  }
+  Range(const Range &) = delete;
+  Range &operator=(const Range &) = delete;
+};
 
 // (both buffers free themselves: an early return from a function that holds one as a local leaks nothing)
 template <typename T>
@@ -202,6 +240,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
                     const ngsld_geno_opts &o, bool normalised) {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   const int log_scale = o.log_scale, ignore_miss = o.ignore_miss_data, on_device = o.on_device;
+  Range range_("ngsld:set_geno (upload + per-site prep)");
   if (o.call_geno && o.N_thresh > o.call_thresh)  // gen_func.cpp:887-888
     return fail(c, NGSLD_ERR_INVALID, "missing data threshold must be smaller than calling genotype threshold!");
   if (gl == nullptr || n_sites == 0 || n_ind == 0) return fail(c, NGSLD_ERR_INVALID, "empty genotype matrix");
@@ -528,6 +567,7 @@ int fetch_replay_site(ngsld_ctx *c, uint64_t s, std::vector<double> &tmp, Replay
 // at this point, while the next batch's pair kernel has the device, can wait for that kernel -- measured 43 ms.)
 int replay_flagged(ngsld_ctx *c, const uint32_t *h_flags, uint64_t base, uint64_t n, ngsld_rec_std *h_std,
                    ngsld_rec_ext *h_ext, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext, hipStream_t st) {
+  Range range_("ngsld:exact-order replay (host)");
   const uint64_t words = (n + 31) / 32;
   const uint32_t *bits = h_flags + 2;
   std::vector<uint64_t> recs;
@@ -791,6 +831,7 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
   if (p->min_maf < 0 || p->min_maf > 1)  // parse_args.cpp:176-177
     return fail(c, NGSLD_ERR_INVALID, "minimum allele frequency must be in [0,1]!");
   HIP_TRY(c, hipSetDevice(c->device));
+  Range range_("ngsld:plan");
   const uint64_t n = c->n_sites;
   c->params = *p;
   c->planned = false;
@@ -979,6 +1020,7 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
   if (s1_begin > s1_end || s1_end > c->n_sites) return fail(c, NGSLD_ERR_INVALID, "row range out of bounds");
   if (d_std == nullptr) return fail(c, NGSLD_ERR_INVALID, "d_std is NULL");
   HIP_TRY(c, hipSetDevice(c->device));
+  Range range_("ngsld:run_device (pair kernels)");
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
   c->ev_used = 0;
   c->timed_stream = st;
@@ -1019,6 +1061,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   if (!c->planned) return fail(c, NGSLD_ERR_INVALID, "ngsld_plan has not been called");
   if (s1_begin > s1_end || s1_end > c->n_sites) return fail(c, NGSLD_ERR_INVALID, "row range out of bounds");
   HIP_TRY(c, hipSetDevice(c->device));
+  Range range_("ngsld:run");
   const bool ext = c->params.extend_out != 0;
   c->ev_used = 0;
   c->timed_stream = c->stream;
@@ -1119,6 +1162,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   };
   std::vector<Item> rel_items;
   auto issue = [&](size_t bi) -> int {  // kernel on `stream`, D2H on `copy_stream`
+    Range range_issue("ngsld:issue batch (pair kernel + D2H)");
     const int k = (int)(bi & 1);
     const Batch &b = batches[bi];
     if (replay) {
@@ -1175,6 +1219,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     out.s1_end = b.r1;
     out.n_pairs = b.n;
     bool as_records = !text;
+    Range range_wait(text ? "ngsld:consume batch (text rows, D2H, replay, sink)" : "ngsld:consume batch (wait for records, replay, sink)");
     if (text) {
       // the batch's text: its length is known now; the rows are written and copied on the copy stream while the pair
       // kernel of the next batch (already enqueued) runs on the compute stream
@@ -1243,6 +1288,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       out.ext = ext ? c->h_ext[k].p : nullptr;
     }
     if (trace) std::fprintf(stderr, "[trace] batch %zu: replay done %.2f\n", bi, now_ms());
+    Range range_sink("ngsld:sink");
     if (sink(user, &out) != 0) rc = fail(c, NGSLD_ERR_SINK, "sink callback failed");
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
