@@ -42,7 +42,13 @@ def main():
         pd_o = pd[:n_have].copy()
     else:
         raw, pd_o = raw_t.cpu().numpy(), None
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0))
+    try:  # the cgroup CPU quota of the lease, when there is one (os.cpu_count() reports the machine)
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            cores = max(1, min(cores, int(float(q[0]) / float(q[1]) + 0.5)))
+    except (OSError, ValueError, IndexError):
+        pass
     t0 = time.perf_counter()
     o = orc.Oracle(raw, pd_o, max_kb_dist=max_kb, n_threads=cores)
     want = o.run(0, rows)
@@ -50,14 +56,19 @@ def main():
     eng = capi.Engine(0)
     try:
         eng.set_geno_raw(raw_t.data_ptr(), n_sites=n_sites, n_ind=n_ind)
+        if len(raw) == n_sites:
+            eng.set_replay_source(raw)          # the exact-order replay reads the caller's values, as the CLI does
         eng.set_pos_dist(pd)
         eng.plan(max_kb_dist=max_kb, extend_out=True)
         t0 = time.perf_counter()
         s1, s2, std, ext = eng.run(0, rows)
         t_gpu = time.perf_counter() - t0
+        eng_replayed = [eng.replay_stats()[0]]
     finally:
         eng.close()
+    replayed = eng_replayed[0]
     out = {"config": which, "n_sites": n_sites, "n_ind": n_ind, "max_kb_dist": max_kb, "rows": rows, "pairs": int(len(want)),
+           "pairs_replayed_exact_order": replayed,
            "oracle_s": round(t_cpu, 1), "oracle_threads": cores, "gpu_sink_path_s": round(t_gpu, 2)}
     ok = len(want) == len(std) and np.array_equal(s1, want["s1"]) and np.array_equal(s2, want["s2"])
     out["pairs_and_order_equal"] = bool(ok)
