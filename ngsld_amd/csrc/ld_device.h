@@ -41,6 +41,12 @@ constexpr bool kDrop0 = NGSLD_DROP0 != 0;
 #ifndef NGSLD_WN_ROWS
 #define NGSLD_WN_ROWS 1  // build-time A/B switch: several wavefronts per pair post their partial sums without v_readlane
 #endif
+#ifndef NGSLD_MASK_DONE
+#define NGSLD_MASK_DONE 1  // build-time A/B switch: converged groups of a lockstep wavefront are masked off (see pair_ld_group_kernel)
+#endif
+#ifndef NGSLD_MASK_SLOTS
+#define NGSLD_MASK_SLOTS 6  // ... from this many individuals per lane on (measured: 3, 4, 5 slots lose 2.5 %, 6 gains 2 %, 7-8 gain 5.5-7 %)
+#endif
 #ifndef NGSLD_EARLY_EPS
 #define NGSLD_EARLY_EPS 1  // build-time A/B switch: the convergence test looks at one change first (see em_pair)
 #endif
@@ -1416,6 +1422,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
     };
     bool done = !active, tie = false;
     uint32_t n_iter = (uint32_t)kIterMax;
+    constexpr bool kMaskDone = NGSLD_MASK_DONE != 0 && SLOTS >= NGSLD_MASK_SLOTS;
     // As in em_pair: the hot loop holds the shared-reciprocal step in its three-value form only; a step that is not sane
     // in some live group leaves it for one iteration with a reciprocal per individual, and as soon as hap 0 of any live
     // group falls below kFullBelow the wavefront leaves it for good and finishes in the full four-value form.
@@ -1426,8 +1433,15 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       if (kTree && !full) {
         bool all_done = false;
         for (; itn < (uint32_t)kIterMax; ++itn) {
-          double n0, n1, n2, n3;
-          em_step(PairedTag(), n0, n1, n2, n3);
+          double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+          // A group that has converged idles until the slowest group of its wavefront has.  It idles with its lanes
+          // SWITCHED OFF (EXEC), not computing on stale values: the device runs these kernels at its power limit
+          // (1.35 kW, 2.05-2.1 GHz of 2.4: profiles/r02/clocks_power_r02.txt), so what idle lanes do not burn comes
+          // back as clock.  (Every cross-lane step of the EM stays inside a group, all of whose lanes are on or off.)
+          // Same-box A/B (tools/ab_mask.sh): +5.5 % at n_ind 100 (configs[1]), +6.9 % at 64, +2 % at 48, +1 % at 200 (two
+          // groups: little to idle); -2.5 % at 24 / 32 / 40 and in the genotype-combination kernel, whose iterations are
+          // too short for the mask's own bookkeeping -- hence only from NGSLD_MASK_SLOTS individuals per lane on.
+          if (!kMaskDone || !done) em_step(PairedTag(), n0, n1, n2, n3);
           if (__any(!done && !(n1 < 2.0))) break;  // an odd step (one NaN reciprocal poisons every R, see em_pair)
           // as in em_pair: eps is at least the change of hap 1, and while that alone is above EPSILON in every live
           // group the other three differences are not formed
@@ -1456,8 +1470,8 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
         if (all_done || itn >= (uint32_t)kIterMax) break;
         if (full) continue;
       }
-      double n0, n1, n2, n3;
-      em_step(SingleTag(), n0, n1, n2, n3);
+      double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+      if (!kMaskDone || !done) em_step(SingleTag(), n0, n1, n2, n3);
       const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
       if (!done) {
         if (!(n1 < 2.0)) {  // the reference's all-NaN step: "converges" at this iteration (see em_pair)

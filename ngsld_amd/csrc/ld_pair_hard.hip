@@ -156,6 +156,10 @@ __global__ __launch_bounds__(256, 4) void pair_ld_hard_kernel(PairArgs A) {
     bool done = !active, tie = false;
     uint32_t n_iter = (uint32_t)kIterMax;
     for (uint32_t itn = 0; itn < (uint32_t)kIterMax; ++itn) {
+      // (kHardMask: groups that have converged would sit out with their lanes switched off as in pair_ld_group_kernel --
+      // measured 2.5 % SLOWER here, the iteration is too short for the mask's own bookkeeping: off)
+      constexpr bool kHardMask = false;
+      if (!kHardMask || !done) {
       const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
       const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
       const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(256, 4) void pair_ld_hard_kernel(PairArgs A) {
             n_iter = itn;
           }
         }
+      }
       }
       if (__all(done)) break;
     }
