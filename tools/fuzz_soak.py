@@ -33,5 +33,7 @@ for k in range(first, last):
     except (AssertionError, capi.NgsldError) as e:
         bad += 1
         print(f"case {k}: n_ind {raw.shape[1]} n_sites {raw.shape[0]} FAILED: {str(e)[:300]}")
-print(f"fuzz soak: cases {first}..{last - 1}, {pairs} pairs compared, {bad} failing cases")
+from util import REPORT
+print(f"fuzz soak: cases {first}..{last - 1}, {pairs} pairs compared, {bad} failing cases; beyond 1e-9: {REPORT['over_tol']}, "
+      f"degenerate pairs held to bit equality: {REPORT['degenerate']}, largest difference {REPORT['max_diff']:.3e}")
 sys.exit(1 if bad else 0)
