@@ -132,6 +132,7 @@ struct ngsld_ctx {
   DevBuf<uint64_t> d_hard_masks;
   DevBuf<double> d_hard_u;
   DevBuf<int> d_all_hard;
+  int h_all_hard = 0, h_prep_status = 0;
   uint32_t mask_words = 0;
 
   // plan
@@ -342,7 +343,8 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   HIP_TRY(c, launch_pack_scalars(c->d_maf.p, c->d_mean.p, c->d_rsx.p, c->d_sc4.p, n_sites, c->stream));
   // Is every likelihood triple a called genotype or "no data" (text genotypes, --call_geno)?  Then the pairs run on the
   // 16 genotype-combination counts instead of the individuals (ld_pair_hard.hip).  NGSLD_HARD_KERNEL=0: never (A/B, tests).
-  int all_hard = 0;
+  int &all_hard = c->h_all_hard;  // (ctx-owned: the asynchronous copies below must not target a stack frame an early return leaves)
+  all_hard = 0;
   const char *hk = std::getenv("NGSLD_HARD_KERNEL");
   const bool try_hard = c->prefetch && n_ind <= kHardMaxInd && !o.per_individual_only && !(hk != nullptr && std::strcmp(hk, "0") == 0);
   if (try_hard) {
@@ -357,7 +359,8 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
     HIP_TRY(c, hipMemcpyAsync(&all_hard, c->d_all_hard.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   }
   c->h_maf.resize(n_sites);
-  int status = 0;
+  int &status = c->h_prep_status;
+  status = 0;
   HIP_TRY(c, hipMemcpyAsync(c->h_maf.data(), c->d_maf.p, n_sites * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(&status, c->d_status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
