@@ -114,3 +114,16 @@ def test_cli_devices_flag(tmp_path, mode):
         outs.append(open(o, "rb").read())
         assert not [f for f in os.listdir(tmp_path) if ".part" in f], "part files must be gone"
     assert outs[0] == outs[1] == outs[2] and outs[0].count(b"\n") > 1000
+
+
+def test_a_failing_part_stops_the_whole_job():
+    """One part cannot get its device (index 99), another meets a NaN: the call returns the error, nothing hangs, no sink call."""
+    raw = synth.make_gl_numpy(120, 40, seed=61)
+    with pytest.raises(capi.NgsldError) as e:
+        capi.run_multi(raw, None, [0, 99], extend_out=True)
+    assert "part 1" in e.value.msg
+    bad = raw.copy()
+    bad[100, 3, :] = -1.0                    # log(-1) = NaN, in the last part only
+    with pytest.raises(capi.NgsldError) as e:
+        capi.run_multi(bad, None, [0, 0, 0], extend_out=True)
+    assert e.value.code == capi.ERR_NAN and "NaN found" in e.value.msg

@@ -116,3 +116,15 @@ def test_plan_parts_covers_the_rows_and_balances_the_pairs():
             assert max(per) - min(per) <= 2 * int(counts.max()) + 1
             for a, b, e in zip(parts["row_begin"], parts["row_end"], parts["site_end"]):
                 assert e == (max(int(ends[a:b].max()), b) if b > a else b)
+
+
+def test_run_multi_fails_loudly_and_does_not_hang_without_a_device():
+    """ngsld_run_multi where ngsld_create fails in every part (no GPU here / a device index that does not exist): the
+    parts must all get through their barriers and the call must come back with the library's message."""
+    import os
+    from ngsld_amd import capi
+    raw = synth.make_gl_numpy(40, 6, seed=1)
+    devices = [0, 1, 2] if not os.path.exists("/dev/kfd") else [97, 98, 99]
+    with pytest.raises(capi.NgsldError) as e:
+        capi.run_multi(raw, None, devices, extend_out=True)
+    assert e.value.code in (capi.ERR_DEVICE, capi.ERR_INVALID) and "part 0" in e.value.msg
