@@ -251,6 +251,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   if (!pair_config(n_ind, c->prefetch, c->row_kernel, &cfg, c->run_kernel, c->ab_kernel))
     return fail(c, NGSLD_ERR_UNSUPPORTED, "n_ind is outside the supported range");
   HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
   c->have_geno = false;
   c->planned = false;
   c->text_mode = false;  // labels belong to a matrix
@@ -834,6 +835,7 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
   if (p->min_maf < 0 || p->min_maf > 1)  // parse_args.cpp:176-177
     return fail(c, NGSLD_ERR_INVALID, "minimum allele frequency must be in [0,1]!");
   HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
   Range range_("ngsld:plan");
   const uint64_t n = c->n_sites;
   c->params = *p;
@@ -963,6 +965,7 @@ int ngsld_set_text_output(ngsld_ctx *c, const char *const *labels, int enable) t
   if (c == nullptr) return NGSLD_ERR_INVALID;
   if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "set the genotype data before the labels");
   HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
   c->text_mode = false;
   if (!enable) return NGSLD_OK;
   c->have_labels = labels != nullptr;
@@ -1012,6 +1015,7 @@ int ngsld_replay_stats(ngsld_ctx *c, uint64_t *pairs, uint64_t *sites) {
 int ngsld_finish_device(ngsld_ctx *c) try {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
   const int rc = finish_device_run(c);
   if (rc != NGSLD_OK) return rc;
   return check_status(c);
@@ -1023,6 +1027,7 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
   if (s1_begin > s1_end || s1_end > c->n_sites) return fail(c, NGSLD_ERR_INVALID, "row range out of bounds");
   if (d_std == nullptr) return fail(c, NGSLD_ERR_INVALID, "d_std is NULL");
   HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
   Range range_("ngsld:run_device (pair kernels)");
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
   c->ev_used = 0;
@@ -1064,6 +1069,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   if (!c->planned) return fail(c, NGSLD_ERR_INVALID, "ngsld_plan has not been called");
   if (s1_begin > s1_end || s1_end > c->n_sites) return fail(c, NGSLD_ERR_INVALID, "row range out of bounds");
   HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
   Range range_("ngsld:run");
   const bool ext = c->params.extend_out != 0;
   c->ev_used = 0;
@@ -1303,6 +1309,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
 int ngsld_last_kernel_time(ngsld_ctx *c, double *total_ms, uint64_t *n_launches, uint64_t *n_pairs) {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
   if (c->timed_stream) HIP_TRY(c, hipStreamSynchronize(c->timed_stream));
   double ms = 0.0;
   for (size_t k = 0; k < c->ev_used; ++k) {
@@ -1344,6 +1351,7 @@ int ngsld_set_tuning(ngsld_ctx *c, uint32_t pairs_per_item, uint64_t batch_pairs
 int ngsld_selftest(ngsld_ctx *c) try {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
   std::vector<double> in(320), out(71, 0.0);
   uint64_t st = 0x9E3779B97F4A7C15ull;
   for (auto &v : in) {

@@ -230,6 +230,19 @@ int ngsld_run_multi(const int *devices, int n_devices, uint64_t n_sites, uint64_
     return NGSLD_ERR_INVALID;
   }
   const int n = n_devices;
+  {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+      (void)hipGetLastError();
+      set_err(err, errlen, "part 0 (device " + std::to_string(devices[0]) + "): no HIP device available; this library has no CPU fallback");
+      return NGSLD_ERR_DEVICE;
+    }
+    for (int k = 0; k < n; ++k)
+      if (devices[k] < 0 || devices[k] >= n_dev) {
+        set_err(err, errlen, "part " + std::to_string(k) + " (device " + std::to_string(devices[k]) + "): device index out of range");
+        return NGSLD_ERR_INVALID;
+      }
+  }
   std::vector<ngsld_slab> parts((size_t)n);
   int rc = ngsld_plan_parts(pos_dist, n_sites, params, n, parts.data());
   if (rc != NGSLD_OK) {
@@ -258,6 +271,7 @@ int ngsld_run_multi(const int *devices, int n_devices, uint64_t n_sites, uint64_
       d_raw.clear();
       broadcast = false;
     }
+    (void)hipGetLastError();  // a handled failure must not surface later as some launch's "last error"
   }
   if (const char *v = std::getenv("NGSLD_MULTI_VERBOSE"))
     if (std::strcmp(v, "0") != 0)

@@ -34,6 +34,8 @@ def test_parts_concatenate_to_the_single_device_run(n_parts, case, monkeypatch):
     raw = synth.make_gl_numpy(n_sites, n_ind, seed=31, depth=4.0)
     chrs, pos = synth.make_positions(n_sites, 31, max_gap=300, n_chr=2)
     pd = shard.pos_dist_from_positions(chrs, pos)
+    for s in (3, n_sites // 3, n_sites // 2, n_sites - 2):     # degenerate sites: their pairs are replayed in every layout
+        raw[s] = [1.0, 0.0, 0.0] if s % 2 else 1.0 / 3.0
     kw = dict(extend_out=True)
     if case == "windowed":
         kw.update(max_kb_dist=8)
