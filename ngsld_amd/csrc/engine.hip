@@ -1107,7 +1107,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     }
   }
   auto need_host_items = [&]() -> int { return ensure_host_items(c); };
-  if (!text) {
+  if (!text || replay) {  // (with the replay on also for text batches: fetched beside a running kernel the copy would wait for it)
     const int rc0 = need_host_items();
     if (rc0 != NGSLD_OK) return rc0;
   }
