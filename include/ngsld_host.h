@@ -78,6 +78,15 @@ size_t ngsld_host_format_double(char *buf, size_t cap, double v, int decimals);
 int ngsld_host_write_batch(const ngsld_batch *b, const ngsld_pos *pos, const double *pos_dist, const double *maf,
                            int n_threads, int fd);
 
+/* gzip-compressed output (optional; the reference writes plain text only): whatever is written to
+ * *fd_to_write is cut into 4 MiB blocks, each deflated by one of n_threads workers into a gzip member of its own, and
+ * written to `path` in order -- a valid .gz file (multi-member), content identical to the plain output.
+ * NGSLD_GZ_LEVEL=1..9 (default 1).  ngsld_host_gz_close: close (or fclose) the write end first or let it be closed
+ * here; returns NGSLD_OK when every block reached the file. */
+typedef struct ngsld_gz ngsld_gz;
+int ngsld_host_gz_open(const char *path, int n_threads, ngsld_gz **out, int *fd_to_write);
+int ngsld_host_gz_close(ngsld_gz *gz);
+
 /* One pair evaluated on the host in the reference's own operation order: read_geno's arithmetic on the two sites' raw
  * values ([n_ind][3] each, as ngsld_set_geno_raw_opts takes them; opts->on_device is ignored), call_geno, est_maf
  * (sequential, gen_func.cpp:974-1009), exp, pearson_r, haplo_freq (gen_func.cpp:1027-1119: sequential sums, the

@@ -90,6 +90,7 @@ SYMBOLS = [
     "ngsld_host_set_threads", "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos", "ngsld_host_pos_slice",
     "ngsld_host_geno_size_ok", "ngsld_host_read_geno_bin", "ngsld_host_read_geno_text", "ngsld_host_format_header", "ngsld_host_format_pair",
     "ngsld_host_format_double", "ngsld_host_write_batch", "ngsld_host_replay_pair",
+    "ngsld_host_gz_open", "ngsld_host_gz_close",
 ]
 
 
@@ -183,6 +184,9 @@ def lib() -> C.CDLL:
         L.ngsld_host_format_double.restype = C.c_size_t
         L.ngsld_host_write_batch.argtypes = [C.POINTER(Batch), vp, vp, vp, C.c_int, C.c_int]
         L.ngsld_host_replay_pair.argtypes = [vp, vp, u64, C.POINTER(GenoOpts), vp, vp, vp]
+        if hasattr(L, "ngsld_host_gz_open"):
+            L.ngsld_host_gz_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp), C.POINTER(C.c_int)]
+            L.ngsld_host_gz_close.argtypes = [vp]
         _lib = L
     return _lib
 

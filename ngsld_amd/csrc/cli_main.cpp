@@ -176,6 +176,15 @@ void parse_cmd_args(Params *pars, int argc, char **argv) {
   if (pars->n_threads > 4096) pars->n_threads = 4096;
 }
 
+ngsld_gz *g_gz = nullptr;  // --out *.gz: the compressor behind pars.out_fh
+void finish_gz() {
+  if (g_gz != nullptr) {
+    ngsld_gz *g = g_gz;
+    g_gz = nullptr;
+    if (ngsld_host_gz_close(g) != NGSLD_OK) fprintf(stderr, "\nERROR: the compressed output is incomplete\n");
+  }
+}
+
 struct SinkState {
   const Params *pars;
   const ngsld_pos *pos;    // may be NULL (no --pos)
@@ -432,7 +441,18 @@ int main(int argc, char **argv) {
       error(__FUNCTION__, "invalid/corrupt genotype input file!");
   }
   // ---- prepare output (ngsLD.cpp:73-77): the header is always written ----
-  if (pars.out != NULL) pars.out_fh = fopen(pars.out, "w");
+  // (new: an --out name ending in .gz is written gzip-compressed, --n_threads deflate workers; the reference has no
+  // compressed output)
+  const char *odot = pars.out ? strrchr(pars.out, '.') : NULL;
+  if (odot != NULL && strcmp(odot, ".gz") == 0) {
+    int wfd = -1;
+    if (ngsld_host_gz_open(pars.out, (int)pars.n_threads, &g_gz, &wfd) != NGSLD_OK)
+      error(__FUNCTION__, "cannot open output file!");
+    pars.out_fh = fdopen(wfd, "w");
+    atexit(finish_gz);  // every path out of main (the streamed and the multi-device runs return early) ends the file
+  } else if (pars.out != NULL) {
+    pars.out_fh = fopen(pars.out, "w");
+  }
   if (pars.out_fh == NULL) error(__FUNCTION__, "cannot open output file!");
   char hdr[512];
   const size_t hn = ngsld_host_format_header(hdr, sizeof(hdr), pars.extend_out);

@@ -78,3 +78,33 @@ def test_api_text_rows(engine):
         dist = float(np.sum(pd[a + 1:b + 1]))
         want = capi.format_pair(labels[a], labels[b], dist, std[k], ext[k], maf[a], maf[b]).encode()
         assert rows[k] + b"\n" == want, (k, rows[k], want)
+
+
+def test_cli_gz_output_is_the_plain_output_compressed(tmp_path):
+    """--out name.gz: gzip members written by --n_threads deflate workers; decompressed = the plain output, byte for byte --
+    resident, streamed (slabs) and multi-device runs."""
+    import gzip
+    import subprocess
+    import numpy as np
+    from ngsld_amd import capi, synth
+    n_sites, n_ind = 3000, 40
+    raw = synth.make_gl_numpy(n_sites, n_ind, seed=71, depth=4.0)
+    chrs, pos = synth.make_positions(n_sites, 71, max_gap=150, n_chr=2)
+    g, p = str(tmp_path / "in.glf"), str(tmp_path / "in.pos")
+    raw.tofile(g)
+    synth.write_pos(p, chrs, pos)
+    base = [capi.CLI_PATH, "--geno", g, "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--pos", p, "--max_kb_dist", "20",
+            "--extend_out", "--verbose", "0", "--n_threads", "4"]
+    plain = str(tmp_path / "plain.ld")
+    r = subprocess.run(base + ["--out", plain], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = open(plain, "rb").read()
+    assert want.count(b"\n") > 100_000
+    for tag, extra, env in (("resident", [], {}), ("slabs", [], {"NGSLD_SLAB_SITES": "700"}), ("devices", ["--devices", "0,0"], {})):
+        out = str(tmp_path / f"{tag}.ld.gz")
+        import os
+        r = subprocess.run(base + extra + ["--out", out], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr
+        with gzip.open(out, "rb") as fh:
+            assert fh.read() == want, tag
+        assert os.path.getsize(out) < len(want) // 2

@@ -217,3 +217,35 @@ def test_read_geno_text_threads_agree(tmp_path):
     b, lb = capi.read_geno_text(g, True, False, fx.n_ind, fx.n_sites)
     L.ngsld_host_set_threads(1)
     assert la == lb and np.array_equal(a, b, equal_nan=True)
+
+
+def test_gz_output_writer_round_trip(tmp_path):
+    """ngsld_host_gz_open / _close: what goes into the pipe comes out of the .gz file, whatever the write sizes; the file is
+    a sequence of gzip members that gzip.open reads through."""
+    import ctypes as C
+    import gzip
+    import os
+    L = capi.lib()
+    rng = np.random.default_rng(3)
+    rows = [("chr1:%d\tchr1:%d\t%d\t%.6f\t%.6f\n" % (a, a + b, b, x, y)).encode()
+            for a, b, x, y in zip(rng.integers(1, 10 ** 8, 400_000), rng.integers(1, 10 ** 5, 400_000), rng.random(400_000),
+                                  rng.random(400_000))]
+    data = b"".join(rows)                                     # ~17 MB: several 4 MiB blocks and a partial one
+    for n_threads, piece in ((1, 1 << 20), (4, 7919), (8, len(data))):
+        path = str(tmp_path / f"out{n_threads}.gz")
+        h, fd = C.c_void_p(), C.c_int(-1)
+        assert L.ngsld_host_gz_open(path.encode(), n_threads, C.byref(h), C.byref(fd)) == capi.OK
+        off = 0
+        while off < len(data):
+            off += os.write(fd.value, data[off:off + piece])
+        os.close(fd.value)
+        assert L.ngsld_host_gz_close(h) == capi.OK
+        with gzip.open(path, "rb") as fh:
+            assert fh.read() == data
+        assert os.path.getsize(path) < len(data) // 2
+    # nothing written at all: an empty, valid file
+    path = str(tmp_path / "empty.gz")
+    h, fd = C.c_void_p(), C.c_int(-1)
+    assert L.ngsld_host_gz_open(path.encode(), 2, C.byref(h), C.byref(fd)) == capi.OK
+    assert L.ngsld_host_gz_close(h) == capi.OK
+    assert os.path.getsize(path) == 0
