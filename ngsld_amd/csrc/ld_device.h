@@ -59,12 +59,12 @@ constexpr double kEpsilon = 1e-5;  // EPSILON,  gen_func.hpp:16
 // engine re-evaluates those on the host in the reference's operation order.  A pair is flagged when
 //   * a hap-derived allele frequency 1 - (f0 + f1) / 1 - (f0 + f2) (ngsLD.cpp:297-298) is within kReplayBelow of 0 or 1:
 //     it carries ~1e-16 of ABSOLUTE rounding noise in the reference, so D' and r2 (quotients by products of these
-//     margins) are only reproducible to 1e-16 / q -- below 2^-18 that is no longer safely inside 1e-9, and at q ~ 1e-16
+//     margins) are only reproducible to 1e-16 / q -- below 2^-16 that is no longer safely inside 1e-9, and at q ~ 1e-16
 //     the noise alone decides between nan, 0 and inf -- or any frequency is NaN;
 //   * eps came within kTieMargin of EPSILON in some iteration (gen_func.cpp:1054: nIter could differ by one);
 //   * one of its sites has expected genotypes that are constant up to rounding (negative rsx, see prep_sites_kernel):
 //     gsl_stats_correlation is then a 0/0-type quotient of its own accumulation noise (ngsLD.cpp:365-367).
-constexpr double kReplayBelow = 0x1p-18;
+constexpr double kReplayBelow = 0x1p-16;  // (at 2^-18 a 39,000-case soak showed differences up to 1.1e-10 just above the threshold: a 9x margin to the 1e-9 bar; 2^-16 makes it ~36x)
 constexpr double kTieMargin = 1e-12;
 constexpr double kEpsilonTie = kEpsilon + kTieMargin;
 constexpr uint32_t kTieBit = 0x80000000u;  // rides on n_iter (<= 100) from the EM loop to write_pair
