@@ -41,6 +41,17 @@ constexpr bool kDrop0 = NGSLD_DROP0 != 0;
 #ifndef NGSLD_WN_ROWS
 #define NGSLD_WN_ROWS 1  // build-time A/B switch: several wavefronts per pair post their partial sums without v_readlane
 #endif
+#ifndef NGSLD_XCH_ASM
+#define NGSLD_XCH_ASM 1  // build-time A/B switch: two / four wavefronts per pair trade their partial sums through LDS accesses the
+                        // compiler does not see (lds_post / lds_gather), so that it cannot order them behind the slice copy in flight
+#endif
+// (same-box A/B, tools/ab_xch.sh: +0.8 % at n_ind 1000, +2.9 % at 2000; eight wavefronts per pair -- 12 reads, 48 registers
+// of partials in flight -- lost 4.5 % at n_ind 4000 and keep the compiler's accesses)
+#ifndef NGSLD_PARKED
+#define NGSLD_PARKED 1  // build-time A/B switch: no meeting of a pair's wavefronts for the Pearson moment (pair_ld_kernel, kParked)
+#endif
+template <int WAVES>
+constexpr bool kXchAsm = NGSLD_XCH_ASM != 0 && WAVES > 1 && WAVES <= 4;
 #ifndef NGSLD_MASK_DONE
 #define NGSLD_MASK_DONE 1  // build-time A/B switch: converged groups of a lockstep wavefront are masked off (see pair_ld_group_kernel)
 #endif
@@ -292,6 +303,60 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// LDS accesses of the exchange between the wavefronts of a pair, written as assembly.  The compiler orders every LDS access
+// it can see behind an asynchronous global->LDS copy in flight (s_waitcnt vmcnt(0) in front of the first ds instruction
+// after a global_load_lds: it cannot tell that the exchange buffer and the copy's target are different bytes) -- and the
+// slice of the NEXT pair is meant to fly through the whole EM loop of this one.  These it does not see; the waiting is done
+// here: lds_barrier() drains the stores, lds_gather ends with its own s_waitcnt.
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_addr(const void *p) {  // LDS byte address of a pointer into __shared__ memory
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+__device__ __forceinline__ void lds_post(uint32_t addr, double v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_post2(uint32_t addr, double a, double b) {
+  dbl2 v = {a, b};
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// N consecutive 16-byte pieces from addr (the same address in every lane: broadcast reads), all in flight together, ONE
+// wait -- written out by the compiler the reads of the partial sums came one LDS round trip after the other, each behind
+// the add that consumed the previous one.
+template <int N>
+__device__ __forceinline__ void lds_gather(uint32_t addr, dbl2 (&q)[N]) {
+  static_assert(N == 2 || N == 3 || N == 4 || N == 6 || N == 8 || N == 12, "lds_gather: unsupported count");
+  if constexpr (N == 2)
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(q[0]), "=&v"(q[1]) : "v"(addr) : "memory");
+  else if constexpr (N == 3)
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]) : "v"(addr) : "memory");
+  else if constexpr (N == 4)
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\t"
+                 "ds_read_b128 %3, %4 offset:48\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]) : "v"(addr) : "memory");
+  else if constexpr (N == 6)
+    asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %6 offset:32\n\t"
+                 "ds_read_b128 %3, %6 offset:48\n\tds_read_b128 %4, %6 offset:64\n\tds_read_b128 %5, %6 offset:80\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]) : "v"(addr) : "memory");
+  else if constexpr (N == 8)
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"
+                 "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
+                 "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])
+                 : "v"(addr) : "memory");
+  else
+    asm volatile("ds_read_b128 %0, %12\n\tds_read_b128 %1, %12 offset:16\n\tds_read_b128 %2, %12 offset:32\n\t"
+                 "ds_read_b128 %3, %12 offset:48\n\tds_read_b128 %4, %12 offset:64\n\tds_read_b128 %5, %12 offset:80\n\t"
+                 "ds_read_b128 %6, %12 offset:96\n\tds_read_b128 %7, %12 offset:112\n\tds_read_b128 %8, %12 offset:128\n\t"
+                 "ds_read_b128 %9, %12 offset:144\n\tds_read_b128 %10, %12 offset:160\n\tds_read_b128 %11, %12 offset:176\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7]),
+                   "=&v"(q[8]), "=&v"(q[9]), "=&v"(q[10]), "=&v"(q[11])
+                 : "v"(addr) : "memory");
+}
+
 // gen_func.cpp:862-868 miss_data with the reference's abs() macro semantics
 __device__ __forceinline__ bool miss_data(double g0, double g1, double g2) {
   double d01 = g0 - g1, d12 = g1 - g2;
@@ -427,11 +492,14 @@ __device__ __forceinline__ uint32_t count_valid(uint32_t vbits) {
 //              all full up to the last slot -- every one but the pair's last -- still takes the one-reciprocal path
 //   pads:      (CHECK_ALL, one wavefront per pair) per-slot 0 / 1 from stage_pair: individuals without data have P == 0 and
 //              pad 1, so the one-reciprocal step runs over all slots although any of them may be empty
+//   xpar:      (WAVES > 1) the caller's count of exchanges so far: its parity picks the half of xch an exchange uses.  Carried
+//              from pair to pair, consecutive exchanges alternate whatever the iteration counts were -- no barrier is needed
+//              between the last exchange of one pair and the first of the next (null: the parity of n_iter, which needs one)
 template <int SLOTS, int WAVES, bool CHECK_ALL, bool TREE_DYN = false>
 __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_t vbits, double inv_x, double m1,
                                             double m2, double &f0, double &f1, double &f2, double &f3,
                                             double (*xch)[WAVES][4], int sub, int lane, int *status,
-                                            const double *pads = nullptr) {
+                                            const double *pads = nullptr, uint32_t *xpar = nullptr) {
   f0 = (1 - m1) * (1 - m2); f1 = (1 - m1) * m2; f2 = m1 * (1 - m2); f3 = m1 * m2;  // gen_func.cpp:1034-1037
   if (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1) {  // error() in the reference (:1030); reported through status
     if (lane == 0 && sub == 0) atomicExch(status, (int)NGSLD_ERR_MAF_RANGE);
@@ -531,13 +599,31 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
       // them (no v_readlane, no copies back to VGPRs), and every wavefront adds the partials up in the same order -- the
       // new frequencies must be the same bit pattern in all of them, they decide together when to leave the loop
       const double w = wave_sum3_rows(t1, t2, t3);
-      const int par = (int)(n_iter & 1u);
+      const int par = (int)((xpar != nullptr ? (*xpar)++ : n_iter) & 1u);
       const int row = lane >> 4;
-      if ((lane & 15) == 0 && row < 3) xch[par][sub][row == 0 ? 1 : (row == 1 ? 3 : 2)] = w;
-      lds_barrier();
-      t1 = xch[par][0][1]; t2 = xch[par][0][2]; t3 = xch[par][0][3];
-      for (int v = 1; v < WAVES; ++v) {
-        t1 += xch[par][v][1]; t2 += xch[par][v][2]; t3 += xch[par][v][3];
+      if (kXchAsm<WAVES>) {
+        // layout of one parity's buffer (WAVES * 32 bytes, as below): [value k = 0..2][wavefront] -- a value's partials side
+        // by side, WAVES / 2 reads of 16 bytes each; added up in the order of the wavefronts, as before
+        const uint32_t base = lds_addr(&xch[par][0][0]);
+        if ((lane & 15) == 0 && row < 3)
+          lds_post(base + (uint32_t)((row == 0 ? 0 : (row == 1 ? 2 : 1)) * WAVES + sub) * 8u, w);
+        lds_barrier();
+        constexpr int kHalf = WAVES > 1 ? WAVES / 2 : 1;  // (one wavefront per pair: instantiated, never run)
+        dbl2 q[3 * kHalf];
+        lds_gather<3 * kHalf>(base, q);
+        t1 = q[0][0] + q[0][1]; t2 = q[kHalf][0] + q[kHalf][1]; t3 = q[2 * kHalf][0] + q[2 * kHalf][1];
+#pragma unroll
+        for (int v = 1; v < kHalf; ++v) {
+          t1 += q[v][0]; t2 += q[kHalf + v][0]; t3 += q[2 * kHalf + v][0];
+          t1 += q[v][1]; t2 += q[kHalf + v][1]; t3 += q[2 * kHalf + v][1];
+        }
+      } else {
+        if ((lane & 15) == 0 && row < 3) xch[par][sub][row == 0 ? 1 : (row == 1 ? 3 : 2)] = w;
+        lds_barrier();
+        t1 = xch[par][0][1]; t2 = xch[par][0][2]; t3 = xch[par][0][3];
+        for (int v = 1; v < WAVES; ++v) {
+          t1 += xch[par][v][1]; t2 += xch[par][v][2]; t3 += xch[par][v][3];
+        }
       }
     } else {
       if (kDrop)
@@ -545,7 +631,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
       else
         wave_sum4(t0, t1, t2, t3);
       if (WAVES > 1) {
-        const int par = (int)(n_iter & 1u);
+        const int par = (int)((xpar != nullptr ? (*xpar)++ : n_iter) & 1u);
         if (lane == 0) {
           if (!kDrop) xch[par][sub][0] = t0;
           xch[par][sub][1] = t1; xch[par][sub][2] = t2; xch[par][sub][3] = t3;
@@ -725,8 +811,14 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
   constexpr int kWavesPerWg = WAVES == 1 ? 4 : WAVES;
   constexpr int kSliceBytes = SLOTS * 64 * 3 * 8;
   constexpr int kXchBase = PFB ? kWavesPerWg * kSliceBytes : 16;
-  __shared__ __attribute__((aligned(16))) char smem[kXchBase + WAVES * 96 + (WAVES > 1 ? 64 * sizeof(PairResult) : 0)];
+  // kParked (several wavefronts per pair, every individual counts): the Pearson cross moment needs no meeting of the
+  // wavefronts before the EM loop -- each parks its partial sum per candidate, thread t adds them up when it writes the record
+  // -- and x is n_ind: one barrier, one LDS round trip and one f64 division less per pair
+  constexpr bool kParked = NGSLD_PARKED != 0 && kXchAsm<WAVES> && !MASKED;
+  __shared__ __attribute__((aligned(16))) char smem[kXchBase + WAVES * 96 + (WAVES > 1 ? 64 * sizeof(PairResult) : 0) +
+                                                    (kParked ? 64 * WAVES * sizeof(double) : 0)];
   PairResult *res = reinterpret_cast<PairResult *>(smem + kXchBase + WAVES * 96);  // WAVES > 1: one per candidate
+  double (*parked)[WAVES] = reinterpret_cast<double (*)[WAVES]>(smem + kXchBase + WAVES * 96 + 64 * sizeof(PairResult));
   double (*xch)[WAVES][4] = reinterpret_cast<double (*)[WAVES][4]>(smem + (PFB ? kWavesPerWg * kSliceBytes : 16));
   double (*xch0)[2] = reinterpret_cast<double (*)[2]>(smem + (PFB ? kWavesPerWg * kSliceBytes : 16) + WAVES * 64);
 
@@ -777,6 +869,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
 
   uint32_t c = next_kept(0);
   if (PFB && c < it.count) dma_slice(it.s2_begin + c);
+  uint32_t xpar = 0;  // exchanges of this workgroup so far (see em_pair)
   while (c < it.count) {
     const uint32_t s2 = it.s2_begin + c;
     const uint32_t cn = next_kept(c + 1);
@@ -803,7 +896,26 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
     }
     uint32_t x = count_valid<SLOTS>(vbits);
     sxy = wave_sum1(sxy);
-    if (WAVES > 1) {
+    if (kParked) {
+      if (lane == 0) lds_post(lds_addr(&parked[c][sub]), sxy);
+      x = A.n_ind;  // (the ballots of the wavefronts add up to it: padding lanes are the only ones left out)
+    } else if (kXchAsm<WAVES>) {
+      // (no barrier behind the reads: xch0 is written again a pair later, and every EM loop has a barrier of its own that
+      // no wavefront passes before all have read these)
+      const uint32_t base = lds_addr(&xch0[0][0]);
+      if (lane == 0) lds_post2(base + (uint32_t)sub * 16u, sxy, (double)x);
+      lds_barrier();
+      dbl2 q[WAVES > 1 ? WAVES : 2];
+      lds_gather<(WAVES > 1 ? WAVES : 2)>(base, q);
+      double sx = 0.0, xs = 0.0;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        sx += q[w][0];
+        xs += q[w][1];
+      }
+      sxy = sx;
+      x = (uint32_t)xs;
+    } else if (WAVES > 1) {
       if (lane == 0) {
         xch0[sub][0] = sxy;
         xch0[sub][1] = (double)x;
@@ -819,8 +931,9 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
       lds_barrier();
     }
     double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair<SLOTS, WAVES, kCheckAll, (WAVES > 1 && !MASKED)>(P, vbits, 1.0 / (double)x, rl.m1, rl.m2, f0, f1, f2, f3, xch, sub,
-                                                             lane, A.status, MASKED ? pads : nullptr);
+    const uint32_t n_iter = em_pair<SLOTS, WAVES, kCheckAll, (WAVES > 1 && !MASKED)>(
+        P, vbits, kParked ? A.inv_n : 1.0 / (double)x, rl.m1, rl.m2, f0, f1, f2, f3, xch, sub, lane, A.status,
+        MASKED ? pads : nullptr, WAVES > 1 ? &xpar : nullptr);
     unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
     if (WAVES == 1) {
       if (lane == 0)
@@ -836,11 +949,17 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
     c = cn;
   }
   if (WAVES > 1) {  // the whole workgroup shares the item: thread t derives and writes the record of candidate t
+    if (kParked) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the parked partial sums are stores the compiler does not see
     __syncthreads();
     const uint32_t t = threadIdx.x;
     if (t < it.count && ((it.mask >> t) & 1ull)) {
       const PairResult r = res[t];
-      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << t) - 1ull)), r.f[0], r.f[1], r.f[2], r.f[3], r.sxy, rsx1,
+      double sxy = r.sxy;
+      if (kParked) {
+        sxy = 0.0;  // (the order the exchange added them in)
+        for (int w = 0; w < WAVES; ++w) sxy += parked[t][w];
+      }
+      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << t) - 1ull)), r.f[0], r.f[1], r.f[2], r.f[3], sxy, rsx1,
                  r.rsx2, r.x, r.n_iter);
     }
   }
