@@ -227,40 +227,6 @@ __device__ __forceinline__ void wave_sum3_mfma(double &t1, double &t2, double &t
   t3 = read_lane(p, 2);
 }
 
-// Three values: same scheme, the third one folded with itself (rows 1 and 3 both end up holding its sum).
-__device__ __forceinline__ void wave_sum3(double &t1, double &t2, double &t3) {
-  if (NGSLD_MFMA_REDUCE) {
-    wave_sum3_mfma(t1, t2, t3);
-    return;
-  }
-  double z12 = fold32(t1, t2);
-  double z33 = fold32(t3, t3);
-  double w = fold16(z12, z33);  // row0: t1, row1: t3, row2: t2, row3: t3
-  w += dpp_mov<0x128>(w);
-  w += dpp_mov<0x124>(w);
-  w += dpp_mov<0x4E>(w);
-  w += dpp_mov<0xB1>(w);
-  t1 = read_lane(w, 0);
-  t3 = read_lane(w, 16);
-  t2 = read_lane(w, 32);
-}
-
-// The same reduction stopped before the v_readlane: every lane of row 0 holds the sum of t1, row 1 (and 3) that of t3,
-// row 2 that of t2.  For the kernels where several wavefronts share a pair: lanes 0 / 16 / 32 post their row's total
-// straight to the exchange buffer.
-__device__ __forceinline__ double wave_sum3_rows(double t1, double t2, double t3) {
-  double z12 = fold32(t1, t2);
-  double z33 = fold32(t3, t3);
-  double w = fold16(z12, z33);
-  w += dpp_mov<0x128>(w);
-  w += dpp_mov<0x124>(w);
-  w += dpp_mov<0x4E>(w);
-  w += dpp_mov<0xB1>(w);
-  return w;
-}
-
-// One value, no permlane swaps (each costs ~14 cycles of issue): four DPP levels inside the rows, then the GFX9 row
-// broadcasts -- lane 15 of rows 0 / 2 into rows 1 / 3, lane 31 into rows 2 and 3 -- leave the total in row 3.
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov_rows(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -268,6 +234,38 @@ __device__ __forceinline__ double dpp_mov_rows(double v) {
   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+
+// Three values: same scheme, and the third goes into the second fold UNFOLDED -- its rows 0+1 end up in row 1, its rows
+// 2+3 in row 3, and once the rows are summed one GFX9 row broadcast (lane 31 into row 3: two DPP moves and an add) joins
+// the halves.  That replaces folding the third value with itself first (two more v_permlane32_swap at ~14 cycles of issue
+// each, NGSLD_FOLD_T3 = 1: the earlier form).  Every lane of row 0 then holds the sum of t1, of row 2 that of t2, of row
+// 3 that of t3.
+#ifndef NGSLD_FOLD_T3
+#define NGSLD_FOLD_T3 0  // build-time A/B switch
+#endif
+__device__ __forceinline__ double wave_sum3_rows(double t1, double t2, double t3) {
+  double z12 = fold32(t1, t2);
+  double w = fold16(z12, NGSLD_FOLD_T3 ? fold32(t3, t3) : t3);  // row0: t1, row2: t2, rows 1 / 3: t3 (whole, or by halves)
+  w += dpp_mov<0x128>(w);
+  w += dpp_mov<0x124>(w);
+  w += dpp_mov<0x4E>(w);
+  w += dpp_mov<0xB1>(w);
+  if (!NGSLD_FOLD_T3) w += dpp_mov_rows<0x143, 0x8>(w);  // row_bcast:31 into row 3
+  return w;
+}
+__device__ __forceinline__ void wave_sum3(double &t1, double &t2, double &t3) {
+  if (NGSLD_MFMA_REDUCE) {
+    wave_sum3_mfma(t1, t2, t3);
+    return;
+  }
+  const double w = wave_sum3_rows(t1, t2, t3);
+  t1 = read_lane(w, 0);
+  t2 = read_lane(w, 32);
+  t3 = read_lane(w, 48);
+}
+
+// One value, no permlane swaps (each costs ~14 cycles of issue): four DPP levels inside the rows, then the GFX9 row
+// broadcasts -- lane 15 of rows 0 / 2 into rows 1 / 3, lane 31 into rows 2 and 3 -- leave the total in row 3.
 __device__ __forceinline__ double wave_sum1_bcast(double v) {
   v += dpp_mov<0xB1>(v);   // quad_perm:[1,0,3,2]
   v += dpp_mov<0x4E>(v);   // quad_perm:[2,3,0,1]
@@ -605,8 +603,8 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
         // layout of one parity's buffer (WAVES * 32 bytes, as below): [value k = 0..2][wavefront] -- a value's partials side
         // by side, WAVES / 2 reads of 16 bytes each; added up in the order of the wavefronts, as before
         const uint32_t base = lds_addr(&xch[par][0][0]);
-        if ((lane & 15) == 0 && row < 3)
-          lds_post(base + (uint32_t)((row == 0 ? 0 : (row == 1 ? 2 : 1)) * WAVES + sub) * 8u, w);
+        if ((lane & 15) == 0 && row != 1)  // rows 0 / 2 / 3 hold t1 / t2 / t3 (wave_sum3_rows)
+          lds_post(base + (uint32_t)((row == 0 ? 0 : row - 1) * WAVES + sub) * 8u, w);
         lds_barrier();
         constexpr int kHalf = WAVES > 1 ? WAVES / 2 : 1;  // (one wavefront per pair: instantiated, never run)
         dbl2 q[3 * kHalf];
@@ -618,7 +616,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
           t1 += q[v][1]; t2 += q[kHalf + v][1]; t3 += q[2 * kHalf + v][1];
         }
       } else {
-        if ((lane & 15) == 0 && row < 3) xch[par][sub][row == 0 ? 1 : (row == 1 ? 3 : 2)] = w;
+        if ((lane & 15) == 0 && row != 1) xch[par][sub][row == 0 ? 1 : row] = w;
         lds_barrier();
         t1 = xch[par][0][1]; t2 = xch[par][0][2]; t3 = xch[par][0][3];
         for (int v = 1; v < WAVES; ++v) {
