@@ -258,10 +258,28 @@ __device__ __forceinline__ void wave_sum3(double &t1, double &t2, double &t3) {
     wave_sum3_mfma(t1, t2, t3);
     return;
   }
-  const double w = wave_sum3_rows(t1, t2, t3);
+  if (NGSLD_FOLD_T3) {
+    const double w = wave_sum3_rows(t1, t2, t3);
+    t1 = read_lane(w, 0);
+    t2 = read_lane(w, 32);
+    t3 = read_lane(w, 48);
+    return;
+  }
+  // as wave_sum3_rows, but only lane 48 of the last step is ever read: the broadcast needs no defined value (no zeroing
+  // moves) in the rows it does not write
+  double z12 = fold32(t1, t2);
+  double w = fold16(z12, t3);
+  w += dpp_mov<0x128>(w);
+  w += dpp_mov<0x124>(w);
+  w += dpp_mov<0x4E>(w);
+  w += dpp_mov<0xB1>(w);
   t1 = read_lane(w, 0);
   t2 = read_lane(w, 32);
-  t3 = read_lane(w, 48);
+  int ulo, uhi;
+  asm("; undefined" : "=v"(ulo), "=v"(uhi));
+  const int lo = __builtin_amdgcn_update_dpp(ulo, __double2loint(w), 0x143, 0x8, 0xf, false);  // row_bcast:31 into row 3
+  const int hi = __builtin_amdgcn_update_dpp(uhi, __double2hiint(w), 0x143, 0x8, 0xf, false);
+  t3 = read_lane(w + __hiloint2double(hi, lo), 48);
 }
 
 // One value, no permlane swaps (each costs ~14 cycles of issue): four DPP levels inside the rows, then the GFX9 row
