@@ -887,9 +887,14 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
     // runs: a row's items cut into ceil(items / kRunItems) runs of near-equal length (one workgroup each)
     std::vector<Run> runs;
     c->h_run_off.assign(n + 1, 0);
+    uint64_t run_len = kRunItems;
+    if (const char *e = getenv("NGSLD_RUN_LEN")) {  // tuning / A-B knob: items per run, 1 .. kRunItems
+      const long v = atol(e);
+      if (v >= 1 && (uint64_t)v <= kRunItems) run_len = (uint64_t)v;
+    }
     for (uint64_t s1 = 0; s1 < n; ++s1) {
       const uint64_t i0 = c->h_item_off[s1], m = c->h_item_off[s1 + 1] - i0;
-      const uint64_t parts = (m + kRunItems - 1) / kRunItems;
+      const uint64_t parts = (m + run_len - 1) / run_len;
       for (uint64_t q = 0; q < parts; ++q) {
         const uint64_t b = i0 + m * q / parts, e = i0 + m * (q + 1) / parts;
         runs.push_back(Run{(uint32_t)b, (uint32_t)(e - b)});
