@@ -21,6 +21,7 @@
 #include <string>
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "../../include/ngsld.h"
@@ -462,8 +463,48 @@ int main(int argc, char **argv) {
   ngsld_host_set_threads((int)pars.n_threads);
   timing_report.mark("arguments, output header");
 
+  // A binary matrix that will plainly run resident (below the 4 GiB from which a windowed run is pipelined in slabs, and
+  // well inside any --max_gpu_mem) is read -- and the positions after it -- by a thread of its own while the device context
+  // comes up: the two take 0.15-0.35 s each and used to run one after the other.  Errors wait for the join and come out
+  // where and as they always did.
+  struct FreeDeleter {
+    void operator()(double *q) const { free(q); }
+  };
+  struct EarlyRead {
+    std::thread th;
+    bool started = false, pos_done = false;
+    int geno_rc = NGSLD_OK, pos_rc = NGSLD_OK;
+    char geno_err[512] = "", pos_err[512] = "";
+    std::unique_ptr<double, FreeDeleter> raw;
+    ngsld_pos *pos = nullptr;
+  } early;
+  const uint64_t geno_bytes = (uint64_t)pars.n_sites * pars.n_ind * 3 * sizeof(double);
+  if (pars.in_bin && geno_bytes < (4ull << 30) && getenv("NGSLD_SLAB_SITES") == nullptr &&
+      (pars.max_gpu_mem <= 0 || pars.max_gpu_mem * 1e9 > 3.0 * (double)geno_bytes) &&
+      !(getenv("NGSLD_EARLY_READ") && strcmp(getenv("NGSLD_EARLY_READ"), "0") == 0)) {
+    early.raw.reset((double *)malloc((size_t)geno_bytes));
+    if (early.raw) {
+      early.started = true;
+      early.th = std::thread([&early, &pars]() {
+        early.geno_rc = ngsld_host_read_geno_bin(pars.in_geno, pars.n_ind, pars.n_sites, early.raw.get(), early.geno_err,
+                                                 sizeof(early.geno_err));
+        if (early.geno_rc == NGSLD_OK && pars.in_pos) {
+          early.pos_rc = ngsld_host_read_pos(pars.in_pos, pars.in_pos_header ? 1 : 0, pars.n_sites, &early.pos,
+                                             early.pos_err, sizeof(early.pos_err));
+          early.pos_done = true;
+        }
+      });
+    }
+  }
+  auto join_early = [&early]() {
+    if (early.th.joinable()) early.th.join();
+  };
+
   // ---- several devices: a windowed run on binary input lets every part read its own slab from the file ----
   if (pars.devices.size() > 1 && pars.in_bin && (pars.max_kb_dist > 0 || pars.max_snp_dist > 0)) {
+    join_early();
+    early.raw.reset();  // (every part reads its own slab)
+    ngsld_host_free_pos(early.pos);
     if (pars.verbose >= 1) fprintf(stderr, "> Reading data from file...\n");
     run_multi(pars, nullptr, 0, pars.in_logscale ? 1 : 0);
     return 0;
@@ -471,7 +512,10 @@ int main(int argc, char **argv) {
 
   // ---- device ----
   ngsld_ctx *ctx = nullptr;
-  if (ngsld_create(pars.device, &ctx) != NGSLD_OK) error("ngsld_create", ngsld_last_error(nullptr));
+  if (ngsld_create(pars.device, &ctx) != NGSLD_OK) {
+    join_early();
+    error("ngsld_create", ngsld_last_error(nullptr));
+  }
 
   timing_report.mark("ngsld_create");
   char err[512];
@@ -502,6 +546,11 @@ int main(int argc, char **argv) {
     slab_sites = std::min<uint64_t>(ngsld_slab_sites_for_budget(pars.n_ind, budget), (pars.n_sites + 5) / 6);
   }
   if (slab_sites > 0) {
+    join_early();  // (an early read is only started for matrices far below these thresholds: normally nothing to wait for)
+    early.raw.reset();
+    ngsld_host_free_pos(early.pos);
+    early.pos = nullptr;
+    early.started = early.pos_done = false;
     ngsld_destroy(ctx);
     ctx = nullptr;
     if (run_streamed(pars, slab_sites, /*may_fall_back=*/fits)) return 0;
@@ -510,11 +559,13 @@ int main(int argc, char **argv) {
 
   // ---- read input data (ngsLD.cpp:85-114; the arithmetic runs on the device) ----
   if (pars.verbose >= 1) fprintf(stderr, "> Reading data from file...\n");
-  struct FreeDeleter {
-    void operator()(double *q) const { free(q); }
-  };
+  join_early();
   // (malloc: 1.2 GB of zero-filling a std::vector before overwriting it was a third of the read time)
-  std::unique_ptr<double, FreeDeleter> raw((double *)malloc((size_t)pars.n_sites * pars.n_ind * 3 * sizeof(double)));
+  std::unique_ptr<double, FreeDeleter> raw;
+  if (early.started)
+    raw = std::move(early.raw);
+  else
+    raw.reset((double *)malloc((size_t)pars.n_sites * pars.n_ind * 3 * sizeof(double)));
   if (!raw) error(__FUNCTION__, "cannot allocate the genotype matrix");
   ngsld_geno_opts go;
   memset(&go, 0, sizeof(go));
@@ -523,7 +574,9 @@ int main(int argc, char **argv) {
   go.call_geno = pars.call_geno ? 1 : 0;
   go.N_thresh = pars.N_thresh;
   go.call_thresh = pars.call_thresh;
-  if (pars.in_bin) {
+  if (early.started) {
+    if (early.geno_rc != NGSLD_OK) error("read_geno", early.geno_err);
+  } else if (pars.in_bin) {
     if (ngsld_host_read_geno_bin(pars.in_geno, pars.n_ind, pars.n_sites, raw.get(), err, sizeof(err)) != NGSLD_OK)
       error("read_geno", err);
   } else {
@@ -569,7 +622,10 @@ int main(int argc, char **argv) {
   if (pars.verbose >= 1) fprintf(stderr, "==> Getting sites coordinates\n");
   ngsld_pos *pos = nullptr;
   if (pars.in_pos) {
-    if (ngsld_host_read_pos(pars.in_pos, pars.in_pos_header ? 1 : 0, pars.n_sites, &pos, err, sizeof(err)) != NGSLD_OK)
+    if (early.pos_done) {
+      if (early.pos_rc != NGSLD_OK) error("read_dist", early.pos_err);
+      pos = early.pos;
+    } else if (ngsld_host_read_pos(pars.in_pos, pars.in_pos_header ? 1 : 0, pars.n_sites, &pos, err, sizeof(err)) != NGSLD_OK)
       error("read_dist", err);
     if (pars.verbose >= 6)
       for (uint64_t s = 0; s < (pars.n_sites < 10 ? pars.n_sites : 10); s++)

@@ -143,6 +143,7 @@ struct ngsld_ctx {
   std::vector<uint8_t> h_keep;
   std::vector<Item> h_items;  // host copy for the sink (which pairs each record belongs to)
   std::vector<uint64_t> h_run_off;  // run kernel: runs before each row
+  uint64_t run_len = 0;             // items per run the list was cut with (0: no list)
   DevBuf<Run> d_runs;
   DevBuf<uint64_t> d_row_off, d_item_off, d_row_seed, d_row_count;
   DevBuf<uint32_t> d_row_end;
@@ -824,6 +825,37 @@ int ngsld_set_pos_dist(ngsld_ctx *c, const double *pos_dist) try {
   return NGSLD_OK;
 } NGSLD_CATCH(c)
 
+// Runs: a row's items cut into ceil(items / run_len) runs of near-equal length, one workgroup each.  run_len = kRunItems
+// (16 items = 1,024 candidates: a whole 100 kb row) is what the pair kernel likes best in one big launch; a run that goes
+// out in SMALL batches -- text batches are 2^21 pairs, i.e. only four rounds of such workgroups on 512 slots, each batch
+// ending in a ragged tail -- is cut finer (ngsld_run).  NGSLD_RUN_LEN overrides (tuning / A-B).
+static int build_runs(ngsld_ctx *c, uint64_t run_len) {
+  if (const char *e = getenv("NGSLD_RUN_LEN")) {
+    const long v = atol(e);
+    if (v >= 1) run_len = (uint64_t)v;
+  }
+  run_len = std::max<uint64_t>(1, std::min<uint64_t>(run_len, kRunItems));
+  if (c->run_len == run_len) return NGSLD_OK;
+  const uint64_t n = c->n_sites;
+  std::vector<Run> runs;
+  c->h_run_off.assign(n + 1, 0);
+  for (uint64_t s1 = 0; s1 < n; ++s1) {
+    const uint64_t i0 = c->h_item_off[s1], m = c->h_item_off[s1 + 1] - i0;
+    const uint64_t parts = (m + run_len - 1) / run_len;
+    for (uint64_t q = 0; q < parts; ++q) {
+      const uint64_t b = i0 + m * q / parts, e = i0 + m * (q + 1) / parts;
+      runs.push_back(Run{(uint32_t)b, (uint32_t)(e - b)});
+    }
+    c->h_run_off[s1 + 1] = runs.size();
+  }
+  if (c->run_len != 0) HIP_TRY(c, hipDeviceSynchronize());  // (a launch, on whatever stream, still reading the old list)
+  HIP_TRY(c, c->d_runs.resize(runs.empty() ? 1 : runs.size()));
+  if (!runs.empty())
+    HIP_TRY(c, hipMemcpy(c->d_runs.p, runs.data(), runs.size() * sizeof(Run), hipMemcpyHostToDevice));
+  c->run_len = run_len;
+  return NGSLD_OK;
+}
+
 int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
   if (c == nullptr || p == nullptr) return NGSLD_ERR_INVALID;
   if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "no genotype data set");
@@ -884,27 +916,10 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
   }
   c->n_items = c->h_item_off[n];
   if (uses_runs(c->cfg.kernel)) {
-    // runs: a row's items cut into ceil(items / kRunItems) runs of near-equal length (one workgroup each)
-    std::vector<Run> runs;
-    c->h_run_off.assign(n + 1, 0);
-    uint64_t run_len = kRunItems;
-    if (const char *e = getenv("NGSLD_RUN_LEN")) {  // tuning / A-B knob: items per run, 1 .. kRunItems
-      const long v = atol(e);
-      if (v >= 1 && (uint64_t)v <= kRunItems) run_len = (uint64_t)v;
-    }
-    for (uint64_t s1 = 0; s1 < n; ++s1) {
-      const uint64_t i0 = c->h_item_off[s1], m = c->h_item_off[s1 + 1] - i0;
-      const uint64_t parts = (m + run_len - 1) / run_len;
-      for (uint64_t q = 0; q < parts; ++q) {
-        const uint64_t b = i0 + m * q / parts, e = i0 + m * (q + 1) / parts;
-        runs.push_back(Run{(uint32_t)b, (uint32_t)(e - b)});
-      }
-      c->h_run_off[s1 + 1] = runs.size();
-    }
     if (c->n_items > 0xffffffffull) return fail(c, NGSLD_ERR_UNSUPPORTED, "more than 2^32 work items in one plan");
-    HIP_TRY(c, c->d_runs.resize(runs.empty() ? 1 : runs.size()));
-    if (!runs.empty())
-      HIP_TRY(c, hipMemcpy(c->d_runs.p, runs.data(), runs.size() * sizeof(Run), hipMemcpyHostToDevice));
+    c->run_len = 0;  // (new items: whatever list there was is stale)
+    const int rcr = build_runs(c, kRunItems);
+    if (rcr != NGSLD_OK) return rcr;
   }
   HIP_TRY(c, c->d_row_end.resize(n));
   HIP_TRY(c, c->d_keep.resize(n));
@@ -1043,6 +1058,10 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
     const int rcf = reset_flags(c, c->d_flags_dev, c->timed_pairs, st);
     if (rcf != NGSLD_OK) return rcf;
   }
+  if (uses_runs(c->cfg.kernel)) {  // (one big launch: whole-row runs, whatever an earlier ngsld_run cut them to)
+    const int rcr = build_runs(c, kRunItems);
+    if (rcr != NGSLD_OK) return rcr;
+  }
   // one launch per <= 2^31-1 workgroups; rows are cut so that each launch's grid fits
   const uint64_t max_items = 0x7ffffff0ull;
   uint64_t r0 = s1_begin;
@@ -1129,6 +1148,14 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     while (r1 < s1_end && c->h_row_off[r1 + 1] - c->h_row_off[r0] <= batch_pairs) ++r1;
     batches.push_back({r0, r1, c->h_row_off[r1] - c->h_row_off[r0]});
     r0 = r1;
+  }
+  if (uses_runs(c->cfg.kernel)) {
+    // every batch should be thousands of workgroups (512 run at a time): the smaller the batches, the shorter the runs.
+    // configs[2] as text (48 batches of 2^21 pairs): 16 items per run 0.82 s for this loop, 8 0.72 s, 4 0.70 s
+    uint64_t want = kRunItems;
+    while (want > 2 && want * item_span(c->cfg, c->pairs_per_item) * 8192 > batch_pairs) want /= 2;
+    const int rcr = build_runs(c, want);
+    if (rcr != NGSLD_OK) return rcr;
   }
   uint64_t cap = 1;
   for (auto &b : batches) cap = std::max(cap, b.n);
