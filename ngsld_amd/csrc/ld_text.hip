@@ -26,6 +26,45 @@ struct Writer {
   char *p;
   __device__ __forceinline__ void put(char c) { *p++ = c; }
 };
+// A row goes out in aligned 8-byte words: the characters collect in a register and every eighth is one store (a thread's
+// row is ~150 bytes of its own, so a byte store is a whole memory request for one byte -- and the 64 lanes of a wave-wide
+// store hit 64 different cache lines either way).  The partial words at the two ends of the row, which it shares with the
+// neighbouring rows, go out byte by byte.
+// (Tried first: rows composed in LDS, the wavefront's contiguous piece copied out 16 bytes per lane.  Its 49 KB of LDS per
+// workgroup cannot sit beside the pair kernel's two 72 KB workgroups on a CU, so the write pass, which runs beside the next
+// batch's pair kernel, starved: 332 ms against 96 ms for the plain byte stores over configs[2].)
+#ifndef NGSLD_TEXT_WORDS
+#define NGSLD_TEXT_WORDS 1  // build-time A/B switch
+#endif
+struct WordWriter {
+  char *p;        // aligned address of the word being filled
+  uint64_t acc;
+  uint32_t cnt;   // bytes of the word filled so far (counting the leading bytes that are not this row's)
+  uint32_t head;  // leading bytes of the FIRST word that belong to the previous row
+  __device__ __forceinline__ explicit WordWriter(char *dst) {
+    const uint32_t mis = (uint32_t)((uintptr_t)dst & 7u);
+    p = dst - mis;
+    acc = 0;
+    cnt = head = mis;
+  }
+  __device__ __forceinline__ void put(char c) {
+    acc |= (uint64_t)(unsigned char)c << (8 * cnt);
+    if (++cnt == 8) {
+      if (head) {
+        for (uint32_t b = head; b < 8; ++b) p[b] = (char)(acc >> (8 * b));
+        head = 0;
+      } else {
+        *reinterpret_cast<uint64_t *>(p) = acc;
+      }
+      p += 8;
+      acc = 0;
+      cnt = 0;
+    }
+  }
+  __device__ __forceinline__ void finish() {
+    for (uint32_t b = head; b < cnt; ++b) p[b] = (char)(acc >> (8 * b));
+  }
+};
 
 template <class E>
 __device__ __forceinline__ void put_u64(E &e, uint64_t v) {
@@ -167,7 +206,11 @@ __global__ __launch_bounds__(256) void text_kernel(TextArgs A) {
   if (c >= it.count || !((it.mask >> c) & 1ull)) return;  // ngsLD.cpp:270-282: not a computed pair
   const uint64_t k = it.first_record - A.out_base + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull));
   const uint32_t s1 = it.s1, s2 = it.s2_begin + c;
-  if (WRITE) {
+  if (WRITE && NGSLD_TEXT_WORDS) {
+    WordWriter w(A.text + A.offs[k]);
+    (void)format_row(w, A, s1, s2, k);
+    w.finish();
+  } else if (WRITE) {
     Writer w{A.text + A.offs[k]};
     (void)format_row(w, A, s1, s2, k);
   } else {
