@@ -111,3 +111,66 @@ def test_ab_form_kernel_matches_the_oracle(n_ind, ignore_miss):
         check_records(std, ext, want)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("n_ind", [100, 500])
+def test_runs_recut_between_text_and_record_runs(n_ind):
+    """ngsld_run cuts the run list to its batch size (text batches: shorter runs), ngsld_run_device back to whole rows:
+    one context alternating between them keeps producing the same record bits, and its text is the text of a fresh context."""
+    import torch
+    n_sites = 1500
+    raw = synth.make_gl_numpy(n_sites, n_ind, 906 + n_ind, depth=6.0)
+    chrs, pos = synth.make_positions(n_sites, 906, max_gap=200)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    labels = [f"{c}:{p}" for c, p in zip(chrs, pos)]
+
+    def fresh():
+        e = capi.Engine(0)
+        e.set_geno_raw(raw)
+        e.set_pos_dist(pd)
+        n = e.plan(30, 0, 0.0, False, True)
+        return e, n
+
+    ref_eng, n = fresh()
+    try:
+        assert ref_eng.pair_kernel() in ("group", "run") and n > 50_000
+        ref_rec = ref_eng.run()
+    finally:
+        ref_eng.close()
+    txt_eng, _ = fresh()
+    try:
+        txt_eng.set_text_output(labels)
+        ref_text, _ = txt_eng.run_text()
+    finally:
+        txt_eng.close()
+
+    eng, _ = fresh()
+    try:
+        dev = torch.device("cuda", 0)
+        d_std = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
+        d_ext = torch.zeros(n * 40, dtype=torch.uint8, device=dev)
+
+        def device_records():
+            d_std.zero_(); d_ext.zero_()
+            torch.cuda.synchronize()
+            eng.run_device(0, n_sites, d_std.data_ptr(), d_ext.data_ptr())
+            torch.cuda.synchronize()
+            return d_std.cpu().numpy().tobytes(), d_ext.cpu().numpy().tobytes()
+
+        # (ngsld_run also replays the pairs whose PRINTED digits rounding could change, ngsld_run_device only the
+        # ill-conditioned ones: the two record sets may differ in last bits there, so each is compared with its own kind)
+        want = device_records()                                # whole-row runs
+        dev_std = np.frombuffer(want[0], dtype=ref_rec[2].dtype)
+        assert np.allclose(dev_std["r2"], ref_rec[2]["r2"], rtol=0, atol=1e-12, equal_nan=True)
+        eng.set_tuning(batch_pairs=20_000)                     # small batches: the run list is cut finer
+        eng.set_text_output(labels)
+        text, _ = eng.run_text()
+        assert text == ref_text
+        assert device_records() == want                       # ... and back to whole rows
+        eng.set_text_output(None, enable=False)
+        got = eng.run()                                        # record batches of 20,000 pairs
+        for a, b in zip(got, ref_rec):
+            assert a.tobytes() == b.tobytes()
+        assert device_records() == want
+    finally:
+        eng.close()
