@@ -474,6 +474,10 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
   a.hard_u = c->d_hard_u.p;
   a.mask_words = c->mask_words;
   a.items_all = c->d_items.p;
+  a.item_off = c->d_item_off.p;
+  a.h_item_off = c->h_item_off.data();
+  a.row0 = (uint32_t)r0;
+  a.row1 = (uint32_t)r1;
   a.sc4 = c->d_sc4.p;
   a.out_base = c->h_row_off[r0];
   a.out_std = d_std;

@@ -119,6 +119,12 @@ struct PairArgs {
   // buffers (null: no flagging)
   uint32_t *flags;
   uint32_t flag_text;  // also flag the pairs whose printed digits (six decimals) rounding noise could change
+  // tiled workgroup order of the multi-wavefront kernel (launch_pair_kernel; tile_nk == 0: workgroup i takes item i):
+  // rows [row0, row1) of the plan, tiles of tile_rows rows x 8 items, tile_nk tiles per row block; workgroup ids without an
+  // item (row beyond row1, item index beyond the row's count) leave at once
+  const uint64_t *item_off;    // device: [n_sites + 1] first item of each row (index into items_all)
+  const uint64_t *h_item_off;  // the same on the host (for the launcher; never dereferenced on the device)
+  uint32_t row0, row1, tile_rows, tile_nk;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -840,11 +846,29 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint64_t item_id = WAVES == 1 ? (uint64_t)blockIdx.x * 4 + (uint64_t)wave : (uint64_t)blockIdx.x;
-  if (item_id >= A.n_items) return;
+  const Item *item_ptr;
+  if (WAVES > 1 && A.tile_nk != 0) {
+    // Tiled order.  Workgroup ids go round the eight XCDs, so with tiles of tile_rows rows x 8 items, laid out row by row,
+    // XCD x works on item column x of every row of the tile: the same ~64 + tile_rows candidate sites for tile_rows rows,
+    // out of its own L2 -- in plain item order the workgroups in flight together are one row's whole candidate range, no
+    // site is used twice while it is anywhere on the chip, and an all-pairs run streams the matrix from HBM once per row
+    // (50,000 x 1,000: 2.1 TB/s, paid for in clock: the device is at its power limit).
+    const uint32_t per = A.tile_rows * 8u;
+    const uint32_t t = blockIdx.x / per, w = blockIdx.x % per;
+    const uint32_t row = A.row0 + (t / A.tile_nk) * A.tile_rows + (w >> 3);
+    const uint32_t k = (t % A.tile_nk) * 8u + (w & 7u);
+    if (row >= A.row1) return;
+    const uint64_t lo = A.item_off[row], hi = A.item_off[row + 1];
+    if ((uint64_t)k >= hi - lo) return;
+    item_ptr = A.items_all + lo + k;
+  } else {
+    const uint64_t item_id = WAVES == 1 ? (uint64_t)blockIdx.x * 4 + (uint64_t)wave : (uint64_t)blockIdx.x;
+    if (item_id >= A.n_items) return;
+    item_ptr = A.items + item_id;
+  }
   const int sub = WAVES == 1 ? 0 : wave;
 
-  const Item it = A.items[item_id];
+  const Item it = *item_ptr;
   const uint32_t s1 = it.s1;
   const double m1 = A.maf[s1];
   const double mean1 = A.mean_e[s1];

@@ -1,6 +1,9 @@
 // ld_pair_w1.hip -- instantiations of the one-wavefront-per-pair kernel (n_ind <= 512) and the launcher.
 #include <cstdlib>
 
+#include <algorithm>
+#include <cstring>
+
 #include "ld_device.h"
 
 namespace ngsld {
@@ -112,6 +115,46 @@ hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs
   if (const char *e = std::getenv("NGSLD_MAX_BLOCKS")) {
     const uint64_t u = std::strtoull(e, nullptr, 10);
     if (u >= 1 && u < max_blocks) max_blocks = u;
+  }
+  // Multi-wavefront kernel over long rows: tiled workgroup order (see pair_ld_kernel), one launch per group of up to 512
+  // rows so that the rows of a launch have nearly the same number of items (ids beyond a row's count are empty workgroups).
+  // NGSLD_TILES=0 keeps the plain item order (A/B); rows of fewer than 32 items (windowed runs: neighbouring rows share
+  // their candidates anyway) always do.
+  if (cfg.kernel == kMulti && cfg.waves > 1 && a.h_item_off != nullptr && a.item_off != nullptr && a.row1 > a.row0 &&
+      !(std::getenv("NGSLD_TILES") && std::strcmp(std::getenv("NGSLD_TILES"), "0") == 0)) {
+    uint64_t longest = 0;
+    for (uint32_t r = a.row0; r < a.row1; ++r) longest = std::max<uint64_t>(longest, a.h_item_off[r + 1] - a.h_item_off[r]);
+    if (longest >= 32) {
+      uint32_t kTileRows = 64, kGroupRows = 512;
+      if (const char *e = std::getenv("NGSLD_TILE_ROWS")) {  // tuning knob: rows per tile (group = 8 tiles)
+        const unsigned long v = std::strtoul(e, nullptr, 10);
+        if (v >= 8 && v <= 1024) kTileRows = (uint32_t)v;
+        kGroupRows = std::max<uint32_t>(512, 4 * kTileRows);
+      }
+      for (uint32_t g0 = a.row0; g0 < a.row1; g0 += kGroupRows) {
+        const uint32_t g1 = std::min<uint32_t>(a.row1, g0 + kGroupRows);
+        uint64_t most = 0;
+        for (uint32_t r = g0; r < g1; ++r) most = std::max<uint64_t>(most, a.h_item_off[r + 1] - a.h_item_off[r]);
+        if (most == 0) continue;
+        PairArgs b = a;
+        b.row0 = g0;
+        b.row1 = g1;
+        b.tile_rows = kTileRows;
+        b.tile_nk = (uint32_t)((most + 7) / 8);
+        const uint64_t row_blocks = (g1 - g0 + kTileRows - 1) / kTileRows;
+        const uint64_t blocks = row_blocks * b.tile_nk * kTileRows * 8ull;
+        if (blocks > max_blocks) {  // (a row of more than 2^22 / 512 * 8 items: not with 64 candidates per item and 2^32 sites)
+          b.tile_nk = 0;
+          b.items = a.items_all + a.h_item_off[g0];
+          b.n_items = a.h_item_off[g1] - a.h_item_off[g0];
+        } else {
+          b.n_items = blocks;  // the grid (launch_pair_wn launches n_items workgroups)
+        }
+        const hipError_t e = launch_pair_chunk(cfg, masked, b, stream);
+        if (e != hipSuccess) return e;
+      }
+      return hipSuccess;
+    }
   }
   const bool by_runs = uses_runs(cfg.kernel);
   const uint64_t total = by_runs ? a.n_runs : a.n_items;

@@ -54,3 +54,52 @@ def test_more_than_2_to_32_threads_in_one_plan():
         assert bool(torch.all(torch.isfinite(d_std.view(-1, 4)[:, 1])))           # D of every pair
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("n_ind,n_sites", [(520, 2300), (1100, 2200), (2100, 2150)])
+def test_tiled_workgroup_order_of_the_multi_wavefront_kernel(n_ind, n_sites):
+    """Rows of 32 and more items (2,048+ candidates) of the multi-wavefront kernel are worked through in tiles of 64 rows x 8
+    items, ids without an item are empty workgroups (launch_pair_kernel): same records, bit for bit, as the plain item order
+    (NGSLD_TILES=0), through record batches and through ngsld_run_device; the first rows against the oracle."""
+    import os
+    import torch
+    from oracle import orc
+    from util import check_records
+    raw = synth.make_gl_numpy(n_sites, n_ind, 77 + n_ind, depth=4.0)
+    eng = capi.Engine(0)
+    try:
+        eng.set_geno_raw(raw)
+        assert eng.pair_kernel() == "multi"
+        eng.set_pos_dist(None)
+        n = eng.plan(0, 0, 0.0, False, True)
+        assert n == n_sites * (n_sites - 1) // 2
+        eng.set_tuning(batch_pairs=300_000)                    # batches of ~140 rows: two whole row blocks and a partial one
+        tiled = eng.run()
+        dev = torch.device("cuda", 0)
+        d_std = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
+        d_ext = torch.zeros(n * 40, dtype=torch.uint8, device=dev)
+
+        def device_records():
+            d_std.zero_(); d_ext.zero_()
+            torch.cuda.synchronize()
+            eng.run_device(0, n_sites, d_std.data_ptr(), d_ext.data_ptr())
+            torch.cuda.synchronize()
+            return d_std.cpu().numpy().tobytes(), d_ext.cpu().numpy().tobytes()
+
+        tiled_dev = device_records()
+        os.environ["NGSLD_TILES"] = "0"
+        try:
+            plain = eng.run()
+            plain_dev = device_records()
+        finally:
+            del os.environ["NGSLD_TILES"]
+        for a, b in zip(tiled, plain):
+            assert a.tobytes() == b.tobytes()
+        assert tiled_dev == plain_dev
+        rows = 12
+        want = orc.Oracle(raw, n_threads=8).run(0, rows)
+        m = tiled[0] < rows
+        assert m.sum() == len(want)
+        check_records(tiled[2][m], tiled[3][m], want)
+    finally:
+        eng.close()
