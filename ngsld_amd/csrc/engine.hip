@@ -478,6 +478,7 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
   a.h_item_off = c->h_item_off.data();
   a.row0 = (uint32_t)r0;
   a.row1 = (uint32_t)r1;
+  a.planes_bytes = c->n_sites * 3ull * c->np * sizeof(double);
   a.sc4 = c->d_sc4.p;
   a.out_base = c->h_row_off[r0];
   a.out_std = d_std;

@@ -125,6 +125,7 @@ struct PairArgs {
   const uint64_t *item_off;    // device: [n_sites + 1] first item of each row (index into items_all)
   const uint64_t *h_item_off;  // the same on the host (for the launcher; never dereferenced on the device)
   uint32_t row0, row1, tile_rows, tile_nk;
+  uint64_t planes_bytes;       // size of the whole planes array (launcher: is the matrix larger than the caches?)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -856,7 +857,10 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
     const uint32_t per = A.tile_rows * 8u;
     const uint32_t t = blockIdx.x / per, w = blockIdx.x % per;
     const uint32_t row = A.row0 + (t / A.tile_nk) * A.tile_rows + (w >> 3);
-    const uint32_t k = (t % A.tile_nk) * 8u + (w & 7u);
+    // (the column an XCD takes rotates from tile to tile: the last tile of a row block is only partly filled, and with a fixed
+    // assignment the XCDs of its first columns would carry all of it -- the dispatcher deals workgroup ids round robin, an
+    // XCD cannot take over another's share: measured -18 % on rows of 7-9 items)
+    const uint32_t k = (t % A.tile_nk) * 8u + ((w + t) & 7u);
     if (row >= A.row1) return;
     const uint64_t lo = A.item_off[row], hi = A.item_off[row + 1];
     if ((uint64_t)k >= hi - lo) return;

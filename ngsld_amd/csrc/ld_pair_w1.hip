@@ -118,13 +118,18 @@ hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs
   }
   // Multi-wavefront kernel over long rows: tiled workgroup order (see pair_ld_kernel), one launch per group of up to 512
   // rows so that the rows of a launch have nearly the same number of items (ids beyond a row's count are empty workgroups).
-  // NGSLD_TILES=0 keeps the plain item order (A/B); rows of fewer than 32 items (windowed runs: neighbouring rows share
-  // their candidates anyway) always do.
+  // NGSLD_TILES=0 keeps the plain item order (A/B).  So do rows of fewer than 32 items (windowed runs: neighbouring rows
+  // share their candidates anyway; tiled, configs[4]'s rows of 7-9 items lost 9 % to empty workgroups) and matrices that
+  // fit the 256 MB Infinity Cache (nothing to gain: 12,000 x 1,000 all pairs -0.4 %).
   if (cfg.kernel == kMulti && cfg.waves > 1 && a.h_item_off != nullptr && a.item_off != nullptr && a.row1 > a.row0 &&
       !(std::getenv("NGSLD_TILES") && std::strcmp(std::getenv("NGSLD_TILES"), "0") == 0)) {
     uint64_t longest = 0;
     for (uint32_t r = a.row0; r < a.row1; ++r) longest = std::max<uint64_t>(longest, a.h_item_off[r + 1] - a.h_item_off[r]);
-    if (longest >= 32) {
+    uint64_t min_items = 32;
+    if (const char *e = std::getenv("NGSLD_TILE_MIN")) min_items = std::strtoull(e, nullptr, 10);  // tuning knob
+    uint64_t min_bytes = 256ull << 20;
+    if (const char *e = std::getenv("NGSLD_TILE_MIN_MB")) min_bytes = std::strtoull(e, nullptr, 10) << 20;  // tests
+    if (longest >= min_items && a.planes_bytes >= min_bytes) {
       uint32_t kTileRows = 64, kGroupRows = 512;
       if (const char *e = std::getenv("NGSLD_TILE_ROWS")) {  // tuning knob: rows per tile (group = 8 tiles)
         const unsigned long v = std::strtoul(e, nullptr, 10);

@@ -66,6 +66,7 @@ def test_tiled_workgroup_order_of_the_multi_wavefront_kernel(n_ind, n_sites):
     from oracle import orc
     from util import check_records
     raw = synth.make_gl_numpy(n_sites, n_ind, 77 + n_ind, depth=4.0)
+    os.environ["NGSLD_TILE_MIN_MB"] = "0"                       # (tiles are for matrices beyond the 256 MB Infinity Cache)
     eng = capi.Engine(0)
     try:
         eng.set_geno_raw(raw)
@@ -102,4 +103,5 @@ def test_tiled_workgroup_order_of_the_multi_wavefront_kernel(n_ind, n_sites):
         assert m.sum() == len(want)
         check_records(tiled[2][m], tiled[3][m], want)
     finally:
+        del os.environ["NGSLD_TILE_MIN_MB"]
         eng.close()
