@@ -12,14 +12,30 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_every_pair_of_configs1_equals_the_oracle():
-    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "parity_config.py"), "c1"], capture_output=True, text=True,
+def _parity(*args):
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "parity_config.py"), *args], capture_output=True, text=True,
                        timeout=1500)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert line, r.stderr[-2000:]
     d = json.loads(line[-1])
     assert r.returncode == 0, d
+    return d
+
+
+def test_every_pair_of_configs1_equals_the_oracle():
+    d = _parity("c1")
     assert d["pairs"] == 12_497_500 and d["pairs_and_order_equal"]
     assert d["n_iter_equal"] and d["sample_size_equal"] and d["within_tolerances"]
     assert max(d[k] for k in d if k.startswith("max_abs_diff_")) <= 1e-9
     print("every pair of configs[1]:", {k: d[k] for k in d if k.startswith("max_abs_diff_") or k.startswith("pairs")})
+
+
+@pytest.mark.parametrize("which,rows,min_pairs", [("c3", "24", 1_100_000), ("c4", "1500", 700_000)])
+def test_first_rows_of_the_large_cohort_configurations_equal_the_oracle(which, rows, min_pairs):
+    """configs[3] at its real size (50,000 x 1,000 all pairs: two wavefronts per pair, tiled workgroup order -- the matrix is
+    1.2 GB) and configs[4]'s shape (60,000 x 2,000, 500 kb window: four wavefronts per pair): every pair of the first rows."""
+    d = _parity(which, rows)
+    assert d["pair_kernel"] == "multi" and d["pairs"] >= min_pairs and d["pairs_and_order_equal"]
+    assert d["n_iter_equal"] and d["sample_size_equal"] and d["within_tolerances"]
+    assert max(d[k] for k in d if k.startswith("max_abs_diff_")) <= 1e-9
+    print(f"every pair of the first {rows} rows of {which}:", {k: d[k] for k in d if k.startswith("max_abs_diff_") or k.startswith("pairs")})

@@ -2,6 +2,9 @@
 
     python tools/parity_config.py c1            # configs[1]: 5,000 x 100, all 12,497,500 pairs
     python tools/parity_config.py c2 [rows]     # configs[2]: 100,000 x 500, 100 kb window, rows [0, rows) (default 3000)
+    python tools/parity_config.py c3 [rows]     # configs[3]: 50,000 x 1,000 all pairs, rows [0, rows) (default 24: 1.2e6 pairs)
+    python tools/parity_config.py c4 [rows] [n_sites]  # configs[4]'s shape: n_sites (default 60,000) x 2,000, 500 kb window over
+                                                # ~1 kb gaps, rows [0, rows) (default 1500)
 
 Per pair: nIter and sample_size exact, hap / D / D' / r2 / r2_ExpG inside the tolerances written in tests/util.py.
 Prints one JSON line (max absolute differences included); exit status 1 on any difference outside the tolerances.
@@ -29,6 +32,15 @@ def main():
     if which == "c1":
         n_sites, n_ind, max_kb, seed, rows = 5000, 100, 0, 2, 5000
         pd = None
+    elif which == "c3":
+        n_sites, n_ind, max_kb, seed = 50_000, 1000, 0, 4
+        rows = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+        pd = None
+    elif which == "c4":
+        n_sites, n_ind, max_kb, seed = (int(sys.argv[3]) if len(sys.argv) > 3 else 60_000), 2000, 500, 5
+        rows = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
+        chrs, pos = synth.make_positions(n_sites, seed, max_gap=2000)
+        pd = shard.pos_dist_from_positions(chrs, pos)
     else:
         n_sites, n_ind, max_kb, seed = 100_000, 500, 100, 3
         rows = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
@@ -59,6 +71,7 @@ def main():
         if len(raw) == n_sites:
             eng.set_replay_source(raw)          # the exact-order replay reads the caller's values, as the CLI does
         eng.set_pos_dist(pd)
+        family = eng.pair_kernel()
         eng.plan(max_kb_dist=max_kb, extend_out=True)
         t0 = time.perf_counter()
         s1, s2, std, ext = eng.run(0, rows)
@@ -68,7 +81,7 @@ def main():
         eng.close()
     replayed = eng_replayed[0]
     out = {"config": which, "n_sites": n_sites, "n_ind": n_ind, "max_kb_dist": max_kb, "rows": rows, "pairs": int(len(want)),
-           "pairs_replayed_exact_order": replayed,
+           "pairs_replayed_exact_order": replayed, "pair_kernel": family,
            "oracle_s": round(t_cpu, 1), "oracle_threads": cores, "gpu_sink_path_s": round(t_gpu, 2)}
     ok = len(want) == len(std) and np.array_equal(s1, want["s1"]) and np.array_equal(s2, want["s2"])
     out["pairs_and_order_equal"] = bool(ok)
