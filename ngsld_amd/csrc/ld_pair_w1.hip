@@ -148,13 +148,18 @@ hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs
         b.tile_nk = (uint32_t)((most + 7) / 8);
         const uint64_t row_blocks = (g1 - g0 + kTileRows - 1) / kTileRows;
         const uint64_t blocks = row_blocks * b.tile_nk * kTileRows * 8ull;
-        if (blocks > max_blocks) {  // (a row of more than 2^22 / 512 * 8 items: not with 64 candidates per item and 2^32 sites)
+        if (blocks > max_blocks) {  // rows of more than 2^22 / 512 * 8 items (or the tests' cap): this group in plain order
           b.tile_nk = 0;
-          b.items = a.items_all + a.h_item_off[g0];
-          b.n_items = a.h_item_off[g1] - a.h_item_off[g0];
-        } else {
-          b.n_items = blocks;  // the grid (launch_pair_wn launches n_items workgroups)
+          const uint64_t first = a.h_item_off[g0], count = a.h_item_off[g1] - first;
+          for (uint64_t off = 0; off < count; off += max_blocks) {
+            b.items = a.items_all + first + off;
+            b.n_items = std::min<uint64_t>(max_blocks, count - off);
+            const hipError_t e = launch_pair_chunk(cfg, masked, b, stream);
+            if (e != hipSuccess) return e;
+          }
+          continue;
         }
+        b.n_items = blocks;  // the grid (launch_pair_wn launches n_items workgroups)
         const hipError_t e = launch_pair_chunk(cfg, masked, b, stream);
         if (e != hipSuccess) return e;
       }

@@ -97,6 +97,11 @@ def test_tiled_workgroup_order_of_the_multi_wavefront_kernel(n_ind, n_sites):
         for a, b in zip(tiled, plain):
             assert a.tobytes() == b.tobytes()
         assert tiled_dev == plain_dev
+        os.environ["NGSLD_MAX_BLOCKS"] = "300"                 # a tile grid beyond the launch cap: that row group in plain order, chunked
+        try:
+            assert device_records() == plain_dev
+        finally:
+            del os.environ["NGSLD_MAX_BLOCKS"]
         rows = 12
         want = orc.Oracle(raw, n_threads=8).run(0, rows)
         m = tiled[0] < rows
