@@ -45,13 +45,14 @@ constexpr bool kDrop0 = NGSLD_DROP0 != 0;
 #define NGSLD_XCH_ASM 1  // build-time A/B switch: two / four wavefronts per pair trade their partial sums through LDS accesses the
                         // compiler does not see (lds_post / lds_gather), so that it cannot order them behind the slice copy in flight
 #endif
-// (same-box A/B, tools/ab_xch.sh: +0.8 % at n_ind 1000, +2.9 % at 2000; eight wavefronts per pair -- 12 reads, 48 registers
-// of partials in flight -- lost 4.5 % at n_ind 4000 and keep the compiler's accesses)
+// (same-box A/B, tools/ab_xch.sh: +0.8 % at n_ind 1000, +2.9 % at 2000.  Eight wavefronts per pair lost 4.5 % at n_ind 4000
+// with 12 such reads -- 48 registers of partials in flight: there every lane reads ONE partial and the eight of a value are
+// added by three DPP steps inside their eight lanes, see em_pair.)
 #ifndef NGSLD_PARKED
 #define NGSLD_PARKED 1  // build-time A/B switch: no meeting of a pair's wavefronts for the Pearson moment (pair_ld_kernel, kParked)
 #endif
 template <int WAVES>
-constexpr bool kXchAsm = NGSLD_XCH_ASM != 0 && WAVES > 1 && WAVES <= 4;
+constexpr bool kXchAsm = NGSLD_XCH_ASM != 0 && WAVES > 1 && WAVES <= 8;
 #ifndef NGSLD_MASK_DONE
 #define NGSLD_MASK_DONE 1  // build-time A/B switch: converged groups of a lockstep wavefront are masked off (see pair_ld_group_kernel)
 #endif
@@ -631,14 +632,25 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
         if ((lane & 15) == 0 && row != 1)  // rows 0 / 2 / 3 hold t1 / t2 / t3 (wave_sum3_rows)
           lds_post(base + (uint32_t)((row == 0 ? 0 : row - 1) * WAVES + sub) * 8u, w);
         lds_barrier();
-        constexpr int kHalf = WAVES > 1 ? WAVES / 2 : 1;  // (one wavefront per pair: instantiated, never run)
-        dbl2 q[3 * kHalf];
-        lds_gather<3 * kHalf>(base, q);
-        t1 = q[0][0] + q[0][1]; t2 = q[kHalf][0] + q[kHalf][1]; t3 = q[2 * kHalf][0] + q[2 * kHalf][1];
+        if constexpr (WAVES == 8) {
+          // 24 partials: lane l < 24 reads partial l (value l / 8 of wavefront l % 8), three DPP steps add the eight of a value
+          // inside their eight lanes -- a fixed tree, the same in every wavefront -- and lanes 0 / 8 / 16 hand the totals out
+          double v;
+          asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(base + (uint32_t)(lane & 31) * 8u) : "memory");
+          v += dpp_mov<0xB1>(v);   // quad_perm:[1,0,3,2]
+          v += dpp_mov<0x4E>(v);   // quad_perm:[2,3,0,1]
+          v += dpp_mov<0x141>(v);  // row_half_mirror: lane l <-> 7 - l inside each 8 lanes
+          t1 = read_lane(v, 0); t2 = read_lane(v, 8); t3 = read_lane(v, 16);
+        } else {
+          constexpr int kHalf = WAVES > 1 ? WAVES / 2 : 1;  // (one wavefront per pair: instantiated, never run)
+          dbl2 q[3 * kHalf];
+          lds_gather<3 * kHalf>(base, q);
+          t1 = q[0][0] + q[0][1]; t2 = q[kHalf][0] + q[kHalf][1]; t3 = q[2 * kHalf][0] + q[2 * kHalf][1];
 #pragma unroll
-        for (int v = 1; v < kHalf; ++v) {
-          t1 += q[v][0]; t2 += q[kHalf + v][0]; t3 += q[2 * kHalf + v][0];
-          t1 += q[v][1]; t2 += q[kHalf + v][1]; t3 += q[2 * kHalf + v][1];
+          for (int v = 1; v < kHalf; ++v) {
+            t1 += q[v][0]; t2 += q[kHalf + v][0]; t3 += q[2 * kHalf + v][0];
+            t1 += q[v][1]; t2 += q[kHalf + v][1]; t3 += q[2 * kHalf + v][1];
+          }
         }
       } else {
         if ((lane & 15) == 0 && row != 1) xch[par][sub][row == 0 ? 1 : row] = w;
