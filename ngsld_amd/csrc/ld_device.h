@@ -1755,18 +1755,32 @@ __global__ __launch_bounds__(256, 2) void pair_ld_stream_kernel(PairArgs A) {
       const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
       const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
       double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
-      for (uint32_t b = (uint32_t)wave; b < n_blocks; b += 4) {
-        const uint32_t i = b * 64 + (uint32_t)lane;
-        const double a0 = pa[i], a1 = pa[np + i], a2 = pa[2 * np + i];
-        const double b0 = pb[i], b1 = pb[np + i], b2 = pb[2 * np + i];
-        bool ok = i < A.n_ind;
-        if (MASKED) ok = ok && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);
-        if (ok) {
+      // Four blocks of 64 individuals per trip: their 24 loads are in flight together, and an individual that does not count
+      // (padding, no data) takes part with r = 0 instead of being branched around -- one block per trip waited an L2 round
+      // trip for every 64 individuals, and its branch kept the loads of the next block behind the arithmetic of this one.
+      // (Same additions in the same order: adding +0 changes nothing.)
+      for (uint32_t bq = (uint32_t)wave; bq < n_blocks; bq += 16) {
+        double av[4][3], bv[4][3];
+        bool okv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t b = bq + 4u * (uint32_t)u;
+          const bool in = b < n_blocks;
+          const uint32_t i = (in ? b : bq) * 64 + (uint32_t)lane;
+          av[u][0] = pa[i]; av[u][1] = pa[np + i]; av[u][2] = pa[2 * np + i];
+          bv[u][0] = pb[i]; bv[u][1] = pb[np + i]; bv[u][2] = pb[2 * np + i];
+          okv[u] = in && i < A.n_ind;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double a0 = av[u][0], a1 = av[u][1], a2 = av[u][2], b0 = bv[u][0], b1 = bv[u][1], b2 = bv[u][2];
+          bool ok = okv[u];
+          if (MASKED) ok = ok && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);
           const double v0 = fma(p11, b2, fma(w1, b1, p00 * b0));  // sum_g2 W[0][g2] b[g2]
           const double v1 = fma(w5, b2, fma(w4, b1, w3 * b0));
           const double v2 = fma(p33, b2, fma(w7, b1, p22 * b0));
           const double s = fma(a2, v2, fma(a1, v1, a0 * v0));
-          const double r = rcp_refined(s);
+          const double r = ok ? rcp_refined(s) : 0.0;
           const double r0 = r * a0, r1 = r * a1, r2 = r * a2;
           R0 = fma(r0, b0, R0); R1 = fma(r0, b1, R1); R2 = fma(r0, b2, R2);
           R3 = fma(r1, b0, R3); R4 = fma(r1, b1, R4); R5 = fma(r1, b2, R5);
