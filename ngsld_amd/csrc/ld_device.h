@@ -458,7 +458,19 @@ __device__ __forceinline__ void unrelabel(bool flip1, bool flip2, double &f0, do
 //   pads (MASKED only, may be null): P of an individual WITHOUT data is zeroed and pads[j] = 1 there (0 elsewhere), so
 //   that em_pair can run its one-reciprocal-per-lane step over all slots: such an individual's s is exactly 1 and it
 //   adds nothing to R (the same device that neutralises the padding lanes of the last slot)
-template <int SLOTS, bool MASKED, bool ONLY_LAST = false, bool UNCENTRED = false>  // ONLY_LAST: only the last slot can hold padding lanes
+__device__ __forceinline__ const double *uniform_ptr(const double *p) {  // a wavefront-uniform pointer, said so: SGPRs
+  const uint64_t v = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return reinterpret_cast<const double *>((uintptr_t)(((uint64_t)hi << 32) | lo));
+}
+
+//   A_GLOBAL: pa points into global memory (the multi-wavefront kernels read their slice of the row vector from L2 for
+//   every pair): the three plane bases are handed to the loads as SGPR pairs + one 32-bit lane offset.  Left to itself the
+//   compiler kept ~10 64-bit VGPR addresses for them, and under --ignore_miss_data, where registers are tightest, SPILLED
+//   them -- seven scratch reloads per pair, one after the other into the same register pair, each an L2 round trip in
+//   front of the load it feeds: 4.7 us of a 15 us pair at n_ind 2,000
+template <int SLOTS, bool MASKED, bool ONLY_LAST = false, bool UNCENTRED = false, bool A_GLOBAL = false>  // ONLY_LAST: only the last slot can hold padding lanes
 __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint32_t ia0, const double *pb, uint32_t npb,
                                            uint32_t ib0, uint32_t ind0, uint32_t n_ind, double mean1, double mean2,
                                            double (&P)[SLOTS][9], uint32_t &vbits, double &sxy, double *pads = nullptr,
@@ -467,12 +479,17 @@ __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint3
   // flip_a / flip_b (wavefront-uniform) relabel the alleles of a site: genotype planes 0 and 2 trade places (see Relabel)
   vbits = 0;
   sxy = 0.0;
-  const double *pa0 = pa + (flip_a ? 2 * npa : 0u), *pa2 = pa + (flip_a ? 0u : 2 * npa);
+  const double *pa0 = pa + (flip_a ? 2 * npa : 0u), *pa1 = pa + npa, *pa2 = pa + (flip_a ? 0u : 2 * npa);
   const double *pb0 = pb + (flip_b ? 2 * npb : 0u), *pb2 = pb + (flip_b ? 0u : 2 * npb);
+  if (A_GLOBAL) {
+    pa0 = uniform_ptr(pa0); pa1 = uniform_ptr(pa1); pa2 = uniform_ptr(pa2);
+  }
 #pragma unroll
   for (int j = 0; j < SLOTS; ++j) {
     const uint32_t ia = ia0 + (uint32_t)j * 64, ib = ib0 + (uint32_t)j * 64;
-    const double a0 = pa0[ia], a1 = pa[npa + ia], a2 = pa2[ia];
+    typedef const __attribute__((address_space(1))) double gdouble_t;  // (said to be global memory: global_load, not flat_load)
+    const double a0 = A_GLOBAL ? ((gdouble_t *)pa0)[ia] : pa0[ia], a1 = A_GLOBAL ? ((gdouble_t *)pa1)[ia] : pa1[ia],
+                 a2 = A_GLOBAL ? ((gdouble_t *)pa2)[ia] : pa2[ia];
     const double b0 = pb0[ib], b1 = pb[npb + ib], b2 = pb2[ib];
     const bool inb = (ONLY_LAST && j < SLOTS - 1) ? true : ind0 + (uint32_t)j * 64 < n_ind;
     bool ok = inb;
@@ -941,9 +958,9 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
     const Relabel rl = relabel(m1, m2, mean1, mean2);
     if (PFB) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice copied during the previous pair has landed
-      stage_pair<SLOTS, MASKED>(pa, A.np, i0, reinterpret_cast<const double *>(lds_b), (uint32_t)(SLOTS * 64),
-                                (uint32_t)lane, i0, A.n_ind, rl.mean1, rl.mean2, P, vbits, sxy, MASKED ? pads : nullptr,
-                                rl.flip1, rl.flip2);
+      stage_pair<SLOTS, MASKED, false, false, true>(pa, A.np, i0, reinterpret_cast<const double *>(lds_b),
+                                                    (uint32_t)(SLOTS * 64), (uint32_t)lane, i0, A.n_ind, rl.mean1, rl.mean2, P,
+                                                    vbits, sxy, MASKED ? pads : nullptr, rl.flip1, rl.flip2);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // a, b and the scalars are all consumed
       if (cn < it.count) dma_slice(it.s2_begin + cn);
     } else {
