@@ -455,9 +455,10 @@ __device__ __forceinline__ void unrelabel(bool flip1, bool flip2, double &f0, do
 // LDS (prefetch kernel); after inlining the compiler knows which and emits global_load or ds_read.
 //   UNCENTRED: sxy comes back as the uncentred cross moment sum e1 e2 -- padding lanes hold a == b == 0, so no bounds
 //   test -- and the caller subtracts n * mean1 * mean2 once per pair
-//   pads (MASKED only, may be null): P of an individual WITHOUT data is zeroed and pads[j] = 1 there (0 elsewhere), so
+//   pads (may be null): MASKED -- P of an individual WITHOUT data is zeroed and pads[j] = 1 there (0 elsewhere), so
 //   that em_pair can run its one-reciprocal-per-lane step over all slots: such an individual's s is exactly 1 and it
-//   adds nothing to R (the same device that neutralises the padding lanes of the last slot)
+//   adds nothing to R (the same device that neutralises the padding lanes of the last slot); not MASKED -- pads[j] = 1 in
+//   the padding lanes of ANY slot (several wavefronts per pair whose padding is not confined to a last slot)
 __device__ __forceinline__ const double *uniform_ptr(const double *p) {  // a wavefront-uniform pointer, said so: SGPRs
   const uint64_t v = (uint64_t)(uintptr_t)p;
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
@@ -500,6 +501,8 @@ __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint3
       const double keep = ok ? 1.0 : 0.0;
       z0 = a0 * keep; z1 = a1 * keep; z2 = a2 * keep;
       pads[j] = 1.0 - keep;
+    } else if (pads != nullptr) {  // every individual counts: only padding lanes (zeros in the planes already) get a pad
+      pads[j] = inb ? 0.0 : 1.0;
     }
     P[j][0] = z0 * b0; P[j][1] = z0 * b1; P[j][2] = z0 * b2;
     P[j][3] = z1 * b0; P[j][4] = z1 * b1; P[j][5] = z1 * b2;
@@ -857,8 +860,14 @@ struct PairResult {
 //          buffer while the EM loop of the current pair runs; the row vector (same for the whole item, L2/L1-hot)
 //          is still read directly.  No extra barrier is needed for the prefetch.
 // ---------------------------------------------------------------------------------------------
-template <int SLOTS, int WAVES, bool MASKED, bool PFB>
+//   PADS   (WAVES > 1, not MASKED) the cohort does not fill all slots but the last: padding lanes in the middle of a
+//          wavefront's slots, or a wavefront that is all padding (513 individuals on 2 x 5 slots: the second wavefront's
+//          fourth slot holds ONE individual, its fifth none).  Without per-slot pads such a wavefront took the step with
+//          one reciprocal per individual in EVERY iteration and the others waited for it at the barrier: n_ind 1,025 ran at
+//          half the rate of 1,024, slower than under --ignore_miss_data, whose kernels have the pads anyway.
+template <int SLOTS, int WAVES, bool MASKED, bool PFB, bool PADS = false>
 __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
+  static_assert(!PADS || (WAVES > 1 && !MASKED && PFB), "PADS: the prefetching multi-wavefront kernel without --ignore_miss_data");
   constexpr bool kCheckAll = MASKED || WAVES > 1;  // otherwise only the last slot can hold padding
   constexpr int kWavesPerWg = WAVES == 1 ? 4 : WAVES;
   constexpr int kSliceBytes = SLOTS * 64 * 3 * 8;
@@ -960,7 +969,7 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice copied during the previous pair has landed
       stage_pair<SLOTS, MASKED, false, false, true>(pa, A.np, i0, reinterpret_cast<const double *>(lds_b),
                                                     (uint32_t)(SLOTS * 64), (uint32_t)lane, i0, A.n_ind, rl.mean1, rl.mean2, P,
-                                                    vbits, sxy, MASKED ? pads : nullptr, rl.flip1, rl.flip2);
+                                                    vbits, sxy, (MASKED || PADS) ? pads : nullptr, rl.flip1, rl.flip2);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // a, b and the scalars are all consumed
       if (cn < it.count) dma_slice(it.s2_begin + cn);
     } else {
@@ -1004,9 +1013,9 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
       lds_barrier();
     }
     double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair<SLOTS, WAVES, kCheckAll, (WAVES > 1 && !MASKED)>(
+    const uint32_t n_iter = em_pair<SLOTS, WAVES, kCheckAll, (WAVES > 1 && !MASKED && !PADS)>(
         P, vbits, kParked ? A.inv_n : 1.0 / (double)x, rl.m1, rl.m2, f0, f1, f2, f3, xch, sub, lane, A.status,
-        MASKED ? pads : nullptr, WAVES > 1 ? &xpar : nullptr);
+        (MASKED || PADS) ? pads : nullptr, WAVES > 1 ? &xpar : nullptr);
     unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
     if (WAVES == 1) {
       if (lane == 0)

@@ -9,11 +9,15 @@ static hipError_t launch_sw(bool masked, bool prefetch, const PairArgs &a, hipSt
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   const dim3 grid((unsigned)blocks), block(WAVES * 64);
+  // every slot but the last one of the last wavefront full?  Otherwise the kernel with per-slot pads (see pair_ld_kernel, PADS)
+  const bool clean = (uint64_t)a.n_ind > (uint64_t)(WAVES * SLOTS - 1) * 64u;
   if (prefetch) {
     if (masked)
       hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, true, true>), grid, block, 0, stream, a);
-    else
+    else if (clean)
       hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, false, true>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, false, true, true>), grid, block, 0, stream, a);
   } else {
     if (masked)
       hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, true, false>), grid, block, 0, stream, a);
