@@ -188,6 +188,11 @@ int ngsld_set_text_output(ngsld_ctx *ctx, const char *const *labels, int enable)
  * reference's by the device's exp/log rounding (exact for ngsld_set_geno_lkl), and --min_maf ties are left to the
  * device's est_maf.  Call after ngsld_set_geno_* (the source belongs to that matrix), before ngsld_plan. */
 int ngsld_set_replay_source(ngsld_ctx *ctx, ngsld_read_sites_fn read, void *user);
+/* The common case of a source -- the caller still HOLDS the matrix it gave ngsld_set_geno_raw_opts / ngsld_set_geno_lkl, as
+ * the reference's main does throughout (ngsLD.cpp:86-89): `values` = that same host array, [site][ind][3], which must stay
+ * valid and unchanged until the context is destroyed or given other data.  Read in place by the replay threads: no callback,
+ * no copy, no lock (the callback form serialises its calls).  NULL removes it.  Replaces any registered callback. */
+int ngsld_set_replay_matrix(ngsld_ctx *ctx, const double *values);
 /* enable == 0: no replay, every record is the kernels' own value. */
 int ngsld_set_replay(ngsld_ctx *ctx, int enable);
 /* Pairs replayed by the last ngsld_run / ngsld_run_device (+ ngsld_finish_device) and sites re-evaluated by the last

@@ -82,7 +82,7 @@ SYMBOLS = [
     "ngsld_version", "ngsld_create", "ngsld_destroy", "ngsld_last_error", "ngsld_set_geno_raw",
     "ngsld_set_geno_raw_opts", "ngsld_set_geno_lkl",
     "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device", "ngsld_set_text_output",
-    "ngsld_set_replay_source", "ngsld_set_replay", "ngsld_replay_stats", "ngsld_finish_device",
+    "ngsld_set_replay_source", "ngsld_set_replay_matrix", "ngsld_set_replay", "ngsld_replay_stats", "ngsld_finish_device",
     "ngsld_plan_parts", "ngsld_run_multi",
     "ngsld_last_kernel_time", "ngsld_pair_kernel", "ngsld_set_tuning", "ngsld_selftest",
     "ngsld_window_ends", "ngsld_plan_slabs", "ngsld_slab_sites_for_budget", "ngsld_device_memory", "ngsld_run_streamed", "ngsld_run_streamed_text",
@@ -137,6 +137,8 @@ def lib() -> C.CDLL:
         L.ngsld_run_device.argtypes = [vp, u64, u64, vp, vp, vp]
         if hasattr(L, "ngsld_set_replay_source"):  # (absent only from older A/B builds loaded through NGSLD_LIB)
             L.ngsld_set_replay_source.argtypes = [vp, READ_FN, vp]
+            if hasattr(L, "ngsld_set_replay_matrix"):
+                L.ngsld_set_replay_matrix.argtypes = [vp, vp]
             L.ngsld_set_replay.argtypes = [vp, C.c_int]
             L.ngsld_replay_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
             L.ngsld_finish_device.argtypes = [vp]
@@ -514,6 +516,10 @@ class Engine:
             return
         arr = np.ascontiguousarray(values, dtype=np.float64).reshape(self.n_sites, -1)
         row = arr.shape[1] * 8
+        if hasattr(self._L, "ngsld_set_replay_matrix") and os.environ.get("NGSLD_PY_REPLAY_CALLBACK") != "1":
+            self._source = (arr, None)   # read in place by the library's replay threads: no callback, no GIL
+            self._check(self._L.ngsld_set_replay_matrix(self._h, arr.ctypes.data))
+            return
 
         def reader(_user, site_begin, n, dst):
             if site_begin + n > arr.shape[0]:

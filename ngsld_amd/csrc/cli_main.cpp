@@ -616,8 +616,10 @@ int main(int argc, char **argv) {
   };
   if (getenv("NGSLD_REPLAY_SOURCE") && strcmp(getenv("NGSLD_REPLAY_SOURCE"), "0") == 0)
     raw.reset();  // (tests: replay from the device's own planes)
-  else if (ngsld_set_replay_source(ctx, read_raw, &raw_src) != NGSLD_OK)
-    error("ngsld_set_replay_source", ngsld_last_error(ctx));
+  else if (getenv("NGSLD_REPLAY_SOURCE") && strcmp(getenv("NGSLD_REPLAY_SOURCE"), "callback") == 0) {  // (tests: the callback form)
+    if (ngsld_set_replay_source(ctx, read_raw, &raw_src) != NGSLD_OK) error("ngsld_set_replay_source", ngsld_last_error(ctx));
+  } else if (ngsld_set_replay_matrix(ctx, raw.get()) != NGSLD_OK)
+    error("ngsld_set_replay_matrix", ngsld_last_error(ctx));
 
   if (pars.verbose >= 1) fprintf(stderr, "==> Getting sites coordinates\n");
   ngsld_pos *pos = nullptr;

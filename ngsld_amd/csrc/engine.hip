@@ -2,6 +2,7 @@
 // batched replacement of the reference's per-s1 thread-pool dispatch, ngsLD.cpp:153-198) and the
 // batch pipeline kernel -> async D2H -> sink.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -178,6 +179,7 @@ struct ngsld_ctx {
   bool replay_on = true;
   ngsld_read_sites_fn replay_read = nullptr;  // the caller's raw values again (null: the device's planes are read back)
   void *replay_user = nullptr;
+  const double *replay_matrix = nullptr;      // ... or the caller's own host array, read in place (ngsld_set_replay_matrix)
   std::mutex replay_mu;                       // serialises the source callback / the plane read-back
   hipStream_t replay_stream = nullptr;        // non-blocking: read-backs must not wait for the next batch's kernel
   ngsld_geno_opts gopts{};
@@ -190,7 +192,7 @@ struct ngsld_ctx {
   DevBuf<ngsld_rec_ext> d_patch_ext;
   DevBuf<char> d_scan_tmp2;                   // text lengths re-derived after a patch, beside the next batch's scan
   uint64_t replayed_pairs = 0, replayed_sites = 0;
-  int replay_threads = 0;                     // 0 = min(8, hardware threads)
+  int replay_threads = 0;                     // 0 = min(32, the threads the process may really use)
   struct {
     bool pending = false;
     uint64_t s1_begin = 0, s1_end = 0;
@@ -258,6 +260,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   c->text_mode = false;  // labels belong to a matrix
   c->replay_read = nullptr;  // and so does the replay source
   c->replay_user = nullptr;
+  c->replay_matrix = nullptr;
   c->dev_run.pending = false;
   c->gopts = o;
   c->normalised = normalised;
@@ -487,6 +490,27 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
   return a;
 }
 
+// Host threads this process may really run on: the affinity mask cut by the cgroup CPU quota (a lease that shows 256 CPUs
+// and grants 16 is common); what the exact-order replay spreads its pairs over when nothing else was asked for.
+unsigned usable_threads() {
+  unsigned n = std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+    const int k = CPU_COUNT(&set);
+    if (k > 0) n = (unsigned)k;
+  }
+  if (FILE *fh = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char a[64] = "";
+    double period = 0;
+    if (std::fscanf(fh, "%63s %lf", a, &period) == 2 && std::strcmp(a, "max") != 0 && period > 0) {
+      const double q = std::atof(a) / period;
+      if (q >= 1.0 && q < (double)n) n = (unsigned)(q + 0.5);
+    }
+    std::fclose(fh);
+  }
+  return n ? n : 1u;
+}
+
 int check_status(ngsld_ctx *c) {
   int status = 0;
   HIP_TRY(c, hipMemcpy(&status, c->d_status.p, sizeof(int), hipMemcpyDeviceToHost));
@@ -540,6 +564,14 @@ bool locate_record(const ngsld_ctx *c, uint64_t rec, uint32_t *s1, uint32_t *s2)
 // device's own planes (already normalised normal-space values; exact for ngsld_set_geno_lkl input).
 int fetch_replay_site(ngsld_ctx *c, uint64_t s, std::vector<double> &tmp, ReplaySite *out) {
   const uint64_t n = c->n_ind;
+  if (c->replay_matrix != nullptr) {  // the caller's own array, read in place
+    const double *v = c->replay_matrix + s * 3 * n;
+    if (c->normalised)
+      replay_site_from_lkl(v, c->h_maf[s], n, out);
+    else
+      replay_site_from_raw(v, n, c->gopts, out);
+    return NGSLD_OK;
+  }
   if (c->replay_read != nullptr) {
     tmp.resize(3 * n);
     {
@@ -593,8 +625,7 @@ int replay_flagged(ngsld_ctx *c, const uint32_t *h_flags, uint64_t base, uint64_
   const bool ign = c->params.ignore_miss_data != 0;
   std::vector<ngsld_rec_std> out_std(recs.size());
   std::vector<ngsld_rec_ext> out_ext(ext ? recs.size() : 0);
-  unsigned hw = std::thread::hardware_concurrency();
-  int T = c->replay_threads > 0 ? c->replay_threads : (int)std::min<unsigned>(8u, hw ? hw : 1u);
+  int T = c->replay_threads > 0 ? c->replay_threads : (int)std::min<unsigned>(32u, usable_threads());
   if ((uint64_t)T > (recs.size() + 15) / 16) T = (int)((recs.size() + 15) / 16);
   std::vector<int> rcs((size_t)T, NGSLD_OK), stats((size_t)T, NGSLD_OK);
   std::vector<uint64_t> sites_done((size_t)T, 0);
@@ -882,7 +913,7 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
   const bool sampling = p->rnd_sample > 0 && p->rnd_sample < 1;
   c->replayed_sites = 0;
   c->dev_run.pending = false;
-  if (c->replay_on && c->replay_read != nullptr && !c->normalised) {
+  if (c->replay_on && (c->replay_read != nullptr || c->replay_matrix != nullptr) && !c->normalised) {
     // A frequency that ties --min_maf to the last bits falls on either side of `maf < min_maf` (ngsLD.cpp:264-275)
     // depending on the order est_maf adds its terms up in (the prep kernel block-reduces them), and one that sits on a
     // rounding point of the sixth decimal prints a different last digit (maf1 / maf2, ngsLD.cpp:338-339).  Such sites get
@@ -1017,8 +1048,19 @@ int ngsld_set_text_output(ngsld_ctx *c, const char *const *labels, int enable) t
 int ngsld_set_replay_source(ngsld_ctx *c, ngsld_read_sites_fn read, void *user) {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "set the genotype data before its replay source");
+  c->replay_matrix = nullptr;
   c->replay_read = read;
   c->replay_user = user;
+  c->planned = false;  // a --min_maf tie is settled at plan time
+  return NGSLD_OK;
+}
+
+int ngsld_set_replay_matrix(ngsld_ctx *c, const double *values) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "set the genotype data before its replay source");
+  c->replay_matrix = values;
+  c->replay_read = nullptr;
+  c->replay_user = nullptr;
   c->planned = false;  // a --min_maf tie is settled at plan time
   return NGSLD_OK;
 }

@@ -55,17 +55,6 @@ struct Barrier {  // all parts meet here (C++17 has no std::barrier)
   }
 };
 
-struct HostSource {  // replay source of one part: its slab as it sits in host memory
-  const double *raw;
-  uint64_t n_sites, n_ind;
-};
-int read_host_source(void *user, uint64_t site_begin, uint64_t n, double *dst) {
-  const HostSource *s = static_cast<const HostSource *>(user);
-  if (site_begin + n > s->n_sites) return 1;
-  std::memcpy(dst, s->raw + site_begin * s->n_ind * 3, n * s->n_ind * 3 * sizeof(double));
-  return 0;
-}
-
 struct PartSink {  // same records, site indices moved from the part's frame to the global one
   uint64_t base;
   int part;
@@ -282,7 +271,6 @@ int ngsld_run_multi(const int *devices, int n_devices, uint64_t n_sites, uint64_
   std::vector<int> rcs((size_t)n, NGSLD_OK), hard((size_t)n, 0);
   std::vector<std::string> msgs((size_t)n);
   std::vector<std::vector<double>> host((size_t)n);
-  std::vector<HostSource> src((size_t)n);
 
   auto work = [&](int k) {
     const ngsld_slab &pt = parts[(size_t)k];
@@ -344,8 +332,7 @@ int ngsld_run_multi(const int *devices, int n_devices, uint64_t n_sites, uint64_
         d_raw[(size_t)k] = nullptr;
       }
       if (!any_failed && r == NGSLD_OK && rows > 0) {
-        src[(size_t)k] = HostSource{slab, m, n_ind};
-        r = ngsld_set_replay_source(ctx, read_host_source, &src[(size_t)k]);
+        r = ngsld_set_replay_matrix(ctx, slab);  // (the part's slab stays in host memory for the run: read in place)
         if (r == NGSLD_OK) r = ngsld_set_pos_dist(ctx, pos_dist ? pos_dist + pt.row_begin : nullptr);
         ngsld_params p = *params;
         p.first_row = params->first_row + pt.row_begin;

@@ -48,19 +48,6 @@ int rebase_sink(void *user, const ngsld_batch *b) {
   return r->sink(r->user, &g);
 }
 
-// Replay source of one slab (ngsld_set_replay_source): its raw values as they sit in the host slab buffer.
-struct SlabSource {
-  const double *raw;
-  uint64_t n_sites, n_ind;
-};
-
-int read_slab_copy(void *user, uint64_t site_begin, uint64_t n, double *dst) {
-  const SlabSource *s = static_cast<const SlabSource *>(user);
-  if (site_begin + n > s->n_sites) return 1;
-  std::memcpy(dst, s->raw + site_begin * s->n_ind * 3, n * s->n_ind * 3 * sizeof(double));
-  return 0;
-}
-
 }  // namespace
 
 extern "C" {
@@ -169,7 +156,6 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
   std::string load_msg;
   slab_pairs.assign(n_slabs, 0);  // (n_slabs <= n_sites words: not guarded separately)
 
-  SlabSource src[2] = {};
   std::thread loader([&]() {
     uint64_t maf_done = 0;  // maf_out[0, maf_done) is final
     for (uint64_t k = 0; k < n_slabs; ++k) {
@@ -196,8 +182,7 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
         so.per_individual_only = 1;
         r = ngsld_set_geno_raw_opts(ctx[b], host[b].data(), m, n_ind, &so);
         // exact-order replay: the slab's raw values stay in host[b] until its run is over
-        src[b] = SlabSource{host[b].data(), m, n_ind};
-        if (r == NGSLD_OK) r = ngsld_set_replay_source(ctx[b], read_slab_copy, &src[b]);
+        if (r == NGSLD_OK) r = ngsld_set_replay_matrix(ctx[b], host[b].data());
         if (r == NGSLD_OK) r = ngsld_set_pos_dist(ctx[b], pos_dist ? pos_dist + sl.row_begin : nullptr);
         if (r == NGSLD_OK) {
           ngsld_params p = *params;

@@ -48,9 +48,14 @@ def all_bits_equal(std, ext, want):
     assert np.array_equal(ext["n_iter"], want["n_iter"]) and np.array_equal(ext["n_ind_data"], want["n_ind_data"])
 
 
+@pytest.mark.parametrize("source", ["matrix", "callback"])
 @pytest.mark.parametrize("ign", [False, True])
 @pytest.mark.parametrize("hard_kernel", [True, False])
-def test_degenerate_pairs_are_the_reference_bits(engine, ign, hard_kernel):
+def test_degenerate_pairs_are_the_reference_bits(engine, ign, hard_kernel, source, monkeypatch):
+    """Both forms of the replay source: the caller's array read in place (ngsld_set_replay_matrix, what the binding uses) and
+    the reader callback (ngsld_set_replay_source)."""
+    if source == "callback":
+        monkeypatch.setenv("NGSLD_PY_REPLAY_CALLBACK", "1")
     raw = degenerate_matrix(all_called=hard_kernel)
     o = orc.Oracle(raw, ignore_miss_data=ign)
     want = o.run()
