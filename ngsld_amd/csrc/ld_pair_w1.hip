@@ -10,11 +10,15 @@ namespace ngsld {
 
 // n_ind -> kernel family and shape.  Lane groups of 8 / 16 / 32 lanes x 8 slots cover 64 / 128 / 256 individuals
 // (group kernel); one wavefront holds up to 8*64 = 512 individuals as 18*8 = 144 VGPRs of P; above that 2..8
-// wavefronts share the pair, and beyond 4096 the streaming kernel takes over.
+// wavefronts share the pair (eight slots per lane, nine just past a doubling), and beyond 4608 the streaming kernel takes over.
 bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg, bool allow_run, bool allow_ab) {
   if (n_ind == 0 || n_ind >= 0xffffffc0ull) return false;
   cfg->group = 64;
-  if (n_ind > 4096) {  // beyond 8 wavefronts x 8 slots x 64 lanes: streaming kernel, one workgroup per pair
+  // Just past a doubling of the wavefronts (1,025..1,152, 2,049..2,304, 4,097..4,608 individuals) NINE slots on half as many
+  // wavefronts beat five on twice as many: half-empty lanes and twice the per-iteration bookkeeping against a few spilled
+  // registers outside the EM loop.  NGSLD_SLOTS9=0: the eight-slot shapes only (A/B).
+  const bool slots9 = allow_prefetch && !(std::getenv("NGSLD_SLOTS9") && std::strcmp(std::getenv("NGSLD_SLOTS9"), "0") == 0);
+  if (n_ind > (slots9 ? 4608u : 4096u)) {  // beyond 8 wavefronts x 8 (9) slots x 64 lanes: streaming kernel, one workgroup per pair
     cfg->kernel = kStream;
     cfg->waves = 4;
     cfg->slots = 0;
@@ -42,6 +46,7 @@ bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig
   }
   int w = 1;
   while ((n_ind + 64ull * w - 1) / (64ull * w) > 8) w *= 2;
+  if (slots9 && w >= 4 && (n_ind + 32ull * w - 1) / (32ull * w) == 9) w /= 2;  // nine slots on w / 2 wavefronts
   cfg->waves = w;
   cfg->slots = (int)((n_ind + 64ull * w - 1) / (64ull * w));
   cfg->np = (uint32_t)(cfg->slots * w * 64);

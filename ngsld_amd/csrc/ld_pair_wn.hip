@@ -1,4 +1,4 @@
-// ld_pair_wn.hip -- instantiations of the multi-wavefront-per-pair kernel (512 < n_ind <= 4096).
+// ld_pair_wn.hip -- instantiations of the multi-wavefront-per-pair kernel (512 < n_ind <= 4608).
 #include "ld_device.h"
 
 namespace ngsld {
@@ -18,11 +18,13 @@ static hipError_t launch_sw(bool masked, bool prefetch, const PairArgs &a, hipSt
       hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, false, true>), grid, block, 0, stream, a);
     else
       hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, false, true, true>), grid, block, 0, stream, a);
-  } else {
+  } else if constexpr (SLOTS <= 8) {  // (nine slots: the prefetching kernel only)
     if (masked)
       hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, true, false>), grid, block, 0, stream, a);
     else
       hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, false, false>), grid, block, 0, stream, a);
+  } else {
+    return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
@@ -34,6 +36,7 @@ static hipError_t launch_w(int slots, bool masked, bool prefetch, const PairArgs
     case 6: return launch_sw<6, WAVES>(masked, prefetch, a, stream);
     case 7: return launch_sw<7, WAVES>(masked, prefetch, a, stream);
     case 8: return launch_sw<8, WAVES>(masked, prefetch, a, stream);
+    case 9: return prefetch ? launch_sw<9, WAVES>(masked, prefetch, a, stream) : hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
 }

@@ -57,6 +57,20 @@ def test_all_pairs_multi_wave(engine, n_sites, n_ind, seed):
     check_against_oracle(engine, raw)
 
 
+@pytest.mark.parametrize("n_sites,n_ind,seed,ignore_miss", [(12, 1100, 26, False), (12, 1152, 27, True), (10, 2200, 28, False),
+                                                            (9, 2304, 29, True), (8, 4300, 30, False), (7, 4608, 31, True)])
+def test_nine_slots_per_lane(engine, n_sites, n_ind, seed, ignore_miss):
+    """Just past a doubling of the wavefronts per pair the kernels hold NINE individuals per lane on half as many wavefronts
+    (2 x 9, 4 x 9, 8 x 9 x 64): with and without --ignore_miss_data, padding inside and at the end of the last wavefront."""
+    raw = synth.make_gl_numpy(n_sites, n_ind, seed, depth=4.0)
+    if ignore_miss:
+        miss = np.random.default_rng(seed).random((n_sites, n_ind)) < 0.15
+        raw[miss] = 1.0 / 3.0
+    engine.set_geno_raw(raw[:2], ignore_miss_data=ignore_miss)
+    assert engine.pair_kernel() == "multi"
+    check_against_oracle(engine, raw, ignore_miss=ignore_miss)
+
+
 def test_windowed_and_snp_dist(engine):
     raw = synth.make_gl_numpy(300, 50, 31, depth=8.0)
     chrs, pos = synth.make_positions(300, 31, max_gap=200, n_chr=2)
