@@ -365,6 +365,23 @@ def main():
     n_iter = ext_i32[:n_pairs, 9].to(torch.float64)
     mean_exec = float(torch.clamp(n_iter + 1, max=100).mean()) if n_pairs else 0.0
 
+    # ---- what this rank computed, as partition-invariant checksums: the executed-iteration total and the wrap-around sum
+    # of every 8-byte word of its records.  Summed over the ranks they must equal a 1-rank run of the same matrix bit for
+    # bit -- sharding changes who computes a pair, never its result (tests/test_gpu_multi_ranks.py holds the driver's
+    # N > 1 launch to that) ----
+    words_std = d_std.view(torch.int64)[:n_pairs * (STD_BYTES // 8)]
+    words_ext = d_ext.view(torch.int64)[:n_pairs * (EXT_BYTES // 8)]
+    r2_col = d_std.view(torch.float64).view(-1, 4)[:n_pairs, 3]
+    mine = {"rank": rank, "rows": [int(lo), int(hi)], "sites_held": [int(slab_lo), int(slab_hi)], "pairs": n_pairs,
+            "executed_iterations": int(torch.clamp(ext_i32[:n_pairs, 9].to(torch.int64) + 1, max=100).sum()) if n_pairs else 0,
+            "sum_r2_finite": float(r2_col[torch.isfinite(r2_col)].sum()) if n_pairs else 0.0,
+            "records_checksum_u64": (int(words_std.sum()) + int(words_ext.sum())) % (1 << 64) if n_pairs else 0,
+            "seconds": elapsed, "device": torch.cuda.get_device_name(dev), "device_index": dev_index}
+    rank_records = [mine]
+    if world > 1:
+        rank_records = [None] * world
+        dist.all_gather_object(rank_records, mine)
+
     if rank == 0:
         value = total_pairs * args.steps / elapsed_max
         bytes_pair = 48 * n_ind + STD_BYTES + EXT_BYTES
@@ -400,6 +417,9 @@ def main():
                        "parallelism": f"rows sharded by pair count over {world} GPU(s), no data-path collective",
                        "pairs_per_rank_min_max": [pairs_min, pairs_max],
                        "rank_seconds_min_max": [elapsed_min, elapsed_max],
+                       "rank_records": rank_records,
+                       "backend": ("gloo, every rank on GPU 0 (NGSLD_BENCH_ONE_DEVICE=1: a dry run of the N > 1 path, not a "
+                                   "scaling measurement)" if one_dev else "nccl (RCCL)") if world > 1 else None,
                        "pairs_replayed_exact_order_rank0_last_step": replayed[0],
                        "gl_generate_s": round(t_gen, 3), "gl_broadcast_s": round(t_bc, 3),
                        "one_off_prep_ms_rank0": round(t_prep * 1e3, 2), "one_off_plan_ms_rank0": round(t_plan * 1e3, 2)},

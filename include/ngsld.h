@@ -298,6 +298,12 @@ int ngsld_run_multi(const int *devices, int n_devices, uint64_t n_sites, uint64_
                     ngsld_read_sites_fn read, void *read_user, double *maf_out, ngsld_multi_sink_fn sink, void *sink_user,
                     const char *const *labels, int text_output, uint64_t *pairs_per_part, char *err, size_t errlen);
 
+/* How the last ngsld_run_multi of this process handed the matrix to its devices (the one collective of the
+ * design is this broadcast): uploaded slab by slab over each part's own PCIe link, copied device to device from the first
+ * device, or ONE ncclBroadcast over RCCL / xGMI. */
+enum { NGSLD_DIST_NONE = 0, NGSLD_DIST_UPLOAD = 1, NGSLD_DIST_PEER_COPY = 2, NGSLD_DIST_RCCL = 3 };
+int ngsld_multi_last_distribution(void);
+
 #ifdef __cplusplus
 }
 #endif

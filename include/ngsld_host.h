@@ -81,8 +81,9 @@ int ngsld_host_write_batch(const ngsld_batch *b, const ngsld_pos *pos, const dou
 /* gzip-compressed output (optional; the reference writes plain text only): whatever is written to
  * *fd_to_write is cut into 4 MiB blocks, each deflated by one of n_threads workers into a gzip member of its own, and
  * written to `path` in order -- a valid .gz file (multi-member), content identical to the plain output.
- * NGSLD_GZ_LEVEL=1..9 (default 1).  ngsld_host_gz_close: close (or fclose) the write end first or let it be closed
- * here; returns NGSLD_OK when every block reached the file. */
+ * NGSLD_GZ_LEVEL=1..9 (default 1).  *fd_to_write belongs to the CALLER: close (or fclose) it, then call
+ * ngsld_host_gz_close, which waits for the end of the stream and returns NGSLD_OK when every block reached the file.  A
+ * write or deflate error never blocks the producer: the rest of the stream is read and dropped, and close reports it. */
 typedef struct ngsld_gz ngsld_gz;
 int ngsld_host_gz_open(const char *path, int n_threads, ngsld_gz **out, int *fd_to_write);
 int ngsld_host_gz_close(ngsld_gz *gz);

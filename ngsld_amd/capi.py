@@ -83,7 +83,7 @@ SYMBOLS = [
     "ngsld_set_geno_raw_opts", "ngsld_set_geno_lkl",
     "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device", "ngsld_set_text_output",
     "ngsld_set_replay_source", "ngsld_set_replay_matrix", "ngsld_set_replay", "ngsld_replay_stats", "ngsld_finish_device",
-    "ngsld_plan_parts", "ngsld_run_multi",
+    "ngsld_plan_parts", "ngsld_run_multi", "ngsld_multi_last_distribution",
     "ngsld_last_kernel_time", "ngsld_pair_kernel", "ngsld_set_tuning", "ngsld_selftest",
     "ngsld_window_ends", "ngsld_plan_slabs", "ngsld_slab_sites_for_budget", "ngsld_device_memory", "ngsld_run_streamed", "ngsld_run_streamed_text",
     "ngsld_host_read_geno_bin_range",
@@ -162,6 +162,8 @@ def lib() -> C.CDLL:
             L.ngsld_run_multi.argtypes = [C.POINTER(C.c_int), C.c_int, u64, u64, vp, C.POINTER(Params), C.POINTER(GenoOpts),
                                           vp, READ_FN, vp, vp, MULTI_SINK_FN, vp, C.POINTER(C.c_char_p), C.c_int,
                                           C.POINTER(u64), C.c_char_p, C.c_size_t]
+        if hasattr(L, "ngsld_multi_last_distribution"):
+            L.ngsld_multi_last_distribution.argtypes = []
         L.ngsld_host_read_geno_bin_range.argtypes = [C.c_char_p, u64, u64, u64, vp, C.c_char_p, C.c_size_t]
         L.ngsld_host_set_threads.argtypes = [C.c_int]
         L.ngsld_host_set_threads.restype = None
@@ -389,6 +391,26 @@ def run_multi(raw: np.ndarray, pos_dist: np.ndarray | None, devices: list[int], 
             out.append((cat(a["s1"], np.uint64), cat(a["s2"], np.uint64), cat(a["std"], REC_STD),
                         cat(a["ext"], REC_EXT) if p.extend_out else None))
     return out, maf, [int(v) for v in per]
+
+
+DIST_NAMES = {0: "none", 1: "upload", 2: "peer_copy", 3: "rccl"}
+
+
+def multi_last_distribution() -> str:
+    """How the last run_multi of this process handed the matrix to its devices: "upload" (slab by slab), "peer_copy"
+    (device to device from the first) or "rccl" (one ncclBroadcast over xGMI)."""
+    return DIST_NAMES[int(lib().ngsld_multi_last_distribution())]
+
+
+def device_count() -> int:
+    """GPUs visible to this process (hipGetDeviceCount through the library's own runtime; 0 without a GPU)."""
+    n = 0
+    while n < 64:
+        free, total = C.c_uint64(0), C.c_uint64(0)
+        if lib().ngsld_device_memory(n, C.byref(free), C.byref(total)) != OK:
+            break
+        n += 1
+    return n
 
 
 def read_geno_text(path: str, in_probs: bool, log_scale: bool, n_ind: int, n_sites: int) -> tuple[np.ndarray, bool]:

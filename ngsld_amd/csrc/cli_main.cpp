@@ -177,13 +177,29 @@ void parse_cmd_args(Params *pars, int argc, char **argv) {
   if (pars->n_threads > 4096) pars->n_threads = 4096;
 }
 
-ngsld_gz *g_gz = nullptr;  // --out *.gz: the compressor behind pars.out_fh
+ngsld_gz *g_gz = nullptr;     // --out *.gz: the compressor behind pars.out_fh
+FILE *g_gz_fh = nullptr;      // ... and the stream over the compressor's pipe (owns the pipe's write descriptor)
+// Ends the compressed file: the stream first (what stdio still buffers goes into the pipe, and the pipe's write end is
+// closed exactly once, by its owner), then the compressor.  Registered with atexit, so that error() exits end the file
+// too -- atexit handlers run BEFORE stdio flushes its streams, hence the explicit fclose here.
 void finish_gz() {
+  if (g_gz_fh != nullptr) {
+    FILE *fh = g_gz_fh;
+    g_gz_fh = nullptr;
+    fclose(fh);
+  }
   if (g_gz != nullptr) {
     ngsld_gz *g = g_gz;
     g_gz = nullptr;
     if (ngsld_host_gz_close(g) != NGSLD_OK) fprintf(stderr, "\nERROR: the compressed output is incomplete\n");
   }
+}
+// fclose(pars.out_fh) for every path out of main
+void close_output(FILE *fh) {
+  if (fh != nullptr && fh == g_gz_fh)
+    finish_gz();
+  else if (fh != nullptr)
+    fclose(fh);
 }
 
 struct SinkState {
@@ -313,7 +329,7 @@ bool run_streamed(Params &pars, uint64_t slab_sites, bool may_fall_back) {
   if (rc == NGSLD_ERR_MAF_RANGE) error("haplo_freq", err);
   if (rc != NGSLD_OK) error("ngsld_run_streamed", rs.err[0] ? rs.err : err);
   if (pars.verbose >= 1) fprintf(stderr, "==> Freeing memory...\n");
-  fclose(pars.out_fh);
+  close_output(pars.out_fh);
   ngsld_host_free_pos(pos);
   if (pars.verbose >= 1) fprintf(stderr, "Done!\n");
   return true;
@@ -415,7 +431,7 @@ void run_multi(Params &pars, const double *raw, int text_semantics, int log_scal
     if (!part_names[(size_t)k].empty()) unlink(part_names[(size_t)k].c_str());
   }
   if (pars.verbose >= 1) fprintf(stderr, "==> Freeing memory...\n");
-  fclose(pars.out_fh);
+  close_output(pars.out_fh);
   ngsld_host_free_pos(pos);
   if (pars.verbose >= 1) fprintf(stderr, "Done!\n");
 }
@@ -449,7 +465,7 @@ int main(int argc, char **argv) {
     int wfd = -1;
     if (ngsld_host_gz_open(pars.out, (int)pars.n_threads, &g_gz, &wfd) != NGSLD_OK)
       error(__FUNCTION__, "cannot open output file!");
-    pars.out_fh = fdopen(wfd, "w");
+    pars.out_fh = g_gz_fh = fdopen(wfd, "w");
     atexit(finish_gz);  // every path out of main (the streamed and the multi-device runs return early) ends the file
   } else if (pars.out != NULL) {
     pars.out_fh = fopen(pars.out, "w");
@@ -685,7 +701,7 @@ int main(int argc, char **argv) {
 
   // ---- free memory (ngsLD.cpp:205-222) ----
   if (pars.verbose >= 1) fprintf(stderr, "==> Freeing memory...\n");
-  fclose(pars.out_fh);
+  close_output(pars.out_fh);
   ngsld_host_free_pos(pos);
   ngsld_destroy(ctx);
   timing_report.mark("free");

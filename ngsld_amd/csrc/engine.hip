@@ -210,6 +210,8 @@ struct ngsld_ctx {
 
 namespace {
 
+int finish_device_run(ngsld_ctx *c);  // (defined below: waits for a run left on a caller's stream and replays what it flagged)
+
 int fail(ngsld_ctx *c, int code, const std::string &msg) {
   if (c) c->err = msg;
   return code;
@@ -255,13 +257,16 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
     return fail(c, NGSLD_ERR_UNSUPPORTED, "n_ind is outside the supported range");
   HIP_TRY(c, hipSetDevice(c->device));
   (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
+  {  // a run left on a caller's stream is finished under the matrix and plan it was started with
+    const int rcp = finish_device_run(c);
+    if (rcp != NGSLD_OK) return rcp;
+  }
   c->have_geno = false;
   c->planned = false;
   c->text_mode = false;  // labels belong to a matrix
   c->replay_read = nullptr;  // and so does the replay source
   c->replay_user = nullptr;
   c->replay_matrix = nullptr;
-  c->dev_run.pending = false;
   c->gopts = o;
   c->normalised = normalised;
   c->n_sites = n_sites;
@@ -905,6 +910,10 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
   HIP_TRY(c, hipSetDevice(c->device));
   (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
   Range range_("ngsld:plan");
+  {  // a run left on a caller's stream still needs the CURRENT plan (record index -> pair) for its replay
+    const int rcp = finish_device_run(c);
+    if (rcp != NGSLD_OK) return rcp;
+  }
   const uint64_t n = c->n_sites;
   c->params = *p;
   c->planned = false;
@@ -912,7 +921,6 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
     return fail(c, NGSLD_ERR_INVALID, "proportion of comparisons to sample must be in ]0,1]!");
   const bool sampling = p->rnd_sample > 0 && p->rnd_sample < 1;
   c->replayed_sites = 0;
-  c->dev_run.pending = false;
   if (c->replay_on && (c->replay_read != nullptr || c->replay_matrix != nullptr) && !c->normalised) {
     // A frequency that ties --min_maf to the last bits falls on either side of `maf < min_maf` (ngsLD.cpp:264-275)
     // depending on the order est_maf adds its terms up in (the prep kernel block-reduces them), and one that sits on a
@@ -1096,6 +1104,13 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
   HIP_TRY(c, hipSetDevice(c->device));
   (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
   Range range_("ngsld:run_device (pair kernels)");
+  {
+    // One pending run per context: the flag buffer and the record pointers of a run on a caller's stream are single.  A second
+    // run before ngsld_finish_device first finishes the earlier one (waits for its stream, replays what it flagged) -- clearing
+    // the flags under kernels still setting them would leave those records with the kernels' unreplayed values.
+    const int rcp = finish_device_run(c);
+    if (rcp != NGSLD_OK) return rcp;
+  }
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
   c->ev_used = 0;
   c->timed_stream = st;
@@ -1142,12 +1157,15 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   HIP_TRY(c, hipSetDevice(c->device));
   (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
   Range range_("ngsld:run");
+  {
+    const int rcp = finish_device_run(c);  // (see ngsld_run_device)
+    if (rcp != NGSLD_OK) return rcp;
+  }
   const bool ext = c->params.extend_out != 0;
   c->ev_used = 0;
   c->timed_stream = c->stream;
   c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
   c->replayed_pairs = 0;
-  c->dev_run.pending = false;
   const bool replay = c->replay_on;
 
   // Device-side TSV: the dist column needs prefix sums of pos_dist that are EXACT (the host writer adds the gaps one

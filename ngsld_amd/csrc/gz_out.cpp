@@ -4,6 +4,7 @@
 // block is deflated on its own by one of n_threads workers into a complete gzip member, and the members are written to
 // the file in order.  A concatenation of gzip members is a valid .gz file (gzip -d, zcat, zlib's gzread all read through
 // it), so the output is what `ngsLD ... | gzip` would produce in content, at n_threads times the speed.
+#include <errno.h>
 #include <fcntl.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -20,7 +21,7 @@
 #include "../../include/ngsld_host.h"
 
 struct ngsld_gz {
-  int fd_out = -1, fd_read = -1, fd_write = -1;
+  int fd_out = -1, fd_read = -1;  // (the pipe's write end belongs to the caller from ngsld_host_gz_open on)
   int level = 1;
   size_t block = 4u << 20;
   struct Slot {
@@ -56,19 +57,36 @@ bool deflate_member(ngsld_gz::Slot &s, int level) {
   return rc == Z_STREAM_END;
 }
 
+// After a failure (a write error such as ENOSPC / EIO, a deflate error) the pipe is still read -- and its content thrown
+// away -- until the producer closes its end: a producer blocked in write() on a full pipe that nobody drains would never
+// get to close it, and the process would hang holding the device.  ngsld_host_gz_close then reports the failure.
+void drain_pipe(ngsld_gz *g) {
+  std::vector<unsigned char> scratch(1u << 20);
+  for (;;) {
+    const ssize_t r = ::read(g->fd_read, scratch.data(), scratch.size());
+    if (r == 0) break;
+    if (r < 0 && errno != EINTR) break;
+  }
+}
+
 void reader_loop(ngsld_gz *g) {
   const size_t n_slots = g->slots.size();
+  bool failed = false;
   for (;;) {
     ngsld_gz::Slot *s;
     {
       std::unique_lock<std::mutex> lk(g->mu);
       s = &g->slots[g->next_fill % n_slots];
       g->cv.wait(lk, [&] { return s->state == 0 || g->failed; });
-      if (g->failed) break;
+      if (g->failed) {
+        failed = true;
+        break;
+      }
     }
     size_t got = 0;
     while (got < g->block) {
       const ssize_t r = ::read(g->fd_read, s->in.data() + got, g->block - got);
+      if (r < 0 && errno == EINTR) continue;
       if (r < 0) {
         std::lock_guard<std::mutex> lk(g->mu);
         g->failed = true;
@@ -78,11 +96,11 @@ void reader_loop(ngsld_gz *g) {
       got += (size_t)r;
     }
     std::lock_guard<std::mutex> lk(g->mu);
-    if (got == 0 || g->failed) {
-      g->eof = true;
-      g->cv.notify_all();
+    if (g->failed) {
+      failed = true;
       break;
     }
+    if (got == 0) break;
     s->n_in = got;
     s->index = g->next_fill++;
     s->state = 1;
@@ -92,9 +110,12 @@ void reader_loop(ngsld_gz *g) {
       break;
     }
   }
-  std::lock_guard<std::mutex> lk(g->mu);
-  g->eof = true;
-  g->cv.notify_all();
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->eof = true;
+    g->cv.notify_all();
+  }
+  if (failed) drain_pipe(g);
 }
 
 void worker_loop(ngsld_gz *g) {
@@ -131,6 +152,7 @@ void writer_loop(ngsld_gz *g) {
     bool bad = false;
     while (left && !bad) {
       const ssize_t w = ::write(g->fd_out, q, left);
+      if (w < 0 && errno == EINTR) continue;
       if (w <= 0) bad = true;
       else { q += w; left -= (size_t)w; }
     }
@@ -167,14 +189,13 @@ int ngsld_host_gz_open(const char *path, int n_threads, ngsld_gz **out, int *fd_
   (void)fcntl(p[1], F_SETPIPE_SZ, 1 << 20);
 #endif
   g->fd_read = p[0];
-  g->fd_write = p[1];
   g->slots.resize((size_t)n_threads * 2 + 2);
   for (auto &s : g->slots) s.in.resize(g->block);
   g->reader = std::thread(reader_loop, g);
   g->writer = std::thread(writer_loop, g);
   for (int t = 0; t < n_threads; ++t) g->workers.emplace_back(worker_loop, g);
   *out = g;
-  *fd_to_write = g->fd_write;
+  *fd_to_write = p[1];
   return NGSLD_OK;
 } catch (...) {
   return NGSLD_ERR_NOMEM;
@@ -182,7 +203,8 @@ int ngsld_host_gz_open(const char *path, int n_threads, ngsld_gz **out, int *fd_
 
 int ngsld_host_gz_close(ngsld_gz *g) {
   if (g == nullptr) return NGSLD_ERR_INVALID;
-  if (g->fd_write >= 0) ::close(g->fd_write);  // (a caller that fdopen'ed it has fclose'd it already: EBADF is harmless)
+  // The caller has closed (or fclose'd) the write end -- it owns that descriptor; closing it here by number, after the caller
+  // did, could hit an unrelated descriptor that another thread was handed in between.  The reader sees EOF and winds down.
   g->reader.join();
   for (auto &w : g->workers) w.join();
   g->writer.join();

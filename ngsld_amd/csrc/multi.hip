@@ -31,7 +31,12 @@
 
 #include "../../include/ngsld.h"
 
+#include <atomic>
+
 namespace {
+
+// how the last ngsld_run_multi of this process distributed the matrix (ngsld_multi_last_distribution)
+std::atomic<int> g_last_distribution{NGSLD_DIST_NONE};
 
 void set_err(char *err, size_t errlen, const std::string &msg) {
   if (err != nullptr && errlen > 0) std::snprintf(err, errlen, "%s", msg.c_str());
@@ -262,6 +267,7 @@ int ngsld_run_multi(const int *devices, int n_devices, uint64_t n_sites, uint64_
     }
     (void)hipGetLastError();  // a handled failure must not surface later as some launch's "last error"
   }
+  g_last_distribution.store(broadcast ? (used_rccl ? NGSLD_DIST_RCCL : NGSLD_DIST_PEER_COPY) : NGSLD_DIST_UPLOAD);
   if (const char *v = std::getenv("NGSLD_MULTI_VERBOSE"))
     if (std::strcmp(v, "0") != 0)
       std::fprintf(stderr, "ngsld_run_multi: %d parts, matrix %s\n", n,
@@ -390,5 +396,7 @@ int ngsld_run_multi(const int *devices, int n_devices, uint64_t n_sites, uint64_
   set_err(err, errlen, "out of host memory");
   return NGSLD_ERR_NOMEM;
 }
+
+int ngsld_multi_last_distribution(void) { return g_last_distribution.load(); }
 
 }  // extern "C"

@@ -247,5 +247,25 @@ def test_gz_output_writer_round_trip(tmp_path):
     path = str(tmp_path / "empty.gz")
     h, fd = C.c_void_p(), C.c_int(-1)
     assert L.ngsld_host_gz_open(path.encode(), 2, C.byref(h), C.byref(fd)) == capi.OK
+    os.close(fd.value)                                        # the write end is the caller's to close
     assert L.ngsld_host_gz_close(h) == capi.OK
     assert os.path.getsize(path) == 0
+
+
+@pytest.mark.timeout(120)
+def test_gz_output_write_error_does_not_block_the_producer():
+    """A write error on the compressed file (/dev/full: ENOSPC on every write) must not leave the producer blocked on a full
+    pipe: the rest of the stream is read and dropped, every byte is accepted, and ngsld_host_gz_close reports the failure."""
+    import ctypes as C
+    import os
+    if not os.path.exists("/dev/full"):
+        pytest.skip("no /dev/full here")
+    L = capi.lib()
+    data = os.urandom(1 << 20) * 48                           # 48 MiB: far beyond the slots (2 threads: 6 x 4 MiB) + the pipe
+    h, fd = C.c_void_p(), C.c_int(-1)
+    assert L.ngsld_host_gz_open(b"/dev/full", 2, C.byref(h), C.byref(fd)) == capi.OK
+    off = 0
+    while off < len(data):
+        off += os.write(fd.value, data[off:off + (1 << 20)])
+    os.close(fd.value)
+    assert L.ngsld_host_gz_close(h) != capi.OK
