@@ -433,9 +433,8 @@ def main():
                          "frac_is": "algorithmic bytes per pair x pairs per launch / kernel time, over the HBM peak -- NOT the "
                                     "HBM utilisation: the row vector is shared through LDS and the window is re-read from L2 / "
                                     "Infinity Cache (`traffic`); the binding roofline is fp64_valu",
-                         "kernel": {"group": "pair_ld_group_kernel", "run": "pair_ld_run_kernel", "wave": "pair_ld_pf_kernel",
+                         "kernel": {"group": "pair_ld_group_kernel", "run": "pair_ld_run_kernel", "ab": "pair_ld_ab_kernel",
                                     "multi": "pair_ld_kernel (multi-wavefront)", "stream": "pair_ld_stream_kernel",
-                                    "direct": "pair_ld_kernel (no prefetch)",
                                     "hard": "pair_ld_hard_kernel (genotype-combination counts)"}.get(family, family),
                          "kernel_ms_per_launch": launch_s * 1e3,
                          "algorithmic_bytes_per_pair": bytes_pair,

@@ -153,8 +153,8 @@ struct ngsld_ctx {
   uint64_t n_items = 0;
 
   // tuning
-  // kernel family selection for A/B runs: NGSLD_PAIR_KERNEL=direct (no prefetch anywhere) | wave (no row kernel)
-  bool prefetch = true, row_kernel = true, run_kernel = true, ab_kernel = false;
+  // kernel family selection for tests and A/B runs: NGSLD_PAIR_KERNEL=multi | ab (PairChoice)
+  int kernel_choice = kChooseAuto;
   uint32_t pairs_per_item = 16;
   uint64_t batch_pairs = 1ull << 23;
 
@@ -253,7 +253,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   if (normalised && maf == nullptr) return fail(c, NGSLD_ERR_INVALID, "maf missing");
   if (n_sites >= 0xffffffffull) return fail(c, NGSLD_ERR_UNSUPPORTED, "n_sites must be below 2^32 - 1");
   PairConfig cfg;
-  if (!pair_config(n_ind, c->prefetch, c->row_kernel, &cfg, c->run_kernel, c->ab_kernel))
+  if (!pair_config(n_ind, &cfg, c->kernel_choice))
     return fail(c, NGSLD_ERR_UNSUPPORTED, "n_ind is outside the supported range");
   HIP_TRY(c, hipSetDevice(c->device));
   (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
@@ -295,6 +295,10 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   a.normalised_input = normalised ? 1 : 0;
   a.text_semantics = o.text_semantics;
   a.call_geno = o.call_geno;
+  {
+    const char *pe = std::getenv("NGSLD_PREP_EXACT");  // tests: every triple through the reference's log / exp chain
+    a.exact_chain = (pe != nullptr && std::strcmp(pe, "0") != 0) ? 1 : 0;
+  }
   a.N_thresh = o.N_thresh;
   a.call_thresh = o.call_thresh;
   a.maf = c->d_maf.p;
@@ -356,7 +360,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   int &all_hard = c->h_all_hard;  // (ctx-owned: the asynchronous copies below must not target a stack frame an early return leaves)
   all_hard = 0;
   const char *hk = std::getenv("NGSLD_HARD_KERNEL");
-  const bool try_hard = c->prefetch && n_ind <= kHardMaxInd && !o.per_individual_only && !(hk != nullptr && std::strcmp(hk, "0") == 0);
+  const bool try_hard = n_ind <= kHardMaxInd && !o.per_individual_only && !(hk != nullptr && std::strcmp(hk, "0") == 0);
   if (try_hard) {
     c->mask_words = (uint32_t)((n_ind + 63) / 64);
     HIP_TRY(c, c->d_hard_masks.resize((size_t)n_sites * 4 * c->mask_words));
@@ -769,11 +773,9 @@ int ngsld_create(int device, ngsld_ctx **out) {
   if (c == nullptr) return NGSLD_ERR_NOMEM;
   c->device = device;
   if (const char *k = std::getenv("NGSLD_PAIR_KERNEL")) {
-    c->prefetch = std::strcmp(k, "direct") != 0;
-    c->row_kernel = std::strcmp(k, "wave") != 0;
-    c->run_kernel = std::strcmp(k, "item") != 0;  // "item": one workgroup per item (pair_ld_pf_kernel), the run kernel's baseline
-    c->ab_kernel = std::strcmp(k, "ab") == 0;  // "ab": 513..1024 individuals on ONE wavefront per pair, EM step in its a/b form
-                                               // (ld_pair_ab.hip: built, measured against the two-wavefront kernel, not the default)
+    // "multi": several wavefronts per pair from 513 individuals on; "ab": 513..1024 individuals on ONE wavefront per pair, EM
+    // step in its a/b form (pair_config picks between them, and the ten-slot run kernel, by measurement)
+    c->kernel_choice = std::strcmp(k, "multi") == 0 ? kChooseMulti : (std::strcmp(k, "ab") == 0 ? kChooseAB : kChooseAuto);
   }
   if (const char *k = std::getenv("NGSLD_BATCH_PAIRS")) {  // tests: many small batches through ngsld_run
     const uint64_t v = std::strtoull(k, nullptr, 10);
@@ -1422,11 +1424,9 @@ int ngsld_last_kernel_time(ngsld_ctx *c, double *total_ms, uint64_t *n_launches,
 
 const char *ngsld_pair_kernel(const ngsld_ctx *c) {
   if (c == nullptr || !c->have_geno) return "";
-  switch (c->cfg.kernel) {
+  switch (effective_kernel(c->cfg, c->params.ignore_miss_data != 0)) {
     case kGroup: return "group";
-    case kWave: return "wave";
     case kMulti: return "multi";
-    case kDirect: return "direct";
     case kStream: return "stream";
     case kRun: return "run";
     case kHard: return "hard";
@@ -1505,7 +1505,7 @@ int ngsld_window_ends(const double *pos_dist, uint64_t n_sites, const ngsld_para
 
 uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes) {
   PairConfig cfg;
-  if (!pair_config(n_ind, true, true, &cfg)) return 0;
+  if (!pair_config(n_ind, &cfg)) return 0;  // (the engine's own default selection: the slabs hold what it will allocate)
   // per context: planes (24*np per site) + maf/mean/rsx + row tables (~64 B per site), two record slots of
   // batch_pairs records, two staging chunks of 256 MiB, items; the fixed part is rounded up generously
   const uint64_t fixed = (2ull * (1ull << 23) * (sizeof(ngsld_rec_std) + sizeof(ngsld_rec_ext))) + (768ull << 20);

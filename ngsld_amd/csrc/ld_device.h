@@ -21,14 +21,8 @@
 
 namespace ngsld {
 
-#ifndef NGSLD_PAIR_RCP
-#define NGSLD_PAIR_RCP 2  // build-time A/B switch of em_pair's reciprocals: 0 = one v_rcp_f64 per individual,
-                         // 1 = one per two individuals, 2 = one per lane (product tree over all slots)
-#endif
-#ifndef NGSLD_DROP0
-#define NGSLD_DROP0 1     // build-time A/B switch: 1 = hap_freq[0] is recovered from sum_k f_k = 1 instead of being accumulated
-#endif
-constexpr bool kDrop0 = NGSLD_DROP0 != 0;
+// Build-time tuning knobs (tools/build_variant.sh); everything that was measured and lost is gone from this file, its
+// numbers are in DESIGN.md section 5.
 #ifndef NGSLD_PRIO_S  // issue priority per stretch of an EM iteration (swept on the bench: differences of +-0.5 %)
 #define NGSLD_PRIO_S 0
 #define NGSLD_PRIO_TREE 3
@@ -36,34 +30,12 @@ constexpr bool kDrop0 = NGSLD_DROP0 != 0;
 #define NGSLD_PRIO_SERIAL 3
 #endif
 #ifndef NGSLD_SETPRIO
-#define NGSLD_SETPRIO 1  // build-time A/B switch: issue priority raised through the serial phases of an EM iteration
-#endif
-#ifndef NGSLD_WN_ROWS
-#define NGSLD_WN_ROWS 1  // build-time A/B switch: several wavefronts per pair post their partial sums without v_readlane
-#endif
-#ifndef NGSLD_XCH_ASM
-#define NGSLD_XCH_ASM 1  // build-time A/B switch: two / four wavefronts per pair trade their partial sums through LDS accesses the
-                        // compiler does not see (lds_post / lds_gather), so that it cannot order them behind the slice copy in flight
-#endif
-// (same-box A/B, tools/ab_xch.sh: +0.8 % at n_ind 1000, +2.9 % at 2000.  Eight wavefronts per pair lost 4.5 % at n_ind 4000
-// with 12 such reads -- 48 registers of partials in flight: there every lane reads ONE partial and the eight of a value are
-// added by three DPP steps inside their eight lanes, see em_pair.)
-#ifndef NGSLD_PARKED
-#define NGSLD_PARKED 1  // build-time A/B switch: no meeting of a pair's wavefronts for the Pearson moment (pair_ld_kernel, kParked)
-#endif
-template <int WAVES>
-constexpr bool kXchAsm = NGSLD_XCH_ASM != 0 && WAVES > 1 && WAVES <= 8;
-#ifndef NGSLD_MASK_DONE
-#define NGSLD_MASK_DONE 1  // build-time A/B switch: converged groups of a lockstep wavefront are masked off (see pair_ld_group_kernel)
+#define NGSLD_SETPRIO 1  // issue priority raised through the serial phases of an EM iteration (round 3, same box: off = -3.5 %)
 #endif
 #ifndef NGSLD_MASK_SLOTS
-#define NGSLD_MASK_SLOTS 6  // ... from this many individuals per lane on (measured: 3, 4, 5 slots lose 2.5 %, 6 gains 2 %, 7-8 gain 5.5-7 %)
+#define NGSLD_MASK_SLOTS 6  // lockstep kernels: converged groups are masked off from this many individuals per lane on
+                            // (measured: 3, 4, 5 slots lose 2.5 %, 6 gains 2 %, 7-8 gain 5.5-7 %)
 #endif
-#ifndef NGSLD_EARLY_EPS
-#define NGSLD_EARLY_EPS 1  // build-time A/B switch: the convergence test looks at one change first (see em_pair)
-#endif
-constexpr bool kPairRcp = NGSLD_PAIR_RCP != 0;
-constexpr bool kTreeRcp = NGSLD_PAIR_RCP == 2;
 constexpr int kIterMax = 100;      // ITER_MAX, gen_func.hpp:18
 constexpr double kEpsilon = 1e-5;  // EPSILON,  gen_func.hpp:16
 
@@ -74,10 +46,17 @@ constexpr double kEpsilon = 1e-5;  // EPSILON,  gen_func.hpp:16
 //     margins) are only reproducible to 1e-16 / q -- below 2^-16 that is no longer safely inside 1e-9, and at q ~ 1e-16
 //     the noise alone decides between nan, 0 and inf -- or any frequency is NaN;
 //   * eps came within kTieMargin of EPSILON in some iteration (gen_func.cpp:1054: nIter could differ by one);
-//   * one of its sites has expected genotypes that are constant up to rounding (negative rsx, see prep_sites_kernel):
-//     gsl_stats_correlation is then a 0/0-type quotient of its own accumulation noise (ngsLD.cpp:365-367).
+//   * the Pearson cross moment is ill conditioned for THIS pair (kPearsonCond): sites whose expected genotypes are nearly
+//     constant -- at the extreme gsl_stats_correlation is a 0/0-type quotient of its own accumulation noise
+//     (ngsLD.cpp:365-367).
 constexpr double kReplayBelow = 0x1p-16;  // (at 2^-18 a 39,000-case soak showed differences up to 1.1e-10 just above the threshold: a 9x margin to the 1e-9 bar; 2^-16 makes it ~36x)
 constexpr double kTieMargin = 1e-12;
+// r = sxy * rsx1 * rsx2 with sxy = sum e1 e2 - n mean1 mean2: the cancellation leaves ~20 ulp * n * size1 * size2 of noise
+// in sxy (size = the expected genotypes' magnitude, <= 2), i.e. |delta r2| <~ 1.8e-14 * n * rsx1 * rsx2.  Pairs with
+// n * rsx1 * rsx2 = 1 / (std1 * std2) above 2^13 are replayed: the bound is then 1.4e-10, a seventh of the 1e-9 bar.
+// (Round 2 marked SITES -- std below 1/500 of the size -- and replayed all their pairs: low-information sites of low-depth
+// data ran at the host's speed although next to an ordinary partner, std ~ 0.5, their r2_ExpG is good to 1e-11.)
+constexpr double kPearsonCond = 0x1p13;
 constexpr double kEpsilonTie = kEpsilon + kTieMargin;
 constexpr uint32_t kTieBit = 0x80000000u;  // rides on n_iter (<= 100) from the EM loop to write_pair
 
@@ -188,53 +167,6 @@ __device__ __forceinline__ void wave_sum4(double &t0, double &t1, double &t2, do
   t3 = read_lane(w, 48);
 }
 
-// Three values through the MATRIX pipe -- built, measured, NOT used (NGSLD_MFMA_REDUCE = 0).  v_mfma_f64_4x4x4_4b is a
-// cross-lane adder: D_b[i][j] = sum_k A_b[i][k] B_b[k][j] with (measured, tools/probe_mfma_f64.hip)
-//   block b = (lane / 4) % 4;   A: i = lane % 4, k = lane / 16;   B: j = lane % 4, k = lane / 16;   D: i = lane / 16, j = lane % 4
-// i.e. it sums over the four 16-lane ROWS and hands the A operand's position-in-quad (lane % 4) to the output ROW.
-//   stage 1  e_v = mfma(t_v, ones): lane l holds sum_rows t_v[(l / 16) + 4 b + 16 k] -- 16 column sums, spread over
-//            (row, b), the same in the four lanes of a quad
-//   stage 2  (1) p = sum_v mfma(e_v, sel_v) chained through C, sel_v[k][j] = (j == v): lane l holds the sum of value
-//            (l % 4)'s four column sums of quad b;  (2) the e_v packed by lane % 4 with selects, one mfma(w, ones): row v
-//            holds value v's quad sums
-//   stage 3  the four quads of a row: two DPP levels (row_ror:4, row_ror:8) on the ONE packed register
-// On paper 6 (or 4) MFMA issues + 4 DPP moves + 2 adds + 6 v_readlane replace 6 v_permlane*_swap (~14 cycles of issue
-// each) + 2 moves + 8 DPP moves + 7 adds + 6 v_readlane.  Same-box A/B on the bench (tools/ab.sh): variant 1 -2.3 %,
-// variant 2 -1.7 % against the swap / DPP reduction: the f64 matrix peak of gfx950 EQUALS its f64 vector peak, and the
-// measurement says why -- an f64 MFMA is not free issue beside the f64 VALU stream, a 4-pass one costs more than the
-// ~14-cycle swap it replaces.  Kept as a build-time switch with its self test (ngsld_selftest covers wave_sum3).
-#ifndef NGSLD_MFMA_REDUCE
-#define NGSLD_MFMA_REDUCE 0  // build-time A/B switch: 0 = the permlane-swap / DPP reduction below, 1 / 2 = the variants above
-#endif
-__device__ __forceinline__ void wave_sum3_mfma(double &t1, double &t2, double &t3) {
-  const unsigned q = threadIdx.x & 3u;  // lane % 4 (a wavefront starts at a multiple of 64)
-  const double one = 1.0;
-  const double sel0 = q == 0u ? 1.0 : 0.0, sel1 = q == 1u ? 1.0 : 0.0, sel2 = q == 2u ? 1.0 : 0.0;
-  const double e1 = __builtin_amdgcn_mfma_f64_4x4x4f64(t1, one, 0.0, 0, 0, 0);
-  const double e2 = __builtin_amdgcn_mfma_f64_4x4x4f64(t2, one, 0.0, 0, 0, 0);
-  const double e3 = __builtin_amdgcn_mfma_f64_4x4x4f64(t3, one, 0.0, 0, 0, 0);
-  double p;
-  if (NGSLD_MFMA_REDUCE == 2) {  // variant: the three stage-1 results packed by lane % 4 with selects, ONE stage-2 MFMA
-    const double w = q == 0u ? e1 : (q == 1u ? e2 : e3);
-    // as the A operand, position-in-quad i' = lane % 4 goes to the output ROW: row v ends up with value v's quad sums
-    p = __builtin_amdgcn_mfma_f64_4x4x4f64(w, one, 0.0, 0, 0, 0);
-    p += dpp_mov<0x124>(p);
-    p += dpp_mov<0x128>(p);
-    t1 = read_lane(p, 0);
-    t2 = read_lane(p, 16);
-    t3 = read_lane(p, 32);
-    return;
-  }
-  p = __builtin_amdgcn_mfma_f64_4x4x4f64(e1, sel0, 0.0, 0, 0, 0);
-  p = __builtin_amdgcn_mfma_f64_4x4x4f64(e2, sel1, p, 0, 0, 0);
-  p = __builtin_amdgcn_mfma_f64_4x4x4f64(e3, sel2, p, 0, 0, 0);
-  p += dpp_mov<0x124>(p);  // row_ror:4
-  p += dpp_mov<0x128>(p);  // row_ror:8
-  t1 = read_lane(p, 0);
-  t2 = read_lane(p, 1);
-  t3 = read_lane(p, 2);
-}
-
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov_rows(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -245,34 +177,21 @@ __device__ __forceinline__ double dpp_mov_rows(double v) {
 
 // Three values: same scheme, and the third goes into the second fold UNFOLDED -- its rows 0+1 end up in row 1, its rows
 // 2+3 in row 3, and once the rows are summed one GFX9 row broadcast (lane 31 into row 3: two DPP moves and an add) joins
-// the halves.  That replaces folding the third value with itself first (two more v_permlane32_swap at ~14 cycles of issue
-// each, NGSLD_FOLD_T3 = 1: the earlier form).  Every lane of row 0 then holds the sum of t1, of row 2 that of t2, of row
-// 3 that of t3.
-#ifndef NGSLD_FOLD_T3
-#define NGSLD_FOLD_T3 0  // build-time A/B switch
-#endif
+// the halves (folding the third value with itself first took two more v_permlane32_swap at ~14 cycles of issue each:
+// -1.1 % on configs[2]).  Every lane of row 0 then holds the sum of t1, of row 2 that of t2, of row 3 that of t3.
+// (The same reduction on the MATRIX pipe -- v_mfma_f64_4x4x4 with a ones / selector operand as a cross-lane adder -- was
+// built and measured at -1.7 ... -2.3 %: an f64 MFMA is not free issue beside an f64 VALU stream.  DESIGN.md section 5.)
 __device__ __forceinline__ double wave_sum3_rows(double t1, double t2, double t3) {
   double z12 = fold32(t1, t2);
-  double w = fold16(z12, NGSLD_FOLD_T3 ? fold32(t3, t3) : t3);  // row0: t1, row2: t2, rows 1 / 3: t3 (whole, or by halves)
+  double w = fold16(z12, t3);  // row0: t1, row2: t2, rows 1 / 3: t3 by halves
   w += dpp_mov<0x128>(w);
   w += dpp_mov<0x124>(w);
   w += dpp_mov<0x4E>(w);
   w += dpp_mov<0xB1>(w);
-  if (!NGSLD_FOLD_T3) w += dpp_mov_rows<0x143, 0x8>(w);  // row_bcast:31 into row 3
+  w += dpp_mov_rows<0x143, 0x8>(w);  // row_bcast:31 into row 3
   return w;
 }
 __device__ __forceinline__ void wave_sum3(double &t1, double &t2, double &t3) {
-  if (NGSLD_MFMA_REDUCE) {
-    wave_sum3_mfma(t1, t2, t3);
-    return;
-  }
-  if (NGSLD_FOLD_T3) {
-    const double w = wave_sum3_rows(t1, t2, t3);
-    t1 = read_lane(w, 0);
-    t2 = read_lane(w, 32);
-    t3 = read_lane(w, 48);
-    return;
-  }
   // as wave_sum3_rows, but only lane 48 of the last step is ever read: the broadcast needs no defined value (no zeroing
   // moves) in the rows it does not write
   double z12 = fold32(t1, t2);
@@ -418,7 +337,7 @@ struct SingleTag { static constexpr bool value = false; };
 typedef __attribute__((address_space(3))) void lds_void_t;        // operands of __builtin_amdgcn_global_load_lds
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
-// Allele relabelling (with kDrop0).  The frequency recovered from the other three carries an ABSOLUTE error of ~1e-16.
+// Allele relabelling.  The frequency recovered from the other three carries an ABSOLUTE error of ~1e-16.
 // That is harmless for the largest of the four and ruinous for a tiny one: with both sites nearly monomorphic the
 // denominators of D' and r2 are products of two small margins (1e-14, say), and 1e-16 in a hap00 of 1e-15 moved D' in
 // the third decimal.  So each site's alleles are labelled such that its estimated frequency is <= 1/2 -- a site with
@@ -431,8 +350,8 @@ struct Relabel {
 };
 __device__ __forceinline__ Relabel relabel(double m1, double m2, double mean1, double mean2) {
   Relabel r;
-  r.flip1 = kDrop0 && m1 > 0.5;
-  r.flip2 = kDrop0 && m2 > 0.5;
+  r.flip1 = m1 > 0.5;
+  r.flip2 = m2 > 0.5;
   r.m1 = r.flip1 ? 1.0 - m1 : m1;
   r.m2 = r.flip2 ? 1.0 - m2 : m2;
   r.mean1 = r.flip1 ? 2.0 - mean1 : mean1;  // expected genotype p1 + 2 p2 of a normalised triple becomes 2 - e
@@ -534,16 +453,23 @@ __device__ __forceinline__ uint32_t count_valid(uint32_t vbits) {
 //   WAVES > 1: the pair is spread over WAVES wavefronts, partial sums meet in xch (LDS, double buffered)
 //   TREE_DYN:  CHECK_ALL kernels without --ignore_miss_data (several wavefronts per pair): a wavefront whose lanes are
 //              all full up to the last slot -- every one but the pair's last -- still takes the one-reciprocal path
-//   pads:      (CHECK_ALL, one wavefront per pair) per-slot 0 / 1 from stage_pair: individuals without data have P == 0 and
-//              pad 1, so the one-reciprocal step runs over all slots although any of them may be empty
+//   pads:      (CHECK_ALL) per-slot 0 / 1 from stage_pair: individuals without data have P == 0 and pad 1, so the
+//              one-reciprocal step runs over all slots although any of them may be empty
 //   xpar:      (WAVES > 1) the caller's count of exchanges so far: its parity picks the half of xch an exchange uses.  Carried
 //              from pair to pair, consecutive exchanges alternate whatever the iteration counts were -- no barrier is needed
-//              between the last exchange of one pair and the first of the next (null: the parity of n_iter, which needs one)
+//              between the last exchange of one pair and the first of the next
+// Reciprocals.  ALL slots of a lane share one v_rcp_f64 (RcpTree).  Padding lanes of the last slot hold P == 0 (the prep
+// kernel zero-fills the planes beyond n_ind); `pad` = 1 there makes their s exactly 1, so they neither disturb the
+// product nor add anything to R.  s lies in (0, 1]; the product of SLOTS values can underflow (all below ~1e-38 for eight
+// slots), and that -- like any other non-finite outcome -- is caught by the sanity test on the new frequencies, after
+// which the iteration is redone with one reciprocal per individual before anything is concluded from it.  (One reciprocal
+// per individual, and one per two individuals, were the earlier forms: -9 % and -4 % against the tree at eight slots.)
 template <int SLOTS, int WAVES, bool CHECK_ALL, bool TREE_DYN = false>
 __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_t vbits, double inv_x, double m1,
                                             double m2, double &f0, double &f1, double &f2, double &f3,
                                             double (*xch)[WAVES][4], int sub, int lane, int *status,
                                             const double *pads = nullptr, uint32_t *xpar = nullptr) {
+  static_assert(WAVES == 1 || WAVES == 2 || WAVES == 4 || WAVES == 8, "em_pair: 1, 2, 4 or 8 wavefronts per pair");
   f0 = (1 - m1) * (1 - m2); f1 = (1 - m1) * m2; f2 = m1 * (1 - m2); f3 = m1 * m2;  // gen_func.cpp:1034-1037
   if (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1) {  // error() in the reference (:1030); reported through status
     if (lane == 0 && sub == 0) atomicExch(status, (int)NGSLD_ERR_MAF_RANGE);
@@ -556,41 +482,33 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   asm("" : "+v"(inv_x));
   bool bad = false, tie = false;
   uint32_t n_iter = 0;
-  // Slots known to be full (no padding / missing lanes) take their reciprocals two at a time:
-  //   r = 1/(s_a s_b),  1/s_a = s_b r,  1/s_b = s_a r      -- one 16-cycle v_rcp_f64 + 3 mul instead of two rcp chains.
-  // s lies in (0, 1]; the product can only underflow when both factors are below 1e-154, and that -- like any other
-  // non-finite outcome -- is caught by the sanity test on the new frequencies, after which the iteration is redone
-  // with one reciprocal per individual before anything is concluded from it.
-  // kTree: ALL slots of the lane share one reciprocal (RcpTree).  Padding lanes of the last slot hold P == 0 (the prep
-  // kernel zero-fills the planes beyond n_ind); `pad` = 1 there makes their s exactly 1, so they neither disturb the
-  // product nor add anything to R.  The product of SLOTS values underflows sooner than a pair's (all below ~1e-38 for
-  // eight slots); the same redo-with-single-reciprocals rule covers it.
-  constexpr int kPaired = CHECK_ALL ? 0 : (SLOTS - 1) / 2;
   const bool mask_tree = CHECK_ALL && !TREE_DYN && pads != nullptr;  // compile-time after inlining
-  constexpr bool kTree = kTreeRcp && SLOTS > 1;
+  constexpr bool kTree = SLOTS > 1;
   const double pad = ((vbits >> (SLOTS - 1)) & 1u) ? 0.0 : 1.0;
-  constexpr bool kScaled = kDrop0 && WAVES == 1;  // (several wavefronts per pair: partial sums are scaled after they met)
+  constexpr bool kScaled = WAVES == 1;  // (several wavefronts per pair: partial sums are scaled after they met)
   bool tree_ok = true;  // wavefront-uniform
   if (CHECK_ALL && kTree && !mask_tree) {
     constexpr uint32_t kNeed = (1u << (SLOTS - 1)) - 1u;  // padding (P == 0, no missing data here) in the last slot only
     tree_ok = TREE_DYN ? !__builtin_amdgcn_ballot_w64((vbits & kNeed) != kNeed) : false;
   }
-  // drop_tag: the step in its three-value form (hap 0 recovered from the sum) or in the full four-value form.  The
-  // shared-reciprocal step only exists in the three-value form; the step with one reciprocal per individual, which
-  // only ever runs outside the hot loop, in the full form -- and, where several wavefronts share a pair, in the
-  // three-value form too (all of them have to exchange the same values, and some take this step in every iteration).
-  auto em_step = [&](auto paired_tag, auto drop_tag, double &n0, double &n1, double &n2, double &n3) {
-    constexpr bool kPair = decltype(paired_tag)::value;
-    constexpr bool kDrop = kDrop0 && decltype(drop_tag)::value;
+  // tree_tag: the step with the shared reciprocal, or with one reciprocal per individual.  drop_tag: the step in its
+  // three-value form (hap 0 recovered from the sum) or in the full four-value form.  The shared-reciprocal step only exists
+  // in the three-value form; the step with one reciprocal per individual, which only ever runs outside the hot loop, in
+  // the full form -- and, where several wavefronts share a pair, in the three-value form too (all of them have to
+  // exchange the same values, and some take this step in every iteration).
+  auto em_step = [&](auto tree_tag, auto drop_tag, double &n0, double &n1, double &n2, double &n3) {
+    constexpr bool kShared = decltype(tree_tag)::value;
+    constexpr bool kDrop = decltype(drop_tag)::value;
+    static_assert(!kShared || (kTree && kDrop), "the shared-reciprocal step: several slots, three-value form");
     // products f_k f_h: they build the two-locus genotype weights W (s = sum_G W[G] P[G] is the
     // reference's 16-term `sum`, gen_func.cpp:1093-1096) and are reused by the t_k contraction below
     const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
     const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
     const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
     double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
-    if (NGSLD_SETPRIO && kPair && kTree) __builtin_amdgcn_s_setprio(NGSLD_PRIO_S);  // the dense s sums start here
+    if (NGSLD_SETPRIO && kShared) __builtin_amdgcn_s_setprio(NGSLD_PRIO_S);  // the dense s sums start here
     auto slot_s = [&](int j, bool padded = false) -> double {
-      // padded: see kTree above (pad = 1 where P == 0); mask_tree: every slot has its own pad
+      // padded: see above (pad = 1 where P == 0); mask_tree: every slot has its own pad
       double s = padded ? fma(p00, P[j][0], mask_tree ? pads[j] : pad) : p00 * P[j][0];
       s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
       s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
@@ -603,8 +521,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
       R3 = fma(P[j][3], r, R3); R4 = fma(P[j][4], r, R4); R5 = fma(P[j][5], r, R5);
       R6 = fma(P[j][6], r, R6); R7 = fma(P[j][7], r, R7); R8 = fma(P[j][8], r, R8);
     };
-    constexpr int kFirstSingle = kPair ? (kTree ? SLOTS : 2 * kPaired) : 0;
-    if constexpr (kPair && kTree) {
+    if constexpr (kShared) {
       double sv[SLOTS], rv[SLOTS];
 #pragma unroll
       for (int j = 0; j < SLOTS; ++j) sv[j] = slot_s(j, mask_tree || j == SLOTS - 1);
@@ -621,63 +538,50 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
 #pragma unroll
       for (int j = 0; j < SLOTS; ++j) slot_acc(j, rv[j]);
       if (NGSLD_SETPRIO) __builtin_amdgcn_s_setprio(NGSLD_PRIO_SERIAL);
-    }
+    } else {
 #pragma unroll
-    for (int q = 0; q < (kPair && !kTree ? kPaired : 0); ++q) {
-      const double sa = slot_s(2 * q), sb = slot_s(2 * q + 1);
-      const double r = rcp_refined(sa * sb);
-      slot_acc(2 * q, sb * r);
-      slot_acc(2 * q + 1, sa * r);
-    }
-#pragma unroll
-    for (int j = kFirstSingle; j < SLOTS; ++j) {
-      if ((!CHECK_ALL && j < SLOTS - 1) || ((vbits >> j) & 1u)) slot_acc(j, rcp_refined(slot_s(j)));
+      for (int j = 0; j < SLOTS; ++j) {
+        if ((!CHECK_ALL && j < SLOTS - 1) || ((vbits >> j) & 1u)) slot_acc(j, rcp_refined(slot_s(j)));
+      }
     }
     // t_k = sum_h f_k f_h R[G(k,h)]  (= this lane's share of ff_k / 2, gen_func.cpp:1098-1104)
     double t0 = kDrop ? 0.0 : fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0)));
     double t1 = fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1)));
     double t2 = fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3)));
     double t3 = fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4)));
-    if (NGSLD_WN_ROWS && WAVES > 1 && kDrop && !NGSLD_MFMA_REDUCE) {
+    if (WAVES > 1 && kDrop) {
       // several wavefronts per pair, three-value form: the row totals go to the exchange buffer from the lanes that hold
       // them (no v_readlane, no copies back to VGPRs), and every wavefront adds the partials up in the same order -- the
-      // new frequencies must be the same bit pattern in all of them, they decide together when to leave the loop
+      // new frequencies must be the same bit pattern in all of them, they decide together when to leave the loop.
+      // The LDS accesses are assembly (lds_post / lds_gather): the compiler must not order them behind the slice copy in flight.
       const double w = wave_sum3_rows(t1, t2, t3);
-      const int par = (int)((xpar != nullptr ? (*xpar)++ : n_iter) & 1u);
+      const int par = (int)((*xpar)++ & 1u);
       const int row = lane >> 4;
-      if (kXchAsm<WAVES>) {
-        // layout of one parity's buffer (WAVES * 32 bytes, as below): [value k = 0..2][wavefront] -- a value's partials side
-        // by side, WAVES / 2 reads of 16 bytes each; added up in the order of the wavefronts, as before
-        const uint32_t base = lds_addr(&xch[par][0][0]);
-        if ((lane & 15) == 0 && row != 1)  // rows 0 / 2 / 3 hold t1 / t2 / t3 (wave_sum3_rows)
-          lds_post(base + (uint32_t)((row == 0 ? 0 : row - 1) * WAVES + sub) * 8u, w);
-        lds_barrier();
-        if constexpr (WAVES == 8) {
-          // 24 partials: lane l < 24 reads partial l (value l / 8 of wavefront l % 8), three DPP steps add the eight of a value
-          // inside their eight lanes -- a fixed tree, the same in every wavefront -- and lanes 0 / 8 / 16 hand the totals out
-          double v;
-          asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(base + (uint32_t)(lane & 31) * 8u) : "memory");
-          v += dpp_mov<0xB1>(v);   // quad_perm:[1,0,3,2]
-          v += dpp_mov<0x4E>(v);   // quad_perm:[2,3,0,1]
-          v += dpp_mov<0x141>(v);  // row_half_mirror: lane l <-> 7 - l inside each 8 lanes
-          t1 = read_lane(v, 0); t2 = read_lane(v, 8); t3 = read_lane(v, 16);
-        } else {
-          constexpr int kHalf = WAVES > 1 ? WAVES / 2 : 1;  // (one wavefront per pair: instantiated, never run)
-          dbl2 q[3 * kHalf];
-          lds_gather<3 * kHalf>(base, q);
-          t1 = q[0][0] + q[0][1]; t2 = q[kHalf][0] + q[kHalf][1]; t3 = q[2 * kHalf][0] + q[2 * kHalf][1];
-#pragma unroll
-          for (int v = 1; v < kHalf; ++v) {
-            t1 += q[v][0]; t2 += q[kHalf + v][0]; t3 += q[2 * kHalf + v][0];
-            t1 += q[v][1]; t2 += q[kHalf + v][1]; t3 += q[2 * kHalf + v][1];
-          }
-        }
+      // layout of one parity's buffer (WAVES * 32 bytes): [value k = 0..2][wavefront] -- a value's partials side
+      // by side, WAVES / 2 reads of 16 bytes each; added up in the order of the wavefronts
+      const uint32_t base = lds_addr(&xch[par][0][0]);
+      if ((lane & 15) == 0 && row != 1)  // rows 0 / 2 / 3 hold t1 / t2 / t3 (wave_sum3_rows)
+        lds_post(base + (uint32_t)((row == 0 ? 0 : row - 1) * WAVES + sub) * 8u, w);
+      lds_barrier();
+      if constexpr (WAVES == 8) {
+        // 24 partials: lane l < 24 reads partial l (value l / 8 of wavefront l % 8), three DPP steps add the eight of a value
+        // inside their eight lanes -- a fixed tree, the same in every wavefront -- and lanes 0 / 8 / 16 hand the totals out
+        // (12 reads of 16 bytes per lane -- 48 registers of partials in flight -- lost 4.5 % at n_ind 4000)
+        double v;
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(base + (uint32_t)(lane & 31) * 8u) : "memory");
+        v += dpp_mov<0xB1>(v);   // quad_perm:[1,0,3,2]
+        v += dpp_mov<0x4E>(v);   // quad_perm:[2,3,0,1]
+        v += dpp_mov<0x141>(v);  // row_half_mirror: lane l <-> 7 - l inside each 8 lanes
+        t1 = read_lane(v, 0); t2 = read_lane(v, 8); t3 = read_lane(v, 16);
       } else {
-        if ((lane & 15) == 0 && row != 1) xch[par][sub][row == 0 ? 1 : row] = w;
-        lds_barrier();
-        t1 = xch[par][0][1]; t2 = xch[par][0][2]; t3 = xch[par][0][3];
-        for (int v = 1; v < WAVES; ++v) {
-          t1 += xch[par][v][1]; t2 += xch[par][v][2]; t3 += xch[par][v][3];
+        constexpr int kHalf = WAVES > 1 ? WAVES / 2 : 1;  // (one wavefront per pair: instantiated, never run)
+        dbl2 q[3 * kHalf];
+        lds_gather<3 * kHalf>(base, q);
+        t1 = q[0][0] + q[0][1]; t2 = q[kHalf][0] + q[kHalf][1]; t3 = q[2 * kHalf][0] + q[2 * kHalf][1];
+#pragma unroll
+        for (int v = 1; v < kHalf; ++v) {
+          t1 += q[v][0]; t2 += q[kHalf + v][0]; t3 += q[2 * kHalf + v][0];
+          t1 += q[v][1]; t2 += q[kHalf + v][1]; t3 += q[2 * kHalf + v][1];
         }
       }
     } else {
@@ -685,26 +589,24 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
         wave_sum3(t1, t2, t3);
       else
         wave_sum4(t0, t1, t2, t3);
-      if (WAVES > 1) {
-        const int par = (int)((xpar != nullptr ? (*xpar)++ : n_iter) & 1u);
+      if (WAVES > 1) {  // (the full four-value form of a pair spread over several wavefronts: rare, plain LDS accesses)
+        const int par = (int)((*xpar)++ & 1u);
         if (lane == 0) {
-          if (!kDrop) xch[par][sub][0] = t0;
-          xch[par][sub][1] = t1; xch[par][sub][2] = t2; xch[par][sub][3] = t3;
+          xch[par][sub][0] = t0; xch[par][sub][1] = t1; xch[par][sub][2] = t2; xch[par][sub][3] = t3;
         }
         lds_barrier();
         t0 = t1 = t2 = t3 = 0.0;
         for (int w = 0; w < WAVES; ++w) {
-          if (!kDrop) t0 += xch[par][w][0];
-          t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
+          t0 += xch[par][w][0]; t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
         }
       }
     }
-    const bool scaled = kPair && kTree && kScaled;
+    const bool scaled = kShared && kScaled;
     n1 = scaled ? t1 : t1 * inv_x; n2 = scaled ? t2 : t2 * inv_x; n3 = scaled ? t3 : t3 * inv_x;
     // sum_k ff_k / (2x) = 1 (every individual's four posterior weights add up to one): in the three-value form the first
     // frequency is what the other three leave, R[0] is never accumulated and three values go through the reduction
     // instead of four
-    n0 = kDrop ? 1.0 - ((n1 + n2) + n3) : (scaled ? t0 : t0 * inv_x);
+    n0 = kDrop ? 1.0 - ((n1 + n2) + n3) : t0 * inv_x;
   };
   // Any individual with s == 0 makes every tmp/sum NaN in the reference, hence all four f NaN and, as a
   // NaN difference never raises eps (gen_func.cpp:1049-1053), "convergence" at this iteration.  Here
@@ -721,38 +623,39 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   // the full four-value form (one reciprocal per individual: slower, and rare): hap 0 then keeps the relative accuracy
   // it had at the switch (1e-16 / kFullBelow ~ 1e-13).
   constexpr double kFullBelow = 0x1p-10;
-  constexpr bool kFast = (kPaired > 0 || kTree) && kPairRcp;
-  bool full = kDrop0 && __builtin_amdgcn_ballot_w64(f0 < kFullBelow) != 0;  // wave-uniform (f is)
+  bool full = __builtin_amdgcn_ballot_w64(f0 < kFullBelow) != 0;  // wave-uniform (f is)
   bool done = false;
   while (!done && n_iter < (uint32_t)kIterMax) {
-    if (kFast && tree_ok && !full) {
-      for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
-        double n0, n1, n2, n3;
-        em_step(PairedTag(), PairedTag(), n0, n1, n2, n3);  // (the tags double as true / false)
-        if (__builtin_amdgcn_ballot_w64(!(n1 < 2.0))) break;  // an odd step (wave-uniform values: all-or-nothing)
-        // eps = the largest of the four changes (gen_func.cpp:1049-1053) is at least the change of hap 1: while that one
-        // alone is above EPSILON -- nine iterations in ten -- the other three differences are not formed
-        bool conv = false;
-        if (!NGSLD_EARLY_EPS || __builtin_amdgcn_ballot_w64(fabs(n1 - f1) < kEpsilonTie)) {
-          const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
-          conv = __builtin_amdgcn_ballot_w64(eps < kEpsilon) != 0;  // gen_func.cpp:1054-1055
-          tie |= __builtin_amdgcn_ballot_w64(fabs(eps - kEpsilon) < kTieMargin) != 0;  // too close to call: replayed
+    if constexpr (kTree) {
+      if (tree_ok && !full) {
+        for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
+          double n0, n1, n2, n3;
+          em_step(PairedTag(), PairedTag(), n0, n1, n2, n3);  // (the tags double as true / false)
+          if (__builtin_amdgcn_ballot_w64(!(n1 < 2.0))) break;  // an odd step (wave-uniform values: all-or-nothing)
+          // eps = the largest of the four changes (gen_func.cpp:1049-1053) is at least the change of hap 1: while that one
+          // alone is above EPSILON -- nine iterations in ten -- the other three differences are not formed (+1.2 %)
+          bool conv = false;
+          if (__builtin_amdgcn_ballot_w64(fabs(n1 - f1) < kEpsilonTie)) {
+            const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
+            conv = __builtin_amdgcn_ballot_w64(eps < kEpsilon) != 0;  // gen_func.cpp:1054-1055
+            tie |= __builtin_amdgcn_ballot_w64(fabs(eps - kEpsilon) < kTieMargin) != 0;  // too close to call: replayed
+          }
+          f0 = n0; f1 = n1; f2 = n2; f3 = n3;
+          if (conv) {
+            done = true;
+            break;
+          }
+          if (__builtin_amdgcn_ballot_w64(n0 < kFullBelow)) {
+            full = true;
+            ++n_iter;  // this iteration is complete
+            break;
+          }
         }
-        f0 = n0; f1 = n1; f2 = n2; f3 = n3;
-        if (conv) {
-          done = true;
-          break;
-        }
-        if (kDrop0 && __builtin_amdgcn_ballot_w64(n0 < kFullBelow)) {
-          full = true;
-          ++n_iter;  // this iteration is complete
-          break;
-        }
+        if (done || n_iter >= (uint32_t)kIterMax) break;
+        if (full) continue;
+        // an odd step: on to the second opinion
+        if (WAVES > 1) lds_barrier();  // n1 is the same in every wavefront: all redo, none still reads the exchange buffer
       }
-      if (done || n_iter >= (uint32_t)kIterMax) break;
-      if (full) continue;
-      // an odd step: on to the second opinion
-      if (WAVES > 1) lds_barrier();  // n1 is the same in every wavefront: all redo, none still reads the exchange buffer
     }
     // one iteration with one reciprocal per individual, four-value form: the kernels' only path where any slot may be
     // empty, the second opinion on an odd step, and how a pair with a tiny hap 0 finishes
@@ -770,7 +673,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     tie |= __builtin_amdgcn_ballot_w64(fabs(eps - kEpsilon) < kTieMargin) != 0;
     if (__builtin_amdgcn_ballot_w64(eps < kEpsilon)) break;
     ++n_iter;
-    if (kDrop0 && !full && __builtin_amdgcn_ballot_w64(f0 < kFullBelow)) full = true;  // (wavefronts without a hot loop)
+    if (!full && __builtin_amdgcn_ballot_w64(f0 < kFullBelow)) full = true;  // (wavefronts without a hot loop)
   }
   if (bad) f0 = f1 = f2 = f3 = __builtin_nan("");
   return n_iter | (tie ? kTieBit : 0u);
@@ -798,10 +701,10 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
   const double Dp = D / den;
   const double rr = D / sqrt(hm0 * hm1 * (1 - hm0) * (1 - hm1));
   // a constant site (rsx = 1/sqrt(0) = inf) is 0/0 = NaN in gsl_stats_correlation; said explicitly because a cross
-  // moment centred after the fact (run kernel) is only ~0 there, not exactly 0.  The sign of rsx is the prep kernel's
-  // "constant up to rounding" mark.
-  const double a1 = fabs(rsx1), a2 = fabs(rsx2);
-  const double r = (a1 == __builtin_inf() || a2 == __builtin_inf()) ? __builtin_nan("") : sxy * a1 * a2;
+  // moment centred after the fact (run kernel) is only ~0 there, not exactly 0.
+  const double a1 = rsx1, a2 = rsx2;
+  const bool constant_site = a1 == __builtin_inf() || a2 == __builtin_inf();
+  const double r = constant_site ? __builtin_nan("") : sxy * a1 * a2;
   ngsld_rec_std o;
   o.r2_ExpG = r * r;
   o.D = D;
@@ -819,7 +722,8 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
     const double q0 = fabs(hm0) <= fabs(1 - hm0) ? fabs(hm0) : fabs(1 - hm0);
     const double q1 = fabs(hm1) <= fabs(1 - hm1) ? fabs(hm1) : fabs(1 - hm1);
     // (NaN frequencies fail both comparisons)
-    bool flag = tie || !(q0 >= kReplayBelow) || !(q1 >= kReplayBelow) || rsx1 < 0 || rsx2 < 0;
+    bool flag = tie || !(q0 >= kReplayBelow) || !(q1 >= kReplayBelow) ||
+                (!constant_site && (double)A.n_ind * a1 * a2 > kPearsonCond);  // (a constant site: NaN on every path)
     // The TSV prints six decimals (ngsLD.cpp:314-349).  A value that sits on a rounding point of the sixth decimal --
     // closer to it than this kernel and the reference can differ -- would print a different last digit, and a D within
     // rounding noise of zero a different sign ("-0.000000"): those pairs are replayed too, so that the text is the
@@ -851,42 +755,41 @@ struct PairResult {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Generic kernel: WAVES wavefronts share one pair (WAVES == 1: four independent wavefronts per 256-thread
-// workgroup, one item each).  Used for n_ind > 512; for WAVES == 1 it is the A/B baseline of the prefetch kernel.
+// Multi-wavefront kernel: WAVES = 2, 4 or 8 wavefronts share one pair (n_ind > 512, or whatever the one-wavefront kernels
+// do not take).
 //   SLOTS  individuals per lane (compile time, P lives in 18*SLOTS VGPRs)
 //   MASKED --ignore_miss_data: individuals missing at either site are left out (gen_func.cpp:1089)
-//   PFB    prefetch the s2 vector: every wavefront only ever reads ITS slice of it (individuals sub*SLOTS*64 ...),
-//          so the slice of the NEXT pair is copied global->LDS asynchronously into a wave-private 1536*SLOTS-byte
-//          buffer while the EM loop of the current pair runs; the row vector (same for the whole item, L2/L1-hot)
-//          is still read directly.  No extra barrier is needed for the prefetch.
-// ---------------------------------------------------------------------------------------------
-//   PADS   (WAVES > 1, not MASKED) the cohort does not fill all slots but the last: padding lanes in the middle of a
+// Every wavefront only ever reads ITS slice of a site vector (individuals sub*SLOTS*64 ...), so the slice of the NEXT
+// pair is copied global->LDS asynchronously into a wave-private 1536*SLOTS-byte buffer while the EM loop of the current
+// pair runs; the row vector (same for the whole item, L2-hot) is read directly.  No extra barrier is needed for the
+// prefetch.  (Without the prefetch -- every pair starting with an L2 / HBM round trip -- the kernel measured 12 % slower.)
+//   PADS   (not MASKED) the cohort does not fill all slots but the last: padding lanes in the middle of a
 //          wavefront's slots, or a wavefront that is all padding (513 individuals on 2 x 5 slots: the second wavefront's
 //          fourth slot holds ONE individual, its fifth none).  Without per-slot pads such a wavefront took the step with
 //          one reciprocal per individual in EVERY iteration and the others waited for it at the barrier: n_ind 1,025 ran at
 //          half the rate of 1,024, slower than under --ignore_miss_data, whose kernels have the pads anyway.
-template <int SLOTS, int WAVES, bool MASKED, bool PFB, bool PADS = false>
-__global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
-  static_assert(!PADS || (WAVES > 1 && !MASKED && PFB), "PADS: the prefetching multi-wavefront kernel without --ignore_miss_data");
-  constexpr bool kCheckAll = MASKED || WAVES > 1;  // otherwise only the last slot can hold padding
-  constexpr int kWavesPerWg = WAVES == 1 ? 4 : WAVES;
+// ---------------------------------------------------------------------------------------------
+template <int SLOTS, int WAVES, bool MASKED, bool PADS = false>
+__global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
+  static_assert(WAVES == 2 || WAVES == 4 || WAVES == 8, "pair_ld_kernel: 2, 4 or 8 wavefronts per pair");
+  static_assert(!PADS || !MASKED, "PADS: the kernel without --ignore_miss_data");
   constexpr int kSliceBytes = SLOTS * 64 * 3 * 8;
-  constexpr int kXchBase = PFB ? kWavesPerWg * kSliceBytes : 16;
-  // kParked (several wavefronts per pair, every individual counts): the Pearson cross moment needs no meeting of the
-  // wavefronts before the EM loop -- each parks its partial sum per candidate, thread t adds them up when it writes the record
-  // -- and x is n_ind: one barrier, one LDS round trip and one f64 division less per pair
-  constexpr bool kParked = NGSLD_PARKED != 0 && kXchAsm<WAVES> && !MASKED;
-  __shared__ __attribute__((aligned(16))) char smem[kXchBase + WAVES * 96 + (WAVES > 1 ? 64 * sizeof(PairResult) : 0) +
+  constexpr int kXchBase = WAVES * kSliceBytes;
+  // kParked (every individual counts): the Pearson cross moment needs no meeting of the wavefronts before the EM loop --
+  // each parks its partial sum per candidate, thread t adds them up when it writes the record -- and x is n_ind: one
+  // barrier, one LDS round trip and one f64 division less per pair
+  constexpr bool kParked = !MASKED;
+  __shared__ __attribute__((aligned(16))) char smem[kXchBase + WAVES * 96 + 64 * sizeof(PairResult) +
                                                     (kParked ? 64 * WAVES * sizeof(double) : 0)];
-  PairResult *res = reinterpret_cast<PairResult *>(smem + kXchBase + WAVES * 96);  // WAVES > 1: one per candidate
+  PairResult *res = reinterpret_cast<PairResult *>(smem + kXchBase + WAVES * 96);  // one per candidate
   double (*parked)[WAVES] = reinterpret_cast<double (*)[WAVES]>(smem + kXchBase + WAVES * 96 + 64 * sizeof(PairResult));
-  double (*xch)[WAVES][4] = reinterpret_cast<double (*)[WAVES][4]>(smem + (PFB ? kWavesPerWg * kSliceBytes : 16));
-  double (*xch0)[2] = reinterpret_cast<double (*)[2]>(smem + (PFB ? kWavesPerWg * kSliceBytes : 16) + WAVES * 64);
+  double (*xch)[WAVES][4] = reinterpret_cast<double (*)[WAVES][4]>(smem + kXchBase);
+  double (*xch0)[2] = reinterpret_cast<double (*)[2]>(smem + kXchBase + WAVES * 64);
 
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int sub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const Item *item_ptr;
-  if (WAVES > 1 && A.tile_nk != 0) {
+  if (A.tile_nk != 0) {
     // Tiled order.  Workgroup ids go round the eight XCDs, so with tiles of tile_rows rows x 8 items, laid out row by row,
     // XCD x works on item column x of every row of the tile: the same ~64 + tile_rows candidate sites for tile_rows rows,
     // out of its own L2 -- in plain item order the workgroups in flight together are one row's whole candidate range, no
@@ -904,11 +807,9 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
     if ((uint64_t)k >= hi - lo) return;
     item_ptr = A.items_all + lo + k;
   } else {
-    const uint64_t item_id = WAVES == 1 ? (uint64_t)blockIdx.x * 4 + (uint64_t)wave : (uint64_t)blockIdx.x;
-    if (item_id >= A.n_items) return;
-    item_ptr = A.items + item_id;
+    if ((uint64_t)blockIdx.x >= A.n_items) return;
+    item_ptr = A.items + blockIdx.x;
   }
-  const int sub = WAVES == 1 ? 0 : wave;
 
   const Item it = *item_ptr;
   const uint32_t s1 = it.s1;
@@ -918,19 +819,17 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
   const uint64_t rec0 = it.first_record - A.out_base;
   const double *pa = A.planes + (uint64_t)s1 * A.site_stride;
   const uint32_t i0 = (uint32_t)sub * (SLOTS * 64) + (uint32_t)lane;
-  char *lds_b = smem + wave * kSliceBytes;
-  // WAVES > 1: the scalars of the item's candidate sites come into LDS once, by one coalesced load per array, so the pair
-  // loop waits for no ordinary global load (a ~2 us round trip per pair, and it would drain the slice copy in flight)
-  __shared__ double site_sc[WAVES > 1 ? 3 : 1][64];
-  if (WAVES > 1) {
-    if (threadIdx.x < it.count) {
-      const uint32_t s2 = it.s2_begin + threadIdx.x;
-      site_sc[0][threadIdx.x] = A.maf[s2];
-      site_sc[WAVES > 1 ? 1 : 0][threadIdx.x] = A.mean_e[s2];
-      site_sc[WAVES > 1 ? 2 : 0][threadIdx.x] = A.rsx[s2];
-    }
-    __syncthreads();
+  char *lds_b = smem + sub * kSliceBytes;
+  // the scalars of the item's candidate sites come into LDS once, by one coalesced load per array, so the pair loop waits
+  // for no ordinary global load (a ~2 us round trip per pair, and it would drain the slice copy in flight)
+  __shared__ double site_sc[3][64];
+  if (threadIdx.x < it.count) {
+    const uint32_t s2 = it.s2_begin + threadIdx.x;
+    site_sc[0][threadIdx.x] = A.maf[s2];
+    site_sc[1][threadIdx.x] = A.mean_e[s2];
+    site_sc[2][threadIdx.x] = A.rsx[s2];
   }
+  __syncthreads();
 
   // copy this wavefront's slice of site s2 (three runs of SLOTS*512 B, one per genotype plane) into lds_b
   auto dma_slice = [&](uint32_t s2) {
@@ -950,45 +849,35 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
   };
 
   uint32_t c = next_kept(0);
-  if (PFB && c < it.count) dma_slice(it.s2_begin + c);
+  if (c < it.count) dma_slice(it.s2_begin + c);
   uint32_t xpar = 0;  // exchanges of this workgroup so far (see em_pair)
   while (c < it.count) {
-    const uint32_t s2 = it.s2_begin + c;
     const uint32_t cn = next_kept(c + 1);
-    // (one wavefront per pair: per-site scalars are fetched here, before the copy of the next site is started: an
-    // ordinary load waited for later would drain that copy too, vmcnt is in-order)
-    const double m2 = WAVES > 1 ? site_sc[0][c] : A.maf[s2];
-    const double mean2 = WAVES > 1 ? site_sc[WAVES > 1 ? 1 : 0][c] : A.mean_e[s2];
-    const double rsx2 = WAVES > 1 ? site_sc[WAVES > 1 ? 2 : 0][c] : A.rsx[s2];
+    const double m2 = site_sc[0][c], mean2 = site_sc[1][c], rsx2 = site_sc[2][c];
     double P[SLOTS][9];
     uint32_t vbits;
     double sxy;
     double pads[SLOTS];  // --ignore_miss_data: 1 where the individual has no data at either site (see stage_pair)
     const Relabel rl = relabel(m1, m2, mean1, mean2);
-    if (PFB) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice copied during the previous pair has landed
-      stage_pair<SLOTS, MASKED, false, false, true>(pa, A.np, i0, reinterpret_cast<const double *>(lds_b),
-                                                    (uint32_t)(SLOTS * 64), (uint32_t)lane, i0, A.n_ind, rl.mean1, rl.mean2, P,
-                                                    vbits, sxy, (MASKED || PADS) ? pads : nullptr, rl.flip1, rl.flip2);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // a, b and the scalars are all consumed
-      if (cn < it.count) dma_slice(it.s2_begin + cn);
-    } else {
-      stage_pair<SLOTS, MASKED>(pa, A.np, i0, A.planes + (uint64_t)s2 * A.site_stride, A.np, i0, i0, A.n_ind, rl.mean1,
-                                rl.mean2, P, vbits, sxy, MASKED ? pads : nullptr, rl.flip1, rl.flip2);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice copied during the previous pair has landed
+    stage_pair<SLOTS, MASKED, false, false, true>(pa, A.np, i0, reinterpret_cast<const double *>(lds_b),
+                                                  (uint32_t)(SLOTS * 64), (uint32_t)lane, i0, A.n_ind, rl.mean1, rl.mean2, P,
+                                                  vbits, sxy, (MASKED || PADS) ? pads : nullptr, rl.flip1, rl.flip2);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // a, b and the scalars are all consumed
+    if (cn < it.count) dma_slice(it.s2_begin + cn);
     uint32_t x = count_valid<SLOTS>(vbits);
     sxy = wave_sum1(sxy);
     if (kParked) {
       if (lane == 0) lds_post(lds_addr(&parked[c][sub]), sxy);
       x = A.n_ind;  // (the ballots of the wavefronts add up to it: padding lanes are the only ones left out)
-    } else if (kXchAsm<WAVES>) {
+    } else {
       // (no barrier behind the reads: xch0 is written again a pair later, and every EM loop has a barrier of its own that
       // no wavefront passes before all have read these)
       const uint32_t base = lds_addr(&xch0[0][0]);
       if (lane == 0) lds_post2(base + (uint32_t)sub * 16u, sxy, (double)x);
       lds_barrier();
-      dbl2 q[WAVES > 1 ? WAVES : 2];
-      lds_gather<(WAVES > 1 ? WAVES : 2)>(base, q);
+      dbl2 q[WAVES];
+      lds_gather<WAVES>(base, q);
       double sx = 0.0, xs = 0.0;
 #pragma unroll
       for (int w = 0; w < WAVES; ++w) {
@@ -997,30 +886,13 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
       }
       sxy = sx;
       x = (uint32_t)xs;
-    } else if (WAVES > 1) {
-      if (lane == 0) {
-        xch0[sub][0] = sxy;
-        xch0[sub][1] = (double)x;
-      }
-      lds_barrier();
-      double sx = 0.0, xs = 0.0;
-      for (int w = 0; w < WAVES; ++w) {
-        sx += xch0[w][0];
-        xs += xch0[w][1];
-      }
-      sxy = sx;
-      x = (uint32_t)xs;
-      lds_barrier();
     }
     double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair<SLOTS, WAVES, kCheckAll, (WAVES > 1 && !MASKED && !PADS)>(
+    const uint32_t n_iter = em_pair<SLOTS, WAVES, true, (!MASKED && !PADS)>(
         P, vbits, kParked ? A.inv_n : 1.0 / (double)x, rl.m1, rl.m2, f0, f1, f2, f3, xch, sub, lane, A.status,
-        (MASKED || PADS) ? pads : nullptr, WAVES > 1 ? &xpar : nullptr);
+        (MASKED || PADS) ? pads : nullptr, &xpar);
     unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
-    if (WAVES == 1) {
-      if (lane == 0)
-        write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, rsx2, x, n_iter);
-    } else if (lane == 0 && sub == 0) {
+    if (lane == 0 && sub == 0) {
       PairResult &r = res[c];
       r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;
       r.sxy = sxy;
@@ -1030,31 +902,28 @@ __global__ __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64, 2) void pair_ld_kern
     }
     c = cn;
   }
-  if (WAVES > 1) {  // the whole workgroup shares the item: thread t derives and writes the record of candidate t
-    if (kParked) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the parked partial sums are stores the compiler does not see
-    __syncthreads();
-    const uint32_t t = threadIdx.x;
-    if (t < it.count && ((it.mask >> t) & 1ull)) {
-      const PairResult r = res[t];
-      double sxy = r.sxy;
-      if (kParked) {
-        sxy = 0.0;  // (the order the exchange added them in)
-        for (int w = 0; w < WAVES; ++w) sxy += parked[t][w];
-      }
-      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << t) - 1ull)), r.f[0], r.f[1], r.f[2], r.f[3], sxy, rsx1,
-                 r.rsx2, r.x, r.n_iter);
+  // the whole workgroup shares the item: thread t derives and writes the record of candidate t
+  if (kParked) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the parked partial sums are stores the compiler does not see
+  __syncthreads();
+  const uint32_t t = threadIdx.x;
+  if (t < it.count && ((it.mask >> t) & 1ull)) {
+    const PairResult r = res[t];
+    double sxy = r.sxy;
+    if (kParked) {
+      sxy = 0.0;  // (the order the exchange added them in)
+      for (int w = 0; w < WAVES; ++w) sxy += parked[t][w];
     }
+    write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << t) - 1ull)), r.f[0], r.f[1], r.f[2], r.f[3], sxy, rsx1,
+               r.rsx2, r.x, r.n_iter);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Prefetch kernel (n_ind <= 512): the four wavefronts of a workgroup work on ONE row s1.
-//   LDS: [row vector a : 24*SLOTS*64 B] [next-site buffer of wavefront 0..3 : 24*SLOTS*64 B each] [claim counter]
-// The row's vector is brought in once per item.  Each wavefront claims the next s2 of the item from an LDS
-// counter (dynamic balance of the 3..100-iteration spread), and as soon as it has turned the current
-// buffer into P it starts the asynchronous copy (global_load_lds, 16 B per lane, no VGPR round trip) of the
-// site it will work on NEXT -- the copy flies during the whole EM loop, so the ~2.5 us HBM/Infinity-Cache
-// latency that the direct kernel pays at every pair start is off the critical path.
+// One wavefront per pair (n_ind <= 640): the four wavefronts of a workgroup work on ONE row s1, whose vector sits in LDS.
+// Each wavefront claims the next s2 from an LDS counter (dynamic balance of the 3..100-iteration spread), and as soon as
+// it has turned the current buffer into P it starts the asynchronous copy (global_load_lds, 16 B per lane, no VGPR round
+// trip) of the site it will work on NEXT -- the copy flies during the whole EM loop, so the ~2.5 us HBM/Infinity-Cache
+// latency that a direct load pays at every pair start is off the critical path (measured: 1.62e8 against 1.42e8 pairs/s).
 // ---------------------------------------------------------------------------------------------
 // Asynchronous copy of one site's planes (SLOTS*1536 B, contiguous) into LDS, 1 KiB per wave-instruction
 // (lane l moves 16 B to lds_dst + k*1024 + l*16).  With `stride` > 1 only chunks k % stride == first are
@@ -1088,117 +957,8 @@ __device__ __forceinline__ void dma_site_to_lds(const double *site, char *lds_ds
   }
 }
 
-template <int SLOTS, bool MASKED>
-__global__ __launch_bounds__(256, 2) void pair_ld_pf_kernel(PairArgs A) {
-  constexpr int kSiteBytes = SLOTS * 64 * 3 * 8;
-  constexpr uint32_t kNp = SLOTS * 64;
-  __shared__ __attribute__((aligned(16))) char smem[kSiteBytes * 5 + 16 + 64 * sizeof(PairResult)];
-  __shared__ double site_sc[3][64];  // maf, mean_e, rsx of the item's candidate sites
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const Item it = A.items[blockIdx.x];
-  const uint32_t s1 = it.s1;
-  const double m1 = A.maf[s1];
-  const double mean1 = A.mean_e[s1];
-  const double rsx1 = A.rsx[s1];
-  const uint64_t rec0 = it.first_record - A.out_base;
-  char *lds_a = smem;
-  char *lds_b = smem + kSiteBytes * (1 + wave);
-  uint32_t *claim = reinterpret_cast<uint32_t *>(smem + kSiteBytes * 5);
-  PairResult *res = reinterpret_cast<PairResult *>(smem + kSiteBytes * 5 + 16);  // one per candidate of the item
-
-  // next unclaimed offset inside the item; offsets 0..3 are pre-assigned to the four wavefronts
-  if (threadIdx.x == 0) *claim = 4;
-  auto claim_next = [&]() -> uint32_t {  // skips pairs dropped by the maf[s2] / sub-sampling filters (ngsLD.cpp:270-282)
-    for (;;) {
-      uint32_t c = 0;
-      if (lane == 0) c = atomicAdd(claim, 1u);
-      c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-      if (c >= it.count || ((it.mask >> c) & 1ull)) return c;
-    }
-  };
-  // Per-site scalars of all candidate sites of the item are brought into LDS once, by one coalesced load per
-  // array: inside the pair loop there is no ordinary global load left to wait for -- a load waited for while a
-  // site copy is in flight would drain the copy too (vmcnt is in-order), and its ~2 us round trip per pair was
-  // 13 % of the wavefronts' time when the scalars were still fetched pair by pair.
-  struct SiteScalars {
-    double maf, mean, rsx;
-  };
-  auto load_scalars = [&](uint32_t c) -> SiteScalars {
-    SiteScalars v{0.0, 0.0, 0.0};
-    if (c < it.count) {
-      v.maf = uniform(site_sc[0][c]);
-      v.mean = uniform(site_sc[1][c]);
-      v.rsx = uniform(site_sc[2][c]);
-    }
-    return v;
-  };
-  if (threadIdx.x < it.count) {
-    const uint32_t s2 = it.s2_begin + threadIdx.x;
-    site_sc[0][threadIdx.x] = A.maf[s2];
-    site_sc[1][threadIdx.x] = A.mean_e[s2];
-    site_sc[2][threadIdx.x] = A.rsx[s2];
-  }
-
-  // the row vector: every wavefront copies a quarter of it
-  dma_site_to_lds<SLOTS>(A.planes + (uint64_t)s1 * A.site_stride, lds_a, lane, wave, 4);
-  __syncthreads();  // claim counter initialised before anybody claims, candidate scalars in place
-  uint32_t c = (uint32_t)wave;
-  if (c < it.count && !((it.mask >> c) & 1ull)) c = claim_next();
-  SiteScalars cur = load_scalars(c);
-  if (c < it.count) dma_site_to_lds<SLOTS>(A.planes + (uint64_t)(it.s2_begin + c) * A.site_stride, lds_b, lane, 0, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // row vector complete in LDS
-
-  while (c < it.count) {
-    const uint32_t cn = claim_next();
-    const SiteScalars nxt = load_scalars(cn);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's site copy (issued a pair ago) has landed
-    double P[SLOTS][9];
-    uint32_t vbits;
-    double sxy;
-    double pads[SLOTS];  // --ignore_miss_data: 1 where the individual has no data at either site
-    const Relabel rl = relabel(m1, cur.maf, mean1, cur.mean);
-    stage_pair<SLOTS, MASKED, !MASKED, true>(reinterpret_cast<const double *>(lds_a), kNp, (uint32_t)lane,
-                                             reinterpret_cast<const double *>(lds_b), kNp, (uint32_t)lane, (uint32_t)lane,
-                                             A.n_ind, rl.mean1, rl.mean2, P, vbits, sxy, MASKED ? pads : nullptr, rl.flip1,
-                                             rl.flip2);
-    // all ds_reads of the buffer are consumed (P is computed): start the copy of the next site over it
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (cn < it.count)
-      dma_site_to_lds<SLOTS>(A.planes + (uint64_t)(it.s2_begin + cn) * A.site_stride, lds_b, lane, 0, 1);
-    // without --ignore_miss_data every individual counts: x = n_ind, 1/x comes precomputed (same IEEE quotient)
-    const uint32_t x = MASKED ? count_valid<SLOTS>(vbits) : A.n_ind;
-    const double inv_x = MASKED ? 1.0 / (double)x : A.inv_n;
-    sxy = fma(-(double)A.n_ind * rl.mean1, rl.mean2, wave_sum1_bcast(sxy));  // centred: sum e1 e2 - n mean1 mean2 (as the run kernel)
-    double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, inv_x, rl.m1, rl.m2, f0, f1, f2, f3,
-                                                      (double (*)[1][4]) nullptr, 0, lane, A.status, MASKED ? pads : nullptr);
-    unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
-    if (lane == 0) {
-      PairResult &r = res[c];
-      r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;
-      r.sxy = sxy;
-      r.rsx2 = cur.rsx;
-      r.x = x;
-      r.n_iter = n_iter;
-    }
-    c = cn;
-    cur = nxt;
-  }
-  // the item is done: thread t derives and writes the record of candidate t (consecutive records: coalesced stores)
-  __syncthreads();
-  const uint32_t t = threadIdx.x;
-  if (t < it.count && ((it.mask >> t) & 1ull)) {
-    const PairResult r = res[t];
-    write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << t) - 1ull)), r.f[0], r.f[1], r.f[2], r.f[3], r.sxy, rsx1,
-               r.rsx2, r.x, r.n_iter);
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Run kernel (n_ind <= 512, the headline shape): pair_ld_pf_kernel's pair pipeline without its per-item costs.
+// Run kernel (n_ind <= 640; eight slots = the headline shape): the pair pipeline above without per-item costs.
 // A workgroup works through a RUN of up to kRunItems consecutive items of one row (512 candidate sites) instead of
 // one item: the row vector is brought into LDS once per run, the four wavefronts claim candidates from one LDS
 // counter for the whole run, and NOTHING inside the run synchronises them -- no barrier at item boundaries, no
@@ -1260,10 +1020,12 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
   constexpr int kSiteBytes = SLOTS * 64 * 3 * 8;
   constexpr int kBuf = kSiteBytes + 32;
   constexpr uint32_t kNp = SLOTS * 64;
-  constexpr uint32_t kRing = 32;
+  // (ten slots: five site buffers of 15 KB leave 5 KB for rings and list under the 80 KB that let two workgroups share a CU)
+  constexpr uint32_t kRing = SLOTS <= 9 ? 32 : 8;
   constexpr int kRingOff = kSiteBytes + 4 * kBuf;
   constexpr int kListOff = kRingOff + 4 * (int)(kRing * sizeof(RunResult));
   __shared__ __attribute__((aligned(16))) char smem[kListOff + sizeof(RunList)];
+  static_assert(sizeof(smem) <= 81920, "run kernel: two workgroups per CU need <= 80 KB of LDS each");
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1387,9 +1149,6 @@ __device__ __forceinline__ double group_sum(double v) {  // sum over the G lanes
 // remaining ones on ONE (lane % 4 == 0: t1, 1: t2, 2 and 3: t3); three quad broadcasts hand the totals back to every lane
 // of the group.  G = 16: 31 instructions instead of 36 (7 f64 adds instead of 12); G = 32: one v_permlane16_swap fold
 // instead of three.  (G = 8 has only three levels: packing does not pay there.)
-#ifndef NGSLD_GROUP_SUM3
-#define NGSLD_GROUP_SUM3 1  // build-time A/B switch
-#endif
 template <int CTRL>
 __device__ __forceinline__ double dpp_quad(double v) {  // quad_perm broadcast of one lane of every quad
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -1400,7 +1159,7 @@ __device__ __forceinline__ double dpp_quad(double v) {  // quad_perm broadcast o
 template <int G>
 __device__ __forceinline__ void group_sum3(double &t1, double &t2, double &t3, bool odd, bool upper) {
   // odd = lane & 1, upper = lane & 2 (loop invariants of the caller)
-  if (!NGSLD_GROUP_SUM3 || G == 8) {
+  if (G == 8) {
     t1 = group_sum<G>(t1); t2 = group_sum<G>(t2); t3 = group_sum<G>(t3);
     return;
   }
@@ -1562,11 +1321,11 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
     }
     const double inv_x = 1.0 / (double)x;
     // one reciprocal per lane and iteration (RcpTree) when only the last slot can hold padding, see em_pair
-    constexpr bool kTree = kTreeRcp && SLOTS > 1;
+    constexpr bool kTree = SLOTS > 1;
     const double pad = ((vbits >> (SLOTS - 1)) & 1u) ? 0.0 : 1.0;
     auto em_step = [&](auto tree_tag, double &n0, double &n1, double &n2, double &n3) {
       constexpr bool kT = decltype(tree_tag)::value;
-      constexpr bool kDrop = kDrop0 && kT;  // shared-reciprocal step: three-value form; the other one: full (see em_pair)
+      constexpr bool kDrop = kT;  // shared-reciprocal step: three-value form; the other one: full (see em_pair)
       const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
       const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
       const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
@@ -1623,12 +1382,12 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
     };
     bool done = !active, tie = false;
     uint32_t n_iter = (uint32_t)kIterMax;
-    constexpr bool kMaskDone = NGSLD_MASK_DONE != 0 && SLOTS >= NGSLD_MASK_SLOTS;
+    constexpr bool kMaskDone = SLOTS >= NGSLD_MASK_SLOTS;
     // As in em_pair: the hot loop holds the shared-reciprocal step in its three-value form only; a step that is not sane
     // in some live group leaves it for one iteration with a reciprocal per individual, and as soon as hap 0 of any live
     // group falls below kFullBelow the wavefront leaves it for good and finishes in the full four-value form.
     constexpr double kFullBelow = 0x1p-10;
-    bool full = kDrop0 && __any(!done && f0 < kFullBelow);
+    bool full = __any(!done && f0 < kFullBelow);
     uint32_t itn = 0;
     while (itn < (uint32_t)kIterMax) {
       if (kTree && !full) {
@@ -1646,7 +1405,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
           if (__any(!done && !(n1 < 2.0))) break;  // an odd step (one NaN reciprocal poisons every R, see em_pair)
           // as in em_pair: eps is at least the change of hap 1, and while that alone is above EPSILON in every live
           // group the other three differences are not formed
-          if (!NGSLD_EARLY_EPS || __any(!done && fabs(n1 - f1) < kEpsilonTie)) {
+          if (__any(!done && fabs(n1 - f1) < kEpsilonTie)) {
             const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
             if (!done && fabs(eps - kEpsilon) < kTieMargin) tie = true;  // too close to call: replayed
             if (!done && eps < kEpsilon) {  // gen_func.cpp:1054-1055
@@ -1662,7 +1421,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
             all_done = true;
             break;
           }
-          if (kDrop0 && __any(!done && f0 < kFullBelow)) {
+          if (__any(!done && f0 < kFullBelow)) {
             full = true;
             ++itn;  // this iteration is complete
             break;
@@ -1846,14 +1605,18 @@ __global__ __launch_bounds__(256, 2) void pair_ld_stream_kernel(PairArgs A) {
 }
 
 // host-callable launchers, defined in ld_pair_w1.hip / ld_pair_wn.hip
-// Kernel families: kGroup = 8/16/32 lanes per pair (n_ind <= 256), kWave = one wavefront per pair with the row vector shared
-// in LDS (n_ind <= 512), kMulti = 2..8 wavefronts per pair (n_ind <= 4096), kStream = any n_ind, vectors re-read every
-// iteration; kDirect = kWave/kMulti shapes without any prefetch (A/B); kRun = kWave's pipeline over runs of items
-// (the default for n_ind 257..512; kWave remains as its per-item A/B baseline).
-// kHard = every likelihood triple of the matrix is a called genotype or "no data": the pairs' 16 genotype-combination
-// counts replace the individuals (any n_ind up to kHardMaxInd).
-// kRunAB = one wavefront per pair for 513..1024 individuals, EM step in its a/b form, run pipeline (ld_pair_ab.hip).
-enum PairKernel { kGroup = 0, kWave = 1, kMulti = 2, kDirect = 3, kStream = 4, kRun = 5, kHard = 6, kRunAB = 7 };
+// Kernel families (pair_config picks by cohort size, by measurement: profiles/r03/sweep_513_1024.txt):
+//   kGroup  8 / 16 / 32 lanes per pair, several pairs per wavefront in lockstep (n_ind <= 128, some shapes up to 224)
+//   kRun    one wavefront per pair, the row vector shared in LDS, runs of items (n_ind <= 640: up to TEN individuals per lane)
+//   kRunAB  one wavefront per pair, EM step in its a/b form, run pipeline (ld_pair_ab.hip: 641..832, and 577..640 under
+//           --ignore_miss_data, whose per-slot pads do not fit beside ten slots of P)
+//   kMulti  2 / 4 / 8 wavefronts per pair (833..4608)
+//   kStream any n_ind, vectors re-read every iteration
+//   kHard   every likelihood triple of the matrix is a called genotype or "no data": the pairs' 16 genotype-combination
+//           counts replace the individuals (any n_ind up to kHardMaxInd)
+enum PairKernel { kGroup = 0, kMulti = 2, kStream = 4, kRun = 5, kHard = 6, kRunAB = 7 };
+// NGSLD_PAIR_KERNEL=multi | ab (tests, A/B): the multi-wavefront kernel from 513 individuals on / the a/b kernel for 513..1024
+enum PairChoice { kChooseAuto = 0, kChooseMulti = 1, kChooseAB = 2 };
 // kernels launched over runs of items (one workgroup per run, candidates addressed as 64 * item + offset)
 inline bool uses_runs(int kernel) { return kernel == kRun || kernel == kGroup || kernel == kHard || kernel == kRunAB; }
 constexpr uint32_t kHardMaxWords = 512;                 // row bit sets in LDS: 4 x 512 x 8 B = 16 KB
@@ -1865,8 +1628,11 @@ struct PairConfig {
   int waves;    // wavefronts per pair
   uint32_t np;  // padded individuals per genotype plane
 };
-bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg, bool allow_run = true,
-                 bool allow_ab = true);
+bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice = kChooseAuto);
+// the kernel a launch really takes: ten slots per lane under --ignore_miss_data run on the a/b kernel (same layout, same runs)
+inline int effective_kernel(const PairConfig &cfg, bool masked) {
+  return (cfg.kernel == kRun && cfg.slots == 10 && masked) ? (int)kRunAB : cfg.kernel;
+}
 hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs &args, hipStream_t stream);
 hipError_t launch_pair_hard(bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_hard.hip
 hipError_t launch_pair_ab(int slots, bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_ab.hip
@@ -1874,12 +1640,12 @@ hipError_t launch_pair_ab(int slots, bool masked, const PairArgs &args, hipStrea
 // cleared when any triple is neither a called genotype (1,0,0) / (0,1,0) / (0,0,1) nor three equal values
 hipError_t launch_classify_hard(const double *planes, uint64_t site_stride, uint32_t np, uint32_t n_ind, uint64_t n_sites,
                                 uint64_t *masks, double *u, int *all_hard, hipStream_t stream);
-// candidate s2 sites per work item: kGroup / kWave items are shared by the four wavefronts of a workgroup
+// candidate s2 sites per work item
 inline uint32_t item_span(const PairConfig &cfg, uint32_t pairs_per_item) {
   if (uses_runs(cfg.kernel)) return 64u;  // run form: candidates are addressed as 64 * item + offset
   // (multi-wavefront kernel: one workgroup works through the item pair by pair; 64 candidates per item instead of 16 means a
-  // quarter of the workgroups and of the per-item scalar loads: -1.3 % kernel time at n_ind 1000, -4.0 % at 2000, tools/ab_items.sh)
-  const uint32_t span = (cfg.kernel == kGroup || cfg.kernel == kWave || cfg.kernel == kMulti) ? 4u * pairs_per_item : pairs_per_item;
+  // quarter of the workgroups and of the per-item scalar loads: -1.3 % kernel time at n_ind 1000, -4.0 % at 2000)
+  const uint32_t span = cfg.kernel == kMulti ? 4u * pairs_per_item : pairs_per_item;
   return span > 64u ? 64u : span;
 }
 

@@ -1,5 +1,7 @@
-// ld_pair_ab.hip -- one wavefront per pair for 513..1024 individuals (BASELINE configs[3]: 50,000 x 1,000): the EM step
-// in its a/b form.  BUILT, MEASURED, NOT THE DEFAULT (NGSLD_PAIR_KERNEL=ab selects it; parity-tested like every kernel).
+// ld_pair_ab.hip -- one wavefront per pair beyond what the P form holds in registers: the EM step in its a/b form.
+// The default for 641..832 individuals, and for 577..640 under --ignore_miss_data (pair_config / effective_kernel, by
+// measurement: profiles/r03/sweep_513_1024.txt -- +9 % at 704, +2 % at 768, +5.5 % at 832 against two wavefronts per pair,
+// +6..13 % under --ignore_miss_data; level at 896..960, -6.5 % at 1,024); NGSLD_PAIR_KERNEL=ab selects it for 513..1024.
 //
 // The idea.  The other kernels keep P = a (x) b (9 products per individual, 18 VGPRs) for the whole pair, which caps a
 // lane at 8 individuals; above 512 individuals a pair is spread over 2..8 wavefronts that meet behind a barrier in EVERY
@@ -16,8 +18,8 @@
 // = 23 f64 VALU + the tree's share against 17 + share in the P form, no barrier, no LDS exchange, the bookkeeping once per
 // 16 slots: 500 VALU instructions per pair and iteration (-11 %), 237-254 VGPRs, no scratch.
 //
-// The measurement (same box, 12,000 x 1,000 all pairs, profiles/r02_multi/pmc_multi_vs_ab_n1000.txt): 8.83e7 pairs/s
-// against 8.98e7 for the two-wavefront kernel.  The counters say why: this kernel needs 8 % FEWER SIMD cycles
+// The measurement at n_ind 1,000 (same box, 12,000 x 1,000 all pairs, profiles/r02_multi/pmc_multi_vs_ab_n1000.txt), where
+// it does NOT pay: 8.83e7 pairs/s against 8.98e7 for the two-wavefront kernel.  The counters say why: this kernel needs 8 % FEWER SIMD cycles
 // (1.65e12 against 1.79e12, VALU busy 87.6 % against 85.1 %) -- and runs at a 9 % LOWER shader clock (1.99 GHz against
 // 2.20 GHz, GRBM_GUI_ACTIVE / duration): the chip is power-limited under these kernels, 5x the LDS traffic
 // (SQ_LDS_IDX_ACTIVE 1.5e11 against 5.8e10) and 35 % more f64 FMAs per individual cost more energy than the barrier
@@ -149,7 +151,7 @@ __device__ __forceinline__ uint32_t em_pair_ab(const double (&B)[SLOTS][3], cons
         em_step(PairedTag(), n0, n1, n2, n3);
         if (__builtin_amdgcn_ballot_w64(!(n1 < 2.0))) break;  // an odd step: second opinion below
         bool conv = false;
-        if (!NGSLD_EARLY_EPS || __builtin_amdgcn_ballot_w64(fabs(n1 - f1) < kEpsilonTie)) {
+        if (__builtin_amdgcn_ballot_w64(fabs(n1 - f1) < kEpsilonTie)) {
           const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
           conv = __builtin_amdgcn_ballot_w64(eps < kEpsilon) != 0;  // gen_func.cpp:1054-1055
           tie |= __builtin_amdgcn_ballot_w64(fabs(eps - kEpsilon) < kTieMargin) != 0;

@@ -1,4 +1,5 @@
-// ld_pair_w1.hip -- instantiations of the one-wavefront-per-pair kernel (n_ind <= 512) and the launcher.
+// ld_pair_w1.hip -- kernel selection by cohort size, instantiations of the one-wavefront-per-pair and lockstep kernels, and
+// the launcher.
 #include <cstdlib>
 
 #include <algorithm>
@@ -8,17 +9,17 @@
 
 namespace ngsld {
 
-// n_ind -> kernel family and shape.  Lane groups of 8 / 16 / 32 lanes x 8 slots cover 64 / 128 / 256 individuals
-// (group kernel); one wavefront holds up to 8*64 = 512 individuals as 18*8 = 144 VGPRs of P; above that 2..8
-// wavefronts share the pair (eight slots per lane, nine just past a doubling), and beyond 4608 the streaming kernel takes over.
-bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig *cfg, bool allow_run, bool allow_ab) {
+// n_ind -> kernel family and shape, by measurement (profiles/r03/sweep_513_1024.txt; profiles/r02b/sweep_nind.txt).
+// Lane groups of 8 / 16 / 32 lanes x 8 slots cover 64 / 128 / 256 individuals (group kernel); one wavefront holds up to
+// 10 * 64 = 640 individuals as 18 * 10 = 180 VGPRs of P (nine and ten slots spill a few registers OUTSIDE the EM loop and
+// still beat two wavefronts of five by 54 % / 29 %: the per-iteration bookkeeping is paid once, nothing meets behind a
+// barrier); up to 832 the a/b form on one wavefront; above that 2..8 wavefronts share the pair (eight slots per lane, nine
+// just past a doubling), and beyond 4608 the streaming kernel takes over.
+bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice) {
   if (n_ind == 0 || n_ind >= 0xffffffc0ull) return false;
   cfg->group = 64;
-  // Just past a doubling of the wavefronts (1,025..1,152, 2,049..2,304, 4,097..4,608 individuals) NINE slots on half as many
-  // wavefronts beat five on twice as many: half-empty lanes and twice the per-iteration bookkeeping against a few spilled
-  // registers outside the EM loop.  NGSLD_SLOTS9=0: the eight-slot shapes only (A/B).
-  const bool slots9 = allow_prefetch && !(std::getenv("NGSLD_SLOTS9") && std::strcmp(std::getenv("NGSLD_SLOTS9"), "0") == 0);
-  if (n_ind > (slots9 ? 4608u : 4096u)) {  // beyond 8 wavefronts x 8 (9) slots x 64 lanes: streaming kernel, one workgroup per pair
+  cfg->waves = 1;
+  if (n_ind > 4608u) {  // beyond 8 wavefronts x 9 slots x 64 lanes: streaming kernel, one workgroup per pair
     cfg->kernel = kStream;
     cfg->waves = 4;
     cfg->slots = 0;
@@ -28,29 +29,39 @@ bool pair_config(uint64_t n_ind, bool allow_prefetch, bool allow_row, PairConfig
   // 32-lane groups pay only where they pad less than 64 lanes do (an odd number of 32-individual slots: measured
   // +6..8 % at n_ind 160 / 200, -3 % at 250 where both shapes hold 256 individuals and lockstep is a pure loss)
   const bool g32 = n_ind > 128 && n_ind <= 256 && (((n_ind + 31) / 32) & 1ull);
-  if (allow_prefetch && allow_row && (n_ind <= 128 || g32)) {
+  if (n_ind <= 128 || g32) {
     cfg->kernel = kGroup;
-    cfg->waves = 1;
     cfg->group = n_ind <= 64 ? 8 : (n_ind <= 128 ? 16 : 32);
     cfg->slots = (int)((n_ind + (uint64_t)cfg->group - 1) / (uint64_t)cfg->group);
     cfg->np = (uint32_t)(cfg->slots * cfg->group);
     return true;
   }
-  if (allow_prefetch && allow_row && allow_run && allow_ab && n_ind > 512 && n_ind <= 1024) {
-    // one wavefront per pair, 9..16 individuals per lane, EM step in its a/b form (ld_pair_ab.hip)
-    cfg->kernel = kRunAB;
-    cfg->waves = 1;
-    cfg->slots = (int)((n_ind + 63) / 64);
-    cfg->np = (uint32_t)(cfg->slots * 64);
+  // one wavefront per pair: P form up to ten slots, a/b form up to thirteen (round 3, same box, pairs/s against two
+  // wavefronts: 513 +54 %, 576 +54 %, 640 +29 %, 704 +9 %, 768 +2 %, 832 +5.5 %; 896 and beyond: the two-wavefront kernel)
+  const uint64_t slots1 = (n_ind + 63) / 64;
+  const bool want_ab = choice == kChooseAB && n_ind > 512 && n_ind <= 1024;
+  if (!want_ab && (n_ind <= 512 || (choice == kChooseAuto && slots1 <= 10))) {
+    cfg->kernel = kRun;
+    cfg->slots = (int)slots1;
+    cfg->np = (uint32_t)(slots1 * 64);
     return true;
   }
-  int w = 1;
+  if (want_ab || (choice == kChooseAuto && slots1 <= 13)) {
+    cfg->kernel = kRunAB;
+    cfg->slots = (int)slots1;
+    cfg->np = (uint32_t)(slots1 * 64);
+    return true;
+  }
+  // Several wavefronts per pair.  Just past a doubling of the wavefronts (1,025..1,152, 2,049..2,304, 4,097..4,608
+  // individuals) NINE slots on half as many wavefronts beat five on twice as many: half-empty lanes and twice the
+  // per-iteration bookkeeping against a few spilled registers outside the EM loop (+35..46 % / +48..63 %).
+  int w = 2;
   while ((n_ind + 64ull * w - 1) / (64ull * w) > 8) w *= 2;
-  if (slots9 && w >= 4 && (n_ind + 32ull * w - 1) / (32ull * w) == 9) w /= 2;  // nine slots on w / 2 wavefronts
+  if (w >= 4 && (n_ind + 32ull * w - 1) / (32ull * w) == 9) w /= 2;  // nine slots on w / 2 wavefronts
   cfg->waves = w;
   cfg->slots = (int)((n_ind + 64ull * w - 1) / (64ull * w));
   cfg->np = (uint32_t)(cfg->slots * w * 64);
-  cfg->kernel = !allow_prefetch ? kDirect : (w == 1 ? (allow_run ? kRun : kWave) : kMulti);
+  cfg->kernel = kMulti;
   return true;
 }
 
@@ -82,31 +93,23 @@ static hipError_t launch_group(int slots, bool masked, const PairArgs &a, hipStr
 }
 
 template <int SLOTS>
-static hipError_t launch_s(int kernel, bool masked, const PairArgs &a, hipStream_t stream) {
-  const uint64_t blocks = kernel == kDirect ? (a.n_items + 3) / 4 : (kernel == kRun ? a.n_runs : a.n_items);
-  if (blocks == 0) return hipSuccess;
-  if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)blocks), block(256);
-  if (kernel == kRun) {
-    if (masked)
+static hipError_t launch_run(bool masked, const PairArgs &a, hipStream_t stream) {
+  if (a.n_runs == 0) return hipSuccess;
+  if (a.n_runs > 0x7fffffffull) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)a.n_runs), block(256);
+  if constexpr (SLOTS <= 9) {
+    if (masked) {
       hipLaunchKernelGGL((pair_ld_run_kernel<SLOTS, true>), grid, block, 0, stream, a);
-    else
-      hipLaunchKernelGGL((pair_ld_run_kernel<SLOTS, false>), grid, block, 0, stream, a);
-  } else if (kernel == kWave) {
-    if (masked)
-      hipLaunchKernelGGL((pair_ld_pf_kernel<SLOTS, true>), grid, block, 0, stream, a);
-    else
-      hipLaunchKernelGGL((pair_ld_pf_kernel<SLOTS, false>), grid, block, 0, stream, a);
-  } else {
-    if (masked)
-      hipLaunchKernelGGL((pair_ld_kernel<SLOTS, 1, true, false>), grid, block, 0, stream, a);
-    else
-      hipLaunchKernelGGL((pair_ld_kernel<SLOTS, 1, false, false>), grid, block, 0, stream, a);
+      return hipGetLastError();
+    }
+  } else if (masked) {
+    return hipErrorInvalidValue;  // (ten slots under --ignore_miss_data: the a/b kernel, see effective_kernel)
   }
+  hipLaunchKernelGGL((pair_ld_run_kernel<SLOTS, false>), grid, block, 0, stream, a);
   return hipGetLastError();
 }
 
-hipError_t launch_pair_wn(int slots, int waves, bool masked, bool prefetch, const PairArgs &a, hipStream_t stream);
+hipError_t launch_pair_wn(int slots, int waves, bool masked, const PairArgs &a, hipStream_t stream);
 
 static hipError_t launch_pair_chunk(const PairConfig &cfg, bool masked, const PairArgs &a, hipStream_t stream);
 
@@ -173,10 +176,9 @@ hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs
   }
   const bool by_runs = uses_runs(cfg.kernel);
   const uint64_t total = by_runs ? a.n_runs : a.n_items;
-  const uint64_t per = max_blocks * ((cfg.kernel == kDirect && cfg.waves == 1) ? 4u : 1u);  // kDirect: 4 items per block
-  for (uint64_t off = 0; off < total; off += per) {
+  for (uint64_t off = 0; off < total; off += max_blocks) {
     PairArgs b = a;
-    const uint64_t n = total - off < per ? total - off : per;
+    const uint64_t n = total - off < max_blocks ? total - off : max_blocks;
     if (by_runs) {
       b.runs = a.runs + off;
       b.n_runs = n;
@@ -201,22 +203,24 @@ static hipError_t launch_pair_chunk(const PairConfig &cfg, bool masked, const Pa
     return hipGetLastError();
   }
   if (cfg.kernel == kHard) return launch_pair_hard(masked, a, stream);
-  if (cfg.kernel == kRunAB) return launch_pair_ab(cfg.slots, masked, a, stream);
+  if (effective_kernel(cfg, masked) == kRunAB) return launch_pair_ab(cfg.slots, masked, a, stream);
   if (cfg.kernel == kGroup) {
     if (cfg.group == 8) return launch_group<8>(cfg.slots, masked, a, stream);
     if (cfg.group == 16) return launch_group<16>(cfg.slots, masked, a, stream);
     return launch_group<32>(cfg.slots, masked, a, stream);
   }
-  if (cfg.waves != 1) return launch_pair_wn(cfg.slots, cfg.waves, masked, cfg.kernel == kMulti, a, stream);
-  switch (cfg.slots) {
-    case 1: return launch_s<1>(cfg.kernel, masked, a, stream);
-    case 2: return launch_s<2>(cfg.kernel, masked, a, stream);
-    case 3: return launch_s<3>(cfg.kernel, masked, a, stream);
-    case 4: return launch_s<4>(cfg.kernel, masked, a, stream);
-    case 5: return launch_s<5>(cfg.kernel, masked, a, stream);
-    case 6: return launch_s<6>(cfg.kernel, masked, a, stream);
-    case 7: return launch_s<7>(cfg.kernel, masked, a, stream);
-    case 8: return launch_s<8>(cfg.kernel, masked, a, stream);
+  if (cfg.kernel == kMulti) return launch_pair_wn(cfg.slots, cfg.waves, masked, a, stream);
+  switch (cfg.slots) {  // kRun
+    case 1: return launch_run<1>(masked, a, stream);
+    case 2: return launch_run<2>(masked, a, stream);
+    case 3: return launch_run<3>(masked, a, stream);
+    case 4: return launch_run<4>(masked, a, stream);
+    case 5: return launch_run<5>(masked, a, stream);
+    case 6: return launch_run<6>(masked, a, stream);
+    case 7: return launch_run<7>(masked, a, stream);
+    case 8: return launch_run<8>(masked, a, stream);
+    case 9: return launch_run<9>(masked, a, stream);
+    case 10: return launch_run<10>(masked, a, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -88,71 +88,187 @@ __device__ __forceinline__ void block_minmax(double (&mn)[1], double (&mx)[1], d
   mx[0] = M;
 }
 
+// One individual's raw triple -> normal-space normalised likelihoods a0..a2 and its two est_maf terms.
+//
+// The reference's sequence (read_data.cpp:37-45, gen_func.cpp:974-1009, ngsLD.cpp:110): log, log-normalise (logsum:
+// three exp and a log), NaN check, [call_geno], est_maf's own logsum and three exp, three exp back to normal space -- 12
+// exp and 5 log per individual, ~750 f64 instructions: the prep kernel was bound by them, not by memory (1.5 TB/s).
+// Mathematically the result is a_k = raw_k / (raw_0 + raw_1 + raw_2) and est_maf's posterior is a itself; the chain of
+// logs only adds rounding noise (~|log raw| * 1e-16).  FAST path: exactly that quotient, for triples that are finite,
+// non-negative, not all zero and in the normal range -- every case in which the chain has no special behaviour.  Everything
+// else (zeros everywhere, negative / NaN / inf values, log-scale or text input, --call_geno) takes the chain as written.
+// Agreement with the reference's compiled est_maf stays far inside the 1e-12 bar (tests: ref_maf of every golden fixture).
+struct PrepFlags {
+  bool log_scale, ignore_miss, text_semantics, call_geno, fast_ok;
+  double N_thresh, call_thresh;
+};
+
+__device__ __forceinline__ bool close_in_log(double x, double y) {  // |log x - log y| < EPSILON (miss_data on log values)
+  constexpr double kExpEps = 1.00001000005000016667;                // exp(1e-5)
+  return x == y || (x < y * kExpEps && y < x * kExpEps);
+}
+
+__device__ __forceinline__ void prep_individual(const PrepFlags &F, double g0, double g1, double g2, double &a0, double &a1,
+                                                double &a2, double &num, double &den, bool &nan_seen) {
+  double mx = g0 > g1 ? g0 : g1;
+  mx = g2 > mx ? g2 : mx;
+  if (F.fast_ok && g0 >= 0.0 && g1 >= 0.0 && g2 >= 0.0 && mx >= 0x1p-960 && mx <= 0x1p+960) {
+    const double r = 1.0 / ((g0 + g1) + g2);
+    a0 = g0 * r;
+    a1 = g1 * r;
+    a2 = g2 * r;
+    if (!(F.ignore_miss && close_in_log(a0, a1) && close_in_log(a1, a2))) {  // miss_data on LOG values, gen_func.cpp:985
+      num += a1 + a2 * 2.0;
+      den += 2.0 * a1 + (a0 + a2) * 2.0;
+    }
+    return;
+  }
+  if (!F.log_scale) {
+    if (F.text_semantics) {  // read_data.cpp:86: plain log(), -inf stays
+      g0 = log(g0);
+      g1 = log(g1);
+      g2 = log(g2);
+    } else {  // read_data.cpp:37-38
+      g0 = conv_log(g0);
+      g1 = conv_log(g1);
+      g2 = conv_log(g2);
+    }
+  }
+  const double norm = logsum3(g0, g1, g2);  // post_prob, read_data.cpp:40
+  g0 -= norm;
+  g1 -= norm;
+  g2 -= norm;
+  if (!F.text_semantics && (g0 != g0 || g1 != g1 || g2 != g2)) nan_seen = true;  // read_data.cpp:42-45
+  if (F.call_geno) call_geno(g0, g1, g2, F.N_thresh, F.call_thresh);             // ngsLD.cpp:92-98
+  // est_maf (gen_func.cpp:974-1009, indF == NULL): closed form of its two identical passes
+  if (!(F.ignore_miss && miss_data(g0, g1, g2))) {  // miss_data on LOG values, :985
+    const double n2 = logsum3(g0, g1, g2);
+    const double p0 = exp(g0 - n2), p1 = exp(g1 - n2), p2 = exp(g2 - n2);
+    num += p1 + p2 * 2.0;
+    den += 2.0 * p1 + (p0 + p2) * 2.0;
+  }
+  a0 = exp(g0);  // ngsLD.cpp:110
+  a1 = exp(g1);
+  a2 = exp(g2);
+}
+
+__device__ __forceinline__ PrepFlags prep_flags(const PrepArgs &A) {
+  PrepFlags F;
+  F.log_scale = A.log_scale != 0;
+  F.ignore_miss = A.ignore_miss != 0;
+  F.text_semantics = A.text_semantics != 0;
+  F.call_geno = A.call_geno != 0;
+  F.fast_ok = !F.log_scale && !F.text_semantics && !F.call_geno && A.exact_chain == 0;
+  F.N_thresh = A.N_thresh;
+  F.call_thresh = A.call_thresh;
+  return F;
+}
+
+// A site's three per-site scalars from its sums.  A site whose expected genotypes are all the same value must come out with
+// variance exactly 0 (gsl_stats_correlation's running mean has delta == 0 there and returns 0/0): min == max makes the
+// mean that value itself rather than a rounded sum / n.
+// (rsx = +inf there: NaN on every path.  Nearly constant sites are dealt with per PAIR: ld_device.h, kPearsonCond.)
+__device__ __forceinline__ double site_rsx(double sq) { return 1.0 / sqrt(sq); }  // sq = sum (e - mean)^2
+
+// n_ind <= 2048: one WAVEFRONT per site, a lane holds the expected genotypes of its <= MAXJ individuals in registers -- no
+// barrier, no second pass over the planes (the workgroup-per-site form re-read them twice and met ten times per site).
+template <int MAXJ>
+__global__ __launch_bounds__(256) void prep_sites_wave_kernel(PrepArgs A) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const PrepFlags F = prep_flags(A);
+  for (uint64_t site = (uint64_t)blockIdx.x * 4 + wave; site < A.n_sites; site += (uint64_t)gridDim.x * 4) {
+    const double *__restrict__ raw = A.raw + site * (uint64_t)A.n_ind * 3;
+    double *__restrict__ pl = A.planes + (A.site0 + site) * A.site_stride;
+    double e[MAXJ];
+    double num = 0.0, den = 0.0, esum = 0.0;
+    double mn = __builtin_inf(), mx = -__builtin_inf();
+    bool nan_seen = false;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const uint32_t i = (uint32_t)lane + 64u * (uint32_t)j;
+      e[j] = 0.0;
+      if (i < A.np) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        if (i < A.n_ind) {
+          const double g0 = raw[3 * (uint64_t)i], g1 = raw[3 * (uint64_t)i + 1], g2 = raw[3 * (uint64_t)i + 2];
+          if (!A.normalised_input) {
+            prep_individual(F, g0, g1, g2, a0, a1, a2, num, den, nan_seen);
+          } else {
+            a0 = g0;
+            a1 = g1;
+            a2 = g2;
+          }
+          const double ev = fma(2.0, a2, a1);  // expected genotype, ngsLD.cpp:113
+          e[j] = ev;
+          esum += ev;
+          mn = ev < mn ? ev : mn;
+          mx = ev > mx ? ev : mx;
+        }
+        pl[i] = a0;
+        pl[A.np + i] = a1;
+        pl[2 * (uint64_t)A.np + i] = a2;
+      }
+    }
+    wave_sum3(num, den, esum);
+    for (int off = 32; off > 0; off >>= 1) {
+      const double x = __shfl_xor(mn, off), y = __shfl_xor(mx, off);
+      mn = x < mn ? x : mn;
+      mx = y > mx ? y : mx;
+    }
+    const double mean = mn == mx ? mn : esum / (double)A.n_ind;
+    double sq = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+      const uint32_t i = (uint32_t)lane + 64u * (uint32_t)j;
+      const double d = i < A.n_ind ? e[j] - mean : 0.0;
+      sq = fma(d, d, sq);
+    }
+    sq = wave_sum1(sq);
+    if (lane == 0) {
+      A.maf[A.site0 + site] = A.normalised_input ? A.maf_in[site] : num / den;
+      A.mean_e[A.site0 + site] = mean;
+      A.rsx[A.site0 + site] = site_rsx(sq);
+    }
+    if (nan_seen) atomicExch(A.status, (int)NGSLD_ERR_NAN);
+  }
+}
+
+// Any n_ind: one workgroup per site, fixed-order workgroup sums.
 __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
   __shared__ double sh3[4][3];
   __shared__ double sh1[4][1];
+  const PrepFlags F = prep_flags(A);
   for (uint64_t site = blockIdx.x; site < A.n_sites; site += gridDim.x) {
-    const double *raw = A.raw + site * (uint64_t)A.n_ind * 3;
-    double *pl = A.planes + (A.site0 + site) * A.site_stride;
+    const double *__restrict__ raw = A.raw + site * (uint64_t)A.n_ind * 3;
+    double *__restrict__ pl = A.planes + (A.site0 + site) * A.site_stride;
     double acc[3] = {0.0, 0.0, 0.0};  // num, den (est_maf), sum of expected genotypes
+    double mn[1] = {__builtin_inf()}, mx[1] = {-__builtin_inf()};
     bool nan_seen = false;
     for (uint32_t i = threadIdx.x; i < A.np; i += 256) {
       double a0 = 0.0, a1 = 0.0, a2 = 0.0;
       if (i < A.n_ind) {
-        double g0 = raw[3 * (uint64_t)i], g1 = raw[3 * (uint64_t)i + 1], g2 = raw[3 * (uint64_t)i + 2];
+        const double g0 = raw[3 * (uint64_t)i], g1 = raw[3 * (uint64_t)i + 1], g2 = raw[3 * (uint64_t)i + 2];
         if (!A.normalised_input) {
-          if (!A.log_scale) {
-            if (A.text_semantics) {  // read_data.cpp:86: plain log(), -inf stays
-              g0 = log(g0);
-              g1 = log(g1);
-              g2 = log(g2);
-            } else {  // read_data.cpp:37-38
-              g0 = conv_log(g0);
-              g1 = conv_log(g1);
-              g2 = conv_log(g2);
-            }
-          }
-          const double norm = logsum3(g0, g1, g2);  // post_prob, read_data.cpp:40
-          g0 -= norm;
-          g1 -= norm;
-          g2 -= norm;
-          if (!A.text_semantics && (g0 != g0 || g1 != g1 || g2 != g2)) nan_seen = true;  // read_data.cpp:42-45
-          if (A.call_geno) call_geno(g0, g1, g2, A.N_thresh, A.call_thresh);             // ngsLD.cpp:92-98
-          // est_maf (gen_func.cpp:974-1009, indF == NULL): closed form of its two identical passes
-          if (!(A.ignore_miss && miss_data(g0, g1, g2))) {  // miss_data on LOG values, :985
-            const double n2 = logsum3(g0, g1, g2);
-            const double p0 = exp(g0 - n2), p1 = exp(g1 - n2), p2 = exp(g2 - n2);
-            acc[0] += p1 + p2 * 2.0;
-            acc[1] += 2.0 * p1 + (p0 + p2) * 2.0;
-          }
-          a0 = exp(g0);  // ngsLD.cpp:110
-          a1 = exp(g1);
-          a2 = exp(g2);
+          prep_individual(F, g0, g1, g2, a0, a1, a2, acc[0], acc[1], nan_seen);
         } else {
           a0 = g0;
           a1 = g1;
           a2 = g2;
         }
-        acc[2] += fma(2.0, a2, a1);  // expected genotype, ngsLD.cpp:113
+        const double ev = fma(2.0, a2, a1);  // expected genotype, ngsLD.cpp:113
+        acc[2] += ev;
+        mn[0] = ev < mn[0] ? ev : mn[0];
+        mx[0] = ev > mx[0] ? ev : mx[0];
       }
       pl[i] = a0;
       pl[A.np + i] = a1;
       pl[2 * (uint64_t)A.np + i] = a2;
     }
     block_sum<3>(acc, sh3);
-    // A site whose expected genotypes are all the same value must come out with variance exactly 0
-    // (gsl_stats_correlation's running mean has delta == 0 there and returns 0/0): take min/max so the
-    // mean is that value itself rather than a rounded sum / n.
-    double mn[1] = {__builtin_inf()}, mx[1] = {-__builtin_inf()};
-    for (uint32_t i = threadIdx.x; i < A.n_ind; i += 256) {
-      const double e = fma(2.0, pl[2 * (uint64_t)A.np + i], pl[A.np + i]);
-      mn[0] = e < mn[0] ? e : mn[0];
-      mx[0] = e > mx[0] ? e : mx[0];
-    }
     block_minmax(mn, mx, sh1);
     const double mean = mn[0] == mx[0] ? mn[0] : acc[2] / (double)A.n_ind;
     double sq[1] = {0.0};
-    for (uint32_t i = threadIdx.x; i < A.n_ind; i += 256) {
+    for (uint32_t i = threadIdx.x; i < A.n_ind; i += 256) {  // (its own stores: visible to the thread that made them)
       const double d = fma(2.0, pl[2 * (uint64_t)A.np + i], pl[A.np + i]) - mean;
       sq[0] = fma(d, d, sq[0]);
     }
@@ -160,14 +276,7 @@ __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
     if (threadIdx.x == 0) {
       A.maf[A.site0 + site] = A.normalised_input ? A.maf_in[site] : acc[0] / acc[1];
       A.mean_e[A.site0 + site] = mean;
-      // A site whose expected genotypes are constant UP TO ROUNDING (spread below 1/500 of their size: nobody carries
-      // information) leaves gsl_stats_correlation a quotient of its own accumulation noise; such a site is marked by a
-      // NEGATIVE rsx and its pairs go through the exact-order replay (ld_device.h, kReplayBelow).  An exactly constant
-      // site (rsx = +inf) is NaN on every path and needs no replay.
-      double rs = 1.0 / sqrt(sq[0]);
-      const double size = fabs(mean) > 1.0 ? fabs(mean) : 1.0;
-      if (rs != __builtin_inf() && sqrt((double)A.n_ind) * size * rs > 500.0) rs = -rs;
-      A.rsx[A.site0 + site] = rs;
+      A.rsx[A.site0 + site] = site_rsx(sq[0]);
     }
     if (nan_seen) atomicExch(A.status, (int)NGSLD_ERR_NAN);
   }
@@ -175,6 +284,17 @@ __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
 
 hipError_t launch_prep(const PrepArgs &a, hipStream_t stream) {
   if (a.n_sites == 0) return hipSuccess;
+  if (a.np <= 2048) {
+    const uint64_t wgs = (a.n_sites + 3) / 4;
+    const unsigned grid = (unsigned)(wgs < 65536 ? wgs : 65536);
+    if (a.np <= 512)
+      hipLaunchKernelGGL(prep_sites_wave_kernel<8>, dim3(grid), dim3(256), 0, stream, a);
+    else if (a.np <= 1024)
+      hipLaunchKernelGGL(prep_sites_wave_kernel<16>, dim3(grid), dim3(256), 0, stream, a);
+    else
+      hipLaunchKernelGGL(prep_sites_wave_kernel<32>, dim3(grid), dim3(256), 0, stream, a);
+    return hipGetLastError();
+  }
   const unsigned grid = (unsigned)(a.n_sites < 65536 ? a.n_sites : 65536);
   hipLaunchKernelGGL(prep_sites_kernel, dim3(grid), dim3(256), 0, stream, a);
   return hipGetLastError();

@@ -67,7 +67,11 @@ def test_tiled_workgroup_order_of_the_multi_wavefront_kernel(n_ind, n_sites):
     from util import check_records
     raw = synth.make_gl_numpy(n_sites, n_ind, 77 + n_ind, depth=4.0)
     os.environ["NGSLD_TILE_MIN_MB"] = "0"                       # (tiles are for matrices beyond the 256 MB Infinity Cache)
-    eng = capi.Engine(0)
+    os.environ["NGSLD_PAIR_KERNEL"] = "multi"                   # (n_ind 520 would run on one wavefront per pair)
+    try:
+        eng = capi.Engine(0)
+    finally:
+        del os.environ["NGSLD_PAIR_KERNEL"]
     try:
         eng.set_geno_raw(raw)
         assert eng.pair_kernel() == "multi"

@@ -1,5 +1,5 @@
-"""GPU: the run kernel (n_ind 257..512, one workgroup per run of up to 8 items of a row) against the oracle and
-against its per-item baseline kernel.
+"""GPU: the run kernels (one wavefront per pair: n_ind 129..640 in the P form, 641..832 in the a/b form; one workgroup per
+run of up to 16 items of a row) against the oracle.
 
 What is specific to it and therefore tested here: rows longer than one run (claims that cross item and run
 boundaries), items whose mask drops candidates (maf[s2] skip, --rnd_sample), the row's short last item, records
@@ -64,32 +64,12 @@ def test_windowed_rows_split_into_equal_runs(engine):
     pd = shard.pos_dist_from_positions(chrs, pos)
     rec = _check(engine, raw[:900], pd[:900], max_kb_dist=60)       # oracle-sized head: full comparison
     assert len(rec) > 200_000
-    # the whole matrix: records of the run kernel and of its per-item baseline are the same BITS
-    out = []
-    import os
-    for kernel in ("", "item"):
-        if kernel:
-            os.environ["NGSLD_PAIR_KERNEL"] = kernel
-        try:
-            eng = capi.Engine(0)
-        finally:
-            if kernel:
-                del os.environ["NGSLD_PAIR_KERNEL"]
-        try:
-            eng.set_geno_raw(raw)
-            eng.set_pos_dist(pd)
-            eng.plan(60, 0, 0.0, False, True)
-            out.append(eng.run())
-        finally:
-            eng.close()
-    for a, b in zip(*out):
-        assert a.tobytes() == b.tobytes()
 
 
 @pytest.mark.parametrize("n_ind,ignore_miss", [(513, False), (640, True), (777, False), (1000, False), (1024, True)])
 def test_ab_form_kernel_matches_the_oracle(n_ind, ignore_miss):
-    """NGSLD_PAIR_KERNEL=ab: one wavefront per pair for 513..1024 individuals, EM step in its a/b form (ld_pair_ab.hip;
-    measured against the two-wavefront kernel and not the default).  Held to the same bars as every kernel."""
+    """NGSLD_PAIR_KERNEL=ab: one wavefront per pair for 513..1024 individuals, EM step in its a/b form (ld_pair_ab.hip: the
+    default for 641..832, and for 577..640 under --ignore_miss_data).  Held to the same bars as every kernel."""
     import os
     from oracle import orc
     from util import check_records
@@ -172,5 +152,55 @@ def test_runs_recut_between_text_and_record_runs(n_ind):
         for a, b in zip(got, ref_rec):
             assert a.tobytes() == b.tobytes()
         assert device_records() == want
+    finally:
+        eng.close()
+
+
+# what pair_config picks by cohort size (profiles/r03/sweep_513_1024.txt), and that every one of those shapes agrees with the oracle
+SHAPES = [(512, False, "run"), (513, False, "run"), (513, True, "run"), (576, False, "run"), (576, True, "run"),
+          (577, False, "run"), (577, True, "ab"), (640, False, "run"), (640, True, "ab"), (641, False, "ab"),
+          (704, True, "ab"), (832, False, "ab"), (832, True, "ab"), (833, False, "multi"), (833, True, "multi")]
+
+
+@pytest.mark.parametrize("n_ind,ignore_miss,family", SHAPES)
+def test_cohort_sizes_around_the_kernel_boundaries(n_ind, ignore_miss, family):
+    """513..640 individuals stay on ONE wavefront per pair (nine / ten individuals per lane), 641..832 take the a/b form,
+    beyond that two wavefronts share a pair: the kernel reported is the one expected, and every one of them meets the
+    oracle -- a monomorphic site, a site without data for a third of the cohort, a row longer than one item."""
+    n_sites = 70
+    raw = synth.make_gl_numpy(n_sites, n_ind, 1300 + n_ind, depth=3.0)
+    raw[5] = [1.0, 0.0, 0.0]
+    raw[9, ::3] = 1.0 / 3.0
+    want = orc.Oracle(raw, ignore_miss_data=ignore_miss, n_threads=8).run()
+    eng = capi.Engine(0)
+    try:
+        eng.set_geno_raw(raw, ignore_miss_data=ignore_miss)
+        eng.set_pos_dist(None)
+        assert eng.plan(ignore_miss_data=ignore_miss) == len(want)
+        assert eng.pair_kernel() == family
+        s1, s2, std, ext = eng.run()
+        check_records(std, ext, want)
+    finally:
+        eng.close()
+
+
+def test_multi_wavefront_kernel_can_be_forced_from_513_on():
+    """NGSLD_PAIR_KERNEL=multi (tests, A/B): the several-wavefronts-per-pair kernel for a cohort the one-wavefront kernels
+    would take -- its five-slot shapes with padding inside the last wavefront keep their coverage."""
+    import os
+    raw = synth.make_gl_numpy(40, 600, 1400, depth=3.0)
+    want = orc.Oracle(raw, n_threads=8).run()
+    os.environ["NGSLD_PAIR_KERNEL"] = "multi"
+    try:
+        eng = capi.Engine(0)
+    finally:
+        del os.environ["NGSLD_PAIR_KERNEL"]
+    try:
+        eng.set_geno_raw(raw)
+        assert eng.pair_kernel() == "multi"
+        eng.set_pos_dist(None)
+        assert eng.plan() == len(want)
+        s1, s2, std, ext = eng.run()
+        check_records(std, ext, want)
     finally:
         eng.close()
