@@ -80,7 +80,10 @@ def parse():
     ap.add_argument("--rnd-sample", type=float, default=1.0, help="--rnd_sample of the plan (not the headline config)")
     ap.add_argument("--hard-calls", action="store_true",
                     help="hard-call the synthetic likelihoods (argmax -> 1/0/0 triples): the genotype-combination kernel (not the headline config)")
-    ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "hbm_traffic.json"))
+    ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "hbm_traffic.json"),
+                    help="fallback for roofline.traffic when rocprofv3 is not available")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not re-run one launch under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE for roofline.traffic")
     a = ap.parse_args()
     preset = CONFIGS[a.config]
     a.custom = any(getattr(a, k) is not None for k in ("sites", "ind", "max_kb", "max_gap", "scaling"))
@@ -207,6 +210,62 @@ def e2e_file_to_tsv(raw_dev, n_sites: int, n_ind: int, chrs, pos, max_kb: int, t
             best = dt if best is None else min(best, dt)
     return {"seconds": best, "n_threads": threads, "what": "ngsld_amd/bin/ngsLD: file read, H2D, per-site prep, plan, pair "
             "kernels, device-side TSV, D2H of the text, write to /dev/null (best of 2)"}
+
+
+def measure_traffic(args) -> dict | None:
+    """roofline.traffic, measured in THIS run: one launch of the same workload under `rocprofv3 --pmc FETCH_SIZE` and one
+    under `--pmc WRITE_SIZE` (the two do not fit one pass; counters never combined with trace domains), outside the timed
+    region, after the engine of the timed run is closed.  Bytes as MI355X_MICROARCH.md (HBM section) prescribes:
+    FETCH_SIZE is in KiB and reports half the bytes of a wide (16 B per lane) coalesced stream on gfx950 -- the pair kernels'
+    site copies are global_load_lds_dwordx4 -- so it is doubled; WRITE_SIZE in KiB as it comes.  The counters sit on the L2's
+    fabric side: Infinity-Cache hits are counted, so this is an upper bound on HBM bytes."""
+    import csv
+    import glob
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    child = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--config", args.config, "--steps", "1",
+             "--warmup", "0", "--no-cpu", "--no-sink", "--no-e2e", "--no-traffic", "--sites", str(args.sites), "--ind",
+             str(args.ind), "--max-kb", str(args.max_kb), "--max-gap", str(args.max_gap), "--scaling", args.scaling,
+             "--depth", repr(args.depth), "--seed", str(args.seed), "--rnd-sample", repr(args.rnd_sample)]
+    if args.ignore_miss:
+        child.append("--ignore-miss")
+    if args.hard_calls:
+        child.append("--hard-calls")
+    if args.pairs_per_item:
+        child += ["--pairs-per-item", str(args.pairs_per_item)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    got, names = {}, set()
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            try:
+                r = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "run", "--"] + child,
+                                   cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+            except (OSError, subprocess.TimeoutExpired) as e:
+                return {"error": f"rocprofv3 --pmc {counter}: {e!r}"}
+            if r.returncode != 0:
+                return {"error": f"rocprofv3 --pmc {counter} exited {r.returncode}: {r.stderr[-300:]}"}
+            per_dispatch = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if "pair_ld" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                            key = (f, row.get("Dispatch_Id"))
+                            per_dispatch[key] = per_dispatch.get(key, 0.0) + float(row["Counter_Value"])
+                            names.add(row["Kernel_Name"].split("(")[0][:80])
+            if not per_dispatch:
+                return {"error": f"no pair-kernel rows in the {counter} pass"}
+            got[counter] = sum(per_dispatch.values())          # the step's launches (one, unless the grid was cut)
+    fetch, write = got["FETCH_SIZE"] * 1024.0 * 2.0, got["WRITE_SIZE"] * 1024.0
+    return {"bytes_per_step": fetch + write, "fetch_bytes_corrected": fetch, "write_bytes": write,
+            "kernels": sorted(names), "seconds": round(time.perf_counter() - t0, 1),
+            "source": "measured_this_run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, two single-step passes of this "
+                      "workload outside the timed region; FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-stream correction, "
+                      "MI355X_MICROARCH.md HBM section) + WRITE_SIZE KiB x 1024; fabric-side counters: Infinity-Cache hits "
+                      "included, an upper bound on HBM bytes"}
 
 
 def main():
@@ -391,16 +450,6 @@ def main():
         # FP64 view: per individual and executed iteration 9 FMA (s) + 8 FMA (R) + 3 of the shared-reciprocal tree
         dp_ops = pairs_per_launch * n_ind * mean_exec * 20.0
         fp64_tflops = 2.0 * dp_ops / launch_s / 1e12
-        traffic, traffic_src = None, None
-        try:
-            with open(args.traffic_json) as fh:
-                tj = json.load(fh)
-            if tj.get("workload") == f"{args.sites}x{n_ind}@{args.max_kb}kb":
-                traffic = tj.get("hbm_bytes_per_launch")
-                traffic_src = ("from_profile: rocprofv3 PMC passes of an earlier run of this workload (" +
-                               os.path.relpath(args.traffic_json, REPO) + "), not measured in this run")
-        except (OSError, ValueError):
-            pass
         preset = CONFIGS[args.config]
         is_preset = not args.custom and not args.hard_calls
         out = {
@@ -429,7 +478,8 @@ def main():
                                   "against the kernels); one pass, all ranks, MAX over ranks",
             "e2e_file_to_tsv_s": e2e,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                         "traffic_per_pair": None, "traffic_detail": None,
                          "frac_is": "algorithmic bytes per pair x pairs per launch / kernel time, over the HBM peak -- NOT the "
                                     "HBM utilisation: the row vector is shared through LDS and the window is re-read from L2 / "
                                     "Infinity Cache (`traffic`); the binding roofline is fp64_valu",
@@ -454,9 +504,31 @@ def main():
                                                args.cpu_seconds, gpu_rows)
         else:
             out["cpu_baseline"] = None
+        traffic, traffic_src, traffic_detail = None, None, None
+        launches_per_step = max(launches, 1) / max(args.steps, 1)
+        if world == 1 and not args.no_traffic:
+            eng.close()                                   # (everything the line needs from it has been taken)
+            eng = None
+            traffic_detail = measure_traffic(args)
+            if traffic_detail and "bytes_per_step" in traffic_detail:
+                traffic = traffic_detail["bytes_per_step"] / launches_per_step
+                traffic_src = traffic_detail["source"]
+        if traffic is None:
+            try:
+                with open(args.traffic_json) as fh:
+                    tj = json.load(fh)
+                if tj.get("workload") == f"{args.sites}x{n_ind}@{args.max_kb}kb":
+                    traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_src = ("from_profile: rocprofv3 PMC passes of an earlier run of this workload (" +
+                                   os.path.relpath(args.traffic_json, REPO) + "), not measured in this run")
+            except (OSError, ValueError):
+                pass
+        out["roofline"].update(traffic=traffic, traffic_source=traffic_src, traffic_detail=traffic_detail,
+                               traffic_per_pair=(traffic / pairs_per_launch) if traffic else None)
         print(json.dumps(out), flush=True)
 
-    eng.close()
+    if eng is not None:
+        eng.close()
     if world > 1:
         dist.destroy_process_group()
 

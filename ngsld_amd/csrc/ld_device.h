@@ -374,10 +374,13 @@ __device__ __forceinline__ void unrelabel(bool flip1, bool flip2, double &f0, do
 // LDS (prefetch kernel); after inlining the compiler knows which and emits global_load or ds_read.
 //   UNCENTRED: sxy comes back as the uncentred cross moment sum e1 e2 -- padding lanes hold a == b == 0, so no bounds
 //   test -- and the caller subtracts n * mean1 * mean2 once per pair
-//   pads (may be null): MASKED -- P of an individual WITHOUT data is zeroed and pads[j] = 1 there (0 elsewhere), so
-//   that em_pair can run its one-reciprocal-per-lane step over all slots: such an individual's s is exactly 1 and it
-//   adds nothing to R (the same device that neutralises the padding lanes of the last slot); not MASKED -- pads[j] = 1 in
-//   the padding lanes of ANY slot (several wavefronts per pair whose padding is not confined to a last slot)
+//   GHOSTS.  A slot that holds no individual -- a padding lane, or under --ignore_miss_data an individual without data at
+//   either site -- is staged as P = (1, 0, ..., 0).  In the hot EM step (shared reciprocal, three-value form) such a slot has
+//   s = f0^2 -- positive, at least 2^-20 while the pair is in that loop -- so it neither zeroes the lane's product tree nor
+//   overflows its reciprocal, and it adds nothing to R[1..8]: r * 0.  R[0] is never accumulated in that form.  The steps
+//   that do accumulate R[0] take one reciprocal per individual and skip the slot by its validity bit.  (Rounds 1-2 kept
+//   P = 0 and added a per-slot `pad` of 0 / 1 to s: two registers per slot in every kernel that may hold empty slots
+//   anywhere -- all of --ignore_miss_data -- which is what spilled there.)
 __device__ __forceinline__ const double *uniform_ptr(const double *p) {  // a wavefront-uniform pointer, said so: SGPRs
   const uint64_t v = (uint64_t)(uintptr_t)p;
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
@@ -393,8 +396,8 @@ __device__ __forceinline__ const double *uniform_ptr(const double *p) {  // a wa
 template <int SLOTS, bool MASKED, bool ONLY_LAST = false, bool UNCENTRED = false, bool A_GLOBAL = false>  // ONLY_LAST: only the last slot can hold padding lanes
 __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint32_t ia0, const double *pb, uint32_t npb,
                                            uint32_t ib0, uint32_t ind0, uint32_t n_ind, double mean1, double mean2,
-                                           double (&P)[SLOTS][9], uint32_t &vbits, double &sxy, double *pads = nullptr,
-                                           bool flip_a = false, bool flip_b = false) {
+                                           double (&P)[SLOTS][9], uint32_t &vbits, double &sxy, bool flip_a = false,
+                                           bool flip_b = false) {
   // pa[g * npa + ia0 + 64 j] / pb[g * npb + ib0 + 64 j] hold genotype g of individual ind0 + 64 j (this lane, slot j);
   // flip_a / flip_b (wavefront-uniform) relabel the alleles of a site: genotype planes 0 and 2 trade places (see Relabel)
   vbits = 0;
@@ -416,14 +419,16 @@ __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint3
     if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);  // gen_func.cpp:1089
     vbits |= (ok ? 1u : 0u) << j;
     double z0 = a0, z1 = a1, z2 = a2;
-    if (MASKED && pads != nullptr) {
+    if (MASKED) {  // an individual without data: P = (1, 0, ..., 0)
       const double keep = ok ? 1.0 : 0.0;
       z0 = a0 * keep; z1 = a1 * keep; z2 = a2 * keep;
-      pads[j] = 1.0 - keep;
-    } else if (pads != nullptr) {  // every individual counts: only padding lanes (zeros in the planes already) get a pad
-      pads[j] = inb ? 0.0 : 1.0;
+      P[j][0] = fma(z0, b0, 1.0 - keep);
+    } else if (!(ONLY_LAST && j < SLOTS - 1)) {  // padding lanes hold zeros in the planes already
+      P[j][0] = fma(a0, b0, inb ? 0.0 : 1.0);
+    } else {
+      P[j][0] = a0 * b0;
     }
-    P[j][0] = z0 * b0; P[j][1] = z0 * b1; P[j][2] = z0 * b2;
+    P[j][1] = z0 * b1; P[j][2] = z0 * b2;
     P[j][3] = z1 * b0; P[j][4] = z1 * b1; P[j][5] = z1 * b2;
     P[j][6] = z2 * b0; P[j][7] = z2 * b1; P[j][8] = z2 * b2;
     // expected genotypes p1 + 2*p2 (ngsLD.cpp:113); pearson_r runs over ALL individuals (ngsLD.cpp:290)
@@ -449,26 +454,21 @@ __device__ __forceinline__ uint32_t count_valid(uint32_t vbits) {
 }
 
 // haplo_freq (gen_func.cpp:1027-1059) on the staged pair.  Returns n_iter; f0..f3 hold hap_freq on exit.
-//   CHECK_ALL: every slot may hold padding / missing individuals (otherwise only the last one can)
+//   vbits:     bit j = slot j of this lane holds an individual that counts (not a ghost, see stage_pair)
 //   WAVES > 1: the pair is spread over WAVES wavefronts, partial sums meet in xch (LDS, double buffered)
-//   TREE_DYN:  CHECK_ALL kernels without --ignore_miss_data (several wavefronts per pair): a wavefront whose lanes are
-//              all full up to the last slot -- every one but the pair's last -- still takes the one-reciprocal path
-//   pads:      (CHECK_ALL) per-slot 0 / 1 from stage_pair: individuals without data have P == 0 and pad 1, so the
-//              one-reciprocal step runs over all slots although any of them may be empty
 //   xpar:      (WAVES > 1) the caller's count of exchanges so far: its parity picks the half of xch an exchange uses.  Carried
 //              from pair to pair, consecutive exchanges alternate whatever the iteration counts were -- no barrier is needed
 //              between the last exchange of one pair and the first of the next
-// Reciprocals.  ALL slots of a lane share one v_rcp_f64 (RcpTree).  Padding lanes of the last slot hold P == 0 (the prep
-// kernel zero-fills the planes beyond n_ind); `pad` = 1 there makes their s exactly 1, so they neither disturb the
-// product nor add anything to R.  s lies in (0, 1]; the product of SLOTS values can underflow (all below ~1e-38 for eight
-// slots), and that -- like any other non-finite outcome -- is caught by the sanity test on the new frequencies, after
-// which the iteration is redone with one reciprocal per individual before anything is concluded from it.  (One reciprocal
-// per individual, and one per two individuals, were the earlier forms: -9 % and -4 % against the tree at eight slots.)
-template <int SLOTS, int WAVES, bool CHECK_ALL, bool TREE_DYN = false>
+// Reciprocals.  ALL slots of a lane share one v_rcp_f64 (RcpTree); ghost slots take part with s = f0^2.  s lies in (0, 1];
+// the product of SLOTS values can underflow (all below ~1e-38 for eight slots), and that -- like any other non-finite
+// outcome -- is caught by the sanity test on the new frequencies, after which the iteration is redone with one reciprocal
+// per individual before anything is concluded from it.  (One reciprocal per individual, and one per two individuals, were
+// the earlier forms: -9 % and -4 % against the tree at eight slots.)
+template <int SLOTS, int WAVES>
 __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_t vbits, double inv_x, double m1,
                                             double m2, double &f0, double &f1, double &f2, double &f3,
                                             double (*xch)[WAVES][4], int sub, int lane, int *status,
-                                            const double *pads = nullptr, uint32_t *xpar = nullptr) {
+                                            uint32_t *xpar = nullptr) {
   static_assert(WAVES == 1 || WAVES == 2 || WAVES == 4 || WAVES == 8, "em_pair: 1, 2, 4 or 8 wavefronts per pair");
   f0 = (1 - m1) * (1 - m2); f1 = (1 - m1) * m2; f2 = m1 * (1 - m2); f3 = m1 * m2;  // gen_func.cpp:1034-1037
   if (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1) {  // error() in the reference (:1030); reported through status
@@ -482,15 +482,8 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   asm("" : "+v"(inv_x));
   bool bad = false, tie = false;
   uint32_t n_iter = 0;
-  const bool mask_tree = CHECK_ALL && !TREE_DYN && pads != nullptr;  // compile-time after inlining
   constexpr bool kTree = SLOTS > 1;
-  const double pad = ((vbits >> (SLOTS - 1)) & 1u) ? 0.0 : 1.0;
   constexpr bool kScaled = WAVES == 1;  // (several wavefronts per pair: partial sums are scaled after they met)
-  bool tree_ok = true;  // wavefront-uniform
-  if (CHECK_ALL && kTree && !mask_tree) {
-    constexpr uint32_t kNeed = (1u << (SLOTS - 1)) - 1u;  // padding (P == 0, no missing data here) in the last slot only
-    tree_ok = TREE_DYN ? !__builtin_amdgcn_ballot_w64((vbits & kNeed) != kNeed) : false;
-  }
   // tree_tag: the step with the shared reciprocal, or with one reciprocal per individual.  drop_tag: the step in its
   // three-value form (hap 0 recovered from the sum) or in the full four-value form.  The shared-reciprocal step only exists
   // in the three-value form; the step with one reciprocal per individual, which only ever runs outside the hot loop, in
@@ -507,9 +500,8 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
     double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
     if (NGSLD_SETPRIO && kShared) __builtin_amdgcn_s_setprio(NGSLD_PRIO_S);  // the dense s sums start here
-    auto slot_s = [&](int j, bool padded = false) -> double {
-      // padded: see above (pad = 1 where P == 0); mask_tree: every slot has its own pad
-      double s = padded ? fma(p00, P[j][0], mask_tree ? pads[j] : pad) : p00 * P[j][0];
+    auto slot_s = [&](int j) -> double {
+      double s = p00 * P[j][0];
       s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
       s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
       s = fma(p22, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(p33, P[j][8], s);
@@ -524,7 +516,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     if constexpr (kShared) {
       double sv[SLOTS], rv[SLOTS];
 #pragma unroll
-      for (int j = 0; j < SLOTS; ++j) sv[j] = slot_s(j, mask_tree || j == SLOTS - 1);
+      for (int j = 0; j < SLOTS; ++j) sv[j] = slot_s(j);
       // Two wavefronts share a SIMD.  The one inside a serial stretch of its iteration (reciprocal tree; contraction,
       // reduction, convergence test and the next f products) has one instruction ready at a time and every cycle it
       // waits for the issue slot lengthens its critical path; the one inside a dense stretch (the s and R sums) has
@@ -541,7 +533,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
     } else {
 #pragma unroll
       for (int j = 0; j < SLOTS; ++j) {
-        if ((!CHECK_ALL && j < SLOTS - 1) || ((vbits >> j) & 1u)) slot_acc(j, rcp_refined(slot_s(j)));
+        if ((vbits >> j) & 1u) slot_acc(j, rcp_refined(slot_s(j)));  // (ghost slots are skipped: this form accumulates R[0])
       }
     }
     // t_k = sum_h f_k f_h R[G(k,h)]  (= this lane's share of ff_k / 2, gen_func.cpp:1098-1104)
@@ -627,7 +619,7 @@ __device__ __forceinline__ uint32_t em_pair(const double (&P)[SLOTS][9], uint32_
   bool done = false;
   while (!done && n_iter < (uint32_t)kIterMax) {
     if constexpr (kTree) {
-      if (tree_ok && !full) {
+      if (!full) {
         for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
           double n0, n1, n2, n3;
           em_step(PairedTag(), PairedTag(), n0, n1, n2, n3);  // (the tags double as true / false)
@@ -763,16 +755,11 @@ struct PairResult {
 // pair is copied global->LDS asynchronously into a wave-private 1536*SLOTS-byte buffer while the EM loop of the current
 // pair runs; the row vector (same for the whole item, L2-hot) is read directly.  No extra barrier is needed for the
 // prefetch.  (Without the prefetch -- every pair starting with an L2 / HBM round trip -- the kernel measured 12 % slower.)
-//   PADS   (not MASKED) the cohort does not fill all slots but the last: padding lanes in the middle of a
-//          wavefront's slots, or a wavefront that is all padding (513 individuals on 2 x 5 slots: the second wavefront's
-//          fourth slot holds ONE individual, its fifth none).  Without per-slot pads such a wavefront took the step with
-//          one reciprocal per individual in EVERY iteration and the others waited for it at the barrier: n_ind 1,025 ran at
-//          half the rate of 1,024, slower than under --ignore_miss_data, whose kernels have the pads anyway.
-// ---------------------------------------------------------------------------------------------
-template <int SLOTS, int WAVES, bool MASKED, bool PADS = false>
+// A cohort that does not fill all slots but the last (513 individuals on 2 x 5 slots: the second wavefront's fourth slot
+// holds ONE individual, its fifth none) needs nothing special: empty slots are ghosts (stage_pair).
+template <int SLOTS, int WAVES, bool MASKED>
 __global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
   static_assert(WAVES == 2 || WAVES == 4 || WAVES == 8, "pair_ld_kernel: 2, 4 or 8 wavefronts per pair");
-  static_assert(!PADS || !MASKED, "PADS: the kernel without --ignore_miss_data");
   constexpr int kSliceBytes = SLOTS * 64 * 3 * 8;
   constexpr int kXchBase = WAVES * kSliceBytes;
   // kParked (every individual counts): the Pearson cross moment needs no meeting of the wavefronts before the EM loop --
@@ -857,12 +844,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
     double P[SLOTS][9];
     uint32_t vbits;
     double sxy;
-    double pads[SLOTS];  // --ignore_miss_data: 1 where the individual has no data at either site (see stage_pair)
     const Relabel rl = relabel(m1, m2, mean1, mean2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice copied during the previous pair has landed
     stage_pair<SLOTS, MASKED, false, false, true>(pa, A.np, i0, reinterpret_cast<const double *>(lds_b),
                                                   (uint32_t)(SLOTS * 64), (uint32_t)lane, i0, A.n_ind, rl.mean1, rl.mean2, P,
-                                                  vbits, sxy, (MASKED || PADS) ? pads : nullptr, rl.flip1, rl.flip2);
+                                                  vbits, sxy, rl.flip1, rl.flip2);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // a, b and the scalars are all consumed
     if (cn < it.count) dma_slice(it.s2_begin + cn);
     uint32_t x = count_valid<SLOTS>(vbits);
@@ -888,9 +874,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
       x = (uint32_t)xs;
     }
     double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair<SLOTS, WAVES, true, (!MASKED && !PADS)>(
-        P, vbits, kParked ? A.inv_n : 1.0 / (double)x, rl.m1, rl.m2, f0, f1, f2, f3, xch, sub, lane, A.status,
-        (MASKED || PADS) ? pads : nullptr, &xpar);
+    const uint32_t n_iter = em_pair<SLOTS, WAVES>(P, vbits, kParked ? A.inv_n : 1.0 / (double)x, rl.m1, rl.m2, f0, f1, f2, f3,
+                                                  xch, sub, lane, A.status, &xpar);
     unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
     if (lane == 0 && sub == 0) {
       PairResult &r = res[c];
@@ -1084,12 +1069,10 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
     double P[SLOTS][9];
     uint32_t vbits;
     double sxy;
-    double pads[SLOTS];  // --ignore_miss_data: 1 where the individual has no data at either site
     const Relabel rl = relabel(m1, m2, mean1, mean2);
     stage_pair<SLOTS, MASKED, !MASKED, true>(reinterpret_cast<const double *>(lds_a), kNp, (uint32_t)lane,
                                              reinterpret_cast<const double *>(lds_b), kNp, (uint32_t)lane, (uint32_t)lane,
-                                             A.n_ind, rl.mean1, rl.mean2, P, vbits, sxy, MASKED ? pads : nullptr, rl.flip1,
-                                             rl.flip2);
+                                             A.n_ind, rl.mean1, rl.mean2, P, vbits, sxy, rl.flip1, rl.flip2);
     // all ds_reads of the buffer are consumed (P is computed): start the copy of the next site over it
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (nxt.ok) dma_site(nxt.s2);
@@ -1097,8 +1080,8 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
     const double inv_x = MASKED ? 1.0 / (double)x : A.inv_n;
     sxy = fma(-(double)A.n_ind * rl.mean1, rl.mean2, wave_sum1_bcast(sxy));  // centred: sum e1 e2 - n mean1 mean2
     double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair<SLOTS, 1, MASKED>(P, vbits, inv_x, rl.m1, rl.m2, f0, f1, f2, f3,
-                                                      (double (*)[1][4]) nullptr, 0, lane, A.status, MASKED ? pads : nullptr);
+    const uint32_t n_iter = em_pair<SLOTS, 1>(P, vbits, inv_x, rl.m1, rl.m2, f0, f1, f2, f3, (double (*)[1][4]) nullptr, 0,
+                                              lane, A.status);
     unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
     if (lane == 0) {
       RunResult &r = ring[held];
@@ -1276,7 +1259,6 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
 
     // ---- stage: P = a (x) b per lane, validity, Pearson cross moment (group sums) ----
     double P[SLOTS][9];
-    double pads[MASKED ? SLOTS : 1];
     uint32_t vbits = 0;
     double sxy = 0.0;
     const double *la = reinterpret_cast<const double *>(lds_a);
@@ -1293,12 +1275,16 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       if (MASKED) ok = ok && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);  // gen_func.cpp:1089
       vbits |= (ok ? 1u : 0u) << j;
       double z0 = a0, z1 = a1, z2 = a2;
-      if (MASKED) {  // an individual without data: P = 0 and pad 1, so the one-reciprocal step can run over all slots
+      if (MASKED) {  // an individual without data is a ghost, P = (1, 0, ..., 0): see stage_pair
         const double keep = ok ? 1.0 : 0.0;
         z0 = a0 * keep; z1 = a1 * keep; z2 = a2 * keep;
-        pads[j] = 1.0 - keep;
+        P[j][0] = fma(z0, b0, 1.0 - keep);
+      } else if (j == SLOTS - 1) {  // padding lanes (zeros in the planes) of the last slot
+        P[j][0] = fma(a0, b0, inb ? 0.0 : 1.0);
+      } else {
+        P[j][0] = a0 * b0;
       }
-      P[j][0] = z0 * b0; P[j][1] = z0 * b1; P[j][2] = z0 * b2;
+      P[j][1] = z0 * b1; P[j][2] = z0 * b2;
       P[j][3] = z1 * b0; P[j][4] = z1 * b1; P[j][5] = z1 * b2;
       P[j][6] = z2 * b0; P[j][7] = z2 * b1; P[j][8] = z2 * b2;
       const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;   // ngsLD.cpp:113, :290
@@ -1320,9 +1306,8 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       f0 = f1 = f2 = f3 = __builtin_nan("");
     }
     const double inv_x = 1.0 / (double)x;
-    // one reciprocal per lane and iteration (RcpTree) when only the last slot can hold padding, see em_pair
+    // one reciprocal per lane and iteration (RcpTree), empty slots are ghosts: see em_pair
     constexpr bool kTree = SLOTS > 1;
-    const double pad = ((vbits >> (SLOTS - 1)) & 1u) ? 0.0 : 1.0;
     auto em_step = [&](auto tree_tag, double &n0, double &n1, double &n2, double &n3) {
       constexpr bool kT = decltype(tree_tag)::value;
       constexpr bool kDrop = kT;  // shared-reciprocal step: three-value form; the other one: full (see em_pair)
@@ -1330,8 +1315,8 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
       const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
       double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
-      auto slot_s = [&](int j, bool padded = false) -> double {
-        double s = padded ? fma(p00, P[j][0], MASKED ? pads[MASKED ? j : 0] : pad) : p00 * P[j][0];
+      auto slot_s = [&](int j) -> double {
+        double s = p00 * P[j][0];
         s = fma(w1, P[j][1], s); s = fma(p11, P[j][2], s);
         s = fma(w3, P[j][3], s); s = fma(w4, P[j][4], s); s = fma(w5, P[j][5], s);
         s = fma(p22, P[j][6], s); s = fma(w7, P[j][7], s); s = fma(p33, P[j][8], s);
@@ -1347,9 +1332,8 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
         double sv[SLOTS], rv[SLOTS];
         if (NGSLD_SETPRIO) __builtin_amdgcn_s_setprio(0);  // dense stretch: see em_pair
 #pragma unroll
-        for (int j = 0; j < SLOTS; ++j) sv[j] = slot_s(j, MASKED);
+        for (int j = 0; j < SLOTS; ++j) sv[j] = slot_s(j);
         if (NGSLD_SETPRIO) __builtin_amdgcn_s_setprio(3);
-        if (!MASKED) sv[SLOTS - 1] += pad;  // (kept as a separate add here: folding it into the first FMA costs registers)
         // 1/x rides on the root inverse (as in em_pair): every R, and with them the three t_k, come out divided by x
         RcpTree<SLOTS>::down(sv, rcp_refined(RcpTree<SLOTS>::prod(sv)) * inv_x, rv);
         if (NGSLD_SETPRIO) __builtin_amdgcn_s_setprio(0);
@@ -1608,9 +1592,8 @@ __global__ __launch_bounds__(256, 2) void pair_ld_stream_kernel(PairArgs A) {
 // Kernel families (pair_config picks by cohort size, by measurement: profiles/r03/sweep_513_1024.txt):
 //   kGroup  8 / 16 / 32 lanes per pair, several pairs per wavefront in lockstep (n_ind <= 128, some shapes up to 224)
 //   kRun    one wavefront per pair, the row vector shared in LDS, runs of items (n_ind <= 640: up to TEN individuals per lane)
-//   kRunAB  one wavefront per pair, EM step in its a/b form, run pipeline (ld_pair_ab.hip: 641..832, and 577..640 under
-//           --ignore_miss_data, whose per-slot pads do not fit beside ten slots of P)
-//   kMulti  2 / 4 / 8 wavefronts per pair (833..4608)
+//   kRunAB  one wavefront per pair, EM step in its a/b form, run pipeline (ld_pair_ab.hip: 641..832)
+//   kMulti  2 / 4 / 8 wavefronts per pair (833..5120)
 //   kStream any n_ind, vectors re-read every iteration
 //   kHard   every likelihood triple of the matrix is a called genotype or "no data": the pairs' 16 genotype-combination
 //           counts replace the individuals (any n_ind up to kHardMaxInd)
@@ -1629,9 +1612,17 @@ struct PairConfig {
   uint32_t np;  // padded individuals per genotype plane
 };
 bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice = kChooseAuto);
-// the kernel a launch really takes: ten slots per lane under --ignore_miss_data run on the a/b kernel (same layout, same runs)
-inline int effective_kernel(const PairConfig &cfg, bool masked) {
-  return (cfg.kernel == kRun && cfg.slots == 10 && masked) ? (int)kRunAB : cfg.kernel;
+// the kernel a launch really takes (a hook for families that differ with --ignore_miss_data; none does at present)
+inline int effective_kernel(const PairConfig &cfg, bool /*masked*/) { return cfg.kernel; }
+// ... and the shape of the multi-wavefront kernel: 2 x 10 slots (1,153..1,280 individuals) run as 4 x 5 under
+// --ignore_miss_data (measured -2.6 % otherwise; both shapes read the same planes: np = 1,280)
+inline void multi_shape(const PairConfig &cfg, bool masked, int *slots, int *waves) {
+  *slots = cfg.slots;
+  *waves = cfg.waves;
+  if (masked && cfg.waves == 2 && cfg.slots == 10) {
+    *slots = 5;
+    *waves = 4;
+  }
 }
 hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs &args, hipStream_t stream);
 hipError_t launch_pair_hard(bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_hard.hip

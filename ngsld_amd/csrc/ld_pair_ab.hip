@@ -1,5 +1,5 @@
 // ld_pair_ab.hip -- one wavefront per pair beyond what the P form holds in registers: the EM step in its a/b form.
-// The default for 641..832 individuals, and for 577..640 under --ignore_miss_data (pair_config / effective_kernel, by
+// The default for 641..832 individuals (pair_config, by
 // measurement: profiles/r03/sweep_513_1024.txt -- +9 % at 704, +2 % at 768, +5.5 % at 832 against two wavefronts per pair,
 // +6..13 % under --ignore_miss_data; level at 896..960, -6.5 % at 1,024); NGSLD_PAIR_KERNEL=ab selects it for 513..1024.
 //

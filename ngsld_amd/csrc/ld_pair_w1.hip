@@ -14,12 +14,12 @@ namespace ngsld {
 // 10 * 64 = 640 individuals as 18 * 10 = 180 VGPRs of P (nine and ten slots spill a few registers OUTSIDE the EM loop and
 // still beat two wavefronts of five by 54 % / 29 %: the per-iteration bookkeeping is paid once, nothing meets behind a
 // barrier); up to 832 the a/b form on one wavefront; above that 2..8 wavefronts share the pair (eight slots per lane, nine
-// just past a doubling), and beyond 4608 the streaming kernel takes over.
+// or ten just past a doubling), and beyond 5120 the streaming kernel takes over.
 bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice) {
   if (n_ind == 0 || n_ind >= 0xffffffc0ull) return false;
   cfg->group = 64;
   cfg->waves = 1;
-  if (n_ind > 4608u) {  // beyond 8 wavefronts x 9 slots x 64 lanes: streaming kernel, one workgroup per pair
+  if (n_ind > 5120u) {  // beyond 8 wavefronts x 10 slots x 64 lanes: streaming kernel, one workgroup per pair
     cfg->kernel = kStream;
     cfg->waves = 4;
     cfg->slots = 0;
@@ -52,12 +52,16 @@ bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice) {
     cfg->np = (uint32_t)(slots1 * 64);
     return true;
   }
-  // Several wavefronts per pair.  Just past a doubling of the wavefronts (1,025..1,152, 2,049..2,304, 4,097..4,608
-  // individuals) NINE slots on half as many wavefronts beat five on twice as many: half-empty lanes and twice the
-  // per-iteration bookkeeping against a few spilled registers outside the EM loop (+35..46 % / +48..63 %).
+  // Several wavefronts per pair.  Just past a doubling of the wavefronts (1,025..1,280, 2,049..2,560, 4,097..5,120
+  // individuals) NINE or TEN slots on half as many wavefronts beat five on twice as many: half-empty lanes and twice the
+  // per-iteration bookkeeping against a few spilled registers outside the EM loop (nine: +35..46 % / +48..63 %; ten, round
+  // 3, once empty slots no longer cost registers: +11 % at 1,153..1,280, +30 % at 2,305..2,560, and 4,609..5,120 stay on the
+  // register kernels at 1.2e7 pairs/s against 6.5e6 for the streaming kernel; profiles/r03/sweep_ghost.txt).  Under
+  // --ignore_miss_data 2 x 10 loses 2.6 % to 4 x 5 -- same plane layout, so the launcher takes that shape there (multi_shape).
   int w = 2;
   while ((n_ind + 64ull * w - 1) / (64ull * w) > 8) w *= 2;
-  if (w >= 4 && (n_ind + 32ull * w - 1) / (32ull * w) == 9) w /= 2;  // nine slots on w / 2 wavefronts
+  const uint64_t half = (n_ind + 32ull * w - 1) / (32ull * w);
+  if (w >= 4 && (half == 9 || half == 10)) w /= 2;
   cfg->waves = w;
   cfg->slots = (int)((n_ind + 64ull * w - 1) / (64ull * w));
   cfg->np = (uint32_t)(cfg->slots * w * 64);
@@ -97,13 +101,9 @@ static hipError_t launch_run(bool masked, const PairArgs &a, hipStream_t stream)
   if (a.n_runs == 0) return hipSuccess;
   if (a.n_runs > 0x7fffffffull) return hipErrorInvalidValue;
   const dim3 grid((unsigned)a.n_runs), block(256);
-  if constexpr (SLOTS <= 9) {
-    if (masked) {
-      hipLaunchKernelGGL((pair_ld_run_kernel<SLOTS, true>), grid, block, 0, stream, a);
-      return hipGetLastError();
-    }
-  } else if (masked) {
-    return hipErrorInvalidValue;  // (ten slots under --ignore_miss_data: the a/b kernel, see effective_kernel)
+  if (masked) {
+    hipLaunchKernelGGL((pair_ld_run_kernel<SLOTS, true>), grid, block, 0, stream, a);
+    return hipGetLastError();
   }
   hipLaunchKernelGGL((pair_ld_run_kernel<SLOTS, false>), grid, block, 0, stream, a);
   return hipGetLastError();
@@ -209,7 +209,11 @@ static hipError_t launch_pair_chunk(const PairConfig &cfg, bool masked, const Pa
     if (cfg.group == 16) return launch_group<16>(cfg.slots, masked, a, stream);
     return launch_group<32>(cfg.slots, masked, a, stream);
   }
-  if (cfg.kernel == kMulti) return launch_pair_wn(cfg.slots, cfg.waves, masked, a, stream);
+  if (cfg.kernel == kMulti) {
+    int slots = cfg.slots, waves = cfg.waves;
+    multi_shape(cfg, masked, &slots, &waves);
+    return launch_pair_wn(slots, waves, masked, a, stream);
+  }
   switch (cfg.slots) {  // kRun
     case 1: return launch_run<1>(masked, a, stream);
     case 2: return launch_run<2>(masked, a, stream);

@@ -1,4 +1,4 @@
-// ld_pair_wn.hip -- instantiations of the multi-wavefront-per-pair kernel (832 < n_ind <= 4608; from 513 on with NGSLD_PAIR_KERNEL=multi).
+// ld_pair_wn.hip -- instantiations of the multi-wavefront-per-pair kernel (832 < n_ind <= 5120; from 513 on with NGSLD_PAIR_KERNEL=multi).
 #include "ld_device.h"
 
 namespace ngsld {
@@ -9,14 +9,10 @@ static hipError_t launch_sw(bool masked, const PairArgs &a, hipStream_t stream) 
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   const dim3 grid((unsigned)blocks), block(WAVES * 64);
-  // every slot but the last one of the last wavefront full?  Otherwise the kernel with per-slot pads (see pair_ld_kernel, PADS)
-  const bool clean = (uint64_t)a.n_ind > (uint64_t)(WAVES * SLOTS - 1) * 64u;
   if (masked)
     hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, true>), grid, block, 0, stream, a);
-  else if (clean)
-    hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, false>), grid, block, 0, stream, a);
   else
-    hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, false, true>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, false>), grid, block, 0, stream, a);
   return hipGetLastError();
 }
 
@@ -28,6 +24,7 @@ static hipError_t launch_w(int slots, bool masked, const PairArgs &a, hipStream_
     case 7: return launch_sw<7, WAVES>(masked, a, stream);
     case 8: return launch_sw<8, WAVES>(masked, a, stream);
     case 9: return launch_sw<9, WAVES>(masked, a, stream);
+    case 10: return launch_sw<10, WAVES>(masked, a, stream);
     default: return hipErrorInvalidValue;
   }
 }

@@ -41,7 +41,7 @@ def _bench(n_ranks: int, sites: int, one_device: bool) -> dict:
     if one_device:
         env["NGSLD_BENCH_ONE_DEVICE"] = "1"
     args = ["bench.py", "--gpus", str(n_ranks), "--config", "c2", "--sites", str(sites), "--ind", str(N_IND), "--steps", "2",
-            "--warmup", "1", "--no-e2e", "--no-cpu"]
+            "--warmup", "1", "--no-e2e", "--no-cpu", "--no-traffic"]
     if n_ranks == 1:
         cmd = [sys.executable] + args
     else:

@@ -58,10 +58,15 @@ def test_all_pairs_multi_wave(engine, n_sites, n_ind, seed):
 
 
 @pytest.mark.parametrize("n_sites,n_ind,seed,ignore_miss", [(12, 1100, 26, False), (12, 1152, 27, True), (10, 2200, 28, False),
-                                                            (9, 2304, 29, True), (8, 4300, 30, False), (7, 4608, 31, True)])
-def test_nine_slots_per_lane(engine, n_sites, n_ind, seed, ignore_miss):
-    """Just past a doubling of the wavefronts per pair the kernels hold NINE individuals per lane on half as many wavefronts
-    (2 x 9, 4 x 9, 8 x 9 x 64): with and without --ignore_miss_data, padding inside and at the end of the last wavefront."""
+                                                            (9, 2304, 29, True), (8, 4300, 30, False), (7, 4608, 31, True),
+                                                            (12, 1153, 32, False), (12, 1200, 33, True), (11, 1280, 34, False),
+                                                            (9, 2305, 35, True), (9, 2560, 36, False), (7, 4609, 37, False),
+                                                            (6, 4700, 38, True), (6, 5000, 39, False), (6, 5120, 40, True)])
+def test_nine_and_ten_slots_per_lane(engine, n_sites, n_ind, seed, ignore_miss):
+    """Just past a doubling of the wavefronts per pair the kernels hold NINE or TEN individuals per lane on half as many
+    wavefronts (2 / 4 / 8 x 9 / 10 x 64; 2 x 10 under --ignore_miss_data runs as 4 x 5 on the same planes): with and without
+    --ignore_miss_data, empty slots inside and at the end of the last wavefront.  4,609..5,120 individuals used to run on the
+    streaming kernel."""
     raw = synth.make_gl_numpy(n_sites, n_ind, seed, depth=4.0)
     if ignore_miss:
         miss = np.random.default_rng(seed).random((n_sites, n_ind)) < 0.15
@@ -191,10 +196,13 @@ def test_long_rows_and_many_items(engine):
     assert float(np.abs(ext["hap"].sum(axis=1) - 1).max()) < 1e-12
 
 
-@pytest.mark.parametrize("n_sites,n_ind,seed,ignore", [(6, 4097, 301, False), (5, 5000, 302, True), (4, 9001, 303, False)])
+@pytest.mark.parametrize("n_sites,n_ind,seed,ignore", [(6, 5121, 301, False), (5, 6000, 302, True), (5, 6000, 304, False),
+                                                       (4, 9001, 303, False), (4, 10000, 305, True)])
 def test_streaming_kernel_large_cohorts(engine, n_sites, n_ind, seed, ignore):
-    """n_ind > 4096: the streaming kernel (site vectors re-read every EM iteration)."""
+    """n_ind > 5120: the streaming kernel (site vectors re-read every EM iteration)."""
     raw = synth.make_gl_numpy(n_sites, n_ind, seed, depth=8.0)
+    engine.set_geno_raw(raw[:2], ignore_miss_data=ignore)
+    assert engine.pair_kernel() == "stream"
     if ignore:
         raw[np.random.default_rng(seed).random((n_sites, n_ind)) < 0.05] = 1.0 / 3.0
     check_against_oracle(engine, raw, ignore_miss=ignore)

@@ -1,0 +1,80 @@
+"""GPU: the per-site prep kernels (ld_prep.hip).  Likelihood triples take a quotient fast path, a_k = raw_k / sum, wherever
+the reference's chain of logs (read_data.cpp:37-45, gen_func.cpp:974-1009, ngsLD.cpp:110) has no special behaviour, and
+the chain itself everywhere else; NGSLD_PREP_EXACT=1 sends every triple through the chain.  Both must agree with the
+reference's compiled est_maf (the oracle, bit-checked against it) to 1e-12 and with each other far inside that, on ordinary
+triples and on every special one: zeros, all-zero triples, called genotypes, denormal and huge values."""
+import os
+
+import numpy as np
+import pytest
+
+from ngsld_amd import capi, synth
+from oracle import orc
+from util import MAF_TOL, check_records, close
+
+pytestmark = pytest.mark.gpu
+
+
+def _special_matrix(n_sites, n_ind, seed):
+    raw = synth.make_gl_numpy(n_sites, n_ind, seed, depth=4.0)
+    rng = np.random.default_rng(seed)
+    raw[1, ::4] = [1.0, 0.0, 0.0]                      # zeros inside a triple (fast path: exact 1 / 0)
+    raw[2, 1::5] = 0.0                                 # all-zero triples: the chain's -1e15 arithmetic (0.3247 each)
+    raw[3] = np.eye(3)[rng.integers(0, 3, n_ind)]      # a called site
+    raw[4, ::3] *= 1e-305                              # denormal range: the chain
+    raw[5, ::3] *= 1e300                               # huge: the chain
+    raw[6] = 1.0 / 3.0                                 # nobody has data
+    raw[7, ::2] = [0.2, 0.2, 0.2]                      # un-normalised "no data"
+    raw[8] *= rng.uniform(1e-30, 1e30, size=(n_ind, 1))  # wildly different scales per individual
+    return raw
+
+
+@pytest.mark.parametrize("n_ind", [24, 100, 500, 700, 1500, 2500])
+@pytest.mark.parametrize("ignore_miss", [False, True])
+def test_fast_path_and_chain_agree_with_the_reference(n_ind, ignore_miss):
+    """n_ind 24..1500: one wavefront per site (8 / 16 / 32 individuals per lane); 2500: one workgroup per site."""
+    n_sites = 40
+    raw = _special_matrix(n_sites, n_ind, 7000 + n_ind)
+    o = orc.Oracle(raw, ignore_miss_data=ignore_miss, n_threads=8)
+    want = o.run()
+    got = {}
+    for mode in ("fast", "chain"):
+        if mode == "chain":
+            os.environ["NGSLD_PREP_EXACT"] = "1"
+        try:
+            eng = capi.Engine(0)
+            try:
+                eng.set_geno_raw(raw, ignore_miss_data=ignore_miss)
+                maf = eng.maf()
+                eng.set_pos_dist(None)
+                assert eng.plan(ignore_miss_data=ignore_miss) == len(want)
+                s1, s2, std, ext = eng.run()
+            finally:
+                eng.close()
+        finally:
+            os.environ.pop("NGSLD_PREP_EXACT", None)
+        assert np.all(close(maf, o.maf, MAF_TOL)), mode            # 1e-12 against the reference's est_maf
+        check_records(std, ext, want)
+        got[mode] = (maf, std, ext)
+    both = np.isfinite(got["fast"][0]) & np.isfinite(got["chain"][0])
+    assert np.array_equal(np.isfinite(got["fast"][0]), np.isfinite(got["chain"][0]))
+    assert np.max(np.abs(got["fast"][0][both] - got["chain"][0][both]), initial=0.0) < 2e-14
+    assert np.array_equal(got["fast"][2]["n_iter"], got["chain"][2]["n_iter"])
+    assert np.array_equal(got["fast"][2]["n_ind_data"], got["chain"][2]["n_ind_data"])
+
+
+def test_nan_input_is_reported_on_both_paths():
+    raw = synth.make_gl_numpy(20, 64, 7100, depth=4.0)
+    raw[11, 5, 1] = -0.25                               # log of a negative value: NaN -> "NaN found!" (read_data.cpp:42-45)
+    for exact in ("0", "1"):
+        os.environ["NGSLD_PREP_EXACT"] = exact
+        try:
+            eng = capi.Engine(0)
+            try:
+                with pytest.raises(capi.NgsldError) as e:
+                    eng.set_geno_raw(raw)
+                assert e.value.code == capi.ERR_NAN
+            finally:
+                eng.close()
+        finally:
+            os.environ.pop("NGSLD_PREP_EXACT", None)

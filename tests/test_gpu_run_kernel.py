@@ -69,7 +69,7 @@ def test_windowed_rows_split_into_equal_runs(engine):
 @pytest.mark.parametrize("n_ind,ignore_miss", [(513, False), (640, True), (777, False), (1000, False), (1024, True)])
 def test_ab_form_kernel_matches_the_oracle(n_ind, ignore_miss):
     """NGSLD_PAIR_KERNEL=ab: one wavefront per pair for 513..1024 individuals, EM step in its a/b form (ld_pair_ab.hip: the
-    default for 641..832, and for 577..640 under --ignore_miss_data).  Held to the same bars as every kernel."""
+    default for 641..832).  Held to the same bars as every kernel."""
     import os
     from oracle import orc
     from util import check_records
@@ -158,7 +158,7 @@ def test_runs_recut_between_text_and_record_runs(n_ind):
 
 # what pair_config picks by cohort size (profiles/r03/sweep_513_1024.txt), and that every one of those shapes agrees with the oracle
 SHAPES = [(512, False, "run"), (513, False, "run"), (513, True, "run"), (576, False, "run"), (576, True, "run"),
-          (577, False, "run"), (577, True, "ab"), (640, False, "run"), (640, True, "ab"), (641, False, "ab"),
+          (577, False, "run"), (577, True, "run"), (640, False, "run"), (640, True, "run"), (641, False, "ab"),
           (704, True, "ab"), (832, False, "ab"), (832, True, "ab"), (833, False, "multi"), (833, True, "multi")]
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Same-box A/B of library builds: tools/ab.sh "<label>=<env assignments>" ...   (each label run ROUNDS times, interleaved)
 ROUNDS=${ROUNDS:-2}
-ARGS=${BENCH_ARGS:---no-cpu}
+ARGS=${BENCH_ARGS:---no-cpu --no-traffic}
 for r in $(seq $ROUNDS); do
   for v in "$@"; do
     label=${v%%=*}; envs=${v#*=}

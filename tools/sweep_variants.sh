@@ -7,7 +7,7 @@ for n in ${NINDS:-513 576 640 704 768 832 896 960 1024}; do
   for m in "" "--ignore-miss"; do
     for v in "$@"; do
       label=${v%%=*}; envs=${v#*=}
-      env $envs python bench.py --no-cpu --no-sink --no-e2e --config c2 --sites $sites --ind $n $m --steps 2 --warmup 1 2>/dev/null | tail -1 | python -c "
+      env $envs python bench.py --no-cpu --no-sink --no-e2e --no-traffic --config c2 --sites $sites --ind $n $m --steps 2 --warmup 1 2>/dev/null | tail -1 | python -c "
 import json,sys
 try:
     d=json.loads(sys.stdin.read()); v=d['value']
