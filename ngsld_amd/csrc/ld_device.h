@@ -846,13 +846,16 @@ __global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
     double sxy;
     const Relabel rl = relabel(m1, m2, mean1, mean2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice copied during the previous pair has landed
-    stage_pair<SLOTS, MASKED, false, false, true>(pa, A.np, i0, reinterpret_cast<const double *>(lds_b),
+    stage_pair<SLOTS, MASKED, false, true, true>(pa, A.np, i0, reinterpret_cast<const double *>(lds_b),
                                                   (uint32_t)(SLOTS * 64), (uint32_t)lane, i0, A.n_ind, rl.mean1, rl.mean2, P,
                                                   vbits, sxy, rl.flip1, rl.flip2);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // a, b and the scalars are all consumed
     if (cn < it.count) dma_slice(it.s2_begin + cn);
     uint32_t x = count_valid<SLOTS>(vbits);
-    sxy = wave_sum1(sxy);
+    // the cross moment comes uncentred (round 3: read off P, no bounds tests, a DPP-only reduction -- ~80 instructions less
+    // per wavefront and pair than centring every element and folding with permlane swaps); n mean1 mean2 is taken off once
+    sxy = wave_sum1_bcast(sxy);
+    const double centre = (double)A.n_ind * rl.mean1 * rl.mean2;
     if (kParked) {
       if (lane == 0) lds_post(lds_addr(&parked[c][sub]), sxy);
       x = A.n_ind;  // (the ballots of the wavefronts add up to it: padding lanes are the only ones left out)
@@ -870,7 +873,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
         sx += q[w][0];
         xs += q[w][1];
       }
-      sxy = sx;
+      sxy = sx - centre;
       x = (uint32_t)xs;
     }
     double f0, f1, f2, f3;
@@ -880,7 +883,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
     if (lane == 0 && sub == 0) {
       PairResult &r = res[c];
       r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;
-      r.sxy = sxy;
+      r.sxy = kParked ? centre : sxy;  // (parked partial sums: the centring term travels in their place)
       r.rsx2 = rsx2;
       r.x = x;
       r.n_iter = n_iter;
@@ -897,6 +900,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
     if (kParked) {
       sxy = 0.0;  // (the order the exchange added them in)
       for (int w = 0; w < WAVES; ++w) sxy += parked[t][w];
+      sxy -= r.sxy;  // centred: sum e1 e2 - n mean1 mean2
     }
     write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << t) - 1ull)), r.f[0], r.f[1], r.f[2], r.f[3], sxy, rsx1,
                r.rsx2, r.x, r.n_iter);
@@ -1287,17 +1291,26 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       P[j][1] = z0 * b1; P[j][2] = z0 * b2;
       P[j][3] = z1 * b0; P[j][4] = z1 * b1; P[j][5] = z1 * b2;
       P[j][6] = z2 * b0; P[j][7] = z2 * b1; P[j][8] = z2 * b2;
-      const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;   // ngsLD.cpp:113, :290
-      const double c2 = inb ? fma(2.0, b2, b1) - mean2 : 0.0;
-      sxy = fma(c1, c2, sxy);
+      // expected genotypes p1 + 2 p2 (ngsLD.cpp:113); pearson_r runs over ALL individuals (ngsLD.cpp:290); the planes
+      // hold zeros beyond n_ind, so the uncentred cross moment needs no bounds test
+      if (!MASKED)  // (a1 + 2 a2)(b1 + 2 b2) = P4 + 2 P5 + 2 P7 + 4 P8
+        sxy += fma(4.0, P[j][8], fma(2.0, P[j][5] + P[j][7], P[j][4]));
+      else          // P of individuals without data is zeroed: take the moment from a and b
+        sxy = fma(fma(2.0, a2, a1), fma(2.0, b2, b1), sxy);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // buffers consumed: start the next generation's copies
     dma_groups(nxt);
-    uint32_t x = 0;  // individuals with data in this group's pair (gen_func.cpp:1091), integer exact
+    // individuals with data in this group's pair (gen_func.cpp:1091), integer exact: everybody without --ignore_miss_data
+    // (then 1/x comes precomputed -- the same IEEE quotient -- instead of a ~35-instruction f64 division per generation)
+    uint32_t x = A.n_ind;
+    if (MASKED) {
+      x = 0;
 #pragma unroll
-    for (int j = 0; j < SLOTS; ++j)
-      x += (uint32_t)__popcll((__ballot((vbits >> j) & 1u) >> (grp * G)) & kGroupMask);
-    sxy = group_sum<G>(sxy);
+      for (int j = 0; j < SLOTS; ++j)
+        x += (uint32_t)__popcll((__ballot((vbits >> j) & 1u) >> (grp * G)) & kGroupMask);
+    }
+    // centred once per pair: sum e1 e2 - n mean1 mean2 (as the run kernel)
+    sxy = fma(-(double)A.n_ind * mean1, mean2, group_sum<G>(sxy));
 
     // ---- haplo_freq (gen_func.cpp:1027-1059), 64/G pairs in lockstep ----
     double f0 = (1 - m1) * (1 - m2), f1 = (1 - m1) * m2, f2 = m1 * (1 - m2), f3 = m1 * m2;
@@ -1305,7 +1318,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
       if (gl == 0) atomicExch(A.status, (int)NGSLD_ERR_MAF_RANGE);
       f0 = f1 = f2 = f3 = __builtin_nan("");
     }
-    const double inv_x = 1.0 / (double)x;
+    const double inv_x = MASKED ? 1.0 / (double)x : A.inv_n;
     // one reciprocal per lane and iteration (RcpTree), empty slots are ghosts: see em_pair
     constexpr bool kTree = SLOTS > 1;
     auto em_step = [&](auto tree_tag, double &n0, double &n1, double &n2, double &n3) {

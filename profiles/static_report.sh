@@ -8,12 +8,17 @@ cat > $T/k.hip <<EOT
 #include "$R/ngsld_amd/csrc/ld_device.h"
 template __global__ void ngsld::pair_ld_run_kernel<8,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_run_kernel<8,true>(ngsld::PairArgs);
-template __global__ void ngsld::pair_ld_pf_kernel<8,false>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_run_kernel<9,false>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_run_kernel<10,false>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_run_kernel<10,true>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_group_kernel<8,3,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_group_kernel<16,7,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_group_kernel<32,7,false>(ngsld::PairArgs);
-template __global__ void ngsld::pair_ld_kernel<8,2,false,true>(ngsld::PairArgs);
-template __global__ void ngsld::pair_ld_kernel<8,4,false,true>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_kernel<8,2,false>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_kernel<8,4,false>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_kernel<8,4,true>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_kernel<10,4,false>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_kernel<10,8,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_stream_kernel<false>(ngsld::PairArgs);
 EOT
 cd $T
