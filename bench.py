@@ -506,7 +506,8 @@ def main():
             out["cpu_baseline"] = None
         traffic, traffic_src, traffic_detail = None, None, None
         launches_per_step = max(launches, 1) / max(args.steps, 1)
-        if world == 1 and not args.no_traffic:
+        under_profiler = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX")) for k in os.environ)
+        if world == 1 and not args.no_traffic and not under_profiler:   # (never a profiler inside a profiler)
             eng.close()                                   # (everything the line needs from it has been taken)
             eng = None
             traffic_detail = measure_traffic(args)

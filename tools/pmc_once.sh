@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 SET=$1; shift
 rm -rf /tmp/pmc_once
-rocprofv3 --pmc $SET --output-format csv -d /tmp/pmc_once -o run -- python $R/bench.py --no-cpu --steps 1 --warmup 0 "$@" > /tmp/pmc_once.log 2>&1
+rocprofv3 --pmc $SET --output-format csv -d /tmp/pmc_once -o run -- python $R/bench.py --no-cpu --no-traffic --no-e2e --steps 1 --warmup 0 "$@" > /tmp/pmc_once.log 2>&1
 python - <<'PY'
 import csv, glob
 acc = {}
