@@ -304,6 +304,12 @@ int ngsld_run_multi(const int *devices, int n_devices, uint64_t n_sites, uint64_
 enum { NGSLD_DIST_NONE = 0, NGSLD_DIST_UPLOAD = 1, NGSLD_DIST_PEER_COPY = 2, NGSLD_DIST_RCCL = 3 };
 int ngsld_multi_last_distribution(void);
 
+/* The RCCL calls of ngsld_run_multi's broadcast -- dlopen of librccl, ncclCommInitAll, ncclGroupStart / ncclBroadcast /
+ * ncclGroupEnd, ncclCommDestroy -- on a communicator of ONE device: `bytes` of a known pattern go to the device, through an
+ * in-place broadcast, and back.  What a one-GPU box can prove about that path; NGSLD_OK, or NGSLD_ERR_DEVICE with the
+ * reason in err. */
+int ngsld_rccl_selftest(int device, uint64_t bytes, char *err, size_t errlen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,7 +83,7 @@ SYMBOLS = [
     "ngsld_set_geno_raw_opts", "ngsld_set_geno_lkl",
     "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device", "ngsld_set_text_output",
     "ngsld_set_replay_source", "ngsld_set_replay_matrix", "ngsld_set_replay", "ngsld_replay_stats", "ngsld_finish_device",
-    "ngsld_plan_parts", "ngsld_run_multi", "ngsld_multi_last_distribution",
+    "ngsld_plan_parts", "ngsld_run_multi", "ngsld_multi_last_distribution", "ngsld_rccl_selftest",
     "ngsld_last_kernel_time", "ngsld_pair_kernel", "ngsld_set_tuning", "ngsld_selftest",
     "ngsld_window_ends", "ngsld_plan_slabs", "ngsld_slab_sites_for_budget", "ngsld_device_memory", "ngsld_run_streamed", "ngsld_run_streamed_text",
     "ngsld_host_read_geno_bin_range",
@@ -164,6 +164,8 @@ def lib() -> C.CDLL:
                                           C.POINTER(u64), C.c_char_p, C.c_size_t]
         if hasattr(L, "ngsld_multi_last_distribution"):
             L.ngsld_multi_last_distribution.argtypes = []
+        if hasattr(L, "ngsld_rccl_selftest"):
+            L.ngsld_rccl_selftest.argtypes = [C.c_int, u64, C.c_char_p, C.c_size_t]
         L.ngsld_host_read_geno_bin_range.argtypes = [C.c_char_p, u64, u64, u64, vp, C.c_char_p, C.c_size_t]
         L.ngsld_host_set_threads.argtypes = [C.c_int]
         L.ngsld_host_set_threads.restype = None
@@ -400,6 +402,14 @@ def multi_last_distribution() -> str:
     """How the last run_multi of this process handed the matrix to its devices: "upload" (slab by slab), "peer_copy"
     (device to device from the first) or "rccl" (one ncclBroadcast over xGMI)."""
     return DIST_NAMES[int(lib().ngsld_multi_last_distribution())]
+
+
+def rccl_selftest(device: int = 0, n_bytes: int = 64 << 20) -> None:
+    """librccl's part in ngsld_run_multi on a one-device communicator (ngsld_rccl_selftest); raises NgsldError."""
+    err = C.create_string_buffer(512)
+    rc = lib().ngsld_rccl_selftest(device, n_bytes, err, len(err))
+    if rc != OK:
+        raise NgsldError(rc, err.value.decode())
 
 
 def device_count() -> int:

@@ -407,6 +407,20 @@ __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint3
   if (A_GLOBAL) {
     pa0 = uniform_ptr(pa0); pa1 = uniform_ptr(pa1); pa2 = uniform_ptr(pa2);
   }
+  // kByCount (several wavefronts per pair, every individual counts): a wavefront's slots are full up to a wavefront-
+  // uniform slot n_full, at most ONE slot is partly filled (lanes below rem), the rest are empty -- validity bits and ghosts
+  // come from those two numbers instead of a compare and a select per slot: inside the loop below these held nine compare
+  // masks and select temporaries beside the loads in flight and cost 64 bytes of scratch per lane (2 x 9 slots: -14 % pairs/s)
+  constexpr bool kByCount = !MASKED && !ONLY_LAST;
+  const uint32_t lane_in_wave = ind0 & 63u;
+  uint32_t n_full = 0, rem = 0;
+  if (kByCount) {
+    const uint32_t first = ind0 - lane_in_wave;  // this wavefront's first individual
+    const uint32_t have = n_ind > first ? n_ind - first : 0u;
+    n_full = (uint32_t)__builtin_amdgcn_readfirstlane((int)(have >> 6 < (uint32_t)SLOTS ? have >> 6 : (uint32_t)SLOTS));
+    rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)(have >> 6 < (uint32_t)SLOTS ? have & 63u : 0u));
+    vbits = ((1u << n_full) - 1u) | ((lane_in_wave < rem ? 1u : 0u) << n_full);
+  }
 #pragma unroll
   for (int j = 0; j < SLOTS; ++j) {
     const uint32_t ia = ia0 + (uint32_t)j * 64, ib = ib0 + (uint32_t)j * 64;
@@ -414,18 +428,21 @@ __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint3
     const double a0 = A_GLOBAL ? ((gdouble_t *)pa0)[ia] : pa0[ia], a1 = A_GLOBAL ? ((gdouble_t *)pa1)[ia] : pa1[ia],
                  a2 = A_GLOBAL ? ((gdouble_t *)pa2)[ia] : pa2[ia];
     const double b0 = pb0[ib], b1 = pb[npb + ib], b2 = pb2[ib];
-    const bool inb = (ONLY_LAST && j < SLOTS - 1) ? true : ind0 + (uint32_t)j * 64 < n_ind;
-    bool ok = inb;
-    if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);  // gen_func.cpp:1089
-    vbits |= (ok ? 1u : 0u) << j;
+    const bool inb = kByCount ? ((vbits >> j) & 1u) != 0
+                              : ((ONLY_LAST && j < SLOTS - 1) ? true : ind0 + (uint32_t)j * 64 < n_ind);
+    if (!kByCount) {
+      bool ok = inb;
+      if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);  // gen_func.cpp:1089
+      vbits |= (ok ? 1u : 0u) << j;
+    }
     double z0 = a0, z1 = a1, z2 = a2;
     if (MASKED) {  // an individual without data: P = (1, 0, ..., 0)
-      const double keep = ok ? 1.0 : 0.0;
+      const double keep = ((vbits >> j) & 1u) ? 1.0 : 0.0;
       z0 = a0 * keep; z1 = a1 * keep; z2 = a2 * keep;
       P[j][0] = fma(z0, b0, 1.0 - keep);
-    } else if (!(ONLY_LAST && j < SLOTS - 1)) {  // padding lanes hold zeros in the planes already
+    } else if (ONLY_LAST && j == SLOTS - 1) {  // padding lanes hold zeros in the planes already
       P[j][0] = fma(a0, b0, inb ? 0.0 : 1.0);
-    } else {
+    } else {                                   // (kByCount: the ghosts are put in after the loop)
       P[j][0] = a0 * b0;
     }
     P[j][1] = z0 * b1; P[j][2] = z0 * b2;
@@ -440,6 +457,15 @@ __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint3
       const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;
       const double c2 = inb ? fma(2.0, b2, b1) - mean2 : 0.0;
       sxy = fma(c1, c2, sxy);
+    }
+  }
+  if (kByCount) {  // ghosts behind scalar branches: full wavefronts -- all but a pair's last -- skip every one of them
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+      if (n_full <= (uint32_t)j) {
+        const bool keep = n_full == (uint32_t)j && lane_in_wave < rem;
+        P[j][0] = keep ? P[j][0] : 1.0;
+      }
     }
   }
 }

@@ -55,8 +55,8 @@ bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice) {
   // Several wavefronts per pair.  Just past a doubling of the wavefronts (1,025..1,280, 2,049..2,560, 4,097..5,120
   // individuals) NINE or TEN slots on half as many wavefronts beat five on twice as many: half-empty lanes and twice the
   // per-iteration bookkeeping against a few spilled registers outside the EM loop (nine: +35..46 % / +48..63 %; ten, round
-  // 3, once empty slots no longer cost registers: +11 % at 1,153..1,280, +30 % at 2,305..2,560, and 4,609..5,120 stay on the
-  // register kernels at 1.2e7 pairs/s against 6.5e6 for the streaming kernel; profiles/r03/sweep_ghost.txt).  Under
+  // 3, once empty slots no longer cost registers: +20 % at 1,153..1,280, +37 % at 2,305..2,560, and 4,609..5,120 stay on the
+  // register kernels at 1.35e7 pairs/s against 6.2e6 for the streaming kernel; profiles/r03/sweep_bycount.txt).  Under
   // --ignore_miss_data 2 x 10 loses 2.6 % to 4 x 5 -- same plane layout, so the launcher takes that shape there (multi_shape).
   int w = 2;
   while ((n_ind + 64ull * w - 1) / (64ull * w) > 8) w *= 2;

@@ -399,4 +399,40 @@ int ngsld_run_multi(const int *devices, int n_devices, uint64_t n_sites, uint64_
 
 int ngsld_multi_last_distribution(void) { return g_last_distribution.load(); }
 
+int ngsld_rccl_selftest(int device, uint64_t bytes, char *err, size_t errlen) try {
+  if (bytes < 8 || bytes > (1ull << 32)) {
+    set_err(err, errlen, "bytes out of range");
+    return NGSLD_ERR_INVALID;
+  }
+  const size_t n = (size_t)(bytes / 8);
+  std::vector<double> host(n), back(n);
+  for (size_t i = 0; i < n; ++i) host[i] = (double)(i % 1021) * 0.5 + 0.25;
+  std::vector<void *> d_raw;
+  bool used_rccl = false;
+  const int devices[1] = {device};
+  const std::string why = broadcast_matrix(devices, 1, host.data(), n * sizeof(double), d_raw, &used_rccl);
+  int rc = NGSLD_OK;
+  if (!why.empty()) {
+    set_err(err, errlen, why);
+    rc = NGSLD_ERR_DEVICE;
+  } else if (!used_rccl) {
+    set_err(err, errlen, "librccl could not be loaded, or one of its calls failed (see stderr)");
+    rc = NGSLD_ERR_DEVICE;
+  } else if (hipSetDevice(device) != hipSuccess ||
+             hipMemcpy(back.data(), d_raw[0], n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+             std::memcmp(back.data(), host.data(), n * sizeof(double)) != 0) {
+    set_err(err, errlen, "the buffer came back changed from the in-place broadcast");
+    rc = NGSLD_ERR_DEVICE;
+  }
+  if (!d_raw.empty() && d_raw[0] != nullptr) {
+    (void)hipSetDevice(device);
+    (void)hipFree(d_raw[0]);
+  }
+  (void)hipGetLastError();
+  return rc;
+} catch (const std::bad_alloc &) {
+  set_err(err, errlen, "out of host memory");
+  return NGSLD_ERR_NOMEM;
+}
+
 }  // extern "C"

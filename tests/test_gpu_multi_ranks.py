@@ -118,3 +118,40 @@ def test_run_multi_on_distinct_devices_broadcasts_over_rccl():
         assert sum(per) == len(s1) and all(n > 0 for n in per)
         assert np.array_equal(got[0], s1) and np.array_equal(got[1], s2)
         assert got[2].tobytes() == std.tobytes() and got[3].tobytes() == ext.tobytes()
+
+
+def test_rccl_calls_of_run_multi_on_a_one_device_communicator():
+    """What one GPU can prove about the broadcast of ngsld_run_multi: librccl loads, ncclCommInitAll / ncclGroupStart /
+    ncclBroadcast / ncclGroupEnd / ncclCommDestroy run on a communicator of one device, 64 MiB come back unchanged."""
+    capi.rccl_selftest(0, 64 << 20)
+
+
+RCCL_ONE_RANK = r"""
+import os, sys
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from ngsld_amd import shard
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)      # the backend bench.py --gpus N uses (RCCL)
+x = torch.arange(1 << 22, dtype=torch.float64, device=dev)
+dist.broadcast(x, src=0)                                                  # bench.py: shard.broadcast_matrix
+s = torch.tensor([3.0, -1.0], dtype=torch.float64, device=dev)
+dist.all_reduce(s, op=dist.ReduceOp.MAX)                                  # bench.py: MAX / SUM over ranks
+got = [None]
+dist.all_gather_object(got, {"rank": 0})                                  # bench.py: rank_records
+dist.barrier()
+torch.cuda.synchronize()
+assert float(x[12345]) == 12345.0 and float(s[0]) == 3.0 and got == [{"rank": 0}]
+dist.destroy_process_group()
+print("rccl one-rank ok")
+"""
+
+
+def test_torch_rccl_backend_runs_the_collectives_bench_uses():
+    """bench.py --gpus N talks RCCL through torch.distributed's nccl backend: a one-rank group on this box runs the three
+    collectives it uses (broadcast of the matrix, all_reduce of the timings, all_gather_object of the rank records)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", RCCL_ONE_RANK, REPO], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]

@@ -1,0 +1,35 @@
+"""Development aids stay honest: every shell script under tools/ and profiles/ parses, and none of them (nor the product's
+build files) names a build-time switch or kernel selection that no longer exists -- a variant that cannot be built cannot rot
+silently (round 2 shipped fourteen switches, of which the default build exercised one setting each)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from ngsld_amd import capi
+
+REPO = capi.REPO_DIR
+SCRIPTS = sorted(os.path.join(d, f) for d in ("tools", "profiles") for f in os.listdir(os.path.join(REPO, d)) if f.endswith(".sh"))
+GONE = ["NGSLD_FOLD_T3", "NGSLD_XCH_ASM", "NGSLD_PARKED", "NGSLD_MASK_DONE", "NGSLD_MFMA_REDUCE", "NGSLD_PAIR_RCP", "NGSLD_DROP0",
+        "NGSLD_WN_ROWS", "NGSLD_EARLY_EPS", "NGSLD_GROUP_SUM3", "NGSLD_SLOTS9", "NGSLD_SLOTS10", "NGSLD_RUN_SLOTS",
+        "PAIR_KERNEL=item", "PAIR_KERNEL=wave", "PAIR_KERNEL=direct"]
+
+
+@pytest.mark.parametrize("path", SCRIPTS)
+def test_script_parses_and_names_no_removed_switch(path):
+    full = os.path.join(REPO, path)
+    assert subprocess.run(["bash", "-n", full], capture_output=True).returncode == 0, f"{path} does not parse"
+    text = open(full).read()
+    for name in GONE:
+        assert name not in text, f"{path} still uses {name}, which the sources no longer know"
+
+
+def test_every_switch_of_the_hot_header_is_known_to_the_docs():
+    """ld_device.h keeps a handful of tuning knobs; each is named in DESIGN.md (what it does, what was measured)."""
+    hdr = open(os.path.join(REPO, "ngsld_amd", "csrc", "ld_device.h")).read()
+    knobs = sorted(set(re.findall(r"#ifndef (NGSLD_[A-Z0-9_]+)", hdr)))
+    assert 1 <= len(knobs) <= 5, knobs
+    design = open(os.path.join(REPO, "DESIGN.md")).read()
+    for k in knobs:
+        assert k in design or k.replace("NGSLD_PRIO_S", "NGSLD_PRIO_") in design, f"{k} is not documented"

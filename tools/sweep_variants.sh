@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Kernel rate over cohort sizes for several kernel selections (env assignments), same box, interleaved:
-#   NINDS="513 576 640" tools/sweep_variants.sh "default=" "ab=NGSLD_PAIR_KERNEL=ab" "run10=NGSLD_RUN_SLOTS=10"
+#   NINDS="513 576 640" tools/sweep_variants.sh "default=" "ab=NGSLD_PAIR_KERNEL=ab" "multi=NGSLD_PAIR_KERNEL=multi"
 # prints one line per (n_ind, mask, variant): pairs/s and ind-pairs/s.
 for n in ${NINDS:-513 576 640 704 768 832 896 960 1024}; do
   sites=$(python -c "print(int(max(4000, min(100000, 4e7 / $n))))")
