@@ -195,3 +195,35 @@ def test_c5_rank_slab_125000x2000_windowed():
         _sample_check(raw, pd, row_off, row_end, std, hap, n_data, n_iter, 60, 9, max_kb, n_rows=n_rows)
     finally:
         eng.close()
+
+
+@pytest.mark.timeout(1500)
+def test_c5_full_size_on_one_gpu_through_the_bench():
+    """configs[4] at FULL size -- 1,000,000 sites x 2,000 individuals, 500 kb window, the 48 GB matrix resident in HBM -- as
+    one `bench.py --config c4` step on this box's GPU (what rank 0 of an 8-GPU run computes is an eighth of it).  The bench's
+    own checks are the test: its host mirror of the window walk and the engine's plan agree on the pair count (asserted
+    inside), and the cpu_baseline leg re-computes the matrix's first rows with the oracle and compares them with the GPU's
+    records of the same rows -- pairs and executed EM iterations EQUAL, sum of r2 to 1e-9 relative."""
+    import json
+    import subprocess
+    import sys
+    free, total = capi.device_memory(0) if hasattr(capi, "device_memory") else (None, None)
+    if free is not None and free < 150 * 2 ** 30:
+        pytest.skip(f"{free / 2 ** 30:.0f} GiB of device memory free: the full-size run needs ~135 GiB")
+    cmd = [sys.executable, "bench.py", "--config", "c4", "--steps", "1", "--warmup", "0", "--no-traffic", "--no-e2e", "--no-sink",
+           "--cpu-seconds", "4"]
+    r = subprocess.run(cmd, cwd=capi.REPO_DIR, capture_output=True, text=True, timeout=1400)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c = d["config"]
+    assert c["n_sites_total"] == 1_000_000 and "2000 ind" in c["workload"] and "BASELINE configs[4]" in c["workload"]
+    assert 4.5e8 < c["pairs_per_step"] < 5.5e8                                 # ~500 partners per site
+    assert 8.5 < c["mean_executed_em_iterations"] < 10.5
+    assert d["roofline"]["kernel"].startswith("pair_ld_kernel") and d["value"] > 2.5e7
+    rec = c["rank_records"][0]
+    assert rec["pairs"] == c["pairs_per_step"] and rec["sites_held"] == [0, 1_000_000]
+    par = d["cpu_baseline"]["parity_on_sample"]
+    assert par["pairs_equal"] and par["executed_iterations_equal"] and par["pairs"] > 20_000, par
+    assert par["abs_diff_sum_r2"] <= 1e-9 * max(1.0, abs(par["sum_r2_cpu"])), par
+    print(f"\n[c5 full size] {c['pairs_per_step']} pairs, {d['value']:.4g} pairs/s, frac {d['roofline']['frac']:.3f}; "
+          f"parity sample {par['pairs']} pairs: iterations equal, |d sum r2| {par['abs_diff_sum_r2']:.2e}")

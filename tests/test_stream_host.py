@@ -95,3 +95,24 @@ def test_ranged_binary_read(tmp_path, compressed):
         capi.read_geno_bin_range(path, 7, 40, 11)             # runs past the end
     with pytest.raises(capi.NgsldError):
         capi.read_geno_bin_range(os.path.join(str(tmp_path), "missing"), 7, 0, 1)
+
+
+# n_ind -> padded individuals per genotype plane of the kernel shape pair_config picks: lane groups of 8 / 16 /
+# 32 up to 128 (and the odd 32-multiples up to 224), one wavefront per pair up to 832 (64 per slot), several wavefronts
+# beyond -- eight slots per lane, nine or ten just past a doubling -- and whole 64-blocks for the streaming kernel
+PLANE_SHAPES = [(24, 24), (64, 64), (65, 80), (100, 112), (128, 128), (160, 160), (200, 224), (250, 256), (500, 512), (512, 512),
+                (513, 576), (576, 576), (577, 640), (640, 640), (641, 704), (832, 832), (833, 896), (1000, 1024), (1024, 1024),
+                (1025, 1152), (1152, 1152), (1153, 1280), (1280, 1280), (1281, 1536), (2000, 2048), (2049, 2304),
+                (2305, 2560), (2561, 3072), (4096, 4096), (4097, 4608), (4609, 5120), (5120, 5120), (5121, 5184),
+                (6000, 6016)]
+
+
+@pytest.mark.parametrize("n_ind,np_want", PLANE_SHAPES)
+def test_budget_helper_sizes_slabs_with_the_engines_own_plane_layout(n_ind, np_want):
+    """ngsld_slab_sites_for_budget must count 24 * np + 64 bytes per site with the np the engine will really allocate
+    (round 2's helper took the a/b kernel's layout for 513..1024 while the engine ran the two-wavefront one: slabs up to
+    11 % too large).  np is read back from the helper at two budgets -- and pins pair_config's shape boundaries on the CPU."""
+    lo, hi = capi.slab_sites_for_budget(n_ind, 64 << 30), capi.slab_sites_for_budget(n_ind, 192 << 30)
+    assert 0 < lo < hi
+    per_site = (64 << 30) / (hi - lo)                      # d(budget / 2) / d(sites)
+    assert abs(per_site - (24 * np_want + 64)) < 1e-3 * per_site, (n_ind, per_site, (per_site - 64) / 24)

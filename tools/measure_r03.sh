@@ -7,6 +7,11 @@
 #   5. cohort sizes 8..5,200 with and without --ignore_miss_data
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r03/final; mkdir -p $O
 cd $R
+#   0. the GPU test suite and two fuzz soaks (the cohort sizes whose kernel changed this round; the round-1 generator)
+( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu_final.txt 2>&1
+grep -E "passed|failed|parity:|c5 full size|multi-ranks" $O/pytest_gpu_final.txt | tail -6
+timeout 900 python tools/fuzz_soak.py 10060 12060 > $O/fuzz_soak_r03_newshapes.txt 2>&1; tail -1 $O/fuzz_soak_r03_newshapes.txt
+timeout 900 python tools/fuzz_soak.py 400 8400 > $O/fuzz_soak_r03.txt 2>&1; tail -1 $O/fuzz_soak_r03.txt
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_r03_final.json 2> $O/bench_r03_final.err
 tail -c 400 $O/bench_r03_final.json
 : > $O/configs_r03.jsonl
