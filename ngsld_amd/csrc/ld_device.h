@@ -1631,8 +1631,8 @@ __global__ __launch_bounds__(256, 2) void pair_ld_stream_kernel(PairArgs A) {
 // Kernel families (pair_config picks by cohort size, by measurement: profiles/r03/sweep_513_1024.txt):
 //   kGroup  8 / 16 / 32 lanes per pair, several pairs per wavefront in lockstep (n_ind <= 128, some shapes up to 224)
 //   kRun    one wavefront per pair, the row vector shared in LDS, runs of items (n_ind <= 640: up to TEN individuals per lane)
-//   kRunAB  one wavefront per pair, EM step in its a/b form, run pipeline (ld_pair_ab.hip: 641..832)
-//   kMulti  2 / 4 / 8 wavefronts per pair (833..5120)
+//   kRunAB  one wavefront per pair, EM step in its a/b form, run pipeline (ld_pair_ab.hip: 641..960)
+//   kMulti  2 / 4 / 8 wavefronts per pair (961..5120)
 //   kStream any n_ind, vectors re-read every iteration
 //   kHard   every likelihood triple of the matrix is a called genotype or "no data": the pairs' 16 genotype-combination
 //           counts replace the individuals (any n_ind up to kHardMaxInd)

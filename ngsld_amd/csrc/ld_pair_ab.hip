@@ -1,16 +1,16 @@
 // ld_pair_ab.hip -- one wavefront per pair beyond what the P form holds in registers: the EM step in its a/b form.
-// The default for 641..832 individuals (pair_config, by
-// measurement: profiles/r03/sweep_513_1024.txt -- +9 % at 704, +2 % at 768, +5.5 % at 832 against two wavefronts per pair,
-// +6..13 % under --ignore_miss_data; level at 896..960, -6.5 % at 1,024); NGSLD_PAIR_KERNEL=ab selects it for 513..1024.
+// The default for 641..960 individuals (pair_config, by measurement: profiles/r03/sweep_513_1024.txt, sweep_areg.txt);
+// NGSLD_PAIR_KERNEL=ab selects it for 513..1024.
 //
 // The idea.  The other kernels keep P = a (x) b (9 products per individual, 18 VGPRs) for the whole pair, which caps a
 // lane at 8 individuals; above 512 individuals a pair is spread over 2..8 wavefronts that meet behind a barrier in EVERY
 // EM iteration (pair_ld_kernel<SLOTS, WAVES>) -- at n_ind 1000 the SIMDs issue VALU 85 % of the time against 97 % in the
 // one-wavefront kernel, and each of the two wavefronts pays the per-iteration bookkeeping (f products, contraction,
 // reduction, convergence test) for 8 slots only: 2 x 280 = 560 VALU instructions per pair and iteration.
-// Here a lane holds 16 individuals of ONE factor: b (site 2) in 96 VGPRs.  The row's vector a sits in LDS once per
-// workgroup (shared by the workgroup's eight wavefronts) and is RE-READ every iteration (24 B per individual-iteration,
-// ~35 % of the LDS bandwidth).  Per individual and iteration
+// Here a lane holds up to 16 individuals of ONE factor: b (site 2) in 6 VGPRs per slot.  The row's vector a sits in LDS once
+// per workgroup (shared by the workgroup's eight wavefronts) and -- round 3 -- a lane copies its own slots of it into
+// REGISTERS once per run wherever they fit beside b (AbRegs: all of them up to 13 slots); what does not fit is re-read from
+// LDS in every iteration (24 B per individual-iteration).  Per individual and iteration
 //     v = W(f) b              9 mul / FMA        (W: the 3x3 two-locus genotype weights)
 //     s = a . v               3 FMA              (the reference's 16-term `sum`, gen_func.cpp:1093-1096)
 //     r = 1 / s               shared: one v_rcp_f64 per TREE individuals of a lane (RcpTree)
@@ -53,10 +53,17 @@ __device__ __forceinline__ void static_for(F &&f) {
 // genotype planes in LDS (already relabelled), element j at [64 j].  Same control flow as em_pair: the hot loop holds the
 // shared-reciprocal step in its three-value form; a step that does not look sane is redone with one reciprocal per
 // individual; a pair whose hap 0 falls below kFullBelow finishes in the full four-value form.
-template <int SLOTS, bool MASKED, int TREE>
-__device__ __forceinline__ uint32_t em_pair_ab(const double (&B)[SLOTS][3], const double *la0, const double *la1,
-                                               const double *la2, uint32_t vbits, const double *pads, double inv_x, double m1,
-                                               double m2, double &f0, double &f1, double &f2, double &f3, int lane, int *status) {
+//   AREG: the row vector's first AREG slots of this lane sit in REGISTERS (Ar, loaded once per run: the row is the same for
+//   every pair of the run), only the slots beyond are re-read from LDS in every iteration
+template <int SLOTS, bool MASKED, int TREE, int AREG>
+__device__ __forceinline__ uint32_t em_pair_ab(const double (&B)[SLOTS][3], const double (&Ar)[AREG > 0 ? AREG : 1][3],
+                                               const double *la0, const double *la1, const double *la2, uint32_t vbits,
+                                               const double *pads, double inv_x, double m1, double m2, double &f0, double &f1,
+                                               double &f2, double &f3, int lane, int *status) {
+  auto a_of = [&](int j, int g) -> double {  // (j, g compile-time after unrolling)
+    if (j < AREG) return Ar[j < AREG ? j : 0][g];
+    return g == 0 ? la0[64 * j] : (g == 1 ? la1[64 * j] : la2[64 * j]);
+  };
   f0 = (1 - m1) * (1 - m2); f1 = (1 - m1) * m2; f2 = m1 * (1 - m2); f3 = m1 * m2;  // gen_func.cpp:1034-1037
   if (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1) {  // error() in the reference (:1030); reported through status
     if (lane == 0) atomicExch(status, (int)NGSLD_ERR_MAF_RANGE);
@@ -98,7 +105,7 @@ __device__ __forceinline__ uint32_t em_pair_ab(const double (&B)[SLOTS][3], cons
         for (int t = 0; t < kT; ++t) {
           const int j = h + t;
           if (j < SLOTS) {
-            av[t][0] = la0[64 * j]; av[t][1] = la1[64 * j]; av[t][2] = la2[64 * j];
+            av[t][0] = a_of(j, 0); av[t][1] = a_of(j, 1); av[t][2] = a_of(j, 2);
             sv[t] = slot_s(j, av[t][0], av[t][1], av[t][2], MASKED || j == SLOTS - 1);
           } else {  // the last tree of a slot count that is no multiple of TREE: a neutral factor
             av[t][0] = av[t][1] = av[t][2] = 0.0;
@@ -121,7 +128,7 @@ __device__ __forceinline__ uint32_t em_pair_ab(const double (&B)[SLOTS][3], cons
 #pragma unroll
       for (int j = 0; j < SLOTS; ++j) {
         if ((vbits >> j) & 1u) {
-          const double a0 = la0[64 * j], a1 = la1[64 * j], a2 = la2[64 * j];
+          const double a0 = a_of(j, 0), a1 = a_of(j, 1), a2 = a_of(j, 2);
           slot_acc(j, a0, a1, a2, rcp_refined(slot_s(j, a0, a1, a2, false)));
         }
       }
@@ -186,8 +193,9 @@ __device__ __forceinline__ uint32_t em_pair_ab(const double (&B)[SLOTS][3], cons
   return n_iter | (tie ? kTieBit : 0u);
 }
 
-template <int SLOTS, bool MASKED, int TREE>
+template <int SLOTS, bool MASKED, int TREE, int AREG = 0>
 __global__ __launch_bounds__(512, 2) void pair_ld_ab_kernel(PairArgs A) {
+  constexpr int kAReg = AREG < SLOTS ? AREG : SLOTS;
   constexpr uint32_t kNp = SLOTS * 64;
   constexpr int kSiteBytes = (int)kNp * 24;
   constexpr int kLand = SLOTS < kAbLand ? SLOTS : kAbLand;
@@ -263,6 +271,16 @@ __global__ __launch_bounds__(512, 2) void pair_ld_ab_kernel(PairArgs A) {
   if (cur.ok) dma_land(cur.s2);
   uint32_t held = 0;
   const double *la = reinterpret_cast<const double *>(lds_a) + lane;
+  // the row vector's first kAReg slots into registers, once per run, already relabelled (flip1 depends on the row's maf only)
+  double Ar[kAReg > 0 ? kAReg : 1][3];
+  {
+    const bool flip1_run = m1 > 0.5;  // (relabel())
+    const double *r0 = la + (flip1_run ? 2 * kNp : 0u), *r1 = la + kNp, *r2 = la + (flip1_run ? 0u : 2 * kNp);
+#pragma unroll
+    for (int j = 0; j < kAReg; ++j) {
+      Ar[j][0] = r0[64 * j]; Ar[j][1] = r1[64 * j]; Ar[j][2] = r2[64 * j];
+    }
+  }
   while (cur.ok) {
     const Cand nxt = claim_next();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's landing copy (issued a pair ago) is complete
@@ -294,7 +312,8 @@ __global__ __launch_bounds__(512, 2) void pair_ld_ab_kernel(PairArgs A) {
     double sxy = 0.0;
 #pragma unroll
     for (int j = 0; j < SLOTS; ++j) {
-      const double a0 = la0[64 * j], a1 = la1[64 * j], a2 = la2[64 * j];
+      const double a0 = j < kAReg ? Ar[j < kAReg ? j : 0][0] : la0[64 * j], a1 = j < kAReg ? Ar[j < kAReg ? j : 0][1] : la1[64 * j],
+                   a2 = j < kAReg ? Ar[j < kAReg ? j : 0][2] : la2[64 * j];
       const bool inb = (uint32_t)lane + 64u * (uint32_t)j < A.n_ind;
       bool ok = inb;
       if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(B[j][0], B[j][1], B[j][2]);  // gen_func.cpp:1089
@@ -315,8 +334,8 @@ __global__ __launch_bounds__(512, 2) void pair_ld_ab_kernel(PairArgs A) {
     const double inv_x = MASKED ? 1.0 / (double)x : A.inv_n;
     sxy = fma(-(double)A.n_ind * rl.mean1, rl.mean2, wave_sum1_bcast(sxy));  // centred: sum e1 e2 - n mean1 mean2
     double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair_ab<SLOTS, MASKED, TREE>(B, la0, la1, la2, vbits, pads, inv_x, rl.m1, rl.m2, f0, f1, f2, f3,
-                                                            lane, A.status);
+    const uint32_t n_iter = em_pair_ab<SLOTS, MASKED, TREE, kAReg>(B, Ar, la0, la1, la2, vbits, pads, inv_x, rl.m1, rl.m2, f0,
+                                                                   f1, f2, f3, lane, A.status);
     unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
     if (lane == 0) {
       RunResult &r = ring[held];
@@ -340,14 +359,26 @@ __global__ __launch_bounds__(512, 2) void pair_ld_ab_kernel(PairArgs A) {
 #define NGSLD_AB_TREE 8  // build-time A/B knob: individuals of a lane that share one reciprocal (4 or 8)
 #endif
 
+// Slots of the row vector a lane keeps in REGISTERS for the whole run (AREG), by slot count, as measured (same box,
+// profiles/r03/sweep_areg.txt; the records are the same bits whatever the split): every individual counts -- all of them up to
+// 13 slots (641..832: +9 % over re-reading them from LDS in every iteration: 1.40 / 1.38 / 1.29 / 1.21e8 pairs/s at 641 / 704 /
+// 768 / 832), six at 14 / 15 slots (b alone is 84 / 90 registers there; at 896 that is +4.6 % over two wavefronts per pair),
+// none at 16 (any split spills inside the EM loop: -5..-11 % at 1,000); --ignore_miss_data, whose per-slot pads take two
+// registers each: eight up to 12 slots (+5..7.5 %), four at 13 / 14 (+3.5 %), none beyond.
+template <int SLOTS>
+struct AbRegs {
+  static constexpr int kAll = SLOTS <= 13 ? SLOTS : (SLOTS <= 15 ? 6 : 0);
+  static constexpr int kMasked = SLOTS <= 12 ? 8 : (SLOTS <= 14 ? 4 : 0);
+};
+
 template <int SLOTS>
 static hipError_t launch_ab_s(bool masked, const PairArgs &a, hipStream_t stream) {
   const dim3 grid((unsigned)a.n_runs), block(512);
   constexpr int kTree = NGSLD_AB_TREE;
   if (masked)
-    hipLaunchKernelGGL((pair_ld_ab_kernel<SLOTS, true, kTree>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((pair_ld_ab_kernel<SLOTS, true, kTree, AbRegs<SLOTS>::kMasked>), grid, block, 0, stream, a);
   else
-    hipLaunchKernelGGL((pair_ld_ab_kernel<SLOTS, false, kTree>), grid, block, 0, stream, a);
+    hipLaunchKernelGGL((pair_ld_ab_kernel<SLOTS, false, kTree, AbRegs<SLOTS>::kAll>), grid, block, 0, stream, a);
   return hipGetLastError();
 }
 

@@ -36,8 +36,10 @@ bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice) {
     cfg->np = (uint32_t)(cfg->slots * cfg->group);
     return true;
   }
-  // one wavefront per pair: P form up to ten slots, a/b form up to thirteen (round 3, same box, pairs/s against two
-  // wavefronts: 513 +54 %, 576 +54 %, 640 +29 %, 704 +9 %, 768 +2 %, 832 +5.5 %; 896 and beyond: the two-wavefront kernel)
+  // one wavefront per pair: P form up to ten slots, a/b form up to fifteen (round 3, same box, pairs/s against two
+  // wavefronts: 513 +54 %, 576 +54 %, 640 +29 %; with the row vector in registers, ld_pair_ab.hip and
+  // profiles/r03/sweep_ab_range.txt: 641 +22 %, 704 +20 %, 768 +12 %, 832 +15 %, 896 +3.6 %, 960 +2.3 %; sixteen slots --
+  // 961..1,024 -- are the two-wavefront kernel's: -5 % for the a/b form at 1,000)
   const uint64_t slots1 = (n_ind + 63) / 64;
   const bool want_ab = choice == kChooseAB && n_ind > 512 && n_ind <= 1024;
   if (!want_ab && (n_ind <= 512 || (choice == kChooseAuto && slots1 <= 10))) {
@@ -46,7 +48,7 @@ bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice) {
     cfg->np = (uint32_t)(slots1 * 64);
     return true;
   }
-  if (want_ab || (choice == kChooseAuto && slots1 <= 13)) {
+  if (want_ab || (choice == kChooseAuto && slots1 <= 15)) {
     cfg->kernel = kRunAB;
     cfg->slots = (int)slots1;
     cfg->np = (uint32_t)(slots1 * 64);

@@ -1,4 +1,4 @@
-// ld_pair_wn.hip -- instantiations of the multi-wavefront-per-pair kernel (832 < n_ind <= 5120; from 513 on with NGSLD_PAIR_KERNEL=multi).
+// ld_pair_wn.hip -- instantiations of the multi-wavefront-per-pair kernel (960 < n_ind <= 5120; from 513 on with NGSLD_PAIR_KERNEL=multi).
 #include "ld_device.h"
 
 namespace ngsld {

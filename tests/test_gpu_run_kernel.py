@@ -1,4 +1,4 @@
-"""GPU: the run kernels (one wavefront per pair: n_ind 129..640 in the P form, 641..832 in the a/b form; one workgroup per
+"""GPU: the run kernels (one wavefront per pair: n_ind 129..640 in the P form, 641..960 in the a/b form; one workgroup per
 run of up to 16 items of a row) against the oracle.
 
 What is specific to it and therefore tested here: rows longer than one run (claims that cross item and run
@@ -66,10 +66,10 @@ def test_windowed_rows_split_into_equal_runs(engine):
     assert len(rec) > 200_000
 
 
-@pytest.mark.parametrize("n_ind,ignore_miss", [(513, False), (640, True), (777, False), (1000, False), (1024, True)])
+@pytest.mark.parametrize("n_ind,ignore_miss", [(513, False), (640, True), (777, False), (896, False), (900, True), (960, False), (1000, False), (1024, True)])
 def test_ab_form_kernel_matches_the_oracle(n_ind, ignore_miss):
     """NGSLD_PAIR_KERNEL=ab: one wavefront per pair for 513..1024 individuals, EM step in its a/b form (ld_pair_ab.hip: the
-    default for 641..832).  Held to the same bars as every kernel."""
+    default for 641..960).  Held to the same bars as every kernel."""
     import os
     from oracle import orc
     from util import check_records
@@ -159,12 +159,13 @@ def test_runs_recut_between_text_and_record_runs(n_ind):
 # what pair_config picks by cohort size (profiles/r03/sweep_513_1024.txt), and that every one of those shapes agrees with the oracle
 SHAPES = [(512, False, "run"), (513, False, "run"), (513, True, "run"), (576, False, "run"), (576, True, "run"),
           (577, False, "run"), (577, True, "run"), (640, False, "run"), (640, True, "run"), (641, False, "ab"),
-          (704, True, "ab"), (832, False, "ab"), (832, True, "ab"), (833, False, "multi"), (833, True, "multi")]
+          (704, True, "ab"), (768, False, "ab"), (832, False, "ab"), (832, True, "ab"), (833, False, "ab"), (896, True, "ab"),
+          (897, False, "ab"), (960, True, "ab"), (961, False, "multi"), (961, True, "multi")]
 
 
 @pytest.mark.parametrize("n_ind,ignore_miss,family", SHAPES)
 def test_cohort_sizes_around_the_kernel_boundaries(n_ind, ignore_miss, family):
-    """513..640 individuals stay on ONE wavefront per pair (nine / ten individuals per lane), 641..832 take the a/b form,
+    """513..640 individuals stay on ONE wavefront per pair (nine / ten individuals per lane), 641..960 take the a/b form,
     beyond that two wavefronts share a pair: the kernel reported is the one expected, and every one of them meets the
     oracle -- a monomorphic site, a site without data for a third of the cohort, a row longer than one item."""
     n_sites = 70

@@ -98,10 +98,10 @@ def test_ranged_binary_read(tmp_path, compressed):
 
 
 # n_ind -> padded individuals per genotype plane of the kernel shape pair_config picks: lane groups of 8 / 16 /
-# 32 up to 128 (and the odd 32-multiples up to 224), one wavefront per pair up to 832 (64 per slot), several wavefronts
+# 32 up to 128 (and the odd 32-multiples up to 224), one wavefront per pair up to 960 (64 per slot), several wavefronts
 # beyond -- eight slots per lane, nine or ten just past a doubling -- and whole 64-blocks for the streaming kernel
 PLANE_SHAPES = [(24, 24), (64, 64), (65, 80), (100, 112), (128, 128), (160, 160), (200, 224), (250, 256), (500, 512), (512, 512),
-                (513, 576), (576, 576), (577, 640), (640, 640), (641, 704), (832, 832), (833, 896), (1000, 1024), (1024, 1024),
+                (513, 576), (576, 576), (577, 640), (640, 640), (641, 704), (832, 832), (833, 896), (897, 960), (960, 960), (961, 1024), (1000, 1024), (1024, 1024),
                 (1025, 1152), (1152, 1152), (1153, 1280), (1280, 1280), (1281, 1536), (2000, 2048), (2049, 2304),
                 (2305, 2560), (2561, 3072), (4096, 4096), (4097, 4608), (4609, 5120), (5120, 5120), (5121, 5184),
                 (6000, 6016)]
