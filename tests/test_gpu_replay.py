@@ -146,6 +146,34 @@ def test_device_records_are_patched(engine):
         all_bits_equal(std[flagged], ext[flagged], want[flagged])
 
 
+def test_a_second_device_run_finishes_the_pending_one_first(engine):
+    """One pending run per context.  Two ngsld_run_device calls on a caller's stream with NO ngsld_finish_device in between --
+    then a re-plan on top: the earlier run's flagged records must still come out replayed (round 2 cleared the flag buffer
+    under the first run's kernels and dropped its pending state, leaving the kernels' own values in those records)."""
+    import torch
+    raw = mixed_matrix(300)
+    want = orc.Oracle(raw, n_threads=4).run()
+    engine.set_geno_raw(raw)
+    engine.set_pos_dist(None)
+    n = engine.plan()
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream()
+    bufs = [(torch.zeros(n * 32, dtype=torch.uint8, device=dev), torch.zeros(n * 40, dtype=torch.uint8, device=dev))
+            for _ in range(3)]
+    engine.run_device(0, engine.n_sites, bufs[0][0].data_ptr(), bufs[0][1].data_ptr(), st.cuda_stream)
+    engine.run_device(0, engine.n_sites, bufs[1][0].data_ptr(), bufs[1][1].data_ptr(), st.cuda_stream)   # settles run 1
+    engine.run_device(0, engine.n_sites, bufs[2][0].data_ptr(), bufs[2][1].data_ptr(), st.cuda_stream)   # settles run 2
+    assert engine.plan() == n                                                                            # settles run 3
+    torch.cuda.synchronize()
+    flagged = np.isin(want["s1"], [4, 17]) | np.isin(want["s2"], [4, 17])
+    for d_std, d_ext in bufs:
+        std = d_std.cpu().numpy().view(capi.REC_STD)
+        ext = d_ext.cpu().numpy().view(capi.REC_EXT)
+        check_records(std, ext, want)
+        all_bits_equal(std[flagged], ext[flagged], want[flagged])
+    engine.finish_device()                                                                               # nothing pending: a no-op
+
+
 def test_device_text_of_replayed_pairs_equals_the_host_text(engine):
     """Text batches: the flagged records are patched on the device before the rows are formatted."""
     raw = mixed_matrix(100)
