@@ -61,7 +61,8 @@ def test_all_pairs_multi_wave(engine, n_sites, n_ind, seed):
                                                             (9, 2304, 29, True), (8, 4300, 30, False), (7, 4608, 31, True),
                                                             (12, 1153, 32, False), (12, 1200, 33, True), (11, 1280, 34, False),
                                                             (9, 2305, 35, True), (9, 2560, 36, False), (7, 4609, 37, False),
-                                                            (6, 4700, 38, True), (6, 5000, 39, False), (6, 5120, 40, True)])
+                                                            (6, 4700, 38, True), (6, 4700, 41, False), (6, 5000, 39, False),
+                                                            (6, 5000, 42, True), (6, 5120, 40, True)])
 def test_nine_and_ten_slots_per_lane(engine, n_sites, n_ind, seed, ignore_miss):
     """Just past a doubling of the wavefronts per pair the kernels hold NINE or TEN individuals per lane on half as many
     wavefronts (2 / 4 / 8 x 9 / 10 x 64; 2 x 10 under --ignore_miss_data runs as 4 x 5 on the same planes): with and without
@@ -197,7 +198,7 @@ def test_long_rows_and_many_items(engine):
 
 
 @pytest.mark.parametrize("n_sites,n_ind,seed,ignore", [(6, 5121, 301, False), (5, 6000, 302, True), (5, 6000, 304, False),
-                                                       (4, 9001, 303, False), (4, 10000, 305, True)])
+                                                       (4, 9001, 303, False), (4, 10000, 305, True), (4, 10000, 306, False)])
 def test_streaming_kernel_large_cohorts(engine, n_sites, n_ind, seed, ignore):
     """n_ind > 5120: the streaming kernel (site vectors re-read every EM iteration)."""
     raw = synth.make_gl_numpy(n_sites, n_ind, seed, depth=8.0)
