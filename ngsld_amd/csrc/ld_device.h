@@ -1495,12 +1495,16 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Streaming kernel (n_ind > 4096): no limit on the number of individuals.  One 256-thread workgroup per pair at a
+// Streaming kernel (n_ind > 5,120): no limit on the number of individuals.  One 256-thread workgroup per pair at a
 // time; wavefront w takes the 64-individual blocks w, w+4, w+8, ...  P does not fit in registers any more, so
 // every EM iteration re-reads both site vectors (from L2: a pair's two vectors are 48*n_ind bytes) and forms
 //   s = sum_g1 a[g1] * (sum_g2 W[g1][g2] b[g2]),   R[g1][g2] += (r a[g1]) * b[g2]
 // on the fly: 24 f64 VALU + rcp + 6 loads per individual and iteration instead of 21 + rcp from registers.
 // Same reduction order rules as the other kernels (fixed, deterministic).
+// (Round 3 tried ONE wavefront per pair instead -- no exchange, no barrier, the four wavefronts of a workgroup walking the same
+// row vector so that a neighbour's lines in the CU's L1 would serve the a-loads: -15..-17 % at 5,121..10,000 individuals,
+// profiles/r03/sweep_stream.txt.  A wavefront streaming a whole pair alone has a quarter of the loads in flight per pair, and
+// the L1 sharing did not happen.)
 // ---------------------------------------------------------------------------------------------
 template <bool MASKED>
 __global__ __launch_bounds__(256, 2) void pair_ld_stream_kernel(PairArgs A) {

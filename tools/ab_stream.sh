@@ -1,0 +1,5 @@
+#!/usr/bin/env bash
+# Same-box: the streaming kernel (n_ind > 5,120) of this build against round 2's library.  tools/ab_stream.sh > gpurun_out/sweep_stream.txt
+A=$PWD/ngsld_amd/ab
+timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "streaming" 2>&1 | tail -3
+NINDS="${NINDS:-5121 6000 8000 10000 16000}" timeout 900 tools/sweep_variants.sh "r02=NGSLD_LIB=$A/libngsld_r02.so" "now="
