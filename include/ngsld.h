@@ -173,8 +173,8 @@ int ngsld_set_text_output(ngsld_ctx *ctx, const char *const *labels, int enable)
  * reference to ~1e-15 wherever the outcome is well conditioned.  A few outcomes are decided by the reference's own
  * rounding noise: D' and r2 of a pair with a site (nearly) monomorphic in the estimated haplotypes (0/0-type
  * quotients, ngsLD.cpp:296-306: -nan, 0.000000 or inf), nIter when eps lands within 1e-12 of EPSILON
- * (gen_func.cpp:1054), the maf < min_maf tests when a frequency ties --min_maf (ngsLD.cpp:264-275), r2_ExpG at a
- * site whose expected genotypes are constant up to rounding (ngsLD.cpp:365-367).  The kernels flag those pairs and
+ * (gen_func.cpp:1054), the maf < min_maf tests when a frequency ties --min_maf (ngsLD.cpp:264-275), r2_ExpG of a
+ * pair of sites whose expected genotypes are both nearly constant (1 / (std1 std2) > 2^13; ngsLD.cpp:365-367).  The kernels flag those pairs and
  * the engine re-evaluates them on the host in the reference's operation order (sequential sums over individuals,
  * the sequential renormalisation, no fused multiply-add: ngsld_host_replay_pair in ngsld_host.h) and overwrites
  * their records -- before a batch reaches the sink, before it is formatted on the device, before ngsld_run_device
@@ -205,8 +205,9 @@ int ngsld_replay_stats(ngsld_ctx *ctx, uint64_t *pairs, uint64_t *sites);
  * (NULL = the ctx's own stream); the call returns after enqueueing when a stream is given. */
 int ngsld_run_device(ngsld_ctx *ctx, uint64_t s1_begin, uint64_t s1_end, void *d_std, void *d_ext, void *hip_stream);
 /* After ngsld_run_device on a caller's stream: waits for that stream, replays the flagged pairs and patches the device
- * records (exact-order replay, above).  Without this call the flagged records keep the kernels' own values.  A no-op
- * after a run on the ctx's own stream (hip_stream == NULL does all of it before returning). */
+ * records (exact-order replay, above).  A context has ONE pending device run: the next ngsld_run_device, ngsld_run,
+ * ngsld_plan or ngsld_set_geno_* finishes it first (as this call would), so a flagged record is never left with the
+ * kernels' own value.  A no-op after a run on the ctx's own stream (hip_stream == NULL does all of it before returning). */
 int ngsld_finish_device(ngsld_ctx *ctx);
 
 /* Timing of the pair kernel launches issued by the last ngsld_run / ngsld_run_device, measured with
