@@ -1,0 +1,38 @@
+"""GPU, last in the suite: the cohort sizes that were cliffs in round 2's sweep, as FLOORS on this box.
+
+Not a benchmark -- `bench.py` and `profiles/` are -- but a claim the driver's own box checks: each floor lies ABOVE what round
+2's kernels reached on a fast box and 10-25 % BELOW what the round-3 kernels reach on the slowest box of the pool seen so
+far (`profiles/r03/sweep_nind_r03.txt`, taken at 2.19 GHz), so a pass means the step after 512 / 640 / 2,304 / 4,608
+individuals is gone here too, and a fail means a kernel selection or a register spill has regressed."""
+import json
+import subprocess
+import sys
+
+import pytest
+
+from ngsld_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+#        n_ind  floor (pairs/s)   round 2, fast box   round 3, 2.19 GHz box   kernel expected
+FLOORS = [(513, 1.45e8),        # 1.20e8              1.82e8                  run kernel, nine individuals per lane
+          (640, 1.30e8),        # 1.21e8              1.53e8                  run kernel, ten
+          (704, 1.17e8),        # 1.13e8              1.33e8                  a/b kernel, row vector in registers
+          (2560, 2.70e7),       # 2.34e7              3.05e7                  four wavefronts x ten
+          (5120, 1.00e7)]       # 6.2e6 (streaming)   1.25e7                  eight wavefronts x ten
+KERNELS = {513: "pair_ld_run_kernel", 640: "pair_ld_run_kernel", 704: "pair_ld_ab_kernel",
+           2560: "pair_ld_kernel (multi-wavefront)", 5120: "pair_ld_kernel (multi-wavefront)"}
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n_ind,floor", FLOORS)
+def test_cohort_sizes_past_the_old_cliffs_keep_their_rate(n_ind, floor):
+    sites = int(max(4000, min(100000, 4e7 / n_ind)))
+    cmd = [sys.executable, "bench.py", "--config", "c2", "--sites", str(sites), "--ind", str(n_ind), "--steps", "2", "--warmup", "1",
+           "--no-cpu", "--no-sink", "--no-e2e", "--no-traffic"]
+    r = subprocess.run(cmd, cwd=capi.REPO_DIR, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["roofline"]["kernel"] == KERNELS[n_ind], d["roofline"]["kernel"]
+    print(f"\n[throughput] n_ind {n_ind}: {d['value']:.4g} pairs/s ({d['roofline']['kernel']}), floor {floor:.3g}")
+    assert d["value"] >= floor, f"n_ind {n_ind}: {d['value']:.4g} pairs/s is below the floor of {floor:.3g}"
