@@ -397,7 +397,9 @@ template <int SLOTS, bool MASKED, bool ONLY_LAST = false, bool UNCENTRED = false
 __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint32_t ia0, const double *pb, uint32_t npb,
                                            uint32_t ib0, uint32_t ind0, uint32_t n_ind, double mean1, double mean2,
                                            double (&P)[SLOTS][9], uint32_t &vbits, double &sxy, bool flip_a = false,
-                                           bool flip_b = false) {
+                                           bool flip_b = false, const double (*a_regs)[3] = nullptr, int n_a_regs = 0) {
+  // a_regs (may be null): this lane's first n_a_regs triples of site 1, already relabelled, held in registers by the caller
+  // for all the pairs of an item (the row vector is the same for every one of them) -- pa is not read for those slots
   // pa[g * npa + ia0 + 64 j] / pb[g * npb + ib0 + 64 j] hold genotype g of individual ind0 + 64 j (this lane, slot j);
   // flip_a / flip_b (wavefront-uniform) relabel the alleles of a site: genotype planes 0 and 2 trade places (see Relabel)
   vbits = 0;
@@ -425,8 +427,10 @@ __device__ __forceinline__ void stage_pair(const double *pa, uint32_t npa, uint3
   for (int j = 0; j < SLOTS; ++j) {
     const uint32_t ia = ia0 + (uint32_t)j * 64, ib = ib0 + (uint32_t)j * 64;
     typedef const __attribute__((address_space(1))) double gdouble_t;  // (said to be global memory: global_load, not flat_load)
-    const double a0 = A_GLOBAL ? ((gdouble_t *)pa0)[ia] : pa0[ia], a1 = A_GLOBAL ? ((gdouble_t *)pa1)[ia] : pa1[ia],
-                 a2 = A_GLOBAL ? ((gdouble_t *)pa2)[ia] : pa2[ia];
+    const bool in_regs = a_regs != nullptr && j < n_a_regs;
+    const double a0 = in_regs ? a_regs[j < n_a_regs ? j : 0][0] : (A_GLOBAL ? ((gdouble_t *)pa0)[ia] : pa0[ia]),
+                 a1 = in_regs ? a_regs[j < n_a_regs ? j : 0][1] : (A_GLOBAL ? ((gdouble_t *)pa1)[ia] : pa1[ia]),
+                 a2 = in_regs ? a_regs[j < n_a_regs ? j : 0][2] : (A_GLOBAL ? ((gdouble_t *)pa2)[ia] : pa2[ia]);
     const double b0 = pb0[ib], b1 = pb[npb + ib], b2 = pb2[ib];
     const bool inb = kByCount ? ((vbits >> j) & 1u) != 0
                               : ((ONLY_LAST && j < SLOTS - 1) ? true : ind0 + (uint32_t)j * 64 < n_ind);
@@ -861,6 +865,26 @@ __global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
     return c;
   };
 
+  // The wavefront's slice of the ROW vector is the same for all 64 candidates of the item: what fits beside P is loaded once,
+  // relabelled (that depends on the row's frequency only) and kept in registers, and every pair is spared those loads from L2
+  // -- and part of their round trip -- at its start.  Up to six slots per lane all of it fits: +6 % at 1,281..1,536 and
+  // 2,561..3,072 individuals, +8..10 % under --ignore_miss_data; seven slots take three, eight slots two (three on two
+  // wavefronts): configs[3] +1.2 % (+3 % masked), configs[4] +1.6 % (+3.5 %), same record bits (profiles/r03/
+  // sweep_multi_aregs.txt, ab_aregs78.txt).  Nine / ten slots: none (they spill as it is).
+  constexpr int kNA = SLOTS <= 6   ? SLOTS
+                      : SLOTS == 7 ? (WAVES == 8 ? 2 : 3)
+                      : SLOTS == 8 ? (WAVES == 2 ? 3 : (WAVES == 8 && MASKED ? 0 : 2))   // 8 x 8 masked would spill 72 B
+                                   : 0;
+  constexpr bool kARegs = kNA > 0;
+  double a_regs[kARegs ? kNA : 1][3];
+  if (kARegs) {
+    const bool flip1 = m1 > 0.5;  // (relabel())
+    const double *q0 = pa + (flip1 ? 2 * A.np : 0u), *q1 = pa + A.np, *q2 = pa + (flip1 ? 0u : 2 * A.np);
+#pragma unroll
+    for (int j = 0; j < kNA; ++j) {
+      a_regs[j][0] = q0[i0 + 64u * (uint32_t)j]; a_regs[j][1] = q1[i0 + 64u * (uint32_t)j]; a_regs[j][2] = q2[i0 + 64u * (uint32_t)j];
+    }
+  }
   uint32_t c = next_kept(0);
   if (c < it.count) dma_slice(it.s2_begin + c);
   uint32_t xpar = 0;  // exchanges of this workgroup so far (see em_pair)
@@ -874,7 +898,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice copied during the previous pair has landed
     stage_pair<SLOTS, MASKED, false, true, true>(pa, A.np, i0, reinterpret_cast<const double *>(lds_b),
                                                   (uint32_t)(SLOTS * 64), (uint32_t)lane, i0, A.n_ind, rl.mean1, rl.mean2, P,
-                                                  vbits, sxy, rl.flip1, rl.flip2);
+                                                  vbits, sxy, rl.flip1, rl.flip2, kARegs ? a_regs : nullptr, kNA);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // a, b and the scalars are all consumed
     if (cn < it.count) dma_slice(it.s2_begin + cn);
     uint32_t x = count_valid<SLOTS>(vbits);

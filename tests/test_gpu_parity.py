@@ -77,6 +77,23 @@ def test_nine_and_ten_slots_per_lane(engine, n_sites, n_ind, seed, ignore_miss):
     check_against_oracle(engine, raw, ignore_miss=ignore_miss)
 
 
+@pytest.mark.parametrize("n_sites,n_ind,seed,ignore_miss", [(12, 1300, 43, False), (10, 1536, 44, True), (10, 1400, 47, False),
+                                                            (8, 2600, 45, False), (8, 3072, 46, True), (8, 1290, 48, True)])
+def test_five_and_six_slots_keep_the_row_slice_in_registers(engine, n_sites, n_ind, seed, ignore_miss):
+    """Several wavefronts per pair with five or six individuals per lane (1,281..1,536 on four wavefronts, 2,561..3,072 on
+    eight): the wavefront's slice of the row vector is loaded once per item and held in registers for its 64 candidates --
+    including the relabelling of a row site with maf > 1/2, a monomorphic site and a site without data for some."""
+    raw = synth.make_gl_numpy(n_sites, n_ind, seed, depth=4.0)
+    raw[1] = raw[1][:, ::-1]                       # maf > 1/2 at a row site: planes 0 and 2 trade places (Relabel)
+    raw[3] = [1.0, 0.0, 0.0]
+    if ignore_miss:
+        miss = np.random.default_rng(seed).random((n_sites, n_ind)) < 0.15
+        raw[miss] = 1.0 / 3.0
+    engine.set_geno_raw(raw[:2], ignore_miss_data=ignore_miss)
+    assert engine.pair_kernel() == "multi"
+    check_against_oracle(engine, raw, ignore_miss=ignore_miss)
+
+
 def test_windowed_and_snp_dist(engine):
     raw = synth.make_gl_numpy(300, 50, 31, depth=8.0)
     chrs, pos = synth.make_positions(300, 31, max_gap=200, n_chr=2)
