@@ -177,9 +177,11 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
       if (r == NGSLD_OK) {
         // One kernel family for the whole job: a slab that happens to hold only called genotypes must not switch to the
         // genotype-combination kernel while its neighbours run the per-individual one (same values to 1e-12, not the
-        // same bits).
+        // same bits).  Known in advance for one kind of job: --call_geno with N_thresh == call_thresh (the default, 0 and
+        // 0) leaves every triple either called or "no data" (gen_func.cpp:886-914: below N_thresh -> missing, at or
+        // above call_thresh -> called, nothing in between), so every slab qualifies, as the resident run does.
         ngsld_geno_opts so = *opts;
-        so.per_individual_only = 1;
+        if (!(opts->call_geno && opts->N_thresh == opts->call_thresh)) so.per_individual_only = 1;
         r = ngsld_set_geno_raw_opts(ctx[b], host[b].data(), m, n_ind, &so);
         // exact-order replay: the slab's raw values stay in host[b] until its run is over
         if (r == NGSLD_OK) r = ngsld_set_replay_matrix(ctx[b], host[b].data());

@@ -78,6 +78,30 @@ def test_streamed_multi_wavefront_cohort(engine):
     _same(got, want)
 
 
+@pytest.mark.parametrize("thresholds,kernel", [((0.0, 0.0), "hard"), ((0.5, 0.5), "hard"), ((0.4, 0.9), None)])
+def test_streamed_called_genotypes_keep_the_resident_kernel(engine, thresholds, kernel):
+    """--call_geno with N_thresh == call_thresh leaves only called genotypes and "no data" (gen_func.cpp:886-914), which
+    is known before the first slab is read: the streamed run takes the genotype-combination kernel like the resident one
+    and gives the same bits.  With a gap between the thresholds some triples stay likelihoods and both keep to the
+    per-individual kernels."""
+    n_sites, n_ind = 1200, 90
+    raw = synth.make_gl_numpy(n_sites, n_ind, 53, depth=3.0)
+    raw[np.random.default_rng(3).random((n_sites, n_ind)) < 0.1] = 1.0 / 3.0
+    chrs, pos = synth.make_positions(n_sites, 53, n_chr=2)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    engine.set_geno_raw(raw, call_geno=thresholds)
+    if kernel is not None:
+        assert engine.pair_kernel() == kernel
+    else:
+        assert engine.pair_kernel() != "hard"
+    engine.set_pos_dist(pd)
+    engine.plan(max_kb_dist=3)
+    want = engine.run() + (engine.maf(),)
+    got = capi.run_streamed(lambda b, m: raw[b:b + m], n_sites, n_ind, pd, 200, call_geno=thresholds, max_kb_dist=3)
+    assert got[5] >= 5 and len(got[0]) > 10000
+    _same(got, want)
+
+
 def test_streamed_errors(engine):
     n_sites, n_ind = 300, 12
     raw = synth.make_gl_numpy(n_sites, n_ind, 43, depth=4.0)
@@ -103,7 +127,8 @@ def test_streamed_errors(engine):
 
 
 @pytest.mark.parametrize("flags", [["--max_kb_dist", "3", "--extend_out"],
-                                   ["--max_kb_dist", "3", "--rnd_sample", "0.5", "--seed", "9", "--min_maf", "0.1"]])
+                                   ["--max_kb_dist", "3", "--rnd_sample", "0.5", "--seed", "9", "--min_maf", "0.1"],
+                                   ["--max_kb_dist", "3", "--probs", "--call_geno"]])
 def test_cli_streamed_output_is_identical(tmp_path, flags):
     """The drop-in binary forced to stream (NGSLD_SLAB_SITES) writes the same bytes as the resident run."""
     n_sites, n_ind = 1500, 40
