@@ -869,8 +869,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
   // relabelled (that depends on the row's frequency only) and kept in registers, and every pair is spared those loads from L2
   // -- and part of their round trip -- at its start.  Up to six slots per lane all of it fits: +6 % at 1,281..1,536 and
   // 2,561..3,072 individuals, +8..10 % under --ignore_miss_data; seven slots take three, eight slots two (three on two
-  // wavefronts): configs[3] +1.2 % (+3 % masked), configs[4] +1.6 % (+3.5 %), same record bits (profiles/r03/
-  // sweep_multi_aregs.txt, ab_aregs78.txt).  Nine / ten slots: none (they spill as it is).
+  // wavefronts): configs[3] +1.2 % (+2.5 % masked), configs[4] +1.6 % (+3.9 %), eight wavefronts +1 %, same record bits
+  // (profiles/r03/sweep_multi_aregs.txt, sweep_multi_aregs_8w.txt, ab_aregs78.txt, ab_aregs_final.txt).  Nine / ten slots:
+  // none (they spill as it is).
   constexpr int kNA = SLOTS <= 6   ? SLOTS
                       : SLOTS == 7 ? (WAVES == 8 ? 2 : 3)
                       : SLOTS == 8 ? (WAVES == 2 ? 3 : (WAVES == 8 && MASKED ? 0 : 2))   // 8 x 8 masked would spill 72 B

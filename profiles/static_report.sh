@@ -14,18 +14,29 @@ template __global__ void ngsld::pair_ld_run_kernel<10,true>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_group_kernel<8,3,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_group_kernel<16,7,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_group_kernel<32,7,false>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_stream_kernel<false>(ngsld::PairArgs);
+EOT
+# the multi-wavefront kernels are built with the scheduler ld_pair_wn.hip is built with (csrc/Makefile: FLAGS_ld_pair_wn)
+cat > $T/kw.hip <<EOT
+#include "$R/ngsld_amd/csrc/ld_device.h"
+template __global__ void ngsld::pair_ld_kernel<6,4,false>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_kernel<6,4,true>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_kernel<7,4,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_kernel<8,2,false>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_kernel<8,2,true>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_kernel<8,4,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_kernel<8,4,true>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_kernel<8,8,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_kernel<10,4,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_kernel<10,8,false>(ngsld::PairArgs);
-template __global__ void ngsld::pair_ld_stream_kernel<false>(ngsld::PairArgs);
 EOT
 cd $T
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -c k.hip -o k.o -save-temps \
   -Rpass-analysis=kernel-resource-usage 2> res.txt || true
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-sched-strategy=iterative-ilp -c kw.hip -o kw.o \
+  -Rpass-analysis=kernel-resource-usage 2>> res.txt || true
 echo "== kernel resources (hipcc -Rpass-analysis=kernel-resource-usage, gfx950) =="
-grep -E "Function Name|VGPRs:|AGPRs|ScratchSize|Occupancy|LDS Size|SGPRs:" res.txt | sed 's/remark:[^:]*:[0-9]*:[0-9]*: *//; s/ \[-Rpass-analysis=kernel-resource-usage\]//' \
+grep -E "Function Name|VGPRs:|AGPRs|ScratchSize|Occupancy|LDS Size|SGPRs:" res.txt | sed 's/^[^ ]*:[0-9]*:[0-9]*: remark: *//; s/remark:[^:]*:[0-9]*:[0-9]*: *//; s/ \[-Rpass-analysis=kernel-resource-usage\]//' \
   | sed 's/_ZN5ngsld//; s/EvNS_8PairArgsE//'
 S=k-hip-amdgcn-amd-amdhsa-gfx950.s
 awk '/^_ZN5ngsld18pair_ld_run_kernelILi8ELb0EEEvNS_8PairArgsE:/,/s_endpgm/' $S > pf.s
