@@ -1656,6 +1656,194 @@ __global__ __launch_bounds__(256, 2) void pair_ld_stream_kernel(PairArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming kernel with the CANDIDATE's vector resident (5,121 .. 10,240 individuals; ld_pair_stream.hip).  Half of what
+// the streaming kernel reads in every EM iteration never changes during a pair: the candidate site's vector b.  Eight
+// wavefronts share a pair here -- wavefront w takes the 64-individual blocks w, w + 8, ... -- and with at most 20 blocks
+// per wavefront b fits in registers (6 VGPRs per slot), loaded once in the pass that counts the individuals and forms the
+// Pearson moment.  An iteration then reads the row vector a only: 24 bytes per individual from L2 instead of 48, half the
+// load instructions, and the step itself is the streaming kernel's (same four-value form, one reciprocal per individual).
+// One workgroup per item of 16 candidates, as there.
+// ---------------------------------------------------------------------------------------------
+template <int SLOTS, bool MASKED>
+__global__ __launch_bounds__(512, 2) void pair_ld_bres_kernel(PairArgs A) {
+  constexpr int kWaves = 8;
+  constexpr int kChunk = SLOTS <= 14 ? 4 : (SLOTS <= 17 ? 3 : 2), kChunks = (SLOTS + kChunk - 1) / kChunk;  // slots whose row values travel together
+  __shared__ double xch[2][kWaves][4];
+  __shared__ double xch0[kWaves][2];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const Item it = A.items[blockIdx.x];
+  const uint32_t s1 = it.s1;
+  const double m1 = A.maf[s1];
+  const double mean1 = A.mean_e[s1];
+  const double rsx1 = A.rsx[s1];
+  const uint64_t rec0 = it.first_record - A.out_base;
+  typedef const __attribute__((address_space(1))) double gdouble_t;  // global_load with an SGPR base + one 32-bit lane offset
+  const uint32_t np = A.np;
+  // the three plane bases of a site as wavefront-uniform pointers (see stage_pair, A_GLOBAL: left to itself the compiler keeps a
+  // 64-bit VGPR address per load of the unrolled loops)
+  const double *pa = A.planes + (uint64_t)s1 * A.site_stride;
+  gdouble_t *pa0 = (gdouble_t *)uniform_ptr(pa), *pa1 = (gdouble_t *)uniform_ptr(pa + np), *pa2 = (gdouble_t *)uniform_ptr(pa + 2 * np);
+  const uint32_t n_blocks = np / 64;  // (> 8 * (SLOTS - 1): the launcher picked SLOTS = ceil(n_blocks / 8))
+  // slot j of this wavefront is block j * 8 + wave; only the last slot can lie beyond the planes (then it re-reads slot 0's
+  // block and counts for nothing)
+  auto index_of = [&](int j) -> uint32_t {
+    const uint32_t blk = (uint32_t)(j * kWaves + wave);
+    return ((j < SLOTS - 1 || blk < n_blocks) ? blk : (uint32_t)wave) * 64u + (uint32_t)lane;
+  };
+  // Every load below is SGPR base + 32-bit byte offset of the slot (one VGPR per slot, shared by the six planes).  The offsets
+  // never change, and that is what has to be hidden from the compiler: loop-invariant code motion otherwise forms each load's
+  // 64-bit address once, in front of the loops, where nothing folds it into the addressing mode any more -- 6 * SLOTS
+  // registers of addresses, spilled and reloaded one by one in front of their loads.
+  typedef const __attribute__((address_space(1))) char gchar_t;
+  uint32_t off[SLOTS];
+#pragma unroll
+  for (int j = 0; j < SLOTS; ++j) off[j] = index_of(j) * 8u;
+  auto hide_offsets = [&]() {
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) asm volatile("" : "+v"(off[j]));
+  };
+  auto ld = [&](gdouble_t *base, int j) -> double { return *(gdouble_t *)((gchar_t *)base + off[j]); };
+
+  auto a_of = [&](int j, int g) -> double { return ld(g == 0 ? pa0 : (g == 1 ? pa1 : pa2), j); };
+
+  for (uint32_t c = 0; c < it.count; ++c) {
+    if (!((it.mask >> c) & 1ull)) continue;  // ngsLD.cpp:270-282
+    const uint32_t s2 = it.s2_begin + c;
+    const double *pb = A.planes + (uint64_t)s2 * A.site_stride;
+    gdouble_t *pb0 = (gdouble_t *)uniform_ptr(pb), *pb1 = (gdouble_t *)uniform_ptr(pb + np), *pb2 = (gdouble_t *)uniform_ptr(pb + 2 * np);
+    const double m2 = A.maf[s2], mean2 = A.mean_e[s2], rsx2 = A.rsx[s2];
+
+    hide_offsets();
+    // ---- pass 0: b into registers; individuals with data, Pearson cross moment (ngsLD.cpp:290: over ALL individuals) ----
+    // (kChunk slots at a time, here and in the iterations: with every load of the unrolled loop hoisted to its top the row
+    // vector's values alone would take 6 * SLOTS registers beside b's 6 * SLOTS)
+    double bv[SLOTS][3];
+    uint32_t vbits = 0, x = 0;
+    double sxy = 0.0;
+#pragma unroll
+    for (int j0 = 0; j0 < SLOTS; j0 += kChunk) {
+#pragma unroll
+      for (int j = j0; j < j0 + kChunk && j < SLOTS; ++j) {
+        const double a0 = a_of(j, 0), a1 = a_of(j, 1), a2 = a_of(j, 2);
+        bv[j][0] = ld(pb0, j); bv[j][1] = ld(pb1, j); bv[j][2] = ld(pb2, j);
+        const bool inb = (j < SLOTS - 1 || (uint32_t)(j * kWaves + wave) < n_blocks) && index_of(j) < A.n_ind;
+        bool ok = inb;
+        if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(bv[j][0], bv[j][1], bv[j][2]);
+        vbits |= (ok ? 1u : 0u) << j;
+        x += (uint32_t)__popcll(__ballot(ok));
+        const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;
+        const double c2 = inb ? fma(2.0, bv[j][2], bv[j][1]) - mean2 : 0.0;
+        sxy = fma(c1, c2, sxy);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    sxy = wave_sum1(sxy);
+    if (lane == 0) {
+      xch0[wave][0] = sxy;
+      xch0[wave][1] = (double)x;
+    }
+    __syncthreads();
+    sxy = 0.0;
+    double xs = 0.0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      sxy += xch0[w][0];
+      xs += xch0[w][1];
+    }
+    x = (uint32_t)xs;
+    __syncthreads();
+
+    // ---- haplo_freq (gen_func.cpp:1027-1059) ----
+    double f0 = (1 - m1) * (1 - m2), f1 = (1 - m1) * m2, f2 = m1 * (1 - m2), f3 = m1 * m2;
+    if (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1) {
+      if (threadIdx.x == 0) atomicExch(A.status, (int)NGSLD_ERR_MAF_RANGE);
+      f0 = f1 = f2 = f3 = __builtin_nan("");
+    }
+    const double inv_x = 1.0 / (double)x;
+    bool bad = false, tie = false;
+    uint32_t n_iter = 0;
+    // The row vector's values arrive one chunk of slots ahead of the arithmetic: chunk k + 1 is requested before chunk k is
+    // worked on -- and chunk 0 of the NEXT iteration (the same values: a does not change) before this iteration's sums meet,
+    // so that its round trip to L2 runs beside the reduction and the exchange instead of in front of the next step.
+    double av[2][kChunk][3];
+    auto fetch = [&](int k) {
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        const int j = k * kChunk + u;
+        if (j < SLOTS) {
+          av[k & 1][u][0] = a_of(j, 0); av[k & 1][u][1] = a_of(j, 1); av[k & 1][u][2] = a_of(j, 2);
+        }
+      }
+    };
+    fetch(0);
+    for (; n_iter < (uint32_t)kIterMax; ++n_iter) {
+      const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
+      const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
+      const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;
+      double R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0, R5 = 0, R6 = 0, R7 = 0, R8 = 0;
+      // An individual that does not count -- padding, no data -- takes part with r = 0 instead of being branched around, as
+      // in the streaming kernel.
+      hide_offsets();
+#pragma unroll
+      for (int k = 0; k < kChunks; ++k) {
+        if (k + 1 < kChunks) fetch(k + 1);
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+          const int j = k * kChunk + u;
+          if (j < SLOTS) {
+            const double a0 = av[k & 1][u][0], a1 = av[k & 1][u][1], a2 = av[k & 1][u][2];
+            const double b0 = bv[j][0], b1 = bv[j][1], b2 = bv[j][2];
+            const double v0 = fma(p11, b2, fma(w1, b1, p00 * b0));  // sum_g2 W[0][g2] b[g2]
+            const double v1 = fma(w5, b2, fma(w4, b1, w3 * b0));
+            const double v2 = fma(p33, b2, fma(w7, b1, p22 * b0));
+            const double s = fma(a2, v2, fma(a1, v1, a0 * v0));
+            const double r = ((vbits >> j) & 1u) ? rcp_refined(s) : 0.0;
+            const double r0 = r * a0, r1 = r * a1, r2 = r * a2;
+            R0 = fma(r0, b0, R0); R1 = fma(r0, b1, R1); R2 = fma(r0, b2, R2);
+            R3 = fma(r1, b0, R3); R4 = fma(r1, b1, R4); R5 = fma(r1, b2, R5);
+            R6 = fma(r2, b0, R6); R7 = fma(r2, b1, R7); R8 = fma(r2, b2, R8);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      fetch(0);  // for the next iteration (dropped if this one converges)
+      __builtin_amdgcn_sched_barrier(0);
+      double t0 = fma(p03, R4, fma(p02, R3, fma(p01, R1, p00 * R0)));
+      double t1 = fma(p13, R5, fma(p12, R4, fma(p11, R2, p01 * R1)));
+      double t2 = fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3)));
+      double t3 = fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4)));
+      wave_sum4(t0, t1, t2, t3);
+      const int par = (int)(n_iter & 1u);
+      if (lane == 0) {
+        xch[par][wave][0] = t0; xch[par][wave][1] = t1; xch[par][wave][2] = t2; xch[par][wave][3] = t3;
+      }
+      lds_barrier();  // (LDS traffic only: the prefetch stays in flight)
+      t0 = t1 = t2 = t3 = 0.0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) {  // the same order in every wavefront: they leave the loop together
+        t0 += xch[par][w][0]; t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
+      }
+      const double n0 = t0 * inv_x, n1 = t1 * inv_x, n2 = t2 * inv_x, n3 = t3 * inv_x;
+      const double sn = (n0 + n1) + (n2 + n3);
+      if (__builtin_amdgcn_readfirstlane((int)!(sn < 2.0))) {  // the reference's all-NaN step (see em_pair)
+        bad = true;
+        break;
+      }
+      const double eps = fmax(fmax(fabs(n0 - f0), fabs(n1 - f1)), fmax(fabs(n2 - f2), fabs(n3 - f3)));
+      f0 = n0; f1 = n1; f2 = n2; f3 = n3;
+      if (fabs(eps - kEpsilon) < kTieMargin) tie = true;
+      if (__builtin_amdgcn_readfirstlane((int)(eps < kEpsilon))) break;
+    }
+    if (bad) f0 = f1 = f2 = f3 = __builtin_nan("");
+    if (threadIdx.x == 0)
+      write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull)), f0, f1, f2, f3, sxy, rsx1, rsx2, x,
+                 n_iter | (tie ? kTieBit : 0u));
+  }
+}
+constexpr int kBresMinSlots = 11, kBresMaxSlots = 20;  // 8 wavefronts x 64 lanes x 11..20 blocks: 5,121 .. 10,240 individuals
+
 // host-callable launchers, defined in ld_pair_w1.hip / ld_pair_wn.hip
 // Kernel families (pair_config picks by cohort size, by measurement: profiles/r03/sweep_513_1024.txt):
 //   kGroup  8 / 16 / 32 lanes per pair, several pairs per wavefront in lockstep (n_ind <= 128, some shapes up to 224)
@@ -1695,6 +1883,8 @@ inline void multi_shape(const PairConfig &cfg, bool masked, int *slots, int *wav
 hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs &args, hipStream_t stream);
 hipError_t launch_pair_hard(bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_hard.hip
 hipError_t launch_pair_ab(int slots, bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_ab.hip
+hipError_t launch_pair_bres(int slots, bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_stream.hip
+int bres_slots(uint32_t np);  // blocks per wavefront of that kernel for planes of np individuals, 0: the plain streaming kernel
 // Per-site classification behind kHard (ld_pair_hard.hip): masks / u as in PairArgs; *all_hard (device int, preset to 1) is
 // cleared when any triple is neither a called genotype (1,0,0) / (0,1,0) / (0,0,1) nor three equal values
 hipError_t launch_classify_hard(const double *planes, uint64_t site_stride, uint32_t np, uint32_t n_ind, uint64_t n_sites,

@@ -1,0 +1,49 @@
+// ld_pair_stream.hip -- instantiations and launcher of the streaming kernel with the candidate's vector resident
+// (pair_ld_bres_kernel, ld_device.h): 5,121 .. 10,240 individuals, eight wavefronts per pair, 11 .. 20 blocks of 64
+// individuals per wavefront.  NGSLD_STREAM_RESIDENT=0 keeps the plain streaming kernel (tests, A/B).
+#include <cstdlib>
+#include <cstring>
+
+#include "ld_device.h"
+
+namespace ngsld {
+
+template <int SLOTS>
+static hipError_t launch_bres_s(bool masked, const PairArgs &a, hipStream_t stream) {
+  if (masked)
+    hipLaunchKernelGGL((pair_ld_bres_kernel<SLOTS, true>), dim3((unsigned)a.n_items), dim3(512), 0, stream, a);
+  else
+    hipLaunchKernelGGL((pair_ld_bres_kernel<SLOTS, false>), dim3((unsigned)a.n_items), dim3(512), 0, stream, a);
+  return hipGetLastError();
+}
+
+// slots per wavefront the planes ask for, or 0 if this kernel does not take them
+int bres_slots(uint32_t np) {
+  static const bool off = [] {
+    const char *e = std::getenv("NGSLD_STREAM_RESIDENT");
+    return e != nullptr && std::strcmp(e, "0") == 0;
+  }();
+  const uint32_t n_blocks = np / 64u;
+  const int slots = (int)((n_blocks + 7u) / 8u);
+  return (!off && np % 64u == 0 && slots >= kBresMinSlots && slots <= kBresMaxSlots) ? slots : 0;
+}
+
+hipError_t launch_pair_bres(int slots, bool masked, const PairArgs &a, hipStream_t stream) {
+  if (a.n_items == 0) return hipSuccess;
+  if (a.n_items > 0x7fffffffull) return hipErrorInvalidValue;
+  switch (slots) {
+    case 11: return launch_bres_s<11>(masked, a, stream);
+    case 12: return launch_bres_s<12>(masked, a, stream);
+    case 13: return launch_bres_s<13>(masked, a, stream);
+    case 14: return launch_bres_s<14>(masked, a, stream);
+    case 15: return launch_bres_s<15>(masked, a, stream);
+    case 16: return launch_bres_s<16>(masked, a, stream);
+    case 17: return launch_bres_s<17>(masked, a, stream);
+    case 18: return launch_bres_s<18>(masked, a, stream);
+    case 19: return launch_bres_s<19>(masked, a, stream);
+    case 20: return launch_bres_s<20>(masked, a, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace ngsld

@@ -198,6 +198,7 @@ static hipError_t launch_pair_chunk(const PairConfig &cfg, bool masked, const Pa
   if (cfg.kernel == kStream) {
     if (a.n_items == 0) return hipSuccess;
     if (a.n_items > 0x7fffffffull) return hipErrorInvalidValue;
+    if (const int slots = bres_slots(a.np)) return launch_pair_bres(slots, masked, a, stream);  // up to 10,240 individuals
     if (masked)
       hipLaunchKernelGGL((pair_ld_stream_kernel<true>), dim3((unsigned)a.n_items), dim3(256), 0, stream, a);
     else

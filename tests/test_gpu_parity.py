@@ -215,9 +215,14 @@ def test_long_rows_and_many_items(engine):
 
 
 @pytest.mark.parametrize("n_sites,n_ind,seed,ignore", [(6, 5121, 301, False), (5, 6000, 302, True), (5, 6000, 304, False),
-                                                       (4, 9001, 303, False), (4, 10000, 305, True), (4, 10000, 306, False)])
+                                                       (4, 9001, 303, False), (4, 10000, 305, True), (4, 10000, 306, False),
+                                                       (5, 5633, 307, True), (4, 7000, 308, False), (4, 7681, 309, True),
+                                                       (4, 8200, 310, False), (3, 10240, 311, False), (3, 10241, 312, False),
+                                                       (3, 10300, 313, True), (3, 12000, 314, False)])
 def test_streaming_kernel_large_cohorts(engine, n_sites, n_ind, seed, ignore):
-    """n_ind > 5120: the streaming kernel (site vectors re-read every EM iteration)."""
+    """n_ind > 5120: the streaming kernels -- up to 10,240 individuals the candidate's vector stays in registers and every EM
+    iteration re-reads the row vector only (11 .. 20 blocks of 64 individuals per wavefront: 5,121 / 5,633 / ... / 10,240 sit
+    on block-count borders), beyond that both site vectors are re-read."""
     raw = synth.make_gl_numpy(n_sites, n_ind, seed, depth=8.0)
     engine.set_geno_raw(raw[:2], ignore_miss_data=ignore)
     assert engine.pair_kernel() == "stream"
