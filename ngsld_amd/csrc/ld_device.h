@@ -1520,7 +1520,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_group_kernel(PairArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Streaming kernel (n_ind > 5,120): no limit on the number of individuals.  One 256-thread workgroup per pair at a
+// Streaming kernel (n_ind > 10,240; 5,121 .. 10,240 go to pair_ld_bres_kernel below): no limit on the number of individuals.  One 256-thread workgroup per pair at a
 // time; wavefront w takes the 64-individual blocks w, w+4, w+8, ...  P does not fit in registers any more, so
 // every EM iteration re-reads both site vectors (from L2: a pair's two vectors are 48*n_ind bytes) and forms
 //   s = sum_g1 a[g1] * (sum_g2 W[g1][g2] b[g2]),   R[g1][g2] += (r a[g1]) * b[g2]

@@ -15,6 +15,8 @@ template __global__ void ngsld::pair_ld_group_kernel<8,3,false>(ngsld::PairArgs)
 template __global__ void ngsld::pair_ld_group_kernel<16,7,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_group_kernel<32,7,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_stream_kernel<false>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_bres_kernel<12,false>(ngsld::PairArgs);
+template __global__ void ngsld::pair_ld_bres_kernel<20,false>(ngsld::PairArgs);
 EOT
 # the multi-wavefront kernels are built with the scheduler ld_pair_wn.hip is built with (csrc/Makefile: FLAGS_ld_pair_wn)
 cat > $T/kw.hip <<EOT

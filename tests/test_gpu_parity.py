@@ -231,6 +231,28 @@ def test_streaming_kernel_large_cohorts(engine, n_sites, n_ind, seed, ignore):
     check_against_oracle(engine, raw, ignore_miss=ignore)
 
 
+def test_streaming_kernel_with_vanishing_weights(engine):
+    """Four individuals of one lane (0, 512, 1024, 1536: blocks 0 / 8 / 16 / 24 are the first four slots of wavefront 0) are
+    certain alt/alt homozygotes at every site while the caller's maf says 1e-45: their s is f3^2 = 1e-180 in the first
+    iteration.  Each has a reciprocal; their PRODUCT has none -- a step that shared one reciprocal among the slots of a
+    lane (measured for this kernel and not kept: profiles/r03/sweep_bres_tree.txt) would end as the reference's all-NaN
+    step here, the reference itself does not."""
+    n_sites, n_ind = 4, 6000
+    raw = synth.make_gl_numpy(n_sites, n_ind, 321, depth=8.0)
+    raw[:, [0, 512, 1024, 1536], :] = [0.0, 0.0, 1.0]
+    o = orc.Oracle(raw, None, n_threads=4)
+    o.maf[:] = 1e-45
+    rec = o.run()
+    assert np.isfinite(rec["hap"]).all() and (rec["n_iter"] > 1).all()
+    engine.set_geno_lkl(o.gl, o.maf)
+    assert engine.pair_kernel() == "stream"
+    engine.set_pos_dist(None)
+    assert engine.plan(0, 0, 0.0, False, True, 1.0, 0) == len(rec)
+    s1, s2, std, ext = engine.run()
+    assert np.array_equal(s1, rec["s1"]) and np.array_equal(s2, rec["s2"])
+    check_records(std, ext, rec)
+
+
 def test_api_error_paths(engine):
     from ngsld_amd import capi
     raw = synth.make_gl_numpy(8, 10, 401, depth=4.0)
