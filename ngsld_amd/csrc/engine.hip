@@ -774,8 +774,10 @@ int ngsld_create(int device, ngsld_ctx **out) {
   c->device = device;
   if (const char *k = std::getenv("NGSLD_PAIR_KERNEL")) {
     // "multi": several wavefronts per pair from 513 individuals on; "ab": 513..1024 individuals on ONE wavefront per pair, EM
-    // step in its a/b form (pair_config picks between them, and the ten-slot run kernel, by measurement)
-    c->kernel_choice = std::strcmp(k, "multi") == 0 ? kChooseMulti : (std::strcmp(k, "ab") == 0 ? kChooseAB : kChooseAuto);
+    // step in its a/b form (pair_config picks between them, and the ten-slot run kernel, by measurement); "stream": beyond
+    // 5,120 individuals the plain streaming kernel instead of the one that keeps the candidate's vector in registers
+    c->kernel_choice = std::strcmp(k, "multi") == 0 ? kChooseMulti
+                       : (std::strcmp(k, "ab") == 0 ? kChooseAB : (std::strcmp(k, "stream") == 0 ? kChoosePlainStream : kChooseAuto));
   }
   if (const char *k = std::getenv("NGSLD_BATCH_PAIRS")) {  // tests: many small batches through ngsld_run
     const uint64_t v = std::strtoull(k, nullptr, 10);

@@ -1665,7 +1665,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_stream_kernel(PairArgs A) {
 // load instructions, and the step itself is the streaming kernel's (same four-value form, one reciprocal per individual).
 // One workgroup per item of 16 candidates, as there.
 // ---------------------------------------------------------------------------------------------
-template <int SLOTS, bool MASKED>
+template <int SLOTS, bool MASKED, bool TAIL = false>
 __global__ __launch_bounds__(512, 2) void pair_ld_bres_kernel(PairArgs A) {
   constexpr int kWaves = 8;
   constexpr int kChunk = SLOTS <= 14 ? 4 : (SLOTS <= 17 ? 3 : 2), kChunks = (SLOTS + kChunk - 1) / kChunk;  // slots whose row values travel together
@@ -1685,13 +1685,16 @@ __global__ __launch_bounds__(512, 2) void pair_ld_bres_kernel(PairArgs A) {
   // 64-bit VGPR address per load of the unrolled loops)
   const double *pa = A.planes + (uint64_t)s1 * A.site_stride;
   gdouble_t *pa0 = (gdouble_t *)uniform_ptr(pa), *pa1 = (gdouble_t *)uniform_ptr(pa + np), *pa2 = (gdouble_t *)uniform_ptr(pa + 2 * np);
-  const uint32_t n_blocks = np / 64;  // (> 8 * (SLOTS - 1): the launcher picked SLOTS = ceil(n_blocks / 8))
+  const uint32_t n_blocks = np / 64;  // (> 8 * (SLOTS - 1): the launcher picked SLOTS = ceil(n_blocks / 8); TAIL: > 8 * SLOTS)
   // slot j of this wavefront is block j * 8 + wave; only the last slot can lie beyond the planes (then it re-reads slot 0's
   // block and counts for nothing)
   auto index_of = [&](int j) -> uint32_t {
     const uint32_t blk = (uint32_t)(j * kWaves + wave);
-    return ((j < SLOTS - 1 || blk < n_blocks) ? blk : (uint32_t)wave) * 64u + (uint32_t)lane;
+    return ((TAIL || j < SLOTS - 1 || blk < n_blocks) ? blk : (uint32_t)wave) * 64u + (uint32_t)lane;
   };
+  // TAIL (more than 10,240 individuals): the blocks beyond the 8 * SLOTS resident ones are streamed as in the plain kernel --
+  // both vectors from memory in every iteration, two blocks per trip, after the resident slots (a fixed order of additions)
+  constexpr uint32_t kTail0 = (uint32_t)(SLOTS * kWaves);
   // Every load below is SGPR base + 32-bit byte offset of the slot (one VGPR per slot, shared by the six planes).  The offsets
   // never change, and that is what has to be hidden from the compiler: loop-invariant code motion otherwise forms each load's
   // 64-bit address once, in front of the loops, where nothing folds it into the addressing mode any more -- 6 * SLOTS
@@ -1728,7 +1731,7 @@ __global__ __launch_bounds__(512, 2) void pair_ld_bres_kernel(PairArgs A) {
       for (int j = j0; j < j0 + kChunk && j < SLOTS; ++j) {
         const double a0 = a_of(j, 0), a1 = a_of(j, 1), a2 = a_of(j, 2);
         bv[j][0] = ld(pb0, j); bv[j][1] = ld(pb1, j); bv[j][2] = ld(pb2, j);
-        const bool inb = (j < SLOTS - 1 || (uint32_t)(j * kWaves + wave) < n_blocks) && index_of(j) < A.n_ind;
+        const bool inb = TAIL || ((j < SLOTS - 1 || (uint32_t)(j * kWaves + wave) < n_blocks) && index_of(j) < A.n_ind);
         bool ok = inb;
         if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(bv[j][0], bv[j][1], bv[j][2]);
         vbits |= (ok ? 1u : 0u) << j;
@@ -1738,6 +1741,19 @@ __global__ __launch_bounds__(512, 2) void pair_ld_bres_kernel(PairArgs A) {
         sxy = fma(c1, c2, sxy);
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if (TAIL) {
+      for (uint32_t blk = kTail0 + (uint32_t)wave; blk < n_blocks; blk += (uint32_t)kWaves) {
+        const uint32_t i = blk * 64u + (uint32_t)lane;
+        const double a0 = pa0[i], a1 = pa1[i], a2 = pa2[i], b0 = pb0[i], b1 = pb1[i], b2 = pb2[i];
+        const bool inb = i < A.n_ind;
+        bool ok = inb;
+        if (MASKED) ok = inb && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);
+        x += (uint32_t)__popcll(__ballot(ok));
+        const double c1 = inb ? fma(2.0, a2, a1) - mean1 : 0.0;
+        const double c2 = inb ? fma(2.0, b2, b1) - mean2 : 0.0;
+        sxy = fma(c1, c2, sxy);
+      }
     }
     sxy = wave_sum1(sxy);
     if (lane == 0) {
@@ -1799,7 +1815,9 @@ __global__ __launch_bounds__(512, 2) void pair_ld_bres_kernel(PairArgs A) {
             const double v1 = fma(w5, b2, fma(w4, b1, w3 * b0));
             const double v2 = fma(p33, b2, fma(w7, b1, p22 * b0));
             const double s = fma(a2, v2, fma(a1, v1, a0 * v0));
-            const double r = ((vbits >> j) & 1u) ? rcp_refined(s) : 0.0;
+            // (every individual counts: the cohort ends inside the LAST slot -- block (n_ind - 1) / 64 is slot SLOTS - 1 of its
+            // wavefront, the planes being padded to the next 64 -- or, TAIL, beyond the resident slots: no select before it)
+            const double r = ((!MASKED && (TAIL || j < SLOTS - 1)) || ((vbits >> j) & 1u)) ? rcp_refined(s) : 0.0;
             const double r0 = r * a0, r1 = r * a1, r2 = r * a2;
             R0 = fma(r0, b0, R0); R1 = fma(r0, b1, R1); R2 = fma(r0, b2, R2);
             R3 = fma(r1, b0, R3); R4 = fma(r1, b1, R4); R5 = fma(r1, b2, R5);
@@ -1807,6 +1825,35 @@ __global__ __launch_bounds__(512, 2) void pair_ld_bres_kernel(PairArgs A) {
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+      }
+      if (TAIL) {
+        for (uint32_t bq = kTail0 + (uint32_t)wave; bq < n_blocks; bq += 2u * (uint32_t)kWaves) {
+          double ta[2][3], tb[2][3];
+          bool okv[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const uint32_t blk = bq + (uint32_t)(u * kWaves);
+            const bool in = blk < n_blocks;
+            const uint32_t i = (in ? blk : bq) * 64u + (uint32_t)lane;
+            ta[u][0] = pa0[i]; ta[u][1] = pa1[i]; ta[u][2] = pa2[i];
+            tb[u][0] = pb0[i]; tb[u][1] = pb1[i]; tb[u][2] = pb2[i];
+            okv[u] = in && i < A.n_ind;
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const double a0 = ta[u][0], a1 = ta[u][1], a2 = ta[u][2], b0 = tb[u][0], b1 = tb[u][1], b2 = tb[u][2];
+            bool ok = okv[u];
+            if (MASKED) ok = ok && !miss_data(a0, a1, a2) && !miss_data(b0, b1, b2);
+            const double v0 = fma(p11, b2, fma(w1, b1, p00 * b0));
+            const double v1 = fma(w5, b2, fma(w4, b1, w3 * b0));
+            const double v2 = fma(p33, b2, fma(w7, b1, p22 * b0));
+            const double r = ok ? rcp_refined(fma(a2, v2, fma(a1, v1, a0 * v0))) : 0.0;
+            const double r0 = r * a0, r1 = r * a1, r2 = r * a2;
+            R0 = fma(r0, b0, R0); R1 = fma(r0, b1, R1); R2 = fma(r0, b2, R2);
+            R3 = fma(r1, b0, R3); R4 = fma(r1, b1, R4); R5 = fma(r1, b2, R5);
+            R6 = fma(r2, b0, R6); R7 = fma(r2, b1, R7); R8 = fma(r2, b2, R8);
+          }
+        }
       }
       fetch(0);  // for the next iteration (dropped if this one converges)
       __builtin_amdgcn_sched_barrier(0);
@@ -1843,6 +1890,7 @@ __global__ __launch_bounds__(512, 2) void pair_ld_bres_kernel(PairArgs A) {
   }
 }
 constexpr int kBresMinSlots = 11, kBresMaxSlots = 20;  // 8 wavefronts x 64 lanes x 11..20 blocks: 5,121 .. 10,240 individuals
+constexpr int kBresTailSlots = 20;                      // beyond: 20 blocks per wavefront resident (10,240 individuals), the rest streamed
 
 // host-callable launchers, defined in ld_pair_w1.hip / ld_pair_wn.hip
 // Kernel families (pair_config picks by cohort size, by measurement: profiles/r03/sweep_513_1024.txt):
@@ -1850,12 +1898,14 @@ constexpr int kBresMinSlots = 11, kBresMaxSlots = 20;  // 8 wavefronts x 64 lane
 //   kRun    one wavefront per pair, the row vector shared in LDS, runs of items (n_ind <= 640: up to TEN individuals per lane)
 //   kRunAB  one wavefront per pair, EM step in its a/b form, run pipeline (ld_pair_ab.hip: 641..960)
 //   kMulti  2 / 4 / 8 wavefronts per pair (961..5120)
-//   kStream any n_ind, vectors re-read every iteration
+//   kStream any n_ind: the candidate's vector (its first 9,216 individuals beyond 10,240) in registers, the row vector -- or,
+//           with cfg.waves == 4 (NGSLD_PAIR_KERNEL=stream), both -- re-read every iteration
 //   kHard   every likelihood triple of the matrix is a called genotype or "no data": the pairs' 16 genotype-combination
 //           counts replace the individuals (any n_ind up to kHardMaxInd)
 enum PairKernel { kGroup = 0, kMulti = 2, kStream = 4, kRun = 5, kHard = 6, kRunAB = 7 };
-// NGSLD_PAIR_KERNEL=multi | ab (tests, A/B): the multi-wavefront kernel from 513 individuals on / the a/b kernel for 513..1024
-enum PairChoice { kChooseAuto = 0, kChooseMulti = 1, kChooseAB = 2 };
+// NGSLD_PAIR_KERNEL=multi | ab | stream (tests, A/B): the multi-wavefront kernel from 513 individuals on / the a/b kernel for
+// 513..1024 / the plain streaming kernel (nothing resident) beyond 5,120
+enum PairChoice { kChooseAuto = 0, kChooseMulti = 1, kChooseAB = 2, kChoosePlainStream = 3 };
 // kernels launched over runs of items (one workgroup per run, candidates addressed as 64 * item + offset)
 inline bool uses_runs(int kernel) { return kernel == kRun || kernel == kGroup || kernel == kHard || kernel == kRunAB; }
 constexpr uint32_t kHardMaxWords = 512;                 // row bit sets in LDS: 4 x 512 x 8 B = 16 KB
@@ -1884,7 +1934,6 @@ hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs
 hipError_t launch_pair_hard(bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_hard.hip
 hipError_t launch_pair_ab(int slots, bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_ab.hip
 hipError_t launch_pair_bres(int slots, bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_stream.hip
-int bres_slots(uint32_t np);  // blocks per wavefront of that kernel for planes of np individuals, 0: the plain streaming kernel
 // Per-site classification behind kHard (ld_pair_hard.hip): masks / u as in PairArgs; *all_hard (device int, preset to 1) is
 // cleared when any triple is neither a called genotype (1,0,0) / (0,1,0) / (0,0,1) nor three equal values
 hipError_t launch_classify_hard(const double *planes, uint64_t site_stride, uint32_t np, uint32_t n_ind, uint64_t n_sites,

@@ -1,6 +1,7 @@
 // ld_pair_stream.hip -- instantiations and launcher of the streaming kernel with the candidate's vector resident
 // (pair_ld_bres_kernel, ld_device.h): 5,121 .. 10,240 individuals, eight wavefronts per pair, 11 .. 20 blocks of 64
-// individuals per wavefront.  NGSLD_STREAM_RESIDENT=0 keeps the plain streaming kernel (tests, A/B).
+// individuals per wavefront; beyond that kBresTailSlots blocks per wavefront stay resident and the rest is streamed.
+// NGSLD_PAIR_KERNEL=stream keeps the plain streaming kernel (tests, A/B).
 #include <cstdlib>
 #include <cstring>
 
@@ -17,20 +18,18 @@ static hipError_t launch_bres_s(bool masked, const PairArgs &a, hipStream_t stre
   return hipGetLastError();
 }
 
-// slots per wavefront the planes ask for, or 0 if this kernel does not take them
-int bres_slots(uint32_t np) {
-  static const bool off = [] {
-    const char *e = std::getenv("NGSLD_STREAM_RESIDENT");
-    return e != nullptr && std::strcmp(e, "0") == 0;
-  }();
-  const uint32_t n_blocks = np / 64u;
-  const int slots = (int)((n_blocks + 7u) / 8u);
-  return (!off && np % 64u == 0 && slots >= kBresMinSlots && slots <= kBresMaxSlots) ? slots : 0;
-}
-
 hipError_t launch_pair_bres(int slots, bool masked, const PairArgs &a, hipStream_t stream) {
   if (a.n_items == 0) return hipSuccess;
-  if (a.n_items > 0x7fffffffull) return hipErrorInvalidValue;
+  // (planes padded to the next 64 individuals and no further: the kernel relies on the cohort ending inside the last block)
+  if (a.n_items > 0x7fffffffull || a.np % 64u != 0 || a.n_ind > a.np || a.np - a.n_ind >= 64u || slots < kBresMinSlots)
+    return hipErrorInvalidValue;
+  if (slots > kBresMaxSlots) {  // more than 10,240 individuals: 8,192 of them resident, the rest streamed
+    if (masked)
+      hipLaunchKernelGGL((pair_ld_bres_kernel<kBresTailSlots, true, true>), dim3((unsigned)a.n_items), dim3(512), 0, stream, a);
+    else
+      hipLaunchKernelGGL((pair_ld_bres_kernel<kBresTailSlots, false, true>), dim3((unsigned)a.n_items), dim3(512), 0, stream, a);
+    return hipGetLastError();
+  }
   switch (slots) {
     case 11: return launch_bres_s<11>(masked, a, stream);
     case 12: return launch_bres_s<12>(masked, a, stream);

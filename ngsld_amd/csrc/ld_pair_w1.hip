@@ -21,7 +21,7 @@ bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice) {
   cfg->waves = 1;
   if (n_ind > 5120u) {  // beyond 8 wavefronts x 10 slots x 64 lanes: streaming kernel, one workgroup per pair
     cfg->kernel = kStream;
-    cfg->waves = 4;
+    cfg->waves = choice == kChoosePlainStream ? 4 : 8;  // 8: the candidate's vector resident (ld_pair_stream.hip)
     cfg->slots = 0;
     cfg->np = (uint32_t)((n_ind + 63) / 64 * 64);
     return true;
@@ -198,7 +198,7 @@ static hipError_t launch_pair_chunk(const PairConfig &cfg, bool masked, const Pa
   if (cfg.kernel == kStream) {
     if (a.n_items == 0) return hipSuccess;
     if (a.n_items > 0x7fffffffull) return hipErrorInvalidValue;
-    if (const int slots = bres_slots(a.np)) return launch_pair_bres(slots, masked, a, stream);  // up to 10,240 individuals
+    if (cfg.waves == 8) return launch_pair_bres((int)((a.np / 64u + 7u) / 8u), masked, a, stream);
     if (masked)
       hipLaunchKernelGGL((pair_ld_stream_kernel<true>), dim3((unsigned)a.n_items), dim3(256), 0, stream, a);
     else

@@ -218,17 +218,41 @@ def test_long_rows_and_many_items(engine):
                                                        (4, 9001, 303, False), (4, 10000, 305, True), (4, 10000, 306, False),
                                                        (5, 5633, 307, True), (4, 7000, 308, False), (4, 7681, 309, True),
                                                        (4, 8200, 310, False), (3, 10240, 311, False), (3, 10241, 312, False),
-                                                       (3, 10300, 313, True), (3, 12000, 314, False)])
+                                                       (3, 10300, 313, True), (3, 12000, 314, False), (3, 9217, 315, True),
+                                                       (3, 9800, 316, False), (3, 20000, 317, False), (3, 33000, 318, True)])
 def test_streaming_kernel_large_cohorts(engine, n_sites, n_ind, seed, ignore):
-    """n_ind > 5120: the streaming kernels -- up to 10,240 individuals the candidate's vector stays in registers and every EM
+    """n_ind > 5120: the streaming kernel -- up to 10,240 individuals the candidate's vector stays in registers and every EM
     iteration re-reads the row vector only (11 .. 20 blocks of 64 individuals per wavefront: 5,121 / 5,633 / ... / 10,240 sit
-    on block-count borders), beyond that both site vectors are re-read."""
+    on block-count borders); beyond that 20 blocks per wavefront (10,240 individuals) stay resident and the rest of both
+    vectors is re-read."""
     raw = synth.make_gl_numpy(n_sites, n_ind, seed, depth=8.0)
     engine.set_geno_raw(raw[:2], ignore_miss_data=ignore)
     assert engine.pair_kernel() == "stream"
     if ignore:
         raw[np.random.default_rng(seed).random((n_sites, n_ind)) < 0.05] = 1.0 / 3.0
     check_against_oracle(engine, raw, ignore_miss=ignore)
+
+
+@pytest.mark.parametrize("n_sites,n_ind,seed,ignore", [(5, 5121, 331, False), (4, 6000, 332, True), (3, 10241, 333, False),
+                                                       (3, 16000, 334, True)])
+def test_plain_streaming_kernel(n_sites, n_ind, seed, ignore):
+    """NGSLD_PAIR_KERNEL=stream: nothing resident, both site vectors re-read in every EM iteration (the kernel the resident
+    form is measured against; held to the same bars)."""
+    import os
+    from ngsld_amd import capi
+    raw = synth.make_gl_numpy(n_sites, n_ind, seed, depth=8.0)
+    if ignore:
+        raw[np.random.default_rng(seed).random((n_sites, n_ind)) < 0.05] = 1.0 / 3.0
+    os.environ["NGSLD_PAIR_KERNEL"] = "stream"
+    try:
+        eng = capi.Engine(0)
+    finally:
+        del os.environ["NGSLD_PAIR_KERNEL"]
+    try:
+        check_against_oracle(eng, raw, ignore_miss=ignore)
+        assert eng.pair_kernel() == "stream"
+    finally:
+        eng.close()
 
 
 def test_streaming_kernel_with_vanishing_weights(engine):
