@@ -24,7 +24,8 @@ FLOORS = [(513, 1.45e8),        # 1.20e8              1.82e8                  ru
           (10000, 3.9e6)]       # 2.6e6               (5.3e6, 2.3 GHz box)    the same, 20 blocks per wavefront
 KERNELS = {513: "pair_ld_run_kernel", 640: "pair_ld_run_kernel", 704: "pair_ld_ab_kernel",
            2560: "pair_ld_kernel (multi-wavefront)", 5120: "pair_ld_kernel (multi-wavefront)",
-           6000: "pair_ld_stream_kernel", 10000: "pair_ld_stream_kernel"}
+           6000: "pair_ld_bres_kernel (streaming, candidate's vector resident)",
+           10000: "pair_ld_bres_kernel (streaming, candidate's vector resident)"}
 
 
 @pytest.mark.timeout(900)
