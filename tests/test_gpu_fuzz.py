@@ -17,8 +17,11 @@ def _case(k):
         n_ind = int(rng.choice([1, 3, 15, 16, 17, 33, 64, 100, 128, 129, 200, 257, 500, 513, 777, 1100, 2100, 4100]))
     elif k < 20_000:   # round 3: the shapes that changed kernel -- nine / ten slots per lane, the a/b kernel's range, the streaming kernel's new start
         n_ind = int(rng.choice([520, 576, 600, 640, 641, 700, 832, 833, 1153, 1200, 1280, 2305, 2500, 4609, 4800, 5120, 5121]))
-    else:              # round 3, last session: the streaming kernel with the candidate's vector resident (11..20 blocks per wavefront) and the plain one beyond
+    elif k < 30_000:   # round 3, last session: the streaming kernel with the candidate's vector resident (11..20 blocks per wavefront; beyond 10,240 with a streamed tail)
         n_ind = int(rng.choice([5121, 5633, 5700, 6145, 6500, 7000, 7681, 8193, 9000, 9729, 10240, 10241, 11000]))
+    else:              # round 3: the multi-wavefront kernel's five to eight slots per lane, whose row slice sits (partly) in registers
+        n_ind = int(rng.choice([961, 1000, 1024, 1281, 1400, 1536, 1537, 1700, 1792, 1793, 2000, 2048, 2561, 2800, 3072, 3073, 3500,
+                                3584, 3585, 4000, 4096]))
     n_sites = int(rng.integers(3, 60 if n_ind <= 600 else (14 if n_ind <= 5121 else 7)))
     depth = float(rng.choice([0.5, 1.0, 2.0, 5.0, 10.0, 30.0]))
     raw = synth.make_gl_numpy(n_sites, n_ind, 5000 + k, depth=depth)
@@ -63,7 +66,7 @@ def pick_min_maf(maf: np.ndarray, k: int) -> float:
     return float(np.round(np.nanquantile(maf[ok], 0.3), 3))
 
 
-@pytest.mark.parametrize("k", list(range(240)) + REGRESSION_SEEDS + list(range(10_000, 10_060)) + list(range(20_000, 20_030)))
+@pytest.mark.parametrize("k", list(range(240)) + REGRESSION_SEEDS + list(range(10_000, 10_060)) + list(range(20_000, 20_030)) + list(range(30_000, 30_040)))
 def test_random_configuration(engine, k):
     raw, pd, kw, call = _case(k)
     o0 = orc.Oracle(raw, pd, log_scale=kw["log_scale"], call_geno=call)
