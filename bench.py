@@ -484,7 +484,7 @@ def main():
                                     "HBM utilisation: the row vector is shared through LDS and the window is re-read from L2 / "
                                     "Infinity Cache (`traffic`); the binding roofline is fp64_valu",
                          "kernel": {"group": "pair_ld_group_kernel", "run": "pair_ld_run_kernel", "ab": "pair_ld_ab_kernel",
-                                    "multi": "pair_ld_kernel (multi-wavefront)",
+                                    "multi": "pair_ld_kernel (multi-wavefront)", "multi-ab": "pair_ld_abm_kernel (multi-wavefront, a/b form)",
                                     "stream": "pair_ld_stream_kernel" if os.environ.get("NGSLD_PAIR_KERNEL") == "stream"
                                     else "pair_ld_bres_kernel (streaming, candidate's vector resident)",
                                     "hard": "pair_ld_hard_kernel (genotype-combination counts)"}.get(family, family),

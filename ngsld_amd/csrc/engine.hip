@@ -253,7 +253,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   if (normalised && maf == nullptr) return fail(c, NGSLD_ERR_INVALID, "maf missing");
   if (n_sites >= 0xffffffffull) return fail(c, NGSLD_ERR_UNSUPPORTED, "n_sites must be below 2^32 - 1");
   PairConfig cfg;
-  if (!pair_config(n_ind, &cfg, c->kernel_choice))
+  if (!pair_config(n_ind, &cfg, c->kernel_choice, ignore_miss != 0))
     return fail(c, NGSLD_ERR_UNSUPPORTED, "n_ind is outside the supported range");
   HIP_TRY(c, hipSetDevice(c->device));
   (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
@@ -777,7 +777,9 @@ int ngsld_create(int device, ngsld_ctx **out) {
     // step in its a/b form (pair_config picks between them, and the ten-slot run kernel, by measurement); "stream": beyond
     // 5,120 individuals the plain streaming kernel instead of the one that keeps the candidate's vector in registers
     c->kernel_choice = std::strcmp(k, "multi") == 0 ? kChooseMulti
-                       : (std::strcmp(k, "ab") == 0 ? kChooseAB : (std::strcmp(k, "stream") == 0 ? kChoosePlainStream : kChooseAuto));
+                       : (std::strcmp(k, "ab") == 0 ? kChooseAB
+                          : (std::strcmp(k, "stream") == 0 ? kChoosePlainStream : (std::strcmp(k, "abm") == 0 ? kChooseABMulti
+                                                               : (std::strcmp(k, "bres") == 0 ? kChooseResidentStream : kChooseAuto))));
   }
   if (const char *k = std::getenv("NGSLD_BATCH_PAIRS")) {  // tests: many small batches through ngsld_run
     const uint64_t v = std::strtoull(k, nullptr, 10);
@@ -1428,7 +1430,7 @@ const char *ngsld_pair_kernel(const ngsld_ctx *c) {
   if (c == nullptr || !c->have_geno) return "";
   switch (effective_kernel(c->cfg, c->params.ignore_miss_data != 0)) {
     case kGroup: return "group";
-    case kMulti: return "multi";
+    case kMulti: return c->cfg.form == 1 ? "multi-ab" : "multi";
     case kStream: return "stream";
     case kRun: return "run";
     case kHard: return "hard";
@@ -1506,8 +1508,11 @@ int ngsld_window_ends(const double *pos_dist, uint64_t n_sites, const ngsld_para
 } NGSLD_CATCH((ngsld_ctx *)nullptr)
 
 uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes) {
-  PairConfig cfg;
-  if (!pair_config(n_ind, &cfg)) return 0;  // (the engine's own default selection: the slabs hold what it will allocate)
+  PairConfig cfg, cfg_masked;
+  // (the engine's own default selection: the slabs hold what it will allocate -- the wider of the two layouts a cohort size
+  // can get, with and without --ignore_miss_data)
+  if (!pair_config(n_ind, &cfg) || !pair_config(n_ind, &cfg_masked, kChooseAuto, true)) return 0;
+  if (cfg_masked.np > cfg.np) cfg.np = cfg_masked.np;
   // per context: planes (24*np per site) + maf/mean/rsx + row tables (~64 B per site), two record slots of
   // batch_pairs records, two staging chunks of 256 MiB, items; the fixed part is rounded up generously
   const uint64_t fixed = (2ull * (1ull << 23) * (sizeof(ngsld_rec_std) + sizeof(ngsld_rec_ext))) + (768ull << 20);

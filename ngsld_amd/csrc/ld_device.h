@@ -1904,8 +1904,9 @@ constexpr int kBresTailSlots = 20;                      // beyond: 20 blocks per
 //           counts replace the individuals (any n_ind up to kHardMaxInd)
 enum PairKernel { kGroup = 0, kMulti = 2, kStream = 4, kRun = 5, kHard = 6, kRunAB = 7 };
 // NGSLD_PAIR_KERNEL=multi | ab | stream (tests, A/B): the multi-wavefront kernel from 513 individuals on / the a/b kernel for
-// 513..1024 / the plain streaming kernel (nothing resident) beyond 5,120
-enum PairChoice { kChooseAuto = 0, kChooseMulti = 1, kChooseAB = 2, kChoosePlainStream = 3 };
+// 513..1024 / the plain streaming kernel (nothing resident) beyond 5,120; abm | bres: several wavefronts per pair in the a/b
+// form wherever it has a shape / never (P form up to 5,120, the streaming kernel with the candidate's vector resident beyond)
+enum PairChoice { kChooseAuto = 0, kChooseMulti = 1, kChooseAB = 2, kChoosePlainStream = 3, kChooseABMulti = 4, kChooseResidentStream = 5 };
 // kernels launched over runs of items (one workgroup per run, candidates addressed as 64 * item + offset)
 inline bool uses_runs(int kernel) { return kernel == kRun || kernel == kGroup || kernel == kHard || kernel == kRunAB; }
 constexpr uint32_t kHardMaxWords = 512;                 // row bit sets in LDS: 4 x 512 x 8 B = 16 KB
@@ -1915,9 +1916,10 @@ struct PairConfig {
   int group;    // kGroup: lanes per pair (8, 16 or 32); 64 otherwise
   int slots;    // individuals per lane
   int waves;    // wavefronts per pair
+  int form;     // kMulti: 0 = P form (pair_ld_kernel), 1 = a/b form (pair_ld_abm_kernel, ld_pair_ab.hip)
   uint32_t np;  // padded individuals per genotype plane
 };
-bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice = kChooseAuto);
+bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice = kChooseAuto, bool masked = false);
 // the kernel a launch really takes (a hook for families that differ with --ignore_miss_data; none does at present)
 inline int effective_kernel(const PairConfig &cfg, bool /*masked*/) { return cfg.kernel; }
 // ... and the shape of the multi-wavefront kernel: 2 x 10 slots (1,153..1,280 individuals) run as 4 x 5 under
@@ -1933,6 +1935,7 @@ inline void multi_shape(const PairConfig &cfg, bool masked, int *slots, int *wav
 hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs &args, hipStream_t stream);
 hipError_t launch_pair_hard(bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_hard.hip
 hipError_t launch_pair_ab(int slots, bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_ab.hip
+hipError_t launch_pair_abm(int slots, int waves, bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_ab.hip
 hipError_t launch_pair_bres(int slots, bool masked, const PairArgs &args, hipStream_t stream);  // ld_pair_stream.hip
 // Per-site classification behind kHard (ld_pair_hard.hip): masks / u as in PairArgs; *all_hard (device int, preset to 1) is
 // cleared when any triple is neither a called genotype (1,0,0) / (0,1,0) / (0,0,1) nor three equal values

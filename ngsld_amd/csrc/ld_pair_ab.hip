@@ -55,18 +55,24 @@ __device__ __forceinline__ void static_for(F &&f) {
 // individual; a pair whose hap 0 falls below kFullBelow finishes in the full four-value form.
 //   AREG: the row vector's first AREG slots of this lane sit in REGISTERS (Ar, loaded once per run: the row is the same for
 //   every pair of the run), only the slots beyond are re-read from LDS in every iteration
-template <int SLOTS, bool MASKED, int TREE, int AREG>
+//   WAVES > 1 (pair_ld_abm_kernel): several wavefronts share the pair, the whole slice of a sits in registers, and the partial
+//   sums of an iteration meet in LDS exactly as in em_pair.  Every individual counts: empty slots are GHOSTS (a = b =
+//   (1, 0, 0): s = f0^2, nothing added to R[1..8]; the steps that accumulate R[0] skip them by their validity bit).
+//   --ignore_miss_data: b = 0 and a pad of 1 read off the validity bit, so that s is exactly 1 and nothing is added to R
+template <int SLOTS, bool MASKED, int TREE, int AREG, int WAVES = 1>
 __device__ __forceinline__ uint32_t em_pair_ab(const double (&B)[SLOTS][3], const double (&Ar)[AREG > 0 ? AREG : 1][3],
                                                const double *la0, const double *la1, const double *la2, uint32_t vbits,
                                                const double *pads, double inv_x, double m1, double m2, double &f0, double &f1,
-                                               double &f2, double &f3, int lane, int *status) {
+                                               double &f2, double &f3, int lane, int *status,
+                                               double (*xch)[WAVES][4] = nullptr, int sub = 0, uint32_t *xpar = nullptr) {
+  static_assert(WAVES == 1 || AREG == SLOTS, "several wavefronts per pair: the whole slice of a in registers");
   auto a_of = [&](int j, int g) -> double {  // (j, g compile-time after unrolling)
     if (j < AREG) return Ar[j < AREG ? j : 0][g];
     return g == 0 ? la0[64 * j] : (g == 1 ? la1[64 * j] : la2[64 * j]);
   };
   f0 = (1 - m1) * (1 - m2); f1 = (1 - m1) * m2; f2 = m1 * (1 - m2); f3 = m1 * m2;  // gen_func.cpp:1034-1037
   if (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1) {  // error() in the reference (:1030); reported through status
-    if (lane == 0) atomicExch(status, (int)NGSLD_ERR_MAF_RANGE);
+    if (lane == 0 && sub == 0) atomicExch(status, (int)NGSLD_ERR_MAF_RANGE);
     f0 = f1 = f2 = f3 = __builtin_nan("");
   }
   asm("" : "+v"(inv_x));
@@ -84,7 +90,8 @@ __device__ __forceinline__ uint32_t em_pair_ab(const double (&B)[SLOTS][3], cons
       const double v0 = fma(p11, B[j][2], fma(w1, B[j][1], p00 * B[j][0]));
       const double v1 = fma(w5, B[j][2], fma(w4, B[j][1], w3 * B[j][0]));
       const double v2 = fma(p33, B[j][2], fma(w7, B[j][1], p22 * B[j][0]));
-      double s = padded ? fma(a0, v0, MASKED ? pads[j] : pad_last) : a0 * v0;
+      const double pad = WAVES > 1 ? (((vbits >> j) & 1u) ? 0.0 : 1.0) : (MASKED ? pads[j] : pad_last);
+      double s = padded ? fma(a0, v0, pad) : a0 * v0;
       s = fma(a1, v1, s);
       return fma(a2, v2, s);
     };
@@ -106,7 +113,7 @@ __device__ __forceinline__ uint32_t em_pair_ab(const double (&B)[SLOTS][3], cons
           const int j = h + t;
           if (j < SLOTS) {
             av[t][0] = a_of(j, 0); av[t][1] = a_of(j, 1); av[t][2] = a_of(j, 2);
-            sv[t] = slot_s(j, av[t][0], av[t][1], av[t][2], MASKED || j == SLOTS - 1);
+            sv[t] = slot_s(j, av[t][0], av[t][1], av[t][2], WAVES == 1 ? (MASKED || j == SLOTS - 1) : MASKED);
           } else {  // the last tree of a slot count that is no multiple of TREE: a neutral factor
             av[t][0] = av[t][1] = av[t][2] = 0.0;
             sv[t] = 1.0;
@@ -139,11 +146,51 @@ __device__ __forceinline__ uint32_t em_pair_ab(const double (&B)[SLOTS][3], cons
     double t2 = fma(p23, R7, fma(p22, R6, fma(p12, R4, p02 * R3)));
     double t3 = fma(p33, R8, fma(p23, R7, fma(p13, R5, p03 * R4)));
     if (kTree) {
-      wave_sum3(t1, t2, t3);
-      n1 = t1; n2 = t2; n3 = t3;  // already divided by x
+      if constexpr (WAVES > 1) {
+        // as em_pair: the row totals go to the exchange buffer from the lanes that hold them, every wavefront adds the
+        // partials up in the same order (the new frequencies must be the same bits in all of them)
+        const double w = wave_sum3_rows(t1, t2, t3);
+        const int par = (int)((*xpar)++ & 1u);
+        const int row = lane >> 4;
+        const uint32_t base = lds_addr(&xch[par][0][0]);  // [value k = 0..2][wavefront]
+        if ((lane & 15) == 0 && row != 1) lds_post(base + (uint32_t)((row == 0 ? 0 : row - 1) * WAVES + sub) * 8u, w);
+        lds_barrier();
+        if constexpr (WAVES == 8) {
+          double v;
+          asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(base + (uint32_t)(lane & 31) * 8u) : "memory");
+          v += dpp_mov<0xB1>(v);
+          v += dpp_mov<0x4E>(v);
+          v += dpp_mov<0x141>(v);
+          t1 = read_lane(v, 0); t2 = read_lane(v, 8); t3 = read_lane(v, 16);
+        } else {
+          constexpr int kHalf = WAVES / 2;
+          dbl2 q[3 * kHalf];
+          lds_gather<3 * kHalf>(base, q);
+          t1 = q[0][0] + q[0][1]; t2 = q[kHalf][0] + q[kHalf][1]; t3 = q[2 * kHalf][0] + q[2 * kHalf][1];
+#pragma unroll
+          for (int v = 1; v < kHalf; ++v) {
+            t1 += q[v][0]; t2 += q[kHalf + v][0]; t3 += q[2 * kHalf + v][0];
+            t1 += q[v][1]; t2 += q[kHalf + v][1]; t3 += q[2 * kHalf + v][1];
+          }
+        }
+      } else {
+        wave_sum3(t1, t2, t3);
+      }
+      n1 = t1; n2 = t2; n3 = t3;  // already divided by x (every wavefront scales its own partial sums)
       n0 = 1.0 - ((n1 + n2) + n3);
     } else {
       wave_sum4(t0, t1, t2, t3);
+      if constexpr (WAVES > 1) {  // rare: plain LDS accesses
+        const int par = (int)((*xpar)++ & 1u);
+        if (lane == 0) {
+          xch[par][sub][0] = t0; xch[par][sub][1] = t1; xch[par][sub][2] = t2; xch[par][sub][3] = t3;
+        }
+        lds_barrier();
+        t0 = t1 = t2 = t3 = 0.0;
+        for (int w = 0; w < WAVES; ++w) {
+          t0 += xch[par][w][0]; t1 += xch[par][w][1]; t2 += xch[par][w][2]; t3 += xch[par][w][3];
+        }
+      }
       n0 = t0 * inv_x; n1 = t1 * inv_x; n2 = t2 * inv_x; n3 = t3 * inv_x;
     }
   };
@@ -176,6 +223,7 @@ __device__ __forceinline__ uint32_t em_pair_ab(const double (&B)[SLOTS][3], cons
       }
       if (done || n_iter >= (uint32_t)kIterMax) break;
       if (full) continue;
+      if (WAVES > 1) lds_barrier();  // an odd step: all redo it (n1 is the same everywhere), none still reads the exchange buffer
     }
     double n0, n1, n2, n3;
     em_step(SingleTag(), n0, n1, n2, n3);
@@ -359,6 +407,195 @@ __global__ __launch_bounds__(512, 2) void pair_ld_ab_kernel(PairArgs A) {
 #define NGSLD_AB_TREE 8  // build-time A/B knob: individuals of a lane that share one reciprocal (4 or 8)
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// Several wavefronts per pair, a/b form (every individual counts; 11 .. 13 slots per lane): where the P form would need
+// twice the wavefronts -- 1,281..1,664 individuals on two, 2,561..3,328 on four, 5,121..6,656 on eight instead of four /
+// eight / the streaming kernel.  Item form as pair_ld_kernel: one workgroup per item of 64 candidates; the wavefront's slice
+// of the ROW vector sits in registers for the whole item (already relabelled), the first kAbLand slots of the next
+// candidate's slice land in LDS while the EM loop runs, the rest is read when the pair starts; empty slots are ghosts
+// (em_pair_ab); the Pearson partial sums are parked per candidate and added up when the records are written.
+// ---------------------------------------------------------------------------------------------
+template <int SLOTS, int WAVES, bool MASKED>
+__global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_abm_kernel(PairArgs A) {
+  static_assert(WAVES == 2 || WAVES == 4 || WAVES == 8, "pair_ld_abm_kernel: 2, 4 or 8 wavefronts per pair");
+  constexpr int kLand = SLOTS < kAbLand ? SLOTS : kAbLand;
+  constexpr int kLandPlane = kLand * 512;  // bytes of one genotype plane's landed slots
+  constexpr int kBuf = 3 * kLandPlane;
+  constexpr int kXchBase = WAVES * kBuf;
+  __shared__ __attribute__((aligned(16))) char smem[kXchBase + WAVES * 96 + 64 * sizeof(PairResult) + 64 * WAVES * sizeof(double)];
+  PairResult *res = reinterpret_cast<PairResult *>(smem + kXchBase + WAVES * 96);  // one per candidate
+  double (*parked)[WAVES] = reinterpret_cast<double (*)[WAVES]>(smem + kXchBase + WAVES * 96 + 64 * sizeof(PairResult));
+  double (*xch)[WAVES][4] = reinterpret_cast<double (*)[WAVES][4]>(smem + kXchBase);
+  double (*xch0)[2] = reinterpret_cast<double (*)[2]>(smem + kXchBase + WAVES * 64);
+
+  const int lane = threadIdx.x & 63;
+  const int sub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const Item *item_ptr;
+  if (A.tile_nk != 0) {  // tiled order: see pair_ld_kernel
+    const uint32_t per = A.tile_rows * 8u;
+    const uint32_t t = blockIdx.x / per, w = blockIdx.x % per;
+    const uint32_t row = A.row0 + (t / A.tile_nk) * A.tile_rows + (w >> 3);
+    const uint32_t k = (t % A.tile_nk) * 8u + ((w + t) & 7u);
+    if (row >= A.row1) return;
+    const uint64_t lo = A.item_off[row], hi = A.item_off[row + 1];
+    if ((uint64_t)k >= hi - lo) return;
+    item_ptr = A.items_all + lo + k;
+  } else {
+    if ((uint64_t)blockIdx.x >= A.n_items) return;
+    item_ptr = A.items + blockIdx.x;
+  }
+  const Item it = *item_ptr;
+  const uint32_t s1 = it.s1;
+  const double m1 = A.maf[s1];
+  const double mean1 = A.mean_e[s1];
+  const double rsx1 = A.rsx[s1];
+  const uint64_t rec0 = it.first_record - A.out_base;
+  const uint32_t np = A.np;
+  const uint32_t i0 = (uint32_t)sub * (SLOTS * 64) + (uint32_t)lane;
+  char *lds_b = smem + sub * kBuf;
+  __shared__ double site_sc[3][64];
+  if (threadIdx.x < it.count) {
+    const uint32_t s2 = it.s2_begin + threadIdx.x;
+    site_sc[0][threadIdx.x] = A.maf[s2];
+    site_sc[1][threadIdx.x] = A.mean_e[s2];
+    site_sc[2][threadIdx.x] = A.rsx[s2];
+  }
+  __syncthreads();
+
+  // the first kLand slots of this wavefront's slice of site s2 (three runs of kLandPlane bytes) -> its landing buffer
+  auto dma_land = [&](uint32_t s2) {
+    const char *g = reinterpret_cast<const char *>(A.planes + (uint64_t)s2 * A.site_stride + (uint32_t)sub * (SLOTS * 64)) + lane * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int k = 0; k < kLandPlane / 1024; ++k)
+        __builtin_amdgcn_global_load_lds((glb_void_t *)(g + (size_t)pl * np * 8 + k * 1024),
+                                         (lds_void_t *)(lds_b + pl * kLandPlane + k * 1024), 16, 0, 0);
+  };
+  auto next_kept = [&](uint32_t c) -> uint32_t {  // first computed pair at or after c (ngsLD.cpp:270-282 filters)
+    while (c < it.count && !((it.mask >> c) & 1ull)) ++c;
+    return c;
+  };
+
+  // the cohort's members among this lane's slots and the row slice, relabelled -- with every individual counting, ghosts in
+  uint32_t inbits = 0;
+  double Ar[SLOTS][3];
+  {
+    const bool flip1 = m1 > 0.5;  // (relabel())
+    const double *pa = A.planes + (uint64_t)s1 * A.site_stride;
+    typedef const __attribute__((address_space(1))) double gdouble_t;
+    gdouble_t *q0 = (gdouble_t *)uniform_ptr(pa + (flip1 ? 2 * np : 0u)), *q1 = (gdouble_t *)uniform_ptr(pa + np),
+              *q2 = (gdouble_t *)uniform_ptr(pa + (flip1 ? 0u : 2 * np));
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+      const uint32_t i = i0 + 64u * (uint32_t)j;
+      const bool inb = i < A.n_ind;
+      inbits |= (inb ? 1u : 0u) << j;
+      const uint32_t ic = i < np ? i : i0;  // (a slice may reach beyond the planes: the wavefronts times the slots round up)
+      const double a0 = q0[ic], a1 = q1[ic], a2 = q2[ic];
+      Ar[j][0] = (MASKED || inb) ? a0 : 1.0; Ar[j][1] = (MASKED || inb) ? a1 : 0.0; Ar[j][2] = (MASKED || inb) ? a2 : 0.0;
+    }
+  }
+  uint32_t c = next_kept(0);
+  if (c < it.count) dma_land(it.s2_begin + c);
+  uint32_t xpar = 0;  // exchanges of this workgroup so far (see em_pair)
+  while (c < it.count) {
+    const uint32_t cn = next_kept(c + 1);
+    const double m2 = site_sc[0][c], mean2 = site_sc[1][c], rsx2 = site_sc[2][c];
+    const Relabel rl = relabel(m1, m2, mean1, mean2);
+    const int gb0 = rl.flip2 ? 2 : 0, gb2 = rl.flip2 ? 0 : 2;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the landing copy issued during the previous pair is complete
+    double B[SLOTS][3];
+    const double *gsite = A.planes + (uint64_t)(it.s2_begin + c) * A.site_stride + i0;
+#pragma unroll
+    for (int j = kLand; j < SLOTS; ++j) {  // issued first: they fly while the landed slots are consumed
+      B[j][0] = gsite[(uint32_t)gb0 * np + 64 * j];
+      B[j][1] = gsite[np + 64 * j];
+      B[j][2] = gsite[(uint32_t)gb2 * np + 64 * j];
+    }
+    const double *lb = reinterpret_cast<const double *>(lds_b) + lane;
+#pragma unroll
+    for (int j = 0; j < kLand; ++j) {
+      B[j][0] = lb[gb0 * (kLandPlane / 8) + 64 * j];
+      B[j][1] = lb[(kLandPlane / 8) + 64 * j];
+      B[j][2] = lb[gb2 * (kLandPlane / 8) + 64 * j];
+    }
+    double sxy = 0.0;
+    uint32_t vbits = inbits;
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+      // expected genotypes p1 + 2 p2 (ngsLD.cpp:113); pearson_r runs over ALL individuals (ngsLD.cpp:290); the planes hold
+      // zeros beyond the cohort
+      if (MASKED) sxy = fma(fma(2.0, Ar[j][2], Ar[j][1]), fma(2.0, B[j][2], B[j][1]), sxy);
+      if (MASKED) {  // an individual without data at either site (gen_func.cpp:1089): b = 0, and em_pair_ab pads its s to 1
+        const bool ok = ((inbits >> j) & 1u) && !miss_data(Ar[j][0], Ar[j][1], Ar[j][2]) && !miss_data(B[j][0], B[j][1], B[j][2]);
+        if (!ok) {
+          vbits &= ~(1u << j);
+          B[j][0] = 0.0; B[j][1] = 0.0; B[j][2] = 0.0;
+        }
+      } else {
+        if (!((inbits >> j) & 1u)) {  // ghost: (1, 0, 0) at both sites -- expected genotype 0, s = f0^2, nothing added to R[1..8]
+          B[j][0] = 1.0; B[j][1] = 0.0; B[j][2] = 0.0;
+        }
+        sxy = fma(fma(2.0, Ar[j][2], Ar[j][1]), fma(2.0, B[j][2], B[j][1]), sxy);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the landing buffer is consumed, the direct loads are in
+    if (cn < it.count) dma_land(it.s2_begin + cn);
+    sxy = wave_sum1_bcast(sxy);
+    const double centre = (double)A.n_ind * rl.mean1 * rl.mean2;
+    uint32_t x = A.n_ind;
+    if (!MASKED) {
+      if (lane == 0) lds_post(lds_addr(&parked[c][sub]), sxy);
+    } else {  // the individuals with data at both sites (gen_func.cpp:1091) and the moment meet before the EM (as pair_ld_kernel)
+      x = count_valid<SLOTS>(vbits);
+      const uint32_t base = lds_addr(&xch0[0][0]);
+      if (lane == 0) lds_post2(base + (uint32_t)sub * 16u, sxy, (double)x);
+      lds_barrier();
+      dbl2 q[WAVES];
+      lds_gather<WAVES>(base, q);
+      double sx = 0.0, xs = 0.0;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        sx += q[w][0];
+        xs += q[w][1];
+      }
+      sxy = sx - centre;
+      x = (uint32_t)xs;
+    }
+    double f0, f1, f2, f3;
+    const uint32_t n_iter = em_pair_ab<SLOTS, MASKED, NGSLD_AB_TREE, SLOTS, WAVES>(B, Ar, nullptr, nullptr, nullptr, vbits, nullptr,
+                                                                                    MASKED ? 1.0 / (double)x : A.inv_n, rl.m1,
+                                                                                    rl.m2, f0, f1, f2, f3, lane, A.status, xch, sub,
+                                                                                    &xpar);
+    unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
+    if (lane == 0 && sub == 0) {
+      PairResult &r = res[c];
+      r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;
+      r.sxy = MASKED ? sxy : centre;  // (parked partial sums: the centring term travels in their place)
+      r.rsx2 = rsx2;
+      r.x = x;
+      r.n_iter = n_iter;
+    }
+    c = cn;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the parked partial sums are stores the compiler does not see
+  __syncthreads();
+  const uint32_t t = threadIdx.x;
+  if (t < it.count && ((it.mask >> t) & 1ull)) {
+    const PairResult r = res[t];
+    double sxy = r.sxy;
+    if (!MASKED) {
+      sxy = 0.0;  // (in the order of the wavefronts)
+      for (int w = 0; w < WAVES; ++w) sxy += parked[t][w];
+      sxy -= r.sxy;  // centred: sum e1 e2 - n mean1 mean2
+    }
+    write_pair(A, rec0 + (uint64_t)__popcll(it.mask & ((1ull << t) - 1ull)), r.f[0], r.f[1], r.f[2], r.f[3], sxy, rsx1,
+               r.rsx2, r.x, r.n_iter);
+  }
+}
+
+
 // Slots of the row vector a lane keeps in REGISTERS for the whole run (AREG), by slot count, as measured (same box,
 // profiles/r03/sweep_areg.txt; the records are the same bits whatever the split): every individual counts -- all of them up to
 // 13 slots (641..832: +9 % over re-reading them from LDS in every iteration: 1.40 / 1.38 / 1.29 / 1.21e8 pairs/s at 641 / 704 /
@@ -380,6 +617,41 @@ static hipError_t launch_ab_s(bool masked, const PairArgs &a, hipStream_t stream
   else
     hipLaunchKernelGGL((pair_ld_ab_kernel<SLOTS, false, kTree, AbRegs<SLOTS>::kAll>), grid, block, 0, stream, a);
   return hipGetLastError();
+}
+
+template <int SLOTS, int WAVES>
+static hipError_t launch_abm_sw(bool masked, const PairArgs &a, hipStream_t stream) {
+  const dim3 grid((unsigned)a.n_items), block(WAVES * 64);
+  if (masked)
+    hipLaunchKernelGGL((pair_ld_abm_kernel<SLOTS, WAVES, true>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((pair_ld_abm_kernel<SLOTS, WAVES, false>), grid, block, 0, stream, a);
+  return hipGetLastError();
+}
+template <int SLOTS>
+static hipError_t launch_abm_s(int waves, bool masked, const PairArgs &a, hipStream_t stream) {
+  switch (waves) {
+    case 2: return launch_abm_sw<SLOTS, 2>(masked, a, stream);
+    case 4: return launch_abm_sw<SLOTS, 4>(masked, a, stream);
+    case 8: return launch_abm_sw<SLOTS, 8>(masked, a, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// several wavefronts per pair, a/b form (item form: n_items workgroups, as launch_pair_wn)
+hipError_t launch_pair_abm(int slots, int waves, bool masked, const PairArgs &a, hipStream_t stream) {
+  if (a.n_items == 0) return hipSuccess;
+  if (a.n_items > 0x7fffffffull || a.np < (uint32_t)(slots * waves * 64)) return hipErrorInvalidValue;
+  switch (slots) {
+    case 9: return launch_abm_s<9>(waves, masked, a, stream);
+    case 10: return launch_abm_s<10>(waves, masked, a, stream);
+    case 11: return launch_abm_s<11>(waves, masked, a, stream);
+    case 12: return launch_abm_s<12>(waves, masked, a, stream);
+    case 13: return launch_abm_s<13>(waves, masked, a, stream);
+    case 14: return launch_abm_s<14>(waves, masked, a, stream);
+    case 15: return launch_abm_s<15>(waves, masked, a, stream);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_pair_ab(int slots, bool masked, const PairArgs &a, hipStream_t stream) {

@@ -15,10 +15,36 @@ namespace ngsld {
 // still beat two wavefronts of five by 54 % / 29 %: the per-iteration bookkeeping is paid once, nothing meets behind a
 // barrier); up to 832 the a/b form on one wavefront; above that 2..8 wavefronts share the pair (eight slots per lane, nine
 // or ten just past a doubling), and beyond 5120 the streaming kernel takes over.
-bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice) {
+bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice, bool masked) {
   if (n_ind == 0 || n_ind >= 0xffffffc0ull) return false;
   cfg->group = 64;
   cfg->waves = 1;
+  cfg->form = 0;
+  // Several wavefronts per pair in the a/b form (pair_ld_abm_kernel, ld_pair_ab.hip: the whole slice of the row vector in
+  // registers, 12 registers per individual instead of the P form's 18) where it measured ahead, same box
+  // (profiles/r03/sweep_abm.txt, sweep_abm2.txt; pairs/s against the P form on twice the wavefronts, or against the streaming
+  // kernel beyond 5,120):
+  //   every individual counts   2 x 11..13 +10 %, 2 x 14 / 15 +3..4 %; 4 x 10 +10..11 %, 4 x 11..13 +25..40 %, 4 x 14 / 15 +29..33 %;
+  //                             8 x 10 +19 %, 8 x 11..13 +58..65 %, 8 x 14 / 15 +47..73 %   (2 x 9 -10 %, 2 x 10 +1 %: the P form's)
+  //   --ignore_miss_data        2 x 10 +16 %, 2 x 11..13 +6..15 %; 4 x 10 +37 %, 4 x 11..13 +28..45 %; 8 x 10 +56 %, 8 x 11..13
+  //                             +35..69 %   (14 / 15 slots spill inside the EM loop there: -10..-31 %, 8 x 14 / 15 +-6 %)
+  // `masked` is what the matrix was set with (ngsld_set_geno_*): both forms compute either way, the layout follows this one.
+  // NGSLD_PAIR_KERNEL=abm: wherever it has a shape (9..15 slots); =multi / =bres: never.
+  if (choice == kChooseABMulti || choice == kChooseAuto) {
+    for (int w = 2; w <= 8; w *= 2) {
+      const uint64_t slots = (n_ind + (uint64_t)w * 64 - 1) / ((uint64_t)w * 64);
+      const uint64_t lo = choice == kChooseABMulti ? 9 : (masked ? 10 : (w == 2 ? 11 : 10));
+      const uint64_t hi = choice == kChooseABMulti ? 15 : (masked ? 13 : 15);
+      if (slots >= lo && slots <= hi) {
+        cfg->kernel = kMulti;
+        cfg->form = 1;
+        cfg->waves = w;
+        cfg->slots = (int)slots;
+        cfg->np = (uint32_t)(slots * (uint64_t)w * 64);
+        return true;
+      }
+    }
+  }
   if (n_ind > 5120u) {  // beyond 8 wavefronts x 10 slots x 64 lanes: streaming kernel, one workgroup per pair
     cfg->kernel = kStream;
     cfg->waves = choice == kChoosePlainStream ? 4 : 8;  // 8: the candidate's vector resident (ld_pair_stream.hip)
@@ -212,6 +238,7 @@ static hipError_t launch_pair_chunk(const PairConfig &cfg, bool masked, const Pa
     if (cfg.group == 16) return launch_group<16>(cfg.slots, masked, a, stream);
     return launch_group<32>(cfg.slots, masked, a, stream);
   }
+  if (cfg.kernel == kMulti && cfg.form == 1) return launch_pair_abm(cfg.slots, cfg.waves, masked, a, stream);
   if (cfg.kernel == kMulti) {
     int slots = cfg.slots, waves = cfg.waves;
     multi_shape(cfg, masked, &slots, &waves);

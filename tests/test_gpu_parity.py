@@ -33,6 +33,27 @@ def check_against_oracle(engine, raw, pos_dist=None, log_scale=False, ignore_mis
     return rec
 
 
+def _forced(kernel):
+    """A context of its own with NGSLD_PAIR_KERNEL=<kernel> (read when the context is created)."""
+    import os
+    from ngsld_amd import capi
+    os.environ["NGSLD_PAIR_KERNEL"] = kernel
+    try:
+        return capi.Engine(0)
+    finally:
+        del os.environ["NGSLD_PAIR_KERNEL"]
+
+
+def multi_ab_shape(n_ind, masked):
+    """pair_config's rule (ld_pair_w1.hip): does the cohort run on several wavefronts per pair in the a/b form?"""
+    for w in (2, 4, 8):
+        slots = -(-n_ind // (64 * w))
+        lo, hi = (10, 13) if masked else ((11 if w == 2 else 10), 15)
+        if lo <= slots <= hi:
+            return True
+    return False
+
+
 def test_selftest(engine):
     engine.selftest()
 
@@ -73,13 +94,20 @@ def test_nine_and_ten_slots_per_lane(engine, n_sites, n_ind, seed, ignore_miss):
         miss = np.random.default_rng(seed).random((n_sites, n_ind)) < 0.15
         raw[miss] = 1.0 / 3.0
     engine.set_geno_raw(raw[:2], ignore_miss_data=ignore_miss)
-    assert engine.pair_kernel() == "multi"
+    assert engine.pair_kernel() == ("multi-ab" if multi_ab_shape(n_ind, ignore_miss) else "multi")
     check_against_oracle(engine, raw, ignore_miss=ignore_miss)
+    eng = _forced("multi")      # the P form on these shapes (the default wherever the a/b form has none or measured behind)
+    try:
+        eng.set_geno_raw(raw[:2], ignore_miss_data=ignore_miss)
+        assert eng.pair_kernel() == "multi"
+        check_against_oracle(eng, raw, ignore_miss=ignore_miss)
+    finally:
+        eng.close()
 
 
 @pytest.mark.parametrize("n_sites,n_ind,seed,ignore_miss", [(12, 1300, 43, False), (10, 1536, 44, True), (10, 1400, 47, False),
                                                             (8, 2600, 45, False), (8, 3072, 46, True), (8, 1290, 48, True)])
-def test_five_and_six_slots_keep_the_row_slice_in_registers(engine, n_sites, n_ind, seed, ignore_miss):
+def test_five_and_six_slots_keep_the_row_slice_in_registers(n_sites, n_ind, seed, ignore_miss):
     """Several wavefronts per pair with five or six individuals per lane (1,281..1,536 on four wavefronts, 2,561..3,072 on
     eight): the wavefront's slice of the row vector is loaded once per item and held in registers for its 64 candidates --
     including the relabelling of a row site with maf > 1/2, a monomorphic site and a site without data for some."""
@@ -89,9 +117,13 @@ def test_five_and_six_slots_keep_the_row_slice_in_registers(engine, n_sites, n_i
     if ignore_miss:
         miss = np.random.default_rng(seed).random((n_sites, n_ind)) < 0.15
         raw[miss] = 1.0 / 3.0
-    engine.set_geno_raw(raw[:2], ignore_miss_data=ignore_miss)
-    assert engine.pair_kernel() == "multi"
-    check_against_oracle(engine, raw, ignore_miss=ignore_miss)
+    eng = _forced("multi")      # (these cohort sizes run in the a/b form by default: test_gpu_run_kernel.py and the fuzz cover it)
+    try:
+        eng.set_geno_raw(raw[:2], ignore_miss_data=ignore_miss)
+        assert eng.pair_kernel() == "multi"
+        check_against_oracle(eng, raw, ignore_miss=ignore_miss)
+    finally:
+        eng.close()
 
 
 def test_windowed_and_snp_dist(engine):
@@ -226,10 +258,17 @@ def test_streaming_kernel_large_cohorts(engine, n_sites, n_ind, seed, ignore):
     on block-count borders); beyond that 20 blocks per wavefront (10,240 individuals) stay resident and the rest of both
     vectors is re-read."""
     raw = synth.make_gl_numpy(n_sites, n_ind, seed, depth=8.0)
-    engine.set_geno_raw(raw[:2], ignore_miss_data=ignore)
-    assert engine.pair_kernel() == "stream"
     if ignore:
         raw[np.random.default_rng(seed).random((n_sites, n_ind)) < 0.05] = 1.0 / 3.0
+    eng = _forced("bres")       # (up to 7,680 individuals the default is eight wavefronts per pair in the a/b form)
+    try:
+        eng.set_geno_raw(raw[:2], ignore_miss_data=ignore)
+        assert eng.pair_kernel() == "stream"
+        check_against_oracle(eng, raw, ignore_miss=ignore)
+    finally:
+        eng.close()
+    engine.set_geno_raw(raw[:2], ignore_miss_data=ignore)
+    assert engine.pair_kernel() == ("multi-ab" if multi_ab_shape(n_ind, ignore) else "stream")
     check_against_oracle(engine, raw, ignore_miss=ignore)
 
 
@@ -255,26 +294,31 @@ def test_plain_streaming_kernel(n_sites, n_ind, seed, ignore):
         eng.close()
 
 
-def test_streaming_kernel_with_vanishing_weights(engine):
-    """Four individuals of one lane (0, 512, 1024, 1536: blocks 0 / 8 / 16 / 24 are the first four slots of wavefront 0) are
-    certain alt/alt homozygotes at every site while the caller's maf says 1e-45: their s is f3^2 = 1e-180 in the first
-    iteration.  Each has a reciprocal; their PRODUCT has none -- a step that shared one reciprocal among the slots of a
-    lane (measured for this kernel and not kept: profiles/r03/sweep_bres_tree.txt) would end as the reference's all-NaN
-    step here, the reference itself does not."""
+def test_kernels_with_vanishing_weights_take_a_second_opinion(engine):
+    """Individuals 0, 64, 128, 192 -- lane 0's first four slots of wavefront 0 at 6,000 individuals on eight wavefronts in the a/b
+    form, where eight slots share ONE reciprocal -- are certain alt/alt homozygotes at every site while the caller's maf says
+    1e-45: their s is f3^2 = 1e-180 in the first iteration.  Each has a reciprocal; their PRODUCT has none: the step has to be
+    redone with one reciprocal per individual instead of ending as the reference's all-NaN step.  (The streaming kernel, which
+    takes one reciprocal per individual throughout, is held to the same records.)"""
     n_sites, n_ind = 4, 6000
     raw = synth.make_gl_numpy(n_sites, n_ind, 321, depth=8.0)
-    raw[:, [0, 512, 1024, 1536], :] = [0.0, 0.0, 1.0]
+    raw[:, [0, 64, 128, 192, 512, 1024, 1536], :] = [0.0, 0.0, 1.0]
     o = orc.Oracle(raw, None, n_threads=4)
     o.maf[:] = 1e-45
     rec = o.run()
     assert np.isfinite(rec["hap"]).all() and (rec["n_iter"] > 1).all()
-    engine.set_geno_lkl(o.gl, o.maf)
-    assert engine.pair_kernel() == "stream"
-    engine.set_pos_dist(None)
-    assert engine.plan(0, 0, 0.0, False, True, 1.0, 0) == len(rec)
-    s1, s2, std, ext = engine.run()
-    assert np.array_equal(s1, rec["s1"]) and np.array_equal(s2, rec["s2"])
-    check_records(std, ext, rec)
+    bres = _forced("bres")
+    try:
+        for eng, name in ((bres, "stream"), (engine, "multi-ab")):   # (the default at 6,000 individuals shares reciprocals: its second opinion)
+            eng.set_geno_lkl(o.gl, o.maf)
+            assert eng.pair_kernel() == name
+            eng.set_pos_dist(None)
+            assert eng.plan(0, 0, 0.0, False, True, 1.0, 0) == len(rec)
+            s1, s2, std, ext = eng.run()
+            assert np.array_equal(s1, rec["s1"]) and np.array_equal(s2, rec["s2"])
+            check_records(std, ext, rec)
+    finally:
+        bres.close()
 
 
 def test_api_error_paths(engine):

@@ -93,6 +93,36 @@ def test_ab_form_kernel_matches_the_oracle(n_ind, ignore_miss):
         eng.close()
 
 
+@pytest.mark.parametrize("n_ind,ignore_miss", [(1281, False), (1400, True), (1536, False), (1664, True), (2561, False), (2700, True),
+                                               (3072, False), (3328, False), (3300, True), (5121, False), (5200, True), (6000, False),
+                                               (6656, True), (6600, False)])
+def test_multi_wavefront_ab_form_kernel_matches_the_oracle(n_ind, ignore_miss):
+    """NGSLD_PAIR_KERNEL=abm: two / four / eight wavefronts per pair in the a/b form, 11..13 individuals per lane with the row
+    slice in registers (pair_ld_abm_kernel, ld_pair_ab.hip).  Held to the same bars as every kernel."""
+    import os
+    from oracle import orc
+    from util import check_records
+    n_sites = 14 if n_ind < 4000 else 7
+    raw = synth.make_gl_numpy(n_sites, n_ind, 1905 + n_ind, depth=3.0)
+    raw[3] = [1.0, 0.0, 0.0]
+    raw[5, ::3] = 1.0 / 3.0
+    want = orc.Oracle(raw, ignore_miss_data=ignore_miss, n_threads=4).run()
+    os.environ["NGSLD_PAIR_KERNEL"] = "abm"
+    try:
+        eng = capi.Engine(0)
+    finally:
+        del os.environ["NGSLD_PAIR_KERNEL"]
+    try:
+        eng.set_geno_raw(raw, ignore_miss_data=ignore_miss)
+        assert eng.pair_kernel() == "multi-ab"
+        eng.set_pos_dist(None)
+        assert eng.plan(ignore_miss_data=ignore_miss) == len(want)
+        s1, s2, std, ext = eng.run()
+        check_records(std, ext, want)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("n_ind", [100, 500])
 def test_runs_recut_between_text_and_record_runs(n_ind):
     """ngsld_run cuts the run list to its batch size (text batches: shorter runs), ngsld_run_device back to whole rows:

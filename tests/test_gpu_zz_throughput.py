@@ -18,13 +18,13 @@ pytestmark = pytest.mark.gpu
 FLOORS = [(513, 1.45e8),        # 1.20e8              1.82e8                  run kernel, nine individuals per lane
           (640, 1.30e8),        # 1.21e8              1.53e8                  run kernel, ten
           (704, 1.17e8),        # 1.13e8              1.33e8                  a/b kernel, row vector in registers
-          (2560, 2.70e7),       # 2.34e7              3.05e7                  four wavefronts x ten
-          (5120, 1.00e7),       # 6.2e6 (streaming)   1.25e7                  eight wavefronts x ten
-          (6000, 6.3e6),        # 5.0e6               (8.3e6, 2.3 GHz box)    streaming, candidate's vector in registers
-          (10000, 3.9e6)]       # 2.6e6               (5.3e6, 2.3 GHz box)    the same, 20 blocks per wavefront
+          (2560, 2.90e7),       # 2.34e7              (3.50e7, 2.3 GHz box)   four wavefronts x ten, a/b form
+          (5120, 1.30e7),       # 6.2e6 (streaming)   (1.61e7, 2.3 GHz box)   eight wavefronts x ten, a/b form
+          (6000, 1.05e7),       # 5.0e6 (streaming)   (1.33e7, 2.3 GHz box)   eight wavefronts x twelve, a/b form
+          (10000, 3.9e6)]       # 2.6e6               (5.3e6, 2.3 GHz box)    streaming, candidate's vector in registers
 KERNELS = {513: "pair_ld_run_kernel", 640: "pair_ld_run_kernel", 704: "pair_ld_ab_kernel",
-           2560: "pair_ld_kernel (multi-wavefront)", 5120: "pair_ld_kernel (multi-wavefront)",
-           6000: "pair_ld_bres_kernel (streaming, candidate's vector resident)",
+           2560: "pair_ld_abm_kernel (multi-wavefront, a/b form)", 5120: "pair_ld_abm_kernel (multi-wavefront, a/b form)",
+           6000: "pair_ld_abm_kernel (multi-wavefront, a/b form)",
            10000: "pair_ld_bres_kernel (streaming, candidate's vector resident)"}
 
 
