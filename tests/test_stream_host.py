@@ -102,9 +102,12 @@ def test_ranged_binary_read(tmp_path, compressed):
 # beyond -- eight slots per lane, nine or ten just past a doubling -- and whole 64-blocks for the streaming kernel
 PLANE_SHAPES = [(24, 24), (64, 64), (65, 80), (100, 112), (128, 128), (160, 160), (200, 224), (250, 256), (500, 512), (512, 512),
                 (513, 576), (576, 576), (577, 640), (640, 640), (641, 704), (832, 832), (833, 896), (897, 960), (960, 960), (961, 1024), (1000, 1024), (1024, 1024),
-                (1025, 1152), (1152, 1152), (1153, 1280), (1280, 1280), (1281, 1536), (2000, 2048), (2049, 2304),
-                (2305, 2560), (2561, 3072), (4096, 4096), (4097, 4608), (4609, 5120), (5120, 5120), (5121, 5184),
-                (6000, 6016)]
+                (1025, 1152), (1152, 1152), (1153, 1280), (1280, 1280), (1281, 1408), (1664, 1664), (1700, 1792), (1900, 2048),
+                (1921, 2048), (2000, 2048), (2049, 2304), (2305, 2560), (2561, 2816), (3328, 3328), (3500, 3584), (3800, 4096),
+                (3841, 4096), (4096, 4096), (4097, 4608), (4609, 5120), (5120, 5120), (5121, 5632), (6000, 6144), (6656, 6656),
+                (7000, 7168), (7680, 7680), (7681, 7744), (10000, 10048)]
+# (several wavefronts per pair in the a/b form, round 3: 2 / 4 / 8 wavefronts x 10..15 slots -- with --ignore_miss_data up to 13; the
+# helper prices the wider of the two layouts: 1,900 individuals are 2 x 15 x 64 = 1,920 slots, or 4 x 8 x 64 = 2,048 under the flag)
 
 
 @pytest.mark.parametrize("n_ind,np_want", PLANE_SHAPES)
