@@ -215,7 +215,7 @@ int ngsld_finish_device(ngsld_ctx *ctx);
 int ngsld_last_kernel_time(ngsld_ctx *ctx, double *total_ms, uint64_t *n_launches, uint64_t *n_pairs);
 
 /* Which pair kernel family the genotype data set last will run on: "group" (8 / 16 / 32 lanes per pair), "run" (one
- * wavefront per pair, up to 640 individuals), "ab" (one wavefront per pair, a/b form of the EM step: 641..960 individuals), "multi" (several wavefronts per pair, up to 5,120 individuals), "stream" (beyond: one vector in registers, the other re-read in every EM iteration), or "hard" -- every
+ * wavefront per pair, up to 640 individuals), "ab" (one wavefront per pair, a/b form of the EM step: 641..960 individuals), "multi" / "multi-ab" (several wavefronts per pair, P form / a/b form, up to 7,680 individuals), "stream" (beyond: one vector in registers, the other re-read in every EM iteration), or "hard" -- every
  * likelihood triple is a called genotype or "no data" (text genotypes, --call_geno: ngsLD.cpp:92-98,
  * read_data.cpp:83-99), the pairs run on their 16 genotype-combination counts.  "" before any data is set. */
 const char *ngsld_pair_kernel(const ngsld_ctx *ctx);

@@ -22,18 +22,18 @@ bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice, bool masked) {
   cfg->form = 0;
   // Several wavefronts per pair in the a/b form (pair_ld_abm_kernel, ld_pair_ab.hip: the whole slice of the row vector in
   // registers, 12 registers per individual instead of the P form's 18) where it measured ahead, same box
-  // (profiles/r03/sweep_abm.txt, sweep_abm2.txt; pairs/s against the P form on twice the wavefronts, or against the streaming
+  // (profiles/r03/sweep_abm.txt, sweep_abm2.txt, sweep_abm3.txt; pairs/s against the P form on twice the wavefronts, or against the streaming
   // kernel beyond 5,120):
-  //   every individual counts   2 x 11..13 +10 %, 2 x 14 / 15 +3..4 %; 4 x 10 +10..11 %, 4 x 11..13 +25..40 %, 4 x 14 / 15 +29..33 %;
-  //                             8 x 10 +19 %, 8 x 11..13 +58..65 %, 8 x 14 / 15 +47..73 %   (2 x 9 -10 %, 2 x 10 +1 %: the P form's)
-  //   --ignore_miss_data        2 x 10 +16 %, 2 x 11..13 +6..15 %; 4 x 10 +37 %, 4 x 11..13 +28..45 %; 8 x 10 +56 %, 8 x 11..13
-  //                             +35..69 %   (14 / 15 slots spill inside the EM loop there: -10..-31 %, 8 x 14 / 15 +-6 %)
+  //   every individual counts   2 x 11..13 +10 %, 2 x 14 / 15 +3..4 %; 4 x 9 +1..2 %, 4 x 10 +10..11 %, 4 x 11..13 +25..40 %, 4 x 14 / 15
+  //                             +29..33 %; 8 x 9 / 10 +19 %, 8 x 11..13 +58..65 %, 8 x 14 / 15 +47..73 %   (2 x 9 -10 %, 2 x 10 +1 %: the P form's)
+  //   --ignore_miss_data        2 x 9 +4 %, 2 x 10 +16 %, 2 x 11..13 +6..15 %; 4 x 9 +25 %, 4 x 10 +37 %, 4 x 11..13 +28..45 %; 8 x 9 +38 %,
+  //                             8 x 10 +56 %, 8 x 11..13 +35..69 %   (14 / 15 slots spill inside the EM loop there: -10..-31 %, 8 x 14 / 15 +-6 %)
   // `masked` is what the matrix was set with (ngsld_set_geno_*): both forms compute either way, the layout follows this one.
   // NGSLD_PAIR_KERNEL=abm: wherever it has a shape (9..15 slots); =multi / =bres: never.
   if (choice == kChooseABMulti || choice == kChooseAuto) {
     for (int w = 2; w <= 8; w *= 2) {
       const uint64_t slots = (n_ind + (uint64_t)w * 64 - 1) / ((uint64_t)w * 64);
-      const uint64_t lo = choice == kChooseABMulti ? 9 : (masked ? 10 : (w == 2 ? 11 : 10));
+      const uint64_t lo = choice == kChooseABMulti ? 9 : (!masked && w == 2 ? 11 : 9);
       const uint64_t hi = choice == kChooseABMulti ? 15 : (masked ? 13 : 15);
       if (slots >= lo && slots <= hi) {
         cfg->kernel = kMulti;

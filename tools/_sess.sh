@@ -1,4 +1,2 @@
-mkdir -p gpurun_out/r03/late3
-O=gpurun_out/r03/late3
-( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu_final.txt 2>&1
-grep -E "passed|failed|parity:|rror" $O/pytest_gpu_final.txt | tail -8
+mkdir -p gpurun_out/r03
+( NINDS="2049 2304 4097 4608" timeout 900 bash tools/sweep_variants.sh "now=" "abm=NGSLD_PAIR_KERNEL=abm" ) > gpurun_out/r03/sweep_abm3.txt 2>&1
