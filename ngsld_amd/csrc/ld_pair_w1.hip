@@ -28,6 +28,7 @@ bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice, bool masked) {
   //                             +29..33 %; 8 x 9 / 10 +19 %, 8 x 11..13 +58..65 %, 8 x 14 / 15 +47..73 %   (2 x 9 -10 %, 2 x 10 +1 %: the P form's)
   //   --ignore_miss_data        2 x 9 +4 %, 2 x 10 +16 %, 2 x 11..13 +6..15 %; 4 x 9 +25 %, 4 x 10 +37 %, 4 x 11..13 +28..45 %; 8 x 9 +38 %,
   //                             8 x 10 +56 %, 8 x 11..13 +35..69 %   (14 / 15 slots spill inside the EM loop there: -10..-31 %, 8 x 14 / 15 +-6 %)
+  //   (sixteen per lane spill ~480 bytes inside the EM loop: -30..-70 %, sweep_abm16.txt)
   // `masked` is what the matrix was set with (ngsld_set_geno_*): both forms compute either way, the layout follows this one.
   // NGSLD_PAIR_KERNEL=abm: wherever it has a shape (9..15 slots); =multi / =bres: never.
   if (choice == kChooseABMulti || choice == kChooseAuto) {
