@@ -32,13 +32,17 @@ template __global__ void ngsld::pair_ld_kernel<8,8,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_kernel<10,4,false>(ngsld::PairArgs);
 template __global__ void ngsld::pair_ld_kernel<10,8,false>(ngsld::PairArgs);
 EOT
+# the a/b-form kernels live in their translation unit (ld_pair_ab.hip): compiled as it is built, a few shapes picked from its report
+( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -c $R/ngsld_amd/csrc/ld_pair_ab.hip -o $T/ab.o \
+    -Rpass-analysis=kernel-resource-usage 2>&1 || true ) | grep -A9 -E "Function Name: .*(pair_ld_abm_kernelILi(9|12|13|15)ELi(2|4|8)ELb0|pair_ld_ab_kernelILi(12|15)ELb0)" \
+  | grep -E "Function Name|VGPRs:|AGPRs|ScratchSize|Occupancy|LDS Size|SGPRs:" > $T/res_ab.txt || true
 cd $T
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -c k.hip -o k.o -save-temps \
   -Rpass-analysis=kernel-resource-usage 2> res.txt || true
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -amdgpu-sched-strategy=iterative-ilp -c kw.hip -o kw.o \
   -Rpass-analysis=kernel-resource-usage 2>> res.txt || true
 echo "== kernel resources (hipcc -Rpass-analysis=kernel-resource-usage, gfx950) =="
-grep -E "Function Name|VGPRs:|AGPRs|ScratchSize|Occupancy|LDS Size|SGPRs:" res.txt | sed 's/^[^ ]*:[0-9]*:[0-9]*: remark: *//; s/remark:[^:]*:[0-9]*:[0-9]*: *//; s/ \[-Rpass-analysis=kernel-resource-usage\]//' \
+cat res.txt res_ab.txt | grep -E "Function Name|VGPRs:|AGPRs|ScratchSize|Occupancy|LDS Size|SGPRs:" | sed 's/^[^ ]*:[0-9]*:[0-9]*: remark: *//; s/remark:[^:]*:[0-9]*:[0-9]*: *//; s/ \[-Rpass-analysis=kernel-resource-usage\]//' \
   | sed 's/_ZN5ngsld//; s/EvNS_8PairArgsE//'
 S=k-hip-amdgcn-amd-amdhsa-gfx950.s
 awk '/^_ZN5ngsld18pair_ld_run_kernelILi8ELb0EEEvNS_8PairArgsE:/,/s_endpgm/' $S > pf.s
