@@ -294,6 +294,25 @@ def test_plain_streaming_kernel(n_sites, n_ind, seed, ignore):
         eng.close()
 
 
+def test_a_matrix_set_without_the_flag_can_be_planned_with_it(engine):
+    """ngsld_set_geno_lkl carries no --ignore_miss_data: the plane layout (and with it the kernel family) follows "every individual
+    counts", and ngsld_plan may still ask for the flag.  1,700 individuals: two wavefronts x 14 per lane in the a/b form either way
+    (set WITH the flag the same cohort takes four wavefronts x 7 in the P form)."""
+    n_sites, n_ind = 10, 1700
+    raw = synth.make_gl_numpy(n_sites, n_ind, 341, depth=3.0)
+    raw[np.random.default_rng(341).random((n_sites, n_ind)) < 0.1] = 1.0 / 3.0
+    o = orc.Oracle(raw, None, ignore_miss_data=True, n_threads=4)
+    rec = o.run()
+    engine.set_geno_lkl(o.gl, o.maf)
+    engine.set_pos_dist(None)
+    assert engine.plan(0, 0, 0.0, True, True, 1.0, 0) == len(rec)
+    assert engine.pair_kernel() == "multi-ab"
+    s1, s2, std, ext = engine.run()
+    check_records(std, ext, rec)
+    engine.set_geno_raw(raw, ignore_miss_data=True)
+    assert engine.pair_kernel() == "multi"
+
+
 def test_kernels_with_vanishing_weights_take_a_second_opinion(engine):
     """Individuals 0, 64, 128, 192 -- lane 0's first four slots of wavefront 0 at 6,000 individuals on eight wavefronts in the a/b
     form, where eight slots share ONE reciprocal -- are certain alt/alt homozygotes at every site while the caller's maf says

@@ -95,7 +95,12 @@ def test_ab_form_kernel_matches_the_oracle(n_ind, ignore_miss):
 
 @pytest.mark.parametrize("n_ind,ignore_miss", [(1281, False), (1400, True), (1536, False), (1664, True), (2561, False), (2700, True),
                                                (3072, False), (3328, False), (3300, True), (5121, False), (5200, True), (6000, False),
-                                               (6656, True), (6600, False)])
+                                               (6656, True), (6600, False),
+                                               # nine / ten per lane, and fourteen / fifteen -- under the flag too, where the default
+                                               # keeps to the P form but a matrix set without the flag may still be planned with it
+                                               (1100, True), (1153, False), (2100, False), (2100, True), (2400, True), (4300, False),
+                                               (4700, True), (1700, False), (1700, True), (1920, True), (3500, False), (3800, True),
+                                               (7000, False), (7000, True), (7680, False)])
 def test_multi_wavefront_ab_form_kernel_matches_the_oracle(n_ind, ignore_miss):
     """NGSLD_PAIR_KERNEL=abm: two / four / eight wavefronts per pair in the a/b form, 11..13 individuals per lane with the row
     slice in registers (pair_ld_abm_kernel, ld_pair_ab.hip).  Held to the same bars as every kernel."""
