@@ -1897,7 +1897,8 @@ constexpr int kBresTailSlots = 20;                      // beyond: 20 blocks per
 //   kGroup  8 / 16 / 32 lanes per pair, several pairs per wavefront in lockstep (n_ind <= 128, some shapes up to 224)
 //   kRun    one wavefront per pair, the row vector shared in LDS, runs of items (n_ind <= 640: up to TEN individuals per lane)
 //   kRunAB  one wavefront per pair, EM step in its a/b form, run pipeline (ld_pair_ab.hip: 641..960)
-//   kMulti  2 / 4 / 8 wavefronts per pair (961..5120)
+//   kMulti  2 / 4 / 8 wavefronts per pair: P form (pair_ld_kernel, 5..10 per lane, 961..5,120) or a/b form (pair_ld_abm_kernel,
+//           9..15 per lane with the row slice in registers: most of 1,281..7,680 -- pair_config has the table)
 //   kStream any n_ind: the candidate's vector (its first 9,216 individuals beyond 10,240) in registers, the row vector -- or,
 //           with cfg.waves == 4 (NGSLD_PAIR_KERNEL=stream), both -- re-read every iteration
 //   kHard   every likelihood triple of the matrix is a called genotype or "no data": the pairs' 16 genotype-combination

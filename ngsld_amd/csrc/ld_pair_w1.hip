@@ -13,8 +13,9 @@ namespace ngsld {
 // Lane groups of 8 / 16 / 32 lanes x 8 slots cover 64 / 128 / 256 individuals (group kernel); one wavefront holds up to
 // 10 * 64 = 640 individuals as 18 * 10 = 180 VGPRs of P (nine and ten slots spill a few registers OUTSIDE the EM loop and
 // still beat two wavefronts of five by 54 % / 29 %: the per-iteration bookkeeping is paid once, nothing meets behind a
-// barrier); up to 832 the a/b form on one wavefront; above that 2..8 wavefronts share the pair (eight slots per lane, nine
-// or ten just past a doubling), and beyond 5120 the streaming kernel takes over.
+// barrier); up to 960 the a/b form on one wavefront; above that 2..8 wavefronts share the pair -- in the P form with up to
+// eight slots per lane (nine or ten just past a doubling), or in the a/b form with nine to fifteen where that measured
+// ahead -- and beyond 7,680 (5,120 where the a/b form has no shape) the streaming kernel takes over.
 bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice, bool masked) {
   if (n_ind == 0 || n_ind >= 0xffffffc0ull) return false;
   cfg->group = 64;
