@@ -82,6 +82,10 @@ __device__ __forceinline__ uint32_t em_pair_ab(const double (&B)[SLOTS][3], cons
 
   auto em_step = [&](auto tree_tag, double &n0, double &n1, double &n2, double &n3) {
     constexpr bool kTree = decltype(tree_tag)::value;  // shared reciprocals, three-value form; otherwise one per individual, full form
+    // (several wavefronts, --ignore_miss_data: the pads are read off the validity bits in every iteration -- were the bits not
+    // hidden here, loop-invariant code motion would form all SLOTS pads in front of the EM loop and keep them in registers the
+    // kernel does not have)
+    if (WAVES > 1 && MASKED) asm volatile("" : "+v"(vbits));
     const double p00 = f0 * f0, p01 = f0 * f1, p02 = f0 * f2, p03 = f0 * f3, p11 = f1 * f1;
     const double p12 = f1 * f2, p13 = f1 * f3, p22 = f2 * f2, p23 = f2 * f3, p33 = f3 * f3;
     const double w1 = p01 + p01, w3 = p02 + p02, w4 = 2.0 * (p03 + p12), w5 = p13 + p13, w7 = p23 + p23;

@@ -28,7 +28,8 @@ bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice, bool masked) {
   //   every individual counts   2 x 11..13 +10 %, 2 x 14 / 15 +3..4 %; 4 x 9 +1..2 %, 4 x 10 +10..11 %, 4 x 11..13 +25..40 %, 4 x 14 / 15
   //                             +29..33 %; 8 x 9 / 10 +19 %, 8 x 11..13 +58..65 %, 8 x 14 / 15 +47..73 %   (2 x 9 -10 %, 2 x 10 +1 %: the P form's)
   //   --ignore_miss_data        2 x 9 +4 %, 2 x 10 +16 %, 2 x 11..13 +6..15 %; 4 x 9 +25 %, 4 x 10 +37 %, 4 x 11..13 +28..45 %; 8 x 9 +38 %,
-  //                             8 x 10 +56 %, 8 x 11..13 +35..69 %   (14 / 15 slots spill inside the EM loop there: -10..-31 %, 8 x 14 / 15 +-6 %)
+  //                             8 x 10 +56 %, 8 x 11..13 +35..69 %; once the pads stopped being hoisted out of the EM loop (sweep_abm_maskfix.txt:
+  //                             13 slots another +12..15 %) 4 x 14 +24 %, 8 x 14 +39 %   (2 x 14 +-0; fifteen slots spill inside the loop: -40 %)
   //   (sixteen per lane spill ~480 bytes inside the EM loop: -30..-70 %, sweep_abm16.txt)
   // `masked` is what the matrix was set with (ngsld_set_geno_*): both forms compute either way, the layout follows this one.
   // NGSLD_PAIR_KERNEL=abm: wherever it has a shape (9..15 slots); =multi / =bres: never.
@@ -36,7 +37,7 @@ bool pair_config(uint64_t n_ind, PairConfig *cfg, int choice, bool masked) {
     for (int w = 2; w <= 8; w *= 2) {
       const uint64_t slots = (n_ind + (uint64_t)w * 64 - 1) / ((uint64_t)w * 64);
       const uint64_t lo = choice == kChooseABMulti ? 9 : (!masked && w == 2 ? 11 : 9);
-      const uint64_t hi = choice == kChooseABMulti ? 15 : (masked ? 13 : 15);
+      const uint64_t hi = choice == kChooseABMulti ? 15 : (masked ? (w == 2 ? 13 : 14) : 15);
       if (slots >= lo && slots <= hi) {
         cfg->kernel = kMulti;
         cfg->form = 1;

@@ -48,7 +48,7 @@ def multi_ab_shape(n_ind, masked):
     """pair_config's rule (ld_pair_w1.hip): does the cohort run on several wavefronts per pair in the a/b form?"""
     for w in (2, 4, 8):
         slots = -(-n_ind // (64 * w))
-        lo, hi = (9, 13) if masked else ((11 if w == 2 else 9), 15)
+        lo, hi = (9, 13 if w == 2 else 14) if masked else ((11 if w == 2 else 9), 15)
         if lo <= slots <= hi:
             return True
     return False
