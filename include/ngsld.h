@@ -118,7 +118,10 @@ const char *ngsld_last_error(const ngsld_ctx *ctx);
 /* Genotype likelihoods exactly as the reference's binary input holds them: n_sites*n_ind*3 doubles,
  * [site][ind][geno] (read_data.cpp:28-47), natural scale or logs (log_scale).  The device does what
  * read_geno + main do to them: log, -inf -> -1e15, log-normalise, NaN check, est_maf, exp, expected
- * genotypes.  `on_device` != 0: gl_raw is a device pointer on this ctx's device (not modified). */
+ * genotypes.  `on_device` != 0: gl_raw is a device pointer on this ctx's device (not modified).
+ * `ignore_miss_data` here also picks the device layout of the matrix (for some cohort sizes the kernels measured best
+ * differ with the flag, and their plane padding with them): give the value ngsld_params.ignore_miss_data will have.
+ * A plan with the other value is computed all the same -- same records, possibly on the slower of two kernels. */
 int ngsld_set_geno_raw(ngsld_ctx *ctx, const double *gl_raw, uint64_t n_sites, uint64_t n_ind, int log_scale,
                        int ignore_miss_data, int on_device);
 /* The same with every input-side switch of the reference's main():
