@@ -118,7 +118,7 @@ struct PinBuf {
 
 struct ngsld_ctx {
   int device = 0;
-  hipStream_t stream = nullptr, copy_stream = nullptr;
+  hipStream_t stream = nullptr, stream2 = nullptr, copy_stream = nullptr;
   std::string err;
 
   // data
@@ -158,12 +158,24 @@ struct ngsld_ctx {
   uint32_t pairs_per_item = 16;
   uint64_t batch_pairs = 1ull << 23;
 
-  // batch pipeline (two slots)
-  DevBuf<ngsld_rec_std> d_std[2];
-  DevBuf<ngsld_rec_ext> d_ext[2];
-  PinBuf<ngsld_rec_std> h_std[2];
-  PinBuf<ngsld_rec_ext> h_ext[2];
-  hipEvent_t ev_kernel_done[2] = {nullptr, nullptr}, ev_copy_done[2] = {nullptr, nullptr};
+  // batch pipeline: kSlots record slots (text batches use two of them)
+  static constexpr int kSlots = 3;
+  DevBuf<ngsld_rec_std> d_std[kSlots];
+  DevBuf<ngsld_rec_ext> d_ext[kSlots];
+  PinBuf<ngsld_rec_std> h_std[kSlots];
+  PinBuf<ngsld_rec_ext> h_ext[kSlots];
+  hipEvent_t ev_kernel_done[kSlots] = {nullptr, nullptr, nullptr}, ev_copy_done[kSlots] = {nullptr, nullptr, nullptr};
+  // how record batches reach the host (ngsld_run without text output; NGSLD_RUN_DIRECT / NGSLD_RUN_STREAMS / NGSLD_RUN_TAPER):
+  //   run_direct   the pair kernels write the records straight into the batch's pinned host buffers over the host link
+  //                (72 B per pair at 2e8 pairs/s is 15 GB/s of posted writes) -- there is no device copy of them and no
+  //                D2H copy behind the last kernel
+  //   run_streams  2: consecutive batches go to two streams, so the workgroups of batch k+1 fill the CUs the last
+  //                workgroups of batch k leave (a batch of whole-row runs drains for ~2.5 ms: 12 batches, 10 ms)
+  //   run_taper    batches shrink towards the end of a run (a third of what is left, at least 2^19 pairs), so that the copy
+  //                exposed behind the last kernel is small
+  bool run_direct = false, run_taper = true;
+  int run_streams = 2;
+  bool timed_overlap = false;  // the launches of the last run overlapped: their time is first start .. last end
 
   // device-side TSV (ngsld_set_text_output)
   bool text_mode = false, have_labels = false;
@@ -184,8 +196,9 @@ struct ngsld_ctx {
   hipStream_t replay_stream = nullptr;        // non-blocking: read-backs must not wait for the next batch's kernel
   ngsld_geno_opts gopts{};
   bool normalised = false;                    // data came through ngsld_set_geno_lkl
-  DevBuf<uint32_t> d_flags[2], d_flags_dev;   // [count, pad, one bit per record ...] per pipeline slot / for ngsld_run_device
-  PinBuf<uint32_t> h_flags[2], h_flags_dev;   // host copies: they travel with the batch's records / text meta
+  DevBuf<uint32_t> d_flags[kSlots], d_flags_dev;   // [count, pad, list of the first kFlagListCap, one bit per record ...] per pipeline slot / for ngsld_run_device
+  PinBuf<uint32_t> h_flags[kSlots], h_flags_dev;   // host copies of the HEAD (count + list): they travel with the batch's records / text meta
+  PinBuf<uint32_t> h_flag_bits;                    // the bitmap, fetched only when a launch flagged more pairs than the list holds
   PinBuf<double> h_site_stage;                // plane read-back of one site (no source registered)
   DevBuf<uint64_t> d_patch_idx;
   DevBuf<ngsld_rec_std> d_patch_std;
@@ -612,21 +625,44 @@ int fetch_replay_site(ngsld_ctx *c, uint64_t s, std::vector<double> &tmp, Replay
   return NGSLD_OK;
 }
 
-// Records [0, n) of a launch whose record 0 is the plan's record `base`: every flagged one is replayed; the new records go
-// to h_std / h_ext (host buffers of the batch) or, when those are null, to d_std / d_ext on stream st (synchronised).
-// h_flags: the launch's flag buffer ([count, pad, bits ...]) in host memory.  (It travels with the batch: a copy issued
-// at this point, while the next batch's pair kernel has the device, can wait for that kernel -- measured 43 ms.)
-int replay_flagged(ngsld_ctx *c, const uint32_t *h_flags, uint64_t base, uint64_t n, ngsld_rec_std *h_std,
-                   ngsld_rec_ext *h_ext, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext, hipStream_t st) {
-  Range range_("ngsld:exact-order replay (host)");
-  const uint64_t words = (n + 31) / 32;
-  const uint32_t *bits = h_flags + 2;
-  std::vector<uint64_t> recs;
+constexpr size_t kFlagHeadBytes = (size_t)kFlagHead * sizeof(uint32_t);
+inline size_t flag_words(uint64_t n) { return (size_t)kFlagHead + (size_t)((n + 31) / 32); }
+
+// The flagged records of a launch of n records, in increasing order.  h_head: the head of its flag buffer (counter + the
+// first kFlagListCap record indices) in host memory -- it travels with the batch, or is copied on the launch's own stream
+// right behind the kernels (a copy issued later, while the next batch's pair kernel has the device, can wait for that
+// kernel: measured 43 ms).  Only a launch that flagged more pairs than the list holds has its bitmap fetched from d_flags,
+// on the replay stream (the kernels that set it are complete when this is called).
+int flagged_records(ngsld_ctx *c, const uint32_t *h_head, const uint32_t *d_flags, uint64_t n, std::vector<uint64_t> &recs) {
+  recs.clear();
+  const uint32_t count = h_head[0];
+  if (count == 0) return NGSLD_OK;
+  if (count <= kFlagListCap) {
+    const uint64_t *list = reinterpret_cast<const uint64_t *>(h_head + 2);
+    recs.assign(list, list + count);
+    std::sort(recs.begin(), recs.end());  // (the order the atomics landed in is not the record order)
+    while (!recs.empty() && recs.back() >= n) recs.pop_back();
+    return NGSLD_OK;
+  }
+  const size_t words = (size_t)((n + 31) / 32);
+  HIP_TRY(c, c->h_flag_bits.resize(words ? words : 1));
+  HIP_TRY(c, hipMemcpyAsync(c->h_flag_bits.p, d_flags + kFlagHead, words * sizeof(uint32_t), hipMemcpyDeviceToHost, c->replay_stream));
+  HIP_TRY(c, hipStreamSynchronize(c->replay_stream));
+  const uint32_t *bits = c->h_flag_bits.p;
+  recs.reserve(count);
   for (uint64_t w = 0; w < words; ++w)
     for (uint32_t m = bits[w]; m; m &= m - 1) {
       const uint64_t r = w * 32 + (uint64_t)__builtin_ctz(m);
       if (r < n) recs.push_back(r);
     }
+  return NGSLD_OK;
+}
+
+// Records `recs` (indices into a launch whose record 0 is the plan's record `base`, increasing) are replayed; the new
+// records go to h_std / h_ext (host buffers of the batch) or, when those are null, to d_std / d_ext on stream st (synchronised).
+int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t base, ngsld_rec_std *h_std,
+                   ngsld_rec_ext *h_ext, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext, hipStream_t st) {
+  Range range_("ngsld:exact-order replay (host)");
   if (recs.empty()) return NGSLD_OK;
   const int rc0 = ensure_host_items(c);
   if (rc0 != NGSLD_OK) return rc0;
@@ -635,7 +671,7 @@ int replay_flagged(ngsld_ctx *c, const uint32_t *h_flags, uint64_t base, uint64_
   std::vector<ngsld_rec_std> out_std(recs.size());
   std::vector<ngsld_rec_ext> out_ext(ext ? recs.size() : 0);
   int T = c->replay_threads > 0 ? c->replay_threads : (int)std::min<unsigned>(32u, usable_threads());
-  if ((uint64_t)T > (recs.size() + 15) / 16) T = (int)((recs.size() + 15) / 16);
+  if ((uint64_t)T > recs.size()) T = (int)recs.size();  // (a launch of 1e8 pairs flags a few dozen: sixteen per thread left them to two threads, 2.6 ms)
   std::vector<int> rcs((size_t)T, NGSLD_OK), stats((size_t)T, NGSLD_OK);
   std::vector<uint64_t> sites_done((size_t)T, 0);
   auto work = [&](int t) {
@@ -716,27 +752,25 @@ int replay_flagged(ngsld_ctx *c, const uint32_t *h_flags, uint64_t base, uint64_
 
 // A flag buffer for n records, zeroed on `stream`.
 int reset_flags(ngsld_ctx *c, DevBuf<uint32_t> &buf, uint64_t n, hipStream_t stream) {
-  const size_t words = 2 + (size_t)((n + 31) / 32);
+  const size_t words = flag_words(n);
   HIP_TRY(c, buf.resize(words));
-  HIP_TRY(c, hipMemsetAsync(buf.p, 0, words * sizeof(uint32_t), stream));
+  HIP_TRY(c, hipMemsetAsync(buf.p, 0, 2 * sizeof(uint32_t), stream));  // the counter (the list behind it needs no clearing)
+  if (words > kFlagHead)
+    HIP_TRY(c, hipMemsetAsync(buf.p + kFlagHead, 0, (words - kFlagHead) * sizeof(uint32_t), stream));
   return NGSLD_OK;
 }
 
 int finish_device_run(ngsld_ctx *c) {
   if (!c->dev_run.pending) return NGSLD_OK;
   c->dev_run.pending = false;
-  HIP_TRY(c, hipStreamSynchronize(c->dev_run.st));
-  if (!c->replay_on || c->d_flags_dev.p == nullptr) return NGSLD_OK;
-  const uint64_t base = c->h_row_off[c->dev_run.s1_begin], n = c->h_row_off[c->dev_run.s1_end] - base;
-  HIP_TRY(c, c->h_flags_dev.resize(2));
-  HIP_TRY(c, hipMemcpyAsync(c->h_flags_dev.p, c->d_flags_dev.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->dev_run.st));
-  HIP_TRY(c, hipStreamSynchronize(c->dev_run.st));
+  HIP_TRY(c, hipStreamSynchronize(c->dev_run.st));  // (the head of the flag buffer came over behind the kernels, ngsld_run_device)
+  if (!c->replay_on || c->d_flags_dev.p == nullptr || c->h_flags_dev.p == nullptr) return NGSLD_OK;
   if (c->h_flags_dev.p[0] == 0) return NGSLD_OK;
-  const size_t words = 2 + (size_t)((n + 31) / 32);
-  HIP_TRY(c, c->h_flags_dev.resize(words));
-  HIP_TRY(c, hipMemcpyAsync(c->h_flags_dev.p, c->d_flags_dev.p, words * sizeof(uint32_t), hipMemcpyDeviceToHost, c->dev_run.st));
-  HIP_TRY(c, hipStreamSynchronize(c->dev_run.st));
-  return replay_flagged(c, c->h_flags_dev.p, base, n, nullptr, nullptr, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st);
+  const uint64_t base = c->h_row_off[c->dev_run.s1_begin], n = c->h_row_off[c->dev_run.s1_end] - base;
+  std::vector<uint64_t> recs;
+  const int rcf = flagged_records(c, c->h_flags_dev.p, c->d_flags_dev.p, n, recs);
+  if (rcf != NGSLD_OK) return rcf;
+  return replay_flagged(c, recs, base, nullptr, nullptr, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st);
 }
 
 }  // namespace
@@ -787,14 +821,17 @@ int ngsld_create(int device, ngsld_ctx **out) {
   }
   if (const char *k = std::getenv("NGSLD_REPLAY")) c->replay_on = std::strcmp(k, "0") != 0;  // A/B, tests
   if (const char *k = std::getenv("NGSLD_REPLAY_THREADS")) c->replay_threads = std::atoi(k);
+  if (const char *k = std::getenv("NGSLD_RUN_DIRECT")) c->run_direct = std::strcmp(k, "0") != 0;  // A/B, tests (see ngsld_ctx)
+  if (const char *k = std::getenv("NGSLD_RUN_TAPER")) c->run_taper = std::strcmp(k, "0") != 0;
+  if (const char *k = std::getenv("NGSLD_RUN_STREAMS")) c->run_streams = std::atoi(k) >= 2 ? 2 : 1;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
-      (e = hipStreamCreate(&c->copy_stream)) != hipSuccess ||
+      (e = hipStreamCreate(&c->stream2)) != hipSuccess || (e = hipStreamCreate(&c->copy_stream)) != hipSuccess ||
       (e = hipStreamCreateWithFlags(&c->replay_stream, hipStreamNonBlocking)) != hipSuccess) {
     g_create_error = std::string("stream setup: ") + hipGetErrorString(e);
     delete c;
     return NGSLD_ERR_DEVICE;
   }
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < ngsld_ctx::kSlots; ++k) {
     (void)hipEventCreateWithFlags(&c->ev_kernel_done[k], hipEventDisableTiming);
     (void)hipEventCreateWithFlags(&c->ev_copy_done[k], hipEventDisableTiming);
   }
@@ -815,7 +852,7 @@ void ngsld_destroy(ngsld_ctx *c) {
   }
   c->d_status.release(); c->d_row_off.release(); c->d_item_off.release(); c->d_row_end.release();
   c->d_row_seed.release(); c->d_row_count.release(); c->d_keep.release(); c->d_items.release();
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < ngsld_ctx::kSlots; ++k) {
     c->d_std[k].release(); c->d_ext[k].release(); c->h_std[k].release(); c->h_ext[k].release();
     if (c->ev_kernel_done[k]) (void)hipEventDestroy(c->ev_kernel_done[k]);
     if (c->ev_copy_done[k]) (void)hipEventDestroy(c->ev_copy_done[k]);
@@ -825,6 +862,7 @@ void ngsld_destroy(ngsld_ctx *c) {
     (void)hipEventDestroy(ev.second);
   }
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->replay_stream) (void)hipStreamDestroy(c->replay_stream);
   delete c;
@@ -1120,11 +1158,13 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
   c->ev_used = 0;
   c->timed_stream = st;
+  c->timed_overlap = false;
   c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
   c->replayed_pairs = 0;
   if (c->replay_on) {
     const int rcf = reset_flags(c, c->d_flags_dev, c->timed_pairs, st);
     if (rcf != NGSLD_OK) return rcf;
+    HIP_TRY(c, c->h_flags_dev.resize(kFlagHead));
   }
   if (uses_runs(c->cfg.kernel)) {  // (one big launch: whole-row runs, whatever an earlier ngsld_run cut them to)
     const int rcr = build_runs(c, kRunItems);
@@ -1142,6 +1182,8 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
     HIP_TRY(c, timed_launch(c, a, st));
     r0 = r1;
   }
+  if (c->replay_on)  // which pairs the kernels flagged: the counter and the list come over behind them, on their stream
+    HIP_TRY(c, hipMemcpyAsync(c->h_flags_dev.p, c->d_flags_dev.p, kFlagHeadBytes, hipMemcpyDeviceToHost, st));
   c->dev_run.pending = true;
   c->dev_run.s1_begin = s1_begin;
   c->dev_run.s1_end = s1_end;
@@ -1206,19 +1248,35 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     const int rc0 = need_host_items();
     if (rc0 != NGSLD_OK) return rc0;
   }
+  // How the batches flow.  Text: two slots, one compute stream -- what limits a text run is the 150-odd bytes per pair going
+  // over PCIe.  Records: three slots and (run_streams == 2) two compute streams, batch k on stream k & 1 -- batch k + 2 is
+  // queued behind batch k, batch k + 1 runs beside it, so the CUs a draining batch leaves are taken at once (one stream:
+  // every batch of whole-row runs ends in a ~2.5 ms tail, 10 ms over the 12 batches of configs[2]) -- and either the kernels
+  // write the records into the pinned host buffers themselves (run_direct) or a D2H copy follows every batch and the batches
+  // shrink towards the end of the run (run_taper), so that what is exposed behind the last kernel is a small copy.
+  const int S = text ? 2 : ngsld_ctx::kSlots;
+  const bool direct = !text && c->run_direct;
+  const bool two_streams = !text && c->run_streams == 2;
+  c->timed_overlap = two_streams;
   struct Batch {
     uint64_t r0, r1, n;
   };
   std::vector<Batch> batches;
-  // text batches are cut four times finer: what limits a text run is the 150-odd bytes per pair going over PCIe, and
-  // smaller batches mean smaller pinned buffers and a finer kernel / copy overlap (configs[2] end to end: 2^23 pairs
-  // per batch 2.2 s, 2^21 1.5 s, 2^19 1.6 s)
+  // text batches are cut four times finer: smaller batches mean smaller pinned buffers and a finer kernel / copy overlap
+  // (configs[2] end to end: 2^23 pairs per batch 2.2 s, 2^21 1.5 s, 2^19 1.6 s)
   const uint64_t batch_pairs = text ? std::min<uint64_t>(c->batch_pairs, 1ull << 21) : c->batch_pairs;
-  for (uint64_t r0 = s1_begin; r0 < s1_end;) {
-    uint64_t r1 = r0 + 1;
-    while (r1 < s1_end && c->h_row_off[r1 + 1] - c->h_row_off[r0] <= batch_pairs) ++r1;
-    batches.push_back({r0, r1, c->h_row_off[r1] - c->h_row_off[r0]});
-    r0 = r1;
+  const bool taper = !text && !direct && c->run_taper;
+  {
+    uint64_t left = c->timed_pairs;
+    for (uint64_t r0 = s1_begin; r0 < s1_end;) {
+      uint64_t target = batch_pairs;
+      if (taper) target = std::min<uint64_t>(batch_pairs, std::max<uint64_t>(left / 3, std::min<uint64_t>(batch_pairs, 1ull << 19)));
+      uint64_t r1 = r0 + 1;
+      while (r1 < s1_end && c->h_row_off[r1 + 1] - c->h_row_off[r0] <= target) ++r1;
+      batches.push_back({r0, r1, c->h_row_off[r1] - c->h_row_off[r0]});
+      left -= std::min(left, c->h_row_off[r1] - c->h_row_off[r0]);
+      r0 = r1;
+    }
   }
   if (uses_runs(c->cfg.kernel)) {
     // every batch should be thousands of workgroups (512 run at a time): the smaller the batches, the shorter the runs.
@@ -1230,9 +1288,11 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   }
   uint64_t cap = 1;
   for (auto &b : batches) cap = std::max(cap, b.n);
-  for (int k = 0; k < 2; ++k) {
-    HIP_TRY(c, c->d_std[k].resize(cap));
-    if (ext) HIP_TRY(c, c->d_ext[k].resize(cap));
+  for (int k = 0; k < S; ++k) {
+    if (!direct) {
+      HIP_TRY(c, c->d_std[k].resize(cap));
+      if (ext) HIP_TRY(c, c->d_ext[k].resize(cap));
+    }
     if (text) {
       HIP_TRY(c, c->d_lens[k].resize(cap));
       HIP_TRY(c, c->d_offs[k].resize(cap));
@@ -1243,8 +1303,20 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       if (ext) HIP_TRY(c, c->h_ext[k].resize(cap));
     }
     if (replay) {
-      HIP_TRY(c, c->d_flags[k].resize(2 + (size_t)((cap + 31) / 32)));
-      HIP_TRY(c, c->h_flags[k].resize(2 + (size_t)((cap + 31) / 32)));
+      HIP_TRY(c, c->d_flags[k].resize(flag_words(cap)));
+      HIP_TRY(c, c->h_flags[k].resize(kFlagHead));
+    }
+  }
+  // (run_direct: the device addresses of the pinned host buffers -- the same numbers under unified addressing, asked for anyway)
+  ngsld_rec_std *dev_std[ngsld_ctx::kSlots] = {nullptr, nullptr, nullptr};
+  ngsld_rec_ext *dev_ext[ngsld_ctx::kSlots] = {nullptr, nullptr, nullptr};
+  for (int k = 0; k < S; ++k) {
+    if (direct) {
+      HIP_TRY(c, hipHostGetDevicePointer((void **)&dev_std[k], c->h_std[k].p, 0));
+      if (ext) HIP_TRY(c, hipHostGetDevicePointer((void **)&dev_ext[k], c->h_ext[k].p, 0));
+    } else {
+      dev_std[k] = c->d_std[k].p;
+      dev_ext[k] = ext ? c->d_ext[k].p : nullptr;
     }
   }
   size_t scan_bytes = 0;
@@ -1273,30 +1345,31 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     return t;
   };
   std::vector<Item> rel_items;
-  auto issue = [&](size_t bi) -> int {  // kernel on `stream`, D2H on `copy_stream`
+  std::vector<uint64_t> recs;
+  auto issue = [&](size_t bi) -> int {  // kernel on a compute stream; text: lengths behind it; records: D2H on `copy_stream`
     Range range_issue("ngsld:issue batch (pair kernel + D2H)");
-    const int k = (int)(bi & 1);
+    const int k = (int)(bi % (size_t)S);
     const Batch &b = batches[bi];
+    hipStream_t st = (two_streams && (bi & 1)) ? c->stream2 : c->stream;
     if (replay) {
-      const int rcf = reset_flags(c, c->d_flags[k], b.n, c->stream);
+      const int rcf = reset_flags(c, c->d_flags[k], b.n, st);
       if (rcf != NGSLD_OK) return rcf;
     }
-    PairArgs a = make_args(c, b.r0, b.r1, c->d_std[k].p, ext ? c->d_ext[k].p : nullptr, replay ? c->d_flags[k].p : nullptr);
-    HIP_TRY(c, timed_launch(c, a, c->stream));
-    const size_t flag_bytes = (2 + (size_t)((b.n + 31) / 32)) * sizeof(uint32_t);
-    if (replay && text)  // which pairs the kernel flagged for the exact-order replay: known to the host with the batch
-      HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, flag_bytes, hipMemcpyDeviceToHost, c->stream));
+    PairArgs a = make_args(c, b.r0, b.r1, dev_std[k], dev_ext[k], replay ? c->d_flags[k].p : nullptr);
+    HIP_TRY(c, timed_launch(c, a, st));
+    if (replay && (text || direct))  // which pairs the kernel flagged for the exact-order replay: known to the host with the batch
+      HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, kFlagHeadBytes, hipMemcpyDeviceToHost, st));
     if (text) {  // row lengths and their prefix sums right behind the pair kernel; the rows are written at consume time
-      HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), c->stream));
+      HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), st));
       const TextArgs t = text_args(b, k);
-      HIP_TRY(c, launch_text_lengths(t, c->stream));
-      HIP_TRY(c, text_scan(c->d_scan_tmp.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n, c->d_text_meta[k].p, c->stream));
-      HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                                c->stream));
-      HIP_TRY(c, hipEventRecord(c->ev_kernel_done[k], c->stream));
+      HIP_TRY(c, launch_text_lengths(t, st));
+      HIP_TRY(c, text_scan(c->d_scan_tmp.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n, c->d_text_meta[k].p, st));
+      HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipEventRecord(c->ev_kernel_done[k], st));
       return NGSLD_OK;
     }
-    HIP_TRY(c, hipEventRecord(c->ev_kernel_done[k], c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_kernel_done[k], st));
+    if (direct) return NGSLD_OK;  // (the records are in host memory when the kernel is done)
     HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_kernel_done[k], 0));
     if (b.n) {
       HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, c->d_std[k].p, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost,
@@ -1306,7 +1379,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
                                   c->copy_stream));
     }
     if (replay)  // the flags travel with the records
-      HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, flag_bytes, hipMemcpyDeviceToHost, c->copy_stream));
+      HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, kFlagHeadBytes, hipMemcpyDeviceToHost, c->copy_stream));
     HIP_TRY(c, hipEventRecord(c->ev_copy_done[k], c->copy_stream));
     return NGSLD_OK;
   };
@@ -1314,13 +1387,14 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   const bool trace = std::getenv("NGSLD_TRACE") != nullptr;  // dev: per-batch host timeline on stderr
   const auto t_run = std::chrono::steady_clock::now();
   auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run).count(); };
-  if (!batches.empty()) rc = issue(0);
+  // S - 1 batches are in flight while one is consumed: the slot of batch bi + S - 1 was last used by batch bi - 1, whose
+  // sink call has returned
+  for (size_t bi = 0; rc == NGSLD_OK && bi + 1 < (size_t)S && bi < batches.size(); ++bi) rc = issue(bi);
   for (size_t bi = 0; rc == NGSLD_OK && bi < batches.size(); ++bi) {
-    const int k = (int)(bi & 1);
+    const int k = (int)(bi % (size_t)S);
     const double t_a = now_ms();
-    if (bi + 1 < batches.size()) {
-      // slot of batch bi+1 was last used by batch bi-1, whose sink call has already returned
-      rc = issue(bi + 1);
+    if (bi + (size_t)S - 1 < batches.size()) {
+      rc = issue(bi + (size_t)S - 1);
       if (rc != NGSLD_OK) break;
     }
     const double t_b = now_ms();
@@ -1339,8 +1413,10 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       if (replay && c->h_flags[k].p[0] != 0) {
         // flagged pairs: replayed on the host, patched into the device records, and the row lengths derived again --
         // all on the copy stream, beside the next batch's pair kernel
-        const int rcr = replay_flagged(c, c->h_flags[k].p, c->h_row_off[b.r0], b.n, nullptr, nullptr, c->d_std[k].p,
-                                       ext ? c->d_ext[k].p : nullptr, c->copy_stream);
+        int rcr = flagged_records(c, c->h_flags[k].p, c->d_flags[k].p, b.n, recs);
+        if (rcr == NGSLD_OK)
+          rcr = replay_flagged(c, recs, c->h_row_off[b.r0], nullptr, nullptr, c->d_std[k].p, ext ? c->d_ext[k].p : nullptr,
+                               c->copy_stream);
         if (rcr != NGSLD_OK) return rcr;
         HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), c->copy_stream));
         const TextArgs t = text_args(b, k);
@@ -1383,11 +1459,12 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
         out.text_len = total;
       }
     } else {
-      HIP_TRY(c, hipEventSynchronize(c->ev_copy_done[k]));
-      if (trace) std::fprintf(stderr, "[trace] batch %zu: issue next %.2f..%.2f, copy done %.2f, flagged %u\n", bi, t_a, t_b, now_ms(), replay ? c->h_flags[k].p[0] : 0u);
+      HIP_TRY(c, hipEventSynchronize(direct ? c->ev_kernel_done[k] : c->ev_copy_done[k]));
+      if (trace) std::fprintf(stderr, "[trace] batch %zu (%llu pairs): issue next %.2f..%.2f, records on the host %.2f, flagged %u\n", bi, (unsigned long long)b.n, t_a, t_b, now_ms(), replay ? c->h_flags[k].p[0] : 0u);
       if (replay && c->h_flags[k].p[0] != 0) {  // flagged pairs: replayed on the host, patched into the batch's buffers
-        const int rcr = replay_flagged(c, c->h_flags[k].p, c->h_row_off[b.r0], b.n, c->h_std[k].p, ext ? c->h_ext[k].p : nullptr,
-                                       nullptr, nullptr, nullptr);
+        int rcr = flagged_records(c, c->h_flags[k].p, c->d_flags[k].p, b.n, recs);
+        if (rcr == NGSLD_OK)
+          rcr = replay_flagged(c, recs, c->h_row_off[b.r0], c->h_std[k].p, ext ? c->h_ext[k].p : nullptr, nullptr, nullptr, nullptr);
         if (rcr != NGSLD_OK) return rcr;
       }
     }
@@ -1404,6 +1481,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     if (sink(user, &out) != 0) rc = fail(c, NGSLD_ERR_SINK, "sink callback failed");
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream2));
   HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
   if (rc != NGSLD_OK) return rc;
   return check_status(c);
@@ -1414,11 +1492,13 @@ int ngsld_last_kernel_time(ngsld_ctx *c, double *total_ms, uint64_t *n_launches,
   HIP_TRY(c, hipSetDevice(c->device));
   (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
   if (c->timed_stream) HIP_TRY(c, hipStreamSynchronize(c->timed_stream));
+  if (c->timed_overlap) HIP_TRY(c, hipStreamSynchronize(c->stream2));
   double ms = 0.0;
   for (size_t k = 0; k < c->ev_used; ++k) {
     float t = 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&t, c->ev_pool[k].first, c->ev_pool[k].second));
-    ms += (double)t;
+    // launches that shared the device (two streams): the span from the first start to the last end, not the sum
+    HIP_TRY(c, hipEventElapsedTime(&t, c->timed_overlap ? c->ev_pool[0].first : c->ev_pool[k].first, c->ev_pool[k].second));
+    ms = c->timed_overlap ? std::max(ms, (double)t) : ms + (double)t;
   }
   if (total_ms) *total_ms = ms;
   if (n_launches) *n_launches = c->ev_used;
@@ -1513,9 +1593,9 @@ uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes) {
   // can get, with and without --ignore_miss_data)
   if (!pair_config(n_ind, &cfg) || !pair_config(n_ind, &cfg_masked, kChooseAuto, true)) return 0;
   if (cfg_masked.np > cfg.np) cfg.np = cfg_masked.np;
-  // per context: planes (24*np per site) + maf/mean/rsx + row tables (~64 B per site), two record slots of
+  // per context: planes (24*np per site) + maf/mean/rsx + row tables (~64 B per site), three record slots of
   // batch_pairs records, two staging chunks of 256 MiB, items; the fixed part is rounded up generously
-  const uint64_t fixed = (2ull * (1ull << 23) * (sizeof(ngsld_rec_std) + sizeof(ngsld_rec_ext))) + (768ull << 20);
+  const uint64_t fixed = ((uint64_t)ngsld_ctx::kSlots * (1ull << 23) * (sizeof(ngsld_rec_std) + sizeof(ngsld_rec_ext))) + (768ull << 20);
   const uint64_t per_ctx = budget_bytes / 2;
   if (per_ctx <= fixed) return 0;
   return (per_ctx - fixed) / (24ull * cfg.np + 64ull);

@@ -59,6 +59,11 @@ constexpr double kTieMargin = 1e-12;
 constexpr double kPearsonCond = 0x1p13;
 constexpr double kEpsilonTie = kEpsilon + kTieMargin;
 constexpr uint32_t kTieBit = 0x80000000u;  // rides on n_iter (<= 100) from the EM loop to write_pair
+// Layout of a launch's flag buffer (uint32 words): [0] count of flagged pairs, [1] unused, [2 .. 2 + 2 kFlagListCap) the
+// record indices (uint64) of the first kFlagListCap flagged pairs in the order their atomics landed, [kFlagHead ...) one bit
+// per record.  A launch of 10^8 pairs flags a few dozen: the host reads the head and never the 12 MB bitmap.
+constexpr uint32_t kFlagListCap = 4096;
+constexpr uint32_t kFlagHead = 2 + 2 * kFlagListCap;
 
 // One unit of work = ngsld_item: pairs (s1, s2_begin + c) for the bits c set in mask, records from first_record.
 typedef ngsld_item Item;
@@ -95,8 +100,10 @@ struct PairArgs {
   const uint64_t *hard_masks;  // [n_sites][4][mask_words]
   const double *hard_u;        // [n_sites] the value of the three equal likelihoods of an individual without data
   uint32_t mask_words;         // ceil(n_ind / 64)
-  // exact-order replay: flags[0] counts the flagged pairs, bit r of flags[2 + r / 32] marks record r of the output
-  // buffers (null: no flagging)
+  // exact-order replay: flags[0] counts the flagged pairs, bit r of flags[kFlagHead + r / 32] marks record r of the output
+  // buffers (null: no flagging); the first kFlagListCap of them are also listed by record index right behind the counter
+  // (flag_list(): what the host reads back is the counter and that list -- 32 KB whatever the launch's size -- and the
+  // bitmap only when more pairs were flagged than the list holds)
   uint32_t *flags;
   uint32_t flag_text;  // also flag the pairs whose printed digits (six decimals) rounding noise could change
   // tiled workgroup order of the multi-wavefront kernel (launch_pair_kernel; tile_nk == 0: workgroup i takes item i):
@@ -762,8 +769,9 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
       flag = flag || near_rounding(f0, d_abs) || near_rounding(f1, d_abs) || near_rounding(f2, d_abs) ||
              near_rounding(f3, d_abs) || near_rounding(hm0, d_abs) || near_rounding(hm1, d_abs);
     if (flag) {
-      atomicOr(&A.flags[2 + (slot >> 5)], 1u << (slot & 31u));
-      atomicAdd(&A.flags[0], 1u);
+      atomicOr(&A.flags[kFlagHead + (slot >> 5)], 1u << (slot & 31u));
+      const uint32_t k = atomicAdd(&A.flags[0], 1u);
+      if (k < kFlagListCap) reinterpret_cast<uint64_t *>(A.flags + 2)[k] = slot;
     }
   }
 }

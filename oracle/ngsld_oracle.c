@@ -815,6 +815,26 @@ void orc_print_header(FILE *fh, int extend_out) {
                      : "");
 }
 
+/* the same two printers into memory (tests: byte comparison with the reference's own fprintf lines, oracle/_ref) */
+long orc_format_header(char *buf, size_t cap, int extend_out) {
+  FILE *fh = fmemopen(buf, cap, "w");
+  if (fh == NULL) return -1;
+  orc_print_header(fh, extend_out);
+  long n = ftell(fh);
+  fclose(fh);
+  return n;
+}
+
+void orc_print_pair(FILE *fh, const orc_params *p, const orc_pair *r);
+long orc_format_pair(char *buf, size_t cap, const orc_params *p, const orc_pair *r) {
+  FILE *fh = fmemopen(buf, cap, "w");
+  if (fh == NULL) return -1;
+  orc_print_pair(fh, p, r);
+  long n = ftell(fh);
+  fclose(fh);
+  return n;
+}
+
 void orc_print_pair(FILE *fh, const orc_params *p, const orc_pair *r) {
   /* labels == NULL reproduces glibc's "(null)" for the reference's NULL labels without --pos
      (ngsLD.cpp:135, gen_func.cpp:729-731) */

@@ -12,10 +12,19 @@
  *     from /root/reference (oracle/build_ref.sh -> oracle/_ref/libngsld_ref.so; only the GSL-free part
  *     of shared/gen_func.cpp + shared/read_data.cpp can be built here, GSL is not installed and no
  *     stand-in for it is written).  Golden vectors from that build are committed under tests/golden/.
- *   - PARITY UNPINNED for what lives in ngsLD.cpp (needs GSL to compile): the window walk
- *     (calc_pair_LD), the derived statistics D/D'/r2/chi2, the TSV formats, and the Pearson r2 of
- *     expected genotypes (gsl_stats_correlation, GSL itself is absent).  These are restated from the
- *     source text / GSL's published algorithm only.
+ *   - ngsLD.cpp as a whole needs GSL to compile, but its in-tree arithmetic does not: since round 4
+ *     build_ref.sh cuts the GSL-free line ranges of calc_pair_LD out of the reference's file by anchor
+ *     and compiles them verbatim -- the s2 walk with its running dist and filters (ngsLD.cpp:240-275),
+ *     D / D' / r2 / hap_maf (:296-306), the float chi2 (:328-333), both fprintf formats (:314-351) and
+ *     the header line (:77).  orc_row / orc_pair_stats / orc_print_pair / orc_print_header are checked
+ *     BIT-FOR-BIT / BYTE-FOR-BYTE against them (tests/test_oracle_vs_ref.py: 10^5 haplotype vectors
+ *     incl. degenerate ones, 8,000 formatted rows, six filter sets), and every golden row was held to
+ *     the reference's own fprintf lines when the fixtures were generated.
+ *   - PARITY UNPINNED at the GSL boundary only: the Pearson r2 of expected genotypes
+ *     (gsl_stats_correlation, ngsLD.cpp:365-367) and the --rnd_sample draws (gsl_rng_taus,
+ *     ngsLD.cpp:69-70,165-166,277).  GSL is absent from /root/reference and from the image; both are
+ *     restated from GSL's published algorithms (the generator reproduces GSL's published self-test
+ *     value, the correlation is held to the textbook formula at 1e-12).
  */
 #ifndef NGSLD_ORACLE_H
 #define NGSLD_ORACLE_H
@@ -130,6 +139,8 @@ uint64_t orc_row_end(const orc_params *p, uint64_t s1);
 /* --- text --- */
 void orc_print_header(FILE *fh, int extend_out);
 void orc_print_pair(FILE *fh, const orc_params *p, const orc_pair *r);
+long orc_format_header(char *buf, size_t cap, int extend_out);
+long orc_format_pair(char *buf, size_t cap, const orc_params *p, const orc_pair *r);
 
 #ifdef __cplusplus
 }

@@ -103,6 +103,12 @@ def lib() -> C.CDLL:
         L.orc_bench.argtypes = [C.POINTER(OrcParams), C.c_uint64, C.c_uint64, c_double_p, C.POINTER(C.c_uint64)]
         L.orc_row_end.restype = C.c_uint64
         L.orc_row_end.argtypes = [C.POINTER(OrcParams), C.c_uint64]
+        L.orc_pair_stats.restype = None
+        L.orc_pair_stats.argtypes = [c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_float)]
+        L.orc_format_header.restype = C.c_long
+        L.orc_format_header.argtypes = [C.c_char_p, C.c_size_t, C.c_int]
+        L.orc_format_pair.restype = C.c_long
+        L.orc_format_pair.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(OrcParams), C.c_void_p]
         _lib = L
     return _lib
 
@@ -136,6 +142,17 @@ def ref():
         R.ref_read_dist.argtypes = [C.c_char_p, C.c_int, C.c_uint64, c_double_p]
         R.ref_read_labels.restype = C.c_uint64
         R.ref_read_labels.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_uint64, C.c_uint64]
+        if hasattr(R, "ref_pair_stats"):   # the GSL-free lines of ngsLD.cpp (build_ref.sh cuts them out by anchor)
+            R.ref_pair_stats.restype = None
+            R.ref_pair_stats.argtypes = [c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_float)]
+            R.ref_format_row.restype = C.c_long
+            R.ref_format_row.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p, C.c_double, C.c_double, c_double_p,
+                                         C.c_uint64, C.c_double, C.c_double, C.c_uint64, C.c_int]
+            R.ref_print_header.restype = C.c_long
+            R.ref_print_header.argtypes = [C.c_char_p, C.c_size_t, C.c_int]
+            R.ref_walk.restype = C.c_uint64
+            R.ref_walk.argtypes = [C.c_uint64, c_double_p, c_double_p, C.c_uint64, C.c_uint64, C.c_double, C.c_uint64,
+                                   C.POINTER(C.c_uint64), c_double_p, C.c_uint64]
         if hasattr(R, "ref_bench_haplo_freq"):
             R.ref_bench_haplo_freq.restype = C.c_uint64
             R.ref_bench_haplo_freq.argtypes = [c_double_p, c_double_p, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64,

@@ -2,9 +2,10 @@
  * ref_shim.cpp -- extern "C" doors into the REFERENCE's own functions (test infrastructure).
  *
  * This file is appended by oracle/build_ref.sh to a translation unit made of the reference's
- * shared/gen_func.{hpp,cpp} and shared/read_data.{hpp,cpp}, read where they lie under
- * /root/reference at build time (never copied into the repo), so every function called below is the
- * reference's code, compiled here.  The shim itself adds no arithmetic except the flat <-> jagged
+ * shared/gen_func.{hpp,cpp}, shared/read_data.{hpp,cpp}, shared/threadpool.h, ngsLD.hpp (GSL lines dropped) and the
+ * GSL-free line ranges of ngsLD.cpp that build_ref.sh wraps into ref_walk_row / ref_pair_stats / ref_format_row /
+ * ref_print_header -- all read where they lie under /root/reference at build time (never copied into the repo), so
+ * every function called below is the reference's code, compiled here.  The shim itself adds no arithmetic except the flat <-> jagged
  * array plumbing and, in ref_preprocess, the one expression of ngsLD.cpp:113 (p1 + 2*p2) that lives
  * in main() and cannot be compiled without GSL.
  *
@@ -20,6 +21,22 @@ static double **ref_rows(const double *flat, uint64_t n) {
 }
 
 extern "C" {
+
+/* The s2 walk of calc_pair_LD (ngsLD.cpp:240-275, compiled verbatim into ref_walk_row by build_ref.sh) for row `site`, from
+ * flat arguments: the `params` the reference's lines read is filled here (verbose = 0: labels and expected genotypes are
+ * not touched).  Returns the number of pairs that pass the distance / SNP-count / maf filters; their s2 and running dist. */
+uint64_t ref_walk(uint64_t n_sites, double *pos_dist, double *maf, uint64_t max_kb_dist, uint64_t max_snp_dist,
+                  double min_maf, uint64_t site, uint64_t *out_s2, double *out_dist, uint64_t cap) {
+  params pars;
+  memset(&pars, 0, sizeof(pars));
+  pars.n_sites = n_sites;
+  pars.pos_dist = pos_dist;
+  pars.maf = maf;
+  pars.max_kb_dist = max_kb_dist;
+  pars.max_snp_dist = max_snp_dist;
+  pars.min_maf = min_maf;
+  return ref_walk_row(&pars, site, out_s2, out_dist, cap);
+}
 
 double ref_logsum(double *a, uint64_t n) { return logsum(a, n); }
 void ref_post_prob(double *pp, double *lkl, uint64_t n) { post_prob(pp, lkl, NULL, n); }

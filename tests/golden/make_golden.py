@@ -6,11 +6,16 @@ outputs.  Which code produced which expected field:
 
   * `ref_*` fields  -- the REFERENCE's own functions, compiled from /root/reference by oracle/build_ref.sh
                        (read_geno binary branch, est_maf, conv_space, haplo_freq, read_dist, labels):
-                       reader hash, maf, hap[4], n_iter, n_ind_data, pos_dist, labels.
-  * `orc_*` fields  -- the CPU oracle (oracle/ngsld_oracle.c), for what cannot be built from the reference
-                       here because it needs GSL (ngsLD.cpp): the pair walk (s1, s2, dist), r2_ExpG (Pearson),
-                       D, D', r2, chi2 and the TSV text.  The script asserts oracle == reference bit for bit
-                       on every `ref_*` field before it writes anything.
+                       reader hash, maf, hap[4], n_iter, n_ind_data, pos_dist, labels -- and, since round 4, the
+                       GSL-free LINES of ngsLD.cpp compiled from where they lie (build_ref.sh cuts them out by
+                       anchor): the s2 walk with its running dist (ngsLD.cpp:240-275; fixtures without
+                       --rnd_sample), D, D', r2, hap_maf (:296-306), the float chi2 (:328-333) and every TSV row
+                       through the reference's own fprintf lines (:314-351; r2_ExpG is the one value that
+                       enters them from the oracle).
+  * `orc_*` fields  -- the CPU oracle (oracle/ngsld_oracle.c).  Only r2_ExpG (gsl_stats_correlation: GSL is not
+                       in the image) and the --rnd_sample draws (gsl_rng_taus) have no reference-compiled twin;
+                       every other `orc_*` field is kept next to its `ref_*` twin and the script asserts
+                       oracle == reference bit for bit before it writes anything.
 
 No reference source text is stored; the fixtures hold inputs and numbers only.
 """
@@ -157,6 +162,35 @@ def make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max
     assert np.array_equal(hap, rec["hap"], equal_nan=True), "EM: oracle != reference haplo_freq"
     assert np.array_equal(n_iter, rec["n_iter"]) and np.array_equal(n_data, rec["n_ind_data"])
 
+    # ---- ngsLD.cpp's own lines (compiled by build_ref.sh): D / D' / r2 / hap_maf / chi2 of every pair, the s2 walk ----
+    def bits(a):
+        a = np.ascontiguousarray(a)
+        return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+    stats = np.empty((len(rec), 5))
+    chi2 = np.empty(len(rec), dtype=np.float32)
+    for k in range(len(rec)):
+        c = C.c_float()
+        R.ref_pair_stats(orc.dp(np.ascontiguousarray(hap[k])), orc.dp(stats[k, 0:1]), orc.dp(stats[k, 1:2]),
+                         orc.dp(stats[k, 2:3]), orc.dp(stats[k, 3:5]), C.byref(c))
+        chi2[k] = c.value
+    for col, got in (("D", stats[:, 0]), ("Dp", stats[:, 1]), ("r2", stats[:, 2]), ("hap_maf", stats[:, 3:5]), ("chi2", chi2)):
+        assert np.array_equal(bits(rec[col].copy()), bits(got.copy())), f"{col}: oracle != the reference's lines"
+    ref_walk = None
+    if rnd_sample >= 1:
+        pdw = np.ascontiguousarray(o.pos_dist.copy())
+        mafw = np.ascontiguousarray(maf.copy())
+        s2buf, dbuf = np.empty(n_sites, dtype=np.uint64), np.empty(n_sites)
+        ws1, ws2, wd = [], [], []
+        for s1 in range(n_sites):
+            n = R.ref_walk(n_sites, orc.dp(pdw), orc.dp(mafw), max_kb, max_snp, float(min_maf), s1,
+                           s2buf.ctypes.data_as(C.POINTER(C.c_uint64)), orc.dp(dbuf), n_sites)
+            ws1 += [s1] * n
+            ws2 += list(s2buf[:n])
+            wd += list(dbuf[:n])
+        ref_walk = (np.array(ws1, dtype=np.uint64), np.array(ws2, dtype=np.uint64), np.array(wd, dtype=np.float64))
+        assert np.array_equal(ref_walk[0], rec["s1"]) and np.array_equal(ref_walk[1], rec["s2"]), "walk: oracle != reference"
+        assert np.array_equal(bits(ref_walk[2]), bits(rec["dist"].copy())), "dist: oracle != reference"
+
     fx = dict(
         raw=raw, geno_text=np.array(gtext if gtext is not None else ""),
         text_mode=np.array(text_mode if text_mode is not None else ""),
@@ -172,6 +206,11 @@ def make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max
         ref_labels=np.array(ref_labels if ref_labels is not None else [], dtype=str),
         orc_s1=rec["s1"], orc_s2=rec["s2"], orc_dist=rec["dist"], orc_r2pear=rec["r2pear"], orc_D=rec["D"],
         orc_Dp=rec["Dp"], orc_r2=rec["r2"], orc_hap_maf=rec["hap_maf"], orc_chi2=rec["chi2"],
+        ref_D=stats[:, 0].copy(), ref_Dp=stats[:, 1].copy(), ref_r2=stats[:, 2].copy(), ref_hap_maf=stats[:, 3:5].copy(),
+        ref_chi2=chi2,
+        ref_walk_s1=ref_walk[0] if ref_walk else np.zeros(0, dtype=np.uint64),
+        ref_walk_s2=ref_walk[1] if ref_walk else np.zeros(0, dtype=np.uint64),
+        ref_walk_dist=ref_walk[2] if ref_walk else np.zeros(0),
     )
     if with_text:
         flags = ["--max_kb_dist", str(max_kb), "--max_snp_dist", str(max_snp), "--min_maf", repr(min_maf)]
@@ -189,6 +228,19 @@ def make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max
             txt = run_cli(raw, ptxt, flags + extra, header, gtext)
             lines = txt.splitlines(keepends=True)
             body = "".join(sorted(lines[1:]))
+            # every row (and the header) once more through the reference's OWN fprintf lines (ngsLD.cpp:77, :314-351)
+            buf = C.create_string_buffer(4096)
+            n = R.ref_print_header(buf, 4096, int(tag == "ext"))
+            assert buf.raw[:n].decode() == lines[0], "header: oracle != the reference's fprintf"
+            assert len(lines) - 1 == len(rec)
+            for k, r in enumerate(rec):
+                l1 = ref_labels[r["s1"]] if ref_labels is not None else None
+                l2 = ref_labels[r["s2"]] if ref_labels is not None else None
+                n = R.ref_format_row(buf, 4096, l1.encode() if l1 is not None else None, l2.encode() if l2 is not None else None,
+                                     float(r["dist"]), float(r["r2pear"]), orc.dp(np.ascontiguousarray(hap[k])),
+                                     int(n_data[k]), float(maf[r["s1"]]), float(maf[r["s2"]]), int(n_iter[k]), int(tag == "ext"))
+                assert buf.raw[:n].decode() == lines[1 + k], f"row {k}: oracle != the reference's fprintf"
+            fx[f"ref_tsv_{tag}_rows_equal"] = np.array(True)
             fx[f"orc_tsv_{tag}_header"] = np.array(lines[0])
             fx[f"orc_tsv_{tag}_md5"] = np.array(hashlib.md5((lines[0] + body).encode()).hexdigest())
             if len(rec) <= 3000:

@@ -1,6 +1,8 @@
 """The oracle against the committed golden vectors (CPU).  `ref_*` fields were produced by the reference's
-own compiled functions (tests/golden/make_golden.py), so this pins the oracle wherever the reference can
-be built; `orc_*` fields freeze the oracle's own output for the unpinned parts (ngsLD.cpp needs GSL)."""
+own compiled functions and -- D / D' / r2 / hap_maf / chi2, the s2 walk, the TSV rows -- by the GSL-free lines of
+ngsLD.cpp compiled from where they lie (tests/golden/make_golden.py, oracle/build_ref.sh), so this pins the oracle
+wherever the reference can be built; the `orc_*` fields without a `ref_*` twin (r2_ExpG: gsl_stats_correlation, and
+the --rnd_sample draws: gsl_rng_taus) freeze the oracle's own output for the one unpinned dependency, GSL."""
 import hashlib
 import subprocess
 import tempfile
@@ -29,10 +31,22 @@ def test_oracle_reproduces_golden(name):
     # reference-pinned EM
     assert np.array_equal(rec["hap"], fx["ref_hap"], equal_nan=True)
     assert np.array_equal(rec["n_iter"], fx["ref_n_iter"]) and np.array_equal(rec["n_ind_data"], fx["ref_n_ind_data"])
-    # frozen oracle output (unpinned parts)
+    # reference-pinned statistics: ngsLD.cpp:296-306 and :328-333, compiled from the reference's text -- bit for bit
+    def bits(a):
+        a = np.ascontiguousarray(a)
+        return a.view(np.uint64 if a.dtype == np.float64 else np.uint32)
+    for col, key in (("D", "ref_D"), ("Dp", "ref_Dp"), ("r2", "ref_r2"), ("hap_maf", "ref_hap_maf"), ("chi2", "ref_chi2")):
+        assert np.array_equal(bits(rec[col].copy()), bits(fx[key])), col
+    # reference-pinned walk (ngsLD.cpp:240-275): which pairs, and their running distance
+    if float(fx["rnd_sample"]) >= 1:
+        assert np.array_equal(rec["s1"], fx["ref_walk_s1"]) and np.array_equal(rec["s2"], fx["ref_walk_s2"])
+        assert np.array_equal(bits(rec["dist"].copy()), bits(fx["ref_walk_dist"]))
+    # frozen oracle output (r2_ExpG is the unpinned one: GSL; the rest repeats the reference-pinned fields above)
     for col, key in (("dist", "orc_dist"), ("r2pear", "orc_r2pear"), ("D", "orc_D"), ("Dp", "orc_Dp"), ("r2", "orc_r2"),
                      ("hap_maf", "orc_hap_maf"), ("chi2", "orc_chi2")):
         assert np.array_equal(rec[col], fx[key], equal_nan=True), col
+    if "orc_tsv_std_md5" in fx:   # the generator held every TSV row to the reference's own fprintf lines (ngsLD.cpp:314-351)
+        assert bool(fx["ref_tsv_std_rows_equal"]) and bool(fx["ref_tsv_ext_rows_equal"])
 
 
 @pytest.mark.parametrize("name", [n for n in fixtures() if "orc_tsv_std_md5" in Fixture(n)])
