@@ -210,7 +210,12 @@ int ngsld_run_device(ngsld_ctx *ctx, uint64_t s1_begin, uint64_t s1_end, void *d
 /* After ngsld_run_device on a caller's stream: waits for that stream, replays the flagged pairs and patches the device
  * records (exact-order replay, above).  A context has ONE pending device run: the next ngsld_run_device, ngsld_run,
  * ngsld_plan or ngsld_set_geno_* finishes it first (as this call would), so a flagged record is never left with the
- * kernels' own value.  A no-op after a run on the ctx's own stream (hip_stream == NULL does all of it before returning). */
+ * kernels' own value.  A no-op after a run on the ctx's own stream (hip_stream == NULL does all of it before returning).
+ * BUFFER LIFETIME: the replay of a pending run reads the matrix it was started with -- through the registered replay source
+ * or matrix (ngsld_set_replay_source / ngsld_set_replay_matrix) -- at the moment the run is finished, whoever finishes it.
+ * Keep that host array (or what the callback reads) valid and UNCHANGED until ngsld_finish_device, or the call that
+ * finishes the run implicitly, has returned: refilling the buffer with the next matrix before ngsld_set_geno_* would have
+ * the old run's flagged records recomputed from the new values, silently. */
 int ngsld_finish_device(ngsld_ctx *ctx);
 
 /* Timing of the pair kernel launches issued by the last ngsld_run / ngsld_run_device, measured with

@@ -692,7 +692,8 @@ int main(int argc, char **argv) {
   timing_report.mark("pair kernels + text + write");
   if (rc == NGSLD_ERR_MAF_RANGE) error("haplo_freq", ngsld_last_error(ctx));
   if (rc != NGSLD_OK) error("ngsld_run", ngsld_last_error(ctx));
-  if (pars.verbose >= 1) {  // (a large share means pairs computed at the host's speed: two nearly monomorphic sites each)
+  if (pars.verbose >= 2) {  // (level 1 is the reference's default: its stderr stays what the reference prints.  A large share
+                            // here means pairs computed at the host's speed: two nearly monomorphic sites each)
     uint64_t rp = 0, rsites = 0;
     ngsld_replay_stats(ctx, &rp, &rsites);
     fprintf(stderr, "==> %lu of %lu pairs replayed in the reference's operation order\n", (unsigned long)rp,

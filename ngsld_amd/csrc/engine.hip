@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -114,6 +116,69 @@ struct PinBuf {
     n = 0;
   }
 };
+// A few parked host threads for the exact-order replay: a launch of 1e8 pairs flags a few dozen pairs, 0.2 ms of arithmetic
+// each -- spawning a thread per pair cost more than the pairs (0.6 ms of a 1.1 ms ngsld_finish_device).  Threads are created
+// on first use and live as long as the context; run(T, fn) executes fn(0 .. T-1), fn(0) on the calling thread.
+class ReplayPool {
+ public:
+  ~ReplayPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : threads_) t.join();
+  }
+  template <typename F>
+  void run(int T, F &&fn) {
+    if (T <= 1) {
+      fn(0);
+      return;
+    }
+    while ((int)threads_.size() < T - 1) {
+      const int id = (int)threads_.size() + 1;
+      threads_.emplace_back([this, id] { loop(id); });
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      job_ = [&fn](int t) { fn(t); };
+      n_ = T;
+      left_ = T - 1;
+      ++epoch_;
+    }
+    cv_.notify_all();
+    fn(0);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [this] { return left_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  void loop(int id) {
+    uint64_t seen = 0;
+    for (;;) {
+      std::function<void(int)> job;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+        if (stop_) return;
+        seen = epoch_;
+        if (id >= n_) continue;  // (this job uses fewer threads)
+        job = job_;
+      }
+      job(id);
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--left_ == 0) done_.notify_all();
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  std::function<void(int)> job_;
+  int n_ = 0, left_ = 0;
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+};
 }  // namespace
 
 struct ngsld_ctx {
@@ -145,6 +210,8 @@ struct ngsld_ctx {
   std::vector<Item> h_items;  // host copy for the sink (which pairs each record belongs to)
   std::vector<uint64_t> h_run_off;  // run kernel: runs before each row
   uint64_t run_len = 0;             // items per run the list was cut with (0: no list)
+  std::vector<uint64_t> run_ends;   // ... and the launch boundaries (rows) whose tails it was shaped for
+  int n_cus = 256;                  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   DevBuf<Run> d_runs;
   DevBuf<uint64_t> d_row_off, d_item_off, d_row_seed, d_row_count;
   DevBuf<uint32_t> d_row_end;
@@ -157,25 +224,34 @@ struct ngsld_ctx {
   int kernel_choice = kChooseAuto;
   uint32_t pairs_per_item = 16;
   uint64_t batch_pairs = 1ull << 23;
+  bool batch_pairs_set = false;  // by the caller (ngsld_set_tuning / NGSLD_BATCH_PAIRS): taken as it is
 
-  // batch pipeline: kSlots record slots (text batches use two of them)
+  // batch pipeline: three slots for record batches, two of them for text batches
   static constexpr int kSlots = 3;
   DevBuf<ngsld_rec_std> d_std[kSlots];
   DevBuf<ngsld_rec_ext> d_ext[kSlots];
   PinBuf<ngsld_rec_std> h_std[kSlots];
   PinBuf<ngsld_rec_ext> h_ext[kSlots];
   hipEvent_t ev_kernel_done[kSlots] = {nullptr, nullptr, nullptr}, ev_copy_done[kSlots] = {nullptr, nullptr, nullptr};
-  // how record batches reach the host (ngsld_run without text output; NGSLD_RUN_DIRECT / NGSLD_RUN_STREAMS / NGSLD_RUN_TAPER):
+  // how record batches reach the host (ngsld_run without text output; NGSLD_RUN_DIRECT / NGSLD_RUN_TAPER):
   //   run_direct   the pair kernels write the records straight into the batch's pinned host buffers over the host link
-  //                (72 B per pair at 2e8 pairs/s is 15 GB/s of posted writes) -- there is no device copy of them and no
-  //                D2H copy behind the last kernel
-  //   run_streams  2: consecutive batches go to two streams, so the workgroups of batch k+1 fill the CUs the last
-  //                workgroups of batch k leave (a batch of whole-row runs drains for ~2.5 ms: 12 batches, 10 ms)
-  //   run_taper    batches shrink towards the end of a run (a third of what is left, at least 2^19 pairs), so that the copy
-  //                exposed behind the last kernel is small
-  bool run_direct = false, run_taper = true;
-  int run_streams = 2;
-  bool timed_overlap = false;  // the launches of the last run overlapped: their time is first start .. last end
+  //                (72 B per pair at 2e8 pairs/s is 15 GB/s of posted writes; same-box A/B, profiles/r04/sink_ab.txt: the
+  //                kernels take the same time) -- there is no device copy of the records and no D2H copy behind the last
+  //                kernel.  Off: device buffers + a D2H copy per batch, and
+  //   run_taper    the batches shrink towards the end of a run (a third of what is left, at least 2^19 pairs), so that the
+  //                copy exposed behind the last kernel is small
+  //   run_streams  1: one compute stream, every batch drains alone -- its last rows cut into short runs (build_runs), which
+  //                takes the loss from 1.4 to ~0.4 ms per launch.  2 (opt-in, NGSLD_RUN_STREAMS=2): consecutive record
+  //                batches on two compute streams HALF A BATCH OUT OF PHASE (the first batch is half a batch), so that
+  //                whenever one stream's batch drains the other is in the middle of its own and fills the slots that fall
+  //                free.  Measured on four boxes (profiles/r04/sink_rr*.txt, host-resident rate over the device-resident
+  //                one, round robin in one process): 1.006 / 0.984 / 0.990 at 2^22 pairs per batch, 0.982 / 0.986 at 2^23 --
+  //                when the dispatcher interleaves the two queues well it beats ONE launch, when it does not it loses to
+  //                one stream (0.987-0.993): not the default.  (In phase -- equal batches on both, first tried -- the device
+  //                shares itself evenly, both drain together: 501 ms on two streams, 500 on one, 484 as one launch.)
+  bool run_direct = true, run_taper = true;
+  int run_streams = 1;
+  bool timed_overlap = false;  // the launches of the last run shared the device: their time is first start .. last end
 
   // device-side TSV (ngsld_set_text_output)
   bool text_mode = false, have_labels = false;
@@ -206,6 +282,7 @@ struct ngsld_ctx {
   DevBuf<char> d_scan_tmp2;                   // text lengths re-derived after a patch, beside the next batch's scan
   uint64_t replayed_pairs = 0, replayed_sites = 0;
   int replay_threads = 0;                     // 0 = min(32, the threads the process may really use)
+  ReplayPool replay_pool;
   struct {
     bool pending = false;
     uint64_t s1_begin = 0, s1_end = 0;
@@ -709,15 +786,8 @@ int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t bas
       rcs[(size_t)t] = NGSLD_ERR_NOMEM;
     }
   };
-  if (T <= 1) {
-    T = 1;
-    work(0);
-  } else {
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto &x : th) x.join();
-  }
+  if (T < 1) T = 1;
+  c->replay_pool.run(T, work);
   for (int t = 0; t < T; ++t) {
     if (rcs[(size_t)t] != NGSLD_OK)
       return fail(c, rcs[(size_t)t], rcs[(size_t)t] == NGSLD_ERR_SINK ? "the replay source callback failed"
@@ -777,7 +847,7 @@ int finish_device_run(ngsld_ctx *c) {
 
 extern "C" {
 
-const char *ngsld_version(void) { return "ngsld-amd 0.1.0 (gfx950; reference ngsLD 1.2.1)"; }
+const char *ngsld_version(void) { return "ngsld-amd 0.2.0 (gfx950; reference ngsLD 1.2.1)"; }
 
 int ngsld_create(int device, ngsld_ctx **out) {
   if (out == nullptr) return NGSLD_ERR_INVALID;
@@ -806,6 +876,7 @@ int ngsld_create(int device, ngsld_ctx **out) {
   ngsld_ctx *c = new (std::nothrow) ngsld_ctx();
   if (c == nullptr) return NGSLD_ERR_NOMEM;
   c->device = device;
+  if (prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount;
   if (const char *k = std::getenv("NGSLD_PAIR_KERNEL")) {
     // "multi": several wavefronts per pair from 513 individuals on; "ab": 513..1024 individuals on ONE wavefront per pair, EM
     // step in its a/b form (pair_config picks between them, and the ten-slot run kernel, by measurement); "stream": beyond
@@ -817,7 +888,10 @@ int ngsld_create(int device, ngsld_ctx **out) {
   }
   if (const char *k = std::getenv("NGSLD_BATCH_PAIRS")) {  // tests: many small batches through ngsld_run
     const uint64_t v = std::strtoull(k, nullptr, 10);
-    if (v > 0) c->batch_pairs = v;
+    if (v > 0) {
+      c->batch_pairs = v;
+      c->batch_pairs_set = true;
+    }
   }
   if (const char *k = std::getenv("NGSLD_REPLAY")) c->replay_on = std::strcmp(k, "0") != 0;  // A/B, tests
   if (const char *k = std::getenv("NGSLD_REPLAY_THREADS")) c->replay_threads = std::atoi(k);
@@ -914,19 +988,44 @@ int ngsld_set_pos_dist(ngsld_ctx *c, const double *pos_dist) try {
 // (16 items = 1,024 candidates: a whole 100 kb row) is what the pair kernel likes best in one big launch; a run that goes
 // out in SMALL batches -- text batches are 2^21 pairs, i.e. only four rounds of such workgroups on 512 slots, each batch
 // ending in a ragged tail -- is cut finer (ngsld_run).  NGSLD_RUN_LEN overrides (tuning / A-B).
-static int build_runs(ngsld_ctx *c, uint64_t run_len) {
+//
+// Tails.  A launch of equal workgroups of length L ends in a drain: the device's 2 x CUs workgroup slots finish evenly over
+// the last L (2.5 ms for whole-row runs at n_ind 500), i.e. L / 2 of the whole device is lost per launch -- 1.4 ms,
+// measured: 12 launches of configs[2] take 500 ms, one launch 484 (profiles/r04/sink_ab.txt).  The rows at the END of every
+// launch are therefore cut into short runs (run_len / 8): as many of them as fill that triangle (CUs x one full run of
+// pairs), so that every slot that falls free during the drain still finds work and all of them end within one short
+// workgroup of each other.  `launch_ends` = the rows (exclusive, increasing) at which the launches this list is for end.
+// NGSLD_TAIL_LEN=0 turns the shaping off, NGSLD_TAIL_PAIRS / NGSLD_TAIL_LEN override its two numbers (A/B).
+// (Also tried, round 4: the FIRST rows of a launch in runs of mixed lengths, so that the workgroups that start together do
+// not turn over together for their first generations -- no gain, 0.9884 against 0.9894 of the device-resident rate,
+// profiles/r04/sink_rr3.txt: dropped.)
+static int build_runs(ngsld_ctx *c, uint64_t run_len, const std::vector<uint64_t> &launch_ends) {
   if (const char *e = getenv("NGSLD_RUN_LEN")) {
     const long v = atol(e);
     if (v >= 1) run_len = (uint64_t)v;
   }
   run_len = std::max<uint64_t>(1, std::min<uint64_t>(run_len, kRunItems));
-  if (c->run_len == run_len) return NGSLD_OK;
+  if (c->run_len == run_len && c->run_ends == launch_ends) return NGSLD_OK;
   const uint64_t n = c->n_sites;
+  uint64_t tail_len = std::max<uint64_t>(1, run_len / 8);
+  uint64_t tail_pairs = (uint64_t)c->n_cus * run_len * item_span(c->cfg, c->pairs_per_item);
+  if (const char *e = getenv("NGSLD_TAIL_LEN")) tail_len = (uint64_t)std::max(0l, atol(e));
+  if (const char *e = getenv("NGSLD_TAIL_PAIRS")) tail_pairs = std::strtoull(e, nullptr, 10);
+  std::vector<uint8_t> in_tail(n, 0);
+  if (tail_len > 0 && tail_len < run_len) {
+    uint64_t begin = 0;
+    for (const uint64_t end : launch_ends) {
+      if (end > n || end < begin) continue;
+      for (uint64_t s1 = end; s1 > begin && c->h_row_off[end] - c->h_row_off[s1 - 1] <= tail_pairs; --s1) in_tail[s1 - 1] = 1;
+      begin = end;
+    }
+  }
   std::vector<Run> runs;
   c->h_run_off.assign(n + 1, 0);
   for (uint64_t s1 = 0; s1 < n; ++s1) {
     const uint64_t i0 = c->h_item_off[s1], m = c->h_item_off[s1 + 1] - i0;
-    const uint64_t parts = (m + run_len - 1) / run_len;
+    const uint64_t len = in_tail[s1] ? tail_len : run_len;
+    const uint64_t parts = (m + len - 1) / len;
     for (uint64_t q = 0; q < parts; ++q) {
       const uint64_t b = i0 + m * q / parts, e = i0 + m * (q + 1) / parts;
       runs.push_back(Run{(uint32_t)b, (uint32_t)(e - b)});
@@ -938,6 +1037,7 @@ static int build_runs(ngsld_ctx *c, uint64_t run_len) {
   if (!runs.empty())
     HIP_TRY(c, hipMemcpy(c->d_runs.p, runs.data(), runs.size() * sizeof(Run), hipMemcpyHostToDevice));
   c->run_len = run_len;
+  c->run_ends = launch_ends;
   return NGSLD_OK;
 }
 
@@ -1005,9 +1105,7 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
   c->n_items = c->h_item_off[n];
   if (uses_runs(c->cfg.kernel)) {
     if (c->n_items > 0xffffffffull) return fail(c, NGSLD_ERR_UNSUPPORTED, "more than 2^32 work items in one plan");
-    c->run_len = 0;  // (new items: whatever list there was is stale)
-    const int rcr = build_runs(c, kRunItems);
-    if (rcr != NGSLD_OK) return rcr;
+    c->run_len = 0;  // (new items: whatever list there was is stale; the new one is cut once the rows' pair counts are known)
   }
   HIP_TRY(c, c->d_row_end.resize(n));
   HIP_TRY(c, c->d_keep.resize(n));
@@ -1056,6 +1154,10 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
   HIP_TRY(c, launch_items(ia, c->stream));
   c->h_items.clear();  // the host copy is fetched on demand by ngsld_run (the sink needs it, ngsld_run_device does not)
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (uses_runs(c->cfg.kernel)) {  // the run list of one launch over the whole plan (ngsld_run_device; ngsld_run cuts its own)
+    const int rcr = build_runs(c, kRunItems, std::vector<uint64_t>{n});
+    if (rcr != NGSLD_OK) return rcr;
+  }
   c->planned = true;
   if (n_pairs) *n_pairs = c->h_row_off[n];
   return NGSLD_OK;
@@ -1166,16 +1268,21 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
     if (rcf != NGSLD_OK) return rcf;
     HIP_TRY(c, c->h_flags_dev.resize(kFlagHead));
   }
-  if (uses_runs(c->cfg.kernel)) {  // (one big launch: whole-row runs, whatever an earlier ngsld_run cut them to)
-    const int rcr = build_runs(c, kRunItems);
-    if (rcr != NGSLD_OK) return rcr;
-  }
   // one launch per <= 2^31-1 workgroups; rows are cut so that each launch's grid fits
   const uint64_t max_items = 0x7ffffff0ull;
-  uint64_t r0 = s1_begin;
-  while (r0 < s1_end) {
+  std::vector<uint64_t> cuts;  // rows at which the launches end
+  for (uint64_t r0 = s1_begin; r0 < s1_end;) {
     uint64_t r1 = r0 + 1;
     while (r1 < s1_end && c->h_item_off[r1 + 1] - c->h_item_off[r0] <= max_items) ++r1;
+    cuts.push_back(r1);
+    r0 = r1;
+  }
+  if (uses_runs(c->cfg.kernel)) {  // (big launches: whole-row runs, whatever an earlier ngsld_run cut them to, short ones at each launch's end)
+    const int rcr = build_runs(c, kRunItems, cuts);
+    if (rcr != NGSLD_OK) return rcr;
+  }
+  uint64_t r0 = s1_begin;
+  for (const uint64_t r1 : cuts) {
     PairArgs a = make_args(c, r0, r1, (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, c->replay_on ? c->d_flags_dev.p : nullptr);
     a.out_base = c->h_row_off[s1_begin];
     a.flag_text = 0;  // these records stay on the device: only numerically ill-conditioned pairs are replayed
@@ -1248,15 +1355,14 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     const int rc0 = need_host_items();
     if (rc0 != NGSLD_OK) return rc0;
   }
-  // How the batches flow.  Text: two slots, one compute stream -- what limits a text run is the 150-odd bytes per pair going
-  // over PCIe.  Records: three slots and (run_streams == 2) two compute streams, batch k on stream k & 1 -- batch k + 2 is
-  // queued behind batch k, batch k + 1 runs beside it, so the CUs a draining batch leaves are taken at once (one stream:
-  // every batch of whole-row runs ends in a ~2.5 ms tail, 10 ms over the 12 batches of configs[2]) -- and either the kernels
-  // write the records into the pinned host buffers themselves (run_direct) or a D2H copy follows every batch and the batches
-  // shrink towards the end of the run (run_taper), so that what is exposed behind the last kernel is a small copy.
-  const int S = text ? 2 : ngsld_ctx::kSlots;
+  // How the batches flow: two slots, the kernel of batch k + 1 runs while batch k is consumed.  Text: the rows are formatted
+  // on the device and copied.  Records: the pair kernels write them straight into the slot's pinned host buffers
+  // (run_direct; nothing is left to copy behind the last kernel; twice the pairs per batch, half the launches), or into
+  // device buffers with a D2H copy per batch, the batches then shrinking towards the end of the run (run_taper).
+  // NGSLD_RUN_STREAMS=2: three slots, two compute streams half a batch out of phase (see ngsld_ctx).
   const bool direct = !text && c->run_direct;
   const bool two_streams = !text && c->run_streams == 2;
+  const int S = two_streams ? ngsld_ctx::kSlots : 2;
   c->timed_overlap = two_streams;
   struct Batch {
     uint64_t r0, r1, n;
@@ -1264,12 +1370,16 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   std::vector<Batch> batches;
   // text batches are cut four times finer: smaller batches mean smaller pinned buffers and a finer kernel / copy overlap
   // (configs[2] end to end: 2^23 pairs per batch 2.2 s, 2^21 1.5 s, 2^19 1.6 s)
-  const uint64_t batch_pairs = text ? std::min<uint64_t>(c->batch_pairs, 1ull << 21) : c->batch_pairs;
+  // (records written by the kernels themselves: every launch costs ~0.4 ms of drain and nothing has to be staged on the
+  // device, so the batches are twice the size -- 2 x 1.2 GB of pinned host memory with the extended record)
+  const uint64_t batch_pairs = text ? std::min<uint64_t>(c->batch_pairs, 1ull << 21)
+                                    : ((direct && !c->batch_pairs_set) ? 2 * c->batch_pairs : c->batch_pairs);
   const bool taper = !text && !direct && c->run_taper;
   {
     uint64_t left = c->timed_pairs;
     for (uint64_t r0 = s1_begin; r0 < s1_end;) {
       uint64_t target = batch_pairs;
+      if (two_streams && batches.empty()) target = batch_pairs / 2;  // (the phase shift between the two streams)
       if (taper) target = std::min<uint64_t>(batch_pairs, std::max<uint64_t>(left / 3, std::min<uint64_t>(batch_pairs, 1ull << 19)));
       uint64_t r1 = r0 + 1;
       while (r1 < s1_end && c->h_row_off[r1 + 1] - c->h_row_off[r0] <= target) ++r1;
@@ -1283,7 +1393,9 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     // configs[2] as text (48 batches of 2^21 pairs): 16 items per run 0.82 s for this loop, 8 0.72 s, 4 0.70 s
     uint64_t want = kRunItems;
     while (want > 2 && want * item_span(c->cfg, c->pairs_per_item) * 8192 > batch_pairs) want /= 2;
-    const int rcr = build_runs(c, want);
+    std::vector<uint64_t> ends;  // every batch is a launch: its last rows go out as short runs (build_runs)
+    for (auto &b : batches) ends.push_back(b.r1);
+    const int rcr = build_runs(c, want, ends);
     if (rcr != NGSLD_OK) return rcr;
   }
   uint64_t cap = 1;
@@ -1357,7 +1469,10 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     }
     PairArgs a = make_args(c, b.r0, b.r1, dev_std[k], dev_ext[k], replay ? c->d_flags[k].p : nullptr);
     HIP_TRY(c, timed_launch(c, a, st));
-    if (replay && (text || direct))  // which pairs the kernel flagged for the exact-order replay: known to the host with the batch
+    // which pairs the kernel flagged for the exact-order replay (counter + list, 32 KB): known to the host with the batch.
+    // On the kernel's own stream, right behind it: on the copy stream, behind the records, this small copy took 9 ms per
+    // batch -- it goes through a copy kernel, and that waited for the next batch's pair kernel to leave it a CU
+    if (replay)
       HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, kFlagHeadBytes, hipMemcpyDeviceToHost, st));
     if (text) {  // row lengths and their prefix sums right behind the pair kernel; the rows are written at consume time
       HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), st));
@@ -1378,8 +1493,6 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
         HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, c->d_ext[k].p, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost,
                                   c->copy_stream));
     }
-    if (replay)  // the flags travel with the records
-      HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, kFlagHeadBytes, hipMemcpyDeviceToHost, c->copy_stream));
     HIP_TRY(c, hipEventRecord(c->ev_copy_done[k], c->copy_stream));
     return NGSLD_OK;
   };
@@ -1525,7 +1638,10 @@ int ngsld_set_tuning(ngsld_ctx *c, uint32_t pairs_per_item, uint64_t batch_pairs
     c->pairs_per_item = pairs_per_item;
     c->planned = false;
   }
-  if (batch_pairs) c->batch_pairs = batch_pairs;
+  if (batch_pairs) {
+    c->batch_pairs = batch_pairs;
+    c->batch_pairs_set = true;
+  }
   return NGSLD_OK;
 }
 

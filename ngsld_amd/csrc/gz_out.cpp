@@ -65,7 +65,13 @@ void drain_pipe(ngsld_gz *g) {
   for (;;) {
     const ssize_t r = ::read(g->fd_read, scratch.data(), scratch.size());
     if (r == 0) break;
-    if (r < 0 && errno != EINTR) break;
+    if (r < 0 && errno != EINTR) {
+      // the pipe cannot be read any more: close the read end, so that a producer blocked in write() on the full pipe gets
+      // EPIPE (SIGPIPE is the caller's to ignore or handle) instead of waiting for a reader that has gone
+      ::close(g->fd_read);
+      g->fd_read = -1;
+      break;
+    }
   }
 }
 
@@ -208,7 +214,7 @@ int ngsld_host_gz_close(ngsld_gz *g) {
   g->reader.join();
   for (auto &w : g->workers) w.join();
   g->writer.join();
-  ::close(g->fd_read);
+  if (g->fd_read >= 0) ::close(g->fd_read);
   const bool bad = g->failed || ::close(g->fd_out) != 0;
   delete g;
   return bad ? NGSLD_ERR_INVALID : NGSLD_OK;

@@ -731,7 +731,10 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
   const double rr = D / sqrt(hm0 * hm1 * (1 - hm0) * (1 - hm1));
   // a constant site (rsx = 1/sqrt(0) = inf) is 0/0 = NaN in gsl_stats_correlation; said explicitly because a cross
   // moment centred after the fact (run kernel) is only ~0 there, not exactly 0.
-  const double a1 = rsx1, a2 = rsx2;
+  // (a negative rsx: a site with a triple that does not sum to 1 whose alleles the kernels relabelled -- their Pearson moment
+  // assumes e' = 2 - e there: ld_prep.hip, signed_rsx; such pairs are replayed)
+  const double a1 = fabs(rsx1), a2 = fabs(rsx2);
+  const bool odd_site = rsx1 < 0 || rsx2 < 0;
   const bool constant_site = a1 == __builtin_inf() || a2 == __builtin_inf();
   const double r = constant_site ? __builtin_nan("") : sxy * a1 * a2;
   ngsld_rec_std o;
@@ -751,7 +754,7 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
     const double q0 = fabs(hm0) <= fabs(1 - hm0) ? fabs(hm0) : fabs(1 - hm0);
     const double q1 = fabs(hm1) <= fabs(1 - hm1) ? fabs(hm1) : fabs(1 - hm1);
     // (NaN frequencies fail both comparisons)
-    bool flag = tie || !(q0 >= kReplayBelow) || !(q1 >= kReplayBelow) ||
+    bool flag = tie || odd_site || !(q0 >= kReplayBelow) || !(q1 >= kReplayBelow) ||
                 (!constant_site && (double)A.n_ind * a1 * a2 > kPearsonCond);  // (a constant site: NaN on every path)
     // The TSV prints six decimals (ngsLD.cpp:314-349).  A value that sits on a rounding point of the sixth decimal --
     // closer to it than this kernel and the reference can differ -- would print a different last digit, and a D within
@@ -1907,7 +1910,7 @@ constexpr int kBresTailSlots = 20;                      // beyond: 20 blocks per
 //   kRunAB  one wavefront per pair, EM step in its a/b form, run pipeline (ld_pair_ab.hip: 641..960)
 //   kMulti  2 / 4 / 8 wavefronts per pair: P form (pair_ld_kernel, 5..10 per lane, 961..5,120) or a/b form (pair_ld_abm_kernel,
 //           9..15 per lane with the row slice in registers: most of 1,281..7,680 -- pair_config has the table)
-//   kStream any n_ind: the candidate's vector (its first 9,216 individuals beyond 10,240) in registers, the row vector -- or,
+//   kStream any n_ind: the candidate's vector (its first 10,240 individuals beyond that many) in registers, the row vector -- or,
 //           with cfg.waves == 4 (NGSLD_PAIR_KERNEL=stream), both -- re-read every iteration
 //   kHard   every likelihood triple of the matrix is a called genotype or "no data": the pairs' 16 genotype-combination
 //           counts replace the individuals (any n_ind up to kHardMaxInd)

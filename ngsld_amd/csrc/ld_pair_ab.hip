@@ -412,7 +412,7 @@ __global__ __launch_bounds__(512, 2) void pair_ld_ab_kernel(PairArgs A) {
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// Several wavefronts per pair, a/b form (every individual counts; 11 .. 13 slots per lane): where the P form would need
+// Several wavefronts per pair, a/b form (every individual counts; 9 .. 15 slots per lane, as pair_config picks them): where the P form would need
 // twice the wavefronts -- 1,281..1,664 individuals on two, 2,561..3,328 on four, 5,121..6,656 on eight instead of four /
 // eight / the streaming kernel.  Item form as pair_ld_kernel: one workgroup per item of 64 candidates; the wavefront's slice
 // of the ROW vector sits in registers for the whole item (already relabelled), the first kAbLand slots of the next

@@ -23,7 +23,7 @@ hipError_t launch_pair_bres(int slots, bool masked, const PairArgs &a, hipStream
   // (planes padded to the next 64 individuals and no further: the kernel relies on the cohort ending inside the last block)
   if (a.n_items > 0x7fffffffull || a.np % 64u != 0 || a.n_ind > a.np || a.np - a.n_ind >= 64u || slots < kBresMinSlots)
     return hipErrorInvalidValue;
-  if (slots > kBresMaxSlots) {  // more than 10,240 individuals: 8,192 of them resident, the rest streamed
+  if (slots > kBresMaxSlots) {  // more than 10,240 individuals: 10,240 of them resident (kBresTailSlots = 20 blocks of 64 in each of eight wavefronts), the rest streamed
     if (masked)
       hipLaunchKernelGGL((pair_ld_bres_kernel<kBresTailSlots, true, true>), dim3((unsigned)a.n_items), dim3(512), 0, stream, a);
     else

@@ -169,6 +169,15 @@ __device__ __forceinline__ PrepFlags prep_flags(const PrepArgs &A) {
 // mean that value itself rather than a rounded sum / n.
 // (rsx = +inf there: NaN on every path.  Nearly constant sites are dealt with per PAIR: ld_device.h, kPearsonCond.)
 __device__ __forceinline__ double site_rsx(double sq) { return 1.0 / sqrt(sq); }  // sq = sum (e - mean)^2
+// The pair kernels relabel the alleles of a site whose frequency is above 1/2 (ld_device.h, Relabel) and take the Pearson
+// moment from the relabelled expected genotypes, 2 - e -- which is what p1 + 2 p0 is only if every triple sums to 1.  The
+// reference's own chain leaves triples that do not: all-zero natural-scale input comes out as 0.3247 three times (the
+// log-sum at -1e15 rounds log 3 to 1.125), and ngsld_set_geno_lkl takes whatever the caller normalised.  A site that holds
+// such a triple AND would be relabelled says so in the SIGN of its rsx: write_pair takes the magnitude and flags every pair
+// of the site for the exact-order replay (r2_ExpG would be off in the second decimal otherwise).
+constexpr double kSumTol = 0x1p-40;
+__device__ __forceinline__ bool odd_triple(double a0, double a1, double a2) { return !(fabs((a0 + a1 + a2) - 1.0) <= kSumTol); }
+__device__ __forceinline__ double signed_rsx(double rsx, bool odd, double maf) { return (odd && maf > 0.5 - 1e-9) ? -rsx : rsx; }
 
 // n_ind <= 2048: one WAVEFRONT per site, a lane holds the expected genotypes of its <= MAXJ individuals in registers -- no
 // barrier, no second pass over the planes (the workgroup-per-site form re-read them twice and met ten times per site).
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256) void prep_sites_wave_kernel(PrepArgs A) {
     double e[MAXJ];
     double num = 0.0, den = 0.0, esum = 0.0;
     double mn = __builtin_inf(), mx = -__builtin_inf();
-    bool nan_seen = false;
+    bool nan_seen = false, odd = false;
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
       const uint32_t i = (uint32_t)lane + 64u * (uint32_t)j;
@@ -198,6 +207,7 @@ __global__ __launch_bounds__(256) void prep_sites_wave_kernel(PrepArgs A) {
             a1 = g1;
             a2 = g2;
           }
+          odd = odd || odd_triple(a0, a1, a2);
           const double ev = fma(2.0, a2, a1);  // expected genotype, ngsLD.cpp:113
           e[j] = ev;
           esum += ev;
@@ -224,10 +234,12 @@ __global__ __launch_bounds__(256) void prep_sites_wave_kernel(PrepArgs A) {
       sq = fma(d, d, sq);
     }
     sq = wave_sum1(sq);
+    const bool any_odd = __ballot(odd) != 0;
     if (lane == 0) {
-      A.maf[A.site0 + site] = A.normalised_input ? A.maf_in[site] : num / den;
+      const double maf = A.normalised_input ? A.maf_in[site] : num / den;
+      A.maf[A.site0 + site] = maf;
       A.mean_e[A.site0 + site] = mean;
-      A.rsx[A.site0 + site] = site_rsx(sq);
+      A.rsx[A.site0 + site] = signed_rsx(site_rsx(sq), any_odd, maf);
     }
     if (nan_seen) atomicExch(A.status, (int)NGSLD_ERR_NAN);
   }
@@ -243,7 +255,7 @@ __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
     double *__restrict__ pl = A.planes + (A.site0 + site) * A.site_stride;
     double acc[3] = {0.0, 0.0, 0.0};  // num, den (est_maf), sum of expected genotypes
     double mn[1] = {__builtin_inf()}, mx[1] = {-__builtin_inf()};
-    bool nan_seen = false;
+    bool nan_seen = false, odd = false;
     for (uint32_t i = threadIdx.x; i < A.np; i += 256) {
       double a0 = 0.0, a1 = 0.0, a2 = 0.0;
       if (i < A.n_ind) {
@@ -255,6 +267,7 @@ __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
           a1 = g1;
           a2 = g2;
         }
+        odd = odd || odd_triple(a0, a1, a2);
         const double ev = fma(2.0, a2, a1);  // expected genotype, ngsLD.cpp:113
         acc[2] += ev;
         mn[0] = ev < mn[0] ? ev : mn[0];
@@ -273,10 +286,12 @@ __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
       sq[0] = fma(d, d, sq[0]);
     }
     block_sum<1>(sq, sh1);
+    const bool any_odd = __syncthreads_or(odd ? 1 : 0) != 0;
     if (threadIdx.x == 0) {
-      A.maf[A.site0 + site] = A.normalised_input ? A.maf_in[site] : acc[0] / acc[1];
+      const double maf = A.normalised_input ? A.maf_in[site] : acc[0] / acc[1];
+      A.maf[A.site0 + site] = maf;
       A.mean_e[A.site0 + site] = mean;
-      A.rsx[A.site0 + site] = site_rsx(sq[0]);
+      A.rsx[A.site0 + site] = signed_rsx(site_rsx(sq[0]), any_odd, maf);
     }
     if (nan_seen) atomicExch(A.status, (int)NGSLD_ERR_NAN);
   }

@@ -158,6 +158,7 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
 
   std::thread loader([&]() {
     uint64_t maf_done = 0;  // maf_out[0, maf_done) is final
+    int hard_job = -1;      // kernel family of the job, fixed by its first slab: 1 = genotype-combination kernel, 0 = per individual
     for (uint64_t k = 0; k < n_slabs; ++k) {
       const int b = (int)(k & 1);
       {
@@ -180,9 +181,23 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
         // same bits).  Known in advance for one kind of job: --call_geno with N_thresh == call_thresh (the default, 0 and
         // 0) leaves every triple either called or "no data" (gen_func.cpp:886-914: below N_thresh -> missing, at or
         // above call_thresh -> called, nothing in between), so every slab qualifies, as the resident run does.
+        // "Every slab qualifies" is checked, not assumed: a triple the classification rejects after all (a NaN under text
+        // semantics sets no NaN status) would put ONE slab on the per-individual kernels.  The first slab fixes the job's
+        // family; if it does not qualify, every later slab is told to stay per individual too; a later slab that disagrees
+        // with a first slab that did qualify ends the job with an error (its predecessors' records are already out).
         ngsld_geno_opts so = *opts;
-        if (!(opts->call_geno && opts->N_thresh == opts->call_thresh)) so.per_individual_only = 1;
+        if (!(opts->call_geno && opts->N_thresh == opts->call_thresh) || hard_job == 0) so.per_individual_only = 1;
         r = ngsld_set_geno_raw_opts(ctx[b], host[b].data(), m, n_ind, &so);
+        if (r == NGSLD_OK && !so.per_individual_only) {
+          const bool is_hard = std::strcmp(ngsld_pair_kernel(ctx[b]), "hard") == 0;
+          if (hard_job < 0) {
+            hard_job = is_hard ? 1 : 0;
+          } else if (hard_job == 1 && !is_hard) {
+            r = NGSLD_ERR_INVALID;
+            msg = "a slab of this --call_geno job holds a likelihood triple that is neither a called genotype nor missing data "
+                  "(NaN?), after earlier slabs ran on the genotype-combination kernel: rerun with NGSLD_HARD_KERNEL=0";
+          }
+        }
         // exact-order replay: the slab's raw values stay in host[b] until its run is over
         if (r == NGSLD_OK) r = ngsld_set_replay_matrix(ctx[b], host[b].data());
         if (r == NGSLD_OK) r = ngsld_set_pos_dist(ctx[b], pos_dist ? pos_dist + sl.row_begin : nullptr);
@@ -208,7 +223,7 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
           // device-side TSV: the slab's sites carry their own labels (set after the matrix, which resets it)
           if (r == NGSLD_OK && text_output) r = ngsld_set_text_output(ctx[b], labels ? labels + sl.row_begin : nullptr, 1);
         }
-        if (r != NGSLD_OK) msg = ngsld_last_error(ctx[b]);
+        if (r != NGSLD_OK && msg.empty()) msg = ngsld_last_error(ctx[b]);
       }
       } catch (...) {
         r = NGSLD_ERR_NOMEM;

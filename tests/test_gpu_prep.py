@@ -29,6 +29,37 @@ def _special_matrix(n_sites, n_ind, seed):
     return raw
 
 
+@pytest.mark.parametrize("n_ind", [24, 100, 500, 700, 1000, 2500, 6000])
+@pytest.mark.parametrize("ignore_miss", [False, True])
+def test_unnormalised_triples_at_a_relabelled_site(n_ind, ignore_miss):
+    """All-zero natural-scale triples leave the reference's chain as 0.3247 three times: they do not sum to 1.  At a site
+    whose allele frequency is above 1/2 the pair kernels relabel the alleles and take the Pearson moment from 2 - e, which
+    such a triple breaks (r2_ExpG off in the second decimal): those sites carry a sign in their rsx and their pairs are
+    replayed.  Sites 2 and 9 here have maf > 1/2 AND all-zero triples -- as row site and as candidate of every kernel family;
+    site 5 has the triples with maf < 1/2 (no relabelling, no replay needed)."""
+    n_sites = 24
+    raw = synth.make_gl_numpy(n_sites, n_ind, 8100 + n_ind, depth=6.0)
+    for s in (2, 9):
+        raw[s] = raw[s, :, ::-1]                        # swap genotypes 0 and 2: frequency 1 - q
+        raw[s, 1::5] = 0.0
+    raw[5, ::4] = 0.0
+    o = orc.Oracle(raw, ignore_miss_data=ignore_miss, n_threads=8)
+    assert o.maf[2] > 0.5 and o.maf[9] > 0.5 and o.maf[5] < 0.5
+    want = o.run()
+    eng = capi.Engine(0)
+    try:
+        eng.set_geno_raw(raw, ignore_miss_data=ignore_miss)
+        eng.set_pos_dist(None)
+        assert eng.plan(ignore_miss_data=ignore_miss) == len(want)
+        s1, s2, std, ext = eng.run()
+        replayed = eng.replay_stats()[0]
+    finally:
+        eng.close()
+    check_records(std, ext, want)
+    touched = int(np.sum((want["s1"] == 2) | (want["s2"] == 2) | (want["s1"] == 9) | (want["s2"] == 9)))
+    assert replayed >= touched                         # every pair of the two relabelled sites went through the replay
+
+
 @pytest.mark.parametrize("n_ind", [24, 100, 500, 700, 1500, 2500])
 @pytest.mark.parametrize("ignore_miss", [False, True])
 def test_fast_path_and_chain_agree_with_the_reference(n_ind, ignore_miss):
