@@ -39,3 +39,13 @@ def test_first_rows_of_the_large_cohort_configurations_equal_the_oracle(which, r
     assert d["n_iter_equal"] and d["sample_size_equal"] and d["within_tolerances"]
     assert max(d[k] for k in d if k.startswith("max_abs_diff_")) <= 1e-9
     print(f"every pair of the first {rows} rows of {which}:", {k: d[k] for k in d if k.startswith("max_abs_diff_") or k.startswith("pairs")})
+
+
+def test_first_rows_of_the_headline_configuration_equal_the_oracle():
+    """configs[2] -- the configuration the metric is quoted on: 100,000 x 500, 100 kb window, the run kernel at eight slots --
+    every pair of its first 3,000 rows (~3.0e6 pairs, ~10 s of oracle): nIter / sample_size exact, the rest within 1e-9."""
+    d = _parity("c2", "3000")
+    assert d["pair_kernel"] == "run" and d["pairs"] >= 2_900_000 and d["pairs_and_order_equal"]
+    assert d["n_iter_equal"] and d["sample_size_equal"] and d["within_tolerances"]
+    assert max(d[k] for k in d if k.startswith("max_abs_diff_")) <= 1e-9
+    print("every pair of the first 3,000 rows of configs[2]:", {k: d[k] for k in d if k.startswith("max_abs_diff_") or k.startswith("pairs")})
