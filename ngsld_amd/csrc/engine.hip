@@ -256,12 +256,13 @@ struct ngsld_ctx {
   // device-side TSV (ngsld_set_text_output)
   bool text_mode = false, have_labels = false;
   uint64_t max_label = 6;  // "(null)"
-  DevBuf<char> d_labels, d_text[2], d_scan_tmp;
-  DevBuf<uint64_t> d_label_off, d_lens[2], d_offs[2], d_text_meta[2];  // meta: {total bytes, needs_host}
+  DevBuf<char> d_labels, d_text[kSlots], d_scan_tmp;
+  DevBuf<uint64_t> d_label_off, d_lens[kSlots], d_offs[kSlots], d_text_meta[kSlots];  // meta: {total bytes, needs_host}
   DevBuf<double> d_cum;
   DevBuf<uint32_t> d_infc;
-  PinBuf<char> h_text[2];
-  PinBuf<uint64_t> h_text_meta[2];
+  PinBuf<char> h_text[kSlots];
+  PinBuf<uint64_t> h_text_meta[kSlots];
+  std::thread reserve_thread;  // ngsld_reserve_text_buffers: pins h_text[0..1] in the background; joined before their first use
 
   // exact-order replay of the pairs the kernels flag (replay.h)
   bool replay_on = true;
@@ -279,7 +280,8 @@ struct ngsld_ctx {
   DevBuf<uint64_t> d_patch_idx;
   DevBuf<ngsld_rec_std> d_patch_std;
   DevBuf<ngsld_rec_ext> d_patch_ext;
-  DevBuf<char> d_scan_tmp2;                   // text lengths re-derived after a patch, beside the next batch's scan
+  DevBuf<char> d_scan_tmp2;                   // prefix sums taken again after a patch changed a row's length, beside the next batch's scan
+  DevBuf<uint32_t> d_patch_s1, d_patch_s2;    // sites of the patched records (their rows' lengths are derived again)
   uint64_t replayed_pairs = 0, replayed_sites = 0;
   int replay_threads = 0;                     // 0 = min(32, the threads the process may really use)
   ReplayPool replay_pool;
@@ -703,6 +705,12 @@ int fetch_replay_site(ngsld_ctx *c, uint64_t s, std::vector<double> &tmp, Replay
 }
 
 constexpr size_t kFlagHeadBytes = (size_t)kFlagHead * sizeof(uint32_t);
+// Rows per text batch (ngsld_run; a smaller NGSLD_BATCH_PAIRS / ngsld_set_tuning wins).  Round 4, configs[2] end to end on one
+// box (profiles/r04/e2e_batch_size.txt): 2^21 1.42-1.46 s, 2^20 1.25-1.35 s, 2^19 1.23-1.25 s -- the loop itself takes the
+// same 0.62 s whatever the count (a batch costs ~0.3 ms since its last rows go out as short runs and a replayed row no longer
+// has every length derived again), while the two pinned buffers (2 x 400 MB at 2^21) cost 0.1 s to pin -- beside the matrix
+// upload, which they slow -- and 0.06 s to give back.
+constexpr uint64_t kTextBatchPairs = 1ull << 19;
 inline size_t flag_words(uint64_t n) { return (size_t)kFlagHead + (size_t)((n + 31) / 32); }
 
 // The flagged records of a launch of n records, in increasing order.  h_head: the head of its flag buffer (counter + the
@@ -738,7 +746,8 @@ int flagged_records(ngsld_ctx *c, const uint32_t *h_head, const uint32_t *d_flag
 // Records `recs` (indices into a launch whose record 0 is the plan's record `base`, increasing) are replayed; the new
 // records go to h_std / h_ext (host buffers of the batch) or, when those are null, to d_std / d_ext on stream st (synchronised).
 int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t base, ngsld_rec_std *h_std,
-                   ngsld_rec_ext *h_ext, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext, hipStream_t st) {
+                   ngsld_rec_ext *h_ext, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext, hipStream_t st,
+                   std::vector<uint32_t> *sites1 = nullptr, std::vector<uint32_t> *sites2 = nullptr) {
   Range range_("ngsld:exact-order replay (host)");
   if (recs.empty()) return NGSLD_OK;
   const int rc0 = ensure_host_items(c);
@@ -747,6 +756,8 @@ int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t bas
   const bool ign = c->params.ignore_miss_data != 0;
   std::vector<ngsld_rec_std> out_std(recs.size());
   std::vector<ngsld_rec_ext> out_ext(ext ? recs.size() : 0);
+  if (sites1) sites1->assign(recs.size(), 0);  // (the pairs' sites, for callers that format the replayed rows again)
+  if (sites2) sites2->assign(recs.size(), 0);
   int T = c->replay_threads > 0 ? c->replay_threads : (int)std::min<unsigned>(32u, usable_threads());
   if ((uint64_t)T > recs.size()) T = (int)recs.size();  // (a launch of 1e8 pairs flags a few dozen: sixteen per thread left them to two threads, 2.6 ms)
   std::vector<int> rcs((size_t)T, NGSLD_OK), stats((size_t)T, NGSLD_OK);
@@ -766,6 +777,8 @@ int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t bas
           rcs[(size_t)t] = NGSLD_ERR_INVALID;
           return;
         }
+        if (sites1) (*sites1)[k] = s1;
+        if (sites2) (*sites2)[k] = s2;
         if (s1 != row_site) {
           const int rc = fetch_replay_site(c, s1, tmp, &row);
           if (rc != NGSLD_OK) { rcs[(size_t)t] = rc; return; }
@@ -915,12 +928,13 @@ int ngsld_create(int device, ngsld_ctx **out) {
 
 void ngsld_destroy(ngsld_ctx *c) {
   if (c == nullptr) return;
+  if (c->reserve_thread.joinable()) c->reserve_thread.join();
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_rsx.release(); c->d_sc4.release(); c->d_runs.release();
   c->d_hard_masks.release(); c->d_hard_u.release(); c->d_all_hard.release();
   c->d_labels.release(); c->d_scan_tmp.release(); c->d_label_off.release(); c->d_cum.release(); c->d_infc.release();
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < ngsld_ctx::kSlots; ++k) {
     c->d_text[k].release(); c->d_lens[k].release(); c->d_offs[k].release(); c->d_text_meta[k].release();
     c->h_text[k].release(); c->h_text_meta[k].release();
   }
@@ -1199,6 +1213,18 @@ int ngsld_set_text_output(ngsld_ctx *c, const char *const *labels, int enable) t
   return NGSLD_OK;
 } NGSLD_CATCH(c)
 
+int ngsld_reserve_text_buffers(ngsld_ctx *c, uint64_t bytes_per_row) try {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (c->reserve_thread.joinable()) c->reserve_thread.join();
+  if (bytes_per_row == 0) return NGSLD_OK;
+  const uint64_t bytes_per_batch = bytes_per_row * std::min<uint64_t>(c->batch_pairs, kTextBatchPairs);
+  c->reserve_thread = std::thread([c, bytes_per_batch] {
+    if (hipSetDevice(c->device) != hipSuccess) return;
+    for (int k = 0; k < 2; ++k) (void)c->h_text[k].resize(bytes_per_batch);  // (a failure here is found again, and reported, at first use)
+  });
+  return NGSLD_OK;
+} NGSLD_CATCH(c)
+
 int ngsld_set_replay_source(ngsld_ctx *c, ngsld_read_sites_fn read, void *user) {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "set the genotype data before its replay source");
@@ -1322,6 +1348,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
   c->replayed_pairs = 0;
   const bool replay = c->replay_on;
+  if (c->reserve_thread.joinable()) c->reserve_thread.join();  // (ngsld_reserve_text_buffers: h_text[] is this thread's again)
 
   // Device-side TSV: the dist column needs prefix sums of pos_dist that are EXACT (the host writer adds the gaps one
   // by one, ngsLD.cpp:241), i.e. integer gaps as read_dist produces them; otherwise the batches go out as records.
@@ -1362,17 +1389,18 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   // NGSLD_RUN_STREAMS=2: three slots, two compute streams half a batch out of phase (see ngsld_ctx).
   const bool direct = !text && c->run_direct;
   const bool two_streams = !text && c->run_streams == 2;
+  // (text with THREE slots, two batches queued ahead, measured no different from two: the compute stream does not run dry,
+  // profiles/r04/e2e_timeline.txt -- and a third of the pinned memory less to allocate and give back)
   const int S = two_streams ? ngsld_ctx::kSlots : 2;
-  c->timed_overlap = two_streams;
   struct Batch {
     uint64_t r0, r1, n;
   };
   std::vector<Batch> batches;
-  // text batches are cut four times finer: smaller batches mean smaller pinned buffers and a finer kernel / copy overlap
-  // (configs[2] end to end: 2^23 pairs per batch 2.2 s, 2^21 1.5 s, 2^19 1.6 s)
+  // text batches are cut sixteen times finer: smaller batches mean smaller pinned buffers and a finer kernel / copy overlap
+  // (kTextBatchPairs; round 1, configs[2] end to end: 2^23 pairs per batch 2.2 s, 2^21 1.5 s)
   // (records written by the kernels themselves: every launch costs ~0.4 ms of drain and nothing has to be staged on the
   // device, so the batches are twice the size -- 2 x 1.2 GB of pinned host memory with the extended record)
-  const uint64_t batch_pairs = text ? std::min<uint64_t>(c->batch_pairs, 1ull << 21)
+  const uint64_t batch_pairs = text ? std::min<uint64_t>(c->batch_pairs, kTextBatchPairs)
                                     : ((direct && !c->batch_pairs_set) ? 2 * c->batch_pairs : c->batch_pairs);
   const bool taper = !text && !direct && c->run_taper;
   {
@@ -1408,8 +1436,8 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     if (text) {
       HIP_TRY(c, c->d_lens[k].resize(cap));
       HIP_TRY(c, c->d_offs[k].resize(cap));
-      HIP_TRY(c, c->d_text_meta[k].resize(2));
-      HIP_TRY(c, c->h_text_meta[k].resize(2));
+      HIP_TRY(c, c->d_text_meta[k].resize(3));  // {total bytes, needs_host, a replayed row changed its length}
+      HIP_TRY(c, c->h_text_meta[k].resize(3));
     } else {
       HIP_TRY(c, c->h_std[k].resize(cap));
       if (ext) HIP_TRY(c, c->h_ext[k].resize(cap));
@@ -1458,6 +1486,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   };
   std::vector<Item> rel_items;
   std::vector<uint64_t> recs;
+  std::vector<uint32_t> rep_s1, rep_s2;
   auto issue = [&](size_t bi) -> int {  // kernel on a compute stream; text: lengths behind it; records: D2H on `copy_stream`
     Range range_issue("ngsld:issue batch (pair kernel + D2H)");
     const int k = (int)(bi % (size_t)S);
@@ -1529,15 +1558,30 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
         int rcr = flagged_records(c, c->h_flags[k].p, c->d_flags[k].p, b.n, recs);
         if (rcr == NGSLD_OK)
           rcr = replay_flagged(c, recs, c->h_row_off[b.r0], nullptr, nullptr, c->d_std[k].p, ext ? c->d_ext[k].p : nullptr,
-                               c->copy_stream);
+                               c->copy_stream, &rep_s1, &rep_s2);
         if (rcr != NGSLD_OK) return rcr;
-        HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), c->copy_stream));
-        const TextArgs t = text_args(b, k);
-        HIP_TRY(c, launch_text_lengths(t, c->copy_stream));
-        HIP_TRY(c, text_scan(c->d_scan_tmp2.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n, c->d_text_meta[k].p, c->copy_stream));
-        HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                                  c->copy_stream));
-        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+        // Only the replayed rows' lengths are derived again (replay_flagged left their record indices in d_patch_idx); the
+        // prefix sums are taken again only if one of them changed -- a full length pass + scan beside the next batch's pair
+        // kernel cost that kernel ~1 ms of every 11 (profiles/r04/e2e_timeline.txt)
+        if (!recs.empty()) {
+          HIP_TRY(c, c->d_patch_s1.resize(recs.size()));
+          HIP_TRY(c, c->d_patch_s2.resize(recs.size()));
+          HIP_TRY(c, hipMemcpyAsync(c->d_patch_s1.p, rep_s1.data(), recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
+          HIP_TRY(c, hipMemcpyAsync(c->d_patch_s2.p, rep_s2.data(), recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
+          HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p + 2, 0, sizeof(uint64_t), c->copy_stream));
+          const TextArgs t = text_args(b, k);
+          HIP_TRY(c, launch_text_relength(t, c->d_patch_idx.p, c->d_patch_s1.p, c->d_patch_s2.p, recs.size(), c->d_text_meta[k].p + 2,
+                                          c->copy_stream));
+          HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                    c->copy_stream));
+          HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+          if (c->h_text_meta[k].p[2] != 0) {
+            HIP_TRY(c, text_scan(c->d_scan_tmp2.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n, c->d_text_meta[k].p, c->copy_stream));
+            HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                      c->copy_stream));
+            HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+          }
+        }
       }
       const uint64_t total = c->h_text_meta[k].p[0];
       bool needs_host = (c->h_text_meta[k].p[1] & 0xffffffffull) != 0;

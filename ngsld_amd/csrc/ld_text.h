@@ -29,6 +29,10 @@ struct TextArgs {
 // pass 1: the byte length of every row; pass 2 (after the prefix sums): the rows themselves
 hipError_t launch_text_lengths(const TextArgs &a, hipStream_t stream);
 hipError_t launch_text_write(const TextArgs &a, hipStream_t stream);
+// the lengths of n rows again (batch-relative record indices rec[], their sites s1[] / s2[], all device arrays): lens[] is
+// updated, *changed (device) set to 1 when any differs from what the length pass found
+hipError_t launch_text_relength(const TextArgs &a, const uint64_t *rec, const uint32_t *s1, const uint32_t *s2, uint64_t n,
+                                uint64_t *changed, hipStream_t stream);
 // exclusive prefix sums of lens -> offs; total (one uint64, device) receives the batch's text length
 size_t text_scan_temp_bytes(uint64_t n);
 hipError_t text_scan(void *temp, size_t temp_bytes, const uint64_t *lens, uint64_t *offs, uint64_t n, uint64_t *total,

@@ -220,6 +220,22 @@ __global__ __launch_bounds__(256) void text_kernel(TextArgs A) {
   }
 }
 
+// Rows whose records were replaced (exact-order replay): their lengths again.  changed is set when one differs from the
+// length pass -- only then do the prefix sums have to be taken again (a replayed record moves a sixth decimal, or turns a
+// rounded zero's sign: the row's length changes once in a few thousand replays).
+__global__ void text_relength_kernel(TextArgs A, const uint64_t *rec, const uint32_t *s1, const uint32_t *s2, uint64_t n,
+                                     uint64_t *changed) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint64_t k = rec[t];
+  Counter c;
+  if (!format_row(c, A, s1[t], s2[t], k)) atomicExch(A.needs_host, 1);
+  if (A.lens[k] != c.n) {
+    A.lens[k] = c.n;
+    *changed = 1;
+  }
+}
+
 __global__ void text_total_kernel(const uint64_t *lens, const uint64_t *offs, uint64_t n, uint64_t *total) {
   *total = n ? offs[n - 1] + lens[n - 1] : 0;
 }
@@ -246,6 +262,12 @@ hipError_t launch(const TextArgs &a, hipStream_t stream, bool write) {
 }  // namespace
 
 hipError_t launch_text_lengths(const TextArgs &a, hipStream_t stream) { return launch(a, stream, false); }
+hipError_t launch_text_relength(const TextArgs &a, const uint64_t *rec, const uint32_t *s1, const uint32_t *s2, uint64_t n,
+                                uint64_t *changed, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(text_relength_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, a, rec, s1, s2, n, changed);
+  return hipGetLastError();
+}
 hipError_t launch_text_write(const TextArgs &a, hipStream_t stream) { return launch(a, stream, true); }
 
 size_t text_scan_temp_bytes(uint64_t n) {
