@@ -84,6 +84,12 @@ def parse():
                     help="fallback for roofline.traffic when rocprofv3 is not available")
     ap.add_argument("--no-traffic", action="store_true",
                     help="do not re-run one launch under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE for roofline.traffic")
+    ap.add_argument("--balance", choices=["pairs", "work"], default="pairs",
+                    help="how rows are dealt to the ranks: equal pair counts (default), or equal ESTIMATED work -- a row's "
+                         "pairs x its executed EM iterations per pair, measured on every ~100th row before the timed region")
+    ap.add_argument("--native-multi", action="store_true",
+                    help="ONE process: the product's own multi-device path (ngsld_run_multi, `ngsLD --devices ...`) on --gpus "
+                         "parts -- one part per device, or all on the devices there are -- with a discarding sink")
     a = ap.parse_args()
     preset = CONFIGS[a.config]
     a.custom = any(getattr(a, k) is not None for k in ("sites", "ind", "max_kb", "max_gap", "scaling"))
@@ -268,8 +274,125 @@ def measure_traffic(args) -> dict | None:
                       "included, an upper bound on HBM bytes"}
 
 
+def estimate_row_work(raw, pos_dist, args, dev_index: int, n_sites: int, n_ind: int) -> tuple[np.ndarray, dict]:
+    """Estimated work per row = its pairs x (executed EM iterations per pair + the per-pair prologue, ~1.1 iterations' worth):
+    every ~100th row is computed for real on this device (the whole matrix is here: this runs before the slabs are cut) and
+    the per-pair figure interpolated in between.  Not timed."""
+    import torch
+    from ngsld_amd import capi
+    t0 = time.perf_counter()
+    eng = capi.Engine(dev_index)
+    try:
+        eng.set_geno_raw(raw.data_ptr(), n_sites=n_sites, n_ind=n_ind, ignore_miss_data=args.ignore_miss)
+        eng.set_replay(False)
+        eng.set_pos_dist(pos_dist)
+        eng.plan(max_kb_dist=args.max_kb, extend_out=True, ignore_miss_data=args.ignore_miss, rnd_sample=args.rnd_sample, seed=12345)
+        row_off, _ = eng.plan_rows()
+        pairs = np.diff(row_off.astype(np.int64))
+        m = int(min(n_sites, max(64, n_sites // 100)))
+        rows = np.unique(np.linspace(0, max(n_sites - 2, 0), m).astype(np.int64))
+        cap = int(pairs[rows].max()) if len(rows) else 1
+        dev = torch.device("cuda", dev_index)
+        d_std = torch.empty(max(cap, 1) * STD_BYTES, dtype=torch.uint8, device=dev)
+        d_ext = torch.empty(max(cap, 1) * EXT_BYTES, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        per_pair = np.zeros(len(rows))
+        for k, r in enumerate(rows):
+            n = int(pairs[r])
+            if n == 0:
+                per_pair[k] = np.nan
+                continue
+            eng.run_device(int(r), int(r) + 1, d_std.data_ptr(), d_ext.data_ptr(), stream)
+            eng.finish_device()
+            it = d_ext.view(torch.int32).view(-1, EXT_BYTES // 4)[:n, 9].to(torch.float64)
+            per_pair[k] = float(torch.clamp(it + 1, max=100).mean()) + 1.1
+    finally:
+        eng.close()
+    ok = np.isfinite(per_pair)
+    if not ok.any():
+        return pairs.astype(np.float64), {"sampled_rows": 0}
+    est = np.interp(np.arange(n_sites), rows[ok], per_pair[ok])
+    info = {"sampled_rows": int(ok.sum()), "per_pair_min_max": [float(per_pair[ok].min()), float(per_pair[ok].max())],
+            "seconds": round(time.perf_counter() - t0, 2)}
+    return pairs.astype(np.float64) * est, info
+
+
+def native_multi(args) -> None:
+    """bench.py --native-multi: the product's OWN multi-device path in one process -- ngsld_run_multi, what `ngsLD --devices
+    0-7` runs (multi.hip: one host thread + context per device, per-part slab upload or ONE RCCL broadcast, per-part sink).
+    A step is the whole call: upload / broadcast, per-site prep, plan and the pair kernels of every part, the records handed
+    to a discarding sink in host memory.  Not the line the driver takes (that is the process-per-GPU path below)."""
+    import torch
+    from ngsld_amd import capi, shard, synth
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda is not available (no CPU fallback)")
+    torch.cuda.set_device(0)
+    n_dev = max(1, capi.device_count())
+    torch.cuda.set_device(0)                      # (counting devices walks hipSetDevice up to the first failure)
+    parts = max(1, args.gpus)
+    devices = [k % n_dev for k in range(parts)]
+    strong = args.scaling == "strong"
+    n_sites = args.sites if strong else args.sites * parts
+    n_ind = args.ind
+    dev = torch.device("cuda", 0)
+    chrs, pos = synth.make_positions(n_sites, args.seed, max_gap=args.max_gap, n_chr=1)
+    pos_dist = shard.pos_dist_from_positions(chrs, pos)
+    raw = synth.make_gl_torch(n_sites, n_ind, args.seed, dev, depth=args.depth)
+    if args.hard_calls:
+        raw = torch.nn.functional.one_hot(raw.argmax(dim=2), 3).to(torch.float64)
+    raw = raw.cpu().numpy()
+    torch.cuda.empty_cache()
+    kw = dict(max_kb_dist=args.max_kb, extend_out=True, ignore_miss_data=args.ignore_miss, rnd_sample=args.rnd_sample, seed=12345)
+
+    def run(check: bool):
+        acc = {"pairs": 0, "iters": 0, "words": 0}
+        import threading
+        lock = threading.Lock()
+
+        def sink(part, n_pairs, std, ext):
+            if check:
+                it = np.minimum(ext["n_iter"].astype(np.int64) + 1, 100).sum()
+                w = (int(std.view(np.int64).sum()) + int(ext.view(np.int64).sum())) % (1 << 64)
+                with lock:
+                    acc["pairs"] += n_pairs
+                    acc["iters"] += int(it)
+                    acc["words"] = (acc["words"] + w) % (1 << 64)
+            return 0
+        t0 = time.perf_counter()
+        per = capi.run_multi_sink(raw, pos_dist, devices, sink if check else None, **kw)
+        return time.perf_counter() - t0, per, acc
+
+    _, per, acc = run(True)                       # untimed: what the parts computed, as partition-invariant checksums
+    for _ in range(args.warmup):
+        run(False)
+    times = [run(False)[0] for _ in range(args.steps)]
+    total_pairs = int(sum(per))
+    elapsed = float(sum(times))
+    out = {
+        "metric": f"SNP-pair EM-LD computations/sec @ n_ind={n_ind}", "value": total_pairs * args.steps / elapsed, "unit": "pairs/s",
+        "n_gpus": parts, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"synthetic binary GL, {args.sites} sites{'' if strong else '/GPU'} x {n_ind} ind, depth {args.depth:g}, "
+                               f"--max_kb_dist {args.max_kb} {'windowed' if args.max_kb else 'all pairs'}, --extend_out"
+                               + (", hard-called" if args.hard_calls else ""),
+                   "n_sites_total": n_sites, "pairs_per_step": total_pairs,
+                   "parallelism": "one process, ngsld_run_multi (one host thread + context per part, records to a discarding "
+                                  "sink in host memory); a step is the WHOLE call: matrix distribution, per-site prep, plan, pair "
+                                  "kernels -- not comparable with the default line, whose inputs are resident before the step",
+                   "devices": devices, "devices_visible": n_dev,
+                   "matrix_distribution": capi.multi_last_distribution(),
+                   "pairs_per_part": [int(v) for v in per],
+                   "executed_iterations_total": acc["iters"], "records_checksum_u64": acc["words"],
+                   "step_seconds": [round(t, 4) for t in times]},
+    }
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
+    if args.native_multi:
+        native_multi(args)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -304,8 +427,6 @@ def main():
     pos_dist = shard.pos_dist_from_positions(chrs, pos)
     row_end = shard.row_ends(pos_dist, args.max_kb, 0)
     counts = row_end - (np.arange(n_sites, dtype=np.int64) + 1)
-    lo, hi = shard.split_rows(counts, world)[rank]
-    slab_lo, slab_hi = shard.slab_for_rows(row_end, lo, hi)
 
     # ---- the GL matrix: rank 0 generates, one RCCL broadcast distributes (not timed) ----
     t_gen = time.perf_counter()
@@ -321,6 +442,20 @@ def main():
     shard.broadcast_matrix(raw, src=0)
     torch.cuda.synchronize()
     t_bc = time.perf_counter() - t_bc
+
+    # ---- which rows are whose: equal pair counts, or (--balance work) equal estimated work -- rank 0 measures every ~100th
+    # row on the whole matrix (everybody holds it at this point) and hands the estimate to the others ----
+    balance_info = None
+    if args.balance == "work" and world > 1:
+        est = torch.zeros(n_sites, dtype=torch.float64, device=dev)
+        if rank == 0:
+            w, balance_info = estimate_row_work(raw, pos_dist, args, dev_index, n_sites, n_ind)
+            est.copy_(torch.from_numpy(w))
+        dist.broadcast(est, src=0)
+        lo, hi = shard.split_rows_weighted(est.cpu().numpy(), world)[rank]
+    else:
+        lo, hi = shard.split_rows(counts, world)[rank]
+    slab_lo, slab_hi = shard.slab_for_rows(row_end, lo, hi)
 
     # ---- engine: this rank's slab (its rows + halo) goes through the device prep kernel ----
     eng = capi.Engine(dev_index)
@@ -436,6 +571,7 @@ def main():
             "executed_iterations": int(torch.clamp(ext_i32[:n_pairs, 9].to(torch.int64) + 1, max=100).sum()) if n_pairs else 0,
             "sum_r2_finite": float(r2_col[torch.isfinite(r2_col)].sum()) if n_pairs else 0.0,
             "records_checksum_u64": (int(words_std.sum()) + int(words_ext.sum())) % (1 << 64) if n_pairs else 0,
+            "mean_executed_iterations": round(mean_exec, 4), "kernel_ms_per_launch": kernel_ms / max(launches, 1),
             "seconds": elapsed, "device": torch.cuda.get_device_name(dev), "device_index": dev_index}
     rank_records = [mine]
     if world > 1:
@@ -464,7 +600,8 @@ def main():
                                    + (f" ({preset['name']})" if is_preset else ""),
                        "n_sites_total": n_sites, "pairs_per_step": total_pairs,
                        "mean_executed_em_iterations": round(mean_exec, 3),
-                       "parallelism": f"rows sharded by pair count over {world} GPU(s), no data-path collective",
+                       "parallelism": f"rows sharded by {'estimated work (pairs x executed iterations, --balance work)' if args.balance == 'work' and world > 1 else 'pair count'} over {world} GPU(s), no data-path collective",
+                       "balance": args.balance, "balance_estimate": balance_info,
                        "pairs_per_rank_min_max": [pairs_min, pairs_max],
                        "rank_seconds_min_max": [elapsed_min, elapsed_max],
                        "rank_records": rank_records,

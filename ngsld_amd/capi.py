@@ -395,6 +395,40 @@ def run_multi(raw: np.ndarray, pos_dist: np.ndarray | None, devices: list[int], 
     return out, maf, [int(v) for v in per]
 
 
+def run_multi_sink(raw: np.ndarray, pos_dist: np.ndarray | None, devices: list[int], sink=None, log_scale: bool = False, **kw):
+    """ngsld_run_multi with the records left where they arrive: sink(part, n_pairs, std, ext) sees every batch as numpy
+    views of the library's host buffers (valid during the call; called on the part's own thread), or nothing is looked at
+    when sink is None.  Returns the pairs per part."""
+    L = lib()
+    raw = np.ascontiguousarray(raw, dtype=np.float64)
+    n_sites, n_ind = raw.shape[0], raw.shape[1]
+    pd = None if pos_dist is None else np.ascontiguousarray(pos_dist, dtype=np.float64)
+    p = _params(**kw)
+    o = GenoOpts(int(log_scale), p.ignore_miss_data, 0, 0, 0, 0, 0.0, 0.0)
+    n = len(devices)
+
+    def cb(_user, part, bp):
+        if sink is None:
+            return 0
+        b = bp.contents
+        k = b.n_pairs
+        if k == 0:
+            return 0
+        std = np.ctypeslib.as_array(C.cast(b.std, C.POINTER(C.c_uint8)), shape=(k * REC_STD.itemsize,)).view(REC_STD)
+        ext = np.ctypeslib.as_array(C.cast(b.ext, C.POINTER(C.c_uint8)), shape=(k * REC_EXT.itemsize,)).view(REC_EXT) \
+            if b.ext else None
+        return int(sink(part, k, std, ext) or 0)
+
+    per = (C.c_uint64 * n)()
+    err = C.create_string_buffer(512)
+    devs = (C.c_int * n)(*devices)
+    rc = L.ngsld_run_multi(devs, n, n_sites, n_ind, None if pd is None else pd.ctypes.data, C.byref(p), C.byref(o),
+                           raw.ctypes.data, READ_FN(0), None, None, MULTI_SINK_FN(cb), None, None, 0, per, err, len(err))
+    if rc != OK:
+        raise NgsldError(rc, err.value.decode())
+    return [int(v) for v in per]
+
+
 DIST_NAMES = {0: "none", 1: "upload", 2: "peer_copy", 3: "rccl"}
 
 

@@ -1762,9 +1762,17 @@ uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes) {
 }
 
 int ngsld_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {
-  if (hipSetDevice(device) != hipSuccess) return NGSLD_ERR_DEVICE;
+  // (a failure is this call's answer -- "no such device" is how callers count devices -- and must not stay behind as the
+  // runtime's last error for whoever asks next: torch raised "invalid device ordinal" on its first allocation)
+  if (hipSetDevice(device) != hipSuccess) {
+    (void)hipGetLastError();
+    return NGSLD_ERR_DEVICE;
+  }
   size_t f = 0, t = 0;
-  if (hipMemGetInfo(&f, &t) != hipSuccess) return NGSLD_ERR_DEVICE;
+  if (hipMemGetInfo(&f, &t) != hipSuccess) {
+    (void)hipGetLastError();
+    return NGSLD_ERR_DEVICE;
+  }
   if (free_bytes) *free_bytes = f;
   if (total_bytes) *total_bytes = t;
   return NGSLD_OK;

@@ -62,6 +62,20 @@ def split_rows(pair_counts: np.ndarray, world_size: int) -> list[tuple[int, int]
     return [(int(bounds[r]), int(bounds[r + 1])) for r in range(world_size)]
 
 
+def split_rows_weighted(weights: np.ndarray, world_size: int) -> list[tuple[int, int]]:
+    """Contiguous row ranges [lo, hi) per rank with (nearly) equal total WEIGHT -- e.g. a row's pairs times its estimated
+    EM iterations per pair (bench.py --balance work): the same cut as split_rows, on float weights."""
+    n = len(weights)
+    cum = np.concatenate([[0.0], np.cumsum(np.asarray(weights, dtype=np.float64))])
+    total = float(cum[-1])
+    bounds = [0]
+    for r in range(1, world_size):
+        bounds.append(int(np.searchsorted(cum, total * r / world_size, side="left")))
+    bounds.append(n)
+    bounds = np.maximum.accumulate(np.minimum(bounds, n))
+    return [(int(bounds[r]), int(bounds[r + 1])) for r in range(world_size)]
+
+
 def slab_for_rows(row_end: np.ndarray, lo: int, hi: int) -> tuple[int, int]:
     """Sites a rank must hold to compute rows [lo, hi): [lo, max row end) -- the rows plus their halo."""
     if hi <= lo:

@@ -34,14 +34,14 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _bench(n_ranks: int, sites: int, one_device: bool) -> dict:
+def _bench(n_ranks: int, sites: int, one_device: bool, extra: tuple = ()) -> dict:
     """One bench.py job exactly as the driver starts it (N = 1: plain python; N > 1: torch.distributed.run)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     env.pop("NGSLD_BENCH_ONE_DEVICE", None)
     if one_device:
         env["NGSLD_BENCH_ONE_DEVICE"] = "1"
     args = ["bench.py", "--gpus", str(n_ranks), "--config", "c2", "--sites", str(sites), "--ind", str(N_IND), "--steps", "2",
-            "--warmup", "1", "--no-e2e", "--no-cpu", "--no-traffic"]
+            "--warmup", "1", "--no-e2e", "--no-cpu", "--no-traffic", *extra]
     if n_ranks == 1:
         cmd = [sys.executable] + args
     else:
@@ -90,6 +90,54 @@ def test_bench_two_ranks_add_up_to_the_one_rank_run():
         assert "gloo" in c2["backend"]
     print(f"\n[multi-ranks] {'RCCL, 2 GPUs' if two_gpus else 'one device, gloo dry run'}: {c2['pairs_per_step']} pairs, "
           f"ranks {lo} / {hi}, {tmin:.3f} / {tmax:.3f} s, checksum {whole['records_checksum_u64']:#018x}")
+
+
+@pytest.mark.timeout(1800)
+def test_bench_two_ranks_balanced_by_estimated_work_add_up_too():
+    """--balance work: rank 0 measures every ~100th row, the rows are cut by estimated work (pairs x executed iterations)
+    instead of pair count -- another partition of the same pair space, so the ranks' records still SUM to the 1-rank run."""
+    two_gpus = capi.device_count() >= 2
+    one = _bench(1, 2 * SITES_PER_RANK, one_device=False)
+    two = _bench(2, SITES_PER_RANK, one_device=not two_gpus, extra=("--balance", "work"))
+    c1, c2 = one["config"], two["config"]
+    assert c2["balance"] == "work" and c2["balance_estimate"]["sampled_rows"] >= 64 and "estimated work" in c2["parallelism"]
+    recs = sorted(c2["rank_records"], key=lambda r: r["rank"])
+    assert recs[0]["rows"][0] == 0 and recs[0]["rows"][1] == recs[1]["rows"][0] and recs[1]["rows"][1] == 2 * SITES_PER_RANK
+    whole = c1["rank_records"][0]
+    assert sum(r["pairs"] for r in recs) == whole["pairs"] == c1["pairs_per_step"]
+    assert sum(r["executed_iterations"] for r in recs) == whole["executed_iterations"]
+    assert sum(r["records_checksum_u64"] for r in recs) % (1 << 64) == whole["records_checksum_u64"]
+    # the estimate does its job: the ranks' executed-iteration totals are within 2 % of each other
+    it = [r["executed_iterations"] for r in recs]
+    assert abs(it[0] - it[1]) <= 0.02 * max(it), it
+    assert all("mean_executed_iterations" in r and r["kernel_ms_per_launch"] > 0 for r in recs)
+
+
+@pytest.mark.timeout(1800)
+def test_bench_native_multi_parts_add_up_to_one_part():
+    """bench.py --native-multi: the product's own one-process multi-device path (ngsld_run_multi) through the same bench.
+    Three parts (on the devices there are: all on GPU 0 on a one-GPU box) against one part of the same 12,000 sites: pair
+    counts, executed-iteration totals and record checksums are EQUAL."""
+    def run(parts, sites):
+        cmd = [sys.executable, "bench.py", "--native-multi", "--gpus", str(parts), "--config", "c2", "--sites", str(sites),
+               "--ind", str(N_IND), "--steps", "2", "--warmup", "1"]
+        r = subprocess.run(cmd, cwd=REPO, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, f"{' '.join(cmd)}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+    one = run(1, 12_000)
+    three = run(3, 4_000)
+    a, b = one["config"], three["config"]
+    assert three["n_gpus"] == 3 and len(b["pairs_per_part"]) == 3 and all(n > 0 for n in b["pairs_per_part"])
+    assert "ngsld_run_multi" in b["parallelism"] and b["matrix_distribution"] in ("upload", "peer_copy", "rccl")
+    assert a["n_sites_total"] == b["n_sites_total"] == 12_000
+    assert sum(b["pairs_per_part"]) == b["pairs_per_step"] == a["pairs_per_step"]
+    assert b["executed_iterations_total"] == a["executed_iterations_total"]
+    assert b["records_checksum_u64"] == a["records_checksum_u64"]
+    assert max(b["pairs_per_part"]) - min(b["pairs_per_part"]) <= 0.02 * max(b["pairs_per_part"])
+    assert three["value"] > 0 and abs(three["value"] - b["pairs_per_step"] * 2 / sum(b["step_seconds"])) <= 2e-3 * three["value"]
 
 
 def test_run_multi_on_distinct_devices_broadcasts_over_rccl():
