@@ -24,6 +24,7 @@
 #include "../../include/ngsld.h"
 #include "ld_device.h"
 #include "ld_prep.h"
+#include "ld_replay.h"
 #include "ld_text.h"
 #include "replay.h"
 #include "taus.h"
@@ -273,9 +274,12 @@ struct ngsld_ctx {
   hipStream_t replay_stream = nullptr;        // non-blocking: read-backs must not wait for the next batch's kernel
   ngsld_geno_opts gopts{};
   bool normalised = false;                    // data came through ngsld_set_geno_lkl
-  DevBuf<uint32_t> d_flags[kSlots], d_flags_dev;   // [count, pad, list of the first kFlagListCap, one bit per record ...] per pipeline slot / for ngsld_run_device
+  DevBuf<uint32_t> d_flags[kSlots], d_flags_dev;   // [count, pad, list of the first flag_cap, one bit per record ...] per pipeline slot / for ngsld_run_device
   PinBuf<uint32_t> h_flags[kSlots], h_flags_dev;   // host copies of the HEAD (count + list): they travel with the batch's records / text meta
   PinBuf<uint32_t> h_flag_bits;                    // the bitmap, fetched only when a launch flagged more pairs than the list holds
+  uint32_t flag_cap[kSlots] = {0, 0, 0}, flag_cap_dev = 0;  // list entries of d_flags[k] / d_flags_dev as last reset
+  bool replay_device = true;                       // called-genotype matrices: flagged pairs replayed by ld_replay.hip (NGSLD_REPLAY_DEVICE=0: host)
+  uint64_t replayed_on_device = 0;
   PinBuf<double> h_site_stage;                // plane read-back of one site (no source registered)
   DevBuf<uint64_t> d_patch_idx;
   DevBuf<ngsld_rec_std> d_patch_std;
@@ -556,9 +560,10 @@ hipError_t timed_launch(ngsld_ctx *c, const PairArgs &a, hipStream_t stream) {
 }
 
 PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext,
-                   uint32_t *d_flags = nullptr) {
+                   uint32_t *d_flags = nullptr, uint32_t flag_cap = 0) {
   PairArgs a{};
   a.flags = d_flags;
+  a.flag_cap = flag_cap;
   a.flag_text = 1;
   a.planes = c->d_planes.p;
   a.site_stride = 3ull * c->np;
@@ -704,34 +709,50 @@ int fetch_replay_site(ngsld_ctx *c, uint64_t s, std::vector<double> &tmp, Replay
   return NGSLD_OK;
 }
 
-constexpr size_t kFlagHeadBytes = (size_t)kFlagHead * sizeof(uint32_t);
 // Rows per text batch (ngsld_run; a smaller NGSLD_BATCH_PAIRS / ngsld_set_tuning wins).  Round 4, configs[2] end to end on one
 // box (profiles/r04/e2e_batch_size.txt): 2^21 1.42-1.46 s, 2^20 1.25-1.35 s, 2^19 1.23-1.25 s -- the loop itself takes the
 // same 0.62 s whatever the count (a batch costs ~0.3 ms since its last rows go out as short runs and a replayed row no longer
 // has every length derived again), while the two pinned buffers (2 x 400 MB at 2^21) cost 0.1 s to pin -- beside the matrix
 // upload, which they slow -- and 0.06 s to give back.
 constexpr uint64_t kTextBatchPairs = 1ull << 19;
-inline size_t flag_words(uint64_t n) { return (size_t)kFlagHead + (size_t)((n + 31) / 32); }
+
+// List entries of a launch of n records: a 256th of them (a called-genotype matrix flags one pair in ~4,000, a likelihood
+// matrix one in 10^6), at least 4,096, at most 2^20 (8 MB of head to read back).
+inline uint32_t flag_cap_for(uint64_t n) { return (uint32_t)std::min<uint64_t>(1ull << 20, std::max<uint64_t>(4096, n / 256)); }
+inline size_t flag_head_bytes(uint32_t cap) { return (size_t)flag_head_words(cap) * sizeof(uint32_t); }
+inline size_t flag_words(uint64_t n, uint32_t cap) { return (size_t)flag_head_words(cap) + (size_t)((n + 31) / 32); }
 
 // The flagged records of a launch of n records, in increasing order.  h_head: the head of its flag buffer (counter + the
-// first kFlagListCap record indices) in host memory -- it travels with the batch, or is copied on the launch's own stream
+// first `cap` record indices) in host memory -- it travels with the batch, or is copied on the launch's own stream
 // right behind the kernels (a copy issued later, while the next batch's pair kernel has the device, can wait for that
 // kernel: measured 43 ms).  Only a launch that flagged more pairs than the list holds has its bitmap fetched from d_flags,
 // on the replay stream (the kernels that set it are complete when this is called).
-int flagged_records(ngsld_ctx *c, const uint32_t *h_head, const uint32_t *d_flags, uint64_t n, std::vector<uint64_t> &recs) {
+int flagged_records(ngsld_ctx *c, const uint32_t *h_head, const uint32_t *d_flags, uint32_t cap, uint64_t n,
+                    std::vector<uint64_t> &recs) {
   recs.clear();
   const uint32_t count = h_head[0];
   if (count == 0) return NGSLD_OK;
-  if (count <= kFlagListCap) {
+  if (count <= cap) {
     const uint64_t *list = reinterpret_cast<const uint64_t *>(h_head + 2);
-    recs.assign(list, list + count);
+    recs.reserve(count);
+    uint64_t on_device = 0;
+    for (uint32_t k = 0; k < count; ++k) {
+      if (list[k] & kFlagDone) {  // the device-side replay (ld_replay.hip) has rewritten this record already
+        ++on_device;
+        continue;
+      }
+      recs.push_back(list[k] & kFlagIndexMask);
+    }
+    c->replayed_on_device += on_device;
+    c->replayed_pairs += on_device;
     std::sort(recs.begin(), recs.end());  // (the order the atomics landed in is not the record order)
     while (!recs.empty() && recs.back() >= n) recs.pop_back();
     return NGSLD_OK;
   }
   const size_t words = (size_t)((n + 31) / 32);
   HIP_TRY(c, c->h_flag_bits.resize(words ? words : 1));
-  HIP_TRY(c, hipMemcpyAsync(c->h_flag_bits.p, d_flags + kFlagHead, words * sizeof(uint32_t), hipMemcpyDeviceToHost, c->replay_stream));
+  HIP_TRY(c, hipMemcpyAsync(c->h_flag_bits.p, d_flags + flag_head_words(cap), words * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                            c->replay_stream));
   HIP_TRY(c, hipStreamSynchronize(c->replay_stream));
   const uint32_t *bits = c->h_flag_bits.p;
   recs.reserve(count);
@@ -833,13 +854,43 @@ int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t bas
   return NGSLD_OK;
 }
 
-// A flag buffer for n records, zeroed on `stream`.
-int reset_flags(ngsld_ctx *c, DevBuf<uint32_t> &buf, uint64_t n, hipStream_t stream) {
-  const size_t words = flag_words(n);
+// A flag buffer for n records with `cap` list entries, zeroed on `stream`.
+int reset_flags(ngsld_ctx *c, DevBuf<uint32_t> &buf, uint64_t n, uint32_t cap, hipStream_t stream) {
+  const size_t words = flag_words(n, cap), head = flag_head_words(cap);
   HIP_TRY(c, buf.resize(words));
   HIP_TRY(c, hipMemsetAsync(buf.p, 0, 2 * sizeof(uint32_t), stream));  // the counter (the list behind it needs no clearing)
-  if (words > kFlagHead)
-    HIP_TRY(c, hipMemsetAsync(buf.p + kFlagHead, 0, (words - kFlagHead) * sizeof(uint32_t), stream));
+  if (words > head)
+    HIP_TRY(c, hipMemsetAsync(buf.p + head, 0, (words - head) * sizeof(uint32_t), stream));
+  return NGSLD_OK;
+}
+
+// Called-genotype matrices: the flagged pairs of a launch replayed on the device (ld_replay.hip), right behind the pair
+// kernels on their stream -- before the head of the flag buffer travels to the host, before text rows are formatted.
+// out_base: plan index of the launch's record 0; d_std / d_ext: where the launch wrote (device, or pinned host memory).
+int device_replay(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
+                  ngsld_rec_ext *d_ext, hipStream_t st) {
+  if (!c->replay_on || !c->replay_device || c->cfg.kernel != kHard || d_flags == nullptr || n == 0) return NGSLD_OK;
+  ReplayHardArgs a{};
+  a.flags = d_flags;
+  a.flag_cap = cap;
+  a.row_off = c->d_row_off.p;
+  a.item_off = c->d_item_off.p;
+  a.items = c->d_items.p;
+  a.n_sites = (uint32_t)c->n_sites;
+  a.rec_base = out_base;
+  a.masks = c->d_hard_masks.p;
+  a.words = c->mask_words;
+  a.n_ind = (uint32_t)c->n_ind;
+  a.ignore_miss = c->params.ignore_miss_data;
+  // "no data" individuals: only call_geno's triple is the same arithmetic on every individual (gen_func.cpp:903-905); a
+  // matrix that came called from elsewhere may hold any three equal values -- its pairs at sites with missing data stay
+  // with the host, which has the caller's raw values
+  a.miss_ok = c->gopts.call_geno && !c->normalised ? 1 : 0;
+  replay_missing_constants(&a.u_lkl, &a.u_pp);
+  a.out_std = d_std;
+  a.out_ext = d_ext;
+  a.status = c->d_status.p;
+  HIP_TRY(c, launch_replay_hard(a, n, st));
   return NGSLD_OK;
 }
 
@@ -851,7 +902,7 @@ int finish_device_run(ngsld_ctx *c) {
   if (c->h_flags_dev.p[0] == 0) return NGSLD_OK;
   const uint64_t base = c->h_row_off[c->dev_run.s1_begin], n = c->h_row_off[c->dev_run.s1_end] - base;
   std::vector<uint64_t> recs;
-  const int rcf = flagged_records(c, c->h_flags_dev.p, c->d_flags_dev.p, n, recs);
+  const int rcf = flagged_records(c, c->h_flags_dev.p, c->d_flags_dev.p, c->flag_cap_dev, n, recs);
   if (rcf != NGSLD_OK) return rcf;
   return replay_flagged(c, recs, base, nullptr, nullptr, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st);
 }
@@ -908,6 +959,7 @@ int ngsld_create(int device, ngsld_ctx **out) {
   }
   if (const char *k = std::getenv("NGSLD_REPLAY")) c->replay_on = std::strcmp(k, "0") != 0;  // A/B, tests
   if (const char *k = std::getenv("NGSLD_REPLAY_THREADS")) c->replay_threads = std::atoi(k);
+  if (const char *k = std::getenv("NGSLD_REPLAY_DEVICE")) c->replay_device = std::strcmp(k, "0") != 0;
   if (const char *k = std::getenv("NGSLD_RUN_DIRECT")) c->run_direct = std::strcmp(k, "0") != 0;  // A/B, tests (see ngsld_ctx)
   if (const char *k = std::getenv("NGSLD_RUN_TAPER")) c->run_taper = std::strcmp(k, "0") != 0;
   if (const char *k = std::getenv("NGSLD_RUN_STREAMS")) c->run_streams = std::atoi(k) >= 2 ? 2 : 1;
@@ -1289,10 +1341,12 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
   c->timed_overlap = false;
   c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
   c->replayed_pairs = 0;
+  c->replayed_on_device = 0;
   if (c->replay_on) {
-    const int rcf = reset_flags(c, c->d_flags_dev, c->timed_pairs, st);
+    c->flag_cap_dev = flag_cap_for(c->timed_pairs);
+    const int rcf = reset_flags(c, c->d_flags_dev, c->timed_pairs, c->flag_cap_dev, st);
     if (rcf != NGSLD_OK) return rcf;
-    HIP_TRY(c, c->h_flags_dev.resize(kFlagHead));
+    HIP_TRY(c, c->h_flags_dev.resize(flag_head_words(c->flag_cap_dev)));
   }
   // one launch per <= 2^31-1 workgroups; rows are cut so that each launch's grid fits
   const uint64_t max_items = 0x7ffffff0ull;
@@ -1309,14 +1363,21 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
   }
   uint64_t r0 = s1_begin;
   for (const uint64_t r1 : cuts) {
-    PairArgs a = make_args(c, r0, r1, (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, c->replay_on ? c->d_flags_dev.p : nullptr);
+    PairArgs a = make_args(c, r0, r1, (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, c->replay_on ? c->d_flags_dev.p : nullptr,
+                           c->flag_cap_dev);
     a.out_base = c->h_row_off[s1_begin];
     a.flag_text = 0;  // these records stay on the device: only numerically ill-conditioned pairs are replayed
     HIP_TRY(c, timed_launch(c, a, st));
     r0 = r1;
   }
-  if (c->replay_on)  // which pairs the kernels flagged: the counter and the list come over behind them, on their stream
-    HIP_TRY(c, hipMemcpyAsync(c->h_flags_dev.p, c->d_flags_dev.p, kFlagHeadBytes, hipMemcpyDeviceToHost, st));
+  if (c->replay_on) {
+    const int rcd = device_replay(c, c->d_flags_dev.p, c->flag_cap_dev, c->h_row_off[s1_begin], c->timed_pairs,
+                                  (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, st);
+    if (rcd != NGSLD_OK) return rcd;
+    // which pairs the kernels flagged (and the device has not settled itself): the counter and the list come over behind
+    // them, on their stream
+    HIP_TRY(c, hipMemcpyAsync(c->h_flags_dev.p, c->d_flags_dev.p, flag_head_bytes(c->flag_cap_dev), hipMemcpyDeviceToHost, st));
+  }
   c->dev_run.pending = true;
   c->dev_run.s1_begin = s1_begin;
   c->dev_run.s1_end = s1_end;
@@ -1347,6 +1408,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   c->timed_stream = c->stream;
   c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
   c->replayed_pairs = 0;
+  c->replayed_on_device = 0;
   const bool replay = c->replay_on;
   if (c->reserve_thread.joinable()) c->reserve_thread.join();  // (ngsld_reserve_text_buffers: h_text[] is this thread's again)
 
@@ -1443,8 +1505,9 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       if (ext) HIP_TRY(c, c->h_ext[k].resize(cap));
     }
     if (replay) {
-      HIP_TRY(c, c->d_flags[k].resize(flag_words(cap)));
-      HIP_TRY(c, c->h_flags[k].resize(kFlagHead));
+      c->flag_cap[k] = flag_cap_for(cap);
+      HIP_TRY(c, c->d_flags[k].resize(flag_words(cap, c->flag_cap[k])));
+      HIP_TRY(c, c->h_flags[k].resize(flag_head_words(c->flag_cap[k])));
     }
   }
   // (run_direct: the device addresses of the pinned host buffers -- the same numbers under unified addressing, asked for anyway)
@@ -1493,16 +1556,20 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     const Batch &b = batches[bi];
     hipStream_t st = (two_streams && (bi & 1)) ? c->stream2 : c->stream;
     if (replay) {
-      const int rcf = reset_flags(c, c->d_flags[k], b.n, st);
+      const int rcf = reset_flags(c, c->d_flags[k], b.n, c->flag_cap[k], st);
       if (rcf != NGSLD_OK) return rcf;
     }
-    PairArgs a = make_args(c, b.r0, b.r1, dev_std[k], dev_ext[k], replay ? c->d_flags[k].p : nullptr);
+    PairArgs a = make_args(c, b.r0, b.r1, dev_std[k], dev_ext[k], replay ? c->d_flags[k].p : nullptr, c->flag_cap[k]);
     HIP_TRY(c, timed_launch(c, a, st));
+    if (replay) {  // (called genotypes: the flagged pairs settled on the device, before anything reads the records)
+      const int rcd = device_replay(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], st);
+      if (rcd != NGSLD_OK) return rcd;
+    }
     // which pairs the kernel flagged for the exact-order replay (counter + list, 32 KB): known to the host with the batch.
     // On the kernel's own stream, right behind it: on the copy stream, behind the records, this small copy took 9 ms per
     // batch -- it goes through a copy kernel, and that waited for the next batch's pair kernel to leave it a CU
     if (replay)
-      HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, kFlagHeadBytes, hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, flag_head_bytes(c->flag_cap[k]), hipMemcpyDeviceToHost, st));
     if (text) {  // row lengths and their prefix sums right behind the pair kernel; the rows are written at consume time
       HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), st));
       const TextArgs t = text_args(b, k);
@@ -1555,7 +1622,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       if (replay && c->h_flags[k].p[0] != 0) {
         // flagged pairs: replayed on the host, patched into the device records, and the row lengths derived again --
         // all on the copy stream, beside the next batch's pair kernel
-        int rcr = flagged_records(c, c->h_flags[k].p, c->d_flags[k].p, b.n, recs);
+        int rcr = flagged_records(c, c->h_flags[k].p, c->d_flags[k].p, c->flag_cap[k], b.n, recs);
         if (rcr == NGSLD_OK)
           rcr = replay_flagged(c, recs, c->h_row_off[b.r0], nullptr, nullptr, c->d_std[k].p, ext ? c->d_ext[k].p : nullptr,
                                c->copy_stream, &rep_s1, &rep_s2);
@@ -1619,7 +1686,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       HIP_TRY(c, hipEventSynchronize(direct ? c->ev_kernel_done[k] : c->ev_copy_done[k]));
       if (trace) std::fprintf(stderr, "[trace] batch %zu (%llu pairs): issue next %.2f..%.2f, records on the host %.2f, flagged %u\n", bi, (unsigned long long)b.n, t_a, t_b, now_ms(), replay ? c->h_flags[k].p[0] : 0u);
       if (replay && c->h_flags[k].p[0] != 0) {  // flagged pairs: replayed on the host, patched into the batch's buffers
-        int rcr = flagged_records(c, c->h_flags[k].p, c->d_flags[k].p, b.n, recs);
+        int rcr = flagged_records(c, c->h_flags[k].p, c->d_flags[k].p, c->flag_cap[k], b.n, recs);
         if (rcr == NGSLD_OK)
           rcr = replay_flagged(c, recs, c->h_row_off[b.r0], c->h_std[k].p, ext ? c->h_ext[k].p : nullptr, nullptr, nullptr, nullptr);
         if (rcr != NGSLD_OK) return rcr;

@@ -59,11 +59,14 @@ constexpr double kTieMargin = 1e-12;
 constexpr double kPearsonCond = 0x1p13;
 constexpr double kEpsilonTie = kEpsilon + kTieMargin;
 constexpr uint32_t kTieBit = 0x80000000u;  // rides on n_iter (<= 100) from the EM loop to write_pair
-// Layout of a launch's flag buffer (uint32 words): [0] count of flagged pairs, [1] unused, [2 .. 2 + 2 kFlagListCap) the
-// record indices (uint64) of the first kFlagListCap flagged pairs in the order their atomics landed, [kFlagHead ...) one bit
-// per record.  A launch of 10^8 pairs flags a few dozen: the host reads the head and never the 12 MB bitmap.
-constexpr uint32_t kFlagListCap = 4096;
-constexpr uint32_t kFlagHead = 2 + 2 * kFlagListCap;
+// Layout of a launch's flag buffer (uint32 words): [0] count of flagged pairs, [1] unused, [2 .. 2 + 2 cap) the record
+// indices (uint64) of the first `cap` flagged pairs in the order their atomics landed, [2 + 2 cap ...) one bit per record;
+// cap = PairArgs::flag_cap, set by the engine from the launch's size (flag_cap_for).  A launch of 10^8 likelihood pairs flags
+// a few dozen, one of called genotypes 26,000 (exact ties of eps with EPSILON): the host reads the head and never the bitmap.
+// A list entry's top bits: kFlagHostOnly -- the pair was flagged for a reason only the host's replay settles (its r2_ExpG:
+// GSL's long double recurrence) --, kFlagDone -- the device-side replay (ld_replay.hip) has already rewritten the record.
+constexpr uint64_t kFlagHostOnly = 1ull << 63, kFlagDone = 1ull << 62, kFlagIndexMask = (1ull << 62) - 1;
+__host__ __device__ inline uint32_t flag_head_words(uint32_t cap) { return 2u + 2u * cap; }
 
 // One unit of work = ngsld_item: pairs (s1, s2_begin + c) for the bits c set in mask, records from first_record.
 typedef ngsld_item Item;
@@ -100,11 +103,12 @@ struct PairArgs {
   const uint64_t *hard_masks;  // [n_sites][4][mask_words]
   const double *hard_u;        // [n_sites] the value of the three equal likelihoods of an individual without data
   uint32_t mask_words;         // ceil(n_ind / 64)
-  // exact-order replay: flags[0] counts the flagged pairs, bit r of flags[kFlagHead + r / 32] marks record r of the output
-  // buffers (null: no flagging); the first kFlagListCap of them are also listed by record index right behind the counter
+  // exact-order replay: flags[0] counts the flagged pairs, bit r of flags[flag_head_words(flag_cap) + r / 32] marks record r
+  // of the output buffers (null: no flagging); the first flag_cap of them are also listed by record index right behind the counter
   // (flag_list(): what the host reads back is the counter and that list -- 32 KB whatever the launch's size -- and the
   // bitmap only when more pairs were flagged than the list holds)
   uint32_t *flags;
+  uint32_t flag_cap;   // entries of the list in flags
   uint32_t flag_text;  // also flag the pairs whose printed digits (six decimals) rounding noise could change
   // tiled workgroup order of the multi-wavefront kernel (launch_pair_kernel; tile_nk == 0: workgroup i takes item i):
   // rows [row0, row1) of the plan, tiles of tile_rows rows x 8 items, tile_nk tiles per row block; workgroup ids without an
@@ -754,8 +758,9 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
     const double q0 = fabs(hm0) <= fabs(1 - hm0) ? fabs(hm0) : fabs(1 - hm0);
     const double q1 = fabs(hm1) <= fabs(1 - hm1) ? fabs(hm1) : fabs(1 - hm1);
     // (NaN frequencies fail both comparisons)
-    bool flag = tie || odd_site || !(q0 >= kReplayBelow) || !(q1 >= kReplayBelow) ||
-                (!constant_site && (double)A.n_ind * a1 * a2 > kPearsonCond);  // (a constant site: NaN on every path)
+    // host_only: reasons that concern r2_ExpG -- what the device-side replay of called genotypes (ld_replay.hip) leaves alone
+    bool host_only = odd_site || (!constant_site && (double)A.n_ind * a1 * a2 > kPearsonCond);  // (a constant site: NaN on every path)
+    bool flag = tie || host_only || !(q0 >= kReplayBelow) || !(q1 >= kReplayBelow);
     // The TSV prints six decimals (ngsLD.cpp:314-349).  A value that sits on a rounding point of the sixth decimal --
     // closer to it than this kernel and the reference can differ -- would print a different last digit, and a D within
     // rounding noise of zero a different sign ("-0.000000"): those pairs are replayed too, so that the text is the
@@ -765,16 +770,16 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
     constexpr double kUlp = 0x1p-52;
     const double d_abs = A.flag_text ? 32 * kUlp : -1.0;  // (negative: near_rounding is never true)
     const double amp = A.flag_text ? 1.0 / q0 + 1.0 / q1 : 0.0;
-    flag = flag || fabs(D) < 2 * d_abs || near_rounding(D, d_abs) || near_rounding(Dp, 2 * d_abs * (1.0 + fabs(Dp) * amp)) ||
-           near_rounding(o.r2, 2 * d_abs * (1.0 + o.r2 * amp)) ||
-           near_rounding(o.r2_ExpG, 0.5 * d_abs * (1.0 + 4.0 * (double)A.n_ind * a1 * a2));
+    host_only = host_only || near_rounding(o.r2_ExpG, 0.5 * d_abs * (1.0 + 4.0 * (double)A.n_ind * a1 * a2));
+    flag = flag || host_only || fabs(D) < 2 * d_abs || near_rounding(D, d_abs) ||
+           near_rounding(Dp, 2 * d_abs * (1.0 + fabs(Dp) * amp)) || near_rounding(o.r2, 2 * d_abs * (1.0 + o.r2 * amp));
     if (A.out_ext != nullptr)
       flag = flag || near_rounding(f0, d_abs) || near_rounding(f1, d_abs) || near_rounding(f2, d_abs) ||
              near_rounding(f3, d_abs) || near_rounding(hm0, d_abs) || near_rounding(hm1, d_abs);
     if (flag) {
-      atomicOr(&A.flags[kFlagHead + (slot >> 5)], 1u << (slot & 31u));
+      atomicOr(&A.flags[flag_head_words(A.flag_cap) + (slot >> 5)], 1u << (slot & 31u));
       const uint32_t k = atomicAdd(&A.flags[0], 1u);
-      if (k < kFlagListCap) reinterpret_cast<uint64_t *>(A.flags + 2)[k] = slot;
+      if (k < A.flag_cap) reinterpret_cast<uint64_t *>(A.flags + 2)[k] = slot | (host_only ? kFlagHostOnly : 0ull);
     }
   }
 }

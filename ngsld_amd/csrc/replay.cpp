@@ -148,6 +148,15 @@ void replay_site_from_raw(const double *raw, uint64_t n_ind, const ngsld_geno_op
   }
 }
 
+void replay_missing_constants(double *u_lkl, double *u_pp) {
+  double g[3];
+  for (int k = 0; k < 3; ++k) g[k] = std::log((double)1 / 3);  // harden(): gen_func.cpp:903-905
+  *u_lkl = std::exp(g[0]);                                    // ngsLD.cpp:110
+  double pp[3] = {g[0], g[1], g[2]};
+  normalise_log(pp);                                          // site_maf(): post_prob, then exp
+  *u_pp = std::exp(pp[0]);
+}
+
 void replay_site_from_lkl(const double *lkl, double maf, uint64_t n_ind, ReplaySite *out) {
   out->maf = maf;
   out->lkl.assign(lkl, lkl + 3 * n_ind);

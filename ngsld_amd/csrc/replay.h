@@ -41,4 +41,9 @@ void replay_site_from_lkl(const double *lkl, double maf, uint64_t n_ind, ReplayS
 void replay_pair(const ReplaySite &a, const ReplaySite &b, uint64_t n_ind, bool ignore_miss_data, ngsld_rec_std *std_rec,
                  ngsld_rec_ext *ext_rec, int *status);
 
+// The "no data" triple call_geno leaves (gen_func.cpp:903-905: log(1/3) three times) as the HOST's libm turns it into the
+// values calc_pair_LD and est_maf see: u_lkl = exp(log(1/3)) (ngsLD.cpp:110), u_pp = the est_maf posterior of that triple
+// (gen_func.cpp:920-932, 986-990).  The device-side replay of called genotypes (ld_replay.hip) takes them as constants.
+void replay_missing_constants(double *u_lkl, double *u_pp);
+
 }  // namespace ngsld

@@ -106,3 +106,46 @@ def test_maf_is_bit_identical_on_called_genotypes(engine, case, n_sites, n_ind, 
         o2 = orc.Oracle(raw, None, min_maf=thr)
         engine.set_pos_dist(None)
         assert engine.plan(0, 0, thr, False, True) == o2.count()
+
+
+@pytest.mark.parametrize("n_ind,call,ignore,miss", [(500, None, False, 0.0), (1000, None, False, 0.0), (500, (0.0, 0.0), False, 0.0),
+                                                  (500, (0.4, 0.4), False, 0.02), (500, (0.4, 0.4), True, 0.02),
+                                                  (2000, None, True, 0.0), (500, None, False, 0.02), (24, None, False, 0.0)])
+def test_device_replay_of_called_genotypes_is_the_hosts(n_ind, call, ignore, miss, monkeypatch):
+    """Called genotypes make exact ties of eps with EPSILON common (D moves in steps of 1 / (4 n^2)): thousands of flagged
+    pairs.  They are replayed ON THE DEVICE (ld_replay.hip: the reference's sequential order, one lane per pair) where the
+    values are the host's bits -- and must come out as the host's replay does, bit for bit in hap / D / D' / r2 / nIter /
+    sample_size (r2_ExpG stays the pair kernel's), and both as the oracle.  With --call_geno the "no data" individuals are
+    part of it (the host's constants for their triple); a matrix that arrives called with missing data (miss > 0, no
+    --call_geno) leaves the pairs of such sites to the host."""
+    from ngsld_amd import capi
+    n_sites = 600 if n_ind <= 1000 else 300
+    raw = np.eye(3)[synth.make_gl_numpy(n_sites, n_ind, 4200 + n_ind, depth=8.0).argmax(axis=2)]
+    if miss:  # (under --call_geno an all-equal triple becomes call_geno's own "no data" triple, gen_func.cpp:897-905)
+        raw[np.random.default_rng(5).random((n_sites, n_ind)) < miss] = 1.0 / 3.0
+    o = orc.Oracle(raw, None, ignore_miss_data=ignore, n_threads=32, call_geno=call)
+    rec = o.run()
+    got = {}
+    for where in ("device", "host"):
+        monkeypatch.setenv("NGSLD_REPLAY_DEVICE", "1" if where == "device" else "0")
+        eng = capi.Engine(0)
+        try:
+            eng.set_geno_raw(raw, ignore_miss_data=ignore, call_geno=call)
+            assert eng.pair_kernel() == "hard"
+            eng.set_pos_dist(None)
+            assert eng.plan(0, 0, 0.0, ignore, True) == len(rec)
+            s1, s2, std, ext = eng.run()
+            replayed = eng.replay_stats()[0]
+        finally:
+            eng.close()
+        check_records(std, ext, rec)
+        got[where] = (std, ext, replayed)
+    (sd, ed, rd), (sh, eh, rh) = got["device"], got["host"]
+    assert rd == rh and (rd > 0 or n_ind < 100), (rd, rh)           # the same pairs were flagged and replayed
+    for col in ("D", "Dp", "r2"):
+        assert np.array_equal(sd[col].view(np.uint64), sh[col].view(np.uint64)), col
+    assert np.array_equal(ed["hap"].view(np.uint64), eh["hap"].view(np.uint64))
+    assert np.array_equal(ed["n_iter"], eh["n_iter"]) and np.array_equal(ed["n_ind_data"], eh["n_ind_data"])
+    assert np.all(close(sd["r2_ExpG"], sh["r2_ExpG"], 1e-12))
+    ties = int(np.sum(rec["n_iter"] <= 2))
+    print(f"\n[device replay] n_ind {n_ind} call {call} ignore {ignore} miss {miss}: {len(rec)} pairs, {rd} replayed, {ties} with nIter <= 2")
