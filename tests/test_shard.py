@@ -47,6 +47,33 @@ def test_split_rows_covers_and_balances(world):
     assert max(per) - min(per) <= 2 * 300
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_split_rows_weighted_balances_the_weight_not_the_count(world):
+    """bench.py --balance work: rows cut by estimated WORK (pairs x executed iterations per pair).  With a cost per pair
+    that grows along the rows the cut moves towards the front; the parts cover the rows, and their weights are within two
+    rows of equal."""
+    n = 4000
+    counts = shard.row_pair_counts(_pd(n, 41), 20, 0).astype(np.float64)
+    cost = counts * np.linspace(9.0, 14.0, n)                        # later rows iterate longer
+    parts = shard.split_rows_weighted(cost, world)
+    assert parts[0][0] == 0 and parts[-1][1] == n and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    per = [float(cost[lo:hi].sum()) for lo, hi in parts]
+    assert abs(sum(per) - float(cost.sum())) <= 1e-6 * cost.sum()
+    assert max(per) - min(per) <= 2 * float(cost.max()) + 1e-9
+    if world > 1:
+        by_count = shard.split_rows(counts.astype(np.int64), world)
+        assert parts[0][1] > by_count[0][1]                         # the first part takes MORE rows: its pairs are cheaper
+    assert shard.split_rows_weighted(counts, world) == shard.split_rows(counts.astype(np.int64), world)   # equal weights: the same cut
+
+
+def test_bench_flags_of_round_4_parse():
+    """--balance / --native-multi are part of the driver-facing script: they must parse without a GPU."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), "--help"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--balance" in r.stdout and "--native-multi" in r.stdout
+
+
 def _worker(rank, world, port, n_sites, n_ind, max_kb, q):
     import torch
     import torch.distributed as dist
