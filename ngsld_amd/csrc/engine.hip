@@ -637,6 +637,34 @@ __global__ void patch_records_kernel(const uint64_t *idx, uint64_t n, const ngsl
   if (dst_ext != nullptr) dst_ext[idx[k]] = src_ext[k];
 }
 
+// (s1, s2) of plan records, on the device: what locate_record below does on the host copy of the items -- which a run that
+// leaves its records on the device never needs otherwise (configs[3]: 7.8e7 items, 2.5 GB to copy and hold for a few
+// hundred flagged pairs: 155 ms of its one 12 s step)
+__global__ void locate_records_kernel(const uint64_t *rec, uint64_t n, uint64_t base, const uint64_t *row_off,
+                                      const uint64_t *item_off, const Item *items, uint32_t n_sites, uint32_t *s1, uint32_t *s2) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  s1[t] = s2[t] = 0xffffffffu;
+  const uint64_t r = base + rec[t];
+  uint32_t lo = 0, hi = n_sites;  // largest row with row_off[row] <= r
+  while (lo + 1 < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (row_off[mid] <= r) lo = mid; else hi = mid;
+  }
+  uint64_t il = item_off[lo], ih = item_off[lo + 1];
+  if (il >= ih) return;
+  while (il + 1 < ih) {
+    const uint64_t mid = il + (ih - il) / 2;
+    if (items[mid].first_record <= r) il = mid; else ih = mid;
+  }
+  const Item it = items[il];
+  uint64_t k = r - it.first_record, m = it.mask;
+  if (k >= (uint64_t)__popcll(m)) return;
+  while (k--) m &= m - 1;
+  s1[t] = it.s1;
+  s2[t] = it.s2_begin + (uint32_t)(__ffsll((unsigned long long)m) - 1);
+}
+
 int ensure_host_items(ngsld_ctx *c) {  // the host copy of the plan's items, fetched on first use
   if (c->h_items.size() != c->n_items) {
     c->h_items.resize(c->n_items);
@@ -771,8 +799,26 @@ int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t bas
                    std::vector<uint32_t> *sites1 = nullptr, std::vector<uint32_t> *sites2 = nullptr) {
   Range range_("ngsld:exact-order replay (host)");
   if (recs.empty()) return NGSLD_OK;
-  const int rc0 = ensure_host_items(c);
-  if (rc0 != NGSLD_OK) return rc0;
+  // which pairs these records are: from the host copy of the plan's items where the run has one anyway (the sink path), from
+  // the device's otherwise
+  const bool have_items = c->h_items.size() == c->n_items;
+  std::vector<uint32_t> loc_s1, loc_s2;
+  if (!have_items) {
+    hipStream_t ls = st != nullptr ? st : c->replay_stream;
+    loc_s1.resize(recs.size());
+    loc_s2.resize(recs.size());
+    HIP_TRY(c, c->d_patch_idx.resize(recs.size()));
+    HIP_TRY(c, c->d_patch_s1.resize(recs.size()));
+    HIP_TRY(c, c->d_patch_s2.resize(recs.size()));
+    HIP_TRY(c, hipMemcpyAsync(c->d_patch_idx.p, recs.data(), recs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ls));
+    hipLaunchKernelGGL(locate_records_kernel, dim3((unsigned)((recs.size() + 63) / 64)), dim3(64), 0, ls, c->d_patch_idx.p,
+                       (uint64_t)recs.size(), base, c->d_row_off.p, c->d_item_off.p, c->d_items.p, (uint32_t)c->n_sites,
+                       c->d_patch_s1.p, c->d_patch_s2.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(loc_s1.data(), c->d_patch_s1.p, recs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
+    HIP_TRY(c, hipMemcpyAsync(loc_s2.data(), c->d_patch_s2.p, recs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
+    HIP_TRY(c, hipStreamSynchronize(ls));
+  }
   const bool ext = (h_std != nullptr ? (void *)h_ext : (void *)d_ext) != nullptr;
   const bool ign = c->params.ignore_miss_data != 0;
   std::vector<ngsld_rec_std> out_std(recs.size());
@@ -794,7 +840,8 @@ int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t bas
     try {
       for (size_t k = k0; k < k1; ++k) {
         uint32_t s1 = 0, s2 = 0;
-        if (!locate_record(c, base + recs[k], &s1, &s2)) {
+        if (have_items ? !locate_record(c, base + recs[k], &s1, &s2)
+                       : ((s1 = loc_s1[k]) == 0xffffffffu || (s2 = loc_s2[k]) == 0xffffffffu)) {
           rcs[(size_t)t] = NGSLD_ERR_INVALID;
           return;
         }
@@ -897,14 +944,23 @@ int device_replay(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_ba
 int finish_device_run(ngsld_ctx *c) {
   if (!c->dev_run.pending) return NGSLD_OK;
   c->dev_run.pending = false;
+  const bool trace = std::getenv("NGSLD_TRACE") != nullptr;  // dev: where ngsld_finish_device's time goes, on stderr
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   HIP_TRY(c, hipStreamSynchronize(c->dev_run.st));  // (the head of the flag buffer came over behind the kernels, ngsld_run_device)
+  const double t_sync = ms();
   if (!c->replay_on || c->d_flags_dev.p == nullptr || c->h_flags_dev.p == nullptr) return NGSLD_OK;
   if (c->h_flags_dev.p[0] == 0) return NGSLD_OK;
   const uint64_t base = c->h_row_off[c->dev_run.s1_begin], n = c->h_row_off[c->dev_run.s1_end] - base;
   std::vector<uint64_t> recs;
   const int rcf = flagged_records(c, c->h_flags_dev.p, c->d_flags_dev.p, c->flag_cap_dev, n, recs);
   if (rcf != NGSLD_OK) return rcf;
-  return replay_flagged(c, recs, base, nullptr, nullptr, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st);
+  const double t_list = ms();
+  const int rcr = replay_flagged(c, recs, base, nullptr, nullptr, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st);
+  if (trace)
+    std::fprintf(stderr, "[trace] finish_device: waited for the kernels %.2f ms, flag list %.2f ms (%u flagged, %zu for the host), "
+                         "host replay + patch %.2f ms\n", t_sync, t_list - t_sync, c->h_flags_dev.p[0], recs.size(), ms() - t_list);
+  return rcr;
 }
 
 }  // namespace
@@ -1440,7 +1496,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     }
   }
   auto need_host_items = [&]() -> int { return ensure_host_items(c); };
-  if (!text || replay) {  // (with the replay on also for text batches: fetched beside a running kernel the copy would wait for it)
+  if (!text) {  // (record batches carry their items to the sink; text batches need none -- the replay finds its pairs on the device)
     const int rc0 = need_host_items();
     if (rc0 != NGSLD_OK) return rc0;
   }
