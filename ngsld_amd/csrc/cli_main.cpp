@@ -10,6 +10,7 @@
 //     the rows are cut into one part per device, the output is the single-device output;
 #include <getopt.h>
 #include <sys/stat.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include <cmath>
@@ -258,6 +259,19 @@ struct TimingReport {  // NGSLD_TIMING=1: wall time since start, per phase, and 
 };
 
 
+// The genotype matrix in host memory: gigabytes touched once by the reader, read once by the upload, given back at exit.
+// Aligned to 2 MB and advised for transparent huge pages -- 600 page faults per 1.2 GB instead of 300,000 on the way in, and as
+// many fewer pages to give back on the way out (where huge pages are off the advice is ignored and this is malloc).
+double *alloc_matrix(size_t bytes) {
+  const size_t huge = (size_t)2 << 20;
+  void *p = nullptr;
+  if (bytes >= 8 * huge && posix_memalign(&p, huge, (bytes + huge - 1) / huge * huge) == 0 && p != nullptr) {
+    (void)madvise(p, (bytes + huge - 1) / huge * huge, MADV_HUGEPAGE);
+    return static_cast<double *>(p);
+  }
+  return static_cast<double *>(malloc(bytes));
+}
+
 struct ReadState {
   const Params *pars;
   char err[512];
@@ -500,7 +514,7 @@ int main(int argc, char **argv) {
   if (pars.in_bin && geno_bytes < (4ull << 30) && getenv("NGSLD_SLAB_SITES") == nullptr &&
       (pars.max_gpu_mem <= 0 || pars.max_gpu_mem * 1e9 > 3.0 * (double)geno_bytes) &&
       !(getenv("NGSLD_EARLY_READ") && strcmp(getenv("NGSLD_EARLY_READ"), "0") == 0)) {
-    early.raw.reset((double *)malloc((size_t)geno_bytes));
+    early.raw.reset(alloc_matrix((size_t)geno_bytes));
     if (early.raw) {
       early.started = true;
       early.th = std::thread([&early, &pars]() {
@@ -587,7 +601,7 @@ int main(int argc, char **argv) {
   if (early.started)
     raw = std::move(early.raw);
   else
-    raw.reset((double *)malloc((size_t)pars.n_sites * pars.n_ind * 3 * sizeof(double)));
+    raw.reset(alloc_matrix((size_t)pars.n_sites * pars.n_ind * 3 * sizeof(double)));
   if (!raw) error(__FUNCTION__, "cannot allocate the genotype matrix");
   ngsld_geno_opts go;
   memset(&go, 0, sizeof(go));
