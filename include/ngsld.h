@@ -171,7 +171,7 @@ int ngsld_run(ngsld_ctx *ctx, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn 
  * needs its finite gaps to be integers (as read_dist produces them), otherwise batches arrive as records. */
 int ngsld_set_text_output(ngsld_ctx *ctx, const char *const *labels, int enable);
 
-/* Optional: start allocating the pinned host buffers of the text batches (two, each for one batch of rows of about
+/* Optional: start allocating the pinned host buffers of the text batches (three, each for one batch of rows of about
  * bytes_per_row) on a library thread, so that pinning them overlaps whatever the caller does next (reading,
  * ngsld_set_geno_*, ngsld_plan) instead of the first batches of ngsld_run.  A batch that needs more gets a larger buffer
  * then.  Callable any time after ngsld_create. */

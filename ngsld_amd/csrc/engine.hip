@@ -257,7 +257,7 @@ struct ngsld_ctx {
   // device-side TSV (ngsld_set_text_output)
   bool text_mode = false, have_labels = false;
   uint64_t max_label = 6;  // "(null)"
-  DevBuf<char> d_labels, d_text[kSlots], d_scan_tmp;
+  DevBuf<char> d_labels, d_text[kSlots], d_scan_tmp, d_scan_tmp_b;  // (_b: the second compute stream's scan space)
   DevBuf<uint64_t> d_label_off, d_lens[kSlots], d_offs[kSlots], d_text_meta[kSlots];  // meta: {total bytes, needs_host}
   DevBuf<double> d_cum;
   DevBuf<uint32_t> d_infc;
@@ -1041,7 +1041,7 @@ void ngsld_destroy(ngsld_ctx *c) {
   (void)hipDeviceSynchronize();
   c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_rsx.release(); c->d_sc4.release(); c->d_runs.release();
   c->d_hard_masks.release(); c->d_hard_u.release(); c->d_all_hard.release();
-  c->d_labels.release(); c->d_scan_tmp.release(); c->d_label_off.release(); c->d_cum.release(); c->d_infc.release();
+  c->d_labels.release(); c->d_scan_tmp.release(); c->d_scan_tmp_b.release(); c->d_label_off.release(); c->d_cum.release(); c->d_infc.release();
   for (int k = 0; k < ngsld_ctx::kSlots; ++k) {
     c->d_text[k].release(); c->d_lens[k].release(); c->d_offs[k].release(); c->d_text_meta[k].release();
     c->h_text[k].release(); c->h_text_meta[k].release();
@@ -1328,7 +1328,7 @@ int ngsld_reserve_text_buffers(ngsld_ctx *c, uint64_t bytes_per_row) try {
   const uint64_t bytes_per_batch = bytes_per_row * std::min<uint64_t>(c->batch_pairs, kTextBatchPairs);
   c->reserve_thread = std::thread([c, bytes_per_batch] {
     if (hipSetDevice(c->device) != hipSuccess) return;
-    for (int k = 0; k < 2; ++k) (void)c->h_text[k].resize(bytes_per_batch);  // (a failure here is found again, and reported, at first use)
+    for (int k = 0; k < ngsld_ctx::kSlots; ++k) (void)c->h_text[k].resize(bytes_per_batch);  // (a failure here is found again, and reported, at first use)
   });
   return NGSLD_OK;
 } NGSLD_CATCH(c)
@@ -1506,9 +1506,14 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   // device buffers with a D2H copy per batch, the batches then shrinking towards the end of the run (run_taper).
   // NGSLD_RUN_STREAMS=2: three slots, two compute streams half a batch out of phase (see ngsld_ctx).
   const bool direct = !text && c->run_direct;
-  const bool two_streams = !text && c->run_streams == 2;
-  // (text with THREE slots, two batches queued ahead, measured no different from two: the compute stream does not run dry,
-  // profiles/r04/e2e_timeline.txt -- and a third of the pinned memory less to allocate and give back)
+  // Text batches are small (2^19 rows: a 2.8 ms pair kernel, a tenth of it ramp and drain) and many: for them the two compute
+  // streams half a batch out of phase DO pay, on every box -- while one stream's kernel drains the other's is in full
+  // flight: configs[2]'s loop 0.58-0.63 -> 0.546-0.551 s (profiles/r04/e2e_text_streams.txt).  NGSLD_TEXT_STREAMS=1: one stream.
+  bool text_two = true;
+  if (const char *e = std::getenv("NGSLD_TEXT_STREAMS")) text_two = std::atoi(e) != 1;
+  const bool two_streams = text ? text_two : c->run_streams == 2;
+  // (text on ONE stream with three slots, two batches queued ahead, measured no different from two slots: the compute stream
+  // does not run dry, profiles/r04/e2e_timeline.txt)
   const int S = two_streams ? ngsld_ctx::kSlots : 2;
   struct Batch {
     uint64_t r0, r1, n;
@@ -1582,6 +1587,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   if (text) {
     scan_bytes = text_scan_temp_bytes(cap);
     HIP_TRY(c, c->d_scan_tmp.resize(scan_bytes ? scan_bytes : 1));
+    if (two_streams) HIP_TRY(c, c->d_scan_tmp_b.resize(scan_bytes ? scan_bytes : 1));
     if (replay) HIP_TRY(c, c->d_scan_tmp2.resize(scan_bytes ? scan_bytes : 1));
   }
   auto text_args = [&](const Batch &b, int k) -> TextArgs {
@@ -1630,7 +1636,8 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), st));
       const TextArgs t = text_args(b, k);
       HIP_TRY(c, launch_text_lengths(t, st));
-      HIP_TRY(c, text_scan(c->d_scan_tmp.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n, c->d_text_meta[k].p, st));
+      HIP_TRY(c, text_scan(st == c->stream ? c->d_scan_tmp.p : c->d_scan_tmp_b.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n,
+                           c->d_text_meta[k].p, st));
       HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
       HIP_TRY(c, hipEventRecord(c->ev_kernel_done[k], st));
       return NGSLD_OK;
