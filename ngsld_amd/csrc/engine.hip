@@ -1523,10 +1523,12 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   // (kTextBatchPairs; round 1, configs[2] end to end: 2^23 pairs per batch 2.2 s, 2^21 1.5 s)
   // (records written by the kernels themselves: every launch costs ~0.4 ms of drain and nothing has to be staged on the
   // device, so the batches are twice the size -- 2 x 1.2 GB of pinned host memory with the extended record)
-  const uint64_t batch_pairs = text ? std::min<uint64_t>(c->batch_pairs, kTextBatchPairs)
-                                    : ((direct && !c->batch_pairs_set) ? 2 * c->batch_pairs : c->batch_pairs);
+  uint64_t batch_pairs = text ? std::min<uint64_t>(c->batch_pairs, kTextBatchPairs)
+                              : ((direct && !c->batch_pairs_set) ? 2 * c->batch_pairs : c->batch_pairs);
   const bool taper = !text && !direct && c->run_taper;
-  {
+  uint64_t cap = 1;
+  for (;;) {  // (a second trip only when the pinned record buffers of this batch size cannot be had: half the size then)
+    batches.clear();
     uint64_t left = c->timed_pairs;
     for (uint64_t r0 = s1_begin; r0 < s1_end;) {
       uint64_t target = batch_pairs;
@@ -1538,6 +1540,27 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       left -= std::min(left, c->h_row_off[r1] - c->h_row_off[r0]);
       r0 = r1;
     }
+    cap = 1;
+    for (auto &b : batches) cap = std::max(cap, b.n);
+    if (text) break;
+    // the batches' host buffers: pinned memory is the scarce kind -- a host that cannot pin two (three) buffers of this size
+    // gets batches of half the size instead of an error, down to 2^20 pairs
+    hipError_t e = hipSuccess;
+    if (const char *lim = std::getenv("NGSLD_PIN_LIMIT_BYTES"))  // tests: a host that cannot pin more than this per buffer
+      if (cap * sizeof(ngsld_rec_std) > std::strtoull(lim, nullptr, 10)) e = hipErrorOutOfMemory;
+    for (int k = 0; k < S && e == hipSuccess; ++k) {
+      e = c->h_std[k].resize(cap);
+      if (e == hipSuccess && ext) e = c->h_ext[k].resize(cap);
+    }
+    if (e == hipSuccess) break;
+    (void)hipGetLastError();
+    if (cap <= (1ull << 16) || batches.size() >= (1u << 20)) return hip_fail(c, e, "pinned host buffers of a record batch");
+    batch_pairs = std::min(batch_pairs, cap);  // (a run smaller than a batch: halve what it actually needed)
+    for (int k = 0; k < S; ++k) {
+      c->h_std[k].release();
+      c->h_ext[k].release();
+    }
+    batch_pairs /= 2;
   }
   if (uses_runs(c->cfg.kernel)) {
     // every batch should be thousands of workgroups (512 run at a time): the smaller the batches, the shorter the runs.
@@ -1549,8 +1572,6 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     const int rcr = build_runs(c, want, ends);
     if (rcr != NGSLD_OK) return rcr;
   }
-  uint64_t cap = 1;
-  for (auto &b : batches) cap = std::max(cap, b.n);
   for (int k = 0; k < S; ++k) {
     if (!direct) {
       HIP_TRY(c, c->d_std[k].resize(cap));
@@ -1561,9 +1582,6 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       HIP_TRY(c, c->d_offs[k].resize(cap));
       HIP_TRY(c, c->d_text_meta[k].resize(3));  // {total bytes, needs_host, a replayed row changed its length}
       HIP_TRY(c, c->h_text_meta[k].resize(3));
-    } else {
-      HIP_TRY(c, c->h_std[k].resize(cap));
-      if (ext) HIP_TRY(c, c->h_ext[k].resize(cap));
     }
     if (replay) {
       c->flag_cap[k] = flag_cap_for(cap);

@@ -21,12 +21,13 @@ VARIANTS = [
     {"NGSLD_BATCH_PAIRS": "40000"},                            # many small batches
     {"NGSLD_BATCH_PAIRS": "40000", "NGSLD_RUN_STREAMS": "2"},
     {"NGSLD_BATCH_PAIRS": "40000", "NGSLD_RUN_DIRECT": "0"},
+    {"NGSLD_PIN_LIMIT_BYTES": "2500000"},                      # pinned memory is scarce: batches halve until two buffers fit
 ]
 
 
 def _run(raw, pd, kw, env, monkeypatch, device_run=False):
     for k in ("NGSLD_RUN_DIRECT", "NGSLD_RUN_TAPER", "NGSLD_RUN_STREAMS", "NGSLD_TAIL_LEN", "NGSLD_TAIL_PAIRS", "NGSLD_BATCH_PAIRS",
-              "NGSLD_REPLAY"):
+              "NGSLD_REPLAY", "NGSLD_PIN_LIMIT_BYTES"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
