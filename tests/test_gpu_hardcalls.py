@@ -123,6 +123,9 @@ def test_device_replay_of_called_genotypes_is_the_hosts(n_ind, call, ignore, mis
     raw = np.eye(3)[synth.make_gl_numpy(n_sites, n_ind, 4200 + n_ind, depth=8.0).argmax(axis=2)]
     if miss:  # (under --call_geno an all-equal triple becomes call_geno's own "no data" triple, gen_func.cpp:897-905)
         raw[np.random.default_rng(5).random((n_sites, n_ind)) < miss] = 1.0 / 3.0
+    raw[7] = np.eye(3)[0]                                # a monomorphic site and a nearly monomorphic one: D' and r2 of their
+    raw[19] = np.eye(3)[0]                               # pairs are 0/0-type quotients (-nan, inf): replayed, bit for bit
+    raw[19, 3] = np.eye(3)[1]
     o = orc.Oracle(raw, None, ignore_miss_data=ignore, n_threads=32, call_geno=call)
     rec = o.run()
     got = {}
