@@ -161,7 +161,9 @@ int ngsld_plan(ngsld_ctx *ctx, const ngsld_params *params, uint64_t *n_pairs);
  * before each row), row_end [n_sites].  Used to shard rows across GPUs by pair count. */
 int ngsld_plan_rows(ngsld_ctx *ctx, const uint64_t **row_off, const uint32_t **row_end);
 
-/* Compute every pair of rows [s1_begin, s1_end) and hand the records to `sink`, batch by batch. */
+/* Compute every pair of rows [s1_begin, s1_end) and hand the records to `sink`, batch by batch.  The records of a batch are
+ * in pinned host memory the pair kernels wrote directly (no device copy, no D2H behind the last kernel): the host-resident
+ * rate is the kernels' rate to within 1 %. */
 int ngsld_run(ngsld_ctx *ctx, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user);
 
 /* Device-side TSV for ngsld_run (replaces the fprintf block of calc_pair_LD, ngsLD.cpp:310-352, at kernel rates):
@@ -234,7 +236,10 @@ int ngsld_last_kernel_time(ngsld_ctx *ctx, double *total_ms, uint64_t *n_launche
  * read_data.cpp:83-99), the pairs run on their 16 genotype-combination counts.  "" before any data is set. */
 const char *ngsld_pair_kernel(const ngsld_ctx *ctx);
 
-/* Tuning knobs (optional): pairs per work item, max pairs per batch of ngsld_run. 0 keeps the default. */
+/* Tuning knobs (optional): pairs per work item, max pairs per batch of ngsld_run. 0 keeps the default -- record batches of
+ * 2^24 pairs (the pair kernels write them straight into two pinned host buffers of that many records; halved, down to 2^16,
+ * on a host that cannot pin them), text batches of 2^19 rows.  A value given here is taken as it is for record batches and as
+ * an upper bound for text batches. */
 int ngsld_set_tuning(ngsld_ctx *ctx, uint32_t pairs_per_item, uint64_t batch_pairs);
 
 /* On-device self test of the wavefront primitives the pair kernel relies on (cross-lane fold
