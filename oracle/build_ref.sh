@@ -51,6 +51,9 @@ drop_gsl_cpp() {   # source: no self-include, no draw_rnd definition (signature 
 #   ref_pair_stats    ngsLD.cpp:296-306  hap-derived maf, D, D', r2      + :328-333  chi2 in float
 #   ref_format_row    ngsLD.cpp:296-306 + :311-351  the two fprintf formats (standard + extended columns) and the newline
 #   ref_print_header  ngsLD.cpp:77       the header line
+# parse_args.cpp (init_pars, parse_cmd_args: the option table, the defaults, the argument echo, the validation messages) uses
+# nothing of GSL but the header it includes: it is compiled WHOLE, with `version` taken from its one line of ngsLD.cpp
+# (ref_parse_args in ref_shim.cpp calls it; tests/test_cli_args_vs_ref.py holds the drop-in binary's own parser to it).
 CPP="$REF/ngsLD.cpp"
 anchor() {  # anchor <regex>: the number of the ONE line of ngsLD.cpp it matches
   local hits
@@ -71,6 +74,7 @@ F1=$(( $(anchor '^    pthread_mutex_unlock\(&printf_mutex\);$') - 1 ))
 C0=$(anchor '^      float chi2 = 0;$')
 C1=$(anchor '^	    chi2 \+= pow\(hap_freq\[i\]-exp_hap_freq\[i\],2\)/exp_hap_freq\[i\];$')
 H0=$(anchor '^  fprintf\(pars->out_fh, "site1\\tsite2\\tdist\\tr2_ExpG')
+V0=$(anchor '^char const\* version = "[^"]*";$')
 # the walk's last line must be the closing brace of the maf[s2] skip, the print block must end with the newline fprintf
 sed -n "${W1}p" "$CPP" | grep -qE '^    \}$' || { echo "build_ref.sh: ngsLD.cpp:$W1 is not the end of the maf[s2] block" >&2; exit 1; }
 sed -n "${F1}p" "$CPP" | grep -qE '^    fprintf\(p->pars->out_fh, "\\n"\);$' || { echo "build_ref.sh: ngsLD.cpp:$F1 is not the newline fprintf" >&2; exit 1; }
@@ -170,8 +174,12 @@ CXX
   return n;
 }
 CXX
+  # -- the command line: parse_args.cpp whole (its include of ngsLD.hpp is already in the stream), `version` from ngsLD.cpp
+  cut_lines "$V0" "$V0"
+  echo '#line 1 "reference:parse_args.cpp"'
+  sed -e '/#include "ngsLD.hpp"/d' "$REF/parse_args.cpp"
   echo '#line 1 "oracle/ref_shim.cpp"'
   cat "$HERE/ref_shim.cpp"
 } | g++ -x c++ -O3 -w -fPIC -shared -ffp-contract=off -o "$HERE/_ref/libngsld_ref.so" - -lz -lpthread
 
-echo "built $HERE/_ref/libngsld_ref.so (ngsLD.cpp lines $W0-$W1, $S0-$S1, $F0-$F1, $H0 compiled in)"
+echo "built $HERE/_ref/libngsld_ref.so (ngsLD.cpp lines $W0-$W1, $S0-$S1, $F0-$F1, $H0, $V0 and parse_args.cpp compiled in)"

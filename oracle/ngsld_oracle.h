@@ -20,6 +20,8 @@
  *     BIT-FOR-BIT / BYTE-FOR-BYTE against them (tests/test_oracle_vs_ref.py: 10^5 haplotype vectors
  *     incl. degenerate ones, 8,000 formatted rows, six filter sets), and every golden row was held to
  *     the reference's own fprintf lines when the fixtures were generated.
+ *   - parse_args.cpp (option table, defaults, argument echo, validation messages) is compiled whole into oracle/_ref as
+ *     well; tests/test_cli_args_vs_ref.py holds the drop-in binary's parser to it (exit status and stderr, 23 argv vectors).
  *   - PARITY UNPINNED at the GSL boundary only: the Pearson r2 of expected genotypes
  *     (gsl_stats_correlation, ngsLD.cpp:365-367) and the --rnd_sample draws (gsl_rng_taus,
  *     ngsLD.cpp:69-70,165-166,277).  GSL is absent from /root/reference and from the image; both are

@@ -153,6 +153,9 @@ def ref():
             R.ref_walk.restype = C.c_uint64
             R.ref_walk.argtypes = [C.c_uint64, c_double_p, c_double_p, C.c_uint64, C.c_uint64, C.c_double, C.c_uint64,
                                    C.POINTER(C.c_uint64), c_double_p, C.c_uint64]
+        if hasattr(R, "ref_parse_args"):   # parse_args.cpp compiled whole (tests/test_cli_args_vs_ref.py)
+            R.ref_parse_args.restype = C.c_int
+            R.ref_parse_args.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
         if hasattr(R, "ref_bench_haplo_freq"):
             R.ref_bench_haplo_freq.restype = C.c_uint64
             R.ref_bench_haplo_freq.argtypes = [c_double_p, c_double_p, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64,

@@ -38,6 +38,26 @@ uint64_t ref_walk(uint64_t n_sites, double *pos_dist, double *maf, uint64_t max_
   return ref_walk_row(&pars, site, out_s2, out_dist, cap);
 }
 
+/* The reference's own command-line parser (parse_args.cpp, compiled whole by build_ref.sh): init_pars + parse_cmd_args on
+ * argv.  Whatever they print goes to stderr as in the reference, an invalid argument ends the PROCESS through error()
+ * (gen_func.cpp:12-18: exit(-1)) -- callers run this in a child process; on return the parsed fields are printed on stdout
+ * as one line (seed left out: its default is the clock). */
+int ref_parse_args(int argc, char **argv) {
+  params pars;
+  init_pars(&pars);
+  optind = 1;
+  parse_cmd_args(&pars, argc, argv);
+  printf("PARSED geno=%s probs=%d log_scale=%d n_ind=%lu n_sites=%lu pos=%s posH=%d max_kb_dist=%lu max_snp_dist=%lu min_maf=%.17g "
+         "ignore_miss_data=%d call_geno=%d N_thresh=%.17g call_thresh=%.17g rnd_sample=%.17g extend_out=%d out=%s n_threads=%u verbose=%u\n",
+         pars.in_geno ? pars.in_geno : "(null)", (int)pars.in_probs, (int)pars.in_logscale, (unsigned long)pars.n_ind,
+         (unsigned long)pars.n_sites, pars.in_pos ? pars.in_pos : "(null)", (int)pars.in_pos_header,
+         (unsigned long)pars.max_kb_dist, (unsigned long)pars.max_snp_dist, pars.min_maf, (int)pars.ignore_miss_data,
+         (int)pars.call_geno, pars.N_thresh, pars.call_thresh, pars.rnd_sample, (int)pars.extend_out,
+         pars.out ? pars.out : "(null)", pars.n_threads, pars.verbose);
+  fflush(stdout);
+  return 0;
+}
+
 double ref_logsum(double *a, uint64_t n) { return logsum(a, n); }
 void ref_post_prob(double *pp, double *lkl, uint64_t n) { post_prob(pp, lkl, NULL, n); }
 int ref_miss_data(double *g) { return miss_data(g) ? 1 : 0; }

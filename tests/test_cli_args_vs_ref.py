@@ -1,0 +1,94 @@
+"""The drop-in binary's command line against the REFERENCE's own parser, compiled (CPU; no GPU needed).
+
+oracle/build_ref.sh compiles parse_args.cpp whole (init_pars, parse_cmd_args: option table, defaults, argument echo,
+validation messages -- it uses nothing of GSL but the header it includes).  For every argv below the reference's parser runs
+in a child process (an invalid argument ends the process through error(), gen_func.cpp:12-18) and `ngsld_amd/bin/ngsLD` runs on
+the same argv: same exit status for argument errors, same stderr -- the "==> Input Arguments:" block line for line (the
+version line names this build), getopt's own complaints, the ERROR block.  Without a GPU the binary stops right after the
+arguments (at the input file or the device), which is all this test needs."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from ngsld_amd import capi
+from oracle import orc
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ref = orc.ref()
+pytestmark = pytest.mark.skipif(ref is None or not hasattr(ref, "ref_parse_args") or not os.path.exists(capi.CLI_PATH),
+                                reason="needs oracle/_ref with parse_args.cpp (oracle/build_ref.sh) and the built ngsLD binary")
+
+OK = ["--geno", "in.glf", "--n_ind", "5", "--n_sites", "7", "--pos", "in.pos", "--seed", "11"]
+CASES = [
+    ("plain", OK, None),
+    ("every flag", OK + ["--probs", "--max_kb_dist", "25", "--max_snp_dist", "9", "--min_maf", "0.05", "--ignore_miss_data",
+                         "--call_geno", "--N_thresh", "0.3", "--call_thresh", "0.9", "--rnd_sample", "0.5", "--extend_out",
+                         "--out", "o.tsv", "--n_threads", "3", "--verbose", "2"], None),
+    ("single dash, abbreviations", ["-geno", "in.glf", "-n_ind", "5", "-n_sites", "7", "-posH", "in.pos", "-seed", "4", "-ext",
+                                    "-ignore", "-max_kb", "3"], None),
+    ("log_scale implies probs", OK + ["--log_scale"], None),
+    ("N_thresh implies call_geno", OK + ["--probs", "--N_thresh", "0.2"], None),
+    ("call_thresh implies call_geno (no probs: error)", OK + ["--call_thresh", "0.8"], "can only call genotypes"),
+    ("no distance limit, no pos", ["--geno", "in.glf", "--n_ind", "5", "--n_sites", "7", "--max_kb_dist", "0", "--seed", "1"], None),
+    ("verbose 0: no echo", OK + ["--verbose", "0"], None),
+    ("verbose 5", OK + ["--verbose", "5"], None),
+    ("geno missing", ["--n_ind", "5", "--n_sites", "7", "--seed", "1"], "genotype input file (--geno) missing!"),
+    ("n_ind missing", ["--geno", "in.glf", "--n_sites", "7", "--seed", "1"], "number of individuals (--n_ind) missing!"),
+    ("n_sites missing", ["--geno", "in.glf", "--n_ind", "5", "--pos", "p", "--seed", "1"], "number of sites (--n_sites) missing!"),
+    ("pos missing", ["--geno", "in.glf", "--n_ind", "5", "--n_sites", "7", "--seed", "1"], "position file necessary"),
+    ("min_maf out of range", OK + ["--min_maf", "1.5"], "minimum allele frequency must be in [0,1]!"),
+    ("min_maf negative", OK + ["--min_maf", "-0.1"], "minimum allele frequency must be in [0,1]!"),
+    ("call_geno without probs", OK + ["--call_geno"], "can only call genotypes from likelihoods/probabilities!"),
+    ("rnd_sample zero", OK + ["--rnd_sample", "0"], "proportion of comparisons to sample must be in ]0,1]!"),
+    ("rnd_sample above one", OK + ["--rnd_sample", "1.01"], "proportion of comparisons to sample must be in ]0,1]!"),
+    ("n_threads zero", OK + ["--n_threads", "0"], "number of threads cannot be less than 1!"),
+    ("unknown flag", OK + ["--no_such_flag"], ""),
+    ("declared flag without a case", OK + ["--outH", "x"], ""),
+    ("flag without its argument", ["--geno", "in.glf", "--n_ind"], ""),
+    ("atoi semantics", ["--geno", "in.glf", "--n_ind", "5x", "--n_sites", "7.9", "--pos", "p", "--seed", "1", "--max_kb_dist", "abc"], None),
+]
+
+_CHILD = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from oracle import orc
+R = orc.ref()
+argv = [b"ngsLD"] + [a.encode() for a in sys.argv[1:]]
+arr = (C.c_char_p * (len(argv) + 1))(*argv, None)
+sys.stdout.flush()
+sys.exit(R.ref_parse_args(len(argv), arr))
+""" % REPO
+
+
+def _norm(stderr: str) -> list[str]:
+    out = []
+    for ln in stderr.splitlines():
+        ln = re.sub(r"^\S*ngsLD:", "ngsLD:", ln)                        # getopt prefixes its complaints with argv[0]
+        ln = re.sub(r"^\tversion: .*$", "\tversion: <build>", ln)
+        out.append(ln)
+    return out
+
+
+@pytest.mark.parametrize("name,args,err", CASES, ids=[c[0] for c in CASES])
+def test_binary_parses_like_the_reference(name, args, err, tmp_path):
+    want = subprocess.run([sys.executable, "-c", _CHILD, *args], capture_output=True, text=True, cwd=str(tmp_path), timeout=120)
+    got = subprocess.run([capi.CLI_PATH, *args], capture_output=True, text=True, cwd=str(tmp_path), timeout=120)
+    w, g = _norm(want.stderr), _norm(got.stderr)
+    if err is None:
+        # valid arguments: the reference's parser returns; the echo block (everything it printed) must head our stderr
+        assert want.returncode == 0 and "PARSED" in want.stdout, want.stderr
+        assert g[:len(w)] == w, f"echo differs:\n{g[:len(w)]}\n--- reference ---\n{w}"
+        # and what follows is not an ARGUMENT error (the run goes on to its input file / device)
+        rest = "\n".join(g[len(w):])
+        assert "parse_cmd_args" not in rest
+    else:
+        # invalid arguments: exit(-1) on both sides, the same text up to the end of the ERROR block (perror's line names errno,
+        # which the two processes need not share)
+        assert want.returncode == 255 and got.returncode == 255, (want.returncode, got.returncode, got.stderr)
+        if err:
+            assert any(err in ln for ln in w) and any(err in ln for ln in g)
+        cut = lambda lines: lines[:max((i for i, ln in enumerate(lines) if ln.startswith("=====")), default=len(lines) - 1) + 1]
+        assert cut(g) == cut(w), f"stderr differs:\n{cut(g)}\n--- reference ---\n{cut(w)}"
