@@ -81,6 +81,31 @@ sed -n "${F1}p" "$CPP" | grep -qE '^    fprintf\(p->pars->out_fh, "\\n"\);$' || 
 [ "$W0" -lt "$W1" ] && [ "$W1" -lt "$S0" ] && [ "$S0" -lt "$S1" ] && [ "$S1" -lt "$F0" ] && [ "$F0" -lt "$C0" ] && [ "$C0" -lt "$C1" ] && [ "$C1" -lt "$F1" ] || {
   echo "build_ref.sh: anchors of ngsLD.cpp out of order ($W0 $W1 $S0 $S1 $F0 $C0 $C1 $F1)" >&2; exit 1; }
 
+# ---- main() and calc_pair_LD WHOLE, minus the statements that need GSL -----------------------------------------------------
+# ngsLD.cpp from `int main` to the end of calc_pair_LD, compiled as it stands but for: the six statements that allocate, seed
+# or free a gsl_rng (main: master stream, per-row streams; calc_pair_LD's free) -- dropped; the --rnd_sample block of
+# calc_pair_LD (`// Random sampling` ... its closing brace: the draw is GSL's) -- dropped, so the door refuses rnd_sample < 1;
+# the ONE call of pearson_r (gsl_stats_correlation) -- replaced by a lookup of the value the caller supplies for that pair
+# (the oracle's r2_ExpG: this column stays unpinned, everything else of the run is the reference's text); `main` renamed
+# ref_main.  shared/threadpool.c is compiled with it (as C++, like the reference's Makefile does).  The counts of what the
+# filter touched are asserted.  ref_main(argc, argv) therefore IS the reference's program flow -- argument parsing, file
+# checks, reader, call_geno loop, est_maf loop, exp / expected genotypes, positions and labels, thread pool, per-row walk, EM,
+# statistics, fprintf -- on real files, writing the reference's TSV.
+M0=$(anchor '^int main \(int argc, char\*\* argv\) \{$')
+M1=$(( $(anchor '^double pearson_r \(double \*s1, double \*s2, uint64_t n_ind\)\{$') - 1 ))
+main_and_calc() {
+  sed -n "${M0},${M1}p" "$CPP" | awk '
+    /^int main \(int argc, char\*\* argv\) \{$/ { print "extern \"C\" int ref_main (int argc, char** argv) {"; renamed++; next }
+    /gsl_rng/ { rng++; next }
+    /^    \/\/ Random sampling$/ { skip=1; blocks++ }
+    skip { if ($0 ~ /^    \}$/) skip=0; next }
+    /^    r2pear = pearson_r\(p->pars->expected_geno\[s1\], p->pars->expected_geno\[s2\], p->pars->n_ind\);$/ {
+      print "    r2pear = ref_r2pear_lookup(s1, s2);"; pear++; next }
+    { print }
+    END { if (renamed != 1 || rng != 6 || blocks != 1 || pear != 1) { print "#error build_ref.sh: ngsLD.cpp changed (main " renamed ", gsl_rng lines " rng ", sampling blocks " blocks ", pearson_r calls " pear ")" } }
+  '
+}
+
 drop_gsl_ngsld_hpp() {  # ngsLD.hpp: no GSL include, no gsl_rng member, no quoted includes (their text is already in the stream)
   sed -e '/#include <gsl\//d' -e '/gsl_rng\* rnd_gen;/d' -e '/#pragma once/d' -e '/#include "read_data.hpp"/d' \
       -e '/#include "threadpool.h"/d' "$1"
@@ -174,6 +199,12 @@ CXX
   return n;
 }
 CXX
+  # -- main() and calc_pair_LD whole (GSL statements removed, see above) + the thread pool
+  echo 'extern "C" double ref_r2pear_lookup(uint64_t s1, uint64_t s2);'
+  echo '#line 1 "reference:shared/threadpool.c"'
+  sed -e '/#include "threadpool.h"/d' "$REF/shared/threadpool.c"
+  echo "#line $M0 \"reference:ngsLD.cpp (main + calc_pair_LD, GSL statements removed)\""
+  main_and_calc
   # -- the command line: parse_args.cpp whole (its include of ngsLD.hpp is already in the stream), `version` from ngsLD.cpp
   cut_lines "$V0" "$V0"
   echo '#line 1 "reference:parse_args.cpp"'

@@ -20,6 +20,10 @@
  *     BIT-FOR-BIT / BYTE-FOR-BYTE against them (tests/test_oracle_vs_ref.py: 10^5 haplotype vectors
  *     incl. degenerate ones, 8,000 formatted rows, six filter sets), and every golden row was held to
  *     the reference's own fprintf lines when the fixtures were generated.
+ *   - main() and calc_pair_LD WHOLE (ngsLD.cpp:27-359) are compiled too, minus the statements that need GSL (gsl_rng: dropped;
+ *     the --rnd_sample block: dropped; the one pearson_r call: a lookup of the caller's value): ref_main runs the reference's
+ *     program flow on real files, and tests/test_ref_main_run.py holds the oracle CLI's TSV to its output byte for byte on 15
+ *     fixtures (r2_ExpG handed in from the oracle).
  *   - parse_args.cpp (option table, defaults, argument echo, validation messages) is compiled whole into oracle/_ref as
  *     well; tests/test_cli_args_vs_ref.py holds the drop-in binary's parser to it (exit status and stderr, 23 argv vectors).
  *   - PARITY UNPINNED at the GSL boundary only: the Pearson r2 of expected genotypes

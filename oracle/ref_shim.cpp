@@ -38,6 +38,25 @@ uint64_t ref_walk(uint64_t n_sites, double *pos_dist, double *maf, uint64_t max_
   return ref_walk_row(&pars, site, out_s2, out_dist, cap);
 }
 
+/* r2_ExpG for ref_main's calc_pair_LD: the one value of a row's output that comes from GSL.  The caller supplies it per pair
+ * ((s1, s2) in increasing order, first[s1] = index of row s1's first pair, first[n_sites] = number of pairs); a pair that is
+ * not in the table gets NaN. */
+static const uint64_t *g_r2_first = NULL, *g_r2_s2 = NULL;
+static const double *g_r2_val = NULL;
+static uint64_t g_r2_sites = 0;
+void ref_set_r2pear(const uint64_t *first, const uint64_t *s2, const double *val, uint64_t n_sites) {
+  g_r2_first = first; g_r2_s2 = s2; g_r2_val = val; g_r2_sites = n_sites;
+}
+double ref_r2pear_lookup(uint64_t s1, uint64_t s2) {
+  if (g_r2_first == NULL || s1 >= g_r2_sites) return NAN;
+  uint64_t lo = g_r2_first[s1], hi = g_r2_first[s1 + 1];
+  while (lo < hi) {
+    uint64_t mid = lo + (hi - lo) / 2;
+    if (g_r2_s2[mid] < s2) lo = mid + 1; else hi = mid;
+  }
+  return (lo < g_r2_first[s1 + 1] && g_r2_s2[lo] == s2) ? g_r2_val[lo] : NAN;
+}
+
 /* The reference's own command-line parser (parse_args.cpp, compiled whole by build_ref.sh): init_pars + parse_cmd_args on
  * argv.  Whatever they print goes to stderr as in the reference, an invalid argument ends the PROCESS through error()
  * (gen_func.cpp:12-18: exit(-1)) -- callers run this in a child process; on return the parsed fields are printed on stdout
