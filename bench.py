@@ -23,9 +23,11 @@ Prints ONE JSON line on rank 0 (contract in the task statement).  Beside the con
                        if every pair streamed both sites from HBM), kernel time from HIP events on the launch stream;
                        `traffic` is the HBM traffic measured with rocprofv3 PMC counters in a separate profiling run
                        (profiles/), not in this run; `fp64_valu` is the roofline that actually binds the kernel
-  cpu_baseline         the host: `port` = the oracle restatement (whole per-pair path), `reference` = the reference's
-                       own compiled haplo_freq (oracle/_ref; the EM only, an upper bound on the reference's rate),
-                       each on the threads this process may really use and on one thread
+  cpu_baseline         the host, on the threads this process may really use: kind "reference" = the reference's OWN program
+                       (oracle/_ref: ngsLD.cpp's main + calc_pair_LD compiled whole minus the statements that need GSL) from a
+                       file of the sample's first sites to TSV; beside it `port` = the oracle restatement (whole per-pair path,
+                       with the whole-sample parity check against the GPU's records) and `reference` = the reference's
+                       compiled haplo_freq alone (the EM only), each also on one thread
 """
 from __future__ import annotations
 
@@ -180,7 +182,64 @@ def cpu_baseline(raw_head: np.ndarray, pos_dist_head: np.ndarray, max_kb: int, t
                             "executed_iterations_equal_port": bool(rrows != rows or rit == iters)}
     else:
         out["reference"] = None
+    # ---- the reference's own PROGRAM (oracle/_ref: ngsLD.cpp's main + calc_pair_LD compiled whole minus the statements that
+    # need GSL, oracle/build_ref.sh): file -> reader -> est_maf -> thread pool -> calc_pair_LD -> fprintf, --n_threads = the
+    # threads this process may use, on a file of the sample's first sites.  pearson_r (gsl_stats_correlation, ~4 % of its
+    # per-pair time by SURVEY 8a) is the one thing it does not do: the column prints -nan.
+    rp = reference_program(raw_head, pos_dist_head, max_kb, min(n_have, rows + halo), nt)
+    out["reference_program"] = rp
+    if rp and "value" in rp:   # the baseline of the line is the reference's own program where it can run; the port stays beside it
+        out["port"] = {k: out[k] for k in ("value", "unit", "cores", "kind", "sample")}
+        out.update(value=rp["value"], cores=rp["cores"], kind="reference", sample=rp["sample"])
     return out
+
+
+_REF_CHILD = r"""
+import ctypes as C, sys, time
+sys.path.insert(0, %r)
+from oracle import orc
+R = orc.ref()
+argv = [b"ngsLD"] + [a.encode() for a in sys.argv[1:]]
+arr = (C.c_char_p * (len(argv) + 1))(*argv, None)
+R.ref_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+t0 = time.perf_counter()
+rc = R.ref_main(len(argv), arr)
+print("REF_MAIN_SECONDS", time.perf_counter() - t0, flush=True)
+sys.exit(rc)
+""" % REPO
+
+
+def reference_program(raw_head: np.ndarray, pos_dist_head: np.ndarray, max_kb: int, n_file: int, threads: int) -> dict | None:
+    from oracle import orc
+    R = orc.ref()
+    if R is None or not hasattr(R, "ref_main") or n_file < 2:
+        return None
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    with tempfile.TemporaryDirectory(dir=base) as d:
+        g, p = os.path.join(d, "sample.glf"), os.path.join(d, "sample.pos")
+        np.ascontiguousarray(raw_head[:n_file]).tofile(g)
+        pos = np.cumsum(np.where(np.isfinite(pos_dist_head[:n_file]), pos_dist_head[:n_file], 0.0)).astype(np.int64)
+        with open(p, "w") as fh:
+            fh.write("".join(f"chr1\t{int(x)}\n" for x in pos))
+        n_pairs = orc.Oracle(raw_head[:n_file], pos_dist_head[:n_file].copy(), max_kb_dist=max_kb, n_threads=threads).count()
+        cmd = [sys.executable, "-c", _REF_CHILD, "--geno", g, "--n_ind", str(raw_head.shape[1]), "--n_sites", str(n_file),
+               "--max_kb_dist", str(max_kb), "--extend_out", "--n_threads", str(threads), "--verbose", "0", "--out", "/dev/null"]
+        if max_kb > 0:
+            cmd += ["--pos", p]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        except subprocess.TimeoutExpired:
+            return {"error": "timeout"}
+        sec = [ln.split()[1] for ln in r.stdout.splitlines() if ln.startswith("REF_MAIN_SECONDS")]
+        if r.returncode != 0 or not sec:
+            return {"error": r.stderr[-300:]}
+        dt = float(sec[0])
+    return {"value": n_pairs / dt, "unit": "pairs/s", "cores": threads, "kind": "reference",
+            "sample": f"the first {n_file} sites of the same matrix as a binary GL file ({n_pairs} pairs, {dt:.1f} s from file to "
+                      f"TSV on /dev/null, --extend_out, --n_threads {threads}): ngsLD.cpp's own main() and calc_pair_LD compiled "
+                      "from /root/reference into oracle/_ref minus the statements that need GSL -- reader, est_maf, thread pool, "
+                      "walk, haplo_freq, D / D' / r2, fprintf; pearson_r (gsl_stats_correlation) is not computed, its column "
+                      "prints -nan"}
 
 
 def e2e_file_to_tsv(raw_dev, n_sites: int, n_ind: int, chrs, pos, max_kb: int, threads: int) -> dict | None:
