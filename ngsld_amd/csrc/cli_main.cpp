@@ -27,6 +27,7 @@
 
 #include "../../include/ngsld.h"
 #include "../../include/ngsld_host.h"
+#include "host_buf.h"
 
 namespace {
 
@@ -259,18 +260,8 @@ struct TimingReport {  // NGSLD_TIMING=1: wall time since start, per phase, and 
 };
 
 
-// The genotype matrix in host memory: gigabytes touched once by the reader, read once by the upload, given back at exit.
-// Aligned to 2 MB and advised for transparent huge pages -- 600 page faults per 1.2 GB instead of 300,000 on the way in, and as
-// many fewer pages to give back on the way out (where huge pages are off the advice is ignored and this is malloc).
-double *alloc_matrix(size_t bytes) {
-  const size_t huge = (size_t)2 << 20;
-  void *p = nullptr;
-  if (bytes >= 8 * huge && posix_memalign(&p, huge, (bytes + huge - 1) / huge * huge) == 0 && p != nullptr) {
-    (void)madvise(p, (bytes + huge - 1) / huge * huge, MADV_HUGEPAGE);
-    return static_cast<double *>(p);
-  }
-  return static_cast<double *>(malloc(bytes));
-}
+// (the genotype matrix in host memory: host_buf.h -- malloc semantics, huge pages)
+double *alloc_matrix(size_t bytes) { return ngsld::alloc_host_matrix(bytes / sizeof(double)); }
 
 struct ReadState {
   const Params *pars;

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/ngsld.h"
+#include "host_buf.h"
 
 #include <atomic>
 
@@ -276,7 +277,7 @@ int ngsld_run_multi(const int *devices, int n_devices, uint64_t n_sites, uint64_
   Barrier barrier(n);
   std::vector<int> rcs((size_t)n, NGSLD_OK), hard((size_t)n, 0);
   std::vector<std::string> msgs((size_t)n);
-  std::vector<std::vector<double>> host((size_t)n);
+  std::vector<ngsld::HostMatrix> host((size_t)n);  // (host_buf.h: a part's raw values, no zero-fill, huge pages)
 
   auto work = [&](int k) {
     const ngsld_slab &pt = parts[(size_t)k];
@@ -296,7 +297,7 @@ int ngsld_run_multi(const int *devices, int n_devices, uint64_t n_sites, uint64_
         if (gl_raw != nullptr) {
           slab = gl_raw + pt.row_begin * n_ind * 3;
         } else {
-          host[(size_t)k].resize(m * n_ind * 3);
+          if (!host[(size_t)k].alloc((size_t)(m * n_ind * 3))) throw std::bad_alloc();
           if (read(read_user, pt.row_begin, m, host[(size_t)k].data()) != 0) {
             r = NGSLD_ERR_INVALID;
             msg = "cannot read the genotype data of a part";

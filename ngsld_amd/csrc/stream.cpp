@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/ngsld.h"
+#include "host_buf.h"
 
 namespace {
 
@@ -129,7 +130,7 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
   for (const ngsld_slab &s : slabs) max_sites = std::max(max_sites, s.site_end - s.row_begin);
 
   ngsld_ctx *ctx[2] = {nullptr, nullptr};
-  std::vector<double> host[2];
+  ngsld::HostMatrix host[2];  // (host_buf.h: no zero-fill, huge pages)
   for (int k = 0; k < 2; ++k) {
     if (k == 1 && n_slabs < 2) break;
     rc = ngsld_create(device, &ctx[k]);
@@ -138,9 +139,7 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
       if (ctx[0]) ngsld_destroy(ctx[0]);
       return rc;
     }
-    try {
-      host[k].resize(max_sites * n_ind * 3);
-    } catch (const std::bad_alloc &) {
+    if (!host[k].alloc((size_t)(max_sites * n_ind * 3))) {
       set_err(err, errlen, "cannot allocate the host slab buffer");
       for (int q = 0; q <= k; ++q) ngsld_destroy(ctx[q]);
       return NGSLD_ERR_NOMEM;
