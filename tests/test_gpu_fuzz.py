@@ -12,6 +12,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _case(k):
+    return _case_full(k)[:4]
+
+
+def _case_full(k):
+    """The case's matrix, pos_dist, options and calling thresholds -- and the positions pos_dist came from, for the tests that
+    hand the case to a program as files (test_gpu_vs_ref_program.py)."""
     rng = np.random.default_rng(1000 + k)
     if k < 10_000:
         n_ind = int(rng.choice([1, 3, 15, 16, 17, 33, 64, 100, 128, 129, 200, 257, 500, 513, 777, 1100, 2100, 4100]))
@@ -43,7 +49,7 @@ def _case(k):
               max_kb_dist=int(rng.choice([0, 0, 1, 5, 50])), max_snp_dist=int(rng.choice([0, 0, 3, 11])),
               rnd_sample=float(rng.choice([1.0, 1.0, 0.5, 0.15])), seed=int(rng.integers(0, 2 ** 40)))
     call = None if rng.random() < 0.8 else tuple(sorted(rng.random(2)))
-    return raw, pd, kw, call
+    return raw, pd, kw, call, chrs, pos
 
 
 # seeds beyond the first 240 on which the first version of the three-value EM step lost D' (hap 0 of ~1e-15 recovered

@@ -1,0 +1,96 @@
+"""GPU: the drop-in binary against the reference's OWN program, same argv, same files, same bytes.
+
+`ngsld_amd/bin/ngsLD` (HIP) and `ref_main` (oracle/_ref: ngsLD.cpp's main() + calc_pair_LD compiled as they stand but for the GSL
+statements, oracle/build_ref.sh) are handed the SAME command line over the SAME input files; the TSV of one must be the TSV of
+the other -- header equal, body equal as sorted lines (the reference's rows come out in thread order, examples/test.sh:16 sorts
+them too).  Fixtures first, then the fuzz generator's cases written out as files (binary likelihoods, chromosome breaks, every
+filter, --ignore_miss_data, --log_scale, --call_geno, allele-frequency thresholds that sit ON a site's frequency).  The
+reference program's r2_ExpG column is the oracle's (GSL is not in the image): the one column this does not pin; --rnd_sample
+needs gsl_rng and is left to the fixtures of test_gpu_golden.py.  (tools/cli_soak.py runs the same comparison over any range.)"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ngsld_amd import capi, synth
+from oracle import orc
+from test_gpu_fuzz import _case_full, pick_min_maf
+from util import Fixture, fixtures, have_ref_program, run_ref_program
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not have_ref_program(), reason="oracle/_ref predates ref_main (rebuild with oracle/build_ref.sh)")]
+
+
+def same_tsv(got: str, want: str) -> str | None:
+    """None when the two programs wrote the same table; else where they differ."""
+    gl, wl = got.splitlines(keepends=True), want.splitlines(keepends=True)
+    if not gl and not wl:
+        return None
+    if len(gl) != len(wl):
+        return f"{len(gl)} lines against the reference's {len(wl)}"
+    if gl[0] != wl[0]:
+        return f"first line {gl[0]!r} against {wl[0]!r}"
+    a, b = sorted(gl[1:]), sorted(wl[1:])
+    for x, y in zip(a, b):
+        if x != y:
+            return f"{sum(1 for p, q in zip(a, b) if p != q)} rows differ, first:\n  hip {x!r}\n  ref {y!r}"
+    return None
+
+
+def both_programs(flags: list[str], rec, n_sites: int, d: str, threads: int = 2):
+    out_ref = os.path.join(d, "ref.tsv")
+    r = run_ref_program(rec, n_sites, flags, out_ref, d, threads)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out_hip = os.path.join(d, "hip.tsv")
+    h = subprocess.run([capi.CLI_PATH, *flags, "--n_threads", str(threads), "--out", out_hip], capture_output=True, text=True,
+                       timeout=600)
+    assert h.returncode == 0, h.stderr[-2000:]
+    return open(out_hip).read(), open(out_ref).read()
+
+
+@pytest.mark.parametrize("name", [n for n in fixtures() if Fixture(n).rnd_sample >= 1 and Fixture(n).n_ind <= 500])
+@pytest.mark.parametrize("extend", [False, True])
+def test_fixture_through_both_programs(name, extend, tmp_path):
+    fx = Fixture(name)
+    d = str(tmp_path)
+    g, p = fx.write_inputs(d)
+    flags = ["--geno", g, "--n_ind", str(fx.n_ind), "--n_sites", str(fx.n_sites), "--verbose", "0"]
+    if p:
+        flags += ["--posH" if fx.header else "--pos", p]
+    flags += fx.cli_flags(extend)
+    got, want = both_programs(flags, fx.oracle().run(), fx.n_sites, d)
+    assert same_tsv(got, want) is None, same_tsv(got, want)
+
+
+def case_files(k: int, d: str):
+    """Fuzz case k as the files and flags of a command line (None: a case the reference program cannot run here)."""
+    raw, pd, kw, call, chrs, pos = _case_full(k)
+    n_sites, n_ind = raw.shape[:2]
+    o0 = orc.Oracle(raw, pd, log_scale=kw["log_scale"], call_geno=call)
+    min_maf = pick_min_maf(o0.maf, k)
+    o = orc.Oracle(raw, pd, min_maf=min_maf, n_threads=4, call_geno=call, log_scale=kw["log_scale"],
+                   ignore_miss_data=kw["ignore_miss_data"], max_kb_dist=kw["max_kb_dist"], max_snp_dist=kw["max_snp_dist"])
+    g, p = os.path.join(d, "in.glf"), os.path.join(d, "in.pos")
+    raw.tofile(g)
+    header = k % 4 == 1
+    synth.write_pos(p, chrs, pos, header=header, extra_col=k % 5 == 2)
+    flags = ["--geno", g, "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--verbose", "0", "--posH" if header else "--pos", p,
+             "--max_kb_dist", str(kw["max_kb_dist"]), "--max_snp_dist", str(kw["max_snp_dist"]), "--min_maf", repr(min_maf)]
+    if kw["log_scale"]:
+        flags.append("--log_scale")
+    if kw["ignore_miss_data"]:
+        flags.append("--ignore_miss_data")
+    if call is not None:
+        flags += ["--probs", "--call_geno", "--N_thresh", repr(float(call[0])), "--call_thresh", repr(float(call[1]))]
+    if k % 3 != 1:
+        flags.append("--extend_out")
+    return flags, o.run(), n_sites
+
+
+@pytest.mark.parametrize("k", list(range(0, 90)) + list(range(10_000, 10_012)) + list(range(30_000, 30_010)))
+def test_random_case_through_both_programs(k, tmp_path):
+    d = str(tmp_path)
+    flags, rec, n_sites = case_files(k, d)
+    got, want = both_programs(flags, rec, n_sites, d, threads=1 + k % 3)
+    assert same_tsv(got, want) is None, f"case {k}: {same_tsv(got, want)}\n{' '.join(flags)}"

@@ -16,28 +16,9 @@ import numpy as np
 import pytest
 
 from oracle import orc
-from util import Fixture, fixtures
+from util import Fixture, fixtures, have_ref_program, run_ref_program
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ref = orc.ref()
-pytestmark = pytest.mark.skipif(ref is None or not hasattr(ref, "ref_main"),
-                                reason="oracle/_ref predates ref_main (rebuild with oracle/build_ref.sh)")
-
-_CHILD = r"""
-import ctypes as C, sys
-import numpy as np
-sys.path.insert(0, %r)
-from oracle import orc
-R = orc.ref()
-tab = np.load(sys.argv[1])
-first, s2, val = (np.ascontiguousarray(tab[k]) for k in ("first", "s2", "val"))
-R.ref_set_r2pear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
-R.ref_set_r2pear(first.ctypes.data, s2.ctypes.data, val.ctypes.data, len(first) - 1)
-argv = [b"ngsLD"] + [a.encode() for a in sys.argv[2:]]
-arr = (C.c_char_p * (len(argv) + 1))(*argv, None)
-R.ref_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
-sys.exit(R.ref_main(len(argv), arr))
-""" % REPO
+pytestmark = pytest.mark.skipif(not have_ref_program(), reason="oracle/_ref predates ref_main (rebuild with oracle/build_ref.sh)")
 
 NAMES = [n for n in fixtures() if Fixture(n).rnd_sample >= 1 and Fixture(n).n_ind <= 500]
 
@@ -49,18 +30,12 @@ def test_reference_program_flow_writes_the_oracles_tsv(name, extend, threads, tm
     d = str(tmp_path)
     g, p = fx.write_inputs(d)
     rec = fx.oracle().run()
-    first = np.zeros(fx.n_sites + 1, dtype=np.uint64)
-    np.add.at(first, rec["s1"].astype(np.int64) + 1, 1)
-    first = np.cumsum(first).astype(np.uint64)
-    tab = os.path.join(d, "r2.npz")
-    np.savez(tab, first=first, s2=rec["s2"].astype(np.uint64), val=rec["r2pear"].astype(np.float64))
     base = ["--geno", g, "--n_ind", str(fx.n_ind), "--n_sites", str(fx.n_sites), "--verbose", "0"]
     if p:
         base += ["--posH" if fx.header else "--pos", p]
     flags = base + fx.cli_flags(extend)
     out_ref = os.path.join(d, "ref.tsv")
-    r = subprocess.run([sys.executable, "-c", _CHILD, tab, *flags, "--n_threads", str(threads), "--out", out_ref],
-                       capture_output=True, text=True, timeout=600)
+    r = run_ref_program(rec, fx.n_sites, flags, out_ref, d, threads)
     assert r.returncode == 0, r.stderr[-2000:]
     want = subprocess.run([orc.ORC_CLI, *flags], check=True, capture_output=True, text=True).stdout
     got = open(out_ref).read()
@@ -73,3 +48,17 @@ def test_reference_program_flow_writes_the_oracles_tsv(name, extend, threads, tm
     if f"orc_tsv_{tag}_md5" in fx:   # and the golden md5 (sorted body, as the reference's own test sorts: examples/test.sh:16)
         lines = got.splitlines(keepends=True)
         assert hashlib.md5((lines[0] + "".join(sorted(lines[1:]))).encode()).hexdigest() == str(fx[f"orc_tsv_{tag}_md5"])
+
+
+@pytest.mark.parametrize("k", list(range(0, 48)) + list(range(10_000, 10_006)) + list(range(30_000, 30_006)))
+def test_reference_program_on_random_cases_writes_the_oracles_tsv(k, tmp_path):
+    """The fuzz generator's cases as files (tests/test_gpu_vs_ref_program.py hands the same command lines to the HIP binary):
+    every filter, chromosome breaks, --log_scale, --ignore_miss_data, --call_geno, thresholds ON a site's frequency."""
+    from test_gpu_vs_ref_program import case_files, same_tsv
+    d = str(tmp_path)
+    flags, rec, n_sites = case_files(k, d)
+    out_ref = os.path.join(d, "ref.tsv")
+    r = run_ref_program(rec, n_sites, flags, out_ref, d, threads=1 + k % 3)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = subprocess.run([orc.ORC_CLI, *flags], check=True, capture_output=True, text=True).stdout
+    assert same_tsv(open(out_ref).read(), want) is None, f"case {k}: {same_tsv(open(out_ref).read(), want)}\n{' '.join(flags)}"

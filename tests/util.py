@@ -174,3 +174,43 @@ def check_records(std, ext, want: dict, tol=TOL, pearson_tol=None, exact_degener
     REPORT["over_tol"] += int(over.sum())
     REPORT["degenerate"] += int(degen.sum())
     return len(degen)
+
+
+# ---- the reference's own program (oracle/_ref: ngsLD.cpp's main() and calc_pair_LD compiled as they stand, minus the GSL
+# statements -- oracle/build_ref.sh) run on real files in a child process (an invalid argument ends the process through error()).
+# Its one GSL column, r2_ExpG, is looked up per pair in the table the caller supplies (the oracle's values).
+_REF_CHILD = r"""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import orc
+R = orc.ref()
+tab = np.load(sys.argv[1])
+first, s2, val = (np.ascontiguousarray(tab[k]) for k in ("first", "s2", "val"))
+R.ref_set_r2pear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+R.ref_set_r2pear(first.ctypes.data, s2.ctypes.data, val.ctypes.data, len(first) - 1)
+argv = [b"ngsLD"] + [a.encode() for a in sys.argv[2:]]
+arr = (C.c_char_p * (len(argv) + 1))(*argv, None)
+R.ref_main.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+sys.exit(R.ref_main(len(argv), arr))
+""" % os.path.dirname(HERE)
+
+
+def have_ref_program() -> bool:
+    from oracle import orc
+    r = orc.ref()
+    return r is not None and hasattr(r, "ref_main")
+
+
+def run_ref_program(rec, n_sites: int, flags: list[str], out_path: str, work_dir: str, threads: int = 1, timeout: int = 600):
+    """ref_main(argv) with `flags` + --n_threads + --out; rec = the oracle's records of the same run (s1, s2 increasing: where
+    the r2_ExpG of every pair is looked up).  Returns the CompletedProcess."""
+    import subprocess
+    import sys
+    first = np.zeros(n_sites + 1, dtype=np.uint64)
+    np.add.at(first, rec["s1"].astype(np.int64) + 1, 1)
+    first = np.cumsum(first).astype(np.uint64)
+    tab = os.path.join(work_dir, "r2_table.npz")
+    np.savez(tab, first=first, s2=rec["s2"].astype(np.uint64), val=rec["r2pear"].astype(np.float64))
+    return subprocess.run([sys.executable, "-c", _REF_CHILD, tab, *flags, "--n_threads", str(threads), "--out", out_path],
+                          capture_output=True, text=True, timeout=timeout)
