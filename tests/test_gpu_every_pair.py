@@ -49,3 +49,22 @@ def test_first_rows_of_the_headline_configuration_equal_the_oracle():
     assert d["n_iter_equal"] and d["sample_size_equal"] and d["within_tolerances"]
     assert max(d[k] for k in d if k.startswith("max_abs_diff_")) <= 1e-9
     print("every pair of the first 3,000 rows of configs[2]:", {k: d[k] for k in d if k.startswith("max_abs_diff_") or k.startswith("pairs")})
+
+
+@pytest.mark.parametrize("args,rows", [(("c1",), 12_497_500), (("c2", "4000"), 3_000_000)])
+def test_whole_table_of_both_programs(args, rows):
+    """tools/cli_vs_ref_config.py: the drop-in binary and the reference's OWN program (oracle/_ref ref_main: ngsLD.cpp's main +
+    calc_pair_LD compiled minus the GSL statements, all host cores) over the same argv and files -- ALL of configs[1]
+    (12,497,500 extended rows, 2 GB of TSV) and the first 4,000 sites of configs[2]'s matrix: first line equal, sorted bodies
+    byte-identical."""
+    from util import have_ref_program
+    if not have_ref_program():
+        pytest.skip("oracle/_ref predates ref_main (rebuild with oracle/build_ref.sh)")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "cli_vs_ref_config.py"), *args], capture_output=True, text=True,
+                       timeout=1500)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert line, r.stderr[-2000:]
+    d = json.loads(line[-1])
+    assert r.returncode == 0 and d["identical"] and d["first_line_equal"], d
+    assert d["rows"] == d["rows_hip"] and d["rows"] >= rows
+    print("whole table through both programs:", d)
