@@ -2,6 +2,9 @@
 
     python tools/cli_vs_ref_config.py c1            # configs[1]: 5,000 x 100, all 12,497,500 pairs, extended columns
     python tools/cli_vs_ref_config.py c2 [sites]    # the first `sites` (default 12,000) sites of configs[2]'s matrix: x 500, 100 kb window
+    python tools/cli_vs_ref_config.py c2call [sites]  # the same with --call_geno --N_thresh 0.4 --call_thresh 0.8
+    python tools/cli_vs_ref_config.py c3 [sites]    # configs[3]'s shape: sites (default 3,000) x 1,000, all pairs
+    python tools/cli_vs_ref_config.py c4 [sites]    # configs[4]'s shape: sites (default 5,000) x 2,000, 500 kb window
 
 Both programs get the same argv over the same files (binary likelihoods + positions).  `ref_main` is ngsLD.cpp's main() +
 calc_pair_LD compiled as they stand minus the GSL statements (oracle/build_ref.sh), on every host core; its r2_ExpG column is
@@ -48,16 +51,27 @@ def sorted_body_md5(path: str, d: str) -> tuple[str, int, str]:
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "c1"
     dev = torch.device("cuda", 0)
+    call = None
     if which == "c1":
         n_sites, n_ind, max_kb, seed = 5000, 100, 0, 2
         raw = synth.make_gl_torch(n_sites, n_ind, seed, dev, depth=10.0).cpu().numpy()
         chrs, pos = synth.make_positions(n_sites, seed)
-    else:
+    elif which == "c3":      # configs[3]'s shape (x 1,000, all pairs: two wavefronts per pair), `sites` of it
+        n_sites, n_ind, max_kb, seed = (int(sys.argv[2]) if len(sys.argv) > 2 else 3000), 1000, 0, 4
+        raw = synth.make_gl_torch(n_sites, n_ind, seed, dev, depth=10.0).cpu().numpy()
+        chrs, pos = synth.make_positions(n_sites, seed)
+    elif which == "c4":      # configs[4]'s shape (x 2,000, 500 kb window over ~1 kb gaps: four wavefronts per pair)
+        n_sites, n_ind, max_kb, seed = (int(sys.argv[2]) if len(sys.argv) > 2 else 5000), 2000, 500, 5
+        raw = synth.make_gl_torch(n_sites, n_ind, seed, dev, depth=10.0).cpu().numpy()
+        chrs, pos = synth.make_positions(n_sites, seed, max_gap=2000)
+    else:                    # c2, or c2call: the same matrix with --call_geno (the genotype-combination kernel, replay on the device)
         n_all, n_ind, max_kb, seed = 100_000, 500, 100, 3
         n_sites = int(sys.argv[2]) if len(sys.argv) > 2 else 12_000
         raw = synth.make_gl_torch(n_all, n_ind, seed, dev, depth=10.0)[:n_sites].cpu().numpy()
         chrs, pos = synth.make_positions(n_all, seed)
         chrs, pos = chrs[:n_sites], pos[:n_sites]
+        if which == "c2call":
+            call = (0.4, 0.8)
     pd = shard.pos_dist_from_positions(chrs, pos)
     cores = len(os.sched_getaffinity(0))
     try:
@@ -72,8 +86,10 @@ def main():
         synth.write_pos(p, chrs, pos)
         flags = ["--geno", g, "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--pos", p, "--max_kb_dist", str(max_kb),
                  "--min_maf", "0", "--extend_out", "--verbose", "0"]
+        if call is not None:
+            flags += ["--probs", "--call_geno", "--N_thresh", repr(call[0]), "--call_thresh", repr(call[1])]
         t0 = time.perf_counter()
-        rec = orc.Oracle(raw, pd, max_kb_dist=max_kb, n_threads=cores).run()
+        rec = orc.Oracle(raw, pd, max_kb_dist=max_kb, n_threads=cores, call_geno=call).run()
         t_orc = time.perf_counter() - t0
         out_ref = os.path.join(d, "ref.tsv")
         t0 = time.perf_counter()
