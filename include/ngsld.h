@@ -235,6 +235,12 @@ int ngsld_last_kernel_time(ngsld_ctx *ctx, double *total_ms, uint64_t *n_launche
  * likelihood triple is a called genotype or "no data" (text genotypes, --call_geno: ngsLD.cpp:92-98,
  * read_data.cpp:83-99), the pairs run on their 16 genotype-combination counts.  "" before any data is set. */
 const char *ngsld_pair_kernel(const ngsld_ctx *ctx);
+/* The same decision without a device or a context: which kernel family and shape a likelihood matrix of n_ind individuals set
+ * with this ignore_miss_data runs on, as text -- "<family> <wavefronts per pair>x<individuals per lane> lanes=<lanes per pair>
+ * np=<padded individuals per genotype plane>", e.g. "run 1x8 lanes=64 np=512" for 500.  (Called-genotype matrices take "hard"
+ * whatever the cohort, up to 4,096 individuals.)  Returns NGSLD_ERR_UNSUPPORTED for a cohort size outside the supported range,
+ * NGSLD_ERR_INVALID when buf is too short.  tests/golden/dispatch_table.txt is this function over 1..12,000. */
+int ngsld_describe_dispatch(uint64_t n_ind, int ignore_miss_data, char *buf, size_t buf_len);
 
 /* Tuning knobs (optional): pairs per work item, max pairs per batch of ngsld_run. 0 keeps the default -- record batches of
  * 2^24 pairs (the pair kernels write them straight into two pinned host buffers of that many records; halved, down to 2^16,

@@ -84,7 +84,7 @@ SYMBOLS = [
     "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device", "ngsld_set_text_output",
     "ngsld_set_replay_source", "ngsld_set_replay_matrix", "ngsld_set_replay", "ngsld_replay_stats", "ngsld_finish_device",
     "ngsld_plan_parts", "ngsld_run_multi", "ngsld_multi_last_distribution", "ngsld_rccl_selftest",
-    "ngsld_last_kernel_time", "ngsld_pair_kernel", "ngsld_set_tuning", "ngsld_selftest", "ngsld_reserve_text_buffers",
+    "ngsld_last_kernel_time", "ngsld_pair_kernel", "ngsld_describe_dispatch", "ngsld_set_tuning", "ngsld_selftest", "ngsld_reserve_text_buffers",
     "ngsld_window_ends", "ngsld_plan_slabs", "ngsld_slab_sites_for_budget", "ngsld_device_memory", "ngsld_run_streamed", "ngsld_run_streamed_text",
     "ngsld_host_read_geno_bin_range",
     "ngsld_host_set_threads", "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos", "ngsld_host_pos_slice",
@@ -444,6 +444,37 @@ def rccl_selftest(device: int = 0, n_bytes: int = 64 << 20) -> None:
     rc = lib().ngsld_rccl_selftest(device, n_bytes, err, len(err))
     if rc != OK:
         raise NgsldError(rc, err.value.decode())
+
+
+def describe_dispatch(n_ind: int, ignore_miss_data: bool = False) -> str:
+    """Kernel family and shape a likelihood matrix of n_ind individuals runs on (no device needed): ngsld_describe_dispatch."""
+    buf = C.create_string_buffer(96)
+    L = lib()
+    L.ngsld_describe_dispatch.argtypes = [C.c_uint64, C.c_int, C.c_char_p, C.c_size_t]
+    rc = L.ngsld_describe_dispatch(int(n_ind), int(bool(ignore_miss_data)), buf, 96)
+    if rc != OK:
+        raise NgsldError(rc, f"no kernel for n_ind = {n_ind}")
+    return buf.value.decode()
+
+
+def dispatch_table(n_max: int = 12_000) -> str:
+    """describe_dispatch over 1..n_max for both settings of ignore_miss_data, as ranges of equal text."""
+    import re
+    lines = []
+
+    def describe(n, masked):  # (the streaming kernel pads to the next 64 whatever the size: one line for all of them)
+        d = describe_dispatch(n, masked)
+        return re.sub(r"np=\d+", "np=n_ind rounded up to 64", d) if d.startswith("stream") else d
+
+    for masked in (False, True):
+        lines.append(f"# ignore_miss_data = {int(masked)}")
+        lo, cur = 1, describe(1, masked)
+        for n in range(2, n_max + 2):
+            d = describe(n, masked) if n <= n_max else None
+            if d != cur:
+                lines.append(f"{lo}..{n - 1}\t{cur}")
+                lo, cur = n, d
+    return "\n".join(lines) + "\n"
 
 
 def device_count() -> int:

@@ -1824,6 +1824,29 @@ const char *ngsld_pair_kernel(const ngsld_ctx *c) {
   }
 }
 
+int ngsld_describe_dispatch(uint64_t n_ind, int ignore_miss_data, char *buf, size_t buf_len) {
+  if (buf == nullptr || buf_len == 0) return NGSLD_ERR_INVALID;
+  buf[0] = 0;
+  PairConfig cfg;
+  const bool masked = ignore_miss_data != 0;
+  if (!pair_config(n_ind, &cfg, kChooseAuto, masked)) return NGSLD_ERR_UNSUPPORTED;
+  const char *family = "";
+  int slots = cfg.slots, waves = cfg.waves;
+  switch (effective_kernel(cfg, masked)) {
+    case kGroup: family = "group"; break;
+    case kMulti:
+      family = cfg.form == 1 ? "multi-ab" : "multi";
+      if (cfg.form == 0) multi_shape(cfg, masked, &slots, &waves);
+      break;
+    case kStream: family = "stream"; break;
+    case kRun: family = "run"; break;
+    case kRunAB: family = "ab"; break;
+    default: return NGSLD_ERR_UNSUPPORTED;
+  }
+  const int n = std::snprintf(buf, buf_len, "%s %dx%d lanes=%d np=%u", family, waves, slots, cfg.group, cfg.np);
+  return (n < 0 || (size_t)n >= buf_len) ? NGSLD_ERR_INVALID : NGSLD_OK;
+}
+
 int ngsld_set_tuning(ngsld_ctx *c, uint32_t pairs_per_item, uint64_t batch_pairs) {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   if (pairs_per_item) {

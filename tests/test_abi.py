@@ -64,3 +64,19 @@ def test_product_never_touches_the_oracle():
                 assert "oracle" not in text.lower().replace("the cpu oracle", ""), f"{f} mentions the oracle"
     out = os.popen(f"ldd {capi.LIB_PATH}").read()
     assert "liborc" not in out and "ngsld_ref" not in out
+
+
+def test_dispatch_table_is_the_committed_one():
+    """Cohort size -> kernel family and shape (ngsld_describe_dispatch, no device needed) over 1..12,000, both settings of
+    ignore_miss_data: tests/golden/dispatch_table.txt is that function's output -- a change of the dispatch is a change of this
+    file, made on purpose (regenerate: python -c "from ngsld_amd import capi; open('tests/golden/dispatch_table.txt','w').write(capi.dispatch_table())")."""
+    from ngsld_amd import capi
+    want = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dispatch_table.txt")).read()
+    assert capi.dispatch_table() == want
+    # the BASELINE.json cohort sizes
+    assert capi.describe_dispatch(100) == "group 1x7 lanes=16 np=112"
+    assert capi.describe_dispatch(500) == "run 1x8 lanes=64 np=512"
+    assert capi.describe_dispatch(1000) == "multi 2x8 lanes=64 np=1024"
+    assert capi.describe_dispatch(2000) == "multi 4x8 lanes=64 np=2048"
+    with pytest.raises(capi.NgsldError):
+        capi.describe_dispatch(0)

@@ -214,6 +214,7 @@ def test_cohort_sizes_around_the_kernel_boundaries(n_ind, ignore_miss, family):
         eng.set_pos_dist(None)
         assert eng.plan(ignore_miss_data=ignore_miss) == len(want)
         assert eng.pair_kernel() == family
+        assert capi.describe_dispatch(n_ind, ignore_miss).split()[0] == family   # the table of tests/golden/dispatch_table.txt is what runs
         s1, s2, std, ext = eng.run()
         check_records(std, ext, want)
     finally:
