@@ -369,6 +369,9 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   c->n_ind = n_ind;
   c->cfg = cfg;
   c->np = cfg.np;
+  const bool trace = std::getenv("NGSLD_TRACE") != nullptr;  // dev: where this call's time goes, on stderr
+  const auto t_0 = std::chrono::steady_clock::now();
+  auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count(); };
   const size_t plane_elems = (size_t)n_sites * 3 * c->np;
   HIP_TRY(c, c->d_planes.resize(plane_elems));
   HIP_TRY(c, c->d_maf.resize(n_sites));
@@ -380,7 +383,10 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
 
   // Host matrices are ingested in chunks of sites through two staging buffers: the H2D copy of chunk k+1 overlaps
   // the prep kernel of chunk k, and the device never holds more than planes + 2 chunks (a 48 GB matrix does not need
-  // a second 48 GB on the device).  Device-resident input is prepped in place in one launch.
+  // a second 48 GB on the device).  Device-resident input is prepped in place in one launch.  Chunks of 64 MB: a pageable
+  // (huge-page) host matrix crosses at 50 GB/s whatever the chunk (tools/probe_h2d.hip: one hipMemcpy 50.6 GB/s, from pinned
+  // memory 55.6), and what this call costs on configs[2] -- 90..117 ms for 1.2 GB -- is hipMalloc of the planes (27..74 ms)
+  // as much as the 25..35 ms of copies; 256 MB chunks measured 10 ms behind 64 / 32 MB (profiles/r04/e2e_stage_ab.txt).
   PrepArgs a{};
   a.planes = c->d_planes.p;
   a.site_stride = 3ull * c->np;
@@ -409,7 +415,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
     HIP_TRY(c, launch_prep(a, c->stream));
   } else {
     const uint64_t site_bytes = n_ind * 3 * sizeof(double);
-    uint64_t stage_bytes = 256ull << 20;
+    uint64_t stage_bytes = 64ull << 20;
     if (const char *e = std::getenv("NGSLD_STAGE_BYTES")) stage_bytes = std::strtoull(e, nullptr, 10);  // tests: force many chunks
     uint64_t chunk = stage_bytes / site_bytes;
     if (chunk < 1) chunk = 1;
@@ -423,6 +429,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
     }
     int rc = NGSLD_OK;
     uint64_t k = 0;
+    if (trace) std::fprintf(stderr, "[trace] set_geno: device buffers + staging allocated at %.2f ms\n", ms_since());
     for (uint64_t s0 = 0; s0 < n_sites && rc == NGSLD_OK; s0 += chunk, ++k) {
       const int b = (int)(k & 1);
       const uint64_t m = std::min(chunk, n_sites - s0);
@@ -433,6 +440,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
       if (e == hipSuccess && normalised)
         e = hipMemcpyAsync(maf_stage[b].p, maf + s0, m * sizeof(double), hipMemcpyHostToDevice, c->copy_stream);
       if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
+      if (trace) std::fprintf(stderr, "[trace] set_geno: chunk %llu (%llu sites) on the device at %.2f ms\n", (unsigned long long)k, (unsigned long long)m, ms_since());
       a.raw = stage[b].p;
       a.maf_in = normalised ? maf_stage[b].p : nullptr;
       a.site0 = s0;
@@ -442,11 +450,13 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
       if (e != hipSuccess) rc = hip_fail(c, e, "chunked genotype upload");
     }
     hipError_t e = hipStreamSynchronize(c->stream);
+    if (trace) std::fprintf(stderr, "[trace] set_geno: last prep kernel done at %.2f ms\n", ms_since());
     for (int q = 0; q < 2; ++q) {
       stage[q].release();
       maf_stage[q].release();
       if (prepped[q]) (void)hipEventDestroy(prepped[q]);
     }
+    if (trace) std::fprintf(stderr, "[trace] set_geno: staging buffers freed at %.2f ms\n", ms_since());
     if (rc != NGSLD_OK) return rc;
     if (e != hipSuccess) return hip_fail(c, e, "chunked genotype upload");
   }
@@ -467,6 +477,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
     HIP_TRY(c, launch_classify_hard(c->d_planes.p, 3ull * c->np, c->np, (uint32_t)n_ind, n_sites, c->d_hard_masks.p,
                                     c->d_hard_u.p, c->d_all_hard.p, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&all_hard, c->d_all_hard.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (trace) std::fprintf(stderr, "[trace] set_geno: called-genotype check enqueued at %.2f ms\n", ms_since());
   }
   c->h_maf.resize(n_sites);
   int &status = c->h_prep_status;
@@ -474,6 +485,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   HIP_TRY(c, hipMemcpyAsync(c->h_maf.data(), c->d_maf.p, n_sites * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(&status, c->d_status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (trace) std::fprintf(stderr, "[trace] set_geno: scalars packed, called-genotype check, maf on the host at %.2f ms\n", ms_since());
   if (status == NGSLD_ERR_NAN) return fail(c, NGSLD_ERR_NAN, "NaN found! Is the file format correct?");
   if (try_hard && all_hard) {
     c->cfg.kernel = kHard;
