@@ -94,3 +94,85 @@ def test_random_case_through_both_programs(k, tmp_path):
     flags, rec, n_sites = case_files(k, d)
     got, want = both_programs(flags, rec, n_sites, d, threads=1 + k % 3)
     assert same_tsv(got, want) is None, f"case {k}: {same_tsv(got, want)}\n{' '.join(flags)}"
+
+
+def _geno_text(mat, header: bool, prefix_cols: bool) -> str:
+    """A beagle-like text genotype file (as tests/golden/make_golden.py writes the f8_* fixtures): optional header line,
+    optional non-numeric leading columns; small integers as integers, everything else with every digit."""
+    lines = []
+    if header:
+        lines.append("marker\tallele1\tallele2\t" + "\t".join(f"Ind{i}" for i in range(mat.shape[1])))
+    for s in range(mat.shape[0]):
+        pre = f"chr1_{s}\tA\tC\t" if prefix_cols else ""
+        lines.append(pre + "\t".join(str(int(x)) if np.isfinite(x) and float(x) == int(x) and abs(x) <= 9 else repr(float(x))
+                                     for x in mat[s].reshape(-1)))
+    return "\n".join(lines) + "\n"
+
+
+def text_case_files(k: int, d: str):
+    """Text (.gz) genotype input, case k: called genotypes (0 / 1 / 2, -1 = no data) or likelihood triples (normal or log
+    scale, optionally hardened by --call_geno) -- the text branch of read_geno (read_data.cpp:50-104)."""
+    import ctypes as C
+    import gzip
+    rng = np.random.default_rng(88_000 + k)
+    called = k % 2 == 0
+    n_ind = int(rng.choice([1, 2, 7, 20, 64, 65, 100, 130, 257, 500, 520]))
+    n_sites = int(rng.integers(4, 50 if n_ind <= 130 else 16))
+    log_scale = (not called) and rng.random() < 0.3
+    call = None
+    if called:
+        p_miss = float(rng.choice([0.0, 0.1, 0.5]))
+        q = rng.uniform(0.05, 0.5, size=n_sites)
+        g = rng.binomial(2, q[:, None], size=(n_sites, n_ind)).astype(float)
+        g[rng.random((n_sites, n_ind)) < p_miss] = -1.0
+        if rng.random() < 0.3:
+            g[int(rng.integers(0, n_sites))] = 0.0                      # a monomorphic site
+        mat, prefix = g, bool(rng.random() < 0.5)
+    else:
+        raw = synth.make_gl_numpy(n_sites, n_ind, 88_500 + k, depth=float(rng.choice([0.5, 2.0, 8.0])))
+        raw /= raw.sum(axis=2, keepdims=True)
+        if rng.random() < 0.4:
+            hc = rng.random((n_sites, n_ind)) < 0.1
+            raw[hc] = np.eye(3)[rng.integers(0, 3, size=int(hc.sum()))]   # exact zeros: log(0) stays -inf in the text branch
+        if log_scale:
+            with np.errstate(divide="ignore"):
+                raw = np.log(raw)
+        if rng.random() < 0.3:
+            call = tuple(sorted(rng.random(2)))
+        mat, prefix = raw.reshape(n_sites, -1), True
+    gpath, ppath = os.path.join(d, "in.geno.gz"), os.path.join(d, "in.pos")
+    with gzip.open(gpath, "wt") as fh:
+        fh.write(_geno_text(mat, header=bool(rng.random() < 0.5), prefix_cols=prefix))
+    chrs, pos = synth.make_positions(n_sites, 88_900 + k, max_gap=int(rng.choice([5, 200, 3000])), n_chr=int(rng.integers(1, 3)))
+    synth.write_pos(ppath, chrs, pos)
+    from ngsld_amd import shard
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    ignore = bool(rng.random() < 0.5)
+    max_kb, max_snp = int(rng.choice([0, 0, 1, 50])), int(rng.choice([0, 0, 5]))
+    gl = np.empty((n_sites, n_ind, 3))
+    err = C.create_string_buffer(256)
+    rc = orc.lib().orc_read_geno_text(gpath.encode(), int(not called), int(log_scale), n_ind, n_sites, orc.dp(gl), err, 256)
+    assert rc == 0, err.value
+    o = orc.Oracle(gl, pd, already_normalised_log=True, ignore_miss_data=ignore, max_kb_dist=max_kb, max_snp_dist=max_snp,
+                   n_threads=4, call_geno=call)
+    flags = ["--geno", gpath, "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--verbose", "0", "--pos", ppath,
+             "--max_kb_dist", str(max_kb), "--max_snp_dist", str(max_snp), "--min_maf", "0"]
+    if not called:
+        flags.append("--probs")
+    if log_scale:
+        flags.append("--log_scale")
+    if ignore:
+        flags.append("--ignore_miss_data")
+    if call is not None:
+        flags += ["--call_geno", "--N_thresh", repr(float(call[0])), "--call_thresh", repr(float(call[1]))]
+    if k % 3 != 1:
+        flags.append("--extend_out")
+    return flags, o.run(), n_sites
+
+
+@pytest.mark.parametrize("k", range(40))
+def test_random_text_input_through_both_programs(k, tmp_path):
+    d = str(tmp_path)
+    flags, rec, n_sites = text_case_files(k, d)
+    got, want = both_programs(flags, rec, n_sites, d, threads=1 + k % 3)
+    assert same_tsv(got, want) is None, f"text case {k}: {same_tsv(got, want)}\n{' '.join(flags)}"

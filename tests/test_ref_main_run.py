@@ -62,3 +62,17 @@ def test_reference_program_on_random_cases_writes_the_oracles_tsv(k, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     want = subprocess.run([orc.ORC_CLI, *flags], check=True, capture_output=True, text=True).stdout
     assert same_tsv(open(out_ref).read(), want) is None, f"case {k}: {same_tsv(open(out_ref).read(), want)}\n{' '.join(flags)}"
+
+
+@pytest.mark.parametrize("k", range(24))
+def test_reference_program_on_random_text_inputs_writes_the_oracles_tsv(k, tmp_path):
+    """Text (.gz) genotype files -- called genotypes, likelihood triples in normal and log scale, --call_geno -- through the
+    reference's program and the oracle CLI (the HIP binary gets the same command lines in tests/test_gpu_vs_ref_program.py)."""
+    from test_gpu_vs_ref_program import same_tsv, text_case_files
+    d = str(tmp_path)
+    flags, rec, n_sites = text_case_files(k, d)
+    out_ref = os.path.join(d, "ref.tsv")
+    r = run_ref_program(rec, n_sites, flags, out_ref, d, threads=1 + k % 3)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = subprocess.run([orc.ORC_CLI, *flags], check=True, capture_output=True, text=True).stdout
+    assert same_tsv(open(out_ref).read(), want) is None, f"text case {k}: {same_tsv(open(out_ref).read(), want)}\n{' '.join(flags)}"
