@@ -214,3 +214,66 @@ CXX
 } | g++ -x c++ -O3 -w -fPIC -shared -ffp-contract=off -o "$HERE/_ref/libngsld_ref.so" - -lz -lpthread
 
 echo "built $HERE/_ref/libngsld_ref.so (ngsLD.cpp lines $W0-$W1, $S0-$S1, $F0-$F1, $H0, $V0 and parse_args.cpp compiled in)"
+
+# ---- the reference's main() with the library plugged in (the drop-in boundary, in situ) ------------------------------------
+# INTEGRATION.md section 2 for real: ngsLD.cpp's main() from where it lies, its thread-pool section (`// Create thread pool`
+# .. "cannot free thread pool!", ngsLD.cpp:153-198) replaced by the ONE line a maintainer would write --
+# ngsld_compute_all(pars), integration/ngsld_binding.h -- and calc_pair_LD's print block (F0..F1, with the two hap-derived
+# frequencies it prints, S0..S0+2) moved as it stands into print_pair(), which the binding's record sink calls.  Dropped besides:
+# the three gsl_rng statements of main outside that section and the free of the pth array the section allocated.  Everything
+# else -- parse_cmd_args, read_geno, call_geno, est_maf, the exp() loop, read_dist, labels, output file + header, the frees --
+# is the reference's text, compiled and run.  Linked against the product's libngsld.so: built only where that exists.
+# -> oracle/_ref/libngsld_ref_hip.so, entry ref_main_hip(argc, argv); tests/test_gpu_ref_main_patched.py.
+LIBDIR=$(cd "$HERE/../ngsld_amd" && pwd)
+if [ ! -f "$LIBDIR/libngsld.so" ]; then
+  echo "build_ref.sh: $LIBDIR/libngsld.so not built yet; skipping the patched main (libngsld_ref_hip.so)" >&2
+  exit 0
+fi
+sed -n "$((S0 + 1))p" "$CPP" | grep -qE '^    maf\[0\] = 1 - \(hap_freq\[0\] \+ hap_freq\[1\]\);$' || { echo "build_ref.sh: ngsLD.cpp:$((S0 + 1)) is not maf[0]" >&2; exit 1; }
+sed -n "$((S0 + 2))p" "$CPP" | grep -qE '^    maf\[1\] = 1 - \(hap_freq\[0\] \+ hap_freq\[2\]\);$' || { echo "build_ref.sh: ngsLD.cpp:$((S0 + 2)) is not maf[1]" >&2; exit 1; }
+main_patched() {
+  sed -n "${M0},${M1}p" "$CPP" | awk '
+    done_main { next }
+    /^int main \(int argc, char\*\* argv\) \{$/ { print "extern \"C\" int ref_main_hip (int argc, char** argv) {"; renamed++; next }
+    /^  \/\/ Create thread pool$/ { skip=1; pool++; print "  ngsld_compute_all(pars);   // integration/ngsld_binding.h, in place of ngsLD.cpp:153-198" }
+    skip { if ($0 ~ /^    error\(__FUNCTION__, "cannot free thread pool!"\);$/) { skip=0; ended++ }; next }
+    /gsl_rng/ { rng++; next }
+    /^  free_ptr\(\(void\*\*\) pth\);/ { pth++; next }
+    { print }
+    /^}$/ { done_main=1 }
+    END { if (renamed != 1 || pool != 1 || ended != 1 || rng != 3 || pth != 1 || !done_main) { print "#error build_ref.sh: ngsLD.cpp main changed (main " renamed ", pool " pool "/" ended ", gsl_rng lines " rng ", pth frees " pth ")" } }
+  '
+}
+{
+  echo '#line 1 "reference:shared/gen_func.hpp (GSL lines dropped)"'
+  drop_gsl_hpp "$REF/shared/gen_func.hpp"
+  echo '#line 1 "reference:shared/read_data.hpp"'
+  drop_gsl_hpp "$REF/shared/read_data.hpp"
+  echo '#line 1 "reference:shared/gen_func.cpp (draw_rnd dropped)"'
+  drop_gsl_cpp "$REF/shared/gen_func.cpp"
+  echo '#line 1 "reference:shared/read_data.cpp"'
+  drop_gsl_cpp "$REF/shared/read_data.cpp"
+  echo '#line 1 "reference:shared/threadpool.h"'
+  sed -e '/#pragma once/d' "$REF/shared/threadpool.h"
+  echo '#line 1 "reference:ngsLD.hpp (GSL include and gsl_rng member dropped)"'
+  drop_gsl_ngsld_hpp "$REF/ngsLD.hpp"
+  echo '#line 1 "integration/ngsld_binding.h"'
+  sed -e '/#pragma once/d' "$HERE/../integration/ngsld_binding.h"
+  cat <<'CXX'
+void print_pair(params *pars_in, uint64_t s1, uint64_t s2, double dist, double r2pear, double D, double Dp, double r2,
+                double *hap_freq, uint64_t n_ind_data, uint64_t n_iter) {
+  pth_struct pth_local; pth_local.pars = pars_in; pth_local.site = s1;
+  pth_struct *p = &pth_local;
+CXX
+  cut_lines "$S0" "$((S0 + 2))"
+  cut_lines "$F0" "$F1"
+  echo '}'
+  echo "#line $M0 \"reference:ngsLD.cpp (main, thread-pool section replaced by ngsld_compute_all)\""
+  main_patched
+  cut_lines "$V0" "$V0"
+  echo '#line 1 "reference:parse_args.cpp"'
+  sed -e '/#include "ngsLD.hpp"/d' "$REF/parse_args.cpp"
+} | g++ -x c++ -O2 -w -fPIC -shared -ffp-contract=off -I"$HERE/../include" -o "$HERE/_ref/libngsld_ref_hip.so" - \
+      -L"$LIBDIR" -lngsld -Wl,-rpath,"$LIBDIR" -Wl,-rpath,/opt/rocm/lib -lz -lpthread
+echo "built $HERE/_ref/libngsld_ref_hip.so (the reference's main with ngsLD.cpp:153-198 replaced by integration/ngsld_binding.h)"
+

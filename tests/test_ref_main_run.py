@@ -76,3 +76,22 @@ def test_reference_program_on_random_text_inputs_writes_the_oracles_tsv(k, tmp_p
     assert r.returncode == 0, r.stderr[-2000:]
     want = subprocess.run([orc.ORC_CLI, *flags], check=True, capture_output=True, text=True).stdout
     assert same_tsv(open(out_ref).read(), want) is None, f"text case {k}: {same_tsv(open(out_ref).read(), want)}\n{' '.join(flags)}"
+
+
+def test_patched_reference_main_fails_loudly_without_a_device(tmp_path):
+    """oracle/_ref/libngsld_ref_hip.so -- the reference's main() with its thread-pool section replaced by the binding of
+    integration/ngsld_binding.h -- on a box without a GPU: the reference's own code parses, reads and estimates, then
+    ngsld_create refuses and the program ends through the reference's error() (exit status 255).  No CPU fallback.
+    (With a GPU: tests/test_gpu_ref_main_patched.py.)"""
+    import torch
+    from util import have_patched_ref_program, run_patched_ref_program
+    if not have_patched_ref_program():
+        pytest.skip("oracle/_ref predates ref_main_hip (rebuild with oracle/build_ref.sh)")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    fx = Fixture(NAMES[0])
+    d = str(tmp_path)
+    g, p = fx.write_inputs(d)
+    flags = ["--geno", g, "--n_ind", str(fx.n_ind), "--n_sites", str(fx.n_sites), "--verbose", "0"] + (["--pos", p] if p else []) + fx.cli_flags(True)
+    r = run_patched_ref_program(flags, os.path.join(d, "out.tsv"))
+    assert r.returncode == 255 and "no HIP device available" in r.stderr and "no CPU fallback" in r.stderr

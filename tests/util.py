@@ -214,3 +214,29 @@ def run_ref_program(rec, n_sites: int, flags: list[str], out_path: str, work_dir
     np.savez(tab, first=first, s2=rec["s2"].astype(np.uint64), val=rec["r2pear"].astype(np.float64))
     return subprocess.run([sys.executable, "-c", _REF_CHILD, tab, *flags, "--n_threads", str(threads), "--out", out_path],
                           capture_output=True, text=True, timeout=timeout)
+
+
+# ---- the same program with the library plugged in: oracle/_ref/libngsld_ref_hip.so = the reference's main() with its thread-pool
+# section (ngsLD.cpp:153-198) replaced by integration/ngsld_binding.h's one call, compiled by oracle/build_ref.sh
+_REF_HIP_CHILD = r"""
+import ctypes as C, os, sys
+R = C.CDLL(os.path.join(%r, "oracle", "_ref", "libngsld_ref_hip.so"))
+argv = [b"ngsLD"] + [a.encode() for a in sys.argv[1:]]
+arr = (C.c_char_p * (len(argv) + 1))(*argv, None)
+R.ref_main_hip.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+sys.exit(R.ref_main_hip(len(argv), arr))
+""" % os.path.dirname(HERE)
+
+
+def have_patched_ref_program() -> bool:
+    return os.path.exists(os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libngsld_ref_hip.so"))
+
+
+def run_patched_ref_program(flags: list[str], out_path: str, threads: int = 1, timeout: int = 600, env: dict | None = None):
+    """ref_main_hip(argv): the reference's own main(), pair loop on the device through the C-ABI.  Returns the CompletedProcess."""
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([sys.executable, "-c", _REF_HIP_CHILD, *flags, "--n_threads", str(threads), "--out", out_path],
+                          capture_output=True, text=True, timeout=timeout, env=e)
