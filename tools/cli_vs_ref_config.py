@@ -10,7 +10,9 @@ Both programs get the same argv over the same files (binary likelihoods + positi
 calc_pair_LD compiled as they stand minus the GSL statements (oracle/build_ref.sh), on every host core; its r2_ExpG column is
 looked up in the oracle's records of the same run (GSL is not in the image).  The two tables are compared as files: first line
 equal, bodies equal after `LC_ALL=C sort` (the reference's rows come out in thread order) -- line counts and md5 of both.
-Prints one JSON line; exit status 1 when they differ."""
+A third program runs when it is built: the reference's own main() with its thread-pool section replaced by
+integration/ngsld_binding.h (oracle/_ref/libngsld_ref_hip.so) -- the reference's reader, est_maf and exp() loop on one host
+thread, the pairs on the device.  Prints one JSON line; exit status 1 when any table differs."""
 import hashlib
 import json
 import os
@@ -26,7 +28,7 @@ import torch  # noqa: E402,F401
 
 from ngsld_amd import capi, shard, synth  # noqa: E402
 from oracle import orc  # noqa: E402
-from util import run_ref_program  # noqa: E402
+from util import have_patched_ref_program, run_patched_ref_program, run_ref_program  # noqa: E402
 
 
 def sorted_body_md5(path: str, d: str) -> tuple[str, int, str]:
@@ -109,12 +111,26 @@ def main():
         size = os.path.getsize(out_ref)
         head_r, n_r, md5_r = sorted_body_md5(out_ref, d)
         head_h, n_h, md5_h = sorted_body_md5(out_hip, d)
-    same = head_r == head_h and n_r == n_h and md5_r == md5_h
+        # third program: the reference's own main() with its thread-pool section replaced by integration/ngsld_binding.h
+        patched = None
+        if have_patched_ref_program():
+            out_p = os.path.join(d, "patched.tsv")
+            t0 = time.perf_counter()
+            pp = run_patched_ref_program(flags, out_p, threads=cores, timeout=3000)
+            t_p = time.perf_counter() - t0
+            if pp.returncode != 0:
+                print(pp.stderr[-2000:], file=sys.stderr)
+                sys.exit(2)
+            head_p, n_p, md5_p = sorted_body_md5(out_p, d)
+            patched = {"seconds": round(t_p, 2), "rows": n_p, "md5_sorted_body": md5_p,
+                       "identical": head_p == head_r and n_p == n_r and md5_p == md5_r}
+    same = head_r == head_h and n_r == n_h and md5_r == md5_h and (patched is None or patched["identical"])
     print(json.dumps({"config": which, "n_sites": n_sites, "n_ind": n_ind, "max_kb_dist": max_kb, "rows": n_r, "rows_hip": n_h,
                       "tsv_bytes": size, "first_line_equal": head_r == head_h, "md5_sorted_body_ref": md5_r,
                       "md5_sorted_body_hip": md5_h, "identical": same, "host_threads": cores,
                       "seconds_reference_program": round(t_ref, 2), "seconds_hip_binary": round(t_hip, 2),
-                      "seconds_oracle_for_r2_ExpG_table": round(t_orc, 2)}))
+                      "seconds_oracle_for_r2_ExpG_table": round(t_orc, 2),
+                      "reference_main_with_the_binding": patched}))
     sys.exit(0 if same else 1)
 
 
