@@ -269,3 +269,58 @@ def test_gz_output_write_error_does_not_block_the_producer():
         off += os.write(fd.value, data[off:off + (1 << 20)])
     os.close(fd.value)
     assert L.ngsld_host_gz_close(h) != capi.OK
+
+
+def test_readers_survive_mutated_input(tmp_path):
+    """Garbage in, an error (or the values) out -- never a crash: 400 byte-level mutations of a text genotype file and of a
+    position file (bytes replaced, runs deleted, lines duplicated / truncated, NULs, very long tokens) through
+    ngsld_host_read_geno_text and ngsld_host_read_pos.  tests/run_asan.sh runs this file on the AddressSanitizer / UBSan build
+    of the host code, where an out-of-bounds read is a failure, not luck."""
+    import gzip
+    rng = np.random.default_rng(77)
+    n_sites, n_ind = 12, 5
+    probs = rng.random((n_sites, n_ind, 3))
+    geno = "marker\ta1\ta2\t" + "\t".join(f"I{i}" for i in range(n_ind)) + "\n" + "".join(
+        f"c_{s}\tA\tC\t" + "\t".join(repr(float(x)) for x in probs[s].reshape(-1)) + "\n" for s in range(n_sites))
+    pos = "".join(f"chr{1 + s // 6}\t{10 * (s % 6 + 1)}\n" for s in range(n_sites))
+
+    def mutate(text: str) -> bytes:
+        b = bytearray(text.encode())
+        for _ in range(int(rng.integers(1, 6))):
+            kind = int(rng.integers(0, 6))
+            at = int(rng.integers(0, max(1, len(b))))
+            if kind == 0 and b:
+                b[at] = int(rng.integers(0, 256))
+            elif kind == 1:
+                del b[at:at + int(rng.integers(1, 40))]
+            elif kind == 2:
+                b[at:at] = b[at:at + int(rng.integers(1, 60))]
+            elif kind == 3:
+                b[at:at] = bytes([0])
+            elif kind == 4:
+                b[at:at] = b"9" * int(rng.integers(100, 5000))
+            else:
+                del b[at:]
+        return bytes(b)
+
+    outcomes = {"ok": 0, "error": 0}
+    for k in range(200):
+        g = tmp_path / f"m{k}.geno.gz"
+        with gzip.open(g, "wb") as fh:
+            fh.write(mutate(geno))
+        try:
+            raw, _ = capi.read_geno_text(str(g), True, bool(k % 2), n_ind, n_sites)
+            assert raw.shape == (n_sites, n_ind, 3)
+            outcomes["ok"] += 1
+        except (capi.NgsldError, RuntimeError, ValueError):
+            outcomes["error"] += 1
+        p = tmp_path / f"m{k}.pos"
+        p.write_bytes(mutate(pos))
+        try:
+            pd, labels = capi.read_pos(str(p), bool(k % 3 == 0), n_sites)
+            assert len(pd) == n_sites and len(labels) == n_sites
+            outcomes["ok"] += 1
+        except (capi.NgsldError, RuntimeError, ValueError):
+            outcomes["error"] += 1
+    assert outcomes["ok"] + outcomes["error"] == 400 and outcomes["error"] > 0
+    print("mutated inputs:", outcomes)
