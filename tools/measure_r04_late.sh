@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Round 4 -- the final tree once more (after the last engine / CLI changes): GPU suite, smoke, the driver's bench line.
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r04/late; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r04/${LATE_DIR:-late}; mkdir -p $O
 cd $R
 ( time timeout 1800 python -m pytest tests -m gpu -x -q ) > $O/pytest_gpu_late.txt 2>&1
 grep -E "passed|failed|parity:" $O/pytest_gpu_late.txt | tail -3
