@@ -38,13 +38,16 @@ def same_tsv(got: str, want: str) -> str | None:
     return None
 
 
-def both_programs(flags: list[str], rec, n_sites: int, d: str, threads: int = 2):
+def both_programs(flags: list[str], rec, n_sites: int, d: str, threads: int = 2, hip_flags=(), hip_env=None):
+    """hip_flags / hip_env: options only the drop-in binary knows (--devices, NGSLD_SLAB_SITES ...), for it alone."""
     out_ref = os.path.join(d, "ref.tsv")
     r = run_ref_program(rec, n_sites, flags, out_ref, d, threads)
     assert r.returncode == 0, r.stderr[-2000:]
     out_hip = os.path.join(d, "hip.tsv")
-    h = subprocess.run([capi.CLI_PATH, *flags, "--n_threads", str(threads), "--out", out_hip], capture_output=True, text=True,
-                       timeout=600)
+    env = dict(os.environ)
+    env.update(hip_env or {})
+    h = subprocess.run([capi.CLI_PATH, *flags, *hip_flags, "--n_threads", str(threads), "--out", out_hip], capture_output=True,
+                       text=True, timeout=600, env=env)
     assert h.returncode == 0, h.stderr[-2000:]
     return open(out_hip).read(), open(out_ref).read()
 
@@ -176,3 +179,18 @@ def test_random_text_input_through_both_programs(k, tmp_path):
     flags, rec, n_sites = text_case_files(k, d)
     got, want = both_programs(flags, rec, n_sites, d, threads=1 + k % 3)
     assert same_tsv(got, want) is None, f"text case {k}: {same_tsv(got, want)}\n{' '.join(flags)}"
+
+
+@pytest.mark.parametrize("k", list(range(200, 230)) + list(range(10_020, 10_024)))
+@pytest.mark.parametrize("how", ["slabs", "parts"])
+def test_streamed_and_multi_part_runs_through_both_programs(k, how, tmp_path):
+    """The drop-in binary's own ways of cutting a job -- row slabs streamed through two alternating contexts
+    (NGSLD_SLAB_SITES: what --max_gpu_mem does to a matrix beyond the budget) and several parts in one process
+    (--devices 0,0,0: three parts on this box's one GPU) -- write the reference program's table too."""
+    d = str(tmp_path)
+    flags, rec, n_sites = case_files(k, d)
+    if how == "slabs":
+        got, want = both_programs(flags, rec, n_sites, d, threads=2, hip_env={"NGSLD_SLAB_SITES": str(max(2, n_sites // 4))})
+    else:
+        got, want = both_programs(flags, rec, n_sites, d, threads=2, hip_flags=("--devices", "0,0,0"))
+    assert same_tsv(got, want) is None, f"case {k} ({how}): {same_tsv(got, want)}\n{' '.join(flags)}"
