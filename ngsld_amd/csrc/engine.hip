@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <sched.h>
 #include <dlfcn.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <chrono>
@@ -95,10 +96,17 @@ struct DevBuf {
   }
 };
 
+// Pinned host memory.  Two megabytes and more: 2 MB-aligned malloc memory on transparent huge pages, registered with the
+// runtime (hipHostRegister, mapped: the pair kernels write records through it, run_direct) -- on the pool's boxes 400 MB cost
+// 17 ms to register and 15 ms to give back, against 72-92 ms and 41-55 ms for hipHostMalloc / hipHostFree of the same size
+// (1.2 GB: 50 + 44 ms against 220-270 + 150-164 ms); copies and kernel writes run at the same 56-57 GB/s either way
+// (tools/probe_pin.hip, profiles/r04/probe_pin.txt).  Smaller buffers, a refused registration, or NGSLD_PIN_REGISTER=0
+// (A/B): hipHostMalloc.
 template <typename T>
 struct PinBuf {
   T *p = nullptr;
   size_t n = 0;
+  bool registered = false;
   PinBuf() = default;
   PinBuf(const PinBuf &) = delete;
   PinBuf &operator=(const PinBuf &) = delete;
@@ -107,14 +115,40 @@ struct PinBuf {
     if (count <= n && p != nullptr) return hipSuccess;
     release();
     if (count == 0) return hipSuccess;
-    hipError_t e = hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault);
+    const size_t huge = (size_t)2 << 20, want = count * sizeof(T);
+    static const bool use_register = [] {
+      const char *e = std::getenv("NGSLD_PIN_REGISTER");
+      return !(e != nullptr && std::strcmp(e, "0") == 0);
+    }();
+    if (use_register && want >= huge) {
+      const size_t bytes = (want + huge - 1) / huge * huge;
+      void *q = nullptr;
+      if (posix_memalign(&q, huge, bytes) == 0) {
+        (void)madvise(q, bytes, MADV_HUGEPAGE);
+        if (hipHostRegister(q, bytes, hipHostRegisterMapped) == hipSuccess) {
+          p = static_cast<T *>(q);
+          n = count;
+          registered = true;
+          return hipSuccess;
+        }
+        (void)hipGetLastError();
+        free(q);
+      }
+    }
+    hipError_t e = hipHostMalloc((void **)&p, want, hipHostMallocDefault);
     if (e == hipSuccess) n = count;
     return e;
   }
   void release() {
-    if (p) (void)hipHostFree(p);
+    if (p && registered) {
+      (void)hipHostUnregister(p);
+      free(p);
+    } else if (p) {
+      (void)hipHostFree(p);
+    }
     p = nullptr;
     n = 0;
+    registered = false;
   }
 };
 // A few parked host threads for the exact-order replay: a launch of 1e8 pairs flags a few dozen pairs, 0.2 ms of arithmetic
