@@ -51,6 +51,7 @@ struct Params {  // ngsLD.hpp:11-44
   int device = 0;
   double max_gpu_mem = 0;  // GB of device memory the run may use; 0 = what is free on the device
   std::vector<int> devices;  // --devices: more than one entry = one part of the rows per device
+  bool keep_parts = false;   // --keep_parts: with --devices and --out, leave parts 1.. in <out>.part<k> instead of appending them
 };
 
 // "0-3", "0,2,5", "1" -> device indices; empty on a malformed list
@@ -108,6 +109,7 @@ void parse_cmd_args(Params *pars, int argc, char **argv) {
                                          {"device", required_argument, NULL, 1001},
                                          {"max_gpu_mem", required_argument, NULL, 1002},
                                          {"devices", required_argument, NULL, 1003},
+                                         {"keep_parts", no_argument, NULL, 1004},
                                          {0, 0, 0, 0}};
   pars->seed = (uint64_t)(time(NULL) + rand() % 1000);  // parse_args.cpp:23
   int c = 0;
@@ -135,6 +137,7 @@ void parse_cmd_args(Params *pars, int argc, char **argv) {
       case 'V': pars->verbose = (unsigned)atoi(optarg); break;
       case 1001: pars->device = atoi(optarg); break;
       case 1002: pars->max_gpu_mem = atof(optarg); break;
+      case 1004: pars->keep_parts = true; break;
       case 1003:
         pars->devices = parse_devices(optarg);
         if (pars->devices.empty()) error(__FUNCTION__, "--devices takes a list like 0-7 or 0,2,5");
@@ -424,16 +427,35 @@ void run_multi(Params &pars, const double *raw, int text_semantics, int log_scal
   if (pars.verbose >= 2)
     for (int k = 0; k < n; ++k)
       fprintf(stderr, "\tdevice %d: %lu pairs\n", pars.devices[(size_t)k], (unsigned long)per[(size_t)k]);
-  // append the spooled parts in order
+  // append the spooled parts in order -- inside the kernel where the file systems allow it (copy_file_range: no trip of the
+  // bytes through this process), through a buffer otherwise.  --keep_parts (with --out): the parts stay where they are,
+  // <out> + <out>.part1 + ... in this order is the table (a shard per device is as good as a merged file, and at
+  // 10^9 rows the merge is a second pass over seven eighths of the output)
   fflush(pars.out_fh);
-  std::vector<char> buf(8u << 20);
+  std::vector<char> buf;
   for (int k = 1; k < n; ++k) {
     FILE *fh = ms.fh[(size_t)k];
     fflush(fh);
-    rewind(fh);
-    size_t got;
-    while ((got = fread(buf.data(), 1, buf.size(), fh)) > 0)
-      if (fwrite(buf.data(), 1, got, pars.out_fh) != got) error(__FUNCTION__, "cannot append a part to the output");
+    if (pars.keep_parts && !part_names[(size_t)k].empty()) {
+      if (fclose(fh) != 0) error(__FUNCTION__, "cannot finish a part file");
+      continue;
+    }
+    const off_t size = lseek(fileno(fh), 0, SEEK_END);
+    off_t done = 0;
+    while (size > 0 && done < size) {  // (the output's own position is at its end: it has only ever been appended to)
+      off_t in_off = done;
+      const ssize_t w = copy_file_range(fileno(fh), &in_off, fileno(pars.out_fh), nullptr, (size_t)std::min<off_t>(size - done, (off_t)1 << 30), 0);
+      if (w <= 0) break;  // (a pipe, /dev/null, another file system on an old kernel: the buffered copy below takes over)
+      done += w;
+    }
+    if (done < size) {
+      if (buf.empty()) buf.resize(8u << 20);
+      if (fseeko(fh, done, SEEK_SET) != 0) error(__FUNCTION__, "cannot re-read a part file");
+      size_t got;
+      while ((got = fread(buf.data(), 1, buf.size(), fh)) > 0)
+        if (fwrite(buf.data(), 1, got, pars.out_fh) != got) error(__FUNCTION__, "cannot append a part to the output");
+      fflush(pars.out_fh);
+    }
     fclose(fh);
     if (!part_names[(size_t)k].empty()) unlink(part_names[(size_t)k].c_str());
   }

@@ -119,6 +119,16 @@ def test_cli_devices_flag(tmp_path, mode):
         outs.append(open(o, "rb").read())
         assert not [f for f in os.listdir(tmp_path) if ".part" in f], "part files must be gone"
     assert outs[0] == outs[1] == outs[2] and outs[0].count(b"\n") > 1000
+    # --keep_parts: parts 1.. stay in <out>.part<k>; the output followed by them, in order, is the same table
+    o = str(tmp_path / "out_kept")
+    r = subprocess.run([capi.CLI_PATH] + flags + ["--devices", "0,0,0", "--keep_parts", "--out", o], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    kept = sorted(f for f in os.listdir(tmp_path) if f.startswith("out_kept.part"))
+    assert kept == ["out_kept.part1", "out_kept.part2"]
+    assert open(o, "rb").read() + b"".join(open(str(tmp_path / f), "rb").read() for f in kept) == outs[0]
+    # ... and a merge that cannot stay inside the kernel (the output is a pipe) takes the buffered copy
+    r = subprocess.run([capi.CLI_PATH] + flags + ["--devices", "0,0,0"], capture_output=True)
+    assert r.returncode == 0 and r.stdout == outs[0]
 
 
 def test_a_failing_part_stops_the_whole_job():

@@ -16,6 +16,7 @@ chrs, pos = synth.make_positions(100000, 3)
 synth.write_pos(os.path.join(d, "in.pos"), chrs, pos)
 PY
 CMD="ngsld_amd/bin/ngsLD --geno $D/in.glf --n_ind 500 --n_sites 100000 --pos $D/in.pos --max_kb_dist 100 --extend_out --n_threads 16 --verbose 0 --out /dev/null"
+case " ${E2E_ENV:-} " in *NGSLD_E2E_DEVICES=*) DEVS=$(echo "${E2E_ENV}" | tr " " "\n" | grep NGSLD_E2E_DEVICES= | cut -d= -f2); CMD="$CMD --devices $DEVS";; esac  # (E2E_ENV="NGSLD_E2E_DEVICES=0,0,0": several parts in one process)
 : > $out
 for i in 1 2 3; do
   echo "== run $i ${E2E_ENV:-}" >> $out
