@@ -96,12 +96,16 @@ struct DevBuf {
   }
 };
 
-// Pinned host memory.  Two megabytes and more: 2 MB-aligned malloc memory on transparent huge pages, registered with the
-// runtime (hipHostRegister, mapped: the pair kernels write records through it, run_direct) -- on the pool's boxes 400 MB cost
-// 17 ms to register and 15 ms to give back, against 72-92 ms and 41-55 ms for hipHostMalloc / hipHostFree of the same size
-// (1.2 GB: 50 + 44 ms against 220-270 + 150-164 ms); copies and kernel writes run at the same 56-57 GB/s either way
-// (tools/probe_pin.hip, profiles/r04/probe_pin.txt).  Smaller buffers, a refused registration, or NGSLD_PIN_REGISTER=0
-// (A/B): hipHostMalloc.
+// Pinned host memory: hipHostMalloc.  NGSLD_PIN_REGISTER=1 (opt-in, A/B): buffers of two megabytes and more as 2 MB-aligned
+// malloc memory on transparent huge pages, registered with the runtime (hipHostRegister, mapped: the pair kernels write records
+// through it, run_direct).  That is 4x cheaper to get and to give back -- 400 MB: 17 + 15 ms against 72-92 + 41-55 ms, 1.2 GB:
+// 50 + 44 ms against 220-270 + 150-164 ms, copies and kernel writes at the same 56-57 GB/s (tools/probe_pin.hip,
+// profiles/r04/probe_pin.txt) -- and took the drop-in binary on configs[2] from 0.97-1.05 to 0.86-0.97 s (pin_ab.txt).  It
+// was the default for five commits and is not any more: one of the two runs of the whole GPU suite made with it (a process that lives nine
+// minutes, creates hundreds of contexts and forks children) ABORTED inside a record run of a fresh context while it was on
+// (profiles/r04/late3/), none of the runs before or after with it off.  Registered user memory stays ordinary anonymous memory
+// -- the kernel may migrate or collapse its pages and the driver has to follow through its notifier -- where hipHostMalloc
+// memory is the driver's own and pinned for good; 70 ms are not worth a crash in somebody's hour-long run.
 template <typename T>
 struct PinBuf {
   T *p = nullptr;
@@ -118,7 +122,7 @@ struct PinBuf {
     const size_t huge = (size_t)2 << 20, want = count * sizeof(T);
     static const bool use_register = [] {
       const char *e = std::getenv("NGSLD_PIN_REGISTER");
-      return !(e != nullptr && std::strcmp(e, "0") == 0);
+      return e != nullptr && std::strcmp(e, "1") == 0;
     }();
     if (use_register && want >= huge) {
       const size_t bytes = (want + huge - 1) / huge * huge;

@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r04
 O=gpurun_out/r04/pin_ab.txt; : > $O
 python -m pytest tests/test_gpu_pipeline.py tests/test_gpu_text.py tests/test_gpu_replay.py tests/test_gpu_golden.py -q -x 2>&1 | grep -E "passed|failed" >> $O
-for v in 1 0 1 0; do
+for v in 1 0 1 0; do  # (1 = registered huge-page memory, opt-in; 0 = hipHostMalloc, the default)
   E2E_NO_TRACE=1 E2E_ENV="NGSLD_PIN_REGISTER=$v" bash tools/e2e_breakdown.sh > /dev/null 2>&1
   echo "#### NGSLD_PIN_REGISTER=$v" >> $O
   grep -E "upload|create|free|real|pair kernels|total" gpurun_out/r04/e2e_breakdown.txt >> $O
