@@ -91,7 +91,7 @@ def case_files(k: int, d: str):
     return flags, o.run(), n_sites
 
 
-@pytest.mark.parametrize("k", list(range(0, 90)) + list(range(10_000, 10_012)) + list(range(30_000, 30_010)))
+@pytest.mark.parametrize("k", list(range(0, 48)) + list(range(10_000, 10_006)) + list(range(30_000, 30_006)))   # (tools/cli_soak.py: 2,900 more)
 def test_random_case_through_both_programs(k, tmp_path):
     d = str(tmp_path)
     flags, rec, n_sites = case_files(k, d)
@@ -173,7 +173,7 @@ def text_case_files(k: int, d: str):
     return flags, o.run(), n_sites
 
 
-@pytest.mark.parametrize("k", range(40))
+@pytest.mark.parametrize("k", range(24))   # (tools/cli_soak.py ... text: 400 more)
 def test_random_text_input_through_both_programs(k, tmp_path):
     d = str(tmp_path)
     flags, rec, n_sites = text_case_files(k, d)
@@ -181,7 +181,7 @@ def test_random_text_input_through_both_programs(k, tmp_path):
     assert same_tsv(got, want) is None, f"text case {k}: {same_tsv(got, want)}\n{' '.join(flags)}"
 
 
-@pytest.mark.parametrize("k", list(range(200, 230)) + list(range(10_020, 10_024)))
+@pytest.mark.parametrize("k", list(range(200, 214)) + list(range(10_020, 10_022)))
 @pytest.mark.parametrize("how", ["slabs", "parts"])
 def test_streamed_and_multi_part_runs_through_both_programs(k, how, tmp_path):
     """The drop-in binary's own ways of cutting a job -- row slabs streamed through two alternating contexts
