@@ -101,9 +101,11 @@ struct DevBuf {
 // through it, run_direct).  That is 4x cheaper to get and to give back -- 400 MB: 17 + 15 ms against 72-92 + 41-55 ms, 1.2 GB:
 // 50 + 44 ms against 220-270 + 150-164 ms, copies and kernel writes at the same 56-57 GB/s (tools/probe_pin.hip,
 // profiles/r04/probe_pin.txt) -- and took the drop-in binary on configs[2] from 0.97-1.05 to 0.86-0.97 s (pin_ab.txt).  It
-// was the default for five commits and is not any more: one of the two runs of the whole GPU suite made with it (a process that lives nine
+// was the default for five commits and is not any more: two of the three runs of the whole GPU suite made with it (a process that lives nine
 // minutes, creates hundreds of contexts and forks children) ABORTED inside a record run of a fresh context while it was on
-// (profiles/r04/late3/), none of the runs before or after with it off.  Registered user memory stays ordinary anonymous memory
+// (profiles/r04/late3/), none of the runs before or after with it off; run again with it on and unbuffered output, the suite died
+// the same way with the runtime's own words: "Memory access fault by GPU node-2 ... on address 0x56bd21b36000" -- an address on
+// the process' brk heap, where glibc had placed the aligned block, a few tests after one that forks a child.  Registered user memory stays ordinary anonymous memory
 // -- the kernel may migrate or collapse its pages and the driver has to follow through its notifier -- where hipHostMalloc
 // memory is the driver's own and pinned for good; 70 ms are not worth a crash in somebody's hour-long run.
 template <typename T>
