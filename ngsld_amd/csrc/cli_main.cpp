@@ -469,6 +469,11 @@ void run_multi(Params &pars, const double *raw, int text_semantics, int log_scal
 
 int main(int argc, char **argv) {
   TimingReport timing_report;
+  // This program's pinned host buffers are registered anonymous memory rather than hipHostMalloc memory (engine.hip, PinBuf):
+  // 4x cheaper to get and to give back -- 0.07 s of a one-second run of configs[2], 3 s of configs[4] at full size.  The
+  // library leaves that off by default (in a long-lived process that forks children it cost a GPU memory fault before the
+  // mapping became fork-proof); this process is short-lived, single-purpose and never forks.  NGSLD_PIN_REGISTER=0 turns it off.
+  setenv("NGSLD_PIN_REGISTER", "1", /*overwrite=*/0);
   Params pars;
   parse_cmd_args(&pars, argc, argv);
 

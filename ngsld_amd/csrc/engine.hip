@@ -96,23 +96,27 @@ struct DevBuf {
   }
 };
 
-// Pinned host memory: hipHostMalloc.  NGSLD_PIN_REGISTER=1 (opt-in, A/B): buffers of two megabytes and more as 2 MB-aligned
-// malloc memory on transparent huge pages, registered with the runtime (hipHostRegister, mapped: the pair kernels write records
-// through it, run_direct).  That is 4x cheaper to get and to give back -- 400 MB: 17 + 15 ms against 72-92 + 41-55 ms, 1.2 GB:
-// 50 + 44 ms against 220-270 + 150-164 ms, copies and kernel writes at the same 56-57 GB/s (tools/probe_pin.hip,
-// profiles/r04/probe_pin.txt) -- and took the drop-in binary on configs[2] from 0.97-1.05 to 0.86-0.97 s (pin_ab.txt).  It
-// was the default for five commits and is not any more: two of the three runs of the whole GPU suite made with it (a process that lives nine
-// minutes, creates hundreds of contexts and forks children) ABORTED inside a record run of a fresh context while it was on
-// (profiles/r04/late3/), none of the runs before or after with it off; run again with it on and unbuffered output, the suite died
-// the same way with the runtime's own words: "Memory access fault by GPU node-2 ... on address 0x56bd21b36000" -- an address on
-// the process' brk heap, where glibc had placed the aligned block, a few tests after one that forks a child.  Registered user memory stays ordinary anonymous memory
-// -- the kernel may migrate or collapse its pages and the driver has to follow through its notifier -- where hipHostMalloc
-// memory is the driver's own and pinned for good; 70 ms are not worth a crash in somebody's hour-long run.
+// Pinned host memory: hipHostMalloc.  NGSLD_PIN_REGISTER=1 (opt-in; the drop-in binary opts in, cli_main.cpp): buffers of two
+// megabytes and more as 2 MB-aligned anonymous memory on transparent huge pages, registered with the runtime (hipHostRegister,
+// mapped: the pair kernels write records through it, run_direct).  That is 4x cheaper to get and to give back -- 400 MB: 17 +
+// 15 ms against 72-92 + 41-55 ms, 1.2 GB: 50 + 44 ms against 220-270 + 150-164 ms, copies and kernel writes at the same
+// 56-57 GB/s (tools/probe_pin.hip, profiles/r04/probe_pin.txt) -- and takes the binary on configs[2] from 0.97-1.05 to
+// 0.86-0.97 s (pin_ab.txt), configs[4] at full size from 25.9 / 19.7 to 22.7 / 16.7 s.
+// Why it is not the library's default.  Its first form took the block from malloc (posix_memalign) and was the default for
+// five commits: two of the three runs of the whole GPU suite made with it -- one process that lives nine minutes, creates
+// hundreds of contexts and forks children -- died of "Memory access fault by GPU node-2 ... on address 0x56bd21b36000", an
+// address on the process' brk heap, a few tests after one that forks (profiles/r04/late3/).  A fork() write-protects the
+// parent's private pages for copy-on-write under the device's mapping, and a freed heap block is handed out again to
+// anybody.  The block is now a mapping of its own with MADV_DONTFORK (what RDMA libraries do to registered memory): four
+// whole-suite runs since, two with it on in the test process, none died (pin_dontfork_suite_runs.txt).  Registered memory still
+// is ordinary anonymous memory whose pages the kernel may migrate under the driver's notifier, hipHostMalloc memory is the
+// driver's own: a host application gets the latter unless it asks.
 template <typename T>
 struct PinBuf {
   T *p = nullptr;
   size_t n = 0;
-  bool registered = false;
+  void *map_base = nullptr;  // registered variant: the anonymous mapping the buffer sits in (null: hipHostMalloc memory)
+  size_t map_len = 0;
   PinBuf() = default;
   PinBuf(const PinBuf &) = delete;
   PinBuf &operator=(const PinBuf &) = delete;
@@ -127,18 +131,23 @@ struct PinBuf {
       return e != nullptr && std::strcmp(e, "1") == 0;
     }();
     if (use_register && want >= huge) {
-      const size_t bytes = (want + huge - 1) / huge * huge;
-      void *q = nullptr;
-      if (posix_memalign(&q, huge, bytes) == 0) {
+      // a mapping of its own (never the malloc heap: a freed block there is handed out again, to anybody), 2 MB aligned, on
+      // huge pages, and kept out of children (MADV_DONTFORK: a fork() would write-protect the pages for copy-on-write under
+      // the device's mapping -- what registered memory of RDMA libraries is protected from the same way)
+      const size_t bytes = (want + huge - 1) / huge * huge, len = bytes + huge;
+      void *m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+      if (m != MAP_FAILED) {
+        void *q = reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(m) + huge - 1) / huge * huge);
         (void)madvise(q, bytes, MADV_HUGEPAGE);
-        if (hipHostRegister(q, bytes, hipHostRegisterMapped) == hipSuccess) {
+        if (madvise(q, bytes, MADV_DONTFORK) == 0 && hipHostRegister(q, bytes, hipHostRegisterMapped) == hipSuccess) {
           p = static_cast<T *>(q);
           n = count;
-          registered = true;
+          map_base = m;
+          map_len = len;
           return hipSuccess;
         }
         (void)hipGetLastError();
-        free(q);
+        (void)munmap(m, len);
       }
     }
     hipError_t e = hipHostMalloc((void **)&p, want, hipHostMallocDefault);
@@ -146,15 +155,16 @@ struct PinBuf {
     return e;
   }
   void release() {
-    if (p && registered) {
+    if (p && map_base) {
       (void)hipHostUnregister(p);
-      free(p);
+      (void)munmap(map_base, map_len);
     } else if (p) {
       (void)hipHostFree(p);
     }
     p = nullptr;
     n = 0;
-    registered = false;
+    map_base = nullptr;
+    map_len = 0;
   }
 };
 // A few parked host threads for the exact-order replay: a launch of 1e8 pairs flags a few dozen pairs, 0.2 ms of arithmetic
