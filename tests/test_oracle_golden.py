@@ -114,3 +114,42 @@ def test_taus_known_answer_and_row_seeds():
     L.orc_taus_set(st, 42)
     for k in range(5):
         assert seeds[k] == int(L.orc_taus_get(st) / 4294967296.0 * 1e15)
+
+
+def test_pearson_against_exact_rational_arithmetic():
+    """How far ANY faithful evaluation of Pearson's r can be from the oracle's: r^2 = Sxy^2 / (Sxx Syy) evaluated EXACTLY on
+    the doubles (Python fractions: every double is a rational) and rounded once, against the square of orc_correlation (GSL's
+    one-pass recurrence with long double accumulators, restated -- GSL itself is not in the image).  Expected-genotype
+    vectors of the shapes the path sees: values in [0, 2], cohorts of 2..500, including nearly constant ones (the
+    ill-conditioned case).  The oracle is within 2e-15 of the exact value of r^2 (a handful of ulps of 1) -- so is any
+    implementation that carries the sums in extended precision, GSL's included -- five orders of magnitude inside the
+    1e-9 the north star asks for: what "parity unpinned at the GSL boundary" can cost is bounded by that."""
+    from fractions import Fraction
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for case in range(120):
+        n = int(rng.choice([2, 3, 8, 24, 100, 500]))
+        if case % 3 == 0:      # expected genotypes of a well-typed site pair
+            x, y = rng.random(n) * 2, rng.random(n) * 2
+        elif case % 3 == 1:    # correlated pair
+            x = rng.random(n) * 2
+            y = np.clip(x + rng.normal(0, 0.05, n), 0, 2)
+        else:                  # nearly constant vectors: 1 / (std1 std2) large
+            x = 1.0 + rng.normal(0, 1e-6, n)
+            y = 0.3 + rng.normal(0, 1e-6, n)
+        fx, fy = [Fraction(float(v)) for v in x], [Fraction(float(v)) for v in y]
+        mx, my = sum(fx) / n, sum(fy) / n
+        sxy = sum((a - mx) * (b - my) for a, b in zip(fx, fy))
+        sxx = sum((a - mx) ** 2 for a in fx)
+        syy = sum((b - my) ** 2 for b in fy)
+        if sxx == 0 or syy == 0:
+            continue
+        exact = float(sxy * sxy / (sxx * syy))
+        got = orc.lib().orc_correlation(orc.dp(np.ascontiguousarray(x)), orc.dp(np.ascontiguousarray(y)), n) ** 2
+        err = abs(got - exact)
+        if case % 3 != 2:
+            assert err < 2e-15, (case, n, got, exact)
+            worst = max(worst, err)
+        else:  # the cancellation in the means costs digits in proportion to 1 / std: still far inside 1e-9
+            assert err < 1e-9, (case, n, got, exact)
+    print(f"oracle r2_ExpG vs exact rational arithmetic: worst absolute difference {worst:.2e} (well-conditioned cases)")
