@@ -321,7 +321,12 @@ struct ngsld_ctx {
   void *replay_user = nullptr;
   const double *replay_matrix = nullptr;      // ... or the caller's own host array, read in place (ngsld_set_replay_matrix)
   std::mutex replay_mu;                       // serialises the source callback / the plane read-back
-  hipStream_t replay_stream = nullptr;        // non-blocking: read-backs must not wait for the next batch's kernel
+  // non-blocking: read-backs must not wait for the next batch's kernel.  Made on FIRST USE (replay_stream_of), not with the
+  // context: it is needed by runs that flag more pairs than their list holds, or that replay without a registered source --
+  // hardly ever -- while a stream costs 11 ms to create and a slot among the runtime's four hardware queues, which ALL of a
+  // process' streams share (tools/probe_init.hip, profiles/r04/probe_init.txt, hw_queues_ab.txt).
+  hipStream_t replay_stream = nullptr;
+  std::mutex replay_stream_mu;
   ngsld_geno_opts gopts{};
   bool normalised = false;                    // data came through ngsld_set_geno_lkl
   DevBuf<uint32_t> d_flags[kSlots], d_flags_dev;   // [count, pad, list of the first flag_cap, one bit per record ...] per pipeline slot / for ngsld_run_device
@@ -366,6 +371,17 @@ int fail(ngsld_ctx *c, int code, const std::string &msg) {
 int hip_fail(ngsld_ctx *c, hipError_t e, const char *what) {
   return fail(c, e == hipErrorOutOfMemory ? NGSLD_ERR_NOMEM : NGSLD_ERR_DEVICE,
               std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// The read-back stream of the exact-order replay (see ngsld_ctx::replay_stream); the copy stream where it cannot be had.
+hipStream_t replay_stream_of(ngsld_ctx *c) {
+  std::lock_guard<std::mutex> g(c->replay_stream_mu);
+  if (c->replay_stream == nullptr && hipStreamCreateWithFlags(&c->replay_stream, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    c->replay_stream = nullptr;
+    return c->copy_stream;
+  }
+  return c->replay_stream;
 }
 
 #define HIP_TRY(c, call)                                \
@@ -786,10 +802,11 @@ int fetch_replay_site(ngsld_ctx *c, uint64_t s, std::vector<double> &tmp, Replay
   double *lkl = tmp.data();
   {
     std::lock_guard<std::mutex> g(c->replay_mu);
-    if (hipSetDevice(c->device) != hipSuccess || c->h_site_stage.resize(3ull * c->np) != hipSuccess ||
-        hipMemcpyAsync(c->h_site_stage.p, c->d_planes.p + s * 3ull * c->np, 3ull * c->np * sizeof(double),
-                       hipMemcpyDeviceToHost, c->replay_stream) != hipSuccess ||
-        hipStreamSynchronize(c->replay_stream) != hipSuccess)
+    if (hipSetDevice(c->device) != hipSuccess || c->h_site_stage.resize(3ull * c->np) != hipSuccess) return NGSLD_ERR_DEVICE;
+    hipStream_t rs = replay_stream_of(c);
+    if (hipMemcpyAsync(c->h_site_stage.p, c->d_planes.p + s * 3ull * c->np, 3ull * c->np * sizeof(double),
+                       hipMemcpyDeviceToHost, rs) != hipSuccess ||
+        hipStreamSynchronize(rs) != hipSuccess)
       return NGSLD_ERR_DEVICE;
     const double *planes = c->h_site_stage.p;
     for (uint64_t i = 0; i < n; ++i)
@@ -841,9 +858,9 @@ int flagged_records(ngsld_ctx *c, const uint32_t *h_head, const uint32_t *d_flag
   }
   const size_t words = (size_t)((n + 31) / 32);
   HIP_TRY(c, c->h_flag_bits.resize(words ? words : 1));
-  HIP_TRY(c, hipMemcpyAsync(c->h_flag_bits.p, d_flags + flag_head_words(cap), words * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                            c->replay_stream));
-  HIP_TRY(c, hipStreamSynchronize(c->replay_stream));
+  hipStream_t rs = replay_stream_of(c);
+  HIP_TRY(c, hipMemcpyAsync(c->h_flag_bits.p, d_flags + flag_head_words(cap), words * sizeof(uint32_t), hipMemcpyDeviceToHost, rs));
+  HIP_TRY(c, hipStreamSynchronize(rs));
   const uint32_t *bits = c->h_flag_bits.p;
   recs.reserve(count);
   for (uint64_t w = 0; w < words; ++w)
@@ -866,7 +883,7 @@ int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t bas
   const bool have_items = c->h_items.size() == c->n_items;
   std::vector<uint32_t> loc_s1, loc_s2;
   if (!have_items) {
-    hipStream_t ls = st != nullptr ? st : c->replay_stream;
+    hipStream_t ls = st != nullptr ? st : replay_stream_of(c);
     loc_s1.resize(recs.size());
     loc_s2.resize(recs.size());
     HIP_TRY(c, c->d_patch_idx.resize(recs.size()));
@@ -1082,8 +1099,7 @@ int ngsld_create(int device, ngsld_ctx **out) {
   if (const char *k = std::getenv("NGSLD_RUN_TAPER")) c->run_taper = std::strcmp(k, "0") != 0;
   if (const char *k = std::getenv("NGSLD_RUN_STREAMS")) c->run_streams = std::atoi(k) >= 2 ? 2 : 1;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
-      (e = hipStreamCreate(&c->stream2)) != hipSuccess || (e = hipStreamCreate(&c->copy_stream)) != hipSuccess ||
-      (e = hipStreamCreateWithFlags(&c->replay_stream, hipStreamNonBlocking)) != hipSuccess) {
+      (e = hipStreamCreate(&c->stream2)) != hipSuccess || (e = hipStreamCreate(&c->copy_stream)) != hipSuccess) {
     g_create_error = std::string("stream setup: ") + hipGetErrorString(e);
     delete c;
     return NGSLD_ERR_DEVICE;
