@@ -95,3 +95,13 @@ def test_patched_reference_main_fails_loudly_without_a_device(tmp_path):
     flags = ["--geno", g, "--n_ind", str(fx.n_ind), "--n_sites", str(fx.n_sites), "--verbose", "0"] + (["--pos", p] if p else []) + fx.cli_flags(True)
     r = run_patched_ref_program(flags, os.path.join(d, "out.tsv"))
     assert r.returncode == 255 and "no HIP device available" in r.stderr and "no CPU fallback" in r.stderr
+
+
+def test_edge_cases_through_the_reference_program_and_the_oracle_cli():
+    """tools/cli_edge_cases.py with the oracle's CLI in the binary's place: one / two sites, one / two individuals, nothing but
+    monomorphic sites or missing data, empty windows, a chromosome per site, thresholds that drop everything, files shorter or
+    longer than --n_sites, positions that repeat or go backwards -- same table, or the same error line (56 runs)."""
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(orc.HERE), "tools", "cli_edge_cases.py"), "--binary", orc.ORC_CLI],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "56 through both programs, 0 differ" in r.stdout

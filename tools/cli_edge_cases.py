@@ -1,0 +1,174 @@
+"""Dev tool (GPU box): hand-built EDGE cases through both programs -- the drop-in binary (ngsld_amd/bin/ngsLD) and the reference's
+own program (oracle/_ref ref_main) -- same argv, same files.  Where the reference program writes a table, the binary must write
+the same one (header equal, sorted bodies byte-identical); where the reference program ends in an error, so must the binary (exit
+status non-zero, the same "[function] ERROR: ..." line).  The fuzz generator (tests/test_gpu_fuzz.py) starts at three sites and
+sorted, well-formed files; this is what lies below and beside it: one / two sites, one / two individuals, nothing but monomorphic
+sites, nothing but missing data, windows that hold no pair, one chromosome per site, thresholds that drop everything, files
+shorter or longer than --n_sites says.
+python tools/cli_edge_cases.py [--json out.json] [--binary PATH]   (--binary oracle/ngsld_oracle: the oracle's CLI instead, no GPU)"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "..", "tests"))
+sys.path.insert(0, os.path.join(HERE, ".."))
+from ngsld_amd import capi, shard, synth  # noqa: E402
+from oracle import orc  # noqa: E402
+from util import run_ref_program  # noqa: E402
+
+
+def same_tsv(got: str, want: str):
+    gl, wl = got.splitlines(keepends=True), want.splitlines(keepends=True)
+    if not gl and not wl:
+        return None
+    if len(gl) != len(wl):
+        return f"{len(gl)} lines against the reference's {len(wl)}"
+    if gl[0] != wl[0]:
+        return f"first line {gl[0]!r} against {wl[0]!r}"
+    a, b = sorted(gl[1:]), sorted(wl[1:])
+    for x, y in zip(a, b):
+        if x != y:
+            return f"{sum(1 for p, q in zip(a, b) if p != q)} rows differ, first:\n  hip {x!r}\n  ref {y!r}"
+    return None
+
+
+def error_line(stderr: str) -> str:
+    for ln in stderr.splitlines():
+        if "ERROR" in ln:   # (the reference's main() is compiled under the name ref_main: its __FUNCTION__ says so)
+            return ln.strip().replace("[ref_main]", "[main]")
+    return ""
+
+
+def cases():
+    """(name, raw [sites][ind][3], (chrs, pos) or None, oracle keywords, extra flags, n_sites override or None)"""
+    rng = np.random.default_rng(424242)
+    gl = lambda s, i, seed, depth=4.0: synth.make_gl_numpy(s, i, seed, depth=depth)  # noqa: E731
+    posn = lambda s, seed, gap=200, n_chr=1: synth.make_positions(s, seed, max_gap=gap, n_chr=n_chr)  # noqa: E731
+    out = []
+    out.append(("one site", gl(1, 5, 1), posn(1, 1), {}, [], None))
+    out.append(("two sites, one individual", gl(2, 1, 2), posn(2, 2), {}, [], None))
+    out.append(("two sites, two individuals", gl(2, 2, 3), posn(2, 3), {}, [], None))
+    out.append(("three sites, one individual, no positions", gl(3, 1, 4), None, {}, [], None))
+    mono = np.tile(np.array([1.0, 0.0, 0.0]), (6, 20, 1))
+    out.append(("every site monomorphic", mono, posn(6, 5), {}, [], None))
+    mono2 = np.tile(np.array([0.0, 0.0, 1.0]), (6, 20, 1))
+    out.append(("every site fixed for the other allele", mono2, posn(6, 6), {}, [], None))
+    het = np.tile(np.array([0.0, 1.0, 0.0]), (5, 12, 1))
+    out.append(("every genotype a called heterozygote", het, posn(5, 7), {}, [], None))
+    miss = np.full((6, 20, 3), 1.0 / 3.0)
+    out.append(("nothing but missing data", miss, posn(6, 8), {}, [], None))
+    out.append(("nothing but missing data, --ignore_miss_data", miss, posn(6, 8), dict(ignore_miss_data=True), [], None))
+    half = gl(8, 30, 9)
+    half[:, 15:] = 1.0 / 3.0
+    out.append(("half the individuals without data, --ignore_miss_data", half, posn(8, 9), dict(ignore_miss_data=True), [], None))
+    out.append(("window that holds no pair", gl(8, 10, 10), (["chr1"] * 8, np.arange(1, 9, dtype=np.int64) * 5000),
+                dict(max_kb_dist=1), [], None))
+    out.append(("one chromosome per site, all pairs", gl(6, 10, 11), posn(6, 11, n_chr=6), {}, [], None))
+    out.append(("one chromosome per site, windowed", gl(6, 10, 11), posn(6, 11, n_chr=6), dict(max_kb_dist=10), [], None))
+    out.append(("--min_maf 0.5", gl(10, 40, 12), posn(10, 12), dict(min_maf=0.5), [], None))
+    out.append(("--min_maf 0.499", gl(10, 40, 12), posn(10, 12), dict(min_maf=0.499), [], None))
+    out.append(("--max_snp_dist 1", gl(10, 40, 13), posn(10, 13), dict(max_snp_dist=1), [], None))
+    out.append(("--max_snp_dist 1 and --max_kb_dist 1", gl(10, 40, 13), posn(10, 13, gap=900), dict(max_snp_dist=1, max_kb_dist=1), [], None))
+    zeros = gl(5, 9, 14)
+    zeros[2, 3] = 0.0
+    zeros[4] = 0.0
+    out.append(("all-zero triples (one individual; one whole site)", zeros, posn(5, 14), {}, [], None))
+    big = gl(5, 9, 15)
+    big[1] *= 1e300
+    big[3] *= 1e-300
+    out.append(("likelihoods near the ends of the double range", big, posn(5, 15), {}, [], None))
+    with np.errstate(divide="ignore"):
+        hard_log = np.log(np.eye(3)[rng.integers(0, 3, size=(6, 11))])
+    out.append(("log scale with -inf entries", hard_log, posn(6, 16), dict(log_scale=True), [], None))
+    out.append(("file longer than --n_sites", gl(10, 7, 17), posn(6, 17), {}, [], 6))
+    out.append(("file shorter than --n_sites", gl(4, 7, 18), posn(6, 18), {}, [], 6))
+    out.append(("positions file shorter than --n_sites", gl(6, 7, 19), posn(5, 19), {}, [], None))
+    out.append(("positions file longer than --n_sites", gl(6, 7, 20), posn(7, 20), {}, [], None))
+    chrs, pos = posn(6, 21)
+    pos = pos.copy()
+    pos[3] = pos[2]
+    out.append(("two sites at one position", gl(6, 7, 21), (chrs, pos), {}, [], None))
+    pos2 = posn(6, 22)[1].copy()
+    pos2[4] = pos2[3] - 1
+    out.append(("positions going backwards", gl(6, 7, 22), (["chr1"] * 6, pos2), {}, [], None))
+    out.append(("--call_geno with both thresholds 0", gl(8, 25, 23), posn(8, 23), dict(call_geno=(0.0, 0.0)),
+                ["--probs", "--call_geno", "--N_thresh", "0.0", "--call_thresh", "0.0"], None))
+    out.append(("--call_geno with both thresholds 1", gl(8, 25, 24), posn(8, 24), dict(call_geno=(1.0, 1.0)),
+                ["--probs", "--call_geno", "--N_thresh", "1.0", "--call_thresh", "1.0"], None))
+    return out
+
+
+def main():
+    results, bad = [], 0
+    binary = sys.argv[sys.argv.index("--binary") + 1] if "--binary" in sys.argv else capi.CLI_PATH
+    for extend in (False, True):
+        for name, raw, pp, kw, extra, n_sites_flag in cases():
+            raw = np.ascontiguousarray(raw, dtype=np.float64)
+            n_file, n_ind = raw.shape[:2]
+            n_sites = n_sites_flag if n_sites_flag is not None else n_file
+            with tempfile.TemporaryDirectory() as d:
+                g = os.path.join(d, "in.glf")
+                raw.tofile(g)
+                flags = ["--geno", g, "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--verbose", "0"]
+                pd = None
+                if pp is not None:
+                    p = os.path.join(d, "in.pos")
+                    synth.write_pos(p, list(pp[0]), pp[1])
+                    flags += ["--pos", p]
+                    if len(pp[1]) == n_sites:
+                        pd = shard.pos_dist_from_positions(list(pp[0]), pp[1])
+                okw = dict(kw)
+                flags += ["--max_kb_dist", str(okw.get("max_kb_dist", 0)), "--max_snp_dist", str(okw.get("max_snp_dist", 0)),
+                          "--min_maf", repr(float(okw.get("min_maf", 0.0)))]
+                if okw.get("log_scale"):
+                    flags.append("--log_scale")
+                if okw.get("ignore_miss_data"):
+                    flags.append("--ignore_miss_data")
+                flags += extra
+                if extend:
+                    flags.append("--extend_out")
+                # the oracle's records: only for the reference program's r2_ExpG column (GSL is not in the image)
+                rec = np.zeros(0, dtype=orc.PAIR_DTYPE)
+                usable = n_file >= n_sites and (pp is None or pd is not None) and (pd is None or not np.any(pd[np.isfinite(pd)] < 1))
+                if usable:
+                    try:
+                        with np.errstate(all="ignore"):
+                            rec = orc.Oracle(raw[:n_sites], pd, n_threads=2, **okw).run()
+                    except (ValueError, RuntimeError):
+                        rec = np.zeros(0, dtype=orc.PAIR_DTYPE)
+                out_ref, out_hip = os.path.join(d, "ref.tsv"), os.path.join(d, "hip.tsv")
+                r = run_ref_program(rec, n_sites, flags, out_ref, d, threads=2)
+                h = subprocess.run([binary, *flags, "--n_threads", "2", "--out", out_hip], capture_output=True, text=True,
+                                   timeout=600)
+                verdict = None
+                if r.returncode == 0:
+                    if h.returncode != 0:
+                        verdict = f"reference program wrote a table, the binary ended with {h.returncode}: {h.stderr[-300:]}"
+                    else:
+                        verdict = same_tsv(open(out_hip).read(), open(out_ref).read())
+                    what = f"table of {max(0, len(open(out_ref).read().splitlines()) - 1)} rows"
+                else:
+                    if h.returncode == 0:
+                        verdict = f"reference program ended with {r.returncode} ({error_line(r.stderr)}), the binary wrote a table"
+                    elif error_line(r.stderr) != error_line(h.stderr):
+                        verdict = f"error lines differ: ref {error_line(r.stderr)!r} hip {error_line(h.stderr)!r}"
+                    what = f"error: {error_line(r.stderr)}"
+                tag = name + (", --extend_out" if extend else "")
+                results.append({"case": tag, "reference": what, "same": verdict is None, "difference": verdict})
+                bad += verdict is not None
+                print(f"{'same     ' if verdict is None else 'DIFFERENT'}  {tag}: {what}" + ("" if verdict is None else f"\n           {verdict}"),
+                      flush=True)
+    print(f"edge cases: {len(results)} through both programs, {bad} differ")
+    if "--json" in sys.argv:
+        with open(sys.argv[sys.argv.index("--json") + 1], "w") as fh:
+            json.dump(results, fh, indent=1)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
