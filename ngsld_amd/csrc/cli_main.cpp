@@ -84,6 +84,14 @@ std::vector<int> parse_devices(const char *txt) {
   exit(-1);
 }
 
+// The function the reference names in front of an error of its positions reader: the file is opened by read_file
+// (gen_func.cpp:244-246), its fields are counted by read_split (read_data.cpp:145-146), everything else is read_dist's own.
+const char *pos_error_function(const char *msg) {
+  if (std::strcmp(msg, "cannot open file!") == 0) return "read_file";
+  if (std::strcmp(msg, "invalid number of fields in file!") == 0) return "read_split";
+  return "read_dist";
+}
+
 void parse_cmd_args(Params *pars, int argc, char **argv) {
   static struct option long_options[] = {{"geno", required_argument, NULL, 'g'},
                                          {"probs", no_argument, NULL, 'p'},
@@ -302,7 +310,7 @@ bool run_streamed(Params &pars, uint64_t slab_sites, bool may_fall_back) {
   if (pars.verbose >= 1) fprintf(stderr, "==> Getting sites coordinates\n");
   if (pars.in_pos &&
       ngsld_host_read_pos(pars.in_pos, pars.in_pos_header ? 1 : 0, pars.n_sites, &pos, err, sizeof(err)) != NGSLD_OK)
-    error("read_dist", err);
+    error(pos_error_function(err), err);
   ngsld_params lp;
   ngsld_geno_opts go;
   fill_run_params(pars, &lp, &go);
@@ -382,7 +390,7 @@ void run_multi(Params &pars, const double *raw, int text_semantics, int log_scal
   if (pars.verbose >= 1) fprintf(stderr, "==> Getting sites coordinates\n");
   if (pars.in_pos &&
       ngsld_host_read_pos(pars.in_pos, pars.in_pos_header ? 1 : 0, pars.n_sites, &pos, err, sizeof(err)) != NGSLD_OK)
-    error("read_dist", err);
+    error(pos_error_function(err), err);
   ngsld_params lp;
   ngsld_geno_opts go;
   fill_run_params(pars, &lp, &go);
@@ -679,10 +687,10 @@ int main(int argc, char **argv) {
   ngsld_pos *pos = nullptr;
   if (pars.in_pos) {
     if (early.pos_done) {
-      if (early.pos_rc != NGSLD_OK) error("read_dist", early.pos_err);
+      if (early.pos_rc != NGSLD_OK) error(pos_error_function(early.pos_err), early.pos_err);
       pos = early.pos;
     } else if (ngsld_host_read_pos(pars.in_pos, pars.in_pos_header ? 1 : 0, pars.n_sites, &pos, err, sizeof(err)) != NGSLD_OK)
-      error("read_dist", err);
+      error(pos_error_function(err), err);
     if (pars.verbose >= 6)
       for (uint64_t s = 0; s < (pars.n_sites < 10 ? pars.n_sites : 10); s++)
         fprintf(stderr, "%lu\t%f\n", (unsigned long)s, ngsld_host_pos_dist(pos)[s]);

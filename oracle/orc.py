@@ -36,8 +36,9 @@ PAIR_DTYPE = np.dtype([
 
 
 def build(force: bool = False) -> None:
+    srcs = [os.path.join(HERE, f) for f in ("ngsld_oracle.c", "ngsld_oracle.h", "ngsld_oracle_main.c")]
     if force or not (os.path.exists(LIBORC) and os.path.exists(ORC_CLI)) or \
-            os.path.getmtime(LIBORC) < os.path.getmtime(os.path.join(HERE, "ngsld_oracle.c")):
+            min(os.path.getmtime(LIBORC), os.path.getmtime(ORC_CLI)) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", HERE, "all"])
 
 

@@ -243,6 +243,84 @@ def main():
             results.append({"case": name, "reference": what, "same": verdict is None, "difference": verdict})
             bad += verdict is not None
             print(f"{'same     ' if verdict is None else 'DIFFERENT'}  {name}: {what}" + ("" if verdict is None else f"\n           {verdict}"), flush=True)
+    # no --out: the table goes to standard output (parse_args.cpp:26), with every thread count the same rows
+    import util
+    for threads in (1, 3):
+        with tempfile.TemporaryDirectory() as d:
+            raw = synth.make_gl_numpy(9, 30, 77, depth=3.0)
+            chrs, pos = synth.make_positions(9, 77, max_gap=300, n_chr=2)
+            g, p = os.path.join(d, "in.glf"), os.path.join(d, "in.pos")
+            raw.tofile(g)
+            synth.write_pos(p, chrs, pos)
+            flags = ["--geno", g, "--n_ind", "30", "--n_sites", "9", "--pos", p, "--verbose", "0", "--max_kb_dist", "0", "--extend_out",
+                     "--n_threads", str(threads)]
+            rec = orc.Oracle(raw, shard.pos_dist_from_positions(chrs, pos), n_threads=2).run()
+            first = np.zeros(10, dtype=np.uint64)
+            np.add.at(first, rec["s1"].astype(np.int64) + 1, 1)
+            tab = os.path.join(d, "r2_table.npz")
+            np.savez(tab, first=np.cumsum(first).astype(np.uint64), s2=rec["s2"].astype(np.uint64), val=rec["r2pear"].astype(np.float64))
+            r = subprocess.run([sys.executable, "-c", util._REF_CHILD, tab, *flags], capture_output=True, text=True, timeout=600)
+            h = subprocess.run([binary, *flags], capture_output=True, text=True, timeout=600)
+            verdict = None
+            if r.returncode != 0 or h.returncode != 0:
+                verdict = f"exit status {h.returncode} against the reference program's {r.returncode}: {h.stderr[-300:]}"
+            else:
+                verdict = same_tsv(h.stdout, r.stdout)
+            name = f"no --out: the table on standard output, --n_threads {threads}"
+            what = f"table of {max(0, len(r.stdout.splitlines()) - 1)} rows"
+            results.append({"case": name, "reference": what, "same": verdict is None, "difference": verdict})
+            bad += verdict is not None
+            print(f"{'same     ' if verdict is None else 'DIFFERENT'}  {name}: {what}" + ("" if verdict is None else f"\n           {verdict}"), flush=True)
+    # files: compressed inputs, and the ones that are not there or cannot be written
+    import gzip as _gz
+    for name, mode in (("binary genotype file gzipped", "geno_gz"), ("positions file gzipped", "pos_gz"), ("genotype file that does not exist", "no_geno"),
+                       ("positions file that does not exist", "no_pos"), ("positions file with a row of three fields among rows of two", "pos_fields"),
+                       ("output path that cannot be written", "bad_out")):
+        with tempfile.TemporaryDirectory() as d:
+            raw = synth.make_gl_numpy(8, 12, 78, depth=3.0)
+            chrs, pos = synth.make_positions(8, 78, max_gap=300)
+            g, p = os.path.join(d, "in.glf"), os.path.join(d, "in.pos")
+            raw.tofile(g)
+            synth.write_pos(p, chrs, pos)
+            if mode == "geno_gz":
+                with open(g, "rb") as fi, _gz.open(g + ".gz", "wb") as fo:
+                    fo.write(fi.read())
+                g += ".gz"
+            if mode == "pos_gz":
+                with open(p, "rb") as fi, _gz.open(p + ".gz", "wb") as fo:
+                    fo.write(fi.read())
+                p += ".gz"
+            if mode == "pos_fields":
+                lines = open(p).read().splitlines()
+                lines[4] += "\textra"
+                open(p, "w").write("\n".join(lines) + "\n")
+            if mode == "no_geno":
+                g = os.path.join(d, "nothing.glf")
+            if mode == "no_pos":
+                p = os.path.join(d, "nothing.pos")
+            flags = ["--geno", g, "--n_ind", "12", "--n_sites", "8", "--pos", p, "--verbose", "0", "--max_kb_dist", "0", "--extend_out"]
+            rec = orc.Oracle(raw, shard.pos_dist_from_positions(chrs, pos), n_threads=2).run()
+            out_ref, out_hip = os.path.join(d, "ref.tsv"), os.path.join(d, "hip.tsv")
+            if mode == "bad_out":
+                out_ref = out_hip = os.path.join(d, "no_such_directory", "out.tsv")
+            r = run_ref_program(rec, 8, flags, out_ref, d, threads=2)
+            h = subprocess.run([binary, *flags, "--n_threads", "2", "--out", out_hip], capture_output=True, text=True, timeout=600)
+            verdict = None
+            if r.returncode == 0:
+                if h.returncode != 0:
+                    verdict = f"reference program wrote a table, the binary ended with {h.returncode}: {h.stderr[-300:]}"
+                else:
+                    verdict = same_tsv(open(out_hip).read(), open(out_ref).read())
+                what = f"table of {max(0, len(open(out_ref).read().splitlines()) - 1)} rows"
+            else:
+                if h.returncode == 0:
+                    verdict = f"reference program ended with {r.returncode} ({error_line(r.stderr)}), the binary wrote a table"
+                elif error_line(r.stderr) != error_line(h.stderr):
+                    verdict = f"error lines differ: ref {error_line(r.stderr)!r} hip {error_line(h.stderr)!r}"
+                what = f"error: {error_line(r.stderr)}"
+            results.append({"case": name, "reference": what, "same": verdict is None, "difference": verdict})
+            bad += verdict is not None
+            print(f"{'same     ' if verdict is None else 'DIFFERENT'}  {name}: {what}" + ("" if verdict is None else f"\n           {verdict}"), flush=True)
     print(f"edge cases: {len(results)} through both programs, {bad} differ")
     if "--json" in sys.argv:
         with open(sys.argv[sys.argv.index("--json") + 1], "w") as fh:
