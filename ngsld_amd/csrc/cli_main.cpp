@@ -85,9 +85,10 @@ std::vector<int> parse_devices(const char *txt) {
 }
 
 // The function the reference names in front of an error of its positions reader: the file is opened by read_file
-// (gen_func.cpp:244-246), its fields are counted by read_split (read_data.cpp:145-146), everything else is read_dist's own.
-const char *pos_error_function(const char *msg) {
-  if (std::strcmp(msg, "cannot open file!") == 0) return "read_file";
+// (gen_func.cpp:244-246), its fields are counted by read_split (read_data.cpp:134-147), everything else is read_dist's own.
+const char *pos_error_function(const char *msg, const char *path) {
+  // (a file that opens but holds no usable line is "cannot open file!" too -- from read_split, read_data.cpp:134-136)
+  if (std::strcmp(msg, "cannot open file!") == 0) return path != nullptr && access(path, R_OK) == 0 ? "read_split" : "read_file";
   if (std::strcmp(msg, "invalid number of fields in file!") == 0) return "read_split";
   return "read_dist";
 }
@@ -310,7 +311,7 @@ bool run_streamed(Params &pars, uint64_t slab_sites, bool may_fall_back) {
   if (pars.verbose >= 1) fprintf(stderr, "==> Getting sites coordinates\n");
   if (pars.in_pos &&
       ngsld_host_read_pos(pars.in_pos, pars.in_pos_header ? 1 : 0, pars.n_sites, &pos, err, sizeof(err)) != NGSLD_OK)
-    error(pos_error_function(err), err);
+    error(pos_error_function(err, pars.in_pos), err);
   ngsld_params lp;
   ngsld_geno_opts go;
   fill_run_params(pars, &lp, &go);
@@ -390,7 +391,7 @@ void run_multi(Params &pars, const double *raw, int text_semantics, int log_scal
   if (pars.verbose >= 1) fprintf(stderr, "==> Getting sites coordinates\n");
   if (pars.in_pos &&
       ngsld_host_read_pos(pars.in_pos, pars.in_pos_header ? 1 : 0, pars.n_sites, &pos, err, sizeof(err)) != NGSLD_OK)
-    error(pos_error_function(err), err);
+    error(pos_error_function(err, pars.in_pos), err);
   ngsld_params lp;
   ngsld_geno_opts go;
   fill_run_params(pars, &lp, &go);
@@ -687,10 +688,10 @@ int main(int argc, char **argv) {
   ngsld_pos *pos = nullptr;
   if (pars.in_pos) {
     if (early.pos_done) {
-      if (early.pos_rc != NGSLD_OK) error(pos_error_function(early.pos_err), early.pos_err);
+      if (early.pos_rc != NGSLD_OK) error(pos_error_function(early.pos_err, pars.in_pos), early.pos_err);
       pos = early.pos;
     } else if (ngsld_host_read_pos(pars.in_pos, pars.in_pos_header ? 1 : 0, pars.n_sites, &pos, err, sizeof(err)) != NGSLD_OK)
-      error(pos_error_function(err), err);
+      error(pos_error_function(err, pars.in_pos), err);
     if (pars.verbose >= 6)
       for (uint64_t s = 0; s < (pars.n_sites < 10 ? pars.n_sites : 10); s++)
         fprintf(stderr, "%lu\t%f\n", (unsigned long)s, ngsld_host_pos_dist(pos)[s]);

@@ -225,8 +225,10 @@ int ngsld_host_read_pos(const char *path, int header, uint64_t n_sites, ngsld_po
     }
     b = e + 1;
   }
-  if (lines.size() != n_sites) return set_err(err, errlen, "wrong number of lines in POS file!");
-
+  // In the reference's order: a file without a usable line leaves read_file's array NULL, which read_split reports as a file
+  // it could not open (read_data.cpp:134-136); read_split then counts the fields of every line it got (:139-147); only then
+  // does read_dist compare the number of lines (:178-181).
+  if (lines.empty()) return set_err(err, errlen, "cannot open file!");
   // every line must have the same number of TAB-separated fields, at least 2 (read_data.cpp:139-147,180-181)
   size_t n_fields = 0;
   for (const auto &l : lines) {
@@ -235,6 +237,7 @@ int ngsld_host_read_pos(const char *path, int header, uint64_t n_sites, ngsld_po
     if (n_fields == 0) n_fields = nf;
     if (nf != n_fields) return set_err(err, errlen, "invalid number of fields in file!");
   }
+  if (lines.size() != n_sites) return set_err(err, errlen, "wrong number of lines in POS file!");
   if (n_fields < 2) return set_err(err, errlen, "wrong POS file format!");
 
   ngsld_pos *p = new ngsld_pos();

@@ -489,18 +489,22 @@ int orc_read_pos(orc_params *p, char *errbuf, size_t errlen) {
     return -1;
   }
   int rc = 0;
-  if (n_rows != p->n_sites) {
-    snprintf(errbuf, errlen, "wrong number of lines in POS file!");
-    rc = -2;
+  if (n_rows == 0) { /* read_file leaves its array NULL; read_split takes that for a file it could not open (read_data.cpp:134-136) */
+    snprintf(errbuf, errlen, "cannot open file!");
+    return -1;
   }
   uint64_t n_fields = 0;
-  for (uint64_t i = 0; rc == 0 && i < n_rows; i++) {
+  for (uint64_t i = 0; rc == 0 && i < n_rows; i++) { /* read_split, all of the lines, before read_dist counts them (read_data.cpp:139-147) */
     uint64_t nf = count_tab_fields(lines[i]);
     if (n_fields == 0) n_fields = nf;
     if (nf != n_fields) {
       snprintf(errbuf, errlen, "invalid number of fields in file!");
       rc = -3;
     }
+  }
+  if (rc == 0 && n_rows != p->n_sites) { /* read_data.cpp:178-179 */
+    snprintf(errbuf, errlen, "wrong number of lines in POS file!");
+    rc = -2;
   }
   if (rc == 0 && n_fields < 2) {
     snprintf(errbuf, errlen, "wrong POS file format!");

@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <sys/stat.h>
 
 #include "ngsld_oracle.h"
@@ -128,7 +129,7 @@ int main(int argc, char **argv) {
   orc_preprocess(&P);
   if (P.in_pos) {
     if (orc_read_pos(&P, err, sizeof(err))) /* the reference's __FUNCTION__: read_file opens (gen_func.cpp:244-246), read_split counts fields (read_data.cpp:145-146) */
-      die(!strcmp(err, "cannot open file!") ? "read_file" : !strcmp(err, "invalid number of fields in file!") ? "read_split" : "read_dist", err);
+      die(!strcmp(err, "cannot open file!") ? (access(P.in_pos, R_OK) == 0 ? "read_split" : "read_file") : !strcmp(err, "invalid number of fields in file!") ? "read_split" : "read_dist", err);
   } else {
     P.pos_dist = (double *)malloc(P.n_sites * sizeof(double));
     for (uint64_t s = 0; s < P.n_sites; s++) P.pos_dist[s] = INFINITY; /* ngsLD.cpp:134 */

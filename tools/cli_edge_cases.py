@@ -275,6 +275,10 @@ def main():
     import gzip as _gz
     for name, mode in (("binary genotype file gzipped", "geno_gz"), ("positions file gzipped", "pos_gz"), ("genotype file that does not exist", "no_geno"),
                        ("positions file that does not exist", "no_pos"), ("positions file with a row of three fields among rows of two", "pos_fields"),
+                       ("positions file with comment lines and blank lines", "pos_comments"), ("positions file with CRLF line ends", "pos_crlf"),
+                       ("positions file without a usable line", "pos_empty"), ("positions file with one line too many AND a row of three fields", "pos_fields_and_count"),
+                       ("positions written with leading zeros (strtoul reads them as octal, read_data.cpp:211)", "pos_octal"),
+                       ("positions in scientific notation (strtod and strtoul disagree, read_data.cpp:204,211)", "pos_sci"),
                        ("output path that cannot be written", "bad_out")):
         with tempfile.TemporaryDirectory() as d:
             raw = synth.make_gl_numpy(8, 12, 78, depth=3.0)
@@ -294,6 +298,22 @@ def main():
                 lines = open(p).read().splitlines()
                 lines[4] += "\textra"
                 open(p, "w").write("\n".join(lines) + "\n")
+            if mode == "pos_comments":
+                lines = open(p).read().splitlines()
+                open(p, "w").write("# positions\n" + "\n".join(lines[:3]) + "\n\n#another\n" + "\n".join(lines[3:]) + "\n\n")
+            if mode == "pos_crlf":
+                crlf = open(p).read().replace("\n", "\r\n")
+                open(p, "w", newline="").write(crlf)
+            if mode == "pos_empty":
+                open(p, "w").write("# nothing but a comment\n\n")
+            if mode == "pos_fields_and_count":
+                lines = open(p).read().splitlines()
+                lines[6] += "\textra"
+                open(p, "w").write("\n".join(lines + ["chr1\t999999"]) + "\n")
+            if mode == "pos_octal":
+                open(p, "w").write("".join(f"chr1\t0{10 * (k + 1)}\n" for k in range(8)))
+            if mode == "pos_sci":
+                open(p, "w").write("".join(f"chr1\t{k + 1}e2\n" for k in range(8)))
             if mode == "no_geno":
                 g = os.path.join(d, "nothing.glf")
             if mode == "no_pos":
