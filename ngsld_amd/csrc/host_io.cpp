@@ -458,48 +458,88 @@ int ngsld_host_read_geno_text(const char *path, int in_probs, int log_scale, uin
     return nullptr;
   };
 
-  // line index: (begin, length) after chomp; an empty line is an error (see the header of this file's section)
+  // line index: (begin, length) after chomp (gen_func.cpp:190-197); length 0 = an empty line
   std::vector<std::pair<size_t, size_t>> lines;
   for (size_t b = 0; b < text.size();) {
     size_t e = text.find('\n', b);
     if (e == std::string::npos) e = text.size();
     size_t len = e - b;
     if (e == text.size() && len > 0 && text[b + len - 1] == '\r') --len;
-    if (len == 0) return set_err(err, errlen, "empty line in GENO file");
     lines.emplace_back(b, len);
     b = e + 1;
   }
-  // header lines at the top: no numeric field at all, or (first line only) fewer than needed (read_data.cpp:64-72)
+
+  // The reference reads line by line (read_data.cpp:46-104): while no site has been stored yet, a line with fewer numeric fields
+  // than a row needs is a header and is skipped (:64); a line without ANY numeric field is skipped wherever it stands; an empty
+  // line takes a site's place without filling it (:58-59); a row's own errors come up when the row is read, the two end-of-file
+  // checks after all of that.  Well-formed files -- headers at the top, then rows -- go through the parallel pass below with
+  // exactly that outcome; anything else (an empty line, a line without numbers among the rows) is walked in the reference's order.
+  auto sequential = [&]() -> int {
+    std::vector<double> v;
+    size_t li = 0;
+    bool empty_seen = false;
+    for (uint64_t s = 0; s < n_sites;) {
+      if (li >= lines.size()) return set_err(err, errlen, "GENO file at premature EOF. Check GENO file and number of sites!");
+      const auto ln = lines[li++];
+      if (ln.second == 0) {  // (the reference leaves this site's values uninitialised and goes on)
+        empty_seen = true;
+        ++s;
+        continue;
+      }
+      numeric_fields(ln.first, ln.second, v);
+      if (v.empty() || (s == 0 && v.size() < need)) continue;  // "> Header found! Skipping line..."
+      if (const char *e = fill_site(v, s)) return set_err(err, errlen, e);
+      ++s;
+    }
+    if (li < lines.size()) return set_err(err, errlen, "GENO file not at EOF. Check GENO file and number of sites!");
+    // the one place this reader parts with the reference: a site that an empty line left without values is an error here
+    if (empty_seen) return set_err(err, errlen, "empty line in GENO file");
+    return NGSLD_OK;
+  };
+
+  // header lines at the top (read_data.cpp:64-72, s == 0 throughout)
   size_t first = 0;
   std::vector<double> vals;
-  while (first < lines.size()) {
+  while (first < lines.size() && lines[first].second > 0) {
     numeric_fields(lines[first].first, lines[first].second, vals);
-    if (vals.empty() || (first == 0 && vals.size() < need)) ++first; else break;
+    if (vals.empty() || vals.size() < need) ++first; else break;
   }
-  if (lines.size() - first < n_sites)
-    return set_err(err, errlen, "GENO file at premature EOF. Check GENO file and number of sites!");
-  if (lines.size() - first > n_sites)
-    return set_err(err, errlen, "GENO file not at EOF. Check GENO file and number of sites!");
+  if (first < lines.size() && lines[first].second == 0) return sequential();
+  const uint64_t avail = lines.size() - first;
+  const uint64_t n_parse = std::min<uint64_t>(n_sites, avail);
 
-  const int nt = (int)std::min<uint64_t>((uint64_t)g_host_threads.load(), n_sites ? n_sites : 1);
+  const int nt = (int)std::min<uint64_t>((uint64_t)g_host_threads.load(), n_parse ? n_parse : 1);
   std::vector<const char *> errors(nt, nullptr);
+  std::vector<uint64_t> error_at(nt, ~0ull);
+  std::atomic<bool> irregular{false};
   auto work = [&](int t) {
     std::vector<double> v;
-    for (uint64_t s = (uint64_t)t; s < n_sites && errors[t] == nullptr; s += (uint64_t)nt) {
-      numeric_fields(lines[first + s].first, lines[first + s].second, v);
-      if (v.empty()) {  // a line without numbers further down is skipped as a header by the reference (:64)
-        errors[t] = "wrong GENO file format. Less fields than expected!";
+    for (uint64_t s = (uint64_t)t; s < n_parse && errors[t] == nullptr && !irregular.load(std::memory_order_relaxed); s += (uint64_t)nt) {
+      const auto ln = lines[first + s];
+      if (ln.second == 0) {
+        irregular.store(true);
+        break;
+      }
+      numeric_fields(ln.first, ln.second, v);
+      if (v.empty()) {  // a line without numbers among the rows: the reference skips it as a header (:64)
+        irregular.store(true);
         break;
       }
       errors[t] = fill_site(v, s);
+      if (errors[t]) error_at[t] = s;
     }
   };
   std::vector<std::thread> th;
   for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
   work(0);
   for (auto &x : th) x.join();
+  if (irregular.load()) return sequential();
+  int worst = -1;  // the reference meets the errors in row order
   for (int t = 0; t < nt; ++t)
-    if (errors[t]) return set_err(err, errlen, errors[t]);
+    if (errors[t] && (worst < 0 || error_at[t] < error_at[worst])) worst = t;
+  if (worst >= 0) return set_err(err, errlen, errors[worst]);
+  if (avail < n_sites) return set_err(err, errlen, "GENO file at premature EOF. Check GENO file and number of sites!");
+  if (avail > n_sites) return set_err(err, errlen, "GENO file not at EOF. Check GENO file and number of sites!");
   return NGSLD_OK;
 } NGSLD_HOST_CATCH
 

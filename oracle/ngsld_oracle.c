@@ -320,7 +320,7 @@ int orc_read_geno_text(const char *path, int in_probs, int log_scale, uint64_t n
   char *line = (char *)malloc(lcap);
   double *t = NULL;
   uint64_t tcap = 0;
-  int rc = 0;
+  int rc = 0, empty_seen = 0;
   for (uint64_t s = 0; s < n_sites && rc == 0; s++) {
     llen = 0;
     for (;;) { /* one line of any length */
@@ -338,10 +338,9 @@ int orc_read_geno_text(const char *path, int in_probs, int log_scale, uint64_t n
       break;
     }
     if (line[llen - 1] == '\n' || line[llen - 1] == '\r') line[--llen] = '\0'; /* chomp */
-    if (llen == 0) {
-      snprintf(errbuf, errlen, "empty line in GENO file");
-      rc = -5;
-      break;
+    if (llen == 0) { /* :58-59 -- the for loop's s++ runs: the empty line takes this site's place and leaves it unfilled */
+      empty_seen = 1;
+      continue;
     }
     uint64_t n_fields = split_doubles(line, &t, &tcap);
     if (!n_fields || (s == 0 && n_fields < n_ind * n_geno)) { /* header, :64-72 */
@@ -382,6 +381,10 @@ int orc_read_geno_text(const char *path, int in_probs, int log_scale, uint64_t n
       snprintf(errbuf, errlen, "GENO file not at EOF. Check GENO file and number of sites!");
       rc = -4;
     }
+  }
+  if (rc == 0 && empty_seen) { /* where this restatement stops following: the reference goes on with that site uninitialised */
+    snprintf(errbuf, errlen, "empty line in GENO file");
+    rc = -5;
   }
   gzclose(fh);
   free(line);

@@ -200,9 +200,9 @@ def test_edge_cases_through_both_programs():
     """tools/cli_edge_cases.py: what lies below and beside the fuzz generator's cases (one / two sites, one / two individuals,
     nothing but monomorphic sites or missing data, empty windows, a chromosome per site, thresholds that drop everything, files
     shorter or longer than --n_sites, positions that repeat or go backwards) -- the binary writes the reference program's table
-    or ends with the reference program's error line (90 runs, twelve over compressed / absent / unwritable files and positions files with comments, CRLF, octal-looking or scientific numbers, no usable line, uneven fields, two with the table on standard output, 20 of them text genotype files: headers, blank lines, CRLF, label columns, fractions, words, too few / too many rows)."""
+    or ends with the reference program's error line (94 runs, twelve over compressed / absent / unwritable files and positions files with comments, CRLF, octal-looking or scientific numbers, no usable line, uneven fields, two with the table on standard output, 20 of them text genotype files: headers, blank lines, CRLF, label columns, fractions, words, too few / too many rows)."""
     import sys
     r = subprocess.run([sys.executable, os.path.join(capi.REPO_DIR, "tools", "cli_edge_cases.py")], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert "90 through both programs, 0 differ" in r.stdout
+    assert "94 through both programs, 0 differ" in r.stdout

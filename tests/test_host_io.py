@@ -324,3 +324,73 @@ def test_readers_survive_mutated_input(tmp_path):
             outcomes["error"] += 1
     assert outcomes["ok"] + outcomes["error"] == 400 and outcomes["error"] > 0
     print("mutated inputs:", outcomes)
+
+
+# ---- text genotype files that are not "headers, then rows": three readers, one outcome --------------------------------
+_REF_TEXT_CHILD = r"""
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, %r)
+from oracle import orc
+R = orc.ref()
+path, in_probs, n_ind, n_sites, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+gl = np.full((n_sites, n_ind, 3), np.nan)
+R.ref_read_geno_text(path.encode(), in_probs, 0, n_ind, n_sites, orc.dp(gl))    # (an error ends the process through error())
+np.save(out, gl)
+""" % capi.REPO_DIR
+
+_ROWS = ["0\t1\t2", "1\t1\t0", "2\t0\t1", "-1\t2\t2", "0\t0\t1"]
+IRREGULAR = [  # (what, file text, n_sites)
+    ("a header line repeated among the rows", "\n".join(_ROWS[:2] + ["marker\ta\tb"] + _ROWS[2:]) + "\n", 5),
+    ("two header lines at the top, the second with a few numbers", "id\tx\ty\n1\tb\tc\n" + "\n".join(_ROWS) + "\n", 5),
+    ("a line of words as the very last line", "\n".join(_ROWS + ["end\tof\tfile"]) + "\n", 5),
+    ("a genotype of 3 in row 2 AND a row too many", "\n".join([_ROWS[0], "0\t3\t1"] + _ROWS[1:] + ["1\t1\t1"]) + "\n", 5),
+    ("a genotype of 3 in row 4 AND a row too few", "\n".join(_ROWS[:3] + ["0\t3\t1"]) + "\n", 5),
+    ("a short row AND a row too many", "\n".join(_ROWS[:2] + ["1\t1"] + _ROWS[2:] + ["1\t1\t1"]) + "\n", 5),
+    ("every row short (n_ind given too large)", "\n".join("\t".join(r.split("\t")[:2]) for r in _ROWS) + "\n", 5),
+    ("an empty line after the rows", "\n".join(_ROWS) + "\n\n", 5),
+    ("an empty line among the rows and as many rows as sites", "\n".join(_ROWS[:2] + [""] + _ROWS[2:]) + "\n", 5),
+    ("a header line among the rows and a row too few", "\n".join(_ROWS[:2] + ["marker\ta\tb"] + _ROWS[2:4]) + "\n", 5),
+    ("rows, then a header line, then surplus rows", "\n".join(_ROWS + ["marker\ta\tb", "1\t1\t1"]) + "\n", 5),
+]
+
+
+@pytest.mark.parametrize("what,text,n_sites", IRREGULAR, ids=[c[0] for c in IRREGULAR])
+def test_irregular_text_genotype_files_read_like_the_reference(what, text, n_sites, tmp_path):
+    """The reference's reader takes a text file line by line (read_data.cpp:46-109): headers are whatever has too few numbers while
+    no site is stored, a line without any number is skipped WHEREVER it stands, a row's own errors come up in row order, the
+    end-of-file checks last.  The product's reader (parallel pass for well-formed files, the reference's walk for the rest) and
+    the oracle's must give the reference's values, or fail where it fails with its message."""
+    import ctypes as C
+    import subprocess
+    import sys
+    from oracle import orc
+    if orc.ref() is None:
+        pytest.skip("oracle/_ref not built")
+    p = tmp_path / "in.geno"
+    p.write_text(text)
+    out = str(tmp_path / "ref.npy")
+    r = subprocess.run([sys.executable, "-c", _REF_TEXT_CHILD, str(p), "0", "3", str(n_sites), out], capture_output=True, text=True,
+                       timeout=120)
+    gl_orc = np.empty((n_sites, 3, 3))
+    err = C.create_string_buffer(256)
+    rc_orc = orc.lib().orc_read_geno_text(str(p).encode(), 0, 0, 3, n_sites, orc.dp(gl_orc), err, 256)
+    try:
+        raw, is_log = capi.read_geno_text(str(p), False, False, 3, n_sites)
+        msg_hip = None
+    except capi.NgsldError as e:
+        raw, msg_hip = None, e.msg
+    if r.returncode == 0:
+        want = np.load(out)
+        assert rc_orc == 0 and np.array_equal(gl_orc, want), (what, err.value)
+        assert raw is not None, (what, msg_hip)
+        got = raw.copy()
+        for t in got.reshape(-1, 3):
+            orc.lib().orc_post_prob(orc.dp(t), orc.dp(t.copy()), 3)   # (text reader output is log scale: is_log)
+        assert is_log and np.array_equal(got, want), what
+    else:
+        ref_msg = next((ln for ln in r.stderr.splitlines() if "ERROR" in ln), "")
+        assert rc_orc != 0 and raw is None, (what, ref_msg, rc_orc, msg_hip)
+        assert err.value.decode() == msg_hip, (what, err.value, msg_hip)
+        if "empty line" not in msg_hip:   # (DESIGN section 8: the one outcome of its own -- the reference goes on with the site unfilled)
+            assert msg_hip in ref_msg, (what, ref_msg, msg_hip)

@@ -100,8 +100,8 @@ def test_patched_reference_main_fails_loudly_without_a_device(tmp_path):
 def test_edge_cases_through_the_reference_program_and_the_oracle_cli():
     """tools/cli_edge_cases.py with the oracle's CLI in the binary's place: one / two sites, one / two individuals, nothing but
     monomorphic sites or missing data, empty windows, a chromosome per site, thresholds that drop everything, files shorter or
-    longer than --n_sites, positions that repeat or go backwards -- same table, or the same error line (90 runs, twelve over compressed / absent / unwritable files and positions files with comments, CRLF, octal-looking or scientific numbers, no usable line, uneven fields, two with the table on standard output, 20 of them text genotype files: headers, blank lines, CRLF, label columns, fractions, words, too few / too many rows)."""
+    longer than --n_sites, positions that repeat or go backwards -- same table, or the same error line (94 runs, twelve over compressed / absent / unwritable files and positions files with comments, CRLF, octal-looking or scientific numbers, no usable line, uneven fields, two with the table on standard output, 20 of them text genotype files: headers, blank lines, CRLF, label columns, fractions, words, too few / too many rows)."""
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(orc.HERE), "tools", "cli_edge_cases.py"), "--binary", orc.ORC_CLI],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert "90 through both programs, 0 differ" in r.stdout
+    assert "94 through both programs, 0 differ" in r.stdout

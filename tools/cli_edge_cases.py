@@ -126,6 +126,10 @@ def text_cases():
     out.append(("text: a word among the genotypes", body.replace("1", "NA", 1), True, 9, 7, False, []))
     out.append(("text: a later row with fewer fields", "\n".join(rows[:4]) + "\n" + "\t".join(rows[4].split("\t")[:5]) + "\n" + "\n".join(rows[5:]) + "\n",
                 True, 9, 7, False, []))
+    out.append(("text: the header line repeated among the rows", "\n".join(rows[:3]) + "\nmarker\tref\talt\n" + "\n".join(rows[3:]) + "\n", True, 9, 7, False, []))
+    out.append(("text: two header lines at the top, the second with a few numbers", "marker\tref\talt\n1\t2\tx\n" + body, True, 9, 7, False, []))
+    out.append(("text: a genotype of 3 in an early row AND a row too many", body.replace("2", "3", 1) + rows[0] + "\n", True, 9, 7, False, []))
+    out.append(("text: an empty line in a row's place (as many lines as sites)", "\n".join(rows[:3]) + "\n\n" + "\n".join(rows[4:]) + "\n", True, 9, 7, False, []))
     out.append(("text: more rows than --n_sites", body, True, 9, 5, False, []))
     out.append(("text: fewer rows than --n_sites", body, True, 9, 9, False, []))
     out.append(("text: empty file", "", True, 9, 7, False, []))
@@ -226,7 +230,9 @@ def main():
             h = subprocess.run([binary, *flags, "--n_threads", "2", "--out", out_hip], capture_output=True, text=True, timeout=600)
             verdict = None
             if r.returncode == 0:
-                if h.returncode != 0:
+                if h.returncode != 0 and "empty line" in name and "empty line in GENO file" in error_line(h.stderr):
+                    pass  # the reference goes on with the site an empty line left uninitialised (read_data.cpp:58-59)
+                elif h.returncode != 0:
                     verdict = f"reference program wrote a table, the binary ended with {h.returncode}: {h.stderr[-300:]}"
                 else:
                     verdict = same_tsv(open(out_hip).read(), open(out_ref).read())
@@ -235,9 +241,9 @@ def main():
                 if h.returncode == 0:
                     verdict = f"reference program ended with {r.returncode} ({error_line(r.stderr)}), the binary wrote a table"
                 elif error_line(r.stderr) != error_line(h.stderr) and not (
-                        "blank lines" in name and "empty line in GENO file" in error_line(h.stderr)):
-                    # (an empty line inside a text genotype file is an error of its own here -- the reference
-                    # counts it as a site it leaves uninitialised, read_data.cpp:58-59, and then trips over the surplus rows)
+                        "empty line" in name and "empty line in GENO file" in error_line(h.stderr)):
+                    # (an empty line that takes a site's place is an error here -- the reference leaves that
+                    # site uninitialised, read_data.cpp:58-59, and goes on)
                     verdict = f"error lines differ: ref {error_line(r.stderr)!r} hip {error_line(h.stderr)!r}"
                 what = f"error: {error_line(r.stderr)}"
             results.append({"case": name, "reference": what, "same": verdict is None, "difference": verdict})
