@@ -243,7 +243,6 @@ int ngsld_host_read_pos(const char *path, int header, uint64_t n_sites, ngsld_po
   ngsld_pos *p = new ngsld_pos();
   p->pos_dist.resize(n_sites);
   std::string prev_chr;
-  bool have_chr = false;
   unsigned long prev_pos = 0;
   for (uint64_t s = 0; s < n_sites; ++s) {
     const std::string &l = lines[s];
@@ -256,10 +255,7 @@ int ngsld_host_read_pos(const char *path, int header, uint64_t n_sites, ngsld_po
       delete p;
       return set_err(err, errlen, "header line found in POS file; use --posH for files with a header");
     }
-    if (!have_chr) {
-      prev_chr = chr;
-      have_chr = true;
-    }
+    if (prev_chr.empty()) prev_chr = chr;  // read_data.cpp:199-200: "first chromosome" is whenever the stored name is empty -- also after a line with an empty first field
     if (chr == prev_chr) {
       p->pos_dist[s] = posd - (double)prev_pos;  // read_data.cpp:204
       if (p->pos_dist[s] < 1) {

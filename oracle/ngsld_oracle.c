@@ -542,6 +542,11 @@ int orc_read_pos(orc_params *p, char *errbuf, size_t errlen) {
       rc = -5;
       break;
     }
+    /* read_data.cpp:199-200: an EMPTY stored name (none yet, or a line whose first field was empty) takes this line's */
+    if (prev_chr != NULL && prev_chr[0] == '\0') {
+      free(prev_chr);
+      prev_chr = NULL;
+    }
     int same = prev_chr == NULL || (strlen(prev_chr) == chr_len && strncmp(prev_chr, line, chr_len) == 0);
     if (prev_chr == NULL) prev_chr = strndup(line, chr_len);
     if (same) {
