@@ -208,3 +208,45 @@ def test_window_walk_equals_the_reference_loop(max_kb, max_snp, min_maf, n_chr):
         assert np.array_equal(s2buf[:n], mine["s2"]) and np.array_equal(_bits(dbuf[:n].copy()), _bits(mine["dist"].copy()))
         total += n
     assert total == len(rec) > 0
+
+
+def test_binary_reader_on_values_at_the_edges_of_the_double_range():
+    """Zeros, denormals, 1e300, negative numbers, -0.0, exact thirds ... in natural and log scale: the oracle's binary reader
+    (normalisation, the NaN check) gives the reference reader's values or fails where it fails (read_data.cpp:28-47,106-116).
+    The reference runs in a forked child: its error() ends the process."""
+    rng = np.random.default_rng(5)
+    special = np.array([0.0, 1.0, 1 / 3, 0.5, 1e-310, 5e-324, 1e-300, 1e300, 1.7e308, -1.0, -0.0, 1e-17, 1 - 1e-16, 2.0, 3.0])
+    failed = 0
+    with tempfile.TemporaryDirectory() as d:
+        path, shared = os.path.join(d, "b.glf"), os.path.join(d, "ref.npy")
+        for trial in range(200):
+            n_sites, n_ind = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+            log_scale = bool(trial % 2)
+            raw = rng.choice(special, size=(n_sites, n_ind, 3))
+            m = rng.random((n_sites, n_ind)) < 0.3
+            raw[m] = rng.dirichlet([1, 1, 1], size=int(m.sum()))
+            if log_scale:
+                with np.errstate(all="ignore"):
+                    raw = np.log(np.abs(raw))
+                if trial % 4 == 1:
+                    raw[rng.random(raw.shape) < 0.1] = rng.choice([1.0, 700.0, -1e15, -745.0, 0.0])
+            raw.tofile(path)
+            pid = os.fork()
+            if pid == 0:
+                os.dup2(os.open(os.devnull, os.O_WRONLY), 2)
+                out = np.empty_like(raw)
+                ref.ref_read_geno_bin(path.encode(), int(log_scale), n_ind, n_sites, orc.dp(out))
+                np.save(shared, out)
+                os._exit(0)
+            _, st = os.waitpid(pid, 0)
+            ok_ref = os.WIFEXITED(st) and os.WEXITSTATUS(st) == 0
+            gl = np.empty_like(raw)
+            err = C.create_string_buffer(256)
+            rc = orc.lib().orc_read_geno_bin(path.encode(), int(log_scale), n_ind, n_sites, orc.dp(gl), err, 256)
+            assert ok_ref == (rc == 0), (trial, ok_ref, rc, err.value)
+            if ok_ref:
+                assert np.array_equal(np.load(shared), gl, equal_nan=True), trial
+            else:
+                failed += 1
+                assert b"NaN found" in err.value
+    assert 20 < failed < 180   # (both outcomes are exercised)
