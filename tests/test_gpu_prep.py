@@ -109,3 +109,16 @@ def test_nan_input_is_reported_on_both_paths():
                 eng.close()
         finally:
             os.environ.pop("NGSLD_PREP_EXACT", None)
+
+
+def test_values_at_the_edges_of_the_double_range_end_like_the_reference_reader():
+    """tools/probe_special_values.py: zeros, denormals, 1e300, negative numbers, -0.0 in both scales through ngsld_set_geno_raw --
+    the device's prep fails with the reader's "NaN found" where the oracle's reader (held to the reference's on the same kind of
+    matrices, tests/test_oracle_vs_ref.py) fails, and gives its allele frequencies where it does not."""
+    import os
+    import subprocess
+    import sys
+    from ngsld_amd import capi
+    r = subprocess.run([sys.executable, os.path.join(capi.REPO_DIR, "tools", "probe_special_values.py"), "150"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and ", 0 differ" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
