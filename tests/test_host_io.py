@@ -412,3 +412,43 @@ def test_mutated_files_read_like_the_reference(what, last):
     r = subprocess.run([sys.executable, os.path.join(capi.REPO_DIR, "tools", "reader_fuzz.py"), what, "0", str(last)], capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and ", 0 differ;" in r.stdout, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_product_formatter_against_the_references_own_fprintf_lines():
+    """ngsld_host_format_pair (the rows the drop-in binary writes when they are not formatted on the device) against
+    ngsLD.cpp:296-351 compiled from the reference (oracle/_ref ref_format_row: hap-derived maf, D / D' / r2, the float chi2 and
+    both fprintf formats) on 4,000 haplotype vectors -- simplex points, exact zeros, nearly monomorphic sites, sums off by
+    rounding, NaN / inf entries -- with inf distances, NaN allele frequencies, r2_ExpG values on rounding points.  The oracle's
+    formatter is held to the same lines in test_oracle_vs_ref.py; this closes the triangle without going through the oracle.
+    (NaN is given with the sign the pipeline produces -- x86's 0/0, which the kernels reproduce: printf writes "-nan".)"""
+    import ctypes as C
+    from oracle import orc
+    from test_oracle_vs_ref import _hap_vectors
+    ref = orc.ref()
+    if ref is None or not hasattr(ref, "ref_format_row"):
+        pytest.skip("oracle/_ref predates ref_format_row (oracle/build_ref.sh)")
+    L = orc.lib()
+    rng = np.random.default_rng(21)
+    maf, maf_nan = rng.uniform(0, 0.5, 2), np.array([-np.nan, 0.25])
+    l1, l2 = "chr1:1234\tsnpA", "chr22:99999999"
+    std, ext = np.zeros(1, dtype=capi.REC_STD), np.zeros(1, dtype=capi.REC_EXT)
+    n = 0
+    for k, h in enumerate(_hap_vectors(4_000, 33)):
+        h = np.ascontiguousarray(h)
+        mm = maf_nan if k % 97 == 0 else maf
+        dist = float("inf") if k % 5 == 0 else float(rng.integers(1, 10 ** 9))
+        r2p = [float(rng.uniform()), -float("nan"), 0.0, 1.0, 0.9999995, 1e-7, 0.0078125][k % 7]
+        n_data, n_iter = int(rng.integers(0, 5000)), int(rng.integers(0, 101))
+        D, Dp, r2, hm, c = np.zeros(1), np.zeros(1), np.zeros(1), np.zeros(2), C.c_float()
+        L.orc_pair_stats(orc.dp(h), orc.dp(D), orc.dp(Dp), orc.dp(r2), orc.dp(hm), C.byref(c))
+        if any(np.isnan(v) and not np.signbit(v) for v in (D[0], Dp[0], r2[0], *h)):
+            continue   # (a NaN of the other sign: only an input NaN could produce one, and the readers refuse those)
+        std["r2_ExpG"], std["D"], std["Dp"], std["r2"] = r2p, D[0], Dp[0], r2[0]
+        ext["hap"], ext["n_ind_data"], ext["n_iter"] = h, n_data, n_iter
+        for extend in (0, 1):
+            b = C.create_string_buffer(2048)
+            nb = ref.ref_format_row(b, 2048, l1.encode(), l2.encode(), dist, r2p, orc.dp(h), n_data, float(mm[0]), float(mm[1]), n_iter, extend)
+            got = capi.format_pair(l1, l2, dist, std, ext if extend else None, float(mm[0]), float(mm[1]))
+            assert nb > 0 and got.encode() == b.raw[:nb], (k, got, b.raw[:nb])
+            n += 1
+    assert n > 7000
