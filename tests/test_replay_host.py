@@ -81,3 +81,47 @@ def test_replay_at_benchmark_cohort_sizes():
         raw = synth.make_gl_numpy(12, n_ind, seed=seed, depth=10.0)
         o = orc.Oracle(raw)
         check_against_oracle(raw, o.run(), o.maf)
+
+
+def test_replay_against_the_references_own_functions():
+    """The triangle closed without the oracle: the product's exact-order replay (reader arithmetic, est_maf, haplo_freq, D / D' / r2)
+    against the REFERENCE's compiled functions called one by one (oracle/_ref: read_geno, the est_maf / exp loop of main(),
+    haplo_freq, ngsLD.cpp:296-306) on matrices with missing data, called genotypes, a monomorphic and an all-missing site --
+    same bits, every pair, with and without --ignore_miss_data.  (r2_ExpG is GSL's on the reference's side: not part of this.)"""
+    import ctypes as C
+    import os
+    import tempfile
+    from oracle import orc
+    ref = orc.ref()
+    if ref is None or not hasattr(ref, "ref_pair_stats"):
+        pytest.skip("oracle/_ref not built (oracle/build_ref.sh)")
+    rng = np.random.default_rng(17)
+    pairs = 0
+    for n_ind, n_sites, depth in ((23, 12, 2.0), (64, 9, 8.0), (130, 7, 0.7)):
+        raw = synth.make_gl_numpy(n_sites, n_ind, seed=400 + n_ind, depth=depth)
+        raw[rng.random((n_sites, n_ind)) < 0.15] = 1.0 / 3.0
+        hc = rng.random((n_sites, n_ind)) < 0.2
+        raw[hc] = np.eye(3)[rng.integers(0, 3, size=int(hc.sum()))]
+        raw[2] = np.array([1.0, 0.0, 0.0])
+        raw[4] = 1.0 / 3.0
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "x.glf")
+            raw.tofile(path)
+            for ign in (0, 1):
+                gl = np.empty_like(raw)
+                ref.ref_read_geno_bin(path.encode(), 0, n_ind, n_sites, orc.dp(gl))
+                maf, expg = np.empty(n_sites), np.empty((n_sites, n_ind))
+                ref.ref_preprocess(orc.dp(gl), n_ind, n_sites, ign, orc.dp(maf), orc.dp(expg))
+                for s1 in range(n_sites):
+                    for s2 in range(s1 + 1, n_sites):
+                        hap, n = np.zeros(4), C.c_uint64()
+                        it = ref.ref_haplo_freq(orc.dp(hap), C.byref(n), orc.dp(gl[s1]), orc.dp(gl[s2]), maf[s1], maf[s2], n_ind, ign)
+                        D, Dp, r2, hm, c = np.zeros(1), np.zeros(1), np.zeros(1), np.zeros(2), C.c_float()
+                        ref.ref_pair_stats(orc.dp(hap), orc.dp(D), orc.dp(Dp), orc.dp(r2), orc.dp(hm), C.byref(c))
+                        s, e, m = capi.replay_pair(raw[s1], raw[s2], ignore_miss_data=bool(ign))
+                        assert same_bits(m, [maf[s1], maf[s2]]), ("maf", s1, s2)
+                        assert int(e["n_iter"]) == it and int(e["n_ind_data"]) == n.value, ("counts", s1, s2)
+                        assert same_bits(e["hap"], hap), ("hap", s1, s2, e["hap"], hap)
+                        assert same_bits(s["D"], D[0]) and same_bits(s["Dp"], Dp[0]) and same_bits(s["r2"], r2[0]), ("stats", s1, s2)
+                        pairs += 1
+    assert pairs == 2 * (66 + 36 + 21)
