@@ -82,6 +82,11 @@ def parse():
     ap.add_argument("--rnd-sample", type=float, default=1.0, help="--rnd_sample of the plan (not the headline config)")
     ap.add_argument("--hard-calls", action="store_true",
                     help="hard-call the synthetic likelihoods (argmax -> 1/0/0 triples): the genotype-combination kernel (not the headline config)")
+    ap.add_argument("--mono-frac", type=float, default=0.0,
+                    help="that share of the sites monomorphic in the population: a matrix that is NOT SNP-called (the reference's "
+                         "README.md:73); not the headline config")
+    ap.add_argument("--sfs", action="store_true",
+                    help="site frequencies log-uniform in [0.001, 0.5] instead of U(0.05, 0.5); not the headline config")
     ap.add_argument("--traffic-json", default=os.path.join(REPO, "profiles", "hbm_traffic.json"),
                     help="fallback for roofline.traffic when rocprofv3 is not available")
     ap.add_argument("--no-traffic", action="store_true",
@@ -295,7 +300,10 @@ def measure_traffic(args) -> dict | None:
     child = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--config", args.config, "--steps", "1",
              "--warmup", "0", "--no-cpu", "--no-sink", "--no-e2e", "--no-traffic", "--sites", str(args.sites), "--ind",
              str(args.ind), "--max-kb", str(args.max_kb), "--max-gap", str(args.max_gap), "--scaling", args.scaling,
-             "--depth", repr(args.depth), "--seed", str(args.seed), "--rnd-sample", repr(args.rnd_sample)]
+             "--depth", repr(args.depth), "--seed", str(args.seed), "--rnd-sample", repr(args.rnd_sample),
+             "--mono-frac", repr(args.mono_frac)]
+    if args.sfs:
+        child.append("--sfs")
     if args.ignore_miss:
         child.append("--ignore-miss")
     if args.hard_calls:
@@ -398,7 +406,7 @@ def native_multi(args) -> None:
     dev = torch.device("cuda", 0)
     chrs, pos = synth.make_positions(n_sites, args.seed, max_gap=args.max_gap, n_chr=1)
     pos_dist = shard.pos_dist_from_positions(chrs, pos)
-    raw = synth.make_gl_torch(n_sites, n_ind, args.seed, dev, depth=args.depth)
+    raw = synth.make_gl_torch(n_sites, n_ind, args.seed, dev, depth=args.depth, mono_frac=args.mono_frac, sfs=args.sfs)
     if args.hard_calls:
         raw = torch.nn.functional.one_hot(raw.argmax(dim=2), 3).to(torch.float64)
     raw = raw.cpu().numpy()
@@ -492,7 +500,7 @@ def main():
     # ---- the GL matrix: rank 0 generates, one RCCL broadcast distributes (not timed) ----
     t_gen = time.perf_counter()
     if rank == 0:
-        raw = synth.make_gl_torch(n_sites, n_ind, args.seed, dev, depth=args.depth)
+        raw = synth.make_gl_torch(n_sites, n_ind, args.seed, dev, depth=args.depth, mono_frac=args.mono_frac, sfs=args.sfs)
     else:
         raw = torch.empty((n_sites, n_ind, 3), dtype=torch.float64, device=dev)
     if args.hard_calls and rank == 0:
@@ -544,7 +552,8 @@ def main():
     n_pairs = int(row_off[n_rows] - row_off[0])
     assert args.rnd_sample < 1.0 or n_pairs == int(counts[lo:hi].sum()), "engine plan and host mirror disagree on the pair count"
 
-    headline = world == 1 and not args.ignore_miss and args.rnd_sample >= 1.0 and not args.hard_calls
+    uncalled = args.mono_frac > 0 or args.sfs
+    headline = world == 1 and not args.ignore_miss and args.rnd_sample >= 1.0 and not args.hard_calls and not uncalled
     raw_head = None
     family = eng.pair_kernel()
     if rank == 0 and headline and not args.no_cpu:
@@ -649,7 +658,7 @@ def main():
         dp_ops = pairs_per_launch * n_ind * mean_exec * 20.0
         fp64_tflops = 2.0 * dp_ops / launch_s / 1e12
         preset = CONFIGS[args.config]
-        is_preset = not args.custom and not args.hard_calls
+        is_preset = not args.custom and not args.hard_calls and not uncalled
         out = {
             "metric": f"SNP-pair EM-LD computations/sec @ n_ind={n_ind}", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -658,6 +667,8 @@ def main():
             "config": {"workload": f"synthetic binary GL, {args.sites} sites{'' if strong else '/GPU'} x {n_ind} ind, depth {args.depth:g}, "
                                    f"--max_kb_dist {args.max_kb} {'windowed' if args.max_kb else 'all pairs'}, --extend_out"
                                    + (", hard-called" if args.hard_calls else "")
+                                   + (f", NOT SNP-called: {args.mono_frac:g} of the sites monomorphic" if args.mono_frac > 0 else "")
+                                   + (", site frequencies log-uniform in [0.001, 0.5]" if args.sfs else "")
                                    + (f" ({preset['name']})" if is_preset else ""),
                        "n_sites_total": n_sites, "pairs_per_step": total_pairs,
                        "mean_executed_em_iterations": round(mean_exec, 3),
