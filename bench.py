@@ -576,11 +576,21 @@ def main():
         eng.finish_device()              # waits for the kernels; exact-order replay of the pairs they flagged
         replayed[0] = eng.replay_stats()[0]
 
+    # the first pass, timed by itself: on a matrix that is not SNP-called it is the one that builds the exact store of the
+    # device-side replay (host libm, once per matrix) -- part of the warm-up when there is one, of the timed steps otherwise
+    torch.cuda.synchronize()
+    t_first = time.perf_counter()
+    first_in_warmup = args.warmup > 0
+    if first_in_warmup:
+        step()
+        torch.cuda.synchronize()
+    t_first = time.perf_counter() - t_first
+
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup - (1 if first_in_warmup else 0)):
         step()
     torch.cuda.synchronize()
     barrier()
@@ -596,6 +606,22 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+
+    replay_info = eng.replay_info()
+    replay_off = None
+    if uncalled and world == 1:          # the same pass with the exact-order replay off: what the replay costs on this input
+        eng.set_replay(False)
+        eng.plan(max_kb_dist=args.max_kb, extend_out=True, ignore_miss_data=args.ignore_miss, rnd_sample=args.rnd_sample, seed=12345)
+        step()
+        torch.cuda.synchronize()
+        t_off = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        t_off = time.perf_counter() - t_off
+        replay_off = {"value": n_pairs / t_off, "ms_per_step": t_off * 1e3}
+        eng.set_replay(True)
+        eng.plan(max_kb_dist=args.max_kb, extend_out=True, ignore_miss_data=args.ignore_miss, rnd_sample=args.rnd_sample, seed=12345)
+        step()                            # (the records of the line's checksums are the replayed ones)
 
     # ---- SURVEY §8(d)'s metric to the letter: last record resident in HOST memory (kernel || D2H || sink) ----
     sink_elapsed, sink_passes = 0.0, max(1, min(args.steps, 3))
@@ -680,6 +706,9 @@ def main():
                        "backend": ("gloo, every rank on GPU 0 (NGSLD_BENCH_ONE_DEVICE=1: a dry run of the N > 1 path, not a "
                                    "scaling measurement)" if one_dev else "nccl (RCCL)") if world > 1 else None,
                        "pairs_replayed_exact_order_rank0_last_step": replayed[0],
+                       "replay_rank0_last_step": replay_info,
+                       "first_pass_s_rank0": round(t_first, 4) if first_in_warmup else None,
+                       "replay_off": replay_off,
                        "gl_generate_s": round(t_gen, 3), "gl_broadcast_s": round(t_bc, 3),
                        "one_off_prep_ms_rank0": round(t_prep * 1e3, 2), "one_off_plan_ms_rank0": round(t_plan * 1e3, 2)},
             "value_host_resident": (total_pairs / sink_max) if sink_max > 0 else None,

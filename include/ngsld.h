@@ -210,6 +210,31 @@ int ngsld_set_replay(ngsld_ctx *ctx, int enable);
  * ngsld_plan and run.  Either pointer may be NULL. */
 int ngsld_replay_stats(ngsld_ctx *ctx, uint64_t *pairs, uint64_t *sites);
 
+/* Where the flagged pairs are replayed.  Called-genotype matrices: on the device (their values are the same bits there).
+ * LIKELIHOOD matrices: a few dozen pairs per 10^8 on SNP-called input, which host threads replay -- but on matrices that are
+ * NOT SNP-called (the reference's README.md:73: "comparisons will show up as nan or inf") every pair with a (nearly)
+ * monomorphic site is flagged, a third of all pairs at 20 % monomorphic sites.  Those are replayed on the DEVICE too, a
+ * wavefront per pair, in the reference's operation order (ld_replay_lkl.hip) -- on an "exact store": the matrix once more in
+ * device memory, normal-space likelihoods and est_maf as the reference holds them when calc_pair_LD runs, i.e. through the
+ * HOST's libm.  Data given through ngsld_set_geno_lkl is that already (nothing is built, the replay is on the device from the
+ * first pair on); without a replay source the device's own prepped values serve (the replay then runs on the device's
+ * exp / log rounding, as the host's did); with a source the store is built by the replay threads from the caller's raw
+ * values -- 17 libm calls per triple, ~0.25 us per individual and site on one thread, once per matrix -- the first time a run
+ * has flagged more pairs than the host should replay (more than half as many as the matrix has sites).
+ * mode: 0 never (host replay only), 1 as described (default), 2 build at the first flagged pair. */
+int ngsld_set_exact_store(ngsld_ctx *ctx, int mode);
+typedef struct {
+  uint64_t pairs_flagged;      /* pairs the kernels of the last run flagged */
+  uint64_t pairs_replayed;     /* ... of them replayed (all, unless the replay is off) */
+  uint64_t pairs_on_device;    /* ... on the device */
+  uint64_t pairs_on_host;      /* ... on host threads */
+  uint64_t sites_reevaluated;  /* sites the host re-evaluated for the last plan + run */
+  int32_t exact_store;         /* 0 none, 1 the planes themselves serve as the store, 2 built from the replay source */
+  int32_t reserved;
+  double exact_store_build_s;  /* host seconds the build took (once per matrix) */
+} ngsld_replay_stats_t;
+int ngsld_replay_info(ngsld_ctx *ctx, ngsld_replay_stats_t *out);
+
 /* Same computation with the records left in caller-owned DEVICE memory (no host transfer):
  * d_std holds ngsld_rec_std[n], d_ext ngsld_rec_ext[n] (may be NULL), n = row_off[s1_end] -
  * row_off[s1_begin], record k = global pair index - row_off[s1_begin].  `hip_stream` is a hipStream_t

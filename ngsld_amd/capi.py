@@ -83,6 +83,7 @@ SYMBOLS = [
     "ngsld_set_geno_raw_opts", "ngsld_set_geno_lkl",
     "ngsld_get_maf", "ngsld_set_pos_dist", "ngsld_plan", "ngsld_plan_rows", "ngsld_run", "ngsld_run_device", "ngsld_set_text_output",
     "ngsld_set_replay_source", "ngsld_set_replay_matrix", "ngsld_set_replay", "ngsld_replay_stats", "ngsld_finish_device",
+    "ngsld_set_exact_store", "ngsld_replay_info",
     "ngsld_plan_parts", "ngsld_run_multi", "ngsld_multi_last_distribution", "ngsld_rccl_selftest",
     "ngsld_last_kernel_time", "ngsld_pair_kernel", "ngsld_describe_dispatch", "ngsld_set_tuning", "ngsld_selftest", "ngsld_reserve_text_buffers",
     "ngsld_window_ends", "ngsld_plan_slabs", "ngsld_slab_sites_for_budget", "ngsld_device_memory", "ngsld_run_streamed", "ngsld_run_streamed_text",
@@ -92,6 +93,13 @@ SYMBOLS = [
     "ngsld_host_format_double", "ngsld_host_write_batch", "ngsld_host_replay_pair",
     "ngsld_host_gz_open", "ngsld_host_gz_close",
 ]
+
+
+class ReplayStats(C.Structure):
+    """ngsld_replay_stats_t (include/ngsld.h)."""
+    _fields_ = [("pairs_flagged", C.c_uint64), ("pairs_replayed", C.c_uint64), ("pairs_on_device", C.c_uint64),
+                ("pairs_on_host", C.c_uint64), ("sites_reevaluated", C.c_uint64), ("exact_store", C.c_int32),
+                ("reserved", C.c_int32), ("exact_store_build_s", C.c_double)]
 
 
 class NgsldError(RuntimeError):
@@ -141,6 +149,9 @@ def lib() -> C.CDLL:
                 L.ngsld_set_replay_matrix.argtypes = [vp, vp]
             L.ngsld_set_replay.argtypes = [vp, C.c_int]
             L.ngsld_replay_stats.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+        if hasattr(L, "ngsld_replay_info"):
+            L.ngsld_set_exact_store.argtypes = [vp, C.c_int]
+            L.ngsld_replay_info.argtypes = [vp, C.POINTER(ReplayStats)]
             L.ngsld_finish_device.argtypes = [vp]
         if hasattr(L, "ngsld_set_text_output"):  # (absent only from older A/B builds loaded through NGSLD_LIB)
             L.ngsld_set_text_output.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int]
@@ -636,6 +647,17 @@ class Engine:
         a, b = C.c_uint64(), C.c_uint64()
         self._check(self._L.ngsld_replay_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def set_exact_store(self, mode: int) -> None:
+        """0: flagged pairs of a likelihood matrix are replayed on host threads only; 1 (default): on the device once a run
+        flags more of them than the host should replay; 2: from the first flagged pair on (ngsld_set_exact_store)."""
+        self._check(self._L.ngsld_set_exact_store(self._h, int(mode)))
+
+    def replay_info(self) -> dict:
+        """ngsld_replay_info: where the flagged pairs of the last run were replayed."""
+        st = ReplayStats()
+        self._check(self._L.ngsld_replay_info(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in ReplayStats._fields_ if k != "reserved"}
 
     def finish_device(self) -> None:
         self._check(self._L.ngsld_finish_device(self._h))

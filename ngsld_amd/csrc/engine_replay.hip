@@ -1,0 +1,598 @@
+// engine_replay.hip -- exact-order replay (replay.h): the pairs the kernels flagged are re-evaluated in the reference's own
+// operation order and their records overwritten -- in the host buffers of a record batch, or on the device (text batches,
+// ngsld_run_device) through a small scatter kernel.
+#include "engine.h"
+
+namespace ngsld {
+namespace eng {
+
+// The read-back stream of the exact-order replay (see ngsld_ctx::replay_stream); the copy stream where it cannot be had.
+hipStream_t replay_stream_of(ngsld_ctx *c) {
+  std::lock_guard<std::mutex> g(c->replay_stream_mu);
+  if (c->replay_stream == nullptr && hipStreamCreateWithFlags(&c->replay_stream, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    c->replay_stream = nullptr;
+    return c->copy_stream;
+  }
+  return c->replay_stream;
+}
+
+// Host threads this process may really run on: the affinity mask cut by the cgroup CPU quota (a lease that shows 256 CPUs
+// and grants 16 is common); what the exact-order replay spreads its pairs over when nothing else was asked for.
+unsigned usable_threads() {
+  unsigned n = std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+    const int k = CPU_COUNT(&set);
+    if (k > 0) n = (unsigned)k;
+  }
+  if (FILE *fh = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char a[64] = "";
+    double period = 0;
+    if (std::fscanf(fh, "%63s %lf", a, &period) == 2 && std::strcmp(a, "max") != 0 && period > 0) {
+      const double q = std::atof(a) / period;
+      if (q >= 1.0 && q < (double)n) n = (unsigned)(q + 0.5);
+    }
+    std::fclose(fh);
+  }
+  return n ? n : 1u;
+}
+
+__global__ void patch_records_kernel(const uint64_t *idx, uint64_t n, const ngsld_rec_std *src_std,
+                                     const ngsld_rec_ext *src_ext, ngsld_rec_std *dst_std, ngsld_rec_ext *dst_ext) {
+  const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  dst_std[idx[k]] = src_std[k];
+  if (dst_ext != nullptr) dst_ext[idx[k]] = src_ext[k];
+}
+
+// (s1, s2) of plan records, on the device: what locate_record below does on the host copy of the items -- which a run that
+// leaves its records on the device never needs otherwise (configs[3]: 7.8e7 items, 2.5 GB to copy and hold for a few
+// hundred flagged pairs: 155 ms of its one 12 s step)
+__global__ void locate_records_kernel(const uint64_t *rec, uint64_t n, uint64_t base, const uint64_t *row_off,
+                                      const uint64_t *item_off, const Item *items, uint32_t n_sites, uint32_t *s1, uint32_t *s2) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  s1[t] = s2[t] = 0xffffffffu;
+  const uint64_t r = base + rec[t];
+  uint32_t lo = 0, hi = n_sites;  // largest row with row_off[row] <= r
+  while (lo + 1 < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (row_off[mid] <= r) lo = mid; else hi = mid;
+  }
+  uint64_t il = item_off[lo], ih = item_off[lo + 1];
+  if (il >= ih) return;
+  while (il + 1 < ih) {
+    const uint64_t mid = il + (ih - il) / 2;
+    if (items[mid].first_record <= r) il = mid; else ih = mid;
+  }
+  const Item it = items[il];
+  uint64_t k = r - it.first_record, m = it.mask;
+  if (k >= (uint64_t)__popcll(m)) return;
+  while (k--) m &= m - 1;
+  s1[t] = it.s1;
+  s2[t] = it.s2_begin + (uint32_t)(__ffsll((unsigned long long)m) - 1);
+}
+
+int ensure_host_items(ngsld_ctx *c) {  // the host copy of the plan's items, fetched on first use
+  if (c->h_items.size() != c->n_items) {
+    c->h_items.resize(c->n_items);
+    if (c->n_items)
+      HIP_TRY(c, hipMemcpy(c->h_items.data(), c->d_items.p, c->n_items * sizeof(Item), hipMemcpyDeviceToHost));
+  }
+  return NGSLD_OK;
+}
+
+// (s1, s2) of the plan's record `rec` (h_items must be present)
+bool locate_record(const ngsld_ctx *c, uint64_t rec, uint32_t *s1, uint32_t *s2) {
+  const auto &off = c->h_row_off;
+  const uint64_t row = (uint64_t)(std::upper_bound(off.begin(), off.end(), rec) - off.begin()) - 1;
+  if (row >= c->n_sites) return false;
+  uint64_t lo = c->h_item_off[row], hi = c->h_item_off[row + 1];
+  while (lo + 1 < hi) {  // last item of the row whose first record is <= rec
+    const uint64_t mid = (lo + hi) / 2;
+    if (c->h_items[mid].first_record <= rec) lo = mid; else hi = mid;
+  }
+  if (lo >= hi) return false;
+  const Item &it = c->h_items[lo];
+  uint64_t k = rec - it.first_record, m = it.mask;
+  if (k >= (uint64_t)__builtin_popcountll(m)) return false;
+  while (k--) m &= m - 1;  // drop the k lowest set bits
+  *s1 = it.s1;
+  *s2 = it.s2_begin + (uint32_t)__builtin_ctzll(m);
+  return true;
+}
+
+// One site in the reference's arithmetic: from the caller's raw values when a source is registered, otherwise from the
+// device's own planes (already normalised normal-space values; exact for ngsld_set_geno_lkl input).
+int fetch_replay_site(ngsld_ctx *c, uint64_t s, std::vector<double> &tmp, ReplaySite *out) {
+  const uint64_t n = c->n_ind;
+  if (c->replay_matrix != nullptr) {  // the caller's own array, read in place
+    const double *v = c->replay_matrix + s * 3 * n;
+    if (c->normalised)
+      replay_site_from_lkl(v, c->h_maf[s], n, out);
+    else
+      replay_site_from_raw(v, n, c->gopts, out);
+    return NGSLD_OK;
+  }
+  if (c->replay_read != nullptr) {
+    tmp.resize(3 * n);
+    {
+      std::lock_guard<std::mutex> g(c->replay_mu);
+      if (c->replay_read(c->replay_user, s, 1, tmp.data()) != 0) return NGSLD_ERR_SINK;
+    }
+    if (c->normalised)
+      replay_site_from_lkl(tmp.data(), c->h_maf[s], n, out);
+    else
+      replay_site_from_raw(tmp.data(), n, c->gopts, out);
+    return NGSLD_OK;
+  }
+  // (pinned staging: a pageable copy would be staged by the runtime; while a pair kernel of the next batch has the device
+  // this read-back can still wait for it -- callers that care register a source)
+  tmp.resize(3 * n);
+  double *lkl = tmp.data();
+  {
+    std::lock_guard<std::mutex> g(c->replay_mu);
+    if (hipSetDevice(c->device) != hipSuccess || c->h_site_stage.resize(3ull * c->np) != hipSuccess) return NGSLD_ERR_DEVICE;
+    hipStream_t rs = replay_stream_of(c);
+    if (hipMemcpyAsync(c->h_site_stage.p, c->d_planes.p + s * 3ull * c->np, 3ull * c->np * sizeof(double),
+                       hipMemcpyDeviceToHost, rs) != hipSuccess ||
+        hipStreamSynchronize(rs) != hipSuccess)
+      return NGSLD_ERR_DEVICE;
+    const double *planes = c->h_site_stage.p;
+    for (uint64_t i = 0; i < n; ++i)
+      for (int g = 0; g < 3; ++g) lkl[3 * i + g] = planes[(uint64_t)g * c->np + i];
+  }
+  replay_site_from_lkl(lkl, c->h_maf[s], n, out);
+  return NGSLD_OK;
+}
+
+// The flagged records of a launch of n records, in increasing order.  h_head: the head of its flag buffer (counter + the
+// first `cap` record indices) in host memory -- it travels with the batch, or is copied on the launch's own stream
+// right behind the kernels (a copy issued later, while the next batch's pair kernel has the device, can wait for that
+// kernel: measured 43 ms).  Only a launch that flagged more pairs than the list holds has its bitmap fetched from d_flags,
+// on the replay stream (the kernels that set it are complete when this is called).
+int flagged_records(ngsld_ctx *c, const uint32_t *h_head, const uint32_t *d_flags, uint32_t cap, uint64_t n,
+                    std::vector<uint64_t> &recs, bool dev_applied) {
+  recs.clear();
+  const uint32_t count = h_head[0];
+  if (count == 0) return NGSLD_OK;
+  const size_t words = flag_bitmap_words(n);
+  auto from_bitmap = [&](size_t first_word, uint32_t expect) -> int {
+    HIP_TRY(c, c->h_flag_bits.resize(words ? words : 1));
+    hipStream_t rs = replay_stream_of(c);
+    HIP_TRY(c, hipMemcpyAsync(c->h_flag_bits.p, d_flags + first_word, words * sizeof(uint32_t), hipMemcpyDeviceToHost, rs));
+    HIP_TRY(c, hipStreamSynchronize(rs));
+    const uint32_t *bits = c->h_flag_bits.p;
+    recs.reserve(expect);
+    for (uint64_t w = 0; w < words; ++w)
+      for (uint32_t m = bits[w]; m; m &= m - 1) {
+        const uint64_t r = w * 32 + (uint64_t)__builtin_ctz(m);
+        if (r < n) recs.push_back(r);
+      }
+    return NGSLD_OK;
+  };
+  if (dev_applied) {
+    // likelihood matrices, device-side replay behind the launch (ld_replay_lkl.hip): it settled every flagged pair but the
+    // host-only ones -- head[2] says how many --, and those have a bitmap of their own
+    c->replayed_on_device += h_head[2];
+    c->replayed_pairs += h_head[2];
+    const uint32_t host_only = h_head[1];
+    if (host_only == 0) return NGSLD_OK;
+    if (count <= cap) {  // (the list names them)
+      const uint64_t *list = reinterpret_cast<const uint64_t *>(h_head + kFlagListAt);
+      for (uint32_t k = 0; k < count; ++k)
+        if (list[k] & kFlagHostOnly) recs.push_back(list[k] & kFlagIndexMask);
+      std::sort(recs.begin(), recs.end());
+      while (!recs.empty() && recs.back() >= n) recs.pop_back();
+      return NGSLD_OK;
+    }
+    return from_bitmap((size_t)flag_head_words(cap) + words, host_only);
+  }
+  if (count <= cap) {
+    const uint64_t *list = reinterpret_cast<const uint64_t *>(h_head + kFlagListAt);
+    recs.reserve(count);
+    uint64_t on_device = 0;
+    for (uint32_t k = 0; k < count; ++k) {
+      if (list[k] & kFlagDone) {  // the device-side replay (ld_replay.hip) has rewritten this record already
+        ++on_device;
+        continue;
+      }
+      recs.push_back(list[k] & kFlagIndexMask);
+    }
+    c->replayed_on_device += on_device;
+    c->replayed_pairs += on_device;
+    std::sort(recs.begin(), recs.end());  // (the order the atomics landed in is not the record order)
+    while (!recs.empty() && recs.back() >= n) recs.pop_back();
+    return NGSLD_OK;
+  }
+  return from_bitmap(flag_head_words(cap), count);
+}
+
+// Records `recs` (indices into a launch whose record 0 is the plan's record `base`, increasing) are replayed; the new
+// records go to h_std / h_ext (host buffers of the batch) or, when those are null, to d_std / d_ext on stream st (synchronised).
+int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t base, ngsld_rec_std *h_std,
+                   ngsld_rec_ext *h_ext, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext, hipStream_t st,
+                   std::vector<uint32_t> *sites1, std::vector<uint32_t> *sites2) {
+  Range range_("ngsld:exact-order replay (host)");
+  if (recs.empty()) return NGSLD_OK;
+  // which pairs these records are: from the host copy of the plan's items where the run has one anyway (the sink path), from
+  // the device's otherwise
+  const bool have_items = c->h_items.size() == c->n_items;
+  std::vector<uint32_t> loc_s1, loc_s2;
+  if (!have_items) {
+    hipStream_t ls = st != nullptr ? st : replay_stream_of(c);
+    loc_s1.resize(recs.size());
+    loc_s2.resize(recs.size());
+    HIP_TRY(c, c->d_patch_idx.resize(recs.size()));
+    HIP_TRY(c, c->d_patch_s1.resize(recs.size()));
+    HIP_TRY(c, c->d_patch_s2.resize(recs.size()));
+    HIP_TRY(c, hipMemcpyAsync(c->d_patch_idx.p, recs.data(), recs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ls));
+    hipLaunchKernelGGL(locate_records_kernel, dim3((unsigned)((recs.size() + 63) / 64)), dim3(64), 0, ls, c->d_patch_idx.p,
+                       (uint64_t)recs.size(), base, c->d_row_off.p, c->d_item_off.p, c->d_items.p, (uint32_t)c->n_sites,
+                       c->d_patch_s1.p, c->d_patch_s2.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(loc_s1.data(), c->d_patch_s1.p, recs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
+    HIP_TRY(c, hipMemcpyAsync(loc_s2.data(), c->d_patch_s2.p, recs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
+    HIP_TRY(c, hipStreamSynchronize(ls));
+  }
+  const bool ext = (h_std != nullptr ? (void *)h_ext : (void *)d_ext) != nullptr;
+  const bool ign = c->params.ignore_miss_data != 0;
+  std::vector<ngsld_rec_std> out_std(recs.size());
+  std::vector<ngsld_rec_ext> out_ext(ext ? recs.size() : 0);
+  if (sites1) sites1->assign(recs.size(), 0);  // (the pairs' sites, for callers that format the replayed rows again)
+  if (sites2) sites2->assign(recs.size(), 0);
+  int T = c->replay_threads > 0 ? c->replay_threads : (int)std::min<unsigned>(32u, usable_threads());
+  if ((uint64_t)T > recs.size()) T = (int)recs.size();  // (a launch of 1e8 pairs flags a few dozen: sixteen per thread left them to two threads, 2.6 ms)
+  std::vector<int> rcs((size_t)T, NGSLD_OK), stats((size_t)T, NGSLD_OK);
+  std::vector<uint64_t> sites_done((size_t)T, 0);
+  auto work = [&](int t) {
+    const size_t k0 = recs.size() * (size_t)t / (size_t)T, k1 = recs.size() * (size_t)(t + 1) / (size_t)T;
+    // records come in (s1, s2) order: the row's site is kept, the partners go through a bounded cache
+    const size_t cache_cap = std::max<size_t>(64, (256ull << 20) / (32 * c->n_ind + 64));
+    std::unordered_map<uint32_t, ReplaySite> cache;
+    std::vector<double> tmp;
+    ReplaySite row;
+    uint32_t row_site = 0xffffffffu;
+    try {
+      for (size_t k = k0; k < k1; ++k) {
+        uint32_t s1 = 0, s2 = 0;
+        if (have_items ? !locate_record(c, base + recs[k], &s1, &s2)
+                       : ((s1 = loc_s1[k]) == 0xffffffffu || (s2 = loc_s2[k]) == 0xffffffffu)) {
+          rcs[(size_t)t] = NGSLD_ERR_INVALID;
+          return;
+        }
+        if (sites1) (*sites1)[k] = s1;
+        if (sites2) (*sites2)[k] = s2;
+        if (s1 != row_site) {
+          const int rc = fetch_replay_site(c, s1, tmp, &row);
+          if (rc != NGSLD_OK) { rcs[(size_t)t] = rc; return; }
+          row_site = s1;
+          ++sites_done[(size_t)t];
+        }
+        auto hit = cache.find(s2);
+        if (hit == cache.end()) {
+          if (cache.size() >= cache_cap) cache.clear();
+          hit = cache.emplace(s2, ReplaySite()).first;
+          const int rc = fetch_replay_site(c, s2, tmp, &hit->second);
+          if (rc != NGSLD_OK) { rcs[(size_t)t] = rc; return; }
+          ++sites_done[(size_t)t];
+        }
+        replay_pair(row, hit->second, c->n_ind, ign, &out_std[k], ext ? &out_ext[k] : nullptr, &stats[(size_t)t]);
+      }
+    } catch (...) {
+      rcs[(size_t)t] = NGSLD_ERR_NOMEM;
+    }
+  };
+  if (T < 1) T = 1;
+  c->replay_pool.run(T, work);
+  for (int t = 0; t < T; ++t) {
+    if (rcs[(size_t)t] != NGSLD_OK)
+      return fail(c, rcs[(size_t)t], rcs[(size_t)t] == NGSLD_ERR_SINK ? "the replay source callback failed"
+                                                                      : "exact-order replay failed");
+    if (stats[(size_t)t] == NGSLD_ERR_MAF_RANGE) {
+      const int v = NGSLD_ERR_MAF_RANGE;
+      HIP_TRY(c, hipMemcpy(c->d_status.p, &v, sizeof(int), hipMemcpyHostToDevice));
+    }
+    c->replayed_sites += sites_done[(size_t)t];
+  }
+  c->replayed_pairs += recs.size();
+  c->host_replayed_total += recs.size();
+  if (h_std != nullptr) {
+    for (size_t k = 0; k < recs.size(); ++k) {
+      h_std[recs[k]] = out_std[k];
+      if (ext && h_ext != nullptr) h_ext[recs[k]] = out_ext[k];
+    }
+    return NGSLD_OK;
+  }
+  HIP_TRY(c, c->d_patch_idx.resize(recs.size()));
+  HIP_TRY(c, c->d_patch_std.resize(recs.size()));
+  if (ext) HIP_TRY(c, c->d_patch_ext.resize(recs.size()));
+  HIP_TRY(c, hipMemcpyAsync(c->d_patch_idx.p, recs.data(), recs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemcpyAsync(c->d_patch_std.p, out_std.data(), recs.size() * sizeof(ngsld_rec_std), hipMemcpyHostToDevice, st));
+  if (ext)
+    HIP_TRY(c, hipMemcpyAsync(c->d_patch_ext.p, out_ext.data(), recs.size() * sizeof(ngsld_rec_ext), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(patch_records_kernel, dim3((unsigned)((recs.size() + 255) / 256)), dim3(256), 0, st, c->d_patch_idx.p,
+                     (uint64_t)recs.size(), c->d_patch_std.p, ext ? c->d_patch_ext.p : nullptr, d_std, ext ? d_ext : nullptr);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(st));  // the pageable source vectors go out of scope
+  return NGSLD_OK;
+}
+
+// A flag buffer for n records with `cap` list entries, zeroed on `stream`.
+int reset_flags(ngsld_ctx *c, DevBuf<uint32_t> &buf, uint64_t n, uint32_t cap, hipStream_t stream) {
+  const size_t words = flag_words(n, cap), head = flag_head_words(cap);
+  HIP_TRY(c, buf.resize(words));
+  HIP_TRY(c, hipMemsetAsync(buf.p, 0, kFlagListAt * sizeof(uint32_t), stream));  // the counters (the list behind them needs no clearing)
+  if (words > head)
+    HIP_TRY(c, hipMemsetAsync(buf.p + head, 0, (words - head) * sizeof(uint32_t), stream));  // both bitmaps
+  return NGSLD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Likelihood matrices: the exact store and the device-side replay (ld_replay_lkl.hip)
+// ---------------------------------------------------------------------------------------------------------------
+bool lkl_device_eligible(const ngsld_ctx *c) {
+  return c->replay_on && c->replay_device && c->exact_mode != 0 && c->have_geno && c->cfg.kernel != kHard &&
+         replay_lkl_waves((uint32_t)c->n_ind) != 0;
+}
+
+// the planes ARE the store: the caller's own normal-space values (ngsld_set_geno_lkl), or no source to build another from
+bool exact_store_is_free(const ngsld_ctx *c) {
+  return c->normalised || (c->replay_matrix == nullptr && c->replay_read == nullptr);
+}
+
+// Host replay costs ~0.15 us per individual and pair on one thread, the store ~0.25 us per individual and SITE (17 libm calls
+// per triple: read_geno's log + post_prob, est_maf's post_prob + exp, main's exp), once: it pays as soon as the host would
+// otherwise replay more pairs than half the matrix has sites.
+bool exact_store_wanted(const ngsld_ctx *c, uint64_t pending) {
+  if (!lkl_device_eligible(c)) return false;
+  if (c->exact_ready || exact_store_is_free(c)) return pending > 0;
+  if (c->exact_mode >= 2) return pending > 0;
+  return c->host_replayed_total + pending > std::max<uint64_t>(4096, c->n_sites / 2);
+}
+
+int ensure_exact_store(ngsld_ctx *c) {
+  if (c->exact_ready) return NGSLD_OK;
+  if (exact_store_is_free(c)) {
+    c->exact_alias = true;
+    c->exact_ready = true;
+    return NGSLD_OK;
+  }
+  Range range_("ngsld:exact store (host libm -> device)");
+  const auto t0 = std::chrono::steady_clock::now();
+  const uint64_t n = c->n_sites, ni = c->n_ind, np = c->np, site_elems = 3 * np;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, c->d_xplanes.resize((size_t)n * site_elems));
+  HIP_TRY(c, c->d_xmaf.resize(n));
+  std::vector<double> xmaf(n);
+  uint64_t chunk = std::max<uint64_t>(1, (32ull << 20) / (site_elems * sizeof(double)));
+  if (chunk > n) chunk = n;
+  hipEvent_t up[2] = {nullptr, nullptr};
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(c, c->h_xstage[k].resize((size_t)chunk * site_elems));
+    HIP_TRY(c, hipEventCreateWithFlags(&up[k], hipEventDisableTiming));
+  }
+  hipStream_t st = replay_stream_of(c);
+  int T = c->replay_threads > 0 ? c->replay_threads : (int)std::min<unsigned>(32u, usable_threads());
+  std::vector<double> raw_chunk;  // (callback source: the chunk's raw values, fetched with one call)
+  int rc = NGSLD_OK;
+  uint64_t k = 0;
+  for (uint64_t s0 = 0; s0 < n && rc == NGSLD_OK; s0 += chunk, ++k) {
+    const int b = (int)(k & 1);
+    const uint64_t m = std::min(chunk, n - s0);
+    if (k >= 2) HIP_TRY(c, hipEventSynchronize(up[b]));  // the upload that last read this staging buffer is done
+    const double *raw = nullptr;
+    if (c->replay_matrix != nullptr) {
+      raw = c->replay_matrix + s0 * 3 * ni;
+    } else {
+      raw_chunk.resize((size_t)m * 3 * ni);
+      std::lock_guard<std::mutex> g(c->replay_mu);
+      if (c->replay_read(c->replay_user, s0, m, raw_chunk.data()) != 0) {
+        rc = fail(c, NGSLD_ERR_SINK, "the replay source callback failed");
+        break;
+      }
+      raw = raw_chunk.data();
+    }
+    double *stage = c->h_xstage[b].p;
+    const int Tm = (int)std::min<uint64_t>((uint64_t)T, m);
+    std::vector<int> ok((size_t)Tm, 1);
+    c->replay_pool.run(Tm, [&](int t) {
+      try {
+        for (uint64_t s = m * (uint64_t)t / (uint64_t)Tm; s < m * (uint64_t)(t + 1) / (uint64_t)Tm; ++s)
+          replay_site_planes(raw + s * 3 * ni, ni, c->gopts, np, stage + s * site_elems, &xmaf[s0 + s]);
+      } catch (...) {
+        ok[(size_t)t] = 0;
+      }
+    });
+    for (int t = 0; t < Tm; ++t)
+      if (!ok[(size_t)t]) rc = fail(c, NGSLD_ERR_NOMEM, "out of host memory");
+    if (rc != NGSLD_OK) break;
+    HIP_TRY(c, hipMemcpyAsync(c->d_xplanes.p + s0 * site_elems, stage, (size_t)m * site_elems * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(c, hipEventRecord(up[b], st));
+  }
+  if (rc == NGSLD_OK) {
+    hipError_t e = hipMemcpyAsync(c->d_xmaf.p, xmaf.data(), n * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = hip_fail(c, e, "exact store upload");
+  } else {
+    (void)hipStreamSynchronize(st);
+  }
+  for (int q = 0; q < 2; ++q)
+    if (up[q]) (void)hipEventDestroy(up[q]);
+  if (rc != NGSLD_OK) return rc;
+  c->exact_alias = false;
+  c->exact_ready = true;
+  c->exact_build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (std::getenv("NGSLD_TRACE") != nullptr)
+    std::fprintf(stderr, "[trace] exact store: %llu sites x %llu individuals through the host's libm on %d threads in %.3f s\n",
+                 (unsigned long long)n, (unsigned long long)ni, T, c->exact_build_s);
+  return NGSLD_OK;
+}
+
+// The flagged pairs of a launch replayed on the device (likelihood matrices), on `st` behind the pair kernels that flagged
+// them -- before the head of the flag buffer travels to the host, before text rows are formatted.  The store must be ready.
+int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
+                      ngsld_rec_ext *d_ext, hipStream_t st) {
+  if (!c->exact_ready || d_flags == nullptr || n == 0) return NGSLD_OK;
+  ReplayLklArgs a{};
+  const size_t head = flag_head_words(cap), words = flag_bitmap_words(n);
+  a.bits = d_flags + head;
+  a.host_bits = d_flags + head + words;
+  a.n_records = n;
+  a.done = d_flags + 2;
+  a.work = d_flags + 3;
+  a.row_off = c->d_row_off.p;
+  a.item_off = c->d_item_off.p;
+  a.items = c->d_items.p;
+  a.n_items = c->n_items;
+  a.n_sites = (uint32_t)c->n_sites;
+  a.rec_base = out_base;
+  a.xplanes = c->exact_alias ? c->d_planes.p : c->d_xplanes.p;
+  a.site_stride = 3ull * c->np;
+  a.np = c->np;
+  a.xmaf = c->exact_alias ? c->d_maf.p : c->d_xmaf.p;
+  a.n_ind = (uint32_t)c->n_ind;
+  a.ignore_miss = c->params.ignore_miss_data;
+  a.out_std = d_std;
+  a.out_ext = d_ext;
+  a.status = c->d_status.p;
+  HIP_TRY(c, launch_replay_lkl(a, c->n_cus, st));
+  return NGSLD_OK;
+}
+
+// Called-genotype matrices: the flagged pairs of a launch replayed on the device (ld_replay.hip), right behind the pair
+// kernels on their stream -- before the head of the flag buffer travels to the host, before text rows are formatted.
+// out_base: plan index of the launch's record 0; d_std / d_ext: where the launch wrote (device, or pinned host memory).
+int device_replay(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
+                  ngsld_rec_ext *d_ext, hipStream_t st) {
+  if (!c->replay_on || !c->replay_device || c->cfg.kernel != kHard || d_flags == nullptr || n == 0) return NGSLD_OK;
+  ReplayHardArgs a{};
+  a.flags = d_flags;
+  a.flag_cap = cap;
+  a.row_off = c->d_row_off.p;
+  a.item_off = c->d_item_off.p;
+  a.items = c->d_items.p;
+  a.n_sites = (uint32_t)c->n_sites;
+  a.rec_base = out_base;
+  a.masks = c->d_hard_masks.p;
+  a.words = c->mask_words;
+  a.n_ind = (uint32_t)c->n_ind;
+  a.ignore_miss = c->params.ignore_miss_data;
+  // "no data" individuals: only call_geno's triple is the same arithmetic on every individual (gen_func.cpp:903-905); a
+  // matrix that came called from elsewhere may hold any three equal values -- its pairs at sites with missing data stay
+  // with the host, which has the caller's raw values
+  a.miss_ok = c->gopts.call_geno && !c->normalised ? 1 : 0;
+  replay_missing_constants(&a.u_lkl, &a.u_pp);
+  a.out_std = d_std;
+  a.out_ext = d_ext;
+  a.status = c->d_status.p;
+  HIP_TRY(c, launch_replay_hard(a, n, st));
+  return NGSLD_OK;
+}
+
+int finish_device_run(ngsld_ctx *c) {
+  if (!c->dev_run.pending) return NGSLD_OK;
+  c->dev_run.pending = false;
+  const bool trace = std::getenv("NGSLD_TRACE") != nullptr;  // dev: where ngsld_finish_device's time goes, on stderr
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  HIP_TRY(c, hipStreamSynchronize(c->dev_run.st));  // (the head of the flag buffer came over behind the kernels, ngsld_run_device)
+  const double t_sync = ms();
+  if (!c->replay_on || c->d_flags_dev.p == nullptr || c->h_flags_dev.p == nullptr) return NGSLD_OK;
+  c->flagged_pairs = c->h_flags_dev.p[0];
+  if (c->h_flags_dev.p[0] == 0) return NGSLD_OK;
+  const uint64_t base = c->h_row_off[c->dev_run.s1_begin], n = c->h_row_off[c->dev_run.s1_end] - base;
+  bool applied = c->dev_run.dev_applied;
+  if (!applied && exact_store_wanted(c, c->h_flags_dev.p[0] - c->h_flags_dev.p[1])) {
+    // a likelihood matrix that flags more pairs than the host should replay: the exact store is built (once per matrix) and
+    // the pairs are replayed on the device, behind the kernels on their stream
+    int rcx = ensure_exact_store(c);
+    if (rcx == NGSLD_OK)
+      rcx = device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, base, n, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st);
+    if (rcx != NGSLD_OK) return rcx;
+    HIP_TRY(c, hipMemcpyAsync(c->h_flags_dev.p, c->d_flags_dev.p, flag_head_bytes(c->flag_cap_dev), hipMemcpyDeviceToHost, c->dev_run.st));
+    HIP_TRY(c, hipStreamSynchronize(c->dev_run.st));
+    applied = true;
+  }
+  const double t_dev = ms();
+  std::vector<uint64_t> recs;
+  const int rcf = flagged_records(c, c->h_flags_dev.p, c->d_flags_dev.p, c->flag_cap_dev, n, recs, applied);
+  if (rcf != NGSLD_OK) return rcf;
+  const double t_list = ms();
+  const int rcr = replay_flagged(c, recs, base, nullptr, nullptr, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st);
+  if (trace)
+    std::fprintf(stderr, "[trace] finish_device: waited for the kernels %.2f ms, exact store + device replay %.2f ms, flag list %.2f ms "
+                         "(%u flagged, %u on the device, %zu for the host), host replay + patch %.2f ms\n", t_sync, t_dev - t_sync,
+                 t_list - t_dev, c->h_flags_dev.p[0], applied ? c->h_flags_dev.p[2] : 0u, recs.size(), ms() - t_list);
+  return rcr;
+}
+}  // namespace eng
+}  // namespace ngsld
+
+extern "C" {
+
+int ngsld_set_replay_source(ngsld_ctx *c, ngsld_read_sites_fn read, void *user) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "set the genotype data before its replay source");
+  c->replay_matrix = nullptr;
+  c->replay_read = read;
+  c->replay_user = user;
+  c->exact_ready = false;  // (the exact store is built from the source)
+  c->planned = false;  // a --min_maf tie is settled at plan time
+  return NGSLD_OK;
+}
+
+int ngsld_set_replay_matrix(ngsld_ctx *c, const double *values) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "set the genotype data before its replay source");
+  c->replay_matrix = values;
+  c->replay_read = nullptr;
+  c->replay_user = nullptr;
+  c->exact_ready = false;  // (the exact store is built from the source)
+  c->planned = false;  // a --min_maf tie is settled at plan time
+  return NGSLD_OK;
+}
+
+int ngsld_set_replay(ngsld_ctx *c, int enable) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  c->replay_on = enable != 0;
+  c->planned = false;
+  return NGSLD_OK;
+}
+
+int ngsld_set_exact_store(ngsld_ctx *c, int mode) {
+  if (c == nullptr || mode < 0 || mode > 2) return NGSLD_ERR_INVALID;
+  c->exact_mode = mode;
+  return NGSLD_OK;
+}
+
+int ngsld_replay_info(ngsld_ctx *c, ngsld_replay_stats_t *out) {
+  if (c == nullptr || out == nullptr) return NGSLD_ERR_INVALID;
+  out->pairs_flagged = c->flagged_pairs;
+  out->pairs_replayed = c->replayed_pairs;
+  out->pairs_on_device = c->replayed_on_device;
+  out->pairs_on_host = c->replayed_pairs - c->replayed_on_device;
+  out->sites_reevaluated = c->replayed_sites;
+  out->exact_store = c->exact_ready ? (c->exact_alias ? 1 : 2) : 0;
+  out->exact_store_build_s = c->exact_build_s;
+  return NGSLD_OK;
+}
+
+int ngsld_replay_stats(ngsld_ctx *c, uint64_t *pairs, uint64_t *sites) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (pairs) *pairs = c->replayed_pairs;
+  if (sites) *sites = c->replayed_sites;
+  return NGSLD_OK;
+}
+
+int ngsld_finish_device(ngsld_ctx *c) try {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
+  const int rc = finish_device_run(c);
+  if (rc != NGSLD_OK) return rc;
+  return check_status(c);
+} NGSLD_CATCH(c)
+
+}  // extern "C"

@@ -1,0 +1,603 @@
+// engine_run.hip -- ngsld_run / ngsld_run_device: the batch pipeline pair kernel -> (device-side replay) -> records or
+// device-side TSV -> sink (replaces threadpool_add(calc_pair_LD) ... threadpool_wait and the fprintf block,
+// ngsLD.cpp:153-198, 310-352).
+#include "engine.h"
+
+namespace ngsld {
+namespace eng {
+
+hipError_t timed_launch(ngsld_ctx *c, const PairArgs &a, hipStream_t stream) {
+  if (c->ev_used == c->ev_pool.size()) {
+    hipEvent_t b, e;
+    hipError_t r = hipEventCreate(&b);
+    if (r != hipSuccess) return r;
+    r = hipEventCreate(&e);
+    if (r != hipSuccess) return r;
+    c->ev_pool.emplace_back(b, e);
+  }
+  auto &ev = c->ev_pool[c->ev_used++];
+  hipError_t r = hipEventRecord(ev.first, stream);
+  if (r != hipSuccess) return r;
+  r = launch_pair_kernel(c->cfg, c->params.ignore_miss_data != 0, a, stream);
+  if (r != hipSuccess) return r;
+  return hipEventRecord(ev.second, stream);
+}
+
+PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext, uint32_t *d_flags,
+                   uint32_t flag_cap, uint64_t flag_n) {
+  PairArgs a{};
+  a.flags = d_flags;
+  a.flags_host = d_flags != nullptr ? d_flags + flag_head_words(flag_cap) + flag_bitmap_words(flag_n) : nullptr;
+  a.flag_cap = flag_cap;
+  a.flag_text = 1;
+  a.planes = c->d_planes.p;
+  a.site_stride = 3ull * c->np;
+  a.np = c->np;
+  a.n_ind = (uint32_t)c->n_ind;
+  a.inv_n = 1.0 / (double)c->n_ind;
+  a.maf = c->d_maf.p;
+  a.mean_e = c->d_mean.p;
+  a.rsx = c->d_rsx.p;
+  a.items = c->d_items.p + c->h_item_off[r0];
+  a.n_items = c->h_item_off[r1] - c->h_item_off[r0];
+  if (uses_runs(c->cfg.kernel)) {
+    a.runs = c->d_runs.p + c->h_run_off[r0];
+    a.n_runs = c->h_run_off[r1] - c->h_run_off[r0];
+  }
+  a.hard_masks = c->d_hard_masks.p;
+  a.hard_u = c->d_hard_u.p;
+  a.mask_words = c->mask_words;
+  a.items_all = c->d_items.p;
+  a.item_off = c->d_item_off.p;
+  a.h_item_off = c->h_item_off.data();
+  a.row0 = (uint32_t)r0;
+  a.row1 = (uint32_t)r1;
+  a.planes_bytes = c->n_sites * 3ull * c->np * sizeof(double);
+  a.sc4 = c->d_sc4.p;
+  a.out_base = c->h_row_off[r0];
+  a.out_std = d_std;
+  a.out_ext = d_ext;
+  a.status = c->d_status.p;
+  return a;
+}
+}  // namespace eng
+}  // namespace ngsld
+
+extern "C" {
+
+int ngsld_set_text_output(ngsld_ctx *c, const char *const *labels, int enable) try {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "set the genotype data before the labels");
+  HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
+  c->text_mode = false;
+  if (!enable) return NGSLD_OK;
+  c->have_labels = labels != nullptr;
+  c->max_label = 6;
+  if (labels != nullptr) {
+    std::vector<uint64_t> off(c->n_sites + 1, 0);
+    for (uint64_t s = 0; s < c->n_sites; ++s) {
+      if (labels[s] == nullptr) return fail(c, NGSLD_ERR_INVALID, "a label is NULL");
+      const uint64_t n = std::strlen(labels[s]);
+      off[s + 1] = off[s] + n;
+      c->max_label = std::max<uint64_t>(c->max_label, n);
+    }
+    std::vector<char> blob(off[c->n_sites] ? off[c->n_sites] : 1);
+    for (uint64_t s = 0; s < c->n_sites; ++s) std::memcpy(blob.data() + off[s], labels[s], off[s + 1] - off[s]);
+    HIP_TRY(c, c->d_labels.resize(blob.size()));
+    HIP_TRY(c, c->d_label_off.resize(c->n_sites + 1));
+    HIP_TRY(c, hipMemcpy(c->d_labels.p, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_label_off.p, off.data(), off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
+  c->text_mode = true;
+  return NGSLD_OK;
+} NGSLD_CATCH(c)
+
+int ngsld_reserve_text_buffers(ngsld_ctx *c, uint64_t bytes_per_row) try {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (c->reserve_thread.joinable()) c->reserve_thread.join();
+  if (bytes_per_row == 0) return NGSLD_OK;
+  const uint64_t bytes_per_batch = bytes_per_row * std::min<uint64_t>(c->batch_pairs, kTextBatchPairs);
+  c->reserve_thread = std::thread([c, bytes_per_batch] {
+    if (hipSetDevice(c->device) != hipSuccess) return;
+    for (int k = 0; k < ngsld_ctx::kSlots; ++k) (void)c->h_text[k].resize(bytes_per_batch);  // (a failure here is found again, and reported, at first use)
+  });
+  return NGSLD_OK;
+} NGSLD_CATCH(c)
+int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_std, void *d_ext, void *hip_stream) try {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->planned) return fail(c, NGSLD_ERR_INVALID, "ngsld_plan has not been called");
+  if (s1_begin > s1_end || s1_end > c->n_sites) return fail(c, NGSLD_ERR_INVALID, "row range out of bounds");
+  if (d_std == nullptr) return fail(c, NGSLD_ERR_INVALID, "d_std is NULL");
+  HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
+  Range range_("ngsld:run_device (pair kernels)");
+  {
+    // One pending run per context: the flag buffer and the record pointers of a run on a caller's stream are single.  A second
+    // run before ngsld_finish_device first finishes the earlier one (waits for its stream, replays what it flagged) -- clearing
+    // the flags under kernels still setting them would leave those records with the kernels' unreplayed values.
+    const int rcp = finish_device_run(c);
+    if (rcp != NGSLD_OK) return rcp;
+  }
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  c->ev_used = 0;
+  c->timed_stream = st;
+  c->timed_overlap = false;
+  c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
+  c->replayed_pairs = 0;
+  c->replayed_on_device = 0;
+  c->flagged_pairs = 0;
+  if (c->replay_on) {
+    c->flag_cap_dev = flag_cap_for(c->timed_pairs);
+    const int rcf = reset_flags(c, c->d_flags_dev, c->timed_pairs, c->flag_cap_dev, st);
+    if (rcf != NGSLD_OK) return rcf;
+    HIP_TRY(c, c->h_flags_dev.resize(flag_head_words(c->flag_cap_dev)));
+  }
+  // one launch per <= 2^31-1 workgroups; rows are cut so that each launch's grid fits
+  const uint64_t max_items = 0x7ffffff0ull;
+  std::vector<uint64_t> cuts;  // rows at which the launches end
+  for (uint64_t r0 = s1_begin; r0 < s1_end;) {
+    uint64_t r1 = r0 + 1;
+    while (r1 < s1_end && c->h_item_off[r1 + 1] - c->h_item_off[r0] <= max_items) ++r1;
+    cuts.push_back(r1);
+    r0 = r1;
+  }
+  if (uses_runs(c->cfg.kernel)) {  // (big launches: whole-row runs, whatever an earlier ngsld_run cut them to, short ones at each launch's end)
+    const int rcr = build_runs(c, kRunItems, cuts);
+    if (rcr != NGSLD_OK) return rcr;
+  }
+  uint64_t r0 = s1_begin;
+  for (const uint64_t r1 : cuts) {
+    PairArgs a = make_args(c, r0, r1, (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, c->replay_on ? c->d_flags_dev.p : nullptr,
+                           c->flag_cap_dev, c->timed_pairs);
+    a.out_base = c->h_row_off[s1_begin];
+    a.flag_text = 0;  // these records stay on the device: only numerically ill-conditioned pairs are replayed
+    HIP_TRY(c, timed_launch(c, a, st));
+    r0 = r1;
+  }
+  c->dev_run.dev_applied = false;
+  if (c->replay_on) {
+    int rcd = device_replay(c, c->d_flags_dev.p, c->flag_cap_dev, c->h_row_off[s1_begin], c->timed_pairs,
+                            (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, st);
+    if (rcd != NGSLD_OK) return rcd;
+    // likelihood matrices: right behind the kernels when the exact store is there (or costs nothing); a run that turns out to
+    // flag many pairs without one has it built in ngsld_finish_device
+    if (lkl_device_eligible(c) && (c->exact_ready || exact_store_is_free(c))) {
+      rcd = ensure_exact_store(c);
+      if (rcd == NGSLD_OK)
+        rcd = device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, c->h_row_off[s1_begin], c->timed_pairs,
+                                (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, st);
+      if (rcd != NGSLD_OK) return rcd;
+      c->dev_run.dev_applied = true;
+    }
+    // which pairs the kernels flagged (and the device has not settled itself): the counter and the list come over behind
+    // them, on their stream
+    HIP_TRY(c, hipMemcpyAsync(c->h_flags_dev.p, c->d_flags_dev.p, flag_head_bytes(c->flag_cap_dev), hipMemcpyDeviceToHost, st));
+  }
+  c->dev_run.pending = true;
+  c->dev_run.s1_begin = s1_begin;
+  c->dev_run.s1_end = s1_end;
+  c->dev_run.d_std = (ngsld_rec_std *)d_std;
+  c->dev_run.d_ext = (ngsld_rec_ext *)d_ext;
+  c->dev_run.st = st;
+  if (hip_stream == nullptr) {
+    const int rcd = finish_device_run(c);  // waits for the kernels, replays what they flagged
+    if (rcd != NGSLD_OK) return rcd;
+    return check_status(c);
+  }
+  return NGSLD_OK;  // (the caller's stream: the records are final after ngsld_finish_device)
+} NGSLD_CATCH(c)
+
+int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user) try {
+  if (c == nullptr || sink == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->planned) return fail(c, NGSLD_ERR_INVALID, "ngsld_plan has not been called");
+  if (s1_begin > s1_end || s1_end > c->n_sites) return fail(c, NGSLD_ERR_INVALID, "row range out of bounds");
+  HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
+  Range range_("ngsld:run");
+  {
+    const int rcp = finish_device_run(c);  // (see ngsld_run_device)
+    if (rcp != NGSLD_OK) return rcp;
+  }
+  const bool ext = c->params.extend_out != 0;
+  c->ev_used = 0;
+  c->timed_stream = c->stream;
+  c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
+  c->replayed_pairs = 0;
+  c->replayed_on_device = 0;
+  c->flagged_pairs = 0;
+  const bool replay = c->replay_on;
+  if (c->reserve_thread.joinable()) c->reserve_thread.join();  // (ngsld_reserve_text_buffers: h_text[] is this thread's again)
+
+  // Device-side TSV: the dist column needs prefix sums of pos_dist that are EXACT (the host writer adds the gaps one
+  // by one, ngsLD.cpp:241), i.e. integer gaps as read_dist produces them; otherwise the batches go out as records.
+  bool text = c->text_mode;
+  if (text) {
+    const uint64_t n = c->n_sites;
+    std::vector<double> cum(n);
+    std::vector<uint32_t> infc(n);
+    double run = 0.0;
+    uint32_t ic = 0;
+    for (uint64_t s = 0; s < n && text; ++s) {
+      const double g = c->h_pos_dist[s];
+      if (std::isinf(g) && g > 0) {
+        ++ic;
+      } else {
+        if (!(g >= 0.0) || g != std::floor(g) || run + g > 9.0e15) text = false;
+        run += g;
+      }
+      cum[s] = run;
+      infc[s] = ic;
+    }
+    if (text) {
+      HIP_TRY(c, c->d_cum.resize(n));
+      HIP_TRY(c, c->d_infc.resize(n));
+      HIP_TRY(c, hipMemcpy(c->d_cum.p, cum.data(), n * sizeof(double), hipMemcpyHostToDevice));
+      HIP_TRY(c, hipMemcpy(c->d_infc.p, infc.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+  }
+  auto need_host_items = [&]() -> int { return ensure_host_items(c); };
+  if (!text) {  // (record batches carry their items to the sink; text batches need none -- the replay finds its pairs on the device)
+    const int rc0 = need_host_items();
+    if (rc0 != NGSLD_OK) return rc0;
+  }
+  // How the batches flow: two slots, the kernel of batch k + 1 runs while batch k is consumed.  Text: the rows are formatted
+  // on the device and copied.  Records: the pair kernels write them straight into the slot's pinned host buffers
+  // (run_direct; nothing is left to copy behind the last kernel; twice the pairs per batch, half the launches), or into
+  // device buffers with a D2H copy per batch, the batches then shrinking towards the end of the run (run_taper).
+  // NGSLD_RUN_STREAMS=2: three slots, two compute streams half a batch out of phase (see ngsld_ctx).
+  const bool direct = !text && c->run_direct;
+  // Text batches are small (2^19 rows: a 2.8 ms pair kernel, a tenth of it ramp and drain) and many: for them the two compute
+  // streams half a batch out of phase DO pay, on every box -- while one stream's kernel drains the other's is in full
+  // flight: configs[2]'s loop 0.58-0.63 -> 0.546-0.551 s (profiles/r04/e2e_text_streams.txt).  NGSLD_TEXT_STREAMS=1: one stream.
+  bool text_two = true;
+  if (const char *e = std::getenv("NGSLD_TEXT_STREAMS")) text_two = std::atoi(e) != 1;
+  const bool two_streams = text ? text_two : c->run_streams == 2;
+  c->timed_overlap = two_streams;  // (ngsld_last_kernel_time: launches on two streams share the device -- first start .. last end)
+  // (text on ONE stream with three slots, two batches queued ahead, measured no different from two slots: the compute stream
+  // does not run dry, profiles/r04/e2e_timeline.txt)
+  const int S = two_streams ? ngsld_ctx::kSlots : 2;
+  struct Batch {
+    uint64_t r0, r1, n;
+  };
+  std::vector<Batch> batches;
+  // text batches are cut sixteen times finer: smaller batches mean smaller pinned buffers and a finer kernel / copy overlap
+  // (kTextBatchPairs; round 1, configs[2] end to end: 2^23 pairs per batch 2.2 s, 2^21 1.5 s)
+  // (records written by the kernels themselves: every launch costs ~0.4 ms of drain and nothing has to be staged on the
+  // device, so the batches are twice the size -- 2 x 1.2 GB of pinned host memory with the extended record)
+  uint64_t batch_pairs = text ? std::min<uint64_t>(c->batch_pairs, kTextBatchPairs)
+                              : ((direct && !c->batch_pairs_set) ? 2 * c->batch_pairs : c->batch_pairs);
+  const bool taper = !text && !direct && c->run_taper;
+  uint64_t cap = 1, last_cap = 0;
+  for (;;) {  // (a second trip only when the pinned record buffers of this batch size cannot be had: half the size then)
+    batches.clear();
+    uint64_t left = c->timed_pairs;
+    for (uint64_t r0 = s1_begin; r0 < s1_end;) {
+      uint64_t target = batch_pairs;
+      if (two_streams && batches.empty()) target = batch_pairs / 2;  // (the phase shift between the two streams)
+      if (taper) target = std::min<uint64_t>(batch_pairs, std::max<uint64_t>(left / 3, std::min<uint64_t>(batch_pairs, 1ull << 19)));
+      uint64_t r1 = r0 + 1;
+      while (r1 < s1_end && c->h_row_off[r1 + 1] - c->h_row_off[r0] <= target) ++r1;
+      batches.push_back({r0, r1, c->h_row_off[r1] - c->h_row_off[r0]});
+      left -= std::min(left, c->h_row_off[r1] - c->h_row_off[r0]);
+      r0 = r1;
+    }
+    cap = 1;
+    for (auto &b : batches) cap = std::max(cap, b.n);
+    if (text) break;
+    // the batches' host buffers: pinned memory is the scarce kind -- a host that cannot pin two (three) buffers of this size
+    // gets batches of half the size instead of an error, down to 2^20 pairs
+    hipError_t e = hipSuccess;
+    if (const char *lim = std::getenv("NGSLD_PIN_LIMIT_BYTES"))  // tests: a host that cannot pin more than this per buffer
+      if (cap * sizeof(ngsld_rec_std) > std::strtoull(lim, nullptr, 10)) e = hipErrorOutOfMemory;
+    for (int k = 0; k < S && e == hipSuccess; ++k) {
+      e = c->h_std[k].resize(cap);
+      if (e == hipSuccess && ext) e = c->h_ext[k].resize(cap);
+    }
+    if (e == hipSuccess) break;
+    (void)hipGetLastError();
+    // (a batch holds at least one row: once the largest row is what sets `cap`, halving the target changes nothing)
+    if (cap <= (1ull << 16) || batches.size() >= (1u << 20) || cap == last_cap || batch_pairs <= 1)
+      return hip_fail(c, e, "pinned host buffers of a record batch");
+    last_cap = cap;
+    batch_pairs = std::min(batch_pairs, cap);  // (a run smaller than a batch: halve what it actually needed)
+    for (int k = 0; k < S; ++k) {
+      c->h_std[k].release();
+      c->h_ext[k].release();
+    }
+    batch_pairs /= 2;
+  }
+  if (uses_runs(c->cfg.kernel)) {
+    // every batch should be thousands of workgroups (512 run at a time): the smaller the batches, the shorter the runs.
+    // configs[2] as text (48 batches of 2^21 pairs): 16 items per run 0.82 s for this loop, 8 0.72 s, 4 0.70 s
+    uint64_t want = kRunItems;
+    while (want > 2 && want * item_span(c->cfg, c->pairs_per_item) * 8192 > batch_pairs) want /= 2;
+    std::vector<uint64_t> ends;  // every batch is a launch: its last rows go out as short runs (build_runs)
+    for (auto &b : batches) ends.push_back(b.r1);
+    const int rcr = build_runs(c, want, ends);
+    if (rcr != NGSLD_OK) return rcr;
+  }
+  for (int k = 0; k < S; ++k) {
+    if (!direct) {
+      HIP_TRY(c, c->d_std[k].resize(cap));
+      if (ext) HIP_TRY(c, c->d_ext[k].resize(cap));
+    }
+    if (text) {
+      HIP_TRY(c, c->d_lens[k].resize(cap));
+      HIP_TRY(c, c->d_offs[k].resize(cap));
+      HIP_TRY(c, c->d_text_meta[k].resize(3));  // {total bytes, needs_host, a replayed row changed its length}
+      HIP_TRY(c, c->h_text_meta[k].resize(3));
+    }
+    if (replay) {
+      c->flag_cap[k] = flag_cap_for(cap);
+      HIP_TRY(c, c->d_flags[k].resize(flag_words(cap, c->flag_cap[k])));
+      HIP_TRY(c, c->h_flags[k].resize(flag_head_words(c->flag_cap[k])));
+    }
+  }
+  // (run_direct: the device addresses of the pinned host buffers -- the same numbers under unified addressing, asked for anyway)
+  ngsld_rec_std *dev_std[ngsld_ctx::kSlots] = {nullptr, nullptr, nullptr};
+  ngsld_rec_ext *dev_ext[ngsld_ctx::kSlots] = {nullptr, nullptr, nullptr};
+  for (int k = 0; k < S; ++k) {
+    if (direct) {
+      HIP_TRY(c, hipHostGetDevicePointer((void **)&dev_std[k], c->h_std[k].p, 0));
+      if (ext) HIP_TRY(c, hipHostGetDevicePointer((void **)&dev_ext[k], c->h_ext[k].p, 0));
+    } else {
+      dev_std[k] = c->d_std[k].p;
+      dev_ext[k] = ext ? c->d_ext[k].p : nullptr;
+    }
+  }
+  size_t scan_bytes = 0;
+  if (text) {
+    scan_bytes = text_scan_temp_bytes(cap);
+    HIP_TRY(c, c->d_scan_tmp.resize(scan_bytes ? scan_bytes : 1));
+    if (two_streams) HIP_TRY(c, c->d_scan_tmp_b.resize(scan_bytes ? scan_bytes : 1));
+    if (replay) HIP_TRY(c, c->d_scan_tmp2.resize(scan_bytes ? scan_bytes : 1));
+  }
+  auto text_args = [&](const Batch &b, int k) -> TextArgs {
+    TextArgs t{};
+    t.items = c->d_items.p + c->h_item_off[b.r0];
+    t.n_items = c->h_item_off[b.r1] - c->h_item_off[b.r0];
+    t.out_base = c->h_row_off[b.r0];
+    t.n_pairs = b.n;
+    t.std_rec = c->d_std[k].p;
+    t.ext_rec = ext ? c->d_ext[k].p : nullptr;
+    t.maf = c->d_maf.p;
+    t.cum = c->d_cum.p;
+    t.infc = c->d_infc.p;
+    t.labels = c->have_labels ? c->d_labels.p : nullptr;
+    t.label_off = c->d_label_off.p;
+    t.lens = c->d_lens[k].p;
+    t.offs = c->d_offs[k].p;
+    t.text = c->d_text[k].p;
+    t.needs_host = reinterpret_cast<int *>(c->d_text_meta[k].p + 1);
+    return t;
+  };
+  std::vector<Item> rel_items;
+  std::vector<uint64_t> recs;
+  std::vector<uint32_t> rep_s1, rep_s2;
+  auto issue = [&](size_t bi) -> int {  // kernel on a compute stream; text: lengths behind it; records: D2H on `copy_stream`
+    Range range_issue("ngsld:issue batch (pair kernel + D2H)");
+    const int k = (int)(bi % (size_t)S);
+    const Batch &b = batches[bi];
+    hipStream_t st = (two_streams && (bi & 1)) ? c->stream2 : c->stream;
+    if (replay) {
+      const int rcf = reset_flags(c, c->d_flags[k], b.n, c->flag_cap[k], st);
+      if (rcf != NGSLD_OK) return rcf;
+    }
+    PairArgs a = make_args(c, b.r0, b.r1, dev_std[k], dev_ext[k], replay ? c->d_flags[k].p : nullptr, c->flag_cap[k], b.n);
+    HIP_TRY(c, timed_launch(c, a, st));
+    c->slot_dev_applied[k] = false;
+    if (replay) {  // (called genotypes: the flagged pairs settled on the device, before anything reads the records)
+      int rcd = device_replay(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], st);
+      if (rcd != NGSLD_OK) return rcd;
+      // (likelihoods: the same once the exact store is there -- a batch issued before that is settled when it is consumed)
+      if (lkl_device_eligible(c) && (c->exact_ready || exact_store_is_free(c))) {
+        rcd = ensure_exact_store(c);
+        if (rcd == NGSLD_OK)
+          rcd = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], st);
+        if (rcd != NGSLD_OK) return rcd;
+        c->slot_dev_applied[k] = true;
+      }
+    }
+    // which pairs the kernel flagged for the exact-order replay (counter + list, 32 KB): known to the host with the batch.
+    // On the kernel's own stream, right behind it: on the copy stream, behind the records, this small copy took 9 ms per
+    // batch -- it goes through a copy kernel, and that waited for the next batch's pair kernel to leave it a CU
+    if (replay)
+      HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, flag_head_bytes(c->flag_cap[k]), hipMemcpyDeviceToHost, st));
+    if (text) {  // row lengths and their prefix sums right behind the pair kernel; the rows are written at consume time
+      HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), st));
+      const TextArgs t = text_args(b, k);
+      HIP_TRY(c, launch_text_lengths(t, st));
+      HIP_TRY(c, text_scan(st == c->stream ? c->d_scan_tmp.p : c->d_scan_tmp_b.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n,
+                           c->d_text_meta[k].p, st));
+      HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(c, hipEventRecord(c->ev_kernel_done[k], st));
+      return NGSLD_OK;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_kernel_done[k], st));
+    if (direct) return NGSLD_OK;  // (the records are in host memory when the kernel is done)
+    HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_kernel_done[k], 0));
+    if (b.n) {
+      HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, c->d_std[k].p, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost,
+                                c->copy_stream));
+      if (ext)
+        HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, c->d_ext[k].p, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost,
+                                  c->copy_stream));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_copy_done[k], c->copy_stream));
+    return NGSLD_OK;
+  };
+  int rc = NGSLD_OK;
+  const bool trace = std::getenv("NGSLD_TRACE") != nullptr;  // dev: per-batch host timeline on stderr
+  const auto t_run = std::chrono::steady_clock::now();
+  auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run).count(); };
+  // S - 1 batches are in flight while one is consumed: the slot of batch bi + S - 1 was last used by batch bi - 1, whose
+  // sink call has returned
+  for (size_t bi = 0; rc == NGSLD_OK && bi + 1 < (size_t)S && bi < batches.size(); ++bi) rc = issue(bi);
+  for (size_t bi = 0; rc == NGSLD_OK && bi < batches.size(); ++bi) {
+    const int k = (int)(bi % (size_t)S);
+    const double t_a = now_ms();
+    if (bi + (size_t)S - 1 < batches.size()) {
+      rc = issue(bi + (size_t)S - 1);
+      if (rc != NGSLD_OK) break;
+    }
+    const double t_b = now_ms();
+    const Batch &b = batches[bi];
+    const uint64_t i0 = c->h_item_off[b.r0], i1 = c->h_item_off[b.r1];
+    ngsld_batch out{};
+    out.s1_begin = b.r0;
+    out.s1_end = b.r1;
+    out.n_pairs = b.n;
+    bool as_records = !text;
+    Range range_wait(text ? "ngsld:consume batch (text rows, D2H, replay, sink)" : "ngsld:consume batch (wait for records, replay, sink)");
+    if (text) {
+      // the batch's text: its length is known now; the rows are written and copied on the copy stream while the pair
+      // kernel of the next batch (already enqueued) runs on the compute stream
+      HIP_TRY(c, hipEventSynchronize(c->ev_kernel_done[k]));
+      if (replay) c->flagged_pairs += c->h_flags[k].p[0];
+      if (replay && c->h_flags[k].p[0] != 0) {
+        bool applied = c->slot_dev_applied[k];
+        if (!applied && exact_store_wanted(c, c->h_flags[k].p[0] - c->h_flags[k].p[1])) {
+          // a likelihood matrix that flags more pairs than the host should replay, and this batch went out before the exact
+          // store was there: build it (once), replay the batch's pairs on the device, take every row's length again
+          int rcx = ensure_exact_store(c);
+          if (rcx == NGSLD_OK)
+            rcx = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, c->d_std[k].p,
+                                    ext ? c->d_ext[k].p : nullptr, c->copy_stream);
+          if (rcx != NGSLD_OK) return rcx;
+          HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, flag_head_bytes(c->flag_cap[k]), hipMemcpyDeviceToHost, c->copy_stream));
+          HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), c->copy_stream));
+          const TextArgs t = text_args(b, k);
+          HIP_TRY(c, launch_text_lengths(t, c->copy_stream));
+          HIP_TRY(c, text_scan(c->d_scan_tmp2.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n, c->d_text_meta[k].p, c->copy_stream));
+          HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
+          HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+          applied = true;
+        }
+        // flagged pairs: replayed on the host, patched into the device records, and the row lengths derived again --
+        // all on the copy stream, beside the next batch's pair kernel
+        int rcr = flagged_records(c, c->h_flags[k].p, c->d_flags[k].p, c->flag_cap[k], b.n, recs, applied);
+        if (rcr == NGSLD_OK)
+          rcr = replay_flagged(c, recs, c->h_row_off[b.r0], nullptr, nullptr, c->d_std[k].p, ext ? c->d_ext[k].p : nullptr,
+                               c->copy_stream, &rep_s1, &rep_s2);
+        if (rcr != NGSLD_OK) return rcr;
+        // Only the replayed rows' lengths are derived again (replay_flagged left their record indices in d_patch_idx); the
+        // prefix sums are taken again only if one of them changed -- a full length pass + scan beside the next batch's pair
+        // kernel cost that kernel ~1 ms of every 11 (profiles/r04/e2e_timeline.txt)
+        if (!recs.empty()) {
+          HIP_TRY(c, c->d_patch_s1.resize(recs.size()));
+          HIP_TRY(c, c->d_patch_s2.resize(recs.size()));
+          HIP_TRY(c, hipMemcpyAsync(c->d_patch_s1.p, rep_s1.data(), recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
+          HIP_TRY(c, hipMemcpyAsync(c->d_patch_s2.p, rep_s2.data(), recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
+          HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p + 2, 0, sizeof(uint64_t), c->copy_stream));
+          const TextArgs t = text_args(b, k);
+          HIP_TRY(c, launch_text_relength(t, c->d_patch_idx.p, c->d_patch_s1.p, c->d_patch_s2.p, recs.size(), c->d_text_meta[k].p + 2,
+                                          c->copy_stream));
+          HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                    c->copy_stream));
+          HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+          if (c->h_text_meta[k].p[2] != 0) {
+            HIP_TRY(c, text_scan(c->d_scan_tmp2.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n, c->d_text_meta[k].p, c->copy_stream));
+            HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                      c->copy_stream));
+            HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+          }
+        }
+      }
+      const uint64_t total = c->h_text_meta[k].p[0];
+      bool needs_host = (c->h_text_meta[k].p[1] & 0xffffffffull) != 0;
+      if (const char *e = std::getenv("NGSLD_TEXT_FALLBACK_EVERY")) {  // tests: every n-th batch takes the record path
+        const uint64_t every = std::strtoull(e, nullptr, 10);
+        if (every > 0 && bi % every == every - 1) needs_host = true;
+      }
+      if (needs_host) {
+        as_records = true;  // a value beyond the device formatter's fast path: this batch goes out as records
+        HIP_TRY(c, c->h_std[k].resize(cap));
+        if (ext) HIP_TRY(c, c->h_ext[k].resize(cap));
+        if (b.n) {
+          HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, c->d_std[k].p, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost,
+                                    c->copy_stream));
+          if (ext)
+            HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, c->d_ext[k].p, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost,
+                                      c->copy_stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+        const int rc1 = need_host_items();
+        if (rc1 != NGSLD_OK) return rc1;
+      } else {
+        if (total > c->d_text[k].n) HIP_TRY(c, c->d_text[k].resize(total + total / 8));
+        if (total > c->h_text[k].n) HIP_TRY(c, c->h_text[k].resize(total + total / 8));
+        if (total) {
+          const TextArgs t = text_args(b, k);
+          HIP_TRY(c, launch_text_write(t, c->copy_stream));
+          HIP_TRY(c, hipMemcpyAsync(c->h_text[k].p, c->d_text[k].p, total, hipMemcpyDeviceToHost, c->copy_stream));
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+        out.text = c->h_text[k].p;
+        out.text_len = total;
+      }
+    } else {
+      HIP_TRY(c, hipEventSynchronize(direct ? c->ev_kernel_done[k] : c->ev_copy_done[k]));
+      if (trace) std::fprintf(stderr, "[trace] batch %zu (%llu pairs): issue next %.2f..%.2f, records on the host %.2f, flagged %u\n", bi, (unsigned long long)b.n, t_a, t_b, now_ms(), replay ? c->h_flags[k].p[0] : 0u);
+      if (replay) c->flagged_pairs += c->h_flags[k].p[0];
+      if (replay && c->h_flags[k].p[0] != 0) {  // flagged pairs: replayed on the host, patched into the batch's buffers
+        bool applied = c->slot_dev_applied[k];
+        if (!applied && exact_store_wanted(c, c->h_flags[k].p[0] - c->h_flags[k].p[1])) {  // (see the text branch above)
+          int rcx = ensure_exact_store(c);
+          if (rcx == NGSLD_OK)
+            rcx = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], c->copy_stream);
+          if (rcx != NGSLD_OK) return rcx;
+          HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, flag_head_bytes(c->flag_cap[k]), hipMemcpyDeviceToHost, c->copy_stream));
+          if (!direct && b.n) {  // (the records had been copied already: once more)
+            HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, c->d_std[k].p, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost, c->copy_stream));
+            if (ext)
+              HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, c->d_ext[k].p, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost, c->copy_stream));
+          }
+          HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+          applied = true;
+        }
+        int rcr = flagged_records(c, c->h_flags[k].p, c->d_flags[k].p, c->flag_cap[k], b.n, recs, applied);
+        if (rcr == NGSLD_OK)
+          rcr = replay_flagged(c, recs, c->h_row_off[b.r0], c->h_std[k].p, ext ? c->h_ext[k].p : nullptr, nullptr, nullptr, nullptr);
+        if (rcr != NGSLD_OK) return rcr;
+      }
+    }
+    if (as_records) {
+      rel_items.assign(c->h_items.begin() + (ptrdiff_t)i0, c->h_items.begin() + (ptrdiff_t)i1);
+      for (auto &it : rel_items) it.first_record -= c->h_row_off[b.r0];
+      out.n_items = i1 - i0;
+      out.items = rel_items.data();
+      out.std = c->h_std[k].p;
+      out.ext = ext ? c->h_ext[k].p : nullptr;
+    }
+    if (trace) std::fprintf(stderr, "[trace] batch %zu: replay done %.2f\n", bi, now_ms());
+    Range range_sink("ngsld:sink");
+    if (sink(user, &out) != 0) rc = fail(c, NGSLD_ERR_SINK, "sink callback failed");
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream2));
+  HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+  if (rc != NGSLD_OK) return rc;
+  return check_status(c);
+} NGSLD_CATCH(c)
+
+int ngsld_last_kernel_time(ngsld_ctx *c, double *total_ms, uint64_t *n_launches, uint64_t *n_pairs) {
+  if (c == nullptr) return NGSLD_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
+  if (c->timed_stream) HIP_TRY(c, hipStreamSynchronize(c->timed_stream));
+  if (c->timed_overlap) HIP_TRY(c, hipStreamSynchronize(c->stream2));
+  double ms = 0.0;
+  for (size_t k = 0; k < c->ev_used; ++k) {
+    float t = 0.f;
+    // launches that shared the device (two streams): the span from the first start to the last end, not the sum
+    HIP_TRY(c, hipEventElapsedTime(&t, c->timed_overlap ? c->ev_pool[0].first : c->ev_pool[k].first, c->ev_pool[k].second));
+    ms = c->timed_overlap ? std::max(ms, (double)t) : ms + (double)t;
+  }
+  if (total_ms) *total_ms = ms;
+  if (n_launches) *n_launches = c->ev_used;
+  if (n_pairs) *n_pairs = c->timed_pairs;
+  return NGSLD_OK;
+}
+
+}  // extern "C"

@@ -40,16 +40,25 @@ constexpr int kIterMax = 100;      // ITER_MAX, gen_func.hpp:18
 constexpr double kEpsilon = 1e-5;  // EPSILON,  gen_func.hpp:16
 
 // Exact-order replay (replay.h): the kernels FLAG the pairs whose outcome the reference's own rounding decides and the
-// engine re-evaluates those on the host in the reference's operation order.  A pair is flagged when
-//   * a hap-derived allele frequency 1 - (f0 + f1) / 1 - (f0 + f2) (ngsLD.cpp:297-298) is within kReplayBelow of 0 or 1:
-//     it carries ~1e-16 of ABSOLUTE rounding noise in the reference, so D' and r2 (quotients by products of these
-//     margins) are only reproducible to 1e-16 / q -- below 2^-16 that is no longer safely inside 1e-9, and at q ~ 1e-16
-//     the noise alone decides between nan, 0 and inf -- or any frequency is NaN;
+// engine re-evaluates those in the reference's operation order (on the device where the reference's input bits are to be had
+// there: ld_replay.hip, ld_replay_lkl.hip; on the host otherwise).  A pair is flagged when
+//   * D' or r2 is not reproducible to kRecordTol: the hap-derived allele frequencies 1 - (f0 + f1) / 1 - (f0 + f2)
+//     (ngsLD.cpp:297-298) carry ~1e-16 of ABSOLUTE rounding noise in the reference and here alike, D' and r2 are quotients by
+//     products of these margins q, so the two evaluations differ by ~ noise * (1 / q0 + 1 / q1) * the value itself.  The
+//     noise is taken as kHapNoise = 2^-50 (8.9e-16: twice what a 39,000-case soak showed -- differences up to 1.1e-10 right
+//     above a then fixed threshold q >= 2^-18, i.e. 4.2e-16), the tolerance as a quarter of the 1e-9 bar.  Below
+//     kReplayFloor the margins themselves may be exact zeros on one side and not on the other (0/0-type quotients: nan,
+//     0 or inf by the noise alone): every such pair is flagged whatever its values;
+//     (rounds 2-4 flagged every pair with q < 2^-16 / 2^-18: on matrices that are not SNP-called that is 40 % of the pairs,
+//     the derived bound 35 %, profiles/r05)
+//   * any frequency is NaN;
 //   * eps came within kTieMargin of EPSILON in some iteration (gen_func.cpp:1054: nIter could differ by one);
 //   * the Pearson cross moment is ill conditioned for THIS pair (kPearsonCond): sites whose expected genotypes are nearly
 //     constant -- at the extreme gsl_stats_correlation is a 0/0-type quotient of its own accumulation noise
 //     (ngsLD.cpp:365-367).
-constexpr double kReplayBelow = 0x1p-16;  // (at 2^-18 a 39,000-case soak showed differences up to 1.1e-10 just above the threshold: a 9x margin to the 1e-9 bar; 2^-16 makes it ~36x)
+constexpr double kHapNoise = 0x1p-50;
+constexpr double kRecordTol = 2.5e-10;
+constexpr double kReplayFloor = 0x1p-30;
 constexpr double kTieMargin = 1e-12;
 // r = sxy * rsx1 * rsx2 with sxy = sum e1 e2 - n mean1 mean2: the cancellation leaves ~20 ulp * n * size1 * size2 of noise
 // in sxy (size = the expected genotypes' magnitude, <= 2), i.e. |delta r2| <~ 1.8e-14 * n * rsx1 * rsx2.  Pairs with
@@ -59,14 +68,17 @@ constexpr double kTieMargin = 1e-12;
 constexpr double kPearsonCond = 0x1p13;
 constexpr double kEpsilonTie = kEpsilon + kTieMargin;
 constexpr uint32_t kTieBit = 0x80000000u;  // rides on n_iter (<= 100) from the EM loop to write_pair
-// Layout of a launch's flag buffer (uint32 words): [0] count of flagged pairs, [1] unused, [2 .. 2 + 2 cap) the record
-// indices (uint64) of the first `cap` flagged pairs in the order their atomics landed, [2 + 2 cap ...) one bit per record;
+// Layout of a launch's flag buffer (uint32 words): [0] count of flagged pairs, [1] count of those that are kFlagHostOnly,
+// [2] pairs the device-side replay of likelihood matrices (ld_replay_lkl.hip) has settled, [3] its work counter,
+// [4 .. 4 + 2 cap) the record indices (uint64) of the first `cap` flagged pairs in the order their atomics landed,
+// [4 + 2 cap ...) one bit per record, and behind that bitmap (PairArgs::flags_host) a second one: the kFlagHostOnly pairs;
 // cap = PairArgs::flag_cap, set by the engine from the launch's size (flag_cap_for).  A launch of 10^8 likelihood pairs flags
 // a few dozen, one of called genotypes 26,000 (exact ties of eps with EPSILON): the host reads the head and never the bitmap.
 // A list entry's top bits: kFlagHostOnly -- the pair was flagged for a reason only the host's replay settles (its r2_ExpG:
 // GSL's long double recurrence) --, kFlagDone -- the device-side replay (ld_replay.hip) has already rewritten the record.
 constexpr uint64_t kFlagHostOnly = 1ull << 63, kFlagDone = 1ull << 62, kFlagIndexMask = (1ull << 62) - 1;
-__host__ __device__ inline uint32_t flag_head_words(uint32_t cap) { return 2u + 2u * cap; }
+constexpr uint32_t kFlagListAt = 4;  // first word of the list
+__host__ __device__ inline uint32_t flag_head_words(uint32_t cap) { return kFlagListAt + 2u * cap; }
 
 // One unit of work = ngsld_item: pairs (s1, s2_begin + c) for the bits c set in mask, records from first_record.
 typedef ngsld_item Item;
@@ -108,6 +120,7 @@ struct PairArgs {
   // (flag_list(): what the host reads back is the counter and that list -- 32 KB whatever the launch's size -- and the
   // bitmap only when more pairs were flagged than the list holds)
   uint32_t *flags;
+  uint32_t *flags_host;  // second bitmap (one bit per record): the flagged pairs only the host's replay settles (may be null)
   uint32_t flag_cap;   // entries of the list in flags
   uint32_t flag_text;  // also flag the pairs whose printed digits (six decimals) rounding noise could change
   // tiled workgroup order of the multi-wavefront kernel (launch_pair_kernel; tile_nk == 0: workgroup i takes item i):
@@ -719,7 +732,7 @@ __device__ __forceinline__ bool near_rounding(double v, double d) {
 }
 
 // ngsLD.cpp:296-306 (hap-derived maf, D, D', r2) + pearson_r, one record per pair; pairs whose outcome the reference's
-// rounding decides are flagged for the exact-order replay (see kReplayBelow).
+// rounding decides are flagged for the exact-order replay (see kHapNoise / kReplayFloor above).
 __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, double f0, double f1, double f2,
                                            double f3, double sxy, double rsx1, double rsx2, uint32_t x,
                                            uint32_t n_iter) {
@@ -760,7 +773,9 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
     // (NaN frequencies fail both comparisons)
     // host_only: reasons that concern r2_ExpG -- what the device-side replay of called genotypes (ld_replay.hip) leaves alone
     bool host_only = odd_site || (!constant_site && (double)A.n_ind * a1 * a2 > kPearsonCond);  // (a constant site: NaN on every path)
-    bool flag = tie || host_only || !(q0 >= kReplayBelow) || !(q1 >= kReplayBelow);
+    // (written so that a NaN anywhere -- frequencies, D', r2 -- flags the pair)
+    const double amp_q = 1.0 / q0 + 1.0 / q1, big = fabs(Dp) >= o.r2 ? fabs(Dp) : o.r2;
+    bool flag = tie || host_only || !(q0 >= kReplayFloor) || !(q1 >= kReplayFloor) || !(kHapNoise * amp_q * big <= kRecordTol);
     // The TSV prints six decimals (ngsLD.cpp:314-349).  A value that sits on a rounding point of the sixth decimal --
     // closer to it than this kernel and the reference can differ -- would print a different last digit, and a D within
     // rounding noise of zero a different sign ("-0.000000"): those pairs are replayed too, so that the text is the
@@ -769,7 +784,7 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
     // (flag_text: only where the records may become text -- ngsld_run; ngsld_run_device leaves them on the device)
     constexpr double kUlp = 0x1p-52;
     const double d_abs = A.flag_text ? 32 * kUlp : -1.0;  // (negative: near_rounding is never true)
-    const double amp = A.flag_text ? 1.0 / q0 + 1.0 / q1 : 0.0;
+    const double amp = A.flag_text ? amp_q : 0.0;
     host_only = host_only || near_rounding(o.r2_ExpG, 0.5 * d_abs * (1.0 + 4.0 * (double)A.n_ind * a1 * a2));
     flag = flag || host_only || fabs(D) < 2 * d_abs || near_rounding(D, d_abs) ||
            near_rounding(Dp, 2 * d_abs * (1.0 + fabs(Dp) * amp)) || near_rounding(o.r2, 2 * d_abs * (1.0 + o.r2 * amp));
@@ -778,8 +793,12 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
              near_rounding(f3, d_abs) || near_rounding(hm0, d_abs) || near_rounding(hm1, d_abs);
     if (flag) {
       atomicOr(&A.flags[flag_head_words(A.flag_cap) + (slot >> 5)], 1u << (slot & 31u));
+      if (host_only && A.flags_host != nullptr) {
+        atomicOr(&A.flags_host[slot >> 5], 1u << (slot & 31u));
+        atomicAdd(&A.flags[1], 1u);
+      }
       const uint32_t k = atomicAdd(&A.flags[0], 1u);
-      if (k < A.flag_cap) reinterpret_cast<uint64_t *>(A.flags + 2)[k] = slot | (host_only ? kFlagHostOnly : 0ull);
+      if (k < A.flag_cap) reinterpret_cast<uint64_t *>(A.flags + kFlagListAt)[k] = slot | (host_only ? kFlagHostOnly : 0ull);
     }
   }
 }

@@ -1,4 +1,5 @@
-// ld_replay.h -- launch interface of the device-side exact-order replay for called-genotype matrices (ld_replay.hip).
+// ld_replay.h -- launch interfaces of the device-side exact-order replays: called-genotype matrices (ld_replay.hip) and
+// genotype-likelihood matrices (ld_replay_lkl.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -28,5 +29,36 @@ struct ReplayHardArgs {
 
 // one lane per listed pair; n_records bounds the grid (a launch cannot flag more pairs than it has)
 hipError_t launch_replay_hard(const ReplayHardArgs &a, uint64_t n_records, hipStream_t stream);
+
+// ---- genotype likelihoods (ld_replay_lkl.hip) ----
+struct ReplayLklArgs {
+  const uint32_t *bits;       // the launch's flag bitmap: one bit per record (ld_device.h)
+  const uint32_t *host_bits;  // ... and the pairs among them that stay with the host (PairArgs::flags_host)
+  uint64_t n_records;         // records in the launch
+  uint32_t *work;             // chunk counter of the persistent teams, zero at launch
+  uint32_t *done;             // receives the number of pairs replayed (added to)
+  const uint64_t *row_off;    // [n_sites + 1] plan: records before each row
+  const uint64_t *item_off;   // [n_sites + 1] plan: items before each row
+  const ngsld_item *items;    // the plan's items
+  uint64_t n_items;
+  uint32_t n_sites;
+  uint64_t rec_base;          // plan index of the launch's record 0
+  // the exact store: normal-space likelihoods and est_maf as the REFERENCE holds them when calc_pair_LD runs (the host's
+  // libm, the sequential est_maf), laid out like the pair kernels' planes
+  const double *xplanes;      // [n_sites][3][np]
+  uint64_t site_stride;       // 3 * np
+  uint32_t np;
+  const double *xmaf;         // [n_sites]
+  uint32_t n_ind;
+  int ignore_miss;
+  ngsld_rec_std *out_std;     // the launch's records (device memory, or pinned host memory written in place)
+  ngsld_rec_ext *out_ext;     // may be null
+  int *status;
+};
+
+// wavefronts per pair for a cohort of n_ind individuals (1 up to 512, then 2 / 4 / 8); 0: beyond the kernel (host replay)
+uint32_t replay_lkl_waves(uint32_t n_ind);
+// a persistent grid sized for n_cus compute units walks the bitmap
+hipError_t launch_replay_lkl(const ReplayLklArgs &a, int n_cus, hipStream_t stream);
 
 }  // namespace ngsld

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64) void replay_hard_kernel(ReplayHardArgs A) {
   const uint32_t count = A.flags[0] < A.flag_cap ? A.flags[0] : A.flag_cap;
   const uint32_t e = blockIdx.x * 64u + (uint32_t)lane;
   if (e >= count) return;
-  uint64_t *list = reinterpret_cast<uint64_t *>(A.flags + 2);
+  uint64_t *list = reinterpret_cast<uint64_t *>(A.flags + kFlagListAt);
   const uint64_t entry = list[e];
   if (entry & (kFlagHostOnly | kFlagDone)) return;
   const uint64_t slot = entry & kFlagIndexMask;

@@ -1,0 +1,314 @@
+// ld_replay_lkl.hip -- exact-order replay ON THE DEVICE for genotype-LIKELIHOOD matrices (gfx950).
+//
+// Why.  The pair kernels flag the pairs whose outcome the reference's own rounding decides (ld_device.h, write_pair).  On
+// SNP-called input that is a few dozen pairs per 10^8 and the host replays them.  On matrices that are NOT SNP-called -- the
+// input the reference's README.md:73 warns about and its own examples/test.sh feeds -- every pair with a (nearly)
+// monomorphic site is such a pair: 35-40 % of the pairs at 20 % monomorphic sites.  Replayed on host threads at the
+// reference's own speed that was 2.2e6 pairs/s for a pass whose kernel runs 2.2e8 (profiles/r05/before).
+//
+// What.  The reference's evaluation of one pair (gen_func.cpp:1027-1119, ngsLD.cpp:296-306) is sequential over the
+// individuals only in ONE respect: the four running sums ff[k] += tmp_k / sum.  Everything an individual contributes to them
+// -- its 16-term `sum`, its four `tmp_k`, the four IEEE divisions -- depends on that individual and on f alone.  So a
+// WAVEFRONT owns a flagged pair: lane l holds individuals l, l + 64, ... (both sites' triples in registers for the whole pair,
+// loaded once, coalesced), computes their four quotients in the reference's own operation order -- products left to right,
+// no fused multiply-add (-ffp-contract=off), IEEE division -- and parks them in LDS in individual order; four lanes then
+// add them up one by one, in the reference's order (the chain: 4 x n_ind dependent additions per iteration, the one part
+// that cannot be spread over the lanes); then ff / (2x), the SEQUENTIAL renormalisation, haplo_freq's convergence test,
+// and after the loop D, D', r2 with a correctly rounded square root.  Same bits as the reference's loop.
+//
+// The inputs must be the reference's bits too: normal-space likelihoods as the HOST's libm leaves them (log -> post_prob ->
+// exp, read_data.cpp:37-45, ngsLD.cpp:110) and est_maf from its sequential loop (gen_func.cpp:974-1009).  The engine keeps
+// those in an "exact store" on the device (engine_replay.hip: built by host threads from the caller's raw values the first
+// time a run flags more pairs than the host should replay; ngsld_set_geno_lkl input IS such a store already), laid out
+// like the planes of the pair kernels: [site][genotype][np].
+//
+// r2_ExpG is left as the pair kernel wrote it (GSL's long double recurrence has no device twin): pairs flagged for a reason
+// that concerns it are marked in a second bitmap (PairArgs::flags_host) and stay with the host.
+//
+// Work distribution.  No list: the launch's flag BITMAP is the work queue.  A team (one wavefront per pair up to 512
+// individuals, 2 / 4 / 8 beyond) claims chunks of kChunkWords words with one atomic, walks their set bits and maps a record
+// index to its pair through a cursor over the plan's items (one binary search per chunk, then steps) -- records of one chunk
+// are neighbours in (s1, s2) order, so the row's vector stays in registers from pair to pair.
+#include "ld_device.h"
+#include "ld_replay.h"
+
+namespace ngsld {
+namespace {
+
+constexpr double kEps = 1e-5;  // EPSILON, gen_func.hpp:16
+constexpr int kMaxIter = 100;  // ITER_MAX, gen_func.hpp:18
+constexpr int kMaxSlots = 8;   // individuals per lane, at most (both sites' triples: 6 doubles each, in registers)
+constexpr uint32_t kChunkWords = 4;  // 128 records per claim
+
+__device__ __forceinline__ double ref_abs(double x) { return x >= 0 ? x : -x; }           // gen_func.hpp:21-23: macros
+__device__ __forceinline__ double ref_min(double a, double b) { return a <= b ? a : b; }
+
+// genotype at site 1 / site 2 of the haplotype pair (h, k): bit 1 = allele at site 1, bit 0 = allele at site 2
+__device__ __forceinline__ constexpr int geno1(int h, int k) { return ((h >> 1) & 1) + ((k >> 1) & 1); }
+__device__ __forceinline__ constexpr int geno2(int h, int k) { return (h & 1) + (k & 1); }
+
+// gen_func.cpp:862-868 on a normal-space triple (pair_freq_iter's use of it, :1089)
+__device__ __forceinline__ bool no_data(const double (&g)[3]) { return ref_abs(g[0] - g[1]) < kEps && ref_abs(g[1] - g[2]) < kEps; }
+
+// One individual's four quotients tmp_k / sum exactly as pair_freq_iter forms them (gen_func.cpp:1092-1104): the loops as
+// the reference writes them.  (f[k] * f[h] does not depend on the individual and the compiler takes it out of the slot
+// loop; the two products inside the parentheses are the same expression: both are exact rewrites, one rounding per
+// operation stays one rounding per operation.)
+__device__ __forceinline__ void quotients(const double (&f)[4], const double (&p)[3], const double (&q)[3], double (&out)[4]) {
+  double sum = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) sum += f[k] * f[h] * p[geno1(k, h)] * q[geno2(k, h)];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double tmp = 0;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) tmp += f[k] * f[h] * (p[geno1(h, k)] * q[geno2(h, k)] + p[geno1(k, h)] * q[geno2(k, h)]);
+    out[k] = tmp / sum;
+  }
+}
+
+// (s1, s2) of plan records met in increasing order: a full search for the first, steps afterwards
+struct Cursor {
+  uint64_t item = ~0ull;  // index into the plan's items
+  Item it;
+  uint32_t pop = 0;
+  __device__ __forceinline__ bool seek(const ReplayLklArgs &A, uint64_t rec, uint32_t *s1, uint32_t *s2) {
+    if (item == ~0ull || rec < it.first_record) {
+      uint32_t lo = 0, hi = A.n_sites;  // largest row with row_off[row] <= rec
+      while (lo + 1 < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (A.row_off[mid] <= rec) lo = mid; else hi = mid;
+      }
+      uint64_t il = A.item_off[lo], ih = A.item_off[lo + 1];
+      if (il >= ih) return false;
+      while (il + 1 < ih) {
+        const uint64_t mid = il + (ih - il) / 2;
+        if (A.items[mid].first_record <= rec) il = mid; else ih = mid;
+      }
+      item = il;
+      it = A.items[item];
+      pop = (uint32_t)__popcll(it.mask);
+    }
+    while (rec >= it.first_record + pop) {  // (items follow one another in record order; an item without a pair is stepped over)
+      if (++item >= A.n_items) return false;
+      it = A.items[item];
+      pop = (uint32_t)__popcll(it.mask);
+    }
+    uint64_t k = rec - it.first_record, mk = it.mask;
+    while (k--) mk &= mk - 1;
+    *s1 = it.s1;
+    *s2 = it.s2_begin + (uint32_t)(__ffsll((unsigned long long)mk) - 1);
+    return true;
+  }
+};
+
+template <int WAVES, int kSlots>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void replay_lkl_kernel(ReplayLklArgs A) {
+  constexpr int kRow = WAVES * kSlots * 64 + 2;  // doubles per row of quotients (+2: the four chain lanes read different banks)
+  __shared__ __attribute__((aligned(16))) double quo[4 * kRow];  // [haplotype][individual]
+  __shared__ double fnew[4];
+  __shared__ uint32_t sh_u32[2 + WAVES];  // [0] claimed chunk, [1] converged, [2 + w] individuals with data in wavefront w
+  const int lane = threadIdx.x & 63;
+  const int wave = WAVES == 1 ? 0 : (int)(threadIdx.x >> 6);
+  const bool ign = A.ignore_miss != 0;
+  const uint64_t n_words = (A.n_records + 31) / 32;
+  constexpr int kTeamSlots = WAVES * kSlots;  // slot t of the team holds individuals 64 t .. 64 t + 63
+  double a[kSlots][3], b[kSlots][3];
+  uint32_t row_site = 0xffffffffu;
+  for (;;) {
+    if (threadIdx.x == 0) sh_u32[0] = atomicAdd(A.work, 1u);
+    __syncthreads();
+    const uint64_t w0 = (uint64_t)sh_u32[0] * kChunkWords;
+    __syncthreads();
+    if (w0 >= n_words) break;
+    Cursor cur;
+    for (uint64_t w = w0; w < w0 + kChunkWords && w < n_words; ++w) {
+      uint32_t bits = A.bits[w] & ~A.host_bits[w];
+      bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)bits);
+      for (; bits; bits &= bits - 1) {
+        const uint64_t slot = w * 32 + (uint64_t)(__ffs((int)bits) - 1);
+        if (slot >= A.n_records) break;
+        uint32_t s1 = 0, s2 = 0;
+        if (!cur.seek(A, A.rec_base + slot, &s1, &s2)) continue;
+        s1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s1);
+        s2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s2);
+
+        // ---- the two sites: this lane's individuals, in registers for the whole pair ----
+        const double *pa = A.xplanes + (uint64_t)s1 * A.site_stride, *pb = A.xplanes + (uint64_t)s2 * A.site_stride;
+        uint32_t valid = 0;
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) {
+          const uint32_t i = (uint32_t)((wave * kSlots + j) * 64 + lane);
+          const bool in = i < A.n_ind;
+          if (s1 != row_site) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) a[j][g] = in ? pa[(uint64_t)g * A.np + i] : 0.0;
+          }
+#pragma unroll
+          for (int g = 0; g < 3; ++g) b[j][g] = in ? pb[(uint64_t)g * A.np + i] : 0.0;
+          if (in && !(ign && (no_data(a[j]) || no_data(b[j])))) valid |= 1u << j;  // gen_func.cpp:1089
+        }
+        row_site = s1;
+        uint32_t x = 0;
+#pragma unroll
+        for (int j = 0; j < kSlots; ++j) x += (uint32_t)__popcll(__ballot((valid >> j) & 1u));
+        if (WAVES > 1) {
+          if (lane == 0) sh_u32[2 + wave] = x;
+          __syncthreads();
+          x = 0;
+          for (int v = 0; v < WAVES; ++v) x += sh_u32[2 + v];
+        }
+
+        // ---- haplo_freq (gen_func.cpp:1027-1059) ----
+        const double m1 = A.xmaf[s1], m2 = A.xmaf[s2];
+        double f[4];
+        uint32_t iter = 0;
+        if (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1) {  // gen_func.cpp:1030-1031
+          if (threadIdx.x == 0) atomicExch(A.status, (int)NGSLD_ERR_MAF_RANGE);
+          f[0] = f[1] = f[2] = f[3] = __builtin_nan("");
+          x = 0;
+        } else {
+          f[0] = (1 - m1) * (1 - m2);
+          f[1] = (1 - m1) * m2;
+          f[2] = m1 * (1 - m2);
+          f[3] = m1 * m2;
+          for (iter = 0; iter < (uint32_t)kMaxIter; ++iter) {
+            // every individual's four quotients, parked in individual order (an individual left out adds +0: ff + 0 == ff)
+#pragma unroll
+            for (int j = 0; j < kSlots; ++j) {
+              // (the nine products p[g1] * q[g2] do not change from iteration to iteration and the compiler would keep them --
+              // 18 more registers per slot, spilled from six slots on; made opaque here they are formed again, 9 multiplies)
+#pragma unroll
+              for (int g = 0; g < 3; ++g) asm volatile("" : "+v"(b[j][g]));
+              double o[4];
+              quotients(f, a[j], b[j], o);
+              const bool on = (valid >> j) & 1u;
+              const int i = (wave * kSlots + j) * 64 + lane;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) quo[k * kRow + i] = on ? o[k] : 0.0;
+              __builtin_amdgcn_sched_barrier(0);  // (one slot at a time: interleaved, the slots' temporaries spill)
+            }
+            __syncthreads();
+            // the chain, gen_func.cpp:1103: ff[k] += tmp / sum, individual by individual
+            if (wave == 0) {
+              double ff = 0;
+              if (lane < 4) {
+                const double *r = quo + lane * kRow;
+#pragma unroll 4
+                for (int i = 0; i < kTeamSlots * 64; i += 2) {
+                  const double2 v = *reinterpret_cast<const double2 *>(r + i);
+                  ff += v.x;
+                  ff += v.y;
+                }
+              }
+              const double twox = (double)(2 * (uint64_t)x);  // gen_func.cpp:1109: 2 * x is an integer product
+              double g[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) g[k] = read_lane(ff, k) / twox;
+              g[0] /= g[0] + g[1] + g[2] + g[3];  // gen_func.cpp:1112-1113: sequential -- f[0] is already divided when f[1] is
+              g[1] /= g[0] + g[1] + g[2] + g[3];
+              g[2] /= g[0] + g[1] + g[2] + g[3];
+              g[3] /= g[0] + g[1] + g[2] + g[3];
+              double eps = 0;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const double d = fabs(g[k] - f[k]);
+                if (d > eps) eps = d;  // (a NaN never raises eps: an all-NaN step ends the loop here)
+              }
+              if (WAVES > 1 && lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) fnew[k] = g[k];
+                sh_u32[1] = eps < kEps ? 1u : 0u;
+              }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) f[k] = g[k];
+              if (WAVES == 1) {
+                if (eps < kEps) break;
+                continue;
+              }
+            }
+            if (WAVES > 1) {
+              __syncthreads();
+#pragma unroll
+              for (int k = 0; k < 4; ++k) f[k] = fnew[k];
+              const bool done = sh_u32[1] != 0;
+              __syncthreads();  // (fnew / the quotients are written again in the next iteration)
+              if (done) break;
+            }
+          }
+        }
+        // ---- ngsLD.cpp:296-306 ----
+        if (threadIdx.x == 0) {
+          const double hm0 = 1 - (f[0] + f[1]);
+          const double hm1 = 1 - (f[0] + f[2]);
+          const double D = f[0] * f[3] - f[1] * f[2];
+          const double Dp = D / (D < 0 ? -ref_min(hm0 * hm1, (1 - hm0) * (1 - hm1)) : ref_min(hm0 * (1 - hm1), (1 - hm0) * hm1));
+          const double rr = D / __dsqrt_rn(hm0 * hm1 * (1 - hm0) * (1 - hm1));
+          ngsld_rec_std o = A.out_std[slot];  // (r2_ExpG stays the pair kernel's)
+          o.D = D;
+          o.Dp = Dp;
+          o.r2 = rr * rr;
+          A.out_std[slot] = o;
+          if (A.out_ext != nullptr) {
+            ngsld_rec_ext r;
+            r.hap[0] = f[0]; r.hap[1] = f[1]; r.hap[2] = f[2]; r.hap[3] = f[3];
+            r.n_ind_data = x;
+            r.n_iter = iter;
+            A.out_ext[slot] = r;
+          }
+          atomicAdd(A.done, 1u);
+        }
+        if (WAVES > 1) __syncthreads();
+      }
+    }
+  }
+}
+
+}  // namespace
+
+uint32_t replay_lkl_waves(uint32_t n_ind) {
+  const uint32_t per = 64u * kMaxSlots;
+  for (uint32_t w = 1; w <= 8; w *= 2)
+    if (n_ind <= per * w) return w;
+  return 0;  // (beyond 4,096 individuals: the host's replay)
+}
+
+hipError_t launch_replay_lkl(const ReplayLklArgs &a, int n_cus, hipStream_t stream) {
+  if (a.bits == nullptr || a.n_records == 0) return hipSuccess;
+  const uint32_t waves = replay_lkl_waves(a.n_ind);
+  if (waves == 0) return hipErrorInvalidValue;
+  // a persistent grid: as many teams as the device holds at two wavefronts per SIMD (the kernel's registers allow no more),
+  // never more than there are chunks to claim
+  const uint64_t chunks = ((a.n_records + 31) / 32 + kChunkWords - 1) / kChunkWords;
+  uint64_t teams = (uint64_t)n_cus * 8 / waves;
+  if (waves == 8) teams = (uint64_t)n_cus;  // (its quotient rows take 131 KB of LDS: one team per CU)
+  if (teams > chunks) teams = chunks;
+  if (teams < 1) teams = 1;
+  const dim3 grid((unsigned)teams);
+  const uint32_t slots = (a.n_ind + 64u * waves - 1) / (64u * waves);  // per wavefront
+#define NGSLD_REPLAY_LKL(W, S) hipLaunchKernelGGL((replay_lkl_kernel<W, S>), grid, dim3(64 * W), 0, stream, a)
+  if (waves == 1) {
+    switch (slots) {
+      case 1: NGSLD_REPLAY_LKL(1, 1); break;
+      case 2: NGSLD_REPLAY_LKL(1, 2); break;
+      case 3: NGSLD_REPLAY_LKL(1, 3); break;
+      case 4: NGSLD_REPLAY_LKL(1, 4); break;
+      case 5: NGSLD_REPLAY_LKL(1, 5); break;
+      case 6: NGSLD_REPLAY_LKL(1, 6); break;
+      case 7: NGSLD_REPLAY_LKL(1, 7); break;
+      default: NGSLD_REPLAY_LKL(1, 8); break;
+    }
+  } else if (waves == 2) {
+    if (slots <= 6) NGSLD_REPLAY_LKL(2, 6); else NGSLD_REPLAY_LKL(2, 8);
+  } else if (waves == 4) {
+    if (slots <= 6) NGSLD_REPLAY_LKL(4, 6); else NGSLD_REPLAY_LKL(4, 8);
+  } else {
+    if (slots <= 6) NGSLD_REPLAY_LKL(8, 6); else NGSLD_REPLAY_LKL(8, 8);
+  }
+#undef NGSLD_REPLAY_LKL
+  return hipGetLastError();
+}
+
+}  // namespace ngsld

@@ -148,6 +148,17 @@ void replay_site_from_raw(const double *raw, uint64_t n_ind, const ngsld_geno_op
   }
 }
 
+void replay_site_planes(const double *raw, uint64_t n_ind, const ngsld_geno_opts &o, uint64_t np, double *planes, double *maf) {
+  thread_local ReplaySite site;  // (its vectors keep their capacity from site to site)
+  replay_site_from_raw(raw, n_ind, o, &site);
+  *maf = site.maf;
+  for (int g = 0; g < 3; ++g) {
+    double *pl = planes + (uint64_t)g * np;
+    for (uint64_t i = 0; i < n_ind; ++i) pl[i] = site.lkl[3 * i + g];
+    for (uint64_t i = n_ind; i < np; ++i) pl[i] = 0.0;
+  }
+}
+
 void replay_missing_constants(double *u_lkl, double *u_pp) {
   double g[3];
   for (int k = 0; k < 3; ++k) g[k] = std::log((double)1 / 3);  // harden(): gen_func.cpp:903-905

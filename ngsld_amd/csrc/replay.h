@@ -32,6 +32,10 @@ struct ReplaySite {
 // to one site, with the host's libm and the reference's operation order.
 void replay_site_from_raw(const double *raw, uint64_t n_ind, const ngsld_geno_opts &opts, ReplaySite *out);
 
+// The same site written as the device holds it: planes[g * np + i] = lkl[i][g] for i < n_ind, zero up to np; *maf = est_maf.
+// What the exact store of the device-side replay (ld_replay_lkl.hip) is built from, site by site, on the replay threads.
+void replay_site_planes(const double *raw, uint64_t n_ind, const ngsld_geno_opts &opts, uint64_t np, double *planes, double *maf);
+
 // The same from values that are already normalised normal-space likelihoods + maf (ngsld_set_geno_lkl, or the
 // device's own planes read back when the caller registered no source): only the expected genotypes are derived.
 void replay_site_from_lkl(const double *lkl, double maf, uint64_t n_ind, ReplaySite *out);

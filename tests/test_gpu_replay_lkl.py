@@ -1,0 +1,174 @@
+"""GPU: the device-side exact-order replay of LIKELIHOOD matrices (ld_replay_lkl.hip, include/ngsld.h: ngsld_set_exact_store).
+
+Matrices that are not SNP-called (the reference's README.md:73) flag a third of their pairs: every pair with a (nearly)
+monomorphic site.  Those are replayed on the device, a wavefront per pair, in the reference's operation order, on an exact
+store built through the host's libm.  Held here: the device replay's records are the HOST replay's records bit for bit
+(hap, D, D', r2, nIter, sample_size of every pair of the run, flagged or not), on every wavefront
+shape of the kernel, with and without --ignore_miss_data, through every path a record can take; and both are the oracle's
+bits on the degenerate pairs."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from ngsld_amd import capi, synth
+from oracle import orc
+from util import check_records, close, same_bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def eng():
+    e = capi.Engine(0)
+    yield e
+    e.close()
+
+
+def uncalled(n_sites, n_ind, seed, depth=6.0, missing=False, **kw):
+    raw = synth.make_gl_numpy(n_sites, n_ind, seed=seed, depth=depth, **kw)
+    if missing:
+        rng = np.random.default_rng(seed + 1)
+        raw[rng.random((n_sites, n_ind)) < 0.08] = 1.0      # individuals without reads: three equal likelihoods
+    return raw
+
+
+def run_records(e, raw, mode, ign=False, **plan):
+    e.set_exact_store(mode)
+    e.set_geno_raw(raw, ignore_miss_data=ign)
+    e.set_pos_dist(None)
+    n = e.plan(ignore_miss_data=ign, **plan)
+    s1, s2, std, ext = e.run()
+    assert len(s1) == n
+    return s1, s2, std.copy(), ext.copy(), e.replay_info()
+
+
+def assert_same_records(a, b):
+    """(r2_ExpG of a pair replayed on the device stays the pair kernel's value -- GSL's long double recurrence has no device twin
+    --, the host's replay writes the recurrence's: the same number to 1e-9, not the same bits)"""
+    assert close(a[2]["r2_ExpG"], b[2]["r2_ExpG"]).all()
+    for col in ("D", "Dp", "r2"):
+        sb = same_bits(a[2][col], b[2][col])
+        assert sb.all(), (col, int((~sb).sum()), a[2][col][~sb][:3], b[2][col][~sb][:3])
+    assert same_bits(a[3]["hap"], b[3]["hap"]).all()
+    assert np.array_equal(a[3]["n_iter"], b[3]["n_iter"]) and np.array_equal(a[3]["n_ind_data"], b[3]["n_ind_data"])
+
+
+# one wavefront per pair with 1..8 individuals per lane, then 2, 4 and 8 wavefronts per pair
+@pytest.mark.parametrize("n_ind", [24, 100, 130, 200, 260, 330, 390, 450, 500, 512, 700, 1000, 1500, 2000, 2600])
+@pytest.mark.parametrize("ign", [False, True])
+def test_device_replay_is_the_hosts_on_every_shape(eng, n_ind, ign):
+    n_sites = 60 if n_ind <= 512 else (36 if n_ind <= 1024 else 24)
+    raw = uncalled(n_sites, n_ind, seed=100 + n_ind, depth=6.0 if n_ind <= 512 else 14.0, mono_frac=0.3, missing=ign)
+    host = run_records(eng, raw, 0, ign)
+    dev = run_records(eng, raw, 2, ign)
+    assert host[4]["pairs_flagged"] == dev[4]["pairs_flagged"] > len(host[0]) // (10 if n_ind <= 512 else 50)
+    assert host[4]["pairs_on_device"] == 0 and host[4]["pairs_on_host"] == host[4]["pairs_replayed"]
+    assert dev[4]["exact_store"] == 2 and dev[4]["pairs_on_device"] > 0
+    assert dev[4]["pairs_on_device"] + dev[4]["pairs_on_host"] == dev[4]["pairs_replayed"] == host[4]["pairs_replayed"]
+    assert_same_records(host, dev)
+    want = orc.Oracle(raw, ignore_miss_data=ign, n_threads=4).run()
+    check_records(dev[2], dev[3], want)          # 1e-9 everywhere, the degenerate pairs bit for bit
+
+
+def test_auto_mode_builds_the_store_only_when_it_pays(eng):
+    """Default policy: a few flagged pairs are the host's; more than half as many as the matrix has sites (and 4,096) build the store."""
+    raw = synth.make_gl_numpy(200, 100, seed=5, depth=8.0)
+    few = run_records(eng, raw, 1)
+    assert few[4]["exact_store"] == 0 and few[4]["pairs_on_device"] == 0
+    raw = uncalled(400, 100, seed=6, mono_frac=0.3)
+    many = run_records(eng, raw, 1)
+    assert many[4]["pairs_flagged"] > 4096
+    assert many[4]["exact_store"] == 2 and many[4]["pairs_on_device"] > 0 and many[4]["exact_store_build_s"] > 0
+    host = run_records(eng, raw, 0)
+    assert_same_records(host, many)
+    again = run_records(eng, raw, 1)             # (a new matrix call: the store is built again, the records are the same)
+    assert_same_records(host, again)
+
+
+@pytest.mark.parametrize("n_ind", [100, 500, 1000])
+def test_normalised_input_is_its_own_store(eng, n_ind):
+    """ngsld_set_geno_lkl: the caller's normal-space values ARE the reference's bits -- nothing is built, the flagged pairs are
+    replayed on the device from the first one on, and the records are the oracle's on the degenerate pairs."""
+    raw = uncalled(40, n_ind, seed=31 + n_ind, mono_frac=0.3)
+    o = orc.Oracle(raw, n_threads=4)
+    want = o.run()
+    lkl, maf = o.gl, o.maf
+    eng.set_exact_store(1)
+    eng.set_geno_lkl(lkl, maf)
+    eng.set_pos_dist(None)
+    eng.plan()
+    s1, s2, std, ext = eng.run()
+    info = eng.replay_info()
+    assert info["exact_store"] == 1 and info["pairs_on_device"] > 0 and info["exact_store_build_s"] == 0
+    check_records(std, ext, want)
+    eng.set_exact_store(0)
+    eng.set_geno_lkl(lkl, maf)
+    eng.set_pos_dist(None)
+    eng.plan()
+    host = eng.run()
+    assert_same_records((s1, s2, std, ext), host)
+
+
+@pytest.mark.parametrize("batch_pairs", [0, 3000])
+def test_text_and_device_records_take_the_same_replay(eng, batch_pairs, monkeypatch):
+    """The TSV of a run with the device replay is the host replay's byte for byte (rows formatted on the device, before and
+    after the store is there: small batches make the first ones go out without it); so are records left on the device."""
+    import torch
+    raw = uncalled(300, 150, seed=77, mono_frac=0.25)
+    chrs, pos = synth.make_positions(300, 9, max_gap=300)
+    labels = [f"{c}:{p}" for c, p in zip(chrs, pos)]
+    from ngsld_amd import shard
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    texts = {}
+    for mode in (0, 1, 2):
+        eng.set_exact_store(mode)
+        eng.set_geno_raw(raw)
+        eng.set_pos_dist(pd)
+        if batch_pairs:
+            eng.set_tuning(batch_pairs=batch_pairs)
+        eng.plan(max_kb_dist=20, extend_out=True)
+        eng.set_text_output(labels)
+        t, fallbacks = eng.run_text()
+        assert fallbacks == 0
+        texts[mode] = hashlib.md5(t).hexdigest()
+        info = eng.replay_info()
+        assert (info["pairs_on_device"] > 0) == (mode != 0), (mode, info)
+        eng.set_text_output(None, enable=False)
+    assert texts[0] == texts[1] == texts[2]
+    # records in caller-owned device memory (ngsld_run_device + ngsld_finish_device)
+    recs = {}
+    for mode in (0, 2):
+        eng.set_exact_store(mode)
+        eng.set_geno_raw(raw)
+        eng.set_pos_dist(pd)
+        n = eng.plan(max_kb_dist=20, extend_out=True)
+        d_std = torch.zeros(n * 32, dtype=torch.uint8, device="cuda")
+        d_ext = torch.zeros(n * 40, dtype=torch.uint8, device="cuda")
+        eng.run_device(0, 300, d_std.data_ptr(), d_ext.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        eng.finish_device()
+        recs[mode] = (d_std.cpu().numpy().tobytes(), d_ext.cpu().numpy().tobytes())
+    for k in (0, 1):
+        a, b = np.frombuffer(recs[0][k], dtype=np.uint64), np.frombuffer(recs[2][k], dtype=np.uint64)
+        if k == 0:                               # (word 0 of a standard record is r2_ExpG: see assert_same_records)
+            a, b = a.reshape(-1, 4)[:, 1:], b.reshape(-1, 4)[:, 1:]
+        assert np.array_equal(a, b)
+
+
+def test_log_scale_and_filters(eng):
+    """--log_scale input (the store is built from logs), --min_maf (rows of monomorphic sites are dropped: what is left flags
+    little) and --rnd_sample (records are a subset: the cursor steps over the dropped candidates)."""
+    raw = uncalled(120, 80, seed=41, mono_frac=0.3)
+    with np.errstate(divide="ignore"):
+        logs = np.log(raw)
+    logs[np.isneginf(logs)] = -1e15
+    for kw in (dict(), dict(min_maf=0.02), dict(rnd_sample=0.3, seed=7)):
+        out = {}
+        for mode in (0, 2):
+            eng.set_exact_store(mode)
+            eng.set_geno_raw(logs, log_scale=True)
+            eng.set_pos_dist(None)
+            n = eng.plan(**kw)
+            out[mode] = eng.run()
+            assert len(out[mode][0]) == n
+        assert_same_records(out[0], out[2])
