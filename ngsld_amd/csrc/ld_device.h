@@ -139,6 +139,12 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ double mk_double(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
 
+// x86 writes the default NaN of an invalid operation (0/0, inf - inf, the x87's "real indefinite" of gsl_stats_correlation)
+// with its sign bit SET -- glibc prints it "-nan", the reference's TSV is full of them -- and hands an operand's NaN on as it
+// is; gfx950 generates NaNs with the bit clear.  Records carry the reference's pattern, whoever computed them (the product's
+// own formatters print every NaN "-nan"; the reference's fprintf, given these records by the binding, prints the sign).
+__device__ __forceinline__ double ref_nan(double v) { return v != v ? mk_double(0u, 0xfff80000u) : v; }
+
 __device__ __forceinline__ double uniform(double v) {  // value is wave-uniform: move it to SGPRs
   return mk_double((unsigned)__builtin_amdgcn_readfirstlane(__double2loint(v)),
                    (unsigned)__builtin_amdgcn_readfirstlane(__double2hiint(v)));
@@ -755,14 +761,14 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
   const bool constant_site = a1 == __builtin_inf() || a2 == __builtin_inf();
   const double r = constant_site ? __builtin_nan("") : sxy * a1 * a2;
   ngsld_rec_std o;
-  o.r2_ExpG = r * r;
-  o.D = D;
-  o.Dp = Dp;
-  o.r2 = rr * rr;
+  o.r2_ExpG = ref_nan(r * r);
+  o.D = ref_nan(D);
+  o.Dp = ref_nan(Dp);
+  o.r2 = ref_nan(rr * rr);
   A.out_std[slot] = o;
   if (A.out_ext != nullptr) {
     ngsld_rec_ext e;
-    e.hap[0] = f0; e.hap[1] = f1; e.hap[2] = f2; e.hap[3] = f3;
+    e.hap[0] = ref_nan(f0); e.hap[1] = ref_nan(f1); e.hap[2] = ref_nan(f2); e.hap[3] = ref_nan(f3);
     e.n_ind_data = x;
     e.n_iter = n_iter;
     A.out_ext[slot] = e;

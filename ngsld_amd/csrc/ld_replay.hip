@@ -179,13 +179,13 @@ __global__ __launch_bounds__(64) void replay_hard_kernel(ReplayHardArgs A) {
   const double Dp = D / (D < 0 ? -ref_min(hm0 * hm1, (1 - hm0) * (1 - hm1)) : ref_min(hm0 * (1 - hm1), (1 - hm0) * hm1));
   const double rr = D / __dsqrt_rn(hm0 * hm1 * (1 - hm0) * (1 - hm1));
   ngsld_rec_std o = A.out_std[slot];  // (r2_ExpG stays the pair kernel's)
-  o.D = D;
-  o.Dp = Dp;
-  o.r2 = rr * rr;
+  o.D = ref_nan(D);
+  o.Dp = ref_nan(Dp);
+  o.r2 = ref_nan(rr * rr);
   A.out_std[slot] = o;
   if (A.out_ext != nullptr) {
     ngsld_rec_ext r;
-    r.hap[0] = f[0]; r.hap[1] = f[1]; r.hap[2] = f[2]; r.hap[3] = f[3];
+    r.hap[0] = ref_nan(f[0]); r.hap[1] = ref_nan(f[1]); r.hap[2] = ref_nan(f[2]); r.hap[3] = ref_nan(f[3]);
     r.n_ind_data = (uint32_t)x;
     r.n_iter = (uint32_t)iter;
     A.out_ext[slot] = r;

@@ -56,28 +56,6 @@ void harden(double *g, double n_thresh, double call_thresh) {
   }
 }
 
-// gen_func.cpp:974-1009 with indF == NULL.  num / den live outside the do-while (they are not reset between passes)
-// and the posterior does not depend on freq, so the loop ends after its second pass; kept as the loop.
-double site_maf(const double *logs, uint64_t n_ind, bool ignore_miss) {
-  double num = 0, den = 0, freq = 0.01, prev;
-  int iters = 0;
-  do {
-    prev = freq;
-    for (uint64_t i = 0; i < n_ind; ++i) {
-      const double *g = logs + 3 * i;
-      if (no_data(g) && ignore_miss) continue;
-      double pp[3] = {g[0], g[1], g[2]};
-      normalise_log(pp);
-      for (int k = 0; k < 3; ++k) pp[k] = std::exp(pp[k]);
-      const double F = 0;
-      num += pp[1] + pp[2] * (2 - F);
-      den += 2 * pp[1] + (pp[0] + pp[2]) * (2 - F);
-    }
-    freq = num / den;
-  } while (ref_abs(prev - freq) > kEps && iters++ < 100);
-  return freq;
-}
-
 // gen_func.cpp:1073-1119: one EM step.  Haplotype k: bit 1 = allele at site 1, bit 0 = allele at site 2.
 inline int geno1(int h, int k) { return ((h >> 1) & 1) + ((k >> 1) & 1); }
 inline int geno2(int h, int k) { return (h & 1) + (k & 1); }
@@ -121,29 +99,95 @@ double correlation(const std::vector<double> &x, const std::vector<double> &y) {
   return (double)r;
 }
 
+// One individual's triple through the chain above, as a pure function of its three raw values and the options: the
+// log-space triple is only needed for est_maf's terms, which depend on nothing else either.  Matrices repeat triples -- a
+// likelihood is a function of a handful of reads -- and the chain is 17 libm calls per triple: a small direct-mapped memo per
+// thread returns the SAME bits for a triple seen before (the key is compared in full) at a twentieth of the cost.
+struct TripleOut {
+  double lkl[3];        // exp of the normalised logs, ngsLD.cpp:110
+  double t_num, t_den;  // what est_maf adds to num / den for this individual (gen_func.cpp:992-993)
+  bool skip_in_maf;     // miss_data on the log values (gen_func.cpp:985), used under --ignore_miss_data
+};
+
+void triple_chain(const double *raw, const ngsld_geno_opts &o, TripleOut *t) {
+  double g[3];
+  for (int k = 0; k < 3; ++k) {
+    double v = raw[k];
+    if (!o.log_scale) {
+      v = std::log(v);                                         // read_data.cpp:37-38 / :86
+      if (!o.text_semantics && v == -INFINITY) v = -kInf;      // conv_space, gen_func.cpp:127-128 (binary input only)
+    }
+    g[k] = v;
+  }
+  normalise_log(g);                                            // read_data.cpp:40 / :98
+  if (o.call_geno) harden(g, o.N_thresh, o.call_thresh);       // ngsLD.cpp:92-98
+  t->skip_in_maf = no_data(g);
+  double pp[3] = {g[0], g[1], g[2]};                           // est_maf's posterior, gen_func.cpp:986-990
+  normalise_log(pp);
+  for (int k = 0; k < 3; ++k) pp[k] = std::exp(pp[k]);
+  const double F = 0;
+  t->t_num = pp[1] + pp[2] * (2 - F);
+  t->t_den = 2 * pp[1] + (pp[0] + pp[2]) * (2 - F);
+  for (int k = 0; k < 3; ++k) t->lkl[k] = std::exp(g[k]);      // ngsLD.cpp:110
+}
+
+struct TripleMemo {
+  static constexpr size_t kEntries = 1u << 12;
+  struct Entry {
+    uint64_t key[3];
+    bool used = false;
+    TripleOut out;
+  };
+  std::vector<Entry> tab;
+  ngsld_geno_opts opts{};
+  const TripleOut &get(const double *raw, const ngsld_geno_opts &o) {
+    if (tab.empty() || o.log_scale != opts.log_scale || o.text_semantics != opts.text_semantics || o.call_geno != opts.call_geno ||
+        std::memcmp(&o.N_thresh, &opts.N_thresh, sizeof(double)) != 0 || std::memcmp(&o.call_thresh, &opts.call_thresh, sizeof(double)) != 0) {
+      tab.assign(kEntries, Entry());
+      opts = o;
+    }
+    uint64_t k[3];
+    std::memcpy(k, raw, sizeof(k));
+    uint64_t h = k[0] * 0x9E3779B97F4A7C15ull;
+    h = (h ^ (h >> 29) ^ k[1]) * 0xBF58476D1CE4E5B9ull;
+    h = (h ^ (h >> 32) ^ k[2]) * 0x94D049BB133111EBull;
+    Entry &e = tab[(h >> 40) & (kEntries - 1)];
+    if (!(e.used && e.key[0] == k[0] && e.key[1] == k[1] && e.key[2] == k[2])) {
+      triple_chain(raw, o, &e.out);
+      e.key[0] = k[0]; e.key[1] = k[1]; e.key[2] = k[2];
+      e.used = true;
+    }
+    return e.out;
+  }
+};
+
 }  // namespace
 
 void replay_site_from_raw(const double *raw, uint64_t n_ind, const ngsld_geno_opts &o, ReplaySite *out) {
-  std::vector<double> logs(3 * n_ind);
-  for (uint64_t i = 0; i < n_ind; ++i) {
-    double *g = logs.data() + 3 * i;
-    for (int k = 0; k < 3; ++k) {
-      double v = raw[3 * i + k];
-      if (!o.log_scale) {
-        v = std::log(v);                                         // read_data.cpp:37-38 / :86
-        if (!o.text_semantics && v == -INFINITY) v = -kInf;      // conv_space, gen_func.cpp:127-128 (binary input only)
-      }
-      g[k] = v;
+  thread_local TripleMemo memo;
+  thread_local std::vector<TripleOut> vals;  // (copies: a later individual of the site may evict an entry)
+  vals.resize(n_ind);
+  for (uint64_t i = 0; i < n_ind; ++i) vals[i] = memo.get(raw + 3 * i, o);
+  // est_maf, gen_func.cpp:974-1009 with indF == NULL (ngsLD.cpp:104-105): num / den live outside the do-while (they are not
+  // reset between passes) and the posterior does not depend on freq, so the loop ends after its second pass; kept as the loop
+  const bool ignore_miss = o.ignore_miss_data != 0;
+  double num = 0, den = 0, freq = 0.01, prev;
+  int iters = 0;
+  do {
+    prev = freq;
+    for (uint64_t i = 0; i < n_ind; ++i) {
+      if (vals[i].skip_in_maf && ignore_miss) continue;
+      num += vals[i].t_num;
+      den += vals[i].t_den;
     }
-    normalise_log(g);                                            // read_data.cpp:40 / :98
-    if (o.call_geno) harden(g, o.N_thresh, o.call_thresh);       // ngsLD.cpp:92-98
-  }
-  out->maf = site_maf(logs.data(), n_ind, o.ignore_miss_data != 0);  // ngsLD.cpp:104-105
+    freq = num / den;
+  } while (ref_abs(prev - freq) > kEps && iters++ < 100);
+  out->maf = freq;
   out->lkl.resize(3 * n_ind);
   out->e.resize(n_ind);
   for (uint64_t i = 0; i < n_ind; ++i) {
     double *p = out->lkl.data() + 3 * i;
-    for (int k = 0; k < 3; ++k) p[k] = std::exp(logs[3 * i + k]);  // ngsLD.cpp:110
+    for (int k = 0; k < 3; ++k) p[k] = vals[i].lkl[k];
     out->e[i] = p[1] + 2 * p[2];                                   // ngsLD.cpp:113
   }
 }

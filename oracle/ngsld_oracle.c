@@ -765,6 +765,7 @@ typedef struct {
   int tid, n_threads;
   uint64_t pairs, iters;
   double sum;
+  int pearson_only; /* orc_bench_pearson: the walk and pearson_r alone (ngsLD.cpp:290, 365-367) */
 } orc_bjob;
 
 static void *orc_bench_worker(void *arg) {
@@ -781,6 +782,11 @@ static void *orc_bench_worker(void *arg) {
         if (q.maf[s2] < q.min_maf) continue;
         orc_pair *o = &r[s2 - b];
         o->r2pear = orc_pearson_r2(q.expected_geno + s1 * q.n_ind, q.expected_geno + s2 * q.n_ind, q.n_ind);
+        if (j->pearson_only) {
+          if (isfinite(o->r2pear)) j->sum += o->r2pear;
+          j->pairs++;
+          continue;
+        }
         o->n_iter = orc_haplo_freq(o->hap, &o->n_ind_data, q.geno_lkl + s1 * q.n_ind * 3, q.geno_lkl + s2 * q.n_ind * 3,
                                    q.maf[s1], q.maf[s2], q.n_ind, q.ignore_miss_data, &err);
         orc_pair_stats(o->hap, &o->D, &o->Dp, &o->r2, o->hap_maf, &o->chi2);
@@ -793,7 +799,17 @@ static void *orc_bench_worker(void *arg) {
   return NULL;
 }
 
+static uint64_t orc_bench_mode(const orc_params *p, uint64_t s1_begin, uint64_t s1_end, double *checksum, uint64_t *iters,
+                               int pearson_only);
 uint64_t orc_bench(const orc_params *p, uint64_t s1_begin, uint64_t s1_end, double *checksum, uint64_t *iters) {
+  return orc_bench_mode(p, s1_begin, s1_end, checksum, iters, 0);
+}
+/* the same rows, pearson_r alone: what the reference's program compiled without GSL (oracle/_ref: ref_main) leaves out */
+uint64_t orc_bench_pearson(const orc_params *p, uint64_t s1_begin, uint64_t s1_end, double *checksum) {
+  return orc_bench_mode(p, s1_begin, s1_end, checksum, NULL, 1);
+}
+static uint64_t orc_bench_mode(const orc_params *p, uint64_t s1_begin, uint64_t s1_end, double *checksum, uint64_t *iters,
+                               int pearson_only) {
   int nt = p->n_threads > 0 ? p->n_threads : 1;
   pthread_t *th = (pthread_t *)malloc((size_t)nt * sizeof(pthread_t));
   orc_bjob *jobs = (orc_bjob *)calloc((size_t)nt, sizeof(orc_bjob));
@@ -803,6 +819,7 @@ uint64_t orc_bench(const orc_params *p, uint64_t s1_begin, uint64_t s1_end, doub
     jobs[t].s1_end = s1_end;
     jobs[t].tid = t;
     jobs[t].n_threads = nt;
+    jobs[t].pearson_only = pearson_only;
     pthread_create(&th[t], NULL, orc_bench_worker, &jobs[t]);
   }
   uint64_t pairs = 0, it = 0;

@@ -139,6 +139,8 @@ uint64_t orc_run(const orc_params *p, uint64_t s1_begin, uint64_t s1_end, orc_pa
 /* cpu_baseline leg of bench.py: compute every pair of rows [s1_begin, s1_end) with n_threads pthreads and
    keep only a checksum (sum of finite r2) so nothing is stored; returns #pairs. */
 uint64_t orc_bench(const orc_params *p, uint64_t s1_begin, uint64_t s1_end, double *checksum, uint64_t *iters);
+/* the walk + pearson_r (gsl_stats_correlation restated) alone over the same rows: (#pairs; checksum = sum of finite r2_ExpG) */
+uint64_t orc_bench_pearson(const orc_params *p, uint64_t s1_begin, uint64_t s1_end, double *checksum);
 /* exclusive end of the contiguous s2 range row s1 walks (before the maf[s2] skip) */
 uint64_t orc_row_end(const orc_params *p, uint64_t s1);
 

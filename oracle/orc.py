@@ -102,6 +102,8 @@ def lib() -> C.CDLL:
         L.orc_row_seeds.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
         L.orc_bench.restype = C.c_uint64
         L.orc_bench.argtypes = [C.POINTER(OrcParams), C.c_uint64, C.c_uint64, c_double_p, C.POINTER(C.c_uint64)]
+        L.orc_bench_pearson.restype = C.c_uint64
+        L.orc_bench_pearson.argtypes = [C.POINTER(OrcParams), C.c_uint64, C.c_uint64, c_double_p]
         L.orc_row_end.restype = C.c_uint64
         L.orc_row_end.argtypes = [C.POINTER(OrcParams), C.c_uint64]
         L.orc_pair_stats.restype = None
@@ -229,6 +231,12 @@ class Oracle:
         chk, it = C.c_double(0.0), C.c_uint64(0)
         n = lib().orc_bench(C.byref(self.p), s1_begin, s1_end, C.byref(chk), C.byref(it))
         return n, chk.value, it.value
+
+    def bench_pearson(self, s1_begin: int, s1_end: int) -> tuple[int, float]:
+        """pearson_r alone over the pairs of rows [s1_begin, s1_end): (#pairs, sum of finite r2_ExpG)."""
+        chk = C.c_double(0.0)
+        n = lib().orc_bench_pearson(C.byref(self.p), s1_begin, s1_end, C.byref(chk))
+        return n, chk.value
 
     def bench_reference(self, s1_begin: int, s1_end: int, n_threads: int) -> tuple[int, int, float] | None:
         """The REFERENCE's own compiled haplo_freq (oracle/_ref) over the pairs of rows [s1_begin, s1_end) of this

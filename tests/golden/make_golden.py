@@ -84,7 +84,16 @@ def run_cli(raw, ptxt, flags, header=False, gtext=None):
     return out
 
 
-def make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max_kb=0, max_snp=0, min_maf=0.0,
+ONLY: list[str] = []   # fixture-name prefixes given on the command line: regenerate just those
+
+
+def make(name, raw, *a, **kw):
+    if ONLY and not any(name.startswith(p) for p in ONLY):
+        return
+    _make(name, raw, *a, **kw)
+
+
+def _make(name, raw, chrs=None, pos=None, log_scale=False, ignore_miss=False, max_kb=0, max_snp=0, min_maf=0.0,
          extra_col=False, header=False, with_text=True, text_mode=None, call=None, geno_header=True,
          rnd_sample=1.0, seed=0):
     """text_mode: None (binary GL file) | "probs" (text GL triples) | "called" (text genotypes, raw = [sites, ind]
@@ -313,7 +322,25 @@ def main():
         raw = synth.make_gl_numpy(ns, ni, seed=seed, depth=10.0)
         chrs, pos = synth.make_positions(ns, seed)
         make(name, raw, chrs, pos, with_text=(ni <= 500))
+    # F10 (round 5): matrices that are NOT SNP-called (the reference's README.md:73; its examples/test.sh feeds such input): 30 %
+    # of the sites monomorphic in the population, three singletons (one heterozygous individual), one site without data for
+    # anybody -- at the cohort sizes of every kernel family, so that each of them flags, and each shape of the device-side
+    # replay (1 / 2 / 4 wavefronts per pair) settles, its share of such pairs
+    for name, ns, ni, seed in (("f10_unfiltered_n100", 48, 100, 101), ("f10_unfiltered_n500", 40, 500, 105),
+                               ("f10_unfiltered_n1000", 22, 1000, 110), ("f10_unfiltered_n2000", 12, 2000, 120)):
+        raw = synth.make_gl_numpy(ns, ni, seed=seed, depth=10.0, mono_frac=0.3)
+        rng = np.random.default_rng(seed)
+        maf0 = orc.Oracle(raw).maf
+        mono = np.flatnonzero(maf0 < 0.01)
+        for s in mono[:3]:                                   # singletons: one individual with five of ten reads alternative
+            raw[s, rng.integers(ni)] = [0.01 ** 5 * 0.99 ** 5, 0.5 ** 10, 0.99 ** 5 * 0.01 ** 5]
+        raw[ns // 2] = 1.0                                   # no data for anybody
+        chrs, pos = synth.make_positions(ns, seed)
+        make(name, raw, chrs, pos, with_text=(ni <= 500))
+    make("f10_unfiltered_n100_ignmiss", synth.make_gl_numpy(48, 100, seed=131, depth=3.0, mono_frac=0.3),
+         *synth.make_positions(48, 131), ignore_miss=True)
 
 
 if __name__ == "__main__":
+    ONLY = sys.argv[1:]
     main()

@@ -40,3 +40,24 @@ def test_cohort_sizes_past_the_old_cliffs_keep_their_rate(n_ind, floor):
     assert d["roofline"]["kernel"] == KERNELS[n_ind], d["roofline"]["kernel"]
     print(f"\n[throughput] n_ind {n_ind}: {d['value']:.4g} pairs/s ({d['roofline']['kernel']}), floor {floor:.3g}")
     assert d["value"] >= floor, f"n_ind {n_ind}: {d['value']:.4g} pairs/s is below the floor of {floor:.3g}"
+
+
+# Round 5: matrices that are NOT SNP-called (README.md:73).  With 20 % monomorphic sites a third of the pairs is flagged for the
+# exact-order replay; on host threads (rounds 1-4) the pass ran at 2.2e6 pairs/s, on the device (ld_replay_lkl.hip) at 1.0e8
+# on a 2.2 GHz box (profiles/r05).  The floor is a third of that -- a pass means the device-side replay is what ran.
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("flags,floor", [(["--mono-frac", "0.2"], 3.0e7), (["--sfs"], 8.0e7)])
+def test_uncalled_input_is_replayed_on_the_device(flags, floor):
+    cmd = [sys.executable, "bench.py", "--config", "c2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-sink", "--no-e2e",
+           "--no-traffic"] + flags
+    r = subprocess.run(cmd, cwd=capi.REPO_DIR, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    rep = d["config"]["replay_rank0_last_step"]
+    print(f"\n[throughput] {' '.join(flags)}: {d['value']:.4g} pairs/s, {rep['pairs_flagged']} of {d['config']['pairs_per_step']} pairs "
+          f"flagged, {rep['pairs_on_device']} replayed on the device, {rep['pairs_on_host']} on the host; replay off: "
+          f"{d['config']['replay_off']['value']:.4g} pairs/s; first pass {d['config']['first_pass_s_rank0']} s, floor {floor:.3g}")
+    assert rep["pairs_flagged"] > d["config"]["pairs_per_step"] // 30
+    assert rep["pairs_on_host"] * 10_000 <= d["config"]["pairs_per_step"], "host-only share of the pairs above 1e-4"
+    assert rep["pairs_on_device"] + rep["pairs_on_host"] == rep["pairs_flagged"]
+    assert d["value"] >= floor, f"{flags}: {d['value']:.4g} pairs/s is below the floor of {floor:.3g}"

@@ -3,6 +3,9 @@
     python tools/cli_vs_ref_config.py c1            # configs[1]: 5,000 x 100, all 12,497,500 pairs, extended columns
     python tools/cli_vs_ref_config.py c2 [sites]    # the first `sites` (default 12,000) sites of configs[2]'s matrix: x 500, 100 kb window
     python tools/cli_vs_ref_config.py c2call [sites]  # the same with --call_geno --N_thresh 0.4 --call_thresh 0.8
+    python tools/cli_vs_ref_config.py c2mono [sites]  # the same shape NOT SNP-called: 20 % of the sites monomorphic (a third of the rows are
+                                                      # replayed in the reference's operation order, on the device: ld_replay_lkl.hip)
+    python tools/cli_vs_ref_config.py c2sfs [sites]   # ... site frequencies log-uniform in [0.001, 0.5]
     python tools/cli_vs_ref_config.py c3 [sites]    # configs[3]'s shape: sites (default 3,000) x 1,000, all pairs
     python tools/cli_vs_ref_config.py c4 [sites]    # configs[4]'s shape: sites (default 5,000) x 2,000, 500 kb window
 
@@ -69,7 +72,8 @@ def main():
     else:                    # c2, or c2call: the same matrix with --call_geno (the genotype-combination kernel, replay on the device)
         n_all, n_ind, max_kb, seed = 100_000, 500, 100, 3
         n_sites = int(sys.argv[2]) if len(sys.argv) > 2 else 12_000
-        raw = synth.make_gl_torch(n_all, n_ind, seed, dev, depth=10.0)[:n_sites].cpu().numpy()
+        raw = synth.make_gl_torch(n_sites if which in ("c2mono", "c2sfs") else n_all, n_ind, seed, dev, depth=10.0,
+                                  mono_frac=0.2 if which == "c2mono" else 0.0, sfs=which == "c2sfs")[:n_sites].cpu().numpy()
         chrs, pos = synth.make_positions(n_all, seed)
         chrs, pos = chrs[:n_sites], pos[:n_sites]
         if which == "c2call":
