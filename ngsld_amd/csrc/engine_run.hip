@@ -172,7 +172,8 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
     }
     // which pairs the kernels flagged (and the device has not settled itself): the counter and the list come over behind
     // them, on their stream
-    HIP_TRY(c, hipMemcpyAsync(c->h_flags_dev.p, c->d_flags_dev.p, flag_head_bytes(c->flag_cap_dev), hipMemcpyDeviceToHost, st));
+    rcd = send_flag_head(c, c->d_flags_dev.p, c->h_flags_dev.p, c->flag_cap_dev, st);
+    if (rcd != NGSLD_OK) return rcd;
   }
   c->dev_run.pending = true;
   c->dev_run.s1_begin = s1_begin;
@@ -402,8 +403,11 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     // which pairs the kernel flagged for the exact-order replay (counter + list, 32 KB): known to the host with the batch.
     // On the kernel's own stream, right behind it: on the copy stream, behind the records, this small copy took 9 ms per
     // batch -- it goes through a copy kernel, and that waited for the next batch's pair kernel to leave it a CU
-    if (replay)
-      HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, flag_head_bytes(c->flag_cap[k]), hipMemcpyDeviceToHost, st));
+    // (a small KERNEL, not a copy: send_flag_head)
+    if (replay) {
+      const int rch = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], st);
+      if (rch != NGSLD_OK) return rch;
+    }
     if (text) {  // row lengths and their prefix sums right behind the pair kernel; the rows are written at consume time
       HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), st));
       const TextArgs t = text_args(b, k);
@@ -450,10 +454,12 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     out.n_pairs = b.n;
     bool as_records = !text;
     Range range_wait(text ? "ngsld:consume batch (text rows, D2H, replay, sink)" : "ngsld:consume batch (wait for records, replay, sink)");
+    double t_ev = 0.0, t_wr = 0.0;
     if (text) {
       // the batch's text: its length is known now; the rows are written and copied on the copy stream while the pair
       // kernel of the next batch (already enqueued) runs on the compute stream
       HIP_TRY(c, hipEventSynchronize(c->ev_kernel_done[k]));
+      t_ev = now_ms();
       if (replay) c->flagged_pairs += c->h_flags[k].p[0];
       if (replay && c->h_flags[k].p[0] != 0) {
         bool applied = c->slot_dev_applied[k];
@@ -465,7 +471,8 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
             rcx = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, c->d_std[k].p,
                                     ext ? c->d_ext[k].p : nullptr, c->copy_stream);
           if (rcx != NGSLD_OK) return rcx;
-          HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, flag_head_bytes(c->flag_cap[k]), hipMemcpyDeviceToHost, c->copy_stream));
+          rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream);
+          if (rcx != NGSLD_OK) return rcx;
           HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), c->copy_stream));
           const TextArgs t = text_args(b, k);
           HIP_TRY(c, launch_text_lengths(t, c->copy_stream));
@@ -533,6 +540,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
           HIP_TRY(c, hipMemcpyAsync(c->h_text[k].p, c->d_text[k].p, total, hipMemcpyDeviceToHost, c->copy_stream));
         }
         HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+        t_wr = now_ms();
         out.text = c->h_text[k].p;
         out.text_len = total;
       }
@@ -547,7 +555,8 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
           if (rcx == NGSLD_OK)
             rcx = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], c->copy_stream);
           if (rcx != NGSLD_OK) return rcx;
-          HIP_TRY(c, hipMemcpyAsync(c->h_flags[k].p, c->d_flags[k].p, flag_head_bytes(c->flag_cap[k]), hipMemcpyDeviceToHost, c->copy_stream));
+          rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream);
+          if (rcx != NGSLD_OK) return rcx;
           if (!direct && b.n) {  // (the records had been copied already: once more)
             HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, c->d_std[k].p, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost, c->copy_stream));
             if (ext)
@@ -570,7 +579,9 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       out.std = c->h_std[k].p;
       out.ext = ext ? c->h_ext[k].p : nullptr;
     }
-    if (trace) std::fprintf(stderr, "[trace] batch %zu: replay done %.2f\n", bi, now_ms());
+    if (trace)
+      std::fprintf(stderr, "[trace] batch %zu: issue next %.2f..%.2f, its kernels done %.2f, text written + on the host %.2f, replay done %.2f\n",
+                   bi, t_a, t_b, t_ev, t_wr, now_ms());
     Range range_sink("ngsld:sink");
     if (sink(user, &out) != 0) rc = fail(c, NGSLD_ERR_SINK, "sink callback failed");
   }

@@ -70,15 +70,19 @@ constexpr double kEpsilonTie = kEpsilon + kTieMargin;
 constexpr uint32_t kTieBit = 0x80000000u;  // rides on n_iter (<= 100) from the EM loop to write_pair
 // Layout of a launch's flag buffer (uint32 words): [0] count of flagged pairs, [1] count of those that are kFlagHostOnly,
 // [2] pairs the device-side replay of likelihood matrices (ld_replay_lkl.hip) has settled, [3] its work counter,
-// [4 .. 4 + 2 cap) the record indices (uint64) of the first `cap` flagged pairs in the order their atomics landed,
-// [4 + 2 cap ...) one bit per record, and behind that bitmap (PairArgs::flags_host) a second one: the kFlagHostOnly pairs;
+// [4 .. 4 + 2 cap) the record indices (uint64) of the first `cap` flagged pairs in the order their atomics landed, then the
+// first kFlagHostCap kFlagHostOnly pairs once more, by themselves (what is left for the host after a device-side replay: read
+// from the head that travels with the batch -- fetching a bitmap for them cost a text batch 7 ms, beside the next batch's
+// pair kernel); behind this head one bit per record, and behind that bitmap (PairArgs::flags_host) a second one: the
+// kFlagHostOnly pairs;
 // cap = PairArgs::flag_cap, set by the engine from the launch's size (flag_cap_for).  A launch of 10^8 likelihood pairs flags
 // a few dozen, one of called genotypes 26,000 (exact ties of eps with EPSILON): the host reads the head and never the bitmap.
 // A list entry's top bits: kFlagHostOnly -- the pair was flagged for a reason only the host's replay settles (its r2_ExpG:
 // GSL's long double recurrence) --, kFlagDone -- the device-side replay (ld_replay.hip) has already rewritten the record.
 constexpr uint64_t kFlagHostOnly = 1ull << 63, kFlagDone = 1ull << 62, kFlagIndexMask = (1ull << 62) - 1;
 constexpr uint32_t kFlagListAt = 4;  // first word of the list
-__host__ __device__ inline uint32_t flag_head_words(uint32_t cap) { return kFlagListAt + 2u * cap; }
+constexpr uint32_t kFlagHostCap = 1024;  // entries of the host-only list
+__host__ __device__ inline uint32_t flag_head_words(uint32_t cap) { return kFlagListAt + 2u * cap + 2u * kFlagHostCap; }
 
 // One unit of work = ngsld_item: pairs (s1, s2_begin + c) for the bits c set in mask, records from first_record.
 typedef ngsld_item Item;
@@ -801,7 +805,8 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
       atomicOr(&A.flags[flag_head_words(A.flag_cap) + (slot >> 5)], 1u << (slot & 31u));
       if (host_only && A.flags_host != nullptr) {
         atomicOr(&A.flags_host[slot >> 5], 1u << (slot & 31u));
-        atomicAdd(&A.flags[1], 1u);
+        const uint32_t kh = atomicAdd(&A.flags[1], 1u);
+        if (kh < kFlagHostCap) reinterpret_cast<uint64_t *>(A.flags + kFlagListAt + 2u * A.flag_cap)[kh] = slot;
       }
       const uint32_t k = atomicAdd(&A.flags[0], 1u);
       if (k < A.flag_cap) reinterpret_cast<uint64_t *>(A.flags + kFlagListAt)[k] = slot | (host_only ? kFlagHostOnly : 0ull);

@@ -35,6 +35,7 @@ struct ReplayLklArgs {
   const uint32_t *bits;       // the launch's flag bitmap: one bit per record (ld_device.h)
   const uint32_t *host_bits;  // ... and the pairs among them that stay with the host (PairArgs::flags_host)
   uint64_t n_records;         // records in the launch
+  uint32_t chunk_words;       // bitmap words per claim (set by launch_replay_lkl)
   uint32_t *work;             // chunk counter of the persistent teams, zero at launch
   uint32_t *done;             // receives the number of pairs replayed (added to)
   const uint64_t *row_off;    // [n_sites + 1] plan: records before each row

@@ -32,13 +32,15 @@
 #include "ld_device.h"
 #include "ld_replay.h"
 
+#include <algorithm>
+
 namespace ngsld {
 namespace {
 
 constexpr double kEps = 1e-5;  // EPSILON, gen_func.hpp:16
 constexpr int kMaxIter = 100;  // ITER_MAX, gen_func.hpp:18
 constexpr int kMaxSlots = 8;   // individuals per lane, at most (both sites' triples: 6 doubles each, in registers)
-constexpr uint32_t kChunkWords = 4;  // 128 records per claim
+constexpr uint32_t kChunkWords = 4;  // 128 records per claim at most (launch_replay_lkl: fewer for small launches)
 
 __device__ __forceinline__ double ref_abs(double x) { return x >= 0 ? x : -x; }           // gen_func.hpp:21-23: macros
 __device__ __forceinline__ double ref_min(double a, double b) { return a <= b ? a : b; }
@@ -120,11 +122,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
   for (;;) {
     if (threadIdx.x == 0) sh_u32[0] = atomicAdd(A.work, 1u);
     __syncthreads();
-    const uint64_t w0 = (uint64_t)sh_u32[0] * kChunkWords;
+    const uint64_t w0 = (uint64_t)sh_u32[0] * A.chunk_words;
     __syncthreads();
     if (w0 >= n_words) break;
     Cursor cur;
-    for (uint64_t w = w0; w < w0 + kChunkWords && w < n_words; ++w) {
+    for (uint64_t w = w0; w < w0 + A.chunk_words && w < n_words; ++w) {
       uint32_t bits = A.bits[w] & ~A.host_bits[w];
       bits = (uint32_t)__builtin_amdgcn_readfirstlane((int)bits);
       for (; bits; bits &= bits - 1) {
@@ -275,15 +277,21 @@ uint32_t replay_lkl_waves(uint32_t n_ind) {
   return 0;  // (beyond 4,096 individuals: the host's replay)
 }
 
-hipError_t launch_replay_lkl(const ReplayLklArgs &a, int n_cus, hipStream_t stream) {
+hipError_t launch_replay_lkl(const ReplayLklArgs &a_in, int n_cus, hipStream_t stream) {
+  ReplayLklArgs a = a_in;
   if (a.bits == nullptr || a.n_records == 0) return hipSuccess;
   const uint32_t waves = replay_lkl_waves(a.n_ind);
   if (waves == 0) return hipErrorInvalidValue;
   // a persistent grid: as many teams as the device holds at two wavefronts per SIMD (the kernel's registers allow no more),
   // never more than there are chunks to claim
-  const uint64_t chunks = ((a.n_records + 31) / 32 + kChunkWords - 1) / kChunkWords;
+  const uint64_t n_words = (a.n_records + 31) / 32;
   uint64_t teams = (uint64_t)n_cus * 8 / waves;
   if (waves == 8) teams = (uint64_t)n_cus;  // (its quotient rows take 131 KB of LDS: one team per CU)
+  // A claim is 128 records where the launch is large (a binary search of the plan per claim, the row's vector kept from pair
+  // to pair) -- but a text batch is 2^19 records, 2 such claims per team, and a monomorphic row flags ALL its pairs: one
+  // team then sat on 256 pairs (10 ms) while the others had gone.  Every team should find sixteen claims or more.
+  a.chunk_words = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(kChunkWords, n_words / (teams * 16)));
+  const uint64_t chunks = (n_words + a.chunk_words - 1) / a.chunk_words;
   if (teams > chunks) teams = chunks;
   if (teams < 1) teams = 1;
   const dim3 grid((unsigned)teams);
