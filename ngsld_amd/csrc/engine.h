@@ -244,6 +244,8 @@ using namespace ngsld::eng;
 struct ngsld_ctx {
   int device = 0;
   hipStream_t stream = nullptr, stream2 = nullptr, copy_stream = nullptr;
+  hipStream_t text_stream = nullptr;  // the row-writing kernels of text batches (made on first use: ngsld_run with text output)
+  hipEvent_t ev_scan_done[3] = {nullptr, nullptr, nullptr};  // a text batch's lengths and prefix sums are there
   std::string err;
 
   // data

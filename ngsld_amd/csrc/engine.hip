@@ -274,6 +274,9 @@ void ngsld_destroy(ngsld_ctx *c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->stream2) (void)hipStreamDestroy(c->stream2);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->text_stream) (void)hipStreamDestroy(c->text_stream);
+  for (int k = 0; k < 3; ++k)
+    if (c->ev_scan_done[k]) (void)hipEventDestroy(c->ev_scan_done[k]);
   if (c->replay_stream) (void)hipStreamDestroy(c->replay_stream);
   delete c;
 }

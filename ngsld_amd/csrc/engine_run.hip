@@ -326,8 +326,12 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     if (text) {
       HIP_TRY(c, c->d_lens[k].resize(cap));
       HIP_TRY(c, c->d_offs[k].resize(cap));
-      HIP_TRY(c, c->d_text_meta[k].resize(3));  // {total bytes, needs_host, a replayed row changed its length}
-      HIP_TRY(c, c->h_text_meta[k].resize(3));
+      HIP_TRY(c, c->d_text_meta[k].resize(4));  // {total bytes, needs_host, a replayed row changed its length, the early write pass ran out of room}
+      HIP_TRY(c, c->h_text_meta[k].resize(4));
+      // the batch's rows are WRITTEN right behind their lengths, on the compute stream, before the host knows how long the
+      // text is (see issue): room for the usual row -- a batch that needs more is written again once its length is known
+      const uint64_t row_guess = 2 * c->max_label + (ext ? 200 : 72);
+      if (c->d_text[k].n < cap * row_guess) HIP_TRY(c, c->d_text[k].resize(cap * row_guess));
     }
     if (replay) {
       c->flag_cap[k] = flag_cap_for(cap);
@@ -349,6 +353,9 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   }
   size_t scan_bytes = 0;
   if (text) {
+    if (c->text_stream == nullptr) HIP_TRY(c, hipStreamCreate(&c->text_stream));
+    for (int k = 0; k < S; ++k)
+      if (c->ev_scan_done[k] == nullptr) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_scan_done[k], hipEventDisableTiming));
     scan_bytes = text_scan_temp_bytes(cap);
     HIP_TRY(c, c->d_scan_tmp.resize(scan_bytes ? scan_bytes : 1));
     if (two_streams) HIP_TRY(c, c->d_scan_tmp_b.resize(scan_bytes ? scan_bytes : 1));
@@ -370,6 +377,8 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     t.lens = c->d_lens[k].p;
     t.offs = c->d_offs[k].p;
     t.text = c->d_text[k].p;
+    t.text_cap = 0;
+    t.overflow = c->d_text_meta[k].p + 3;
     t.needs_host = reinterpret_cast<int *>(c->d_text_meta[k].p + 1);
     return t;
   };
@@ -408,14 +417,26 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       const int rch = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], st);
       if (rch != NGSLD_OK) return rch;
     }
-    if (text) {  // row lengths and their prefix sums right behind the pair kernel; the rows are written at consume time
-      HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), st));
-      const TextArgs t = text_args(b, k);
+    if (text) {  // row lengths and their prefix sums right behind the pair kernel, the rows behind those
+      HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 4 * sizeof(uint64_t), st));
+      TextArgs t = text_args(b, k);
       HIP_TRY(c, launch_text_lengths(t, st));
       HIP_TRY(c, text_scan(st == c->stream ? c->d_scan_tmp.p : c->d_scan_tmp_b.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n,
                            c->d_text_meta[k].p, st));
-      HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-      HIP_TRY(c, hipEventRecord(c->ev_kernel_done[k], st));
+      // The rows themselves, at once: on a stream of their own that waits for this batch's prefix sums -- no trip through
+      // the host.  Rounds 1-4 wrote the rows from the host's side of the loop (on the copy stream, once the host had read the
+      // batch's length): with fewer hardware queues than busy streams (GPU_MAX_HW_QUEUES, or other streams in the process) that
+      // kernel was SUBMITTED behind the pair kernels of the next two batches, queued behind them, and the host waited for
+      // them before it issued more -- 0.55 s for configs[2]'s loop on four queues, 0.80 on two, 0.94 on one
+      // (profiles/r04/hw_queues_ab.txt).  Submitted here it stands before them in whatever queue it shares; the copy stream
+      // carries nothing but the D2H copies (SDMA).  A batch whose records are patched afterwards (host replay) or that
+      // outgrows the buffer is written again when consumed.
+      t.text_cap = c->d_text[k].n;
+      HIP_TRY(c, hipEventRecord(c->ev_scan_done[k], st));
+      HIP_TRY(c, hipStreamWaitEvent(c->text_stream, c->ev_scan_done[k], 0));
+      HIP_TRY(c, launch_text_write(t, c->text_stream));
+      HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->text_stream));
+      HIP_TRY(c, hipEventRecord(c->ev_kernel_done[k], c->text_stream));
       return NGSLD_OK;
     }
     HIP_TRY(c, hipEventRecord(c->ev_kernel_done[k], st));
@@ -460,6 +481,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       // kernel of the next batch (already enqueued) runs on the compute stream
       HIP_TRY(c, hipEventSynchronize(c->ev_kernel_done[k]));
       t_ev = now_ms();
+      bool rewrite = false;  // the rows the issue wrote are stale: records were patched since
       if (replay) c->flagged_pairs += c->h_flags[k].p[0];
       if (replay && c->h_flags[k].p[0] != 0) {
         bool applied = c->slot_dev_applied[k];
@@ -473,13 +495,14 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
           if (rcx != NGSLD_OK) return rcx;
           rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream);
           if (rcx != NGSLD_OK) return rcx;
-          HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 2 * sizeof(uint64_t), c->copy_stream));
+          HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 4 * sizeof(uint64_t), c->copy_stream));
           const TextArgs t = text_args(b, k);
           HIP_TRY(c, launch_text_lengths(t, c->copy_stream));
           HIP_TRY(c, text_scan(c->d_scan_tmp2.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n, c->d_text_meta[k].p, c->copy_stream));
-          HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
+          HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
           HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
           applied = true;
+          rewrite = true;
         }
         // flagged pairs: replayed on the host, patched into the device records, and the row lengths derived again --
         // all on the copy stream, beside the next batch's pair kernel
@@ -492,6 +515,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
         // prefix sums are taken again only if one of them changed -- a full length pass + scan beside the next batch's pair
         // kernel cost that kernel ~1 ms of every 11 (profiles/r04/e2e_timeline.txt)
         if (!recs.empty()) {
+          rewrite = true;
           HIP_TRY(c, c->d_patch_s1.resize(recs.size()));
           HIP_TRY(c, c->d_patch_s2.resize(recs.size()));
           HIP_TRY(c, hipMemcpyAsync(c->d_patch_s1.p, rep_s1.data(), recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
@@ -532,11 +556,17 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
         const int rc1 = need_host_items();
         if (rc1 != NGSLD_OK) return rc1;
       } else {
-        if (total > c->d_text[k].n) HIP_TRY(c, c->d_text[k].resize(total + total / 8));
+        if (total > c->d_text[k].n) {
+          HIP_TRY(c, c->d_text[k].resize(total + total / 8));
+          rewrite = true;
+        }
+        if (c->h_text_meta[k].p[3] != 0) rewrite = true;  // (the early write pass ran out of room)
         if (total > c->h_text[k].n) HIP_TRY(c, c->h_text[k].resize(total + total / 8));
         if (total) {
-          const TextArgs t = text_args(b, k);
-          HIP_TRY(c, launch_text_write(t, c->copy_stream));
+          if (rewrite) {
+            const TextArgs t = text_args(b, k);
+            HIP_TRY(c, launch_text_write(t, c->copy_stream));
+          }
           HIP_TRY(c, hipMemcpyAsync(c->h_text[k].p, c->d_text[k].p, total, hipMemcpyDeviceToHost, c->copy_stream));
         }
         HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
@@ -587,6 +617,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream2));
+  if (c->text_stream) HIP_TRY(c, hipStreamSynchronize(c->text_stream));
   HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
   if (rc != NGSLD_OK) return rc;
   return check_status(c);

@@ -23,6 +23,8 @@ struct TextArgs {
   uint64_t *lens;           // [n_pairs] out (length pass) / in (write pass)
   const uint64_t *offs;     // [n_pairs] exclusive prefix sums of lens (write pass)
   char *text;               // write pass: the batch's text
+  uint64_t text_cap;        // ... and its capacity in bytes (0: not checked); a row that would end beyond it is not written and
+  uint64_t *overflow;       // *overflow is set (the write pass issued before the host knows the batch's length: engine_run.hip)
   int *needs_host;          // set to 1 when a value is outside the device formatter's range
 };
 

@@ -206,6 +206,10 @@ __global__ __launch_bounds__(256) void text_kernel(TextArgs A) {
   if (c >= it.count || !((it.mask >> c) & 1ull)) return;  // ngsLD.cpp:270-282: not a computed pair
   const uint64_t k = it.first_record - A.out_base + (uint64_t)__popcll(it.mask & ((1ull << c) - 1ull));
   const uint32_t s1 = it.s1, s2 = it.s2_begin + c;
+  if (WRITE && A.text_cap != 0 && A.offs[k] + A.lens[k] > A.text_cap) {
+    *A.overflow = 1;
+    return;
+  }
   if (WRITE && NGSLD_TEXT_WORDS) {
     WordWriter w(A.text + A.offs[k]);
     (void)format_row(w, A, s1, s2, k);
