@@ -78,6 +78,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-sink", action="store_true", help="skip the host-resident leg (value_host_resident)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file -> TSV leg of the drop-in binary")
+    ap.add_argument("--no-unfiltered", action="store_true",
+                    help="skip the `unfiltered_input` leg (the same pass on 10,000 sites that are NOT SNP-called)")
     ap.add_argument("--ignore-miss", action="store_true", help="run the --ignore_miss_data kernels (not the headline config)")
     ap.add_argument("--rnd-sample", type=float, default=1.0, help="--rnd_sample of the plan (not the headline config)")
     ap.add_argument("--hard-calls", action="store_true",
@@ -307,7 +309,7 @@ def measure_traffic(args) -> dict | None:
     if not os.path.exists(exe):
         return None
     child = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--config", args.config, "--steps", "1",
-             "--warmup", "0", "--no-cpu", "--no-sink", "--no-e2e", "--no-traffic", "--sites", str(args.sites), "--ind",
+             "--warmup", "0", "--no-cpu", "--no-sink", "--no-e2e", "--no-traffic", "--no-unfiltered", "--sites", str(args.sites), "--ind",
              str(args.ind), "--max-kb", str(args.max_kb), "--max-gap", str(args.max_gap), "--scaling", args.scaling,
              "--depth", repr(args.depth), "--seed", str(args.seed), "--rnd-sample", repr(args.rnd_sample),
              "--mono-frac", repr(args.mono_frac)]
@@ -350,6 +352,55 @@ def measure_traffic(args) -> dict | None:
                       "workload outside the timed region; FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-stream correction, "
                       "MI355X_MICROARCH.md HBM section) + WRITE_SIZE KiB x 1024; fabric-side counters: Infinity-Cache hits "
                       "included, an upper bound on HBM bytes"}
+
+
+def unfiltered_input_leg(n_sites: int, n_ind: int, max_kb: int, max_gap: int, depth: float, dev_index: int) -> dict:
+    """The same pass on a matrix that is NOT SNP-called (the reference's README.md:73: "these comparisons will show up as nan or
+    inf"; its own examples/test.sh feeds such input): 20 % of the sites monomorphic in the population and, a second matrix, site
+    frequencies log-uniform in [0.001, 0.5].  A third of the pairs (a fourteenth) are then pairs the reference's own rounding
+    decides -- flagged by the pair kernels and replayed in the reference's operation order, on the DEVICE (ld_replay_lkl.hip) once the
+    exact store is built (host libm, once per matrix: inside `first_pass_s`).  Small (n_sites sites) so that the default line carries
+    it every round; `bench.py --mono-frac 0.2` / `--sfs` is the same at full size."""
+    import torch
+    from ngsld_amd import capi, shard, synth
+    dev = torch.device("cuda", dev_index)
+    out = {"n_sites": n_sites, "n_ind": n_ind, "max_kb_dist": max_kb}
+    chrs, pos = synth.make_positions(n_sites, 33, max_gap=max_gap)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    for name, kw in (("mono_frac_0.2", {"mono_frac": 0.2}), ("sfs", {"sfs": True})):
+        raw = synth.make_gl_torch(n_sites, n_ind, 33, dev, depth=depth, **kw)
+        host = raw.cpu().numpy()
+        eng = capi.Engine(dev_index)
+        try:
+            eng.set_geno_raw(raw.data_ptr(), n_sites=n_sites, n_ind=n_ind)
+            eng.set_replay_source(host)
+            eng.set_pos_dist(pd)
+            n_pairs = eng.plan(max_kb_dist=max_kb, extend_out=True)
+            d_std = torch.empty(max(n_pairs, 1) * STD_BYTES, dtype=torch.uint8, device=dev)
+            d_ext = torch.empty(max(n_pairs, 1) * EXT_BYTES, dtype=torch.uint8, device=dev)
+            st = torch.cuda.current_stream().cuda_stream
+
+            def one():
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                eng.run_device(0, n_sites, d_std.data_ptr(), d_ext.data_ptr(), st)
+                eng.finish_device()
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0
+            first = one()
+            best = min(one() for _ in range(3))
+            info = eng.replay_info()
+            eng.set_replay(False)
+            eng.plan(max_kb_dist=max_kb, extend_out=True)
+            one()
+            off = min(one() for _ in range(2))
+            out[name] = {"pairs": n_pairs, "value": n_pairs / best, "unit": "pairs/s", "ms_per_pass": best * 1e3,
+                         "first_pass_s": round(first, 4), "value_replay_off": n_pairs / off, "replay": info}
+        finally:
+            eng.close()
+        del raw, host
+        torch.cuda.empty_cache()
+    return out
 
 
 def estimate_row_work(raw, pos_dist, args, dev_index: int, n_sites: int, n_ind: int) -> tuple[np.ndarray, dict]:
@@ -572,6 +623,9 @@ def main():
     if rank == 0 and headline and not args.no_e2e and args.config == "c2" and not args.custom:
         torch.cuda.synchronize()
         e2e = e2e_file_to_tsv(raw, n_sites, n_ind, chrs, pos, args.max_kb, host_cpus()["threads_used"])
+    unfiltered = None
+    if rank == 0 and headline and not args.no_unfiltered and args.config == "c2" and not args.custom:
+        unfiltered = unfiltered_input_leg(10_000, n_ind, args.max_kb, args.max_gap, args.depth, dev_index)
     del slab, raw
     torch.cuda.empty_cache()
 
@@ -726,6 +780,7 @@ def main():
                                   f"buffers over the host link, two batches in turn); mean of {sink_passes} consecutive passes, all "
                                   "ranks, MAX over ranks",
             "e2e_file_to_tsv_s": e2e,
+            "unfiltered_input": unfiltered,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "traffic_per_pair": None, "traffic_detail": None,

@@ -465,8 +465,9 @@ bool exact_store_is_free(const ngsld_ctx *c);
 int ensure_exact_store(ngsld_ctx *c);
 // should a run that has `pending` flagged pairs for the host build the store instead?
 bool exact_store_wanted(const ngsld_ctx *c, uint64_t pending);
+// flag_text: the launch's records become text (PairArgs::flag_text)
 int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
-                      ngsld_rec_ext *d_ext, hipStream_t st);
+                      ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text);
 int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t base, ngsld_rec_std *h_std,
                    ngsld_rec_ext *h_ext, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext, hipStream_t st,
                    std::vector<uint32_t> *sites1 = nullptr, std::vector<uint32_t> *sites2 = nullptr);

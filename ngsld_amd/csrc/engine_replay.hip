@@ -455,12 +455,17 @@ int ensure_exact_store(ngsld_ctx *c) {
 // The flagged pairs of a launch replayed on the device (likelihood matrices), on `st` behind the pair kernels that flagged
 // them -- before the head of the flag buffer travels to the host, before text rows are formatted.  The store must be ready.
 int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
-                      ngsld_rec_ext *d_ext, hipStream_t st) {
+                      ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text) {
   if (!c->exact_ready || d_flags == nullptr || n == 0) return NGSLD_OK;
   ReplayLklArgs a{};
   const size_t head = flag_head_words(cap), words = flag_bitmap_words(n);
   a.bits = d_flags + head;
   a.host_bits = d_flags + head + words;
+  a.flags = d_flags;
+  a.flag_cap = cap;
+  a.flag_text = flag_text ? 1u : 0u;
+  a.mean_e = c->d_mean.p;
+  a.rsx = c->d_rsx.p;
   a.n_records = n;
   a.done = d_flags + 2;
   a.work = d_flags + 3;
@@ -531,7 +536,7 @@ int finish_device_run(ngsld_ctx *c) {
     // the pairs are replayed on the device, behind the kernels on their stream
     int rcx = ensure_exact_store(c);
     if (rcx == NGSLD_OK)
-      rcx = device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, base, n, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st);
+      rcx = device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, base, n, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st, false);
     if (rcx != NGSLD_OK) return rcx;
     rcx = send_flag_head(c, c->d_flags_dev.p, c->h_flags_dev.p, c->flag_cap_dev, c->dev_run.st);
     if (rcx != NGSLD_OK) return rcx;

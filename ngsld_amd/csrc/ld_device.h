@@ -127,6 +127,8 @@ struct PairArgs {
   uint32_t *flags_host;  // second bitmap (one bit per record): the flagged pairs only the host's replay settles (may be null)
   uint32_t flag_cap;   // entries of the list in flags
   uint32_t flag_text;  // also flag the pairs whose printed digits (six decimals) rounding noise could change
+  uint32_t pearson_on_device;  // an ill-conditioned Pearson moment (kPearsonCond) is settled by the device-side replay of likelihood
+                               // matrices (ld_replay_lkl.hip: two passes over the exact values); 0: such pairs are the host's
   // tiled workgroup order of the multi-wavefront kernel (launch_pair_kernel; tile_nk == 0: workgroup i takes item i):
   // rows [row0, row1) of the plan, tiles of tile_rows rows x 8 items, tile_nk tiles per row block; workgroup ids without an
   // item (row beyond row1, item index beyond the row's count) leave at once
@@ -782,10 +784,11 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
     const double q1 = fabs(hm1) <= fabs(1 - hm1) ? fabs(hm1) : fabs(1 - hm1);
     // (NaN frequencies fail both comparisons)
     // host_only: reasons that concern r2_ExpG -- what the device-side replay of called genotypes (ld_replay.hip) leaves alone
-    bool host_only = odd_site || (!constant_site && (double)A.n_ind * a1 * a2 > kPearsonCond);  // (a constant site: NaN on every path)
+    const bool pearson_bad = !constant_site && (double)A.n_ind * a1 * a2 > kPearsonCond;  // (a constant site: NaN on every path)
+    bool host_only = odd_site || (pearson_bad && !A.pearson_on_device);
     // (written so that a NaN anywhere -- frequencies, D', r2 -- flags the pair)
     const double amp_q = 1.0 / q0 + 1.0 / q1, big = fabs(Dp) >= o.r2 ? fabs(Dp) : o.r2;
-    bool flag = tie || host_only || !(q0 >= kReplayFloor) || !(q1 >= kReplayFloor) || !(kHapNoise * amp_q * big <= kRecordTol);
+    bool flag = tie || host_only || pearson_bad || !(q0 >= kReplayFloor) || !(q1 >= kReplayFloor) || !(kHapNoise * amp_q * big <= kRecordTol);
     // The TSV prints six decimals (ngsLD.cpp:314-349).  A value that sits on a rounding point of the sixth decimal --
     // closer to it than this kernel and the reference can differ -- would print a different last digit, and a D within
     // rounding noise of zero a different sign ("-0.000000"): those pairs are replayed too, so that the text is the
@@ -795,7 +798,8 @@ __device__ __forceinline__ void write_pair(const PairArgs &A, uint64_t slot, dou
     constexpr double kUlp = 0x1p-52;
     const double d_abs = A.flag_text ? 32 * kUlp : -1.0;  // (negative: near_rounding is never true)
     const double amp = A.flag_text ? amp_q : 0.0;
-    host_only = host_only || near_rounding(o.r2_ExpG, 0.5 * d_abs * (1.0 + 4.0 * (double)A.n_ind * a1 * a2));
+    // (a pair whose moment is ill conditioned: this r2_ExpG is not the number to look at -- whoever replays the pair does)
+    host_only = host_only || (!pearson_bad && near_rounding(o.r2_ExpG, 0.5 * d_abs * (1.0 + 4.0 * (double)A.n_ind * a1 * a2)));
     flag = flag || host_only || fabs(D) < 2 * d_abs || near_rounding(D, d_abs) ||
            near_rounding(Dp, 2 * d_abs * (1.0 + fabs(Dp) * amp)) || near_rounding(o.r2, 2 * d_abs * (1.0 + o.r2 * amp));
     if (A.out_ext != nullptr)

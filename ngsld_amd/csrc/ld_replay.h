@@ -33,7 +33,12 @@ hipError_t launch_replay_hard(const ReplayHardArgs &a, uint64_t n_records, hipSt
 // ---- genotype likelihoods (ld_replay_lkl.hip) ----
 struct ReplayLklArgs {
   const uint32_t *bits;       // the launch's flag bitmap: one bit per record (ld_device.h)
-  const uint32_t *host_bits;  // ... and the pairs among them that stay with the host (PairArgs::flags_host)
+  uint32_t *host_bits;        // ... and the pairs among them that stay with the host (PairArgs::flags_host); the kernel adds the
+                              // pairs whose r2_ExpG it cannot settle itself (see below)
+  uint32_t *flags;            // the launch's flag buffer (its counters and host-only list, ld_device.h)
+  uint32_t flag_cap;
+  uint32_t flag_text;         // the records become text: r2_ExpG values on a sixth-decimal rounding point are the host's
+  const double *mean_e, *rsx; // [n_sites] the pair kernels' per-site moments (which pairs they flagged for their Pearson moment)
   uint64_t n_records;         // records in the launch
   uint32_t chunk_words;       // bitmap words per claim (set by launch_replay_lkl)
   uint32_t *work;             // chunk counter of the persistent teams, zero at launch

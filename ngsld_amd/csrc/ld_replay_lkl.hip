@@ -22,8 +22,14 @@
 // time a run flags more pairs than the host should replay; ngsld_set_geno_lkl input IS such a store already), laid out
 // like the planes of the pair kernels: [site][genotype][np].
 //
-// r2_ExpG is left as the pair kernel wrote it (GSL's long double recurrence has no device twin): pairs flagged for a reason
-// that concerns it are marked in a second bitmap (PairArgs::flags_host) and stay with the host.
+// r2_ExpG is left as the pair kernel wrote it, with one exception.  GSL's long double recurrence has no device twin, so bit
+// equality with it is the host's business -- but a pair flagged because the pair kernel's cross moment is ILL CONDITIONED
+// (both sites nearly constant: 1 / (std1 std2) > 2^13, every pair of two monomorphic sites of deep data) needs no bit
+// equality, only a sound evaluation: two passes over the exact expected genotypes (mean, then centred sums), which agree
+// with the recurrence to ~n 2^-64 (2 + mean1 / std1 + mean2 / std2) -- inside 1e-9 as long as neither site's mean / std
+// exceeds 2^20.  Those are settled here; the rest (mean / std beyond that, or a value that lands on a sixth-decimal rounding
+// point of a text run) are ADDED to the host-only bitmap and list for the host.  Pairs that were host-only from the start
+// (PairArgs::flags_host) are never touched.
 //
 // Work distribution.  No list: the launch's flag BITMAP is the work queue.  A team (one wavefront per pair up to 512
 // individuals, 2 / 4 / 8 beyond) claims chunks of kChunkWords words with one atomic, walks their set bits and maps a record
@@ -40,6 +46,7 @@ namespace {
 constexpr double kEps = 1e-5;  // EPSILON, gen_func.hpp:16
 constexpr int kMaxIter = 100;  // ITER_MAX, gen_func.hpp:18
 constexpr int kMaxSlots = 8;   // individuals per lane, at most (both sites' triples: 6 doubles each, in registers)
+constexpr double kMeanOverStd = 0x1p20;  // r2_ExpG on the device only where GSL's own recurrence is good to 1e-9
 constexpr uint32_t kChunkWords = 4;  // 128 records per claim at most (launch_replay_lkl: fewer for small launches)
 
 __device__ __forceinline__ double ref_abs(double x) { return x >= 0 ? x : -x; }           // gen_func.hpp:21-23: macros
@@ -106,11 +113,33 @@ struct Cursor {
   }
 };
 
+// sum of two values over the team's lanes (every lane gets both); `red`: 2 * WAVES doubles of LDS
+template <int WAVES>
+__device__ __forceinline__ void team_sum2(double &u, double &v, double *red, int wave, int lane) {
+  double w = 0;
+  wave_sum3(u, v, w);
+  if (WAVES > 1) {
+    __syncthreads();
+    if (lane == 0) {
+      red[2 * wave] = u;
+      red[2 * wave + 1] = v;
+    }
+    __syncthreads();
+    u = 0;
+    v = 0;
+    for (int q = 0; q < WAVES; ++q) {
+      u += red[2 * q];
+      v += red[2 * q + 1];
+    }
+  }
+}
+
 template <int WAVES, int kSlots>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void replay_lkl_kernel(ReplayLklArgs A) {
   constexpr int kRow = WAVES * kSlots * 64 + 2;  // doubles per row of quotients (+2: the four chain lanes read different banks)
   __shared__ __attribute__((aligned(16))) double quo[4 * kRow];  // [haplotype][individual]
   __shared__ double fnew[4];
+  __shared__ double red[2 * WAVES];
   __shared__ uint32_t sh_u32[2 + WAVES];  // [0] claimed chunk, [1] converged, [2 + w] individuals with data in wavefront w
   const int lane = threadIdx.x & 63;
   const int wave = WAVES == 1 ? 0 : (int)(threadIdx.x >> 6);
@@ -161,6 +190,51 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
           __syncthreads();
           x = 0;
           for (int v = 0; v < WAVES; ++v) x += sh_u32[2 + v];
+        }
+
+        // ---- r2_ExpG where the pair kernel's moment is ill conditioned (same test, same per-site values as write_pair) ----
+        const double c1 = fabs(A.rsx[s1]), c2 = fabs(A.rsx[s2]);
+        if (c1 != __builtin_inf() && c2 != __builtin_inf() && (double)A.n_ind * c1 * c2 > kPearsonCond) {
+          // pearson_r (ngsLD.cpp:365-367) over ALL individuals of expected_geno = p1 + 2 p2 (ngsLD.cpp:113), two passes
+          double ex[kSlots], ey[kSlots], sx = 0, sy = 0;
+#pragma unroll
+          for (int j = 0; j < kSlots; ++j) {
+            ex[j] = a[j][1] + 2 * a[j][2];
+            ey[j] = b[j][1] + 2 * b[j][2];
+            sx += ex[j];  // (individuals beyond n_ind are zeros)
+            sy += ey[j];
+          }
+          team_sum2<WAVES>(sx, sy, red, wave, lane);
+          const double mx = sx / (double)A.n_ind, my = sy / (double)A.n_ind;
+          double sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+          for (int j = 0; j < kSlots; ++j) {
+            const bool in = (uint32_t)((wave * kSlots + j) * 64 + lane) < A.n_ind;
+            const double dx = in ? ex[j] - mx : 0.0, dy = in ? ey[j] - my : 0.0;
+            sxx += dx * dx;
+            syy += dy * dy;
+            sxy += dx * dy;
+          }
+          team_sum2<WAVES>(sxx, syy, red, wave, lane);
+          double zero = 0;
+          team_sum2<WAVES>(sxy, zero, red, wave, lane);
+          const double r = sxy / (__dsqrt_rn(sxx) * __dsqrt_rn(syy)), r2 = r * r;
+          const double n = (double)A.n_ind;
+          const double ms1 = fabs(mx) * __dsqrt_rn(n / sxx), ms2 = fabs(my) * __dsqrt_rn(n / syy);
+          // what GSL's recurrence may differ from this by (long double: 2^-64 per operation, the running means' rounding
+          // carried into every centred term), plus this evaluation's own few ulp
+          const double bound = 0x1p-50 + 2 * fabs(r) * n * 0x1p-63 * (2 + ms1 + ms2);
+          const double t6 = r2 * 1e6;
+          const bool on_edge = A.flag_text != 0 && fabs((t6 - floor(t6)) - 0.5) < bound * 1e6;
+          if (!(ms1 <= kMeanOverStd) || !(ms2 <= kMeanOverStd) || !(sxx > 0) || !(syy > 0) || on_edge) {
+            if (threadIdx.x == 0) {  // the host's: marked where the host looks for its pairs
+              atomicOr(&A.host_bits[slot >> 5], 1u << (slot & 31u));
+              const uint32_t kh = atomicAdd(&A.flags[1], 1u);
+              if (kh < kFlagHostCap) reinterpret_cast<uint64_t *>(A.flags + kFlagListAt + 2u * A.flag_cap)[kh] = slot;
+            }
+            continue;
+          }
+          if (threadIdx.x == 0) A.out_std[slot].r2_ExpG = r2;
         }
 
         // ---- haplo_freq (gen_func.cpp:1027-1059) ----

@@ -172,3 +172,39 @@ def test_log_scale_and_filters(eng):
             out[mode] = eng.run()
             assert len(out[mode][0]) == n
         assert_same_records(out[0], out[2])
+
+
+@pytest.mark.parametrize("n_ind", [100, 500, 1000])
+def test_ill_conditioned_pearson_moments_are_settled_on_the_device(eng, n_ind):
+    """Deep data: the expected genotypes of a monomorphic site are constant to 1e-5, and every pair of two such sites has a
+    cross moment the pair kernels cannot form (1 / (std1 std2) > 2^13: rounds 2-4 left those to the host -- 4 % of the pairs at
+    20 % monomorphic sites).  The device-side replay takes two passes over the exact values instead; what is left for the host
+    are sites whose mean / std is beyond what GSL's own long double recurrence resolves to 1e-9."""
+    raw = uncalled(50, n_ind, seed=300 + n_ind, depth=30.0, mono_frac=0.4)
+    o = orc.Oracle(raw, n_threads=4)
+    want = o.run()
+    std = o.expg.std(axis=1)
+    with np.errstate(divide="ignore"):
+        cond = 1.0 / (std[want["s1"]] * std[want["s2"]])
+    bad = int(np.count_nonzero(np.isfinite(cond) & (cond > 2.0 ** 13)))
+    assert bad > len(want) // 20
+    host = run_records(eng, raw, 0)
+    dev = run_records(eng, raw, 2)
+    assert dev[4]["pairs_flagged"] == host[4]["pairs_flagged"] >= bad
+    assert dev[4]["pairs_on_host"] <= bad // 20, dev[4]
+    assert_same_records(host, dev)               # (r2_ExpG: within 1e-9 of the recurrence the host ran)
+    check_records(dev[2], dev[3], want)
+    # the same as text: the device's r2_ExpG prints the host's digits (values on a rounding point go to the host)
+    labels = [f"s:{k}" for k in range(50)]
+    texts = {}
+    for mode in (0, 2):
+        eng.set_exact_store(mode)
+        eng.set_geno_raw(raw)
+        eng.set_pos_dist(None)
+        eng.plan(extend_out=True)
+        eng.set_text_output(labels)
+        t, fallbacks = eng.run_text()
+        assert fallbacks == 0
+        texts[mode] = t
+        eng.set_text_output(None, enable=False)
+    assert texts[0] == texts[2]
