@@ -180,7 +180,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
 
 extern "C" {
 
-const char *ngsld_version(void) { return "ngsld-amd 0.2.0 (gfx950; reference ngsLD 1.2.1)"; }
+const char *ngsld_version(void) { return "ngsld-amd 0.3.0 (gfx950; reference ngsLD 1.2.1)"; }
 
 int ngsld_create(int device, ngsld_ctx **out) {
   if (out == nullptr) return NGSLD_ERR_INVALID;
