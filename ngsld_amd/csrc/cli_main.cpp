@@ -189,6 +189,15 @@ void parse_cmd_args(Params *pars, int argc, char **argv) {
   // (n_threads is unsigned in the reference too, ngsLD.hpp:33: a negative value passes the test above as 4 billion and
   // its thread pool then fails to start; here it would only ask for that many formatter threads)
   if (pars->n_threads > 4096) pars->n_threads = 4096;
+  // --keep_parts (new here): <out>, <out>.part1, ... in this order are the table.  Part 0 of a compressed output would be a gzip
+  // member and the others plain text -- their concatenation neither a gzip stream nor a table -- so the two do not combine;
+  // and without --out or with a single device there are no part files to keep: said, not silently ignored
+  if (pars->keep_parts) {
+    const char *dot = pars->out ? strrchr(pars->out, '.') : NULL;
+    if (dot != NULL && strcmp(dot, ".gz") == 0) error(__FUNCTION__, "--keep_parts cannot be combined with a compressed output (--out *.gz)!");
+    if (pars->out == NULL || pars->devices.size() < 2)
+      fprintf(stderr, "WARN: --keep_parts has no effect without --out and --devices with two or more devices\n");
+  }
 }
 
 ngsld_gz *g_gz = nullptr;     // --out *.gz: the compressor behind pars.out_fh
@@ -577,10 +586,6 @@ int main(int argc, char **argv) {
   }
 
   timing_report.mark("ngsld_create");
-  // the pinned host buffers the text batches will land in: allocated by a library thread while the matrix is read, uploaded
-  // and prepped (pinning ~0.7 GB costs ~0.1 s, which the first batches of the run used to wait for)
-  if (!(getenv("NGSLD_HOST_TEXT") && strcmp(getenv("NGSLD_HOST_TEXT"), "1") == 0))
-    (void)ngsld_reserve_text_buffers(ctx, pars.extend_out ? 190 : 95);
   char err[512];
   // ---- does the matrix fit the device?  If not, a windowed run on binary input is streamed slab by slab ----
   uint64_t budget = 0;
@@ -619,6 +624,13 @@ int main(int argc, char **argv) {
     if (run_streamed(pars, slab_sites, /*may_fall_back=*/fits)) return 0;
     if (ngsld_create(pars.device, &ctx) != NGSLD_OK) error("ngsld_create", ngsld_last_error(nullptr));
   }
+
+  // the pinned host buffers the text batches will land in: allocated by a library thread while the matrix is read, uploaded
+  // and prepped (pinning ~0.7 GB costs ~0.1 s, which the first batches of the run used to wait for).  Only now that the run is
+  // known to be resident: a streamed run uses contexts of its own, and destroying this one had to wait for the pinning to
+  // finish only to undo it
+  if (!(getenv("NGSLD_HOST_TEXT") && strcmp(getenv("NGSLD_HOST_TEXT"), "1") == 0))
+    (void)ngsld_reserve_text_buffers(ctx, pars.extend_out ? 190 : 95);
 
   // ---- read input data (ngsLD.cpp:85-114; the arithmetic runs on the device) ----
   if (pars.verbose >= 1) fprintf(stderr, "> Reading data from file...\n");
