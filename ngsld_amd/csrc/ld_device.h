@@ -855,6 +855,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
 
   const int lane = threadIdx.x & 63;
   const int sub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#ifdef NGSLD_PHASE_DELAY
+  // Experiment (round 5, tools/ab_phase.sh; not in the product build): the review's idea for configs[4] -- a SIMD holds one
+  // wavefront of each of the CU's two workgroups, and VALU sits idle when both are in the serial stretch of their iteration --
+  // start one of the two half an iteration late.  Which of the two: the wavefront slot's parity (HW_ID bits 3:0).
+  {
+    const unsigned hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | ((4 - 1) << 11));
+    if (__syncthreads_or((int)(hw & 1u))) __builtin_amdgcn_s_sleep(NGSLD_PHASE_DELAY);  // (x 64 cycles)
+  }
+#endif
   const Item *item_ptr;
   if (A.tile_nk != 0) {
     // Tiled order.  Workgroup ids go round the eight XCDs, so with tiles of tile_rows rows x 8 items, laid out row by row,

@@ -11,7 +11,7 @@ mkdir -p $B $R/ngsld_amd/ab
 make -C $C -s all
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result"
 pids=()
-UNITS="ld_pair_w1 ld_pair_wn ld_pair_ab ld_pair_stream ld_pair_hard ld_prep ld_text ld_replay engine multi"
+UNITS="ld_pair_w1 ld_pair_wn ld_pair_ab ld_pair_stream ld_pair_hard ld_prep ld_text ld_replay ld_replay_lkl engine engine_plan engine_run engine_replay multi"
 for u in $UNITS; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c $C/$u.hip -o $B/$u.o &
   pids+=($!)
