@@ -353,6 +353,15 @@ struct ngsld_ctx {
   // source it is built by the replay threads from the caller's raw values, the first time a run flags more pairs than the host
   // should replay (exact_store_wanted), and kept until the matrix or its source changes.
   DevBuf<double> d_xplanes, d_xmaf;
+  DevBuf<double> d_xT;                 // the store once more, individual-major, for the lane-per-pair kernel (ld_replay_lkl.hip)
+  bool xT_ready = false;
+  struct LaneScratch {   // what the lane-per-pair replay of one launch needs: the located pairs and their sorted order
+    DevBuf<ReplayEntry> list;
+    DevBuf<uint64_t> keys_a, keys_b;
+    DevBuf<uint32_t> vals_a, vals_b;
+    DevBuf<char> temp;
+    void release() { list.release(); keys_a.release(); keys_b.release(); vals_a.release(); vals_b.release(); temp.release(); }
+  } lane_scratch[kSlots], lane_scratch_dev;  // per pipeline slot / for ngsld_run_device
   PinBuf<double> h_xstage[2];
   bool exact_ready = false, exact_alias = false;
   int exact_mode = 1;                  // NGSLD_EXACT_STORE / ngsld_set_exact_store: 0 never (host replay only), 1 when it pays (default), 2 at the first flagged pair
@@ -466,8 +475,9 @@ int ensure_exact_store(ngsld_ctx *c);
 // should a run that has `pending` flagged pairs for the host build the store instead?
 bool exact_store_wanted(const ngsld_ctx *c, uint64_t pending);
 // flag_text: the launch's records become text (PairArgs::flag_text)
+// slot: the pipeline slot whose pair list the launch uses (-1: ngsld_run_device's)
 int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
-                      ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text);
+                      ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text, int slot);
 int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t base, ngsld_rec_std *h_std,
                    ngsld_rec_ext *h_ext, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext, hipStream_t st,
                    std::vector<uint32_t> *sites1 = nullptr, std::vector<uint32_t> *sites2 = nullptr);

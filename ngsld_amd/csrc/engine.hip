@@ -39,6 +39,8 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   c->host_replayed_total = 0;
   c->d_xplanes.release();
   c->d_xmaf.release();
+  c->d_xT.release();
+  c->xT_ready = false;
   c->gopts = o;
   c->normalised = normalised;
   c->n_sites = n_sites;
@@ -254,7 +256,9 @@ void ngsld_destroy(ngsld_ctx *c) {
   (void)hipDeviceSynchronize();
   c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_rsx.release(); c->d_sc4.release(); c->d_runs.release();
   c->d_hard_masks.release(); c->d_hard_u.release(); c->d_all_hard.release();
-  c->d_xplanes.release(); c->d_xmaf.release(); c->h_xstage[0].release(); c->h_xstage[1].release();
+  c->d_xplanes.release(); c->d_xmaf.release(); c->d_xT.release(); c->h_xstage[0].release(); c->h_xstage[1].release();
+  c->lane_scratch_dev.release();
+  for (int k = 0; k < ngsld_ctx::kSlots; ++k) c->lane_scratch[k].release();
   c->d_labels.release(); c->d_scan_tmp.release(); c->d_scan_tmp_b.release(); c->d_label_off.release(); c->d_cum.release(); c->d_infc.release();
   for (int k = 0; k < ngsld_ctx::kSlots; ++k) {
     c->d_text[k].release(); c->d_lens[k].release(); c->d_offs[k].release(); c->d_text_meta[k].release();

@@ -374,12 +374,36 @@ bool exact_store_wanted(const ngsld_ctx *c, uint64_t pending) {
   return c->host_replayed_total + pending > std::max<uint64_t>(4096, c->n_sites / 2);
 }
 
+// The individual-major copy for the lane-per-pair kernel, where the device has room for the matrix once more (NGSLD_REPLAY_LANES=0:
+// never -- the wavefront-per-pair kernel takes everything, as in the round's first sessions).
+static int build_lane_store(ngsld_ctx *c) {
+  c->xT_ready = false;
+  if (const char *e = std::getenv("NGSLD_REPLAY_LANES"))
+    if (std::strcmp(e, "0") == 0) return NGSLD_OK;
+  const size_t elems = (size_t)c->n_sites * c->n_ind * 3;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < elems * sizeof(double) + (4ull << 30)) {
+    (void)hipGetLastError();
+    return NGSLD_OK;
+  }
+  if (c->d_xT.resize(elems) != hipSuccess) {
+    (void)hipGetLastError();
+    return NGSLD_OK;
+  }
+  hipStream_t st = replay_stream_of(c);
+  HIP_TRY(c, launch_transpose_store(c->exact_alias ? c->d_planes.p : c->d_xplanes.p, 3ull * c->np, c->np, (uint32_t)c->n_ind, c->n_sites,
+                                    c->d_xT.p, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  c->xT_ready = true;
+  return NGSLD_OK;
+}
+
 int ensure_exact_store(ngsld_ctx *c) {
   if (c->exact_ready) return NGSLD_OK;
   if (exact_store_is_free(c)) {
     c->exact_alias = true;
     c->exact_ready = true;
-    return NGSLD_OK;
+    return build_lane_store(c);
   }
   Range range_("ngsld:exact store (host libm -> device)");
   const auto t0 = std::chrono::steady_clock::now();
@@ -445,6 +469,10 @@ int ensure_exact_store(ngsld_ctx *c) {
   if (rc != NGSLD_OK) return rc;
   c->exact_alias = false;
   c->exact_ready = true;
+  {
+    const int rcl = build_lane_store(c);
+    if (rcl != NGSLD_OK) return rcl;
+  }
   c->exact_build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (std::getenv("NGSLD_TRACE") != nullptr)
     std::fprintf(stderr, "[trace] exact store: %llu sites x %llu individuals through the host's libm on %d threads in %.3f s\n",
@@ -455,7 +483,7 @@ int ensure_exact_store(ngsld_ctx *c) {
 // The flagged pairs of a launch replayed on the device (likelihood matrices), on `st` behind the pair kernels that flagged
 // them -- before the head of the flag buffer travels to the host, before text rows are formatted.  The store must be ready.
 int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
-                      ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text) {
+                      ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text, int slot) {
   if (!c->exact_ready || d_flags == nullptr || n == 0) return NGSLD_OK;
   ReplayLklArgs a{};
   const size_t head = flag_head_words(cap), words = flag_bitmap_words(n);
@@ -484,6 +512,24 @@ int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t ou
   a.out_std = d_std;
   a.out_ext = d_ext;
   a.status = c->d_status.p;
+  a.xt_sites = c->n_sites;
+  if (c->xT_ready) {
+    // one lane per pair wherever the individual-major copy is there: the launch's bitmap becomes a list of located pairs (the
+    // bits listed are cleared), the lanes work through it; what stays in the bitmap -- ill-conditioned Pearson moments, pairs
+    // beyond the list -- is the wavefront-per-pair kernel's, as everything is without the copy
+    ngsld_ctx::LaneScratch &ls = slot < 0 ? c->lane_scratch_dev : c->lane_scratch[slot];
+    const uint64_t list_cap = std::min<uint64_t>(n, 1ull << 26);
+    const size_t temp_bytes = replay_sort_temp_bytes(list_cap, (uint32_t)c->n_sites);
+    HIP_TRY(c, ls.list.resize(list_cap));
+    HIP_TRY(c, ls.keys_a.resize(list_cap));
+    HIP_TRY(c, ls.keys_b.resize(list_cap));
+    HIP_TRY(c, ls.vals_a.resize(list_cap));
+    HIP_TRY(c, ls.vals_b.resize(list_cap));
+    HIP_TRY(c, ls.temp.resize(temp_bytes ? temp_bytes : 1));
+    HIP_TRY(c, launch_replay_expand(a, ls.list.p, list_cap, st));
+    HIP_TRY(c, launch_replay_sort(a, ls.list.p, list_cap, ls.keys_a.p, ls.keys_b.p, ls.vals_a.p, ls.vals_b.p, ls.temp.p, temp_bytes, st));
+    HIP_TRY(c, launch_replay_lanes(a, ls.list.p, ls.vals_b.p, c->d_xT.p, c->n_cus, st));
+  }
   HIP_TRY(c, launch_replay_lkl(a, c->n_cus, st));
   return NGSLD_OK;
 }
@@ -536,7 +582,7 @@ int finish_device_run(ngsld_ctx *c) {
     // the pairs are replayed on the device, behind the kernels on their stream
     int rcx = ensure_exact_store(c);
     if (rcx == NGSLD_OK)
-      rcx = device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, base, n, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st, false);
+      rcx = device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, base, n, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st, false, -1);
     if (rcx != NGSLD_OK) return rcx;
     rcx = send_flag_head(c, c->d_flags_dev.p, c->h_flags_dev.p, c->flag_cap_dev, c->dev_run.st);
     if (rcx != NGSLD_OK) return rcx;
@@ -567,6 +613,7 @@ int ngsld_set_replay_source(ngsld_ctx *c, ngsld_read_sites_fn read, void *user) 
   c->replay_read = read;
   c->replay_user = user;
   c->exact_ready = false;  // (the exact store is built from the source)
+  c->xT_ready = false;
   c->planned = false;  // a --min_maf tie is settled at plan time
   return NGSLD_OK;
 }
@@ -578,6 +625,7 @@ int ngsld_set_replay_matrix(ngsld_ctx *c, const double *values) {
   c->replay_read = nullptr;
   c->replay_user = nullptr;
   c->exact_ready = false;  // (the exact store is built from the source)
+  c->xT_ready = false;
   c->planned = false;  // a --min_maf tie is settled at plan time
   return NGSLD_OK;
 }

@@ -167,7 +167,7 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
       rcd = ensure_exact_store(c);
       if (rcd == NGSLD_OK)
         rcd = device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, c->h_row_off[s1_begin], c->timed_pairs,
-                                (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, st, false);
+                                (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, st, false, -1);
       if (rcd != NGSLD_OK) return rcd;
       c->dev_run.dev_applied = true;
     }
@@ -405,7 +405,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       if (lkl_device_eligible(c) && (c->exact_ready || exact_store_is_free(c))) {
         rcd = ensure_exact_store(c);
         if (rcd == NGSLD_OK)
-          rcd = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], st, true);
+          rcd = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], st, true, k);
         if (rcd != NGSLD_OK) return rcd;
         c->slot_dev_applied[k] = true;
       }
@@ -492,7 +492,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
           int rcx = ensure_exact_store(c);
           if (rcx == NGSLD_OK)
             rcx = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, c->d_std[k].p,
-                                    ext ? c->d_ext[k].p : nullptr, c->copy_stream, true);
+                                    ext ? c->d_ext[k].p : nullptr, c->copy_stream, true, k);
           if (rcx != NGSLD_OK) return rcx;
           rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream);
           if (rcx != NGSLD_OK) return rcx;
@@ -584,7 +584,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
         if (!applied && exact_store_wanted(c, c->h_flags[k].p[0] - c->h_flags[k].p[1])) {  // (see the text branch above)
           int rcx = ensure_exact_store(c);
           if (rcx == NGSLD_OK)
-            rcx = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], c->copy_stream, true);
+            rcx = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], c->copy_stream, true, k);
           if (rcx != NGSLD_OK) return rcx;
           rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream);
           if (rcx != NGSLD_OK) return rcx;

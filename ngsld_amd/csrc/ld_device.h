@@ -69,8 +69,9 @@ constexpr double kPearsonCond = 0x1p13;
 constexpr double kEpsilonTie = kEpsilon + kTieMargin;
 constexpr uint32_t kTieBit = 0x80000000u;  // rides on n_iter (<= 100) from the EM loop to write_pair
 // Layout of a launch's flag buffer (uint32 words): [0] count of flagged pairs, [1] count of those that are kFlagHostOnly,
-// [2] pairs the device-side replay of likelihood matrices (ld_replay_lkl.hip) has settled, [3] its work counter,
-// [4 .. 4 + 2 cap) the record indices (uint64) of the first `cap` flagged pairs in the order their atomics landed, then the
+// [2] pairs the device-side replay of likelihood matrices (ld_replay_lkl.hip) has settled, [3] the work counter of its
+// wavefront-per-pair kernel, [4] entries of its pair list, [5] the work counter of its lane-per-pair kernel, [6 .. 7] unused,
+// [8 .. 8 + 2 cap) the record indices (uint64) of the first `cap` flagged pairs in the order their atomics landed, then the
 // first kFlagHostCap kFlagHostOnly pairs once more, by themselves (what is left for the host after a device-side replay: read
 // from the head that travels with the batch -- fetching a bitmap for them cost a text batch 7 ms, beside the next batch's
 // pair kernel); behind this head one bit per record, and behind that bitmap (PairArgs::flags_host) a second one: the
@@ -80,7 +81,7 @@ constexpr uint32_t kTieBit = 0x80000000u;  // rides on n_iter (<= 100) from the 
 // A list entry's top bits: kFlagHostOnly -- the pair was flagged for a reason only the host's replay settles (its r2_ExpG:
 // GSL's long double recurrence) --, kFlagDone -- the device-side replay (ld_replay.hip) has already rewritten the record.
 constexpr uint64_t kFlagHostOnly = 1ull << 63, kFlagDone = 1ull << 62, kFlagIndexMask = (1ull << 62) - 1;
-constexpr uint32_t kFlagListAt = 4;  // first word of the list
+constexpr uint32_t kFlagListAt = 8;  // first word of the list
 constexpr uint32_t kFlagHostCap = 1024;  // entries of the host-only list
 __host__ __device__ inline uint32_t flag_head_words(uint32_t cap) { return kFlagListAt + 2u * cap + 2u * kFlagHostCap; }
 

@@ -32,7 +32,7 @@ hipError_t launch_replay_hard(const ReplayHardArgs &a, uint64_t n_records, hipSt
 
 // ---- genotype likelihoods (ld_replay_lkl.hip) ----
 struct ReplayLklArgs {
-  const uint32_t *bits;       // the launch's flag bitmap: one bit per record (ld_device.h)
+  uint32_t *bits;             // the launch's flag bitmap: one bit per record (ld_device.h); launch_replay_expand clears the bits it lists
   uint32_t *host_bits;        // ... and the pairs among them that stay with the host (PairArgs::flags_host); the kernel adds the
                               // pairs whose r2_ExpG it cannot settle itself (see below)
   uint32_t *flags;            // the launch's flag buffer (its counters and host-only list, ld_device.h)
@@ -55,12 +55,35 @@ struct ReplayLklArgs {
   uint64_t site_stride;       // 3 * np
   uint32_t np;
   const double *xmaf;         // [n_sites]
+  uint64_t xt_sites;          // sites of the individual-major copy (lane-per-pair kernel): xT[(i * xt_sites + s) * 3 + g]
   uint32_t n_ind;
   int ignore_miss;
   ngsld_rec_std *out_std;     // the launch's records (device memory, or pinned host memory written in place)
   ngsld_rec_ext *out_ext;     // may be null
   int *status;
 };
+
+// ---- the lane-per-pair form (ld_replay_lkl.hip): one LANE per flagged pair, every lane walking the individuals in order ----
+struct ReplayEntry {  // a flagged pair, located
+  uint64_t slot;      // its record in the launch
+  uint32_t s1, s2;
+};
+// individual-major copy of the exact store: xT[(i * n_sites + s) * 3 + g] = xplanes[s][g][i]
+hipError_t launch_transpose_store(const double *xplanes, uint64_t site_stride, uint32_t np, uint32_t n_ind, uint64_t n_sites,
+                                  double *xT, hipStream_t stream);
+// Walks the launch's bitmap (a thread per word), appends the pairs the lane-per-pair kernel takes to `list` (at most list_cap;
+// counter: flags[4]) and CLEARS their bits: what stays set -- pairs whose Pearson moment is ill conditioned, pairs beyond the
+// list's capacity -- is the wavefront-per-pair kernel's.
+hipError_t launch_replay_expand(const ReplayLklArgs &a, ReplayEntry *list, uint64_t list_cap, hipStream_t stream);
+// The list's entries ordered by (the pair's rarer site, its other site): keys_b / vals_b receive the sorted keys and the entries'
+// indices in that order (ALL list_cap positions are sorted -- the list's length is known to the device only --, unused ones
+// behind the real ones).  temp: replay_sort_temp_bytes(list_cap, n_sites) bytes.
+size_t replay_sort_temp_bytes(uint64_t list_cap, uint32_t n_sites);
+hipError_t launch_replay_sort(const ReplayLklArgs &a, const ReplayEntry *list, uint64_t list_cap, uint64_t *keys_a, uint64_t *keys_b,
+                              uint32_t *vals_a, uint32_t *vals_b, void *temp, size_t temp_bytes, hipStream_t stream);
+// the lane-per-pair kernel over list[order[0 .. flags[4])] (work counter: flags[5])
+hipError_t launch_replay_lanes(const ReplayLklArgs &a, const ReplayEntry *list, const uint32_t *order, const double *xT, int n_cus,
+                               hipStream_t stream);
 
 // wavefronts per pair for a cohort of n_ind individuals (1 up to 512, then 2 / 4 / 8); 0: beyond the kernel (host replay)
 uint32_t replay_lkl_waves(uint32_t n_ind);

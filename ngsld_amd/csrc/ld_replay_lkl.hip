@@ -40,6 +40,8 @@
 
 #include <algorithm>
 
+#include <hipcub/hipcub.hpp>
+
 namespace ngsld {
 namespace {
 
@@ -342,7 +344,277 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The lane-per-pair form.  The wavefront-per-pair kernel above spends a third of its issue slots on four lanes adding
+// 4 x n_ind numbers one by one, and with several wavefronts per pair the others wait for that chain (n_ind 2,000: 6e6
+// replayed pairs/s against 5.4e7 at 500).  Here a LANE owns a pair and walks the individuals in the reference's own order --
+// no chain, no idle lanes: every pair has the same number of individuals, so the 64 lanes of a wavefront reach the end of
+// their EM iteration together, and a lane whose pair has converged takes its next pair there.  ~144 instructions per
+// individual and iteration for 64 pairs at once.  The lanes of a wavefront hold neighbouring pairs (claimed in list order),
+// and the store is read individual-major -- xT[i][site][3] -- so that for one individual their 24-byte triples are neighbours
+// in memory (a monomorphic row's candidates: consecutive sites, 1.5 KB contiguous).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_store_kernel(const double *__restrict__ xplanes, uint64_t site_stride, uint32_t np,
+                                                              uint32_t n_ind, uint64_t n_sites, double *__restrict__ xT) {
+  __shared__ double tile[3][64][65];  // [genotype][site][individual]
+  const uint64_t s0 = (uint64_t)blockIdx.x * 64;
+  const uint32_t i0 = blockIdx.y * 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int ls = w; ls < 64; ls += 4) {
+    const uint64_t s = s0 + ls;
+    const uint32_t i = i0 + lane;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) tile[g][ls][lane] = (s < n_sites && i < n_ind) ? xplanes[s * site_stride + (uint64_t)g * np + i] : 0.0;
+  }
+  __syncthreads();
+  // individual li of the tile: its 64 sites x 3 values are 192 consecutive doubles of xT
+  for (int li = w; li < 64; li += 4) {
+    const uint32_t i = i0 + li;
+    if (i >= n_ind) continue;
+    for (int t = lane; t < 192; t += 64) {
+      const int ls = t / 3, g = t % 3;
+      if (s0 + ls < n_sites) xT[((uint64_t)i * n_sites + s0 + ls) * 3 + g] = tile[g][ls][li];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void replay_expand_kernel(ReplayLklArgs A, ReplayEntry *list, uint64_t list_cap) {
+  const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t n_words = (A.n_records + 31) / 32;
+  if (w >= n_words) return;
+  uint32_t bits = A.bits[w] & ~A.host_bits[w];
+  if (w == n_words - 1 && (A.n_records & 31)) bits &= (1u << (A.n_records & 31)) - 1u;
+  if (!bits) return;
+  // which of them the lane-per-pair kernel takes: all but the pairs whose Pearson moment is ill conditioned (write_pair's
+  // test on the same per-site values: those need the two passes of the wavefront-per-pair kernel)
+  Cursor cur;
+  uint32_t take = 0, s1s[32], s2s[32];
+  for (uint32_t m = bits; m; m &= m - 1) {
+    const int b = __ffs((int)m) - 1;
+    uint32_t s1 = 0, s2 = 0;
+    if (!cur.seek(A, A.rec_base + w * 32 + (uint64_t)b, &s1, &s2)) continue;
+    const double c1 = fabs(A.rsx[s1]), c2 = fabs(A.rsx[s2]);
+    if (c1 != __builtin_inf() && c2 != __builtin_inf() && (double)A.n_ind * c1 * c2 > kPearsonCond) continue;
+    take |= 1u << b;
+    s1s[b] = s1;
+    s2s[b] = s2;
+  }
+  if (!take) return;
+  const uint32_t n = (uint32_t)__popc(take);
+  const uint32_t at = atomicAdd(&A.flags[4], n);
+  if ((uint64_t)at + n > list_cap) {  // (no room: these stay in the bitmap; the counter is put back so that the lanes see only what was written)
+    atomicSub(&A.flags[4], n);
+    return;
+  }
+  uint32_t k = 0;
+  for (uint32_t m = take; m; m &= m - 1, ++k) {
+    const int b = __ffs((int)m) - 1;
+    ReplayEntry e;
+    e.slot = w * 32 + (uint64_t)b;
+    e.s1 = s1s[b];
+    e.s2 = s2s[b];
+    list[at + k] = e;
+  }
+  A.bits[w] &= ~take;  // (this thread owns the word)
+}
+
+// Sort keys of the listed pairs: (the pair's rarer site, its other site).  A wavefront's lanes take NEIGHBOURS of the sorted
+// list, so for one individual they read ONE triple of the site they share and triples of (nearly) consecutive other sites --
+// a monomorphic site's partners, whether it is the pair's row or its candidate; in list order half the pairs of an un-called
+// matrix (ordinary row, monomorphic candidate) had a cache line to themselves per lane and individual.
+__global__ void replay_keys_kernel(ReplayLklArgs A, const ReplayEntry *list, uint64_t list_cap, uint64_t *keys, uint32_t *vals, int site_bits) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= list_cap) return;
+  vals[i] = (uint32_t)i;
+  if (i >= A.flags[4]) {
+    keys[i] = ~0ull >> (64 - 2 * site_bits);  // (behind every real key)
+    return;
+  }
+  const ReplayEntry e = list[i];
+  const double m1 = A.xmaf[e.s1], m2 = A.xmaf[e.s2];
+  const double r1 = m1 <= 0.5 ? m1 : 1 - m1, r2 = m2 <= 0.5 ? m2 : 1 - m2;  // (NaN: compares false, the row's site is the shared one)
+  const bool by2 = r2 < r1;
+  const uint64_t shared = by2 ? e.s2 : e.s1, other = by2 ? e.s1 : e.s2;
+  keys[i] = (shared << site_bits) | other;
+}
+
+constexpr uint32_t kLaneChunk = 256;  // sorted entries a wavefront claims at a time
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void replay_lane_kernel(ReplayLklArgs A, const ReplayEntry *list,
+                                                                                                      const uint32_t *order,
+                                                                                                      const double *xT) {
+  const bool ign = A.ignore_miss != 0;
+  const uint64_t row = A.xt_sites * 3;  // doubles from one individual to the next
+  const uint32_t total = A.flags[4];
+  bool have = false, dry = false;       // this lane holds a pair / the list has run out
+  ReplayEntry e{};
+  const double *pa = xT, *pb = xT;
+  double f[4] = {0, 0, 0, 0};
+  uint32_t iter = 0, pos = 0, end = 0;  // (pos, end: the wavefront's chunk of the sorted list, wave-uniform)
+  for (;;) {
+    // lanes without a pair take the next entries of the wavefront's chunk, in lane order; a new chunk with one atomic
+    for (;;) {
+      const uint64_t need = __ballot(!have && !dry);
+      if (!need) break;
+      if (pos == end) {
+        uint32_t c0 = 0;
+        if ((uint32_t)__lane_id() == (uint32_t)(__ffsll((unsigned long long)need) - 1)) c0 = atomicAdd(&A.flags[5], kLaneChunk);
+        c0 = (uint32_t)__builtin_amdgcn_readlane((int)c0, __ffsll((unsigned long long)need) - 1);
+        if (c0 >= total) {
+          if (!have) dry = true;
+          break;
+        }
+        pos = c0;
+        end = c0 + kLaneChunk < total ? c0 + kLaneChunk : total;
+      }
+      const uint32_t rank = (uint32_t)__popcll(need & ((1ull << __lane_id()) - 1ull));
+      const bool take = !have && !dry && pos + rank < end;
+      const uint32_t n_need = (uint32_t)__popcll(need);
+      if (take) {
+        e = list[order[pos + rank]];
+        const double m1 = A.xmaf[e.s1], m2 = A.xmaf[e.s2];
+        if (m1 < 0 || m1 > 1 || m2 < 0 || m2 > 1) {  // gen_func.cpp:1030-1031: error() in the reference
+          atomicExch(A.status, (int)NGSLD_ERR_MAF_RANGE);
+          f[0] = f[1] = f[2] = f[3] = __builtin_nan("");
+        } else {
+          f[0] = (1 - m1) * (1 - m2);  // gen_func.cpp:1034-1037
+          f[1] = (1 - m1) * m2;
+          f[2] = m1 * (1 - m2);
+          f[3] = m1 * m2;
+        }
+        pa = xT + (uint64_t)e.s1 * 3;
+        pb = xT + (uint64_t)e.s2 * 3;
+        iter = 0;
+        have = true;
+      }
+      pos = pos + n_need < end ? pos + n_need : end;
+    }
+    if (!__any(have)) break;
+    // ---- one EM step (gen_func.cpp:1076-1119) for every lane that holds a pair ----
+    double ff[4] = {0, 0, 0, 0};
+    uint32_t x = 0;
+    if (have) {
+      double a[3], b[3], an[3], bn[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        an[g] = pa[g];
+        bn[g] = pb[g];
+      }
+      for (uint32_t i = 0; i < A.n_ind; ++i) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          a[g] = an[g];
+          b[g] = bn[g];
+        }
+        if (i + 1 < A.n_ind) {  // the next individual's triples are on their way while this one is worked on
+          const double *qa = pa + (uint64_t)(i + 1) * row, *qb = pb + (uint64_t)(i + 1) * row;
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            an[g] = qa[g];
+            bn[g] = qb[g];
+          }
+        }
+        if (ign && (no_data(a) || no_data(b))) continue;  // gen_func.cpp:1089
+        ++x;
+        double o[4];
+        quotients(f, a, b, o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ff[k] += o[k];  // gen_func.cpp:1103, in the reference's order
+      }
+      const double twox = (double)(2 * (uint64_t)x);  // gen_func.cpp:1109
+      double g4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g4[k] = ff[k] / twox;
+      g4[0] /= g4[0] + g4[1] + g4[2] + g4[3];  // gen_func.cpp:1112-1113: sequential
+      g4[1] /= g4[0] + g4[1] + g4[2] + g4[3];
+      g4[2] /= g4[0] + g4[1] + g4[2] + g4[3];
+      g4[3] /= g4[0] + g4[1] + g4[2] + g4[3];
+      double eps = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double d = fabs(g4[k] - f[k]);
+        if (d > eps) eps = d;  // (a NaN never raises eps)
+        f[k] = g4[k];
+      }
+      bool finished = eps < kEps;             // gen_func.cpp:1054: break with n_iter = iter
+      if (!finished && ++iter == (uint32_t)kMaxIter) finished = true;  // ... or the loop runs out: n_iter = ITER_MAX
+      if (finished) {
+        const double hm0 = 1 - (f[0] + f[1]);  // ngsLD.cpp:296-306
+        const double hm1 = 1 - (f[0] + f[2]);
+        const double D = f[0] * f[3] - f[1] * f[2];
+        const double Dp = D / (D < 0 ? -ref_min(hm0 * hm1, (1 - hm0) * (1 - hm1)) : ref_min(hm0 * (1 - hm1), (1 - hm0) * hm1));
+        const double rr = D / __dsqrt_rn(hm0 * hm1 * (1 - hm0) * (1 - hm1));
+        ngsld_rec_std o = A.out_std[e.slot];  // (r2_ExpG stays the pair kernel's)
+        o.D = ref_nan(D);
+        o.Dp = ref_nan(Dp);
+        o.r2 = ref_nan(rr * rr);
+        A.out_std[e.slot] = o;
+        if (A.out_ext != nullptr) {
+          ngsld_rec_ext r;
+          r.hap[0] = ref_nan(f[0]); r.hap[1] = ref_nan(f[1]); r.hap[2] = ref_nan(f[2]); r.hap[3] = ref_nan(f[3]);
+          r.n_ind_data = x;
+          r.n_iter = iter;
+          A.out_ext[e.slot] = r;
+        }
+        atomicAdd(A.done, 1u);
+        have = false;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+hipError_t launch_transpose_store(const double *xplanes, uint64_t site_stride, uint32_t np, uint32_t n_ind, uint64_t n_sites,
+                                  double *xT, hipStream_t stream) {
+  if (n_sites == 0 || n_ind == 0) return hipSuccess;
+  const dim3 grid((unsigned)((n_sites + 63) / 64), (unsigned)((n_ind + 63) / 64));
+  hipLaunchKernelGGL(transpose_store_kernel, grid, dim3(256), 0, stream, xplanes, site_stride, np, n_ind, n_sites, xT);
+  return hipGetLastError();
+}
+
+hipError_t launch_replay_expand(const ReplayLklArgs &a, ReplayEntry *list, uint64_t list_cap, hipStream_t stream) {
+  if (a.bits == nullptr || a.n_records == 0 || list == nullptr) return hipSuccess;
+  const uint64_t n_words = (a.n_records + 31) / 32;
+  hipLaunchKernelGGL(replay_expand_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, a, list, list_cap);
+  return hipGetLastError();
+}
+
+static int replay_site_bits(uint32_t n_sites) {
+  int b = 1;
+  while (b < 32 && (1ull << b) < (uint64_t)n_sites) ++b;
+  return b;
+}
+
+size_t replay_sort_temp_bytes(uint64_t list_cap, uint32_t n_sites) {
+  size_t bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr,
+                                           (uint32_t *)nullptr, (int)list_cap, 0, 2 * replay_site_bits(n_sites));
+  return bytes;
+}
+
+hipError_t launch_replay_sort(const ReplayLklArgs &a, const ReplayEntry *list, uint64_t list_cap, uint64_t *keys_a, uint64_t *keys_b,
+                              uint32_t *vals_a, uint32_t *vals_b, void *temp, size_t temp_bytes, hipStream_t stream) {
+  if (list_cap == 0) return hipSuccess;
+  if (list_cap > 0x7fffffffull) return hipErrorInvalidValue;
+  const int bits = replay_site_bits(a.n_sites);
+  hipLaunchKernelGGL(replay_keys_kernel, dim3((unsigned)((list_cap + 255) / 256)), dim3(256), 0, stream, a, list, list_cap, keys_a, vals_a, bits);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_a, keys_b, vals_a, vals_b, (int)list_cap, 0, 2 * bits, stream);
+}
+
+hipError_t launch_replay_lanes(const ReplayLklArgs &a, const ReplayEntry *list, const uint32_t *order, const double *xT, int n_cus,
+                               hipStream_t stream) {
+  if (list == nullptr || xT == nullptr || a.n_records == 0) return hipSuccess;
+  // a persistent grid: four wavefronts per SIMD (96 registers, no LDS: the gathers want the company); never more lanes than the launch has records
+  uint64_t waves = (uint64_t)n_cus * 4 * 4;
+  const uint64_t most = (a.n_records + 63) / 64;
+  if (waves > most) waves = most;
+  hipLaunchKernelGGL(replay_lane_kernel, dim3((unsigned)waves), dim3(64), 0, stream, a, list, order, xT);
+  return hipGetLastError();
+}
 
 uint32_t replay_lkl_waves(uint32_t n_ind) {
   const uint32_t per = 64u * kMaxSlots;
