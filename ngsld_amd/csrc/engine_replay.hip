@@ -324,19 +324,20 @@ int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t bas
 // it, whatever stream it came from: the 86 MB D2H copy of the previous batch's text (copy stream) did not start until the pair
 // kernel AND the device-side replay of the next batch had finished (rocprofv3 --memory-copy-trace, profiles/r05): 8.7 ms a
 // text batch instead of 7.3 on un-called input, 2.9 instead of 2.5 on the headline's.
-__global__ void flag_head_to_host_kernel(const uint32_t *flags, uint32_t *h_head, uint32_t cap) {
+__global__ void flag_head_to_host_kernel(const uint32_t *flags, uint32_t *h_head, uint32_t cap, int with_list) {
   const uint32_t count = flags[0], host_only = flags[1];
   if (threadIdx.x < kFlagListAt) h_head[threadIdx.x] = flags[threadIdx.x];
-  const uint32_t n_list = 2u * (count < cap ? count : cap), n_host = 2u * (host_only < kFlagHostCap ? host_only : kFlagHostCap);
+  // (with_list == 0: a device-side replay has been through the launch -- the host reads the counters and the host-only list)
+  const uint32_t n_list = with_list ? 2u * (count < cap ? count : cap) : 0u, n_host = 2u * (host_only < kFlagHostCap ? host_only : kFlagHostCap);
   for (uint32_t w = threadIdx.x; w < n_list; w += blockDim.x) h_head[kFlagListAt + w] = flags[kFlagListAt + w];
   const uint32_t at = kFlagListAt + 2u * cap;
   for (uint32_t w = threadIdx.x; w < n_host; w += blockDim.x) h_head[at + w] = flags[at + w];
 }
 
-int send_flag_head(ngsld_ctx *c, const uint32_t *d_flags, uint32_t *h_head, uint32_t cap, hipStream_t st) {
+int send_flag_head(ngsld_ctx *c, const uint32_t *d_flags, uint32_t *h_head, uint32_t cap, hipStream_t st, bool with_list) {
   uint32_t *dev_view = nullptr;
   HIP_TRY(c, hipHostGetDevicePointer((void **)&dev_view, h_head, 0));
-  hipLaunchKernelGGL(flag_head_to_host_kernel, dim3(1), dim3(256), 0, st, d_flags, dev_view, cap);
+  hipLaunchKernelGGL(flag_head_to_host_kernel, dim3(1), dim3(256), 0, st, d_flags, dev_view, cap, with_list ? 1 : 0);
   HIP_TRY(c, hipGetLastError());
   return NGSLD_OK;
 }
@@ -513,7 +514,11 @@ int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t ou
   a.out_ext = d_ext;
   a.status = c->d_status.p;
   a.xt_sites = c->n_sites;
-  if (c->xT_ready) {
+  // (a launch of a few hundred thousand records -- a text batch -- stays with the wavefront-per-pair kernel: a lane takes
+  // milliseconds over ONE pair, four wavefronts to a SIMD, and such a launch has no second pair for most lanes: 6 ms a batch
+  // against 4, profiles/r05/e2e_uncalled_lanes_on_text_batches.json)
+  if (c->xT_ready && n >= (1ull << 22)) {
+    a.after_lanes = 1;
     // one lane per pair wherever the individual-major copy is there: the launch's bitmap becomes a list of located pairs (the
     // bits listed are cleared), the lanes work through it; what stays in the bitmap -- ill-conditioned Pearson moments, pairs
     // beyond the list -- is the wavefront-per-pair kernel's, as everything is without the copy
@@ -584,7 +589,7 @@ int finish_device_run(ngsld_ctx *c) {
     if (rcx == NGSLD_OK)
       rcx = device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, base, n, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st, false, -1);
     if (rcx != NGSLD_OK) return rcx;
-    rcx = send_flag_head(c, c->d_flags_dev.p, c->h_flags_dev.p, c->flag_cap_dev, c->dev_run.st);
+    rcx = send_flag_head(c, c->d_flags_dev.p, c->h_flags_dev.p, c->flag_cap_dev, c->dev_run.st, false);
     if (rcx != NGSLD_OK) return rcx;
     HIP_TRY(c, hipStreamSynchronize(c->dev_run.st));
     applied = true;

@@ -173,7 +173,7 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
     }
     // which pairs the kernels flagged (and the device has not settled itself): the counter and the list come over behind
     // them, on their stream
-    rcd = send_flag_head(c, c->d_flags_dev.p, c->h_flags_dev.p, c->flag_cap_dev, st);
+    rcd = send_flag_head(c, c->d_flags_dev.p, c->h_flags_dev.p, c->flag_cap_dev, st, !c->dev_run.dev_applied);
     if (rcd != NGSLD_OK) return rcd;
   }
   c->dev_run.pending = true;
@@ -415,7 +415,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     // batch -- it goes through a copy kernel, and that waited for the next batch's pair kernel to leave it a CU
     // (a small KERNEL, not a copy: send_flag_head)
     if (replay) {
-      const int rch = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], st);
+      const int rch = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], st, !c->slot_dev_applied[k]);
       if (rch != NGSLD_OK) return rch;
     }
     if (text) {  // row lengths and their prefix sums right behind the pair kernel, the rows behind those
@@ -494,7 +494,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
             rcx = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, c->d_std[k].p,
                                     ext ? c->d_ext[k].p : nullptr, c->copy_stream, true, k);
           if (rcx != NGSLD_OK) return rcx;
-          rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream);
+          rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream, false);
           if (rcx != NGSLD_OK) return rcx;
           HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 4 * sizeof(uint64_t), c->copy_stream));
           const TextArgs t = text_args(b, k);
@@ -586,7 +586,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
           if (rcx == NGSLD_OK)
             rcx = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], c->copy_stream, true, k);
           if (rcx != NGSLD_OK) return rcx;
-          rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream);
+          rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream, false);
           if (rcx != NGSLD_OK) return rcx;
           if (!direct && b.n) {  // (the records had been copied already: once more)
             HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, c->d_std[k].p, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost, c->copy_stream));

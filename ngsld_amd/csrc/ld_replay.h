@@ -41,6 +41,7 @@ struct ReplayLklArgs {
   const double *mean_e, *rsx; // [n_sites] the pair kernels' per-site moments (which pairs they flagged for their Pearson moment)
   uint64_t n_records;         // records in the launch
   uint32_t chunk_words;       // bitmap words per claim (set by launch_replay_lkl)
+  uint32_t after_lanes;       // launch_replay_expand has run: flags[6] counts the bits it left in the bitmap
   uint32_t *work;             // chunk counter of the persistent teams, zero at launch
   uint32_t *done;             // receives the number of pairs replayed (added to)
   const uint64_t *row_off;    // [n_sites + 1] plan: records before each row

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
   constexpr int kTeamSlots = WAVES * kSlots;  // slot t of the team holds individuals 64 t .. 64 t + 63
   double a[kSlots][3], b[kSlots][3];
   uint32_t row_site = 0xffffffffu;
+  if (A.after_lanes && A.flags[6] == 0) return;  // (the lane-per-pair kernel took everything: nothing to walk the bitmap for)
   for (;;) {
     if (threadIdx.x == 0) sh_u32[0] = atomicAdd(A.work, 1u);
     __syncthreads();
@@ -400,11 +401,13 @@ __global__ __launch_bounds__(256) void replay_expand_kernel(ReplayLklArgs A, Rep
     s1s[b] = s1;
     s2s[b] = s2;
   }
+  if (bits & ~take) atomicAdd(&A.flags[6], (uint32_t)__popc(bits & ~take));  // (left in the bitmap for the wavefront-per-pair kernel)
   if (!take) return;
   const uint32_t n = (uint32_t)__popc(take);
   const uint32_t at = atomicAdd(&A.flags[4], n);
   if ((uint64_t)at + n > list_cap) {  // (no room: these stay in the bitmap; the counter is put back so that the lanes see only what was written)
     atomicSub(&A.flags[4], n);
+    atomicAdd(&A.flags[6], n);
     return;
   }
   uint32_t k = 0;

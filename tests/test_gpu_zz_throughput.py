@@ -43,10 +43,11 @@ def test_cohort_sizes_past_the_old_cliffs_keep_their_rate(n_ind, floor):
 
 
 # Round 5: matrices that are NOT SNP-called (README.md:73).  With 20 % monomorphic sites a third of the pairs is flagged for the
-# exact-order replay; on host threads (rounds 1-4) the pass ran at 2.2e6 pairs/s, on the device (ld_replay_lkl.hip) at 1.0e8
-# on a 2.2 GHz box (profiles/r05).  The floor is a third of that -- a pass means the device-side replay is what ran.
+# exact-order replay; on host threads (rounds 1-4) the pass ran at 2.2e6 pairs/s, on the device (ld_replay_lkl.hip) at 1.3e8
+# (2.15e8 with the log-uniform spectrum) on a 2.2 GHz box (profiles/r05/d).  The floors are half of that -- a pass means the
+# device-side replay, in its lane-per-pair form, is what ran.
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("flags,floor", [(["--mono-frac", "0.2"], 3.0e7), (["--sfs"], 8.0e7)])
+@pytest.mark.parametrize("flags,floor", [(["--mono-frac", "0.2"], 6.0e7), (["--sfs"], 1.1e8)])
 def test_uncalled_input_is_replayed_on_the_device(flags, floor):
     cmd = [sys.executable, "bench.py", "--config", "c2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-sink", "--no-e2e",
            "--no-traffic"] + flags
