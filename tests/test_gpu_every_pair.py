@@ -51,6 +51,18 @@ def test_first_rows_of_the_headline_configuration_equal_the_oracle():
     print("every pair of the first 3,000 rows of configs[2]:", {k: d[k] for k in d if k.startswith("max_abs_diff_") or k.startswith("pairs")})
 
 
+def test_first_rows_of_the_headline_shape_not_snp_called_equal_the_oracle():
+    """configs[2]'s shape with 20 % of the sites monomorphic (README.md:73): every pair of the first 2,000 rows -- a third of them
+    pairs the reference's own rounding decides, replayed on the device -- nIter / sample_size exact, everything within 1e-9, NaN
+    and inf where the reference has them, the degenerate pairs bit for bit (tests/util.py)."""
+    d = _parity("c2mono", "2000")
+    assert d["pair_kernel"] == "run" and d["pairs"] >= 1_900_000 and d["pairs_and_order_equal"]
+    assert d["n_iter_equal"] and d["sample_size_equal"] and d["within_tolerances"]
+    assert d["replay"]["pairs_on_device"] > d["pairs"] // 5 and d["replay"]["pairs_on_host"] * 10_000 <= d["pairs"]
+    print("every pair of the first 2,000 rows of configs[2]'s shape, 20 % monomorphic sites:",
+          {k: d[k] for k in d if k.startswith("max_abs_diff_") or k.startswith("pairs") or k == "replay"})
+
+
 # (round 5: c2mono -- the same shape NOT SNP-called, 20 % of the sites monomorphic: a third of its rows are pairs the reference's own
 # rounding decides, replayed in its operation order on the device; the patched reference main hands over normal-space values,
 # whose replay is on the device from the first pair on)

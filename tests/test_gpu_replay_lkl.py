@@ -208,3 +208,55 @@ def test_ill_conditioned_pearson_moments_are_settled_on_the_device(eng, n_ind):
         texts[mode] = t
         eng.set_text_output(None, enable=False)
     assert texts[0] == texts[2]
+
+
+def _bits_but_r2expg(a_std, a_ext, b_std, b_ext):
+    assert close(a_std["r2_ExpG"], b_std["r2_ExpG"]).all()
+    for col in ("D", "Dp", "r2"):
+        assert same_bits(a_std[col], b_std[col]).all(), col
+    assert a_ext.tobytes() == b_ext.tobytes()
+
+
+@pytest.mark.parametrize("slab", [96, 300])
+def test_streamed_slabs_build_their_own_store(eng, slab, monkeypatch):
+    """A streamed run (row slabs, two contexts alternating: BASELINE configs[4]'s mode) of an un-called matrix: every slab's
+    context builds the store of ITS sites from its host buffer and replays on the device -- the resident run's records
+    (r2_ExpG of a replayed pair: to 1e-9, see assert_same_records)."""
+    from ngsld_amd import shard
+    n_sites, n_ind = 700, 60
+    raw = uncalled(n_sites, n_ind, seed=55, mono_frac=0.3)
+    chrs, pos = synth.make_positions(n_sites, 55, n_chr=2)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    kw = dict(max_kb_dist=3)
+    monkeypatch.setenv("NGSLD_EXACT_STORE", "0")
+    host = capi.run_streamed(lambda b, m: raw[b:b + m], n_sites, n_ind, pd, slab, **kw)
+    monkeypatch.setenv("NGSLD_EXACT_STORE", "2")
+    dev = capi.run_streamed(lambda b, m: raw[b:b + m], n_sites, n_ind, pd, slab, **kw)
+    assert np.array_equal(host[0], dev[0]) and np.array_equal(host[1], dev[1])
+    _bits_but_r2expg(host[2], host[3], dev[2], dev[3])
+    eng.set_exact_store(2)
+    eng.set_geno_raw(raw)
+    eng.set_pos_dist(pd)
+    eng.plan(**kw)
+    s1, s2, std, ext = eng.run()
+    assert eng.replay_info()["pairs_on_device"] > len(s1) // 10
+    assert np.array_equal(s1, dev[0]) and np.array_equal(s2, dev[1])
+    _bits_but_r2expg(std, ext, dev[2], dev[3])
+
+
+@pytest.mark.parametrize("n_parts", [2, 3])
+def test_parts_of_one_process_build_their_own_stores(n_parts, monkeypatch):
+    """ngsld_run_multi (`ngsLD --devices`): every part's context replays its flagged pairs on its device."""
+    from ngsld_amd import shard
+    n_sites, n_ind = 500, 80
+    raw = uncalled(n_sites, n_ind, seed=66, mono_frac=0.3)
+    chrs, pos = synth.make_positions(n_sites, 66, max_gap=300)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    kw = dict(extend_out=True, max_kb_dist=10)
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("NGSLD_EXACT_STORE", mode)
+        parts, maf, per = capi.run_multi(raw, pd, [0] * n_parts, **kw)
+        out[mode] = [np.concatenate([p[k] for p in parts]) for k in range(4)]
+    assert np.array_equal(out["0"][0], out["2"][0]) and np.array_equal(out["0"][1], out["2"][1])
+    _bits_but_r2expg(out["0"][2], out["0"][3], out["2"][2], out["2"][3])

@@ -2,6 +2,8 @@
 
     python tools/parity_config.py c1            # configs[1]: 5,000 x 100, all 12,497,500 pairs
     python tools/parity_config.py c2 [rows]     # configs[2]: 100,000 x 500, 100 kb window, rows [0, rows) (default 3000)
+    python tools/parity_config.py c2mono [rows] # the same shape NOT SNP-called (20 % of the sites monomorphic): a third of the pairs are
+                                                # replayed in the reference's operation order on the device -- bit for bit the oracle's
     python tools/parity_config.py c3 [rows]     # configs[3]: 50,000 x 1,000 all pairs, rows [0, rows) (default 24: 1.2e6 pairs)
     python tools/parity_config.py c4 [rows] [n_sites]  # configs[4]'s shape: n_sites (default 60,000) x 2,000, 500 kb window over
                                                 # ~1 kb gaps, rows [0, rows) (default 1500)
@@ -46,7 +48,7 @@ def main():
         rows = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
         chrs, pos = synth.make_positions(n_sites, seed)
         pd = shard.pos_dist_from_positions(chrs, pos)
-    raw_t = synth.make_gl_torch(n_sites, n_ind, seed, dev, depth=10.0)
+    raw_t = synth.make_gl_torch(n_sites, n_ind, seed, dev, depth=10.0, mono_frac=0.2 if which == "c2mono" else 0.0)
     if pd is not None:  # the oracle only needs the rows and their halo
         ends = shard.row_ends(pd, max_kb, 0)
         n_have = int(ends[:rows].max())
@@ -70,6 +72,9 @@ def main():
         eng.set_geno_raw(raw_t.data_ptr(), n_sites=n_sites, n_ind=n_ind)
         if len(raw) == n_sites:
             eng.set_replay_source(raw)          # the exact-order replay reads the caller's values, as the CLI does
+        elif which == "c2mono":                 # (there the replay is a third of the run: the whole matrix, as the binary holds it)
+            whole = raw_t.cpu().numpy()
+            eng.set_replay_source(whole)
         eng.set_pos_dist(pd)
         family = eng.pair_kernel()
         eng.plan(max_kb_dist=max_kb, extend_out=True)
@@ -77,11 +82,12 @@ def main():
         s1, s2, std, ext = eng.run(0, rows)
         t_gpu = time.perf_counter() - t0
         eng_replayed = [eng.replay_stats()[0]]
+        eng_info = eng.replay_info()
     finally:
         eng.close()
     replayed = eng_replayed[0]
     out = {"config": which, "n_sites": n_sites, "n_ind": n_ind, "max_kb_dist": max_kb, "rows": rows, "pairs": int(len(want)),
-           "pairs_replayed_exact_order": replayed, "pair_kernel": family,
+           "pairs_replayed_exact_order": replayed, "replay": eng_info, "pair_kernel": family,
            "oracle_s": round(t_cpu, 1), "oracle_threads": cores, "gpu_sink_path_s": round(t_gpu, 2)}
     ok = len(want) == len(std) and np.array_equal(s1, want["s1"]) and np.array_equal(s2, want["s2"])
     out["pairs_and_order_equal"] = bool(ok)
