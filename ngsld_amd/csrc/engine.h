@@ -364,6 +364,7 @@ struct ngsld_ctx {
   } lane_scratch[kSlots], lane_scratch_dev;  // per pipeline slot / for ngsld_run_device
   PinBuf<double> h_xstage[2];
   bool exact_ready = false, exact_alias = false;
+  bool exact_failed = false;           // the device had no room for this matrix' store: host replay
   int exact_mode = 1;                  // NGSLD_EXACT_STORE / ngsld_set_exact_store: 0 never (host replay only), 1 when it pays (default), 2 at the first flagged pair
   double exact_build_s = 0.0;          // host seconds the store of this matrix took to build (0: an alias, or not built)
   uint64_t host_replayed_total = 0;    // pairs the host threads replayed since the matrix was set (what the decision to build looks at)
@@ -475,6 +476,9 @@ int ensure_exact_store(ngsld_ctx *c);
 // should a run that has `pending` flagged pairs for the host build the store instead?
 bool exact_store_wanted(const ngsld_ctx *c, uint64_t pending);
 // flag_text: the launch's records become text (PairArgs::flag_text)
+// ensure_exact_store + device_replay_lkl; *applied says whether the replay was launched (false: no store to be had)
+int try_device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
+                          ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text, int slot, bool *applied);
 // slot: the pipeline slot whose pair list the launch uses (-1: ngsld_run_device's)
 int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
                       ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text, int slot);

@@ -35,6 +35,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   c->replay_matrix = nullptr;
   c->exact_ready = false;    // ... and the exact store of the device-side replay
   c->exact_alias = false;
+  c->exact_failed = false;
   c->exact_build_s = 0.0;
   c->host_replayed_total = 0;
   c->d_xplanes.release();

@@ -369,7 +369,7 @@ bool exact_store_is_free(const ngsld_ctx *c) {
 // per triple: read_geno's log + post_prob, est_maf's post_prob + exp, main's exp), once: it pays as soon as the host would
 // otherwise replay more pairs than half the matrix has sites.
 bool exact_store_wanted(const ngsld_ctx *c, uint64_t pending) {
-  if (!lkl_device_eligible(c)) return false;
+  if (!lkl_device_eligible(c) || c->exact_failed) return false;
   if (c->exact_ready || exact_store_is_free(c)) return pending > 0;
   if (c->exact_mode >= 2) return pending > 0;
   return c->host_replayed_total + pending > std::max<uint64_t>(4096, c->n_sites / 2);
@@ -410,8 +410,15 @@ int ensure_exact_store(ngsld_ctx *c) {
   const auto t0 = std::chrono::steady_clock::now();
   const uint64_t n = c->n_sites, ni = c->n_ind, np = c->np, site_elems = 3 * np;
   HIP_TRY(c, hipSetDevice(c->device));
-  HIP_TRY(c, c->d_xplanes.resize((size_t)n * site_elems));
-  HIP_TRY(c, c->d_xmaf.resize(n));
+  // (a device without room for the matrix once more: no store for this matrix -- its flagged pairs stay with the host's threads)
+  const bool pretend = std::getenv("NGSLD_EXACT_STORE_NO_ROOM") != nullptr;  // tests
+  if (pretend || c->d_xplanes.resize((size_t)n * site_elems) != hipSuccess || c->d_xmaf.resize(n) != hipSuccess) {
+    (void)hipGetLastError();
+    c->d_xplanes.release();
+    c->d_xmaf.release();
+    c->exact_failed = true;
+    return NGSLD_OK;
+  }
   std::vector<double> xmaf(n);
   uint64_t chunk = std::max<uint64_t>(1, (32ull << 20) / (site_elems * sizeof(double)));
   if (chunk > n) chunk = n;
@@ -479,6 +486,16 @@ int ensure_exact_store(ngsld_ctx *c) {
     std::fprintf(stderr, "[trace] exact store: %llu sites x %llu individuals through the host's libm on %d threads in %.3f s\n",
                  (unsigned long long)n, (unsigned long long)ni, T, c->exact_build_s);
   return NGSLD_OK;
+}
+
+int try_device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
+                          ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text, int slot, bool *applied) {
+  *applied = false;
+  int rc = ensure_exact_store(c);
+  if (rc != NGSLD_OK || !c->exact_ready) return rc;
+  rc = device_replay_lkl(c, d_flags, cap, out_base, n, d_std, d_ext, st, flag_text, slot);
+  if (rc == NGSLD_OK) *applied = true;
+  return rc;
 }
 
 // The flagged pairs of a launch replayed on the device (likelihood matrices), on `st` behind the pair kernels that flagged
@@ -585,14 +602,14 @@ int finish_device_run(ngsld_ctx *c) {
   if (!applied && exact_store_wanted(c, c->h_flags_dev.p[0] - c->h_flags_dev.p[1])) {
     // a likelihood matrix that flags more pairs than the host should replay: the exact store is built (once per matrix) and
     // the pairs are replayed on the device, behind the kernels on their stream
-    int rcx = ensure_exact_store(c);
-    if (rcx == NGSLD_OK)
-      rcx = device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, base, n, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st, false, -1);
+    int rcx = try_device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, base, n, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st,
+                                    false, -1, &applied);
     if (rcx != NGSLD_OK) return rcx;
-    rcx = send_flag_head(c, c->d_flags_dev.p, c->h_flags_dev.p, c->flag_cap_dev, c->dev_run.st, false);
-    if (rcx != NGSLD_OK) return rcx;
-    HIP_TRY(c, hipStreamSynchronize(c->dev_run.st));
-    applied = true;
+    if (applied) {
+      rcx = send_flag_head(c, c->d_flags_dev.p, c->h_flags_dev.p, c->flag_cap_dev, c->dev_run.st, false);
+      if (rcx != NGSLD_OK) return rcx;
+      HIP_TRY(c, hipStreamSynchronize(c->dev_run.st));
+    }
   }
   const double t_dev = ms();
   std::vector<uint64_t> recs;

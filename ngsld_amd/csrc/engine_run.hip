@@ -164,12 +164,9 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
     // likelihood matrices: right behind the kernels when the exact store is there (or costs nothing); a run that turns out to
     // flag many pairs without one has it built in ngsld_finish_device
     if (lkl_device_eligible(c) && (c->exact_ready || exact_store_is_free(c))) {
-      rcd = ensure_exact_store(c);
-      if (rcd == NGSLD_OK)
-        rcd = device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, c->h_row_off[s1_begin], c->timed_pairs,
-                                (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, st, false, -1);
+      rcd = try_device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, c->h_row_off[s1_begin], c->timed_pairs,
+                                  (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, st, false, -1, &c->dev_run.dev_applied);
       if (rcd != NGSLD_OK) return rcd;
-      c->dev_run.dev_applied = true;
     }
     // which pairs the kernels flagged (and the device has not settled itself): the counter and the list come over behind
     // them, on their stream
@@ -403,11 +400,9 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       if (rcd != NGSLD_OK) return rcd;
       // (likelihoods: the same once the exact store is there -- a batch issued before that is settled when it is consumed)
       if (lkl_device_eligible(c) && (c->exact_ready || exact_store_is_free(c))) {
-        rcd = ensure_exact_store(c);
-        if (rcd == NGSLD_OK)
-          rcd = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], st, true, k);
+        rcd = try_device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], st, true, k,
+                                    &c->slot_dev_applied[k]);
         if (rcd != NGSLD_OK) return rcd;
-        c->slot_dev_applied[k] = true;
       }
     }
     // which pairs the kernel flagged for the exact-order replay (counter + list, 32 KB): known to the host with the batch.
@@ -489,21 +484,20 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
         if (!applied && exact_store_wanted(c, c->h_flags[k].p[0] - c->h_flags[k].p[1])) {
           // a likelihood matrix that flags more pairs than the host should replay, and this batch went out before the exact
           // store was there: build it (once), replay the batch's pairs on the device, take every row's length again
-          int rcx = ensure_exact_store(c);
-          if (rcx == NGSLD_OK)
-            rcx = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, c->d_std[k].p,
-                                    ext ? c->d_ext[k].p : nullptr, c->copy_stream, true, k);
+          int rcx = try_device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, c->d_std[k].p,
+                                          ext ? c->d_ext[k].p : nullptr, c->copy_stream, true, k, &applied);
           if (rcx != NGSLD_OK) return rcx;
-          rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream, false);
-          if (rcx != NGSLD_OK) return rcx;
-          HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 4 * sizeof(uint64_t), c->copy_stream));
-          const TextArgs t = text_args(b, k);
-          HIP_TRY(c, launch_text_lengths(t, c->copy_stream));
-          HIP_TRY(c, text_scan(c->d_scan_tmp2.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n, c->d_text_meta[k].p, c->copy_stream));
-          HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
-          HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
-          applied = true;
-          rewrite = true;
+          if (applied) {
+            rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream, false);
+            if (rcx != NGSLD_OK) return rcx;
+            HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p, 0, 4 * sizeof(uint64_t), c->copy_stream));
+            const TextArgs t = text_args(b, k);
+            HIP_TRY(c, launch_text_lengths(t, c->copy_stream));
+            HIP_TRY(c, text_scan(c->d_scan_tmp2.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n, c->d_text_meta[k].p, c->copy_stream));
+            HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, c->copy_stream));
+            HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+            rewrite = true;
+          }
         }
         // flagged pairs: replayed on the host, patched into the device records, and the row lengths derived again --
         // all on the copy stream, beside the next batch's pair kernel
@@ -582,19 +576,19 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       if (replay && c->h_flags[k].p[0] != 0) {  // flagged pairs: replayed on the host, patched into the batch's buffers
         bool applied = c->slot_dev_applied[k];
         if (!applied && exact_store_wanted(c, c->h_flags[k].p[0] - c->h_flags[k].p[1])) {  // (see the text branch above)
-          int rcx = ensure_exact_store(c);
-          if (rcx == NGSLD_OK)
-            rcx = device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], c->copy_stream, true, k);
+          int rcx = try_device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k],
+                                          c->copy_stream, true, k, &applied);
           if (rcx != NGSLD_OK) return rcx;
-          rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream, false);
-          if (rcx != NGSLD_OK) return rcx;
-          if (!direct && b.n) {  // (the records had been copied already: once more)
-            HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, c->d_std[k].p, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost, c->copy_stream));
-            if (ext)
-              HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, c->d_ext[k].p, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost, c->copy_stream));
+          if (applied) {
+            rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream, false);
+            if (rcx != NGSLD_OK) return rcx;
+            if (!direct && b.n) {  // (the records had been copied already: once more)
+              HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, c->d_std[k].p, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost, c->copy_stream));
+              if (ext)
+                HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, c->d_ext[k].p, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost, c->copy_stream));
+            }
+            HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
           }
-          HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
-          applied = true;
         }
         int rcr = flagged_records(c, c->h_flags[k].p, c->d_flags[k].p, c->flag_cap[k], b.n, recs, applied);
         if (rcr == NGSLD_OK)

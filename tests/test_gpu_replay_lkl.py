@@ -260,3 +260,15 @@ def test_parts_of_one_process_build_their_own_stores(n_parts, monkeypatch):
         out[mode] = [np.concatenate([p[k] for p in parts]) for k in range(4)]
     assert np.array_equal(out["0"][0], out["2"][0]) and np.array_equal(out["0"][1], out["2"][1])
     _bits_but_r2expg(out["0"][2], out["0"][3], out["2"][2], out["2"][3])
+
+
+def test_a_device_without_room_for_the_store_leaves_the_pairs_to_the_host(eng, monkeypatch):
+    """The store is the matrix once more in device memory; where that cannot be had the run does not fail -- its flagged pairs
+    are replayed on host threads as before (NGSLD_EXACT_STORE_NO_ROOM pretends)."""
+    raw = uncalled(300, 60, seed=88, mono_frac=0.3)
+    want = run_records(eng, raw, 0)
+    monkeypatch.setenv("NGSLD_EXACT_STORE_NO_ROOM", "1")
+    got = run_records(eng, raw, 2)
+    assert got[4]["exact_store"] == 0 and got[4]["pairs_on_device"] == 0 and got[4]["pairs_on_host"] == want[4]["pairs_on_host"] > 0
+    for k in (2, 3):
+        assert got[k].tobytes() == want[k].tobytes()
