@@ -490,7 +490,7 @@ int reset_flags(ngsld_ctx *c, DevBuf<uint32_t> &buf, uint64_t n, uint32_t cap, h
 // with_list == false: the launch had the device-side replay of likelihood matrices behind it (the listed pairs are settled)
 int send_flag_head(ngsld_ctx *c, const uint32_t *d_flags, uint32_t *h_head, uint32_t cap, hipStream_t st, bool with_list = true);
 int device_replay(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
-                  ngsld_rec_ext *d_ext, hipStream_t st);
+                  ngsld_rec_ext *d_ext, hipStream_t st, int slot);
 int finish_device_run(ngsld_ctx *c);  // waits for a run left on a caller's stream and replays what it flagged
 
 }  // namespace eng

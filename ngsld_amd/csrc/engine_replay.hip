@@ -172,6 +172,7 @@ int flagged_records(ngsld_ctx *c, const uint32_t *h_head, const uint32_t *d_flag
       }
     return NGSLD_OK;
   };
+  if (h_head[7] != 0) dev_applied = true;  // (called genotypes: the launch overflowed its list and the device took all of it, ld_replay.hip)
   if (dev_applied) {
     // likelihood matrices, device-side replay behind the launch (ld_replay_lkl.hip): it settled every flagged pair but the
     // host-only ones -- head[2] says how many --, and those have a bitmap of their own
@@ -560,9 +561,16 @@ int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t ou
 // kernels on their stream -- before the head of the flag buffer travels to the host, before text rows are formatted.
 // out_base: plan index of the launch's record 0; d_std / d_ext: where the launch wrote (device, or pinned host memory).
 int device_replay(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
-                  ngsld_rec_ext *d_ext, hipStream_t st) {
+                  ngsld_rec_ext *d_ext, hipStream_t st, int slot) {
   if (!c->replay_on || !c->replay_device || c->cfg.kernel != kHard || d_flags == nullptr || n == 0) return NGSLD_OK;
+  // A launch that flags more pairs than its list holds (every pair of a monomorphic called site): the bitmap is turned into a
+  // list of located pairs and a second kernel works through that -- both leave at once unless the list did overflow
+  ngsld_ctx::LaneScratch &ls = slot < 0 ? c->lane_scratch_dev : c->lane_scratch[slot];
+  const uint64_t list_cap = std::min<uint64_t>(n, 1ull << 26);
+  HIP_TRY(c, ls.list.resize(list_cap));
   ReplayHardArgs a{};
+  a.list = ls.list.p;
+  a.host_bits = d_flags + flag_head_words(cap) + flag_bitmap_words(n);
   a.flags = d_flags;
   a.flag_cap = cap;
   a.row_off = c->d_row_off.p;
@@ -583,6 +591,25 @@ int device_replay(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_ba
   a.out_ext = d_ext;
   a.status = c->d_status.p;
   HIP_TRY(c, launch_replay_hard(a, n, st));
+  {
+    ReplayLklArgs x{};  // (what launch_replay_expand reads)
+    x.bits = d_flags + flag_head_words(cap);
+    x.host_bits = a.host_bits;
+    x.n_records = n;
+    x.flags = d_flags;
+    x.flag_cap = cap;
+    x.row_off = a.row_off;
+    x.item_off = a.item_off;
+    x.items = a.items;
+    x.n_items = c->n_items;
+    x.n_sites = a.n_sites;
+    x.rec_base = out_base;
+    x.rsx = c->d_rsx.p;
+    x.n_ind = a.n_ind;
+    x.only_if_overflow = 1;
+    HIP_TRY(c, launch_replay_expand(x, ls.list.p, list_cap, st));
+    HIP_TRY(c, launch_replay_hard_list(a, c->n_cus, st));
+  }
   return NGSLD_OK;
 }
 

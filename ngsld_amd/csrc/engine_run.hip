@@ -159,7 +159,7 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
   c->dev_run.dev_applied = false;
   if (c->replay_on) {
     int rcd = device_replay(c, c->d_flags_dev.p, c->flag_cap_dev, c->h_row_off[s1_begin], c->timed_pairs,
-                            (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, st);
+                            (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, st, -1);
     if (rcd != NGSLD_OK) return rcd;
     // likelihood matrices: right behind the kernels when the exact store is there (or costs nothing); a run that turns out to
     // flag many pairs without one has it built in ngsld_finish_device
@@ -396,7 +396,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     HIP_TRY(c, timed_launch(c, a, st));
     c->slot_dev_applied[k] = false;
     if (replay) {  // (called genotypes: the flagged pairs settled on the device, before anything reads the records)
-      int rcd = device_replay(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], st);
+      int rcd = device_replay(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], st, k);
       if (rcd != NGSLD_OK) return rcd;
       // (likelihoods: the same once the exact store is there -- a batch issued before that is settled when it is consumed)
       if (lkl_device_eligible(c) && (c->exact_ready || exact_store_is_free(c))) {
@@ -571,7 +571,12 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       }
     } else {
       HIP_TRY(c, hipEventSynchronize(direct ? c->ev_kernel_done[k] : c->ev_copy_done[k]));
-      if (trace) std::fprintf(stderr, "[trace] batch %zu (%llu pairs): issue next %.2f..%.2f, records on the host %.2f, flagged %u\n", bi, (unsigned long long)b.n, t_a, t_b, now_ms(), replay ? c->h_flags[k].p[0] : 0u);
+      if (trace) {
+        const uint32_t *hd = c->h_flags[k].p;
+        std::fprintf(stderr, "[trace] batch %zu (%llu pairs): issue next %.2f..%.2f, records on the host %.2f, flag head %u %u %u %u %u %u %u %u\n", bi,
+                     (unsigned long long)b.n, t_a, t_b, now_ms(), replay ? hd[0] : 0u, replay ? hd[1] : 0u, replay ? hd[2] : 0u, replay ? hd[3] : 0u,
+                     replay ? hd[4] : 0u, replay ? hd[5] : 0u, replay ? hd[6] : 0u, replay ? hd[7] : 0u);
+      }
       if (replay) c->flagged_pairs += c->h_flags[k].p[0];
       if (replay && c->h_flags[k].p[0] != 0) {  // flagged pairs: replayed on the host, patched into the batch's buffers
         bool applied = c->slot_dev_applied[k];

@@ -71,7 +71,7 @@ constexpr uint32_t kTieBit = 0x80000000u;  // rides on n_iter (<= 100) from the 
 // Layout of a launch's flag buffer (uint32 words): [0] count of flagged pairs, [1] count of those that are kFlagHostOnly,
 // [2] pairs the device-side replay of likelihood matrices (ld_replay_lkl.hip) has settled, [3] the work counter of its
 // wavefront-per-pair kernel, [4] entries of its pair list, [5] the work counter of its lane-per-pair kernel, [6] the flagged pairs its expansion left in the
-// bitmap, [7] unused,
+// bitmap, [7] set by the called-genotype replay when it took a launch that overflowed its list (ld_replay.hip),
 // [8 .. 8 + 2 cap) the record indices (uint64) of the first `cap` flagged pairs in the order their atomics landed, then the
 // first kFlagHostCap kFlagHostOnly pairs once more, by themselves (what is left for the host after a device-side replay: read
 // from the head that travels with the batch -- fetching a bitmap for them cost a text batch 7 ms, beside the next batch's

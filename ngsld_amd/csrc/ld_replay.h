@@ -25,10 +25,15 @@ struct ReplayHardArgs {
   ngsld_rec_std *out_std;    // the launch's records (device memory, or pinned host memory written in place)
   ngsld_rec_ext *out_ext;    // may be null
   int *status;
+  // a launch that flags more pairs than its list holds: its located pairs (launch_replay_expand), null where that route is not set up
+  const struct ReplayEntry *list;
+  uint32_t *host_bits;       // the launch's host-only bitmap (replay_hard_list_kernel adds what it cannot settle)
 };
 
 // one lane per listed pair; n_records bounds the grid (a launch cannot flag more pairs than it has)
 hipError_t launch_replay_hard(const ReplayHardArgs &a, uint64_t n_records, hipStream_t stream);
+// the overflow route: a persistent grid over a.list (does nothing unless the launch flagged more pairs than its list holds)
+hipError_t launch_replay_hard_list(const ReplayHardArgs &a, int n_cus, hipStream_t stream);
 
 // ---- genotype likelihoods (ld_replay_lkl.hip) ----
 struct ReplayLklArgs {
@@ -42,6 +47,7 @@ struct ReplayLklArgs {
   uint64_t n_records;         // records in the launch
   uint32_t chunk_words;       // bitmap words per claim (set by launch_replay_lkl)
   uint32_t after_lanes;       // launch_replay_expand has run: flags[6] counts the bits it left in the bitmap
+  uint32_t only_if_overflow;  // launch_replay_expand: do nothing unless the launch flagged more pairs than its list holds (called genotypes)
   uint32_t *work;             // chunk counter of the persistent teams, zero at launch
   uint32_t *done;             // receives the number of pairs replayed (added to)
   const uint64_t *row_off;    // [n_sites + 1] plan: records before each row

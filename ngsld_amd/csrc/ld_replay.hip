@@ -68,19 +68,8 @@ __device__ double site_maf(const uint64_t *m, uint32_t W, uint32_t n_ind, bool i
   return freq;
 }
 
-__global__ __launch_bounds__(64) void replay_hard_kernel(ReplayHardArgs A) {
-  __shared__ double val[64 * 64];  // [16 combinations x 4 haplotypes][lane]: this lane's tmp_k / sum per combination
-  const int lane = threadIdx.x;
-  const uint32_t count = A.flags[0] < A.flag_cap ? A.flags[0] : A.flag_cap;
-  const uint32_t e = blockIdx.x * 64u + (uint32_t)lane;
-  if (e >= count) return;
-  uint64_t *list = reinterpret_cast<uint64_t *>(A.flags + kFlagListAt);
-  const uint64_t entry = list[e];
-  if (entry & (kFlagHostOnly | kFlagDone)) return;
-  const uint64_t slot = entry & kFlagIndexMask;
-  const uint64_t rec = A.rec_base + slot;
-
-  // ---- (s1, s2) of the plan's record `rec` (engine.hip: locate_record) ----
+// (s1, s2) of the plan's record `rec` (engine_replay.hip: locate_record); false: no such record
+__device__ bool locate_hard(const ReplayHardArgs &A, uint64_t rec, uint32_t *ps1, uint32_t *ps2) {
   uint32_t lo = 0, hi = A.n_sites;  // largest row with row_off[row] <= rec
   while (lo + 1 < hi) {
     const uint32_t mid = lo + (hi - lo) / 2;
@@ -88,16 +77,23 @@ __global__ __launch_bounds__(64) void replay_hard_kernel(ReplayHardArgs A) {
   }
   const uint32_t row = lo;
   uint64_t il = A.item_off[row], ih = A.item_off[row + 1];
-  if (il >= ih) return;
+  if (il >= ih) return false;
   while (il + 1 < ih) {
     const uint64_t mid = il + (ih - il) / 2;
     if (A.items[mid].first_record <= rec) il = mid; else ih = mid;
   }
   const Item it = A.items[il];
   uint64_t k = rec - it.first_record, mk = it.mask;
-  if (k >= (uint64_t)__popcll(mk)) return;
+  if (k >= (uint64_t)__popcll(mk)) return false;
   while (k--) mk &= mk - 1;
-  const uint32_t s1 = it.s1, s2 = it.s2_begin + (uint32_t)(__ffsll((unsigned long long)mk) - 1);
+  *ps1 = it.s1;
+  *ps2 = it.s2_begin + (uint32_t)(__ffsll((unsigned long long)mk) - 1);
+  return true;
+}
+
+// One flagged pair in the reference's operation order (see the header of this file); val: the calling lane's column of the
+// workgroup's LDS table.  false: the pair is left to the host (a site with missing individuals whose triples may be anything).
+__device__ bool replay_hard_pair(const ReplayHardArgs &A, double *val, int lane, uint64_t slot, uint32_t s1, uint32_t s2) {
 
   const uint32_t W = A.words;
   const uint64_t *ma = A.masks + (uint64_t)s1 * 4 * W, *mb = A.masks + (uint64_t)s2 * 4 * W;
@@ -105,7 +101,7 @@ __global__ __launch_bounds__(64) void replay_hard_kernel(ReplayHardArgs A) {
   bool missing = false;
   const double m1 = site_maf(ma, W, A.n_ind, ign, A.u_pp, &missing);
   const double m2 = site_maf(mb, W, A.n_ind, ign, A.u_pp, &missing);
-  if (missing && !A.miss_ok) return;  // (the host has the caller's raw values for these)
+  if (missing && !A.miss_ok) return false;  // (the host has the caller's raw values for these)
 
   // ---- haplo_freq (gen_func.cpp:1027-1059) ----
   double f[4];
@@ -190,7 +186,53 @@ __global__ __launch_bounds__(64) void replay_hard_kernel(ReplayHardArgs A) {
     r.n_iter = (uint32_t)iter;
     A.out_ext[slot] = r;
   }
-  list[e] = entry | kFlagDone;
+  return true;
+}
+
+__global__ __launch_bounds__(64) void replay_hard_kernel(ReplayHardArgs A) {
+  __shared__ double val[64 * 64];  // [16 combinations x 4 haplotypes][lane]: this lane's tmp_k / sum per combination
+  const int lane = threadIdx.x;
+  if (A.list != nullptr && A.flags[0] > A.flag_cap) return;  // (more flagged pairs than the list holds: replay_hard_list_kernel takes all of them)
+  const uint32_t count = A.flags[0] < A.flag_cap ? A.flags[0] : A.flag_cap;
+  const uint32_t e = blockIdx.x * 64u + (uint32_t)lane;
+  if (e >= count) return;
+  uint64_t *list = reinterpret_cast<uint64_t *>(A.flags + kFlagListAt);
+  const uint64_t entry = list[e];
+  if (entry & (kFlagHostOnly | kFlagDone)) return;
+  const uint64_t slot = entry & kFlagIndexMask;
+  uint32_t s1 = 0, s2 = 0;
+  if (!locate_hard(A, A.rec_base + slot, &s1, &s2)) return;
+  if (replay_hard_pair(A, val, lane, slot, s1, s2)) list[e] = entry | kFlagDone;
+}
+
+// A launch that flagged MORE pairs than its list holds (a called-genotype matrix with monomorphic sites: every pair of such a
+// site; rounds 2-4 left all of those to the host's threads -- bench --hard-calls --mono-frac 0.2: 2.1e8 pairs/s for a pass whose
+// kernel runs 1.6e9): the launch's bitmap has been turned into a list of located pairs (launch_replay_expand, shared with the
+// likelihood replay), a persistent grid works through it, one lane per pair.  What this kernel cannot settle (see
+// replay_hard_pair) is added to the host-only bitmap and list; flags[7] tells the host that the rest is done.
+__global__ __launch_bounds__(64) void replay_hard_list_kernel(ReplayHardArgs A) {
+  __shared__ double val[64 * 64];
+  const int lane = threadIdx.x;
+  if (A.flags[0] <= A.flag_cap) return;
+  if (blockIdx.x == 0 && lane == 0) A.flags[7] = 1u;
+  const uint32_t total = A.flags[4];
+  for (;;) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&A.flags[5], 64u);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (base >= total) return;
+    const uint32_t idx = base + (uint32_t)lane;
+    if (idx < total) {  // (no `continue` for the others: the claim above is the wavefront's, every lane must come back to it together)
+      const ReplayEntry e = A.list[idx];
+      if (replay_hard_pair(A, val, lane, e.slot, e.s1, e.s2)) {
+        atomicAdd(&A.flags[2], 1u);
+      } else {
+        atomicOr(&A.host_bits[e.slot >> 5], 1u << (e.slot & 31u));
+        const uint32_t kh = atomicAdd(&A.flags[1], 1u);
+        if (kh < kFlagHostCap) reinterpret_cast<uint64_t *>(A.flags + kFlagListAt + 2u * A.flag_cap)[kh] = e.slot;
+      }
+    }
+  }
 }
 
 }  // namespace
@@ -199,6 +241,12 @@ hipError_t launch_replay_hard(const ReplayHardArgs &a, uint64_t n_records, hipSt
   if (a.flags == nullptr || n_records == 0) return hipSuccess;
   const uint64_t most = n_records < (uint64_t)a.flag_cap ? n_records : (uint64_t)a.flag_cap;
   hipLaunchKernelGGL(replay_hard_kernel, dim3((unsigned)((most + 63) / 64)), dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_replay_hard_list(const ReplayHardArgs &a, int n_cus, hipStream_t stream) {
+  if (a.flags == nullptr || a.list == nullptr) return hipSuccess;
+  hipLaunchKernelGGL(replay_hard_list_kernel, dim3((unsigned)(n_cus * 8)), dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256) void replay_expand_kernel(ReplayLklArgs A, Rep
   const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint64_t n_words = (A.n_records + 31) / 32;
   if (w >= n_words) return;
+  if (A.only_if_overflow && A.flags[0] <= A.flag_cap) return;
   uint32_t bits = A.bits[w] & ~A.host_bits[w];
   if (w == n_words - 1 && (A.n_records & 31)) bits &= (1u << (A.n_records & 31)) - 1u;
   if (!bits) return;

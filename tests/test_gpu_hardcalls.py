@@ -152,3 +152,47 @@ def test_device_replay_of_called_genotypes_is_the_hosts(n_ind, call, ignore, mis
     assert np.all(close(sd["r2_ExpG"], sh["r2_ExpG"], 1e-12))
     ties = int(np.sum(rec["n_iter"] <= 2))
     print(f"\n[device replay] n_ind {n_ind} call {call} ignore {ignore} miss {miss}: {len(rec)} pairs, {rd} replayed, {ties} with nIter <= 2")
+
+
+@pytest.mark.parametrize("n_ind,call,ignore,miss", [(200, None, False, 0.0), (500, (0.4, 0.4), False, 0.03), (500, (0.4, 0.4), True, 0.03),
+                                                  (500, None, False, 0.02)])
+def test_a_launch_that_overflows_its_flag_list_is_replayed_on_the_device_too(n_ind, call, ignore, miss, monkeypatch):
+    """A called-genotype matrix with MONOMORPHIC sites (a VCF that was never SNP-filtered; the reference's README.md:73) flags
+    every pair of such a site: more than the launch's list holds.  Rounds 2-4 left ALL flagged pairs of such a launch to the host's
+    threads; now the bitmap is turned into a list of located pairs on the device and a second kernel replays those
+    (ld_replay.hip: replay_hard_list_kernel).  Device against host replay, bit for bit; both against the oracle.  A matrix that
+    arrives called with missing data and no --call_geno (last case) still leaves the pairs of such sites to the host."""
+    from ngsld_amd import capi
+    n_sites = 400
+    rng = np.random.default_rng(77 + n_ind)
+    raw = np.eye(3)[synth.make_gl_numpy(n_sites, n_ind, 5200 + n_ind, depth=8.0).argmax(axis=2)]
+    mono = rng.random(n_sites) < 0.3
+    raw[mono] = np.eye(3)[0]
+    if miss:
+        raw[rng.random((n_sites, n_ind)) < miss] = 1.0 / 3.0
+    rec = orc.Oracle(raw, None, ignore_miss_data=ignore, n_threads=32, call_geno=call).run()
+    got = {}
+    for where in ("device", "host"):
+        monkeypatch.setenv("NGSLD_REPLAY_DEVICE", "1" if where == "device" else "0")
+        eng = capi.Engine(0)
+        try:
+            eng.set_geno_raw(raw, ignore_miss_data=ignore, call_geno=call)
+            assert eng.pair_kernel() == "hard"
+            eng.set_pos_dist(None)
+            assert eng.plan(0, 0, 0.0, ignore, True) == len(rec)
+            s1, s2, std, ext = eng.run()
+            info = eng.replay_info()
+        finally:
+            eng.close()
+        check_records(std, ext, rec)
+        got[where] = (std, ext, info)
+    (sd, ed, idv), (sh, eh, ih) = got["device"], got["host"]
+    assert idv["pairs_flagged"] == ih["pairs_flagged"] > max(4096, len(rec) // 256)          # (the list did overflow)
+    assert ih["pairs_on_device"] == 0
+    if call is not None or not miss:
+        assert idv["pairs_on_device"] > idv["pairs_flagged"] * 0.9, idv
+    for col in ("D", "Dp", "r2"):
+        assert np.array_equal(sd[col].view(np.uint64), sh[col].view(np.uint64)), col
+    assert np.array_equal(ed["hap"].view(np.uint64), eh["hap"].view(np.uint64))
+    assert np.array_equal(ed["n_iter"], eh["n_iter"]) and np.array_equal(ed["n_ind_data"], eh["n_ind_data"])
+    assert np.all(close(sd["r2_ExpG"], sh["r2_ExpG"], 1e-12))
