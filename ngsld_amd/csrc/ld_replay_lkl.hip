@@ -325,11 +325,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
           const double D = f[0] * f[3] - f[1] * f[2];
           const double Dp = D / (D < 0 ? -ref_min(hm0 * hm1, (1 - hm0) * (1 - hm1)) : ref_min(hm0 * (1 - hm1), (1 - hm0) * hm1));
           const double rr = D / __dsqrt_rn(hm0 * hm1 * (1 - hm0) * (1 - hm1));
-          ngsld_rec_std o = A.out_std[slot];  // (r2_ExpG stays the pair kernel's)
-          o.D = ref_nan(D);
-          o.Dp = ref_nan(Dp);
-          o.r2 = ref_nan(rr * rr);
-          A.out_std[slot] = o;
+          ngsld_rec_std *o = A.out_std + slot;  // (r2_ExpG stays the pair kernel's: three stores, no read -- the records may sit in
+          o->D = ref_nan(D);                     // pinned host memory, a read would cross the host link)
+          o->Dp = ref_nan(Dp);
+          o->r2 = ref_nan(rr * rr);
           if (A.out_ext != nullptr) {
             ngsld_rec_ext r;
             r.hap[0] = ref_nan(f[0]); r.hap[1] = ref_nan(f[1]); r.hap[2] = ref_nan(f[2]); r.hap[3] = ref_nan(f[3]);
@@ -549,11 +548,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
         const double D = f[0] * f[3] - f[1] * f[2];
         const double Dp = D / (D < 0 ? -ref_min(hm0 * hm1, (1 - hm0) * (1 - hm1)) : ref_min(hm0 * (1 - hm1), (1 - hm0) * hm1));
         const double rr = D / __dsqrt_rn(hm0 * hm1 * (1 - hm0) * (1 - hm1));
-        ngsld_rec_std o = A.out_std[e.slot];  // (r2_ExpG stays the pair kernel's)
-        o.D = ref_nan(D);
-        o.Dp = ref_nan(Dp);
-        o.r2 = ref_nan(rr * rr);
-        A.out_std[e.slot] = o;
+        ngsld_rec_std *o = A.out_std + e.slot;  // (r2_ExpG stays the pair kernel's: three stores, no read)
+        o->D = ref_nan(D);
+        o->Dp = ref_nan(Dp);
+        o->r2 = ref_nan(rr * rr);
         if (A.out_ext != nullptr) {
           ngsld_rec_ext r;
           r.hap[0] = ref_nan(f[0]); r.hap[1] = ref_nan(f[1]); r.hap[2] = ref_nan(f[2]); r.hap[3] = ref_nan(f[3]);
