@@ -624,7 +624,8 @@ def main():
         torch.cuda.synchronize()
         e2e = e2e_file_to_tsv(raw, n_sites, n_ind, chrs, pos, args.max_kb, host_cpus()["threads_used"])
     unfiltered = None
-    if rank == 0 and headline and not args.no_unfiltered and args.config == "c2" and not args.custom:
+    profiled = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX")) for k in os.environ)  # (its kernels would land in the profile)
+    if rank == 0 and headline and not args.no_unfiltered and args.config == "c2" and not args.custom and not profiled:
         unfiltered = unfiltered_input_leg(10_000, n_ind, args.max_kb, args.max_gap, args.depth, dev_index)
     del slab, raw
     torch.cuda.empty_cache()

@@ -10,12 +10,12 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=/tmp/prof_$TAG; OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $O $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python $R/bench.py --no-cpu --no-sink --no-e2e --no-traffic "$@" > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python $R/bench.py --no-cpu --no-sink --no-e2e --no-traffic --no-unfiltered "$@" > $OUT/stats.log 2>&1
 cp $O/stats/run_kernel_stats.csv $OUT/kernel_stats.csv
 grep -m1 '^{' $OUT/stats.log > $OUT/bench_under_rocprof.json
 for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_WAVE32_INSTS SQ_INSTS_VALU_TRANS SQ_LDS_BANK_CONFLICT"; do
   N=$(echo $SET | cut -d' ' -f1)
-  rocprofv3 --pmc $SET --output-format csv -d $O/pmc_$N -o run -- python $R/bench.py --no-cpu --no-sink --no-e2e --no-traffic --steps 1 --warmup 0 "$@" > $OUT/pmc_$N.log 2>&1
+  rocprofv3 --pmc $SET --output-format csv -d $O/pmc_$N -o run -- python $R/bench.py --no-cpu --no-sink --no-e2e --no-traffic --no-unfiltered --steps 1 --warmup 0 "$@" > $OUT/pmc_$N.log 2>&1
   python - "$O/pmc_$N" "$OUT/pmc_$N.csv" <<'PY'
 import csv, glob, sys
 src, dst = sys.argv[1], sys.argv[2]
