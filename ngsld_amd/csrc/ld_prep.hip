@@ -175,6 +175,16 @@ __device__ __forceinline__ double site_rsx(double sq) { return 1.0 / sqrt(sq); }
 // log-sum at -1e15 rounds log 3 to 1.125), and ngsld_set_geno_lkl takes whatever the caller normalised.  A site that holds
 // such a triple AND would be relabelled says so in the SIGN of its rsx: write_pair takes the magnitude and flags every pair
 // of the site for the exact-order replay (r2_ExpG would be off in the second decimal otherwise).
+// A site whose expected genotypes are all EQUAL here need not be constant in the reference: the quotient path gives 1/3 three
+// times for (1, 1, 1) and for (0.001, 0.001, 0.001) alike, the reference's log / exp chain 1.0 and 0.9999999999999996 -- and
+// gsl_stats_correlation then correlates that rounding noise (two individuals: r2_ExpG = 1 where this side says NaN; found by the
+// round-5 fuzz over matrices that are not SNP-called).  Individuals with IDENTICAL raw triples are identical there too; a
+// site that is constant here over raw triples that differ says so in the sign of its (infinite) rsx: its pairs go to the host's
+// replay, which has the caller's values.
+__device__ __forceinline__ uint64_t triple_key(double g0, double g1, double g2) {
+  const uint64_t a = (uint64_t)__double_as_longlong(g0), b = (uint64_t)__double_as_longlong(g1), c = (uint64_t)__double_as_longlong(g2);
+  return a ^ ((b << 21) | (b >> 43)) ^ ((c << 42) | (c >> 22));
+}
 constexpr double kSumTol = 0x1p-40;
 __device__ __forceinline__ bool odd_triple(double a0, double a1, double a2) { return !(fabs((a0 + a1 + a2) - 1.0) <= kSumTol); }
 __device__ __forceinline__ double signed_rsx(double rsx, bool odd, double maf) { return (odd && maf > 0.5 - 1e-9) ? -rsx : rsx; }
@@ -191,6 +201,7 @@ __global__ __launch_bounds__(256) void prep_sites_wave_kernel(PrepArgs A) {
     double e[MAXJ];
     double num = 0.0, den = 0.0, esum = 0.0;
     double mn = __builtin_inf(), mx = -__builtin_inf();
+    uint64_t kmin = ~0ull, kmax = 0ull;
     bool nan_seen = false, odd = false;
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) {
@@ -200,6 +211,9 @@ __global__ __launch_bounds__(256) void prep_sites_wave_kernel(PrepArgs A) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         if (i < A.n_ind) {
           const double g0 = raw[3 * (uint64_t)i], g1 = raw[3 * (uint64_t)i + 1], g2 = raw[3 * (uint64_t)i + 2];
+          const uint64_t key = triple_key(g0, g1, g2);
+          kmin = key < kmin ? key : kmin;
+          kmax = key > kmax ? key : kmax;
           if (!A.normalised_input) {
             prep_individual(F, g0, g1, g2, a0, a1, a2, num, den, nan_seen);
           } else {
@@ -224,6 +238,9 @@ __global__ __launch_bounds__(256) void prep_sites_wave_kernel(PrepArgs A) {
       const double x = __shfl_xor(mn, off), y = __shfl_xor(mx, off);
       mn = x < mn ? x : mn;
       mx = y > mx ? y : mx;
+      const uint64_t p = (uint64_t)__shfl_xor((long long)kmin, off), q = (uint64_t)__shfl_xor((long long)kmax, off);
+      kmin = p < kmin ? p : kmin;
+      kmax = q > kmax ? q : kmax;
     }
     const double mean = mn == mx ? mn : esum / (double)A.n_ind;
     double sq = 0.0;
@@ -239,7 +256,9 @@ __global__ __launch_bounds__(256) void prep_sites_wave_kernel(PrepArgs A) {
       const double maf = A.normalised_input ? A.maf_in[site] : num / den;
       A.maf[A.site0 + site] = maf;
       A.mean_e[A.site0 + site] = mean;
-      A.rsx[A.site0 + site] = signed_rsx(site_rsx(sq), any_odd, maf);
+      double rsx = signed_rsx(site_rsx(sq), any_odd, maf);
+      if (mn == mx && kmin != kmax && !A.normalised_input) rsx = -__builtin_inf();  // (constant here over raw triples that differ: see triple_key)
+      A.rsx[A.site0 + site] = rsx;
     }
     if (nan_seen) atomicExch(A.status, (int)NGSLD_ERR_NAN);
   }
@@ -255,11 +274,20 @@ __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
     double *__restrict__ pl = A.planes + (A.site0 + site) * A.site_stride;
     double acc[3] = {0.0, 0.0, 0.0};  // num, den (est_maf), sum of expected genotypes
     double mn[1] = {__builtin_inf()}, mx[1] = {-__builtin_inf()};
+    uint64_t key0 = 0;
+    bool have_key = false, differs = false;
     bool nan_seen = false, odd = false;
     for (uint32_t i = threadIdx.x; i < A.np; i += 256) {
       double a0 = 0.0, a1 = 0.0, a2 = 0.0;
       if (i < A.n_ind) {
         const double g0 = raw[3 * (uint64_t)i], g1 = raw[3 * (uint64_t)i + 1], g2 = raw[3 * (uint64_t)i + 2];
+        const uint64_t key = triple_key(g0, g1, g2);
+        if (!have_key) {
+          key0 = key;
+          have_key = true;
+        } else if (key != key0) {
+          differs = true;
+        }
         if (!A.normalised_input) {
           prep_individual(F, g0, g1, g2, a0, a1, a2, acc[0], acc[1], nan_seen);
         } else {
@@ -287,11 +315,16 @@ __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
     }
     block_sum<1>(sq, sh1);
     const bool any_odd = __syncthreads_or(odd ? 1 : 0) != 0;
+    // (raw triples all identical: every thread's own are, and every thread's first equals individual 0's)
+    const uint64_t first_key = triple_key(raw[0], raw[1], raw[2]);
+    const bool raw_differs = __syncthreads_or((differs || (have_key && key0 != first_key)) ? 1 : 0) != 0;
     if (threadIdx.x == 0) {
       const double maf = A.normalised_input ? A.maf_in[site] : acc[0] / acc[1];
       A.maf[A.site0 + site] = maf;
       A.mean_e[A.site0 + site] = mean;
-      A.rsx[A.site0 + site] = signed_rsx(site_rsx(sq[0]), any_odd, maf);
+      double rsx = signed_rsx(site_rsx(sq[0]), any_odd, maf);
+      if (mn[0] == mx[0] && raw_differs && !A.normalised_input) rsx = -__builtin_inf();  // (see triple_key)
+      A.rsx[A.site0 + site] = rsx;
     }
     if (nan_seen) atomicExch(A.status, (int)NGSLD_ERR_NAN);
   }

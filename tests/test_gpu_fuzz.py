@@ -23,6 +23,8 @@ def _case_full(k):
         n_ind = int(rng.choice([1, 3, 15, 16, 17, 33, 64, 100, 128, 129, 200, 257, 500, 513, 777, 1100, 2100, 4100]))
     elif k < 20_000:   # round 3: the shapes that changed kernel -- nine / ten slots per lane, the a/b kernel's range, the streaming kernel's new start
         n_ind = int(rng.choice([520, 576, 600, 640, 641, 700, 832, 833, 1153, 1200, 1280, 2305, 2500, 4609, 4800, 5120, 5121]))
+    elif k >= 40_000:  # round 5: matrices that are NOT SNP-called (monomorphic sites, a log-uniform spectrum): a third of the pairs flagged
+        n_ind = int(rng.choice([2, 17, 64, 100, 129, 200, 300, 385, 500, 512, 513, 700, 1024, 1100, 2000, 2100, 4096, 4100]))
     elif k < 30_000:   # round 3, last session: the streaming kernel with the candidate's vector resident (11..20 blocks per wavefront; beyond 10,240 with a streamed tail)
         n_ind = int(rng.choice([5121, 5633, 5700, 6145, 6500, 7000, 7681, 8193, 9000, 9729, 10240, 10241, 11000]))
     else:              # round 3: the multi-wavefront kernel's five to eight slots per lane, whose row slice sits (partly) in registers
@@ -30,7 +32,12 @@ def _case_full(k):
                                 3584, 3585, 4000, 4096]))
     n_sites = int(rng.integers(3, 60 if n_ind <= 600 else (14 if n_ind <= 5121 else 7)))
     depth = float(rng.choice([0.5, 1.0, 2.0, 5.0, 10.0, 30.0]))
-    raw = synth.make_gl_numpy(n_sites, n_ind, 5000 + k, depth=depth)
+    if k >= 40_000:
+        n_sites = int(rng.integers(8, 70 if n_ind <= 600 else 24))
+        raw = synth.make_gl_numpy(n_sites, n_ind, 5000 + k, depth=max(depth, 2.0), mono_frac=float(rng.choice([0.0, 0.2, 0.5])),
+                                  sfs=bool(rng.random() < 0.4))
+    else:
+        raw = synth.make_gl_numpy(n_sites, n_ind, 5000 + k, depth=depth)
     miss = rng.random((n_sites, n_ind)) < rng.choice([0.0, 0.05, 0.4])
     raw[miss] = rng.choice([1.0 / 3.0, 0.5, 1e-3])
     if rng.random() < 0.3:                                       # some hard-called individuals / a monomorphic site
@@ -72,9 +79,13 @@ def pick_min_maf(maf: np.ndarray, k: int) -> float:
     return float(np.round(np.nanquantile(maf[ok], 0.3), 3))
 
 
-@pytest.mark.parametrize("k", list(range(240)) + REGRESSION_SEEDS + list(range(10_000, 10_060)) + list(range(20_000, 20_030)) + list(range(30_000, 30_040)))
+@pytest.mark.parametrize("k", list(range(240)) + REGRESSION_SEEDS + list(range(10_000, 10_060)) + list(range(20_000, 20_030)) + list(range(30_000, 30_040)) +
+                         list(range(40_000, 40_060)))
 def test_random_configuration(engine, k):
     raw, pd, kw, call = _case(k)
+    # (un-called cases: the flagged pairs on the device from the first one on -- the suite's matrices are too small to reach
+    # the build threshold by themselves; every other case keeps the default policy)
+    engine.set_exact_store(2 if k >= 40_000 else 1)
     o0 = orc.Oracle(raw, pd, log_scale=kw["log_scale"], call_geno=call)
     min_maf = pick_min_maf(o0.maf, k)
     o = orc.Oracle(raw, pd, min_maf=min_maf, n_threads=4, call_geno=call, **kw)
