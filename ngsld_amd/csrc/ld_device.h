@@ -45,8 +45,9 @@ constexpr double kEpsilon = 1e-5;  // EPSILON,  gen_func.hpp:16
 //   * D' or r2 is not reproducible to kRecordTol: the hap-derived allele frequencies 1 - (f0 + f1) / 1 - (f0 + f2)
 //     (ngsLD.cpp:297-298) carry ~1e-16 of ABSOLUTE rounding noise in the reference and here alike, D' and r2 are quotients by
 //     products of these margins q, so the two evaluations differ by ~ noise * (1 / q0 + 1 / q1) * the value itself.  The
-//     noise is taken as kHapNoise = 2^-50 (8.9e-16: twice what a 39,000-case soak showed -- differences up to 1.1e-10 right
-//     above a then fixed threshold q >= 2^-18, i.e. 4.2e-16), the tolerance as a quarter of the 1e-9 bar.  Below
+//     noise is taken as kHapNoise = 2^-49 (1.8e-15: four times what a 39,000-case soak showed -- differences up to 1.1e-10
+//     right above a then fixed threshold q >= 2^-18, i.e. 4.2e-16; with 2^-50 the round-5 soak over 10,000 un-called cases saw
+//     3.1e-10 on a pair just under the bound), the tolerance as a quarter of the 1e-9 bar.  Below
 //     kReplayFloor the margins themselves may be exact zeros on one side and not on the other (0/0-type quotients: nan,
 //     0 or inf by the noise alone): every such pair is flagged whatever its values;
 //     (rounds 2-4 flagged every pair with q < 2^-16 / 2^-18: on matrices that are not SNP-called that is 40 % of the pairs,
@@ -56,7 +57,7 @@ constexpr double kEpsilon = 1e-5;  // EPSILON,  gen_func.hpp:16
 //   * the Pearson cross moment is ill conditioned for THIS pair (kPearsonCond): sites whose expected genotypes are nearly
 //     constant -- at the extreme gsl_stats_correlation is a 0/0-type quotient of its own accumulation noise
 //     (ngsLD.cpp:365-367).
-constexpr double kHapNoise = 0x1p-50;
+constexpr double kHapNoise = 0x1p-49;
 constexpr double kRecordTol = 2.5e-10;
 constexpr double kReplayFloor = 0x1p-30;
 constexpr double kTieMargin = 1e-12;
