@@ -77,3 +77,32 @@ def test_every_route_delivers_the_same_records(shape, monkeypatch):
         got = _run(raw, pd, kw, env, monkeypatch)
         assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
         assert got[2] == base[2] and got[3] == base[3], f"records differ on route {env}"
+
+
+@pytest.mark.parametrize("streams", ["1", "2"])
+def test_reported_kernel_time_of_a_two_stream_run_is_a_span_not_a_sum(streams, monkeypatch):
+    """ngsld_last_kernel_time after ngsld_run (round 4's advisor): launches on two compute streams share the device, so their time
+    is first start .. last end -- the sum of their durations would exceed the wall time of the run.  Text batches (two streams by
+    default; NGSLD_TEXT_STREAMS=1: one) of a run long enough to measure."""
+    import time
+    monkeypatch.setenv("NGSLD_TEXT_STREAMS", streams)
+    n_sites, n_ind = 6000, 200
+    raw = synth.make_gl_numpy(n_sites, n_ind, seed=9, depth=8.0)
+    chrs, pos = synth.make_positions(n_sites, 9)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    eng = capi.Engine(0)
+    try:
+        eng.set_geno_raw(raw)
+        eng.set_pos_dist(pd)
+        eng.set_tuning(batch_pairs=1 << 17)
+        n = eng.plan(max_kb_dist=100, extend_out=True)
+        eng.set_text_output([f"c:{p}" for p in pos])
+        eng.run_text()                                   # (buffers sized and pinned)
+        t0 = time.perf_counter()
+        eng.run_text()
+        wall_ms = (time.perf_counter() - t0) * 1e3
+        ms, launches, pairs = eng.last_kernel_time()
+    finally:
+        eng.close()
+    assert pairs == n and launches >= 20
+    assert 0.2 * wall_ms < ms <= 1.02 * wall_ms, (streams, ms, wall_ms, launches)
