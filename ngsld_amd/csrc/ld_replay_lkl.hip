@@ -61,21 +61,55 @@ __device__ __forceinline__ constexpr int geno2(int h, int k) { return (h & 1) + 
 // gen_func.cpp:862-868 on a normal-space triple (pair_freq_iter's use of it, :1089)
 __device__ __forceinline__ bool no_data(const double (&g)[3]) { return ref_abs(g[0] - g[1]) < kEps && ref_abs(g[1] - g[2]) < kEps; }
 
-// One individual's four quotients tmp_k / sum exactly as pair_freq_iter forms them (gen_func.cpp:1092-1104): the loops as
-// the reference writes them.  (f[k] * f[h] does not depend on the individual and the compiler takes it out of the slot
-// loop; the two products inside the parentheses are the same expression: both are exact rewrites, one rounding per
-// operation stays one rounding per operation.)
-__device__ __forceinline__ void quotients(const double (&f)[4], const double (&p)[3], const double (&q)[3], double (&out)[4]) {
-  double sum = 0;
+// One individual's four quotients tmp_k / sum exactly as pair_freq_iter forms them (gen_func.cpp:1092-1104) -- the reference's
+// expression trees, with what they share taken out.  Every rewrite below is EXACT (the same correctly rounded operations on the
+// same operands, or an operation whose result IEEE arithmetic fixes without rounding):
+//   * f[k] * f[h] is the leftmost product of every term (C associates left to right) and does not depend on the individual:
+//     formed once per iteration (FreqProducts), f[k] * f[h] == f[h] * f[k];
+//   * inside the parentheses of `tmp`, p[G1(h,k)] * q[G2(h,k)] and p[G1(k,h)] * q[G2(k,h)] are the same product (G1 and G2 are
+//     symmetric), and x + x == 2 x without rounding; (f[k] f[h]) * (2 J) and (2 f[k] f[h]) * J are the same real number rounded
+//     once (doubling is exact): the doubled products are formed once per iteration too;
+//   * `sum = 0; sum += t0` and `tmp = 0; tmp += t0`: 0 + t0 == t0 for every t0 >= +0 or NaN, and the terms are products of
+//     likelihoods and frequencies -- never negative, never -0.
+// 9 + 20 + 10 multiplies, 15 + 12 additions, 4 divisions per individual and iteration (the literal loops: 9 + 32 + 16
+// multiplies, 16 + 16 + 16 additions); the records are the same bits (tests/test_gpu_replay_lkl.py: device against host replay).
+struct FreqProducts {
+  double g[10], h2[10];  // f[k] * f[h] for k <= h, and twice that
+  __device__ __forceinline__ static constexpr int at(int k, int h) {  // index of the unordered pair {k, h}
+    return (k <= h) ? (k * 4 - k * (k - 1) / 2 + (h - k)) : (h * 4 - h * (h - 1) / 2 + (k - h));
+  }
+  __device__ __forceinline__ void set(const double (&f)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int h = k; h < 4; ++h) {
+        g[at(k, h)] = f[k] * f[h];
+        h2[at(k, h)] = 2 * g[at(k, h)];
+      }
+  }
+};
+
+__device__ __forceinline__ void quotients(const FreqProducts &F, const double (&p)[3], const double (&q)[3], double (&out)[4]) {
+  double J[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) J[a][b] = p[a] * q[b];
+  // gen_func.cpp:1093-1096: sum += f[k] * f[h] * p[0][G1] * p[1][G2], k outer, h inner
+  double t[10];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
 #pragma unroll
-    for (int h = 0; h < 4; ++h) sum += f[k] * f[h] * p[geno1(k, h)] * q[geno2(k, h)];
+    for (int h = k; h < 4; ++h) t[FreqProducts::at(k, h)] = F.g[FreqProducts::at(k, h)] * p[geno1(k, h)] * q[geno2(k, h)];
+  double sum = t[FreqProducts::at(0, 0)];
+#pragma unroll
+  for (int kh = 1; kh < 16; ++kh) sum += t[FreqProducts::at(kh >> 2, kh & 3)];
+  // gen_func.cpp:1098-1104
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    double tmp = 0;
+    double tmp = F.h2[FreqProducts::at(k, 0)] * J[geno1(0, k)][geno2(0, k)];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) tmp += f[k] * f[h] * (p[geno1(h, k)] * q[geno2(h, k)] + p[geno1(k, h)] * q[geno2(k, h)]);
+    for (int h = 1; h < 4; ++h) tmp += F.h2[FreqProducts::at(k, h)] * J[geno1(h, k)][geno2(h, k)];
     out[k] = tmp / sum;
   }
 }
@@ -255,6 +289,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
           f[3] = m1 * m2;
           for (iter = 0; iter < (uint32_t)kMaxIter; ++iter) {
             // every individual's four quotients, parked in individual order (an individual left out adds +0: ff + 0 == ff)
+            FreqProducts F;
+            F.set(f);
 #pragma unroll
             for (int j = 0; j < kSlots; ++j) {
               // (the nine products p[g1] * q[g2] do not change from iteration to iteration and the compiler would keep them --
@@ -262,7 +298,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
               for (int g = 0; g < 3; ++g) asm volatile("" : "+v"(b[j][g]));
               double o[4];
-              quotients(f, a[j], b[j], o);
+              quotients(F, a[j], b[j], o);
               const bool on = (valid >> j) & 1u;
               const int i = (wave * kSlots + j) * 64 + lane;
 #pragma unroll
@@ -504,6 +540,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
         an[g] = pa[g];
         bn[g] = pb[g];
       }
+      FreqProducts F;
+      F.set(f);
       for (uint32_t i = 0; i < A.n_ind; ++i) {
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
@@ -521,7 +559,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
         if (ign && (no_data(a) || no_data(b))) continue;  // gen_func.cpp:1089
         ++x;
         double o[4];
-        quotients(f, a, b, o);
+        quotients(F, a, b, o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) ff[k] += o[k];  // gen_func.cpp:1103, in the reference's order
       }
