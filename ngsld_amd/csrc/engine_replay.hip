@@ -535,7 +535,9 @@ int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t ou
   // (a launch of a few hundred thousand records -- a text batch -- stays with the wavefront-per-pair kernel: a lane takes
   // milliseconds over ONE pair, four wavefronts to a SIMD, and such a launch has no second pair for most lanes: 6 ms a batch
   // against 4, profiles/r05/e2e_uncalled_lanes_on_text_batches.json)
-  if (c->xT_ready && n >= (1ull << 22)) {
+  uint64_t lanes_from = 1ull << 22;
+  if (const char *v = std::getenv("NGSLD_REPLAY_LANES_FROM")) lanes_from = std::strtoull(v, nullptr, 10);  // A/B
+  if (c->xT_ready && n >= lanes_from) {
     a.after_lanes = 1;
     // one lane per pair wherever the individual-major copy is there: the launch's bitmap becomes a list of located pairs (the
     // bits listed are cleared), the lanes work through it; what stays in the bitmap -- ill-conditioned Pearson moments, pairs
@@ -551,7 +553,7 @@ int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t ou
     HIP_TRY(c, ls.temp.resize(temp_bytes ? temp_bytes : 1));
     HIP_TRY(c, launch_replay_expand(a, ls.list.p, list_cap, st));
     HIP_TRY(c, launch_replay_sort(a, ls.list.p, list_cap, ls.keys_a.p, ls.keys_b.p, ls.vals_a.p, ls.vals_b.p, ls.temp.p, temp_bytes, st));
-    HIP_TRY(c, launch_replay_lanes(a, ls.list.p, ls.vals_b.p, c->d_xT.p, c->n_cus, st));
+    HIP_TRY(c, launch_replay_lanes(a, ls.list.p, ls.vals_b.p, c->d_xT.p, c->n_cus, n >= (1ull << 22) ? 4 : 1, st));
   }
   HIP_TRY(c, launch_replay_lkl(a, c->n_cus, st));
   return NGSLD_OK;

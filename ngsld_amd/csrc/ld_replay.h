@@ -89,8 +89,10 @@ size_t replay_sort_temp_bytes(uint64_t list_cap, uint32_t n_sites);
 hipError_t launch_replay_sort(const ReplayLklArgs &a, const ReplayEntry *list, uint64_t list_cap, uint64_t *keys_a, uint64_t *keys_b,
                               uint32_t *vals_a, uint32_t *vals_b, void *temp, size_t temp_bytes, hipStream_t stream);
 // the lane-per-pair kernel over list[order[0 .. flags[4])] (work counter: flags[5])
+// waves_per_simd: 4 where the launch has pairs for every lane many times over; 1 for a launch of a few hundred thousand records (a
+// lane's pair then takes a quarter of the time, and the launch lasts as long as its slowest lane)
 hipError_t launch_replay_lanes(const ReplayLklArgs &a, const ReplayEntry *list, const uint32_t *order, const double *xT, int n_cus,
-                               hipStream_t stream);
+                               int waves_per_simd, hipStream_t stream);
 
 // wavefronts per pair for a cohort of n_ind individuals (1 up to 512, then 2 / 4 / 8); 0: beyond the kernel (host replay)
 uint32_t replay_lkl_waves(uint32_t n_ind);

@@ -646,10 +646,10 @@ hipError_t launch_replay_sort(const ReplayLklArgs &a, const ReplayEntry *list, u
 }
 
 hipError_t launch_replay_lanes(const ReplayLklArgs &a, const ReplayEntry *list, const uint32_t *order, const double *xT, int n_cus,
-                               hipStream_t stream) {
+                               int waves_per_simd, hipStream_t stream) {
   if (list == nullptr || xT == nullptr || a.n_records == 0) return hipSuccess;
   // a persistent grid: four wavefronts per SIMD (96 registers, no LDS: the gathers want the company); never more lanes than the launch has records
-  uint64_t waves = (uint64_t)n_cus * 4 * 4;
+  uint64_t waves = (uint64_t)n_cus * 4 * (uint64_t)(waves_per_simd < 1 ? 1 : (waves_per_simd > 4 ? 4 : waves_per_simd));
   const uint64_t most = (a.n_records + 63) / 64;
   if (waves > most) waves = most;
   hipLaunchKernelGGL(replay_lane_kernel, dim3((unsigned)waves), dim3(64), 0, stream, a, list, order, xT);

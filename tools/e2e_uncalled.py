@@ -27,7 +27,10 @@ out = {"n_sites": n_sites, "n_ind": n_ind, "threads": threads, "runs": {}}
 chrs, pos = synth.make_positions(n_sites, 3)
 n_pairs = int(shard.row_pair_counts(shard.pos_dist_from_positions(chrs, pos), 100, 0).sum())
 out["pairs"] = n_pairs
+only = os.environ.get("E2E_ONLY")
 for name, kw in (("default", {}), ("mono20", {"mono_frac": 0.2}), ("sfs", {"sfs": True})):
+    if only and name not in only.split(","):
+        continue
     with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
         raw = synth.make_gl_torch(n_sites, n_ind, 3, torch.device("cuda", 0), **kw)
         g, p = os.path.join(d, "in.glf"), os.path.join(d, "in.pos")
