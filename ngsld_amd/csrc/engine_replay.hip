@@ -423,7 +423,14 @@ int ensure_exact_store(ngsld_ctx *c) {
   std::vector<double> xmaf(n);
   uint64_t chunk = std::max<uint64_t>(1, (32ull << 20) / (site_elems * sizeof(double)));
   if (chunk > n) chunk = n;
-  hipEvent_t up[2] = {nullptr, nullptr};
+  struct Events {  // (destroyed on every way out)
+    hipEvent_t e[2] = {nullptr, nullptr};
+    ~Events() {
+      for (hipEvent_t x : e)
+        if (x) (void)hipEventDestroy(x);
+    }
+    hipEvent_t &operator[](int k) { return e[k]; }
+  } up;
   for (int k = 0; k < 2; ++k) {
     HIP_TRY(c, c->h_xstage[k].resize((size_t)chunk * site_elems));
     HIP_TRY(c, hipEventCreateWithFlags(&up[k], hipEventDisableTiming));
@@ -473,8 +480,6 @@ int ensure_exact_store(ngsld_ctx *c) {
   } else {
     (void)hipStreamSynchronize(st);
   }
-  for (int q = 0; q < 2; ++q)
-    if (up[q]) (void)hipEventDestroy(up[q]);
   if (rc != NGSLD_OK) return rc;
   c->exact_alias = false;
   c->exact_ready = true;

@@ -264,7 +264,9 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   // (kTextBatchPairs; round 1, configs[2] end to end: 2^23 pairs per batch 2.2 s, 2^21 1.5 s)
   // (records written by the kernels themselves: every launch costs ~0.4 ms of drain and nothing has to be staged on the
   // device, so the batches are twice the size -- 2 x 1.2 GB of pinned host memory with the extended record)
-  uint64_t batch_pairs = text ? std::min<uint64_t>(c->batch_pairs, kTextBatchPairs)
+  uint64_t text_batch = kTextBatchPairs;
+  if (const char *e = std::getenv("NGSLD_TEXT_BATCH_PAIRS")) text_batch = std::max<uint64_t>(1024, std::strtoull(e, nullptr, 10));  // A/B
+  uint64_t batch_pairs = text ? std::min<uint64_t>(c->batch_pairs, text_batch)
                               : ((direct && !c->batch_pairs_set) ? 2 * c->batch_pairs : c->batch_pairs);
   const bool taper = !text && !direct && c->run_taper;
   uint64_t cap = 1, last_cap = 0;
