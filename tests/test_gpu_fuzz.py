@@ -86,6 +86,13 @@ def test_random_configuration(engine, k):
     # (un-called cases: the flagged pairs on the device from the first one on -- the suite's matrices are too small to reach
     # the build threshold by themselves; every other case keeps the default policy)
     engine.set_exact_store(2 if k >= 40_000 else 1)
+    try:
+        _run_case(engine, k, raw, pd, kw, call)
+    finally:
+        engine.set_exact_store(1)        # (the engine is the session's: the next test finds the default policy)
+
+
+def _run_case(engine, k, raw, pd, kw, call):
     o0 = orc.Oracle(raw, pd, log_scale=kw["log_scale"], call_geno=call)
     min_maf = pick_min_maf(o0.maf, k)
     o = orc.Oracle(raw, pd, min_maf=min_maf, n_threads=4, call_geno=call, **kw)
