@@ -230,7 +230,7 @@ typedef struct {
   uint64_t pairs_on_host;      /* ... on host threads */
   uint64_t sites_reevaluated;  /* sites the host re-evaluated for the last plan + run */
   int32_t exact_store;         /* 0 none, 1 the planes themselves serve as the store, 2 built from the replay source */
-  int32_t reserved;
+  int32_t text_rows_patched;   /* text runs: rows of pairs replayed on the host whose value columns were overwritten in the host's copy of the text */
   double exact_store_build_s;  /* host seconds the build took (once per matrix) */
 } ngsld_replay_stats_t;
 int ngsld_replay_info(ngsld_ctx *ctx, ngsld_replay_stats_t *out);

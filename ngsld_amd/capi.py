@@ -99,7 +99,7 @@ class ReplayStats(C.Structure):
     """ngsld_replay_stats_t (include/ngsld.h)."""
     _fields_ = [("pairs_flagged", C.c_uint64), ("pairs_replayed", C.c_uint64), ("pairs_on_device", C.c_uint64),
                 ("pairs_on_host", C.c_uint64), ("sites_reevaluated", C.c_uint64), ("exact_store", C.c_int32),
-                ("reserved", C.c_int32), ("exact_store_build_s", C.c_double)]
+                ("text_rows_patched", C.c_int32), ("exact_store_build_s", C.c_double)]
 
 
 class NgsldError(RuntimeError):
@@ -657,7 +657,7 @@ class Engine:
         """ngsld_replay_info: where the flagged pairs of the last run were replayed."""
         st = ReplayStats()
         self._check(self._L.ngsld_replay_info(self._h, C.byref(st)))
-        return {k: getattr(st, k) for k, _ in ReplayStats._fields_ if k != "reserved"}
+        return {k: getattr(st, k) for k, _ in ReplayStats._fields_}
 
     def finish_device(self) -> None:
         self._check(self._L.ngsld_finish_device(self._h))

@@ -241,6 +241,15 @@ class ReplayPool {
 using namespace ngsld;       // (an internal header: only the engine_*.hip units include it)
 using namespace ngsld::eng;
 
+// One pair a text batch leaves to the host's exact-order replay, written by the device right behind the batch's row lengths
+// (engine_replay.hip: flag_rows_to_host_kernel): with it the host replays the pair and overwrites the row's value columns in
+// the text it has received -- nothing goes back to the device, no kernel is submitted when the batch is consumed.
+struct FlagRow {
+  uint64_t rec, off;  // record index within the batch; first byte of its row in the batch's text
+  uint32_t len, s1, s2, pad;
+};
+constexpr uint32_t kFlagRowsCap = 256;
+
 struct ngsld_ctx {
   int device = 0;
   hipStream_t stream = nullptr, stream2 = nullptr, copy_stream = nullptr;
@@ -343,9 +352,11 @@ struct ngsld_ctx {
   DevBuf<uint32_t> d_flags[kSlots], d_flags_dev;   // [count, pad, list of the first flag_cap, one bit per record ...] per pipeline slot / for ngsld_run_device
   PinBuf<uint32_t> h_flags[kSlots], h_flags_dev;   // host copies of the HEAD (count + list): they travel with the batch's records / text meta
   PinBuf<uint32_t> h_flag_bits;                    // the bitmap, fetched only when a launch flagged more pairs than the list holds
+  PinBuf<FlagRow> h_flag_rows[kSlots];             // text batches: where the rows of the listed pairs lie in the batch's text (send_flag_rows)
   uint32_t flag_cap[kSlots] = {0, 0, 0}, flag_cap_dev = 0;  // list entries of d_flags[k] / d_flags_dev as last reset
   bool replay_device = true;                       // flagged pairs replayed on the device where that is possible: called genotypes (ld_replay.hip), likelihoods (ld_replay_lkl.hip); NGSLD_REPLAY_DEVICE=0: host
   uint64_t replayed_on_device = 0;
+  uint64_t text_rows_patched = 0;                  // rows of host-replayed pairs overwritten in the host's copy of a batch's text (last run)
   // The exact store of the device-side replay of LIKELIHOOD matrices (ld_replay_lkl.hip): normal-space likelihoods and est_maf
   // as the reference holds them when calc_pair_LD runs -- the HOST's libm, the sequential est_maf -- laid out like the planes.
   // Input that came through ngsld_set_geno_lkl is such a store already (the planes are the caller's values), and so are the
@@ -462,6 +473,12 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
                    uint32_t *d_flags = nullptr, uint32_t flag_cap = 0, uint64_t flag_n = 0);
 
 // ---- engine_replay.hip ----
+// send_flag_rows: for the pairs a text batch leaves to the host (its flag list, or its host-only list behind a device-side
+// replay -- at most kFlagRowsCap of them), which pair each is and where its row lies in the batch's text
+int send_flag_rows(ngsld_ctx *c, const uint32_t *d_flags, uint32_t cap, bool dev_applied, const uint64_t *d_offs, const uint64_t *d_lens,
+                   uint64_t n_records, uint64_t base, FlagRow *h_rows, hipStream_t st);
+// the pairs (s1[k], s2[k]) in the reference's operation order on the host's threads -> out_std[k] / out_ext[k] (null: not wanted)
+int replay_pairs_on_host(ngsld_ctx *c, const uint32_t *s1, const uint32_t *s2, size_t n, ngsld_rec_std *out_std, ngsld_rec_ext *out_ext);
 unsigned usable_threads();
 hipStream_t replay_stream_of(ngsld_ctx *c);
 int ensure_host_items(ngsld_ctx *c);

@@ -49,12 +49,9 @@ __global__ void patch_records_kernel(const uint64_t *idx, uint64_t n, const ngsl
 // (s1, s2) of plan records, on the device: what locate_record below does on the host copy of the items -- which a run that
 // leaves its records on the device never needs otherwise (configs[3]: 7.8e7 items, 2.5 GB to copy and hold for a few
 // hundred flagged pairs: 155 ms of its one 12 s step)
-__global__ void locate_records_kernel(const uint64_t *rec, uint64_t n, uint64_t base, const uint64_t *row_off,
-                                      const uint64_t *item_off, const Item *items, uint32_t n_sites, uint32_t *s1, uint32_t *s2) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  s1[t] = s2[t] = 0xffffffffu;
-  const uint64_t r = base + rec[t];
+__device__ inline void locate_record_on_device(uint64_t r, const uint64_t *row_off, const uint64_t *item_off, const Item *items,
+                                               uint32_t n_sites, uint32_t *s1, uint32_t *s2) {
+  *s1 = *s2 = 0xffffffffu;
   uint32_t lo = 0, hi = n_sites;  // largest row with row_off[row] <= r
   while (lo + 1 < hi) {
     const uint32_t mid = lo + (hi - lo) / 2;
@@ -70,8 +67,15 @@ __global__ void locate_records_kernel(const uint64_t *rec, uint64_t n, uint64_t 
   uint64_t k = r - it.first_record, m = it.mask;
   if (k >= (uint64_t)__popcll(m)) return;
   while (k--) m &= m - 1;
-  s1[t] = it.s1;
-  s2[t] = it.s2_begin + (uint32_t)(__ffsll((unsigned long long)m) - 1);
+  *s1 = it.s1;
+  *s2 = it.s2_begin + (uint32_t)(__ffsll((unsigned long long)m) - 1);
+}
+
+__global__ void locate_records_kernel(const uint64_t *rec, uint64_t n, uint64_t base, const uint64_t *row_off,
+                                      const uint64_t *item_off, const Item *items, uint32_t n_sites, uint32_t *s1, uint32_t *s2) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  locate_record_on_device(base + rec[t], row_off, item_off, items, n_sites, &s1[t], &s2[t]);
 }
 
 int ensure_host_items(ngsld_ctx *c) {  // the host copy of the plan's items, fetched on first use
@@ -209,45 +213,17 @@ int flagged_records(ngsld_ctx *c, const uint32_t *h_head, const uint32_t *d_flag
   return from_bitmap(flag_head_words(cap), count);
 }
 
-// Records `recs` (indices into a launch whose record 0 is the plan's record `base`, increasing) are replayed; the new
-// records go to h_std / h_ext (host buffers of the batch) or, when those are null, to d_std / d_ext on stream st (synchronised).
-int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t base, ngsld_rec_std *h_std,
-                   ngsld_rec_ext *h_ext, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext, hipStream_t st,
-                   std::vector<uint32_t> *sites1, std::vector<uint32_t> *sites2) {
-  Range range_("ngsld:exact-order replay (host)");
-  if (recs.empty()) return NGSLD_OK;
-  // which pairs these records are: from the host copy of the plan's items where the run has one anyway (the sink path), from
-  // the device's otherwise
-  const bool have_items = c->h_items.size() == c->n_items;
-  std::vector<uint32_t> loc_s1, loc_s2;
-  if (!have_items) {
-    hipStream_t ls = st != nullptr ? st : replay_stream_of(c);
-    loc_s1.resize(recs.size());
-    loc_s2.resize(recs.size());
-    HIP_TRY(c, c->d_patch_idx.resize(recs.size()));
-    HIP_TRY(c, c->d_patch_s1.resize(recs.size()));
-    HIP_TRY(c, c->d_patch_s2.resize(recs.size()));
-    HIP_TRY(c, hipMemcpyAsync(c->d_patch_idx.p, recs.data(), recs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ls));
-    hipLaunchKernelGGL(locate_records_kernel, dim3((unsigned)((recs.size() + 63) / 64)), dim3(64), 0, ls, c->d_patch_idx.p,
-                       (uint64_t)recs.size(), base, c->d_row_off.p, c->d_item_off.p, c->d_items.p, (uint32_t)c->n_sites,
-                       c->d_patch_s1.p, c->d_patch_s2.p);
-    HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(loc_s1.data(), c->d_patch_s1.p, recs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
-    HIP_TRY(c, hipMemcpyAsync(loc_s2.data(), c->d_patch_s2.p, recs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
-    HIP_TRY(c, hipStreamSynchronize(ls));
-  }
-  const bool ext = (h_std != nullptr ? (void *)h_ext : (void *)d_ext) != nullptr;
+// The pairs (s1[k], s2[k]), k < n, in the reference's operation order on the host's threads.
+int replay_pairs_on_host(ngsld_ctx *c, const uint32_t *s1v, const uint32_t *s2v, size_t n, ngsld_rec_std *out_std, ngsld_rec_ext *out_ext) {
+  if (n == 0) return NGSLD_OK;
   const bool ign = c->params.ignore_miss_data != 0;
-  std::vector<ngsld_rec_std> out_std(recs.size());
-  std::vector<ngsld_rec_ext> out_ext(ext ? recs.size() : 0);
-  if (sites1) sites1->assign(recs.size(), 0);  // (the pairs' sites, for callers that format the replayed rows again)
-  if (sites2) sites2->assign(recs.size(), 0);
   int T = c->replay_threads > 0 ? c->replay_threads : (int)std::min<unsigned>(32u, usable_threads());
-  if ((uint64_t)T > recs.size()) T = (int)recs.size();  // (a launch of 1e8 pairs flags a few dozen: sixteen per thread left them to two threads, 2.6 ms)
+  if ((uint64_t)T > n) T = (int)n;  // (a launch of 1e8 pairs flags a few dozen: sixteen per thread left them to two threads, 2.6 ms)
+  if (T < 1) T = 1;
   std::vector<int> rcs((size_t)T, NGSLD_OK), stats((size_t)T, NGSLD_OK);
   std::vector<uint64_t> sites_done((size_t)T, 0);
   auto work = [&](int t) {
-    const size_t k0 = recs.size() * (size_t)t / (size_t)T, k1 = recs.size() * (size_t)(t + 1) / (size_t)T;
+    const size_t k0 = n * (size_t)t / (size_t)T, k1 = n * (size_t)(t + 1) / (size_t)T;
     // records come in (s1, s2) order: the row's site is kept, the partners go through a bounded cache
     const size_t cache_cap = std::max<size_t>(64, (256ull << 20) / (32 * c->n_ind + 64));
     std::unordered_map<uint32_t, ReplaySite> cache;
@@ -256,14 +232,11 @@ int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t bas
     uint32_t row_site = 0xffffffffu;
     try {
       for (size_t k = k0; k < k1; ++k) {
-        uint32_t s1 = 0, s2 = 0;
-        if (have_items ? !locate_record(c, base + recs[k], &s1, &s2)
-                       : ((s1 = loc_s1[k]) == 0xffffffffu || (s2 = loc_s2[k]) == 0xffffffffu)) {
+        const uint32_t s1 = s1v[k], s2 = s2v[k];
+        if (s1 >= c->n_sites || s2 >= c->n_sites) {
           rcs[(size_t)t] = NGSLD_ERR_INVALID;
           return;
         }
-        if (sites1) (*sites1)[k] = s1;
-        if (sites2) (*sites2)[k] = s2;
         if (s1 != row_site) {
           const int rc = fetch_replay_site(c, s1, tmp, &row);
           if (rc != NGSLD_OK) { rcs[(size_t)t] = rc; return; }
@@ -278,13 +251,12 @@ int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t bas
           if (rc != NGSLD_OK) { rcs[(size_t)t] = rc; return; }
           ++sites_done[(size_t)t];
         }
-        replay_pair(row, hit->second, c->n_ind, ign, &out_std[k], ext ? &out_ext[k] : nullptr, &stats[(size_t)t]);
+        replay_pair(row, hit->second, c->n_ind, ign, &out_std[k], out_ext ? &out_ext[k] : nullptr, &stats[(size_t)t]);
       }
     } catch (...) {
       rcs[(size_t)t] = NGSLD_ERR_NOMEM;
     }
   };
-  if (T < 1) T = 1;
   c->replay_pool.run(T, work);
   for (int t = 0; t < T; ++t) {
     if (rcs[(size_t)t] != NGSLD_OK)
@@ -296,6 +268,46 @@ int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t bas
     }
     c->replayed_sites += sites_done[(size_t)t];
   }
+  return NGSLD_OK;
+}
+
+// Records `recs` (indices into a launch whose record 0 is the plan's record `base`, increasing) are replayed; the new
+// records go to h_std / h_ext (host buffers of the batch) or, when those are null, to d_std / d_ext on stream st (synchronised).
+int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t base, ngsld_rec_std *h_std,
+                   ngsld_rec_ext *h_ext, ngsld_rec_std *d_std, ngsld_rec_ext *d_ext, hipStream_t st,
+                   std::vector<uint32_t> *sites1, std::vector<uint32_t> *sites2) {
+  Range range_("ngsld:exact-order replay (host)");
+  if (recs.empty()) return NGSLD_OK;
+  // which pairs these records are: from the host copy of the plan's items where the run has one anyway (the sink path), from
+  // the device's otherwise
+  const bool have_items = c->h_items.size() == c->n_items;
+  std::vector<uint32_t> loc_s1(recs.size()), loc_s2(recs.size());
+  if (!have_items) {
+    hipStream_t ls = st != nullptr ? st : replay_stream_of(c);
+    HIP_TRY(c, c->d_patch_idx.resize(recs.size()));
+    HIP_TRY(c, c->d_patch_s1.resize(recs.size()));
+    HIP_TRY(c, c->d_patch_s2.resize(recs.size()));
+    HIP_TRY(c, hipMemcpyAsync(c->d_patch_idx.p, recs.data(), recs.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ls));
+    hipLaunchKernelGGL(locate_records_kernel, dim3((unsigned)((recs.size() + 63) / 64)), dim3(64), 0, ls, c->d_patch_idx.p,
+                       (uint64_t)recs.size(), base, c->d_row_off.p, c->d_item_off.p, c->d_items.p, (uint32_t)c->n_sites,
+                       c->d_patch_s1.p, c->d_patch_s2.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(loc_s1.data(), c->d_patch_s1.p, recs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
+    HIP_TRY(c, hipMemcpyAsync(loc_s2.data(), c->d_patch_s2.p, recs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
+    HIP_TRY(c, hipStreamSynchronize(ls));
+  } else {
+    for (size_t k = 0; k < recs.size(); ++k)
+      if (!locate_record(c, base + recs[k], &loc_s1[k], &loc_s2[k])) loc_s1[k] = loc_s2[k] = 0xffffffffu;
+  }
+  for (size_t k = 0; k < recs.size(); ++k)
+    if (loc_s1[k] == 0xffffffffu || loc_s2[k] == 0xffffffffu) return fail(c, NGSLD_ERR_INVALID, "exact-order replay failed");
+  const bool ext = (h_std != nullptr ? (void *)h_ext : (void *)d_ext) != nullptr;
+  std::vector<ngsld_rec_std> out_std(recs.size());
+  std::vector<ngsld_rec_ext> out_ext(ext ? recs.size() : 0);
+  const int rcp = replay_pairs_on_host(c, loc_s1.data(), loc_s2.data(), recs.size(), out_std.data(), ext ? out_ext.data() : nullptr);
+  if (rcp != NGSLD_OK) return rcp;
+  if (sites1) *sites1 = loc_s1;  // (the pairs' sites, for callers that format the replayed rows again)
+  if (sites2) *sites2 = loc_s2;
   c->replayed_pairs += recs.size();
   c->host_replayed_total += recs.size();
   if (h_std != nullptr) {
@@ -316,6 +328,43 @@ int replay_flagged(ngsld_ctx *c, const std::vector<uint64_t> &recs, uint64_t bas
                      (uint64_t)recs.size(), c->d_patch_std.p, ext ? c->d_patch_ext.p : nullptr, d_std, ext ? d_ext : nullptr);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(st));  // the pageable source vectors go out of scope
+  return NGSLD_OK;
+}
+
+// Text batches: which pair each record the batch leaves to the host is, and where its row lies in the batch's text -- written
+// into pinned host memory right behind the batch's row lengths and prefix sums, on the pair kernel's stream.  With it the host
+// settles such a batch without submitting anything to the device (engine_run.hip): the kernels that located the pairs, patched
+// the records, took the rows' lengths again and wrote the text again stood -- in a hardware queue shared with the compute
+// streams -- behind the pair kernels of the next two batches, and the loop ran dry behind them (GPU_MAX_HW_QUEUES=1 / 2:
+// 0.67-0.69 s for configs[2]'s loop against 0.556, profiles/r05/hw_queues_ab.txt).
+__global__ void flag_rows_to_host_kernel(const uint32_t *flags, uint32_t cap, int dev_applied, const uint64_t *offs, const uint64_t *lens,
+                                         uint64_t n_records, uint64_t base, const uint64_t *row_off, const uint64_t *item_off, const Item *items,
+                                         uint32_t n_sites, FlagRow *rows) {
+  // (flags[7]: called genotypes, the launch overflowed its list and the device took all of it -- flagged_records)
+  const bool host_list = dev_applied != 0 || flags[7] != 0;
+  const uint32_t n = host_list ? flags[1] : flags[0];
+  if (n > kFlagRowsCap || n > (host_list ? kFlagHostCap : cap)) return;
+  const uint64_t *list = reinterpret_cast<const uint64_t *>(flags + kFlagListAt + (host_list ? 2u * cap : 0u));
+  for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+    FlagRow r{};
+    r.rec = list[j] & kFlagIndexMask;
+    r.s1 = r.s2 = 0xffffffffu;
+    if (r.rec < n_records) {
+      r.off = offs[r.rec];
+      r.len = (uint32_t)lens[r.rec];
+      locate_record_on_device(base + r.rec, row_off, item_off, items, n_sites, &r.s1, &r.s2);
+    }
+    rows[j] = r;
+  }
+}
+
+int send_flag_rows(ngsld_ctx *c, const uint32_t *d_flags, uint32_t cap, bool dev_applied, const uint64_t *d_offs, const uint64_t *d_lens,
+                   uint64_t n_records, uint64_t base, FlagRow *h_rows, hipStream_t st) {
+  FlagRow *dev_view = nullptr;
+  HIP_TRY(c, hipHostGetDevicePointer((void **)&dev_view, h_rows, 0));
+  hipLaunchKernelGGL(flag_rows_to_host_kernel, dim3(1), dim3(64), 0, st, d_flags, cap, dev_applied ? 1 : 0, d_offs, d_lens, n_records, base,
+                     c->d_row_off.p, c->d_item_off.p, c->d_items.p, (uint32_t)c->n_sites, dev_view);
+  HIP_TRY(c, hipGetLastError());
   return NGSLD_OK;
 }
 
@@ -480,6 +529,8 @@ int ensure_exact_store(ngsld_ctx *c) {
   } else {
     (void)hipStreamSynchronize(st);
   }
+  c->h_xstage[0].release();  // (64 MB of pinned host memory, used once per matrix)
+  c->h_xstage[1].release();
   if (rc != NGSLD_OK) return rc;
   c->exact_alias = false;
   c->exact_ready = true;
@@ -707,6 +758,7 @@ int ngsld_replay_info(ngsld_ctx *c, ngsld_replay_stats_t *out) {
   out->pairs_on_host = c->replayed_pairs - c->replayed_on_device;
   out->sites_reevaluated = c->replayed_sites;
   out->exact_store = c->exact_ready ? (c->exact_alias ? 1 : 2) : 0;
+  out->text_rows_patched = (int32_t)std::min<uint64_t>(c->text_rows_patched, 0x7fffffffull);
   out->exact_store_build_s = c->exact_build_s;
   return NGSLD_OK;
 }

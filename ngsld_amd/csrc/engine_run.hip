@@ -2,6 +2,7 @@
 // device-side TSV -> sink (replaces threadpool_add(calc_pair_LD) ... threadpool_wait and the fprintf block,
 // ngsLD.cpp:153-198, 310-352).
 #include "engine.h"
+#include "../../include/ngsld_host.h"
 
 namespace ngsld {
 namespace eng {
@@ -128,6 +129,7 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
   c->replayed_pairs = 0;
   c->replayed_on_device = 0;
   c->flagged_pairs = 0;
+  c->text_rows_patched = 0;
   if (c->replay_on) {
     c->flag_cap_dev = flag_cap_for(c->timed_pairs);
     const int rcf = reset_flags(c, c->d_flags_dev, c->timed_pairs, c->flag_cap_dev, st);
@@ -205,6 +207,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   c->replayed_pairs = 0;
   c->replayed_on_device = 0;
   c->flagged_pairs = 0;
+  c->text_rows_patched = 0;
   const bool replay = c->replay_on;
   if (c->reserve_thread.joinable()) c->reserve_thread.join();  // (ngsld_reserve_text_buffers: h_text[] is this thread's again)
 
@@ -337,6 +340,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       c->flag_cap[k] = flag_cap_for(cap);
       HIP_TRY(c, c->d_flags[k].resize(flag_words(cap, c->flag_cap[k])));
       HIP_TRY(c, c->h_flags[k].resize(flag_head_words(c->flag_cap[k])));
+      if (text) HIP_TRY(c, c->h_flag_rows[k].resize(kFlagRowsCap));
     }
   }
   // (run_direct: the device addresses of the pinned host buffers -- the same numbers under unified addressing, asked for anyway)
@@ -430,6 +434,11 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       // carries nothing but the D2H copies (SDMA).  A batch whose records are patched afterwards (host replay) or that
       // outgrows the buffer is written again when consumed.
       t.text_cap = c->d_text[k].n;
+      if (replay) {  // (the pairs left to the host: which they are, where their rows lie -- see consume)
+        const int rcw = send_flag_rows(c, c->d_flags[k].p, c->flag_cap[k], c->slot_dev_applied[k], c->d_offs[k].p, c->d_lens[k].p, b.n,
+                                       c->h_row_off[b.r0], c->h_flag_rows[k].p, st);
+        if (rcw != NGSLD_OK) return rcw;
+      }
       HIP_TRY(c, hipEventRecord(c->ev_scan_done[k], st));
       HIP_TRY(c, hipStreamWaitEvent(c->text_stream, c->ev_scan_done[k], 0));
       HIP_TRY(c, launch_text_write(t, c->text_stream));
@@ -450,10 +459,143 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     HIP_TRY(c, hipEventRecord(c->ev_copy_done[k], c->copy_stream));
     return NGSLD_OK;
   };
-  int rc = NGSLD_OK;
-  const bool trace = std::getenv("NGSLD_TRACE") != nullptr;  // dev: per-batch host timeline on stderr
   const auto t_run = std::chrono::steady_clock::now();
   auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run).count(); };
+  // ---- what consuming a text batch is made of (see the loop below) ----
+  const bool host_patch_on = [] {
+    const char *e = std::getenv("NGSLD_TEXT_HOST_PATCH");  // A/B: 0 = the replayed rows through the device again, as up to round 5
+    return e == nullptr || std::strcmp(e, "0") != 0;
+  }();
+  std::vector<ngsld_rec_std> hp_std;
+  std::vector<ngsld_rec_ext> hp_ext;
+  std::vector<uint32_t> hp_row;  // recs[j]'s entry of the slot's h_flag_rows
+  auto batch_needs_host = [&](int k, size_t bi) -> bool {  // a value beyond the device formatter's fast path: the batch goes out as records
+    bool needs_host = (c->h_text_meta[k].p[1] & 0xffffffffull) != 0;
+    if (const char *e = std::getenv("NGSLD_TEXT_FALLBACK_EVERY")) {  // tests: every n-th batch takes the record path
+      const uint64_t every = std::strtoull(e, nullptr, 10);
+      if (every > 0 && bi % every == every - 1) needs_host = true;
+    }
+    return needs_host;
+  };
+  // recs' entries among what send_flag_rows wrote for the slot (the same list, the same bound as the kernel's): rep_s1 / rep_s2 /
+  // hp_row filled; false when the batch left more pairs than the kernel writes, or one is not there
+  auto find_flag_rows = [&](int k, bool applied) -> bool {
+    const uint32_t *hd = c->h_flags[k].p;
+    const bool host_list = applied || hd[7] != 0;
+    const uint32_t n = host_list ? hd[1] : hd[0];
+    if (n > kFlagRowsCap || n > (host_list ? kFlagHostCap : c->flag_cap[k]) || recs.size() > n) return false;
+    const FlagRow *rows = c->h_flag_rows[k].p;
+    rep_s1.resize(recs.size());
+    rep_s2.resize(recs.size());
+    hp_row.resize(recs.size());
+    for (size_t j = 0; j < recs.size(); ++j) {
+      uint32_t at = n;
+      for (uint32_t q = 0; q < n; ++q)
+        if (rows[q].rec == recs[j]) { at = q; break; }
+      if (at == n || rows[at].s1 >= c->n_sites || rows[at].s2 >= c->n_sites) return false;
+      hp_row[j] = at;
+      rep_s1[j] = rows[at].s1;
+      rep_s2[j] = rows[at].s2;
+    }
+    return true;
+  };
+  // the replayed records' value columns over the old ones in the text the host holds; false: a row has another length now (or
+  // is not where it should be) -- the caller takes the device's way
+  uint64_t patch_fail_every = 0;  // tests: every n-th patched batch pretends its last row changed length (the fallback's way out)
+  if (const char *e = std::getenv("NGSLD_TEXT_HOST_PATCH_FAIL_EVERY")) patch_fail_every = std::strtoull(e, nullptr, 10);
+  uint64_t patched_batches = 0;
+  auto apply_host_patch = [&](int k) -> bool {
+    const uint64_t total = c->h_text_meta[k].p[0];
+    const bool pretend = patch_fail_every != 0 && ++patched_batches % patch_fail_every == 0;
+    char *text_p = c->h_text[k].p;
+    const int tabs = ext ? 16 : 4;  // the columns behind `dist` (ngsLD.cpp:314-351): labels may hold tabs of their own, values never
+    char buf[2048];
+    for (size_t j = 0; j < recs.size(); ++j) {
+      const FlagRow &r = c->h_flag_rows[k].p[hp_row[j]];
+      if (r.len < 2 || r.off + r.len > total || text_p[r.off + r.len - 1] != '\n') return false;
+      char *row = text_p + r.off;
+      uint32_t at = r.len;
+      for (int seen = 0; at > 0 && seen < tabs;)
+        if (row[--at] == '\t') ++seen;
+      if (row[at] != '\t') return false;
+      const size_t m = ngsld_host_format_pair(buf, sizeof(buf), "", "", 0.0, &hp_std[j], ext ? &hp_ext[j] : nullptr, c->h_maf[rep_s1[j]],
+                                              c->h_maf[rep_s2[j]]);
+      if (m < 4 || m - 3 != (size_t)(r.len - at)) return false;  // ("\t\t0" stands for the labels and dist)
+      if (pretend && j + 1 == recs.size()) return false;
+      std::memcpy(row + at, buf + 3, m - 3);
+    }
+    return true;
+  };
+  auto device_patch = [&](int k, const Batch &b, bool &rewrite) -> int {
+    // flagged pairs: replayed on the host, patched into the device records, and the row lengths derived again --
+    // all on the copy stream, beside the next batch's pair kernel
+    int rcr = replay_flagged(c, recs, c->h_row_off[b.r0], nullptr, nullptr, c->d_std[k].p, ext ? c->d_ext[k].p : nullptr,
+                           c->copy_stream, &rep_s1, &rep_s2);
+    if (rcr != NGSLD_OK) return rcr;
+    // Only the replayed rows' lengths are derived again (replay_flagged left their record indices in d_patch_idx); the
+    // prefix sums are taken again only if one of them changed -- a full length pass + scan beside the next batch's pair
+    // kernel cost that kernel ~1 ms of every 11 (profiles/r04/e2e_timeline.txt)
+    if (!recs.empty()) {
+      rewrite = true;
+      HIP_TRY(c, c->d_patch_s1.resize(recs.size()));
+      HIP_TRY(c, c->d_patch_s2.resize(recs.size()));
+      HIP_TRY(c, hipMemcpyAsync(c->d_patch_s1.p, rep_s1.data(), recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
+      HIP_TRY(c, hipMemcpyAsync(c->d_patch_s2.p, rep_s2.data(), recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
+      HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p + 2, 0, sizeof(uint64_t), c->copy_stream));
+      const TextArgs t = text_args(b, k);
+      HIP_TRY(c, launch_text_relength(t, c->d_patch_idx.p, c->d_patch_s1.p, c->d_patch_s2.p, recs.size(), c->d_text_meta[k].p + 2,
+                                      c->copy_stream));
+      HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                c->copy_stream));
+      HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+      if (c->h_text_meta[k].p[2] != 0) {
+        HIP_TRY(c, text_scan(c->d_scan_tmp2.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n, c->d_text_meta[k].p, c->copy_stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                  c->copy_stream));
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+      }
+    }
+    return NGSLD_OK;
+  };
+  auto finish_text = [&](int k, size_t bi, const Batch &b, bool &rewrite, bool &as_records, ngsld_batch &out, double &t_wr) -> int {
+    const uint64_t total = c->h_text_meta[k].p[0];
+    if (batch_needs_host(k, bi)) {
+      as_records = true;  // a value beyond the device formatter's fast path: this batch goes out as records
+      HIP_TRY(c, c->h_std[k].resize(cap));
+      if (ext) HIP_TRY(c, c->h_ext[k].resize(cap));
+      if (b.n) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, c->d_std[k].p, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost,
+                                  c->copy_stream));
+        if (ext)
+          HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, c->d_ext[k].p, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost,
+                                    c->copy_stream));
+      }
+      HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+      const int rc1 = need_host_items();
+      if (rc1 != NGSLD_OK) return rc1;
+    } else {
+      if (total > c->d_text[k].n) {
+        HIP_TRY(c, c->d_text[k].resize(total + total / 8));
+        rewrite = true;
+      }
+      if (c->h_text_meta[k].p[3] != 0) rewrite = true;  // (the early write pass ran out of room)
+      if (total > c->h_text[k].n) HIP_TRY(c, c->h_text[k].resize(total + total / 8));
+      if (total) {
+        if (rewrite) {
+          const TextArgs t = text_args(b, k);
+          HIP_TRY(c, launch_text_write(t, c->copy_stream));
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->h_text[k].p, c->d_text[k].p, total, hipMemcpyDeviceToHost, c->copy_stream));
+      }
+      HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+      t_wr = now_ms();
+      out.text = c->h_text[k].p;
+      out.text_len = total;
+    }
+    return NGSLD_OK;
+  };
+  int rc = NGSLD_OK;
+  const bool trace = std::getenv("NGSLD_TRACE") != nullptr;  // dev: per-batch host timeline on stderr
   // S - 1 batches are in flight while one is consumed: the slot of batch bi + S - 1 was last used by batch bi - 1, whose
   // sink call has returned
   for (size_t bi = 0; rc == NGSLD_OK && bi + 1 < (size_t)S && bi < batches.size(); ++bi) rc = issue(bi);
@@ -480,6 +622,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       HIP_TRY(c, hipEventSynchronize(c->ev_kernel_done[k]));
       t_ev = now_ms();
       bool rewrite = false;  // the rows the issue wrote are stale: records were patched since
+      bool host_patch = false;  // the host's pairs go into the text the host holds (below)
       if (replay) c->flagged_pairs += c->h_flags[k].p[0];
       if (replay && c->h_flags[k].p[0] != 0) {
         bool applied = c->slot_dev_applied[k];
@@ -501,75 +644,36 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
             rewrite = true;
           }
         }
-        // flagged pairs: replayed on the host, patched into the device records, and the row lengths derived again --
-        // all on the copy stream, beside the next batch's pair kernel
         int rcr = flagged_records(c, c->h_flags[k].p, c->d_flags[k].p, c->flag_cap[k], b.n, recs, applied);
-        if (rcr == NGSLD_OK)
-          rcr = replay_flagged(c, recs, c->h_row_off[b.r0], nullptr, nullptr, c->d_std[k].p, ext ? c->d_ext[k].p : nullptr,
-                               c->copy_stream, &rep_s1, &rep_s2);
         if (rcr != NGSLD_OK) return rcr;
-        // Only the replayed rows' lengths are derived again (replay_flagged left their record indices in d_patch_idx); the
-        // prefix sums are taken again only if one of them changed -- a full length pass + scan beside the next batch's pair
-        // kernel cost that kernel ~1 ms of every 11 (profiles/r04/e2e_timeline.txt)
-        if (!recs.empty()) {
-          rewrite = true;
-          HIP_TRY(c, c->d_patch_s1.resize(recs.size()));
-          HIP_TRY(c, c->d_patch_s2.resize(recs.size()));
-          HIP_TRY(c, hipMemcpyAsync(c->d_patch_s1.p, rep_s1.data(), recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
-          HIP_TRY(c, hipMemcpyAsync(c->d_patch_s2.p, rep_s2.data(), recs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->copy_stream));
-          HIP_TRY(c, hipMemsetAsync(c->d_text_meta[k].p + 2, 0, sizeof(uint64_t), c->copy_stream));
-          const TextArgs t = text_args(b, k);
-          HIP_TRY(c, launch_text_relength(t, c->d_patch_idx.p, c->d_patch_s1.p, c->d_patch_s2.p, recs.size(), c->d_text_meta[k].p + 2,
-                                          c->copy_stream));
-          HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                                    c->copy_stream));
-          HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
-          if (c->h_text_meta[k].p[2] != 0) {
-            HIP_TRY(c, text_scan(c->d_scan_tmp2.p, scan_bytes, c->d_lens[k].p, c->d_offs[k].p, b.n, c->d_text_meta[k].p, c->copy_stream));
-            HIP_TRY(c, hipMemcpyAsync(c->h_text_meta[k].p, c->d_text_meta[k].p, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                                      c->copy_stream));
-            HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
-          }
+        // The pairs left to the host (the headline's few dozen, a batch's host-only pairs behind a device-side replay): replayed
+        // on the host's threads and written over their rows' value columns in the text the host receives -- send_flag_rows told
+        // which pairs they are and where their rows lie, so NOTHING is submitted to the device here.  (Rounds 1-5 located them,
+        // patched the device's records, took the rows' lengths again and wrote the batch's text again -- kernels that, in a
+        // hardware queue shared with the compute streams, stood behind the pair kernels of the next two batches.)
+        host_patch = host_patch_on && !recs.empty() && !rewrite && applied == c->slot_dev_applied[k] && !batch_needs_host(k, bi) &&
+                     c->h_text_meta[k].p[3] == 0 && c->h_text_meta[k].p[0] <= c->d_text[k].n && find_flag_rows(k, applied);
+        if (host_patch) {
+          hp_std.resize(recs.size());
+          hp_ext.resize(ext ? recs.size() : 0);
+          rcr = replay_pairs_on_host(c, rep_s1.data(), rep_s2.data(), recs.size(), hp_std.data(), ext ? hp_ext.data() : nullptr);
+        } else {
+          rcr = device_patch(k, b, rewrite);
         }
+        if (rcr != NGSLD_OK) return rcr;
       }
-      const uint64_t total = c->h_text_meta[k].p[0];
-      bool needs_host = (c->h_text_meta[k].p[1] & 0xffffffffull) != 0;
-      if (const char *e = std::getenv("NGSLD_TEXT_FALLBACK_EVERY")) {  // tests: every n-th batch takes the record path
-        const uint64_t every = std::strtoull(e, nullptr, 10);
-        if (every > 0 && bi % every == every - 1) needs_host = true;
-      }
-      if (needs_host) {
-        as_records = true;  // a value beyond the device formatter's fast path: this batch goes out as records
-        HIP_TRY(c, c->h_std[k].resize(cap));
-        if (ext) HIP_TRY(c, c->h_ext[k].resize(cap));
-        if (b.n) {
-          HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, c->d_std[k].p, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost,
-                                    c->copy_stream));
-          if (ext)
-            HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, c->d_ext[k].p, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost,
-                                      c->copy_stream));
+      int rcf = finish_text(k, bi, b, rewrite, as_records, out, t_wr);
+      if (rcf != NGSLD_OK) return rcf;
+      if (host_patch) {
+        if (!as_records && apply_host_patch(k)) {
+          c->replayed_pairs += recs.size();
+          c->host_replayed_total += recs.size();
+          c->text_rows_patched += recs.size();
+        } else {  // (a replayed row of another length -- once in a few thousand replays: the device's way, the text copied again)
+          rcf = device_patch(k, b, rewrite);
+          if (rcf == NGSLD_OK) rcf = finish_text(k, bi, b, rewrite, as_records, out, t_wr);
+          if (rcf != NGSLD_OK) return rcf;
         }
-        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
-        const int rc1 = need_host_items();
-        if (rc1 != NGSLD_OK) return rc1;
-      } else {
-        if (total > c->d_text[k].n) {
-          HIP_TRY(c, c->d_text[k].resize(total + total / 8));
-          rewrite = true;
-        }
-        if (c->h_text_meta[k].p[3] != 0) rewrite = true;  // (the early write pass ran out of room)
-        if (total > c->h_text[k].n) HIP_TRY(c, c->h_text[k].resize(total + total / 8));
-        if (total) {
-          if (rewrite) {
-            const TextArgs t = text_args(b, k);
-            HIP_TRY(c, launch_text_write(t, c->copy_stream));
-          }
-          HIP_TRY(c, hipMemcpyAsync(c->h_text[k].p, c->d_text[k].p, total, hipMemcpyDeviceToHost, c->copy_stream));
-        }
-        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
-        t_wr = now_ms();
-        out.text = c->h_text[k].p;
-        out.text_len = total;
       }
     } else {
       HIP_TRY(c, hipEventSynchronize(direct ? c->ev_kernel_done[k] : c->ev_copy_done[k]));

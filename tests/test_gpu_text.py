@@ -108,3 +108,59 @@ def test_cli_gz_output_is_the_plain_output_compressed(tmp_path):
         with gzip.open(out, "rb") as fh:
             assert fh.read() == want, tag
         assert os.path.getsize(out) < len(want) // 2
+
+
+def _text_run(eng, raw, pd, labels, **plan):
+    eng.set_geno_raw(raw)
+    eng.set_pos_dist(pd)
+    eng.plan(**plan)
+    eng.set_text_output(labels)
+    try:
+        text, fallbacks = eng.run_text()
+    finally:
+        eng.set_text_output(None, enable=False)
+    return text, fallbacks, eng.replay_info()
+
+
+@pytest.mark.parametrize("extend", [False, True])
+def test_host_replayed_rows_are_overwritten_in_the_hosts_text(monkeypatch, extend):
+    """The pairs a text batch leaves to the host's exact-order replay (engine_run.hip: send_flag_rows / apply_host_patch): their
+    rows' value columns are overwritten in the text the host has received -- nothing goes back to the device.  The text is the
+    one the device's way gives (NGSLD_TEXT_HOST_PATCH=0: records patched on the device, the batch written again), also when a
+    patched batch falls back to that way half-way through (NGSLD_TEXT_HOST_PATCH_FAIL_EVERY), with labels that hold TABs."""
+    n_sites, n_ind = 500, 50
+    raw = synth.make_gl_numpy(n_sites, n_ind, 123, depth=2.0, mono_frac=0.1)
+    chrs, pos = synth.make_positions(n_sites, 123, n_chr=2)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    labels = [f"{c}:{q}" + ("\tid\t%d" % k if k % 5 == 0 else "") for k, (c, q) in enumerate(zip(chrs, pos))]
+    plan = dict(max_kb_dist=0, extend_out=extend)
+    eng = capi.Engine(0)
+    try:
+        eng.set_exact_store(0)            # (every flagged pair is the host's)
+        eng.set_tuning(batch_pairs=3000)
+        monkeypatch.setenv("NGSLD_TEXT_HOST_PATCH", "0")
+        want, fb0, info0 = _text_run(eng, raw, pd, labels, **plan)
+        monkeypatch.delenv("NGSLD_TEXT_HOST_PATCH")
+        got, fb1, info1 = _text_run(eng, raw, pd, labels, **plan)
+        monkeypatch.setenv("NGSLD_TEXT_HOST_PATCH_FAIL_EVERY", "2")
+        half, fb2, info2 = _text_run(eng, raw, pd, labels, **plan)
+        monkeypatch.delenv("NGSLD_TEXT_HOST_PATCH_FAIL_EVERY")
+        assert fb0 == fb1 == fb2 == 0
+        assert info0["pairs_on_host"] > 50 and info0["text_rows_patched"] == 0
+        # (a batch that leaves the host more than 256 pairs -- kFlagRowsCap -- goes the device's way)
+        assert info1["pairs_on_host"] == info0["pairs_on_host"] and 1000 < info1["text_rows_patched"] <= info1["pairs_on_host"]
+        assert 0 < info2["text_rows_patched"] < info1["text_rows_patched"] and info2["pairs_on_host"] == info0["pairs_on_host"]
+        assert got == want and half == want
+        # ... and the rows are the host formatter's over the replayed records
+        maf = eng.maf()
+        s1, s2, std, ext = eng.run()
+    finally:
+        eng.close()
+    rows = got.split(b"\n")
+    assert len(rows) - 1 == len(s1)
+    for k in range(0, len(s1), 37):
+        a, b = int(s1[k]), int(s2[k])
+        dist = float(np.sum(pd[a + 1:b + 1]))
+        assert rows[k] + b"\n" == capi.format_pair(labels[a], labels[b], dist, std[k], ext[k] if extend else None, maf[a], maf[b]).encode()
+    print(f"text rows overwritten in the host's text: {info1['text_rows_patched']} of {len(s1)} pairs; with every second patched batch "
+          f"falling back {info2['text_rows_patched']}")
