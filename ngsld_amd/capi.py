@@ -288,13 +288,13 @@ def device_memory(device: int = 0) -> tuple[int, int]:
 
 
 def run_streamed(read_sites, n_sites: int, n_ind: int, pos_dist: np.ndarray | None, max_slab_sites: int, device: int = 0,
-                 log_scale: bool = False, call_geno: tuple[float, float] | None = None, **kw):
+                 log_scale: bool = False, call_geno: tuple[float, float] | None = None, text: bool = False, **kw):
     """The whole job slab by slab (ngsld_run_streamed).  read_sites(site_begin, n) -> array [n, n_ind, 3] of raw values.
     Returns (s1, s2, std, ext, maf, n_slabs) with global site indices."""
     L = lib()
     pd = None if pos_dist is None else np.ascontiguousarray(pos_dist, dtype=np.float64)
     p = _params(**kw)
-    o = GenoOpts(int(log_scale), p.ignore_miss_data, 0, 0, int(call_geno is not None), 0,
+    o = GenoOpts(int(log_scale), p.ignore_miss_data, 0, int(text), int(call_geno is not None), 0,
                  call_geno[0] if call_geno else 0.0, call_geno[1] if call_geno else 0.0)
     s1s, s2s, stds, exts = [], [], [], []
 

@@ -181,9 +181,12 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
         // 0) leaves every triple either called or "no data" (gen_func.cpp:886-914: below N_thresh -> missing, at or
         // above call_thresh -> called, nothing in between), so every slab qualifies, as the resident run does.
         // "Every slab qualifies" is checked, not assumed: a triple the classification rejects after all (a NaN under text
-        // semantics sets no NaN status) would put ONE slab on the per-individual kernels.  The first slab fixes the job's
-        // family; if it does not qualify, every later slab is told to stay per individual too; a later slab that disagrees
-        // with a first slab that did qualify ends the job with an error (its predecessors' records are already out).
+        // semantics sets no NaN status) puts ITS slab on the per-individual kernels.  The first slab fixes the job's family;
+        // if it does not qualify, every later slab is told to stay per individual too.  A later slab that disagrees with a
+        // first slab that did qualify -- its predecessors' rows are out already -- is loaded again for the per-individual
+        // kernels, and so are the slabs after it: their records are the ones the resident run would give (which runs per
+        // individual as a whole, holding that triple), the earlier slabs' agree with them to 1e-12 instead of bit for bit.
+        // (Up to round 5 such a job ended with an error and a truncated table.)
         ngsld_geno_opts so = *opts;
         if (!(opts->call_geno && opts->N_thresh == opts->call_thresh) || hard_job == 0) so.per_individual_only = 1;
         r = ngsld_set_geno_raw_opts(ctx[b], host[b].data(), m, n_ind, &so);
@@ -192,9 +195,9 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
           if (hard_job < 0) {
             hard_job = is_hard ? 1 : 0;
           } else if (hard_job == 1 && !is_hard) {
-            r = NGSLD_ERR_INVALID;
-            msg = "a slab of this --call_geno job holds a likelihood triple that is neither a called genotype nor missing data "
-                  "(NaN?), after earlier slabs ran on the genotype-combination kernel: rerun with NGSLD_HARD_KERNEL=0";
+            hard_job = 0;
+            so.per_individual_only = 1;
+            r = ngsld_set_geno_raw_opts(ctx[b], host[b].data(), m, n_ind, &so);
           }
         }
         // exact-order replay: the slab's raw values stay in host[b] until its run is over

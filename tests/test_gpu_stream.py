@@ -102,6 +102,33 @@ def test_streamed_called_genotypes_keep_the_resident_kernel(engine, thresholds, 
     _same(got, want)
 
 
+def test_a_later_slab_that_is_not_all_called_goes_on_per_individual(engine):
+    """A --call_geno job whose first slabs ran on the genotype-combination kernel and whose LATER slab holds a triple that is
+    neither called nor missing (a NaN from a text file sets no NaN status): that slab and the ones after it are loaded again for
+    the per-individual kernels and the job completes (up to round 5 it ended with an error behind a truncated table).  The
+    resident run holds that triple and runs per individual as a whole: the same pairs, the same nIter / sample_size, every value
+    within 1e-9 -- bit for bit from the disagreeing slab on."""
+    n_sites, n_ind = 1200, 40
+    raw = synth.make_gl_numpy(n_sites, n_ind, 61, depth=3.0)
+    raw[900, 7, :] = np.nan
+    chrs, pos = synth.make_positions(n_sites, 61)
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    engine.set_geno_raw(raw, text=True, call_geno=(0.0, 0.0))
+    assert engine.pair_kernel() != "hard"
+    engine.set_pos_dist(pd)
+    engine.plan(max_kb_dist=3)
+    want = engine.run()
+    got = capi.run_streamed(lambda b, m: raw[b:b + m], n_sites, n_ind, pd, 200, call_geno=(0.0, 0.0), text=True, max_kb_dist=3)
+    assert got[5] >= 5 and len(got[0]) == len(want[0]) > 10000
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(got[3]["n_iter"], want[3]["n_iter"]) and np.array_equal(got[3]["n_ind_data"], want[3]["n_ind_data"])
+    for f in ("r2_ExpG", "D", "Dp", "r2"):
+        a, b = got[2][f], want[2][f]
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.all((np.abs(a - b) <= 1e-9) | (a == b) | np.isnan(a)), f
+    late = got[0] >= 1000                                     # (rows of the slabs behind the disagreeing one)
+    assert late.sum() > 1000 and got[2][late].tobytes() == want[2][late].tobytes()
+
+
 def test_streamed_errors(engine):
     n_sites, n_ind = 300, 12
     raw = synth.make_gl_numpy(n_sites, n_ind, 43, depth=4.0)
