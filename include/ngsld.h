@@ -218,9 +218,12 @@ int ngsld_replay_stats(ngsld_ctx *ctx, uint64_t *pairs, uint64_t *sites);
  * device memory, normal-space likelihoods and est_maf as the reference holds them when calc_pair_LD runs, i.e. through the
  * HOST's libm.  Data given through ngsld_set_geno_lkl is that already (nothing is built, the replay is on the device from the
  * first pair on); without a replay source the device's own prepped values serve (the replay then runs on the device's
- * exp / log rounding, as the host's did); with a source the store is built by the replay threads from the caller's raw
- * values -- 17 libm calls per triple, ~0.25 us per individual and site on one thread, once per matrix -- the first time a run
- * has flagged more pairs than the host should replay (more than half as many as the matrix has sites).
+ * exp / log rounding, as the host's did); with a source the store is built from the caller's raw values -- 17 libm calls per
+ * triple, ~0.25 us per individual and site on one thread, once per matrix -- the first time a run has flagged more pairs than
+ * the host should replay (more than half as many as the matrix has sites).  The build runs on threads of its own BESIDE the
+ * ngsld_run that asked for it, in site order: a batch's replay waits only until the builder has passed the batch's last
+ * window; the run returns when the build has ended (the source is read during runs only).  ngsld_finish_device builds it
+ * before it replays.
  * mode: 0 never (host replay only), 1 as described (default), 2 build at the first flagged pair. */
 int ngsld_set_exact_store(ngsld_ctx *ctx, int mode);
 typedef struct {

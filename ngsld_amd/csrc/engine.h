@@ -12,6 +12,7 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -365,7 +366,7 @@ struct ngsld_ctx {
   // should replay (exact_store_wanted), and kept until the matrix or its source changes.
   DevBuf<double> d_xplanes, d_xmaf;
   DevBuf<double> d_xT;                 // the store once more, individual-major, for the lane-per-pair kernel (ld_replay_lkl.hip)
-  bool xT_ready = false;
+  std::atomic<bool> xT_ready{false};
   struct LaneScratch {   // what the lane-per-pair replay of one launch needs: the located pairs and their sorted order
     DevBuf<ReplayEntry> list;
     DevBuf<uint64_t> keys_a, keys_b;
@@ -374,7 +375,21 @@ struct ngsld_ctx {
     void release() { list.release(); keys_a.release(); keys_b.release(); vals_a.release(); vals_b.release(); temp.release(); }
   } lane_scratch[kSlots], lane_scratch_dev;  // per pipeline slot / for ngsld_run_device
   PinBuf<double> h_xstage[2];
-  bool exact_ready = false, exact_alias = false;
+  // A store that has to be BUILT is built by a thread of its own, in site order, while the run that asked for it goes on: a
+  // launch's device-side replay needs the sites up to the end of its last row's window only (exact_frontier), and the build
+  // (~0.25 us per individual and site) stays ahead of the pipeline (pair kernel + replay of the rows of those sites).  A run
+  // that started the build waits for its end before it returns: the registered source is read during runs only.
+  std::thread exact_thread;
+  std::atomic<int> exact_state{0};          // 0 no store, 1 being built, 2 complete (every site + the lane kernel's copy where it fits), -1 the build failed
+  std::atomic<uint64_t> exact_frontier{0};  // sites [0, exact_frontier) of d_xplanes / d_xmaf are on the device
+  std::atomic<bool> exact_cancel{false};
+  std::mutex exact_mu;                      // exact_cv, exact_rc, exact_msg
+  std::condition_variable exact_cv;
+  int exact_rc = 0;
+  std::string exact_msg;
+  hipStream_t exact_stream = nullptr;       // the builder's uploads
+  ReplayPool exact_pool;                    // the builder's threads (replay_pool is the run's: host-only pairs beside the build)
+  bool exact_ready = false, exact_alias = false;  // exact_ready: the run's view -- complete, errors collected
   bool exact_failed = false;           // the device had no room for this matrix' store: host replay
   int exact_mode = 1;                  // NGSLD_EXACT_STORE / ngsld_set_exact_store: 0 never (host replay only), 1 when it pays (default), 2 at the first flagged pair
   double exact_build_s = 0.0;          // host seconds the store of this matrix took to build (0: an alias, or not built)
@@ -489,13 +504,27 @@ int flagged_records(ngsld_ctx *c, const uint32_t *h_head, const uint32_t *d_flag
 // likelihood matrices: can the flagged pairs of this context's runs be replayed on the device at all / right now?
 bool lkl_device_eligible(const ngsld_ctx *c);
 bool exact_store_is_free(const ngsld_ctx *c);
-int ensure_exact_store(ngsld_ctx *c);
+// the store there or on its way (device_replay_lkl may be asked for launches whose sites it covers)
+inline bool exact_store_started(const ngsld_ctx *c) { return c->exact_state.load() >= 1; }
+// starts the build where there is something to build (idempotent); the alias forms are complete at once
+int start_exact_store(ngsld_ctx *c);
+// waits until sites [0, need_sites) are on the device (need_sites >= n_sites: until the store is complete); *have = false when
+// there is no store to be had (no room on the device: host replay); an error of the build comes back as the return value
+int wait_exact_store(ngsld_ctx *c, uint64_t need_sites, bool *have);
+int ensure_exact_store(ngsld_ctx *c);  // start + wait for all of it
+void stop_exact_store(ngsld_ctx *c);   // the matrix or its source changes, the context goes: the builder is cancelled and joined
+// sites a launch over rows [r0, r1) reads: up to the furthest window end among its rows (a row a filter emptied ends at itself)
+inline uint64_t exact_sites_needed(const ngsld_ctx *c, uint64_t r0, uint64_t r1) {
+  uint64_t need = r1;
+  for (uint64_t r = r0; r < r1 && r < c->h_row_end.size(); ++r) need = std::max<uint64_t>(need, c->h_row_end[r]);
+  return std::min<uint64_t>(need, c->n_sites);
+}
 // should a run that has `pending` flagged pairs for the host build the store instead?
 bool exact_store_wanted(const ngsld_ctx *c, uint64_t pending);
 // flag_text: the launch's records become text (PairArgs::flag_text)
-// ensure_exact_store + device_replay_lkl; *applied says whether the replay was launched (false: no store to be had)
+// start + wait for the launch's sites + device_replay_lkl; *applied says whether the replay was launched (false: no store to be had)
 int try_device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
-                          ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text, int slot, bool *applied);
+                          ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text, int slot, bool *applied, uint64_t need_sites);
 // slot: the pipeline slot whose pair list the launch uses (-1: ngsld_run_device's)
 int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
                       ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text, int slot);

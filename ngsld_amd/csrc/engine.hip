@@ -27,6 +27,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
     const int rcp = finish_device_run(c);
     if (rcp != NGSLD_OK) return rcp;
   }
+  stop_exact_store(c);  // (the builder of the last matrix' exact store, if it is still at it)
   c->have_geno = false;
   c->planned = false;
   c->text_mode = false;  // labels belong to a matrix
@@ -253,8 +254,10 @@ int ngsld_create(int device, ngsld_ctx **out) {
 void ngsld_destroy(ngsld_ctx *c) {
   if (c == nullptr) return;
   if (c->reserve_thread.joinable()) c->reserve_thread.join();
+  stop_exact_store(c);
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  if (c->exact_stream) (void)hipStreamDestroy(c->exact_stream);
   c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_rsx.release(); c->d_sc4.release(); c->d_runs.release();
   c->d_hard_masks.release(); c->d_hard_u.release(); c->d_all_hard.release();
   c->d_xplanes.release(); c->d_xmaf.release(); c->d_xT.release(); c->h_xstage[0].release(); c->h_xstage[1].release();

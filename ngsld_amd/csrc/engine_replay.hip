@@ -420,136 +420,250 @@ bool exact_store_is_free(const ngsld_ctx *c) {
 // otherwise replay more pairs than half the matrix has sites.
 bool exact_store_wanted(const ngsld_ctx *c, uint64_t pending) {
   if (!lkl_device_eligible(c) || c->exact_failed) return false;
-  if (c->exact_ready || exact_store_is_free(c)) return pending > 0;
+  if (exact_store_started(c) || exact_store_is_free(c)) return pending > 0;
   if (c->exact_mode >= 2) return pending > 0;
   return c->host_replayed_total + pending > std::max<uint64_t>(4096, c->n_sites / 2);
 }
 
 // The individual-major copy for the lane-per-pair kernel, where the device has room for the matrix once more (NGSLD_REPLAY_LANES=0:
-// never -- the wavefront-per-pair kernel takes everything, as in the round's first sessions).
-static int build_lane_store(ngsld_ctx *c) {
+// never -- the wavefront-per-pair kernel takes everything, as in the round's first sessions).  On stream st, synchronised.
+static hipError_t build_lane_store(ngsld_ctx *c, hipStream_t st) {
   c->xT_ready = false;
   if (const char *e = std::getenv("NGSLD_REPLAY_LANES"))
-    if (std::strcmp(e, "0") == 0) return NGSLD_OK;
+    if (std::strcmp(e, "0") == 0) return hipSuccess;
   const size_t elems = (size_t)c->n_sites * c->n_ind * 3;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < elems * sizeof(double) + (4ull << 30)) {
     (void)hipGetLastError();
-    return NGSLD_OK;
+    return hipSuccess;
   }
   if (c->d_xT.resize(elems) != hipSuccess) {
     (void)hipGetLastError();
-    return NGSLD_OK;
+    return hipSuccess;
   }
-  hipStream_t st = replay_stream_of(c);
-  HIP_TRY(c, launch_transpose_store(c->exact_alias ? c->d_planes.p : c->d_xplanes.p, 3ull * c->np, c->np, (uint32_t)c->n_ind, c->n_sites,
-                                    c->d_xT.p, st));
-  HIP_TRY(c, hipStreamSynchronize(st));
+  hipError_t e = launch_transpose_store(c->exact_alias ? c->d_planes.p : c->d_xplanes.p, 3ull * c->np, c->np, (uint32_t)c->n_ind, c->n_sites,
+                                        c->d_xT.p, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
   c->xT_ready = true;
-  return NGSLD_OK;
+  return hipSuccess;
 }
 
-int ensure_exact_store(ngsld_ctx *c) {
-  if (c->exact_ready) return NGSLD_OK;
-  if (exact_store_is_free(c)) {
-    c->exact_alias = true;
-    c->exact_ready = true;
-    return build_lane_store(c);
-  }
+// The builder (ngsld_ctx::exact_thread): the registered source through the host's libm, chunk by chunk in site order -- two
+// pinned staging buffers, a chunk's upload beside the next chunk's arithmetic --, the frontier published as the uploads land;
+// then the lane kernel's copy.  Touches nothing of the context a run touches but the store's own buffers and atomics.
+static void exact_builder(ngsld_ctx *c) {
   Range range_("ngsld:exact store (host libm -> device)");
   const auto t0 = std::chrono::steady_clock::now();
-  const uint64_t n = c->n_sites, ni = c->n_ind, np = c->np, site_elems = 3 * np;
+  int rc = NGSLD_OK;
+  std::string msg;
+  auto hip_bad = [&](hipError_t e, const char *what) {
+    if (e == hipSuccess) return false;
+    (void)hipGetLastError();
+    rc = NGSLD_ERR_DEVICE;
+    msg = std::string(what) + ": " + hipGetErrorString(e);
+    return true;
+  };
+  try {
+    const uint64_t n = c->n_sites, ni = c->n_ind, np = c->np, site_elems = 3 * np;
+    uint64_t chunk = std::max<uint64_t>(1, (32ull << 20) / (site_elems * sizeof(double)));
+    uint64_t slow_us = 0;  // tests: small chunks, a builder the run has to wait for
+    if (const char *e = std::getenv("NGSLD_EXACT_CHUNK_SITES")) chunk = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+    if (const char *e = std::getenv("NGSLD_EXACT_SLOW_US")) slow_us = std::strtoull(e, nullptr, 10);
+    if (chunk > n) chunk = n;
+    struct Events {  // (destroyed on every way out)
+      hipEvent_t e[2] = {nullptr, nullptr};
+      ~Events() {
+        for (hipEvent_t x : e)
+          if (x) (void)hipEventDestroy(x);
+      }
+    } up;
+    bool ok = !hip_bad(hipSetDevice(c->device), "exact store");
+    if (ok && c->exact_stream == nullptr) ok = !hip_bad(hipStreamCreateWithFlags(&c->exact_stream, hipStreamNonBlocking), "exact store stream");
+    for (int k = 0; k < 2 && ok; ++k) {
+      ok = !hip_bad(c->h_xstage[k].resize((size_t)chunk * (site_elems + 1)), "exact store staging") &&  // (+ 1: the site's est_maf behind the planes)
+           !hip_bad(hipEventCreateWithFlags(&up.e[k], hipEventDisableTiming), "exact store event");
+    }
+    hipStream_t st = c->exact_stream;
+    const int T = c->replay_threads > 0 ? c->replay_threads : (int)std::min<unsigned>(32u, usable_threads());
+    std::vector<double> raw_chunk;  // (callback source: the chunk's raw values, fetched with one call)
+    uint64_t k = 0, prev_end = 0;
+    for (uint64_t s0 = 0; s0 < n && ok && !c->exact_cancel.load(); s0 += chunk, ++k) {
+      const int b = (int)(k & 1);
+      const uint64_t m = std::min(chunk, n - s0);
+      // (buffer b was last read by the upload of chunk k - 2, whose event was waited for when chunk k - 1 was issued)
+      const double *raw = nullptr;
+      if (c->replay_matrix != nullptr) {
+        raw = c->replay_matrix + s0 * 3 * ni;
+      } else {
+        raw_chunk.resize((size_t)m * 3 * ni);
+        std::lock_guard<std::mutex> g(c->replay_mu);
+        if (c->replay_read(c->replay_user, s0, m, raw_chunk.data()) != 0) {
+          rc = NGSLD_ERR_SINK;
+          msg = "the replay source callback failed";
+          ok = false;
+          break;
+        }
+        raw = raw_chunk.data();
+      }
+      if (slow_us) std::this_thread::sleep_for(std::chrono::microseconds(slow_us));
+      double *stage = c->h_xstage[b].p, *stage_maf = stage + (size_t)chunk * site_elems;
+      const int Tm = (int)std::min<uint64_t>((uint64_t)T, m);
+      std::vector<int> good((size_t)Tm, 1);
+      c->exact_pool.run(Tm, [&](int t) {
+        try {
+          for (uint64_t s = m * (uint64_t)t / (uint64_t)Tm; s < m * (uint64_t)(t + 1) / (uint64_t)Tm; ++s)
+            replay_site_planes(raw + s * 3 * ni, ni, c->gopts, np, stage + s * site_elems, &stage_maf[s]);
+        } catch (...) {
+          good[(size_t)t] = 0;
+        }
+      });
+      for (int t = 0; t < Tm; ++t)
+        if (!good[(size_t)t]) {
+          rc = NGSLD_ERR_NOMEM;
+          msg = "out of host memory";
+          ok = false;
+        }
+      if (!ok) break;
+      if (hip_bad(hipMemcpyAsync(c->d_xplanes.p + s0 * site_elems, stage, (size_t)m * site_elems * sizeof(double), hipMemcpyHostToDevice, st),
+                  "exact store upload") ||
+          hip_bad(hipMemcpyAsync(c->d_xmaf.p + s0, stage_maf, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st), "exact store upload") ||
+          hip_bad(hipEventRecord(up.e[b], st), "exact store upload")) {
+        ok = false;
+        break;
+      }
+      if (k >= 1) {  // the chunk before this one has landed (its upload ran beside this chunk's arithmetic): publish it
+        if (hip_bad(hipEventSynchronize(up.e[b ^ 1]), "exact store upload")) {
+          ok = false;
+          break;
+        }
+        c->exact_frontier.store(prev_end);
+        c->exact_cv.notify_all();
+      }
+      prev_end = s0 + m;
+    }
+    if (c->exact_stream != nullptr) {
+      const hipError_t e = hipStreamSynchronize(c->exact_stream);
+      if (ok) ok = !hip_bad(e, "exact store upload");
+    }
+    if (ok && !c->exact_cancel.load()) {
+      c->exact_frontier.store(n);
+      c->exact_cv.notify_all();
+      ok = !hip_bad(build_lane_store(c, c->exact_stream), "exact store, individual-major copy");
+    }
+    c->h_xstage[0].release();  // (64 MB of pinned host memory, used once per matrix)
+    c->h_xstage[1].release();
+  } catch (...) {
+    rc = NGSLD_ERR_NOMEM;
+    msg = "out of host memory";
+  }
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  {
+    std::lock_guard<std::mutex> g(c->exact_mu);
+    c->exact_rc = rc;
+    c->exact_msg = msg;
+    c->exact_build_s = secs;
+    c->exact_state.store(rc == NGSLD_OK && !c->exact_cancel.load() ? 2 : -1);
+  }
+  c->exact_cv.notify_all();
+  if (std::getenv("NGSLD_TRACE") != nullptr)
+    std::fprintf(stderr, "[trace] exact store: %llu sites x %llu individuals through the host's libm in %.3f s (a thread of its own beside the run)\n",
+                 (unsigned long long)c->n_sites, (unsigned long long)c->n_ind, secs);
+}
+
+void stop_exact_store(ngsld_ctx *c) {
+  if (c->exact_thread.joinable()) {
+    c->exact_cancel.store(true);
+    c->exact_thread.join();
+  }
+  c->exact_cancel.store(false);
+  c->exact_state.store(0);
+  c->exact_frontier.store(0);
+  c->exact_rc = NGSLD_OK;
+  c->exact_msg.clear();
+  c->exact_ready = false;
+  c->xT_ready = false;
+}
+
+int start_exact_store(ngsld_ctx *c) {
+  if (c->exact_state.load() != 0 || c->exact_failed) return NGSLD_OK;
   HIP_TRY(c, hipSetDevice(c->device));
+  if (exact_store_is_free(c)) {  // the planes ARE the store
+    c->exact_alias = true;
+    c->exact_frontier.store(c->n_sites);
+    const hipError_t e = build_lane_store(c, replay_stream_of(c));
+    if (e != hipSuccess) return hip_fail(c, e, "exact store, individual-major copy");
+    c->exact_state.store(2);
+    c->exact_ready = true;
+    return NGSLD_OK;
+  }
   // (a device without room for the matrix once more: no store for this matrix -- its flagged pairs stay with the host's threads)
   const bool pretend = std::getenv("NGSLD_EXACT_STORE_NO_ROOM") != nullptr;  // tests
-  if (pretend || c->d_xplanes.resize((size_t)n * site_elems) != hipSuccess || c->d_xmaf.resize(n) != hipSuccess) {
+  if (pretend || c->d_xplanes.resize((size_t)c->n_sites * 3 * c->np) != hipSuccess || c->d_xmaf.resize(c->n_sites) != hipSuccess) {
     (void)hipGetLastError();
     c->d_xplanes.release();
     c->d_xmaf.release();
     c->exact_failed = true;
     return NGSLD_OK;
   }
-  std::vector<double> xmaf(n);
-  uint64_t chunk = std::max<uint64_t>(1, (32ull << 20) / (site_elems * sizeof(double)));
-  if (chunk > n) chunk = n;
-  struct Events {  // (destroyed on every way out)
-    hipEvent_t e[2] = {nullptr, nullptr};
-    ~Events() {
-      for (hipEvent_t x : e)
-        if (x) (void)hipEventDestroy(x);
-    }
-    hipEvent_t &operator[](int k) { return e[k]; }
-  } up;
-  for (int k = 0; k < 2; ++k) {
-    HIP_TRY(c, c->h_xstage[k].resize((size_t)chunk * site_elems));
-    HIP_TRY(c, hipEventCreateWithFlags(&up[k], hipEventDisableTiming));
-  }
-  hipStream_t st = replay_stream_of(c);
-  int T = c->replay_threads > 0 ? c->replay_threads : (int)std::min<unsigned>(32u, usable_threads());
-  std::vector<double> raw_chunk;  // (callback source: the chunk's raw values, fetched with one call)
-  int rc = NGSLD_OK;
-  uint64_t k = 0;
-  for (uint64_t s0 = 0; s0 < n && rc == NGSLD_OK; s0 += chunk, ++k) {
-    const int b = (int)(k & 1);
-    const uint64_t m = std::min(chunk, n - s0);
-    if (k >= 2) HIP_TRY(c, hipEventSynchronize(up[b]));  // the upload that last read this staging buffer is done
-    const double *raw = nullptr;
-    if (c->replay_matrix != nullptr) {
-      raw = c->replay_matrix + s0 * 3 * ni;
-    } else {
-      raw_chunk.resize((size_t)m * 3 * ni);
-      std::lock_guard<std::mutex> g(c->replay_mu);
-      if (c->replay_read(c->replay_user, s0, m, raw_chunk.data()) != 0) {
-        rc = fail(c, NGSLD_ERR_SINK, "the replay source callback failed");
-        break;
-      }
-      raw = raw_chunk.data();
-    }
-    double *stage = c->h_xstage[b].p;
-    const int Tm = (int)std::min<uint64_t>((uint64_t)T, m);
-    std::vector<int> ok((size_t)Tm, 1);
-    c->replay_pool.run(Tm, [&](int t) {
-      try {
-        for (uint64_t s = m * (uint64_t)t / (uint64_t)Tm; s < m * (uint64_t)(t + 1) / (uint64_t)Tm; ++s)
-          replay_site_planes(raw + s * 3 * ni, ni, c->gopts, np, stage + s * site_elems, &xmaf[s0 + s]);
-      } catch (...) {
-        ok[(size_t)t] = 0;
-      }
-    });
-    for (int t = 0; t < Tm; ++t)
-      if (!ok[(size_t)t]) rc = fail(c, NGSLD_ERR_NOMEM, "out of host memory");
-    if (rc != NGSLD_OK) break;
-    HIP_TRY(c, hipMemcpyAsync(c->d_xplanes.p + s0 * site_elems, stage, (size_t)m * site_elems * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(c, hipEventRecord(up[b], st));
-  }
-  if (rc == NGSLD_OK) {
-    hipError_t e = hipMemcpyAsync(c->d_xmaf.p, xmaf.data(), n * sizeof(double), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) rc = hip_fail(c, e, "exact store upload");
-  } else {
-    (void)hipStreamSynchronize(st);
-  }
-  c->h_xstage[0].release();  // (64 MB of pinned host memory, used once per matrix)
-  c->h_xstage[1].release();
-  if (rc != NGSLD_OK) return rc;
+  if (c->exact_thread.joinable()) c->exact_thread.join();  // (a builder that ended by itself)
   c->exact_alias = false;
-  c->exact_ready = true;
-  {
-    const int rcl = build_lane_store(c);
-    if (rcl != NGSLD_OK) return rcl;
+  c->exact_cancel.store(false);
+  c->exact_frontier.store(0);
+  c->exact_state.store(1);
+  try {
+    c->exact_thread = std::thread(exact_builder, c);
+  } catch (...) {
+    c->exact_state.store(0);
+    c->exact_failed = true;  // (no thread to be had: host replay)
   }
-  c->exact_build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  if (std::getenv("NGSLD_TRACE") != nullptr)
-    std::fprintf(stderr, "[trace] exact store: %llu sites x %llu individuals through the host's libm on %d threads in %.3f s\n",
-                 (unsigned long long)n, (unsigned long long)ni, T, c->exact_build_s);
   return NGSLD_OK;
 }
 
+int wait_exact_store(ngsld_ctx *c, uint64_t need_sites, bool *have) {
+  *have = false;
+  if (c->exact_failed || c->exact_state.load() == 0) return NGSLD_OK;
+  const bool all = need_sites >= c->n_sites;
+  {
+    std::unique_lock<std::mutex> lk(c->exact_mu);
+    // (the builder publishes the frontier without the lock: a short timed wait instead of a missed wake-up)
+    while (c->exact_state.load() == 1 && (all || c->exact_frontier.load() < need_sites)) c->exact_cv.wait_for(lk, std::chrono::milliseconds(1));
+    if (c->exact_state.load() == -1) {
+      const int rc = c->exact_rc;
+      const std::string msg = c->exact_msg;
+      lk.unlock();
+      if (c->exact_thread.joinable()) c->exact_thread.join();
+      c->exact_state.store(0);
+      c->exact_failed = true;  // (not again for this matrix)
+      c->d_xplanes.release();
+      c->d_xmaf.release();
+      return rc != NGSLD_OK ? fail(c, rc, msg.c_str()) : NGSLD_OK;
+    }
+  }
+  if (c->exact_state.load() == 2) {
+    if (c->exact_thread.joinable()) c->exact_thread.join();
+    c->exact_ready = true;
+  }
+  *have = true;
+  return NGSLD_OK;
+}
+
+int ensure_exact_store(ngsld_ctx *c) {
+  if (c->exact_ready) return NGSLD_OK;
+  const int rc = start_exact_store(c);
+  if (rc != NGSLD_OK) return rc;
+  bool have = false;
+  return wait_exact_store(c, c->n_sites, &have);
+}
+
 int try_device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
-                          ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text, int slot, bool *applied) {
+                          ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text, int slot, bool *applied, uint64_t need_sites) {
   *applied = false;
-  int rc = ensure_exact_store(c);
-  if (rc != NGSLD_OK || !c->exact_ready) return rc;
+  int rc = start_exact_store(c);
+  if (rc != NGSLD_OK) return rc;
+  bool have = false;
+  rc = wait_exact_store(c, need_sites, &have);
+  if (rc != NGSLD_OK || !have) return rc;
   rc = device_replay_lkl(c, d_flags, cap, out_base, n, d_std, d_ext, st, flag_text, slot);
   if (rc == NGSLD_OK) *applied = true;
   return rc;
@@ -559,7 +673,7 @@ int try_device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_
 // them -- before the head of the flag buffer travels to the host, before text rows are formatted.  The store must be ready.
 int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_base, uint64_t n, ngsld_rec_std *d_std,
                       ngsld_rec_ext *d_ext, hipStream_t st, bool flag_text, int slot) {
-  if (!c->exact_ready || d_flags == nullptr || n == 0) return NGSLD_OK;
+  if (!exact_store_started(c) || d_flags == nullptr || n == 0) return NGSLD_OK;
   ReplayLklArgs a{};
   const size_t head = flag_head_words(cap), words = flag_bitmap_words(n);
   a.bits = d_flags + head;
@@ -688,7 +802,7 @@ int finish_device_run(ngsld_ctx *c) {
     // a likelihood matrix that flags more pairs than the host should replay: the exact store is built (once per matrix) and
     // the pairs are replayed on the device, behind the kernels on their stream
     int rcx = try_device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, base, n, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st,
-                                    false, -1, &applied);
+                                    false, -1, &applied, c->n_sites);
     if (rcx != NGSLD_OK) return rcx;
     if (applied) {
       rcx = send_flag_head(c, c->d_flags_dev.p, c->h_flags_dev.p, c->flag_cap_dev, c->dev_run.st, false);
@@ -716,11 +830,10 @@ extern "C" {
 int ngsld_set_replay_source(ngsld_ctx *c, ngsld_read_sites_fn read, void *user) {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "set the genotype data before its replay source");
+  stop_exact_store(c);  // (the exact store is built from the source)
   c->replay_matrix = nullptr;
   c->replay_read = read;
   c->replay_user = user;
-  c->exact_ready = false;  // (the exact store is built from the source)
-  c->xT_ready = false;
   c->planned = false;  // a --min_maf tie is settled at plan time
   return NGSLD_OK;
 }
@@ -728,11 +841,10 @@ int ngsld_set_replay_source(ngsld_ctx *c, ngsld_read_sites_fn read, void *user) 
 int ngsld_set_replay_matrix(ngsld_ctx *c, const double *values) {
   if (c == nullptr) return NGSLD_ERR_INVALID;
   if (!c->have_geno) return fail(c, NGSLD_ERR_INVALID, "set the genotype data before its replay source");
+  stop_exact_store(c);  // (the exact store is built from the source)
   c->replay_matrix = values;
   c->replay_read = nullptr;
   c->replay_user = nullptr;
-  c->exact_ready = false;  // (the exact store is built from the source)
-  c->xT_ready = false;
   c->planned = false;  // a --min_maf tie is settled at plan time
   return NGSLD_OK;
 }
@@ -757,7 +869,7 @@ int ngsld_replay_info(ngsld_ctx *c, ngsld_replay_stats_t *out) {
   out->pairs_on_device = c->replayed_on_device;
   out->pairs_on_host = c->replayed_pairs - c->replayed_on_device;
   out->sites_reevaluated = c->replayed_sites;
-  out->exact_store = c->exact_ready ? (c->exact_alias ? 1 : 2) : 0;
+  out->exact_store = c->exact_state.load() == 2 ? (c->exact_alias ? 1 : 2) : 0;
   out->text_rows_patched = (int32_t)std::min<uint64_t>(c->text_rows_patched, 0x7fffffffull);
   out->exact_store_build_s = c->exact_build_s;
   return NGSLD_OK;

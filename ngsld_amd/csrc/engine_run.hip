@@ -165,9 +165,9 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
     if (rcd != NGSLD_OK) return rcd;
     // likelihood matrices: right behind the kernels when the exact store is there (or costs nothing); a run that turns out to
     // flag many pairs without one has it built in ngsld_finish_device
-    if (lkl_device_eligible(c) && (c->exact_ready || exact_store_is_free(c))) {
+    if (lkl_device_eligible(c) && (exact_store_started(c) || exact_store_is_free(c))) {
       rcd = try_device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, c->h_row_off[s1_begin], c->timed_pairs,
-                                  (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, st, false, -1, &c->dev_run.dev_applied);
+                                  (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, st, false, -1, &c->dev_run.dev_applied, c->n_sites);
       if (rcd != NGSLD_OK) return rcd;
     }
     // which pairs the kernels flagged (and the device has not settled itself): the counter and the list come over behind
@@ -200,6 +200,15 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     const int rcp = finish_device_run(c);  // (see ngsld_run_device)
     if (rcp != NGSLD_OK) return rcp;
   }
+  // (a build of the exact store this run starts has ended when the run returns, whichever way: the registered source is read
+  // during runs only -- include/ngsld.h, BUFFER LIFETIME)
+  struct StoreGuard {
+    ngsld_ctx *c;
+    ~StoreGuard() {
+      std::unique_lock<std::mutex> lk(c->exact_mu);
+      while (c->exact_state.load() == 1) c->exact_cv.wait_for(lk, std::chrono::milliseconds(1));
+    }
+  } store_guard{c};
   const bool ext = c->params.extend_out != 0;
   c->ev_used = 0;
   c->timed_stream = c->stream;
@@ -405,9 +414,9 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       int rcd = device_replay(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], st, k);
       if (rcd != NGSLD_OK) return rcd;
       // (likelihoods: the same once the exact store is there -- a batch issued before that is settled when it is consumed)
-      if (lkl_device_eligible(c) && (c->exact_ready || exact_store_is_free(c))) {
+      if (lkl_device_eligible(c) && (exact_store_started(c) || exact_store_is_free(c))) {
         rcd = try_device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], st, true, k,
-                                    &c->slot_dev_applied[k]);
+                                    &c->slot_dev_applied[k], exact_sites_needed(c, b.r0, b.r1));
         if (rcd != NGSLD_OK) return rcd;
       }
     }
@@ -630,7 +639,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
           // a likelihood matrix that flags more pairs than the host should replay, and this batch went out before the exact
           // store was there: build it (once), replay the batch's pairs on the device, take every row's length again
           int rcx = try_device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, c->d_std[k].p,
-                                          ext ? c->d_ext[k].p : nullptr, c->copy_stream, true, k, &applied);
+                                          ext ? c->d_ext[k].p : nullptr, c->copy_stream, true, k, &applied, exact_sites_needed(c, b.r0, b.r1));
           if (rcx != NGSLD_OK) return rcx;
           if (applied) {
             rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream, false);
@@ -688,7 +697,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
         bool applied = c->slot_dev_applied[k];
         if (!applied && exact_store_wanted(c, c->h_flags[k].p[0] - c->h_flags[k].p[1])) {  // (see the text branch above)
           int rcx = try_device_replay_lkl(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k],
-                                          c->copy_stream, true, k, &applied);
+                                          c->copy_stream, true, k, &applied, exact_sites_needed(c, b.r0, b.r1));
           if (rcx != NGSLD_OK) return rcx;
           if (applied) {
             rcx = send_flag_head(c, c->d_flags[k].p, c->h_flags[k].p, c->flag_cap[k], c->copy_stream, false);
@@ -726,6 +735,11 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   if (c->text_stream) HIP_TRY(c, hipStreamSynchronize(c->text_stream));
   HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
   if (rc != NGSLD_OK) return rc;
+  if (c->exact_state.load() == 1) {  // (the store's builder is still at the sites behind this run's rows: its errors are this run's)
+    bool have = false;
+    const int rcs = wait_exact_store(c, c->n_sites, &have);
+    if (rcs != NGSLD_OK) return rcs;
+  }
   return check_status(c);
 } NGSLD_CATCH(c)
 

@@ -272,3 +272,78 @@ def test_a_device_without_room_for_the_store_leaves_the_pairs_to_the_host(eng, m
     assert got[4]["exact_store"] == 0 and got[4]["pairs_on_device"] == 0 and got[4]["pairs_on_host"] == want[4]["pairs_on_host"] > 0
     for k in (2, 3):
         assert got[k].tobytes() == want[k].tobytes()
+
+
+@pytest.mark.parametrize("callback", [False, True])
+def test_store_built_beside_the_run_in_site_order(eng, monkeypatch, callback):
+    """The exact store is built by a thread of its own while the run that asked for it goes on (engine_replay.hip: exact_builder):
+    a batch's device-side replay waits only until the builder has passed the batch's last window.  Here the builder is slowed
+    and works in chunks of 16 sites, so that every one of the run's many batches -- text rows and records -- catches up with the
+    frontier and waits: the records are the host replay's, bit for bit, and the text is the same bytes."""
+    n_sites, n_ind = 900, 60
+    raw = uncalled(n_sites, n_ind, 811, mono_frac=0.25)
+    raw *= 1.0 + 0.01 * np.random.default_rng(5).random(raw.shape)      # no triple repeats: the builder's memo never hits
+    if callback:
+        monkeypatch.setenv("NGSLD_PY_REPLAY_CALLBACK", "1")             # ngsld_set_replay_source instead of ngsld_set_replay_matrix
+    eng.set_tuning(batch_pairs=2500)
+    want = run_records(eng, raw, 0, max_snp_dist=60)
+    assert want[4]["pairs_on_host"] > 5000
+    monkeypatch.setenv("NGSLD_EXACT_CHUNK_SITES", "16")
+    monkeypatch.setenv("NGSLD_EXACT_SLOW_US", "1500")
+    got = run_records(eng, raw, 2, max_snp_dist=60)
+    assert got[4]["exact_store"] == 2 and got[4]["pairs_on_device"] > 5000 and got[4]["pairs_on_host"] * 20 < got[4]["pairs_on_device"]
+    assert got[4]["exact_store_build_s"] > 0.05
+    assert_same_records(got, want)
+    labels = [f"s{k}" for k in range(n_sites)]
+    texts = []
+    for mode in (0, 2):
+        eng.set_exact_store(mode)
+        eng.set_geno_raw(raw)                                           # (a new matrix: the store is built again, beside this run)
+        eng.set_pos_dist(None)
+        eng.plan(max_snp_dist=60)
+        eng.set_text_output(labels)
+        try:
+            text, fallbacks = eng.run_text()
+        finally:
+            eng.set_text_output(None, enable=False)
+        assert fallbacks == 0
+        texts.append(hashlib.md5(text).hexdigest())
+    assert texts[0] == texts[1]
+    eng.set_exact_store(1)
+
+
+def test_a_failing_replay_source_ends_the_run_that_built_the_store(monkeypatch):
+    """A callback source that fails while the builder reads it: the run that started the build returns the error (the builder has
+    ended by then), the context stays usable -- the next matrix runs."""
+    import ctypes as C
+    n_sites, n_ind = 400, 40
+    raw = uncalled(n_sites, n_ind, 33, mono_frac=0.3)
+    e = capi.Engine(0)
+    try:
+        e.set_exact_store(2)
+        e.set_geno_raw(raw, replay_source=False)
+        calls = [0]
+
+        def reader(_user, site_begin, n, dst):
+            calls[0] += 1
+            if site_begin >= 200:
+                return 1
+            C.memmove(dst, raw.ctypes.data + int(site_begin) * n_ind * 24, int(n) * n_ind * 24)
+            return 0
+
+        cb = capi.READ_FN(reader)
+        e._check(e._L.ngsld_set_replay_source(e._h, cb, None))
+        monkeypatch.setenv("NGSLD_EXACT_CHUNK_SITES", "50")
+        e.set_pos_dist(None)
+        e.plan(max_snp_dist=40)
+        with pytest.raises(capi.NgsldError) as err:
+            e.run()
+        assert "replay source" in str(err.value) and calls[0] >= 5
+        monkeypatch.delenv("NGSLD_EXACT_CHUNK_SITES")
+        e.set_geno_raw(raw)                                             # the array itself as the source: all is well
+        e.set_pos_dist(None)
+        n = e.plan(max_snp_dist=40)
+        s1, _, _, _ = e.run()
+        assert len(s1) == n and e.replay_info()["pairs_on_device"] > 100
+    finally:
+        e.close()
