@@ -10,7 +10,7 @@ from test_gpu_fuzz import _case
 
 first, last = int(sys.argv[1]) if len(sys.argv) > 1 else 0, int(sys.argv[2]) if len(sys.argv) > 2 else 300
 eng = capi.Engine(0)
-bad = rows_total = fallbacks_total = 0
+bad = rows_total = fallbacks_total = patched = on_host = 0
 for k in range(first, last):
     raw, pd, kw, call = _case(k)
     n_sites = raw.shape[0]
@@ -23,6 +23,9 @@ for k in range(first, last):
     eng.set_text_output(labels)
     text, fallbacks = eng.run_text()
     eng.set_text_output(None, enable=False)
+    info = eng.replay_info()
+    patched += info["text_rows_patched"]
+    on_host += info["pairs_on_host"]
     fallbacks_total += fallbacks
     if fallbacks:
         continue          # the batch went out as records: nothing to compare
@@ -40,5 +43,6 @@ for k in range(first, last):
             if g != w:
                 print(f"case {k}: first differing row\n  device {g}\n  host   {w}")
                 break
-print(f"text soak: cases {first}..{last - 1}, {rows_total} rows compared, {fallbacks_total} batches fell back to records, {bad} differing cases")
+print(f"text soak: cases {first}..{last - 1}, {rows_total} rows compared, {fallbacks_total} batches fell back to records, "
+      f"{on_host} pairs replayed on the host of which {patched} rows overwritten in the host's text, {bad} differing cases")
 sys.exit(1 if bad else 0)
