@@ -301,7 +301,9 @@ int ngsld_plan_slabs(const double *pos_dist, uint64_t n_sites, const ngsld_param
                      ngsld_slab *slabs, uint64_t cap, uint64_t *n_slabs);
 
 /* How many sites of n_ind individuals fit a slab when `budget_bytes` of device memory may be used in total
- * (both contexts, their record buffers included); 0 when the budget is too small for any. */
+ * (both contexts, their record buffers included, the matrix priced THREE times per context: the planes, and the exact store of
+ * the device-side replay with its individual-major copy, which input that is not SNP-called makes the library build); 0 when
+ * the budget is too small for any. */
 uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes);
 
 /* Free and total memory of HIP device `device`, in bytes. */

@@ -431,7 +431,9 @@ uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes) {
   const uint64_t fixed = ((uint64_t)ngsld_ctx::kSlots * (1ull << 23) * (sizeof(ngsld_rec_std) + sizeof(ngsld_rec_ext))) + (768ull << 20);
   const uint64_t per_ctx = budget_bytes / 2;
   if (per_ctx <= fixed) return 0;
-  return (per_ctx - fixed) / (24ull * cfg.np + 64ull);
+  // (the matrix three times: the planes, and the exact store of the device-side replay with its individual-major copy, which
+  // un-called input has built -- engine_replay.hip)
+  return (per_ctx - fixed) / (72ull * cfg.np + 64ull);
 }
 
 int ngsld_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {

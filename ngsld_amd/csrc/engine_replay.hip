@@ -426,21 +426,27 @@ bool exact_store_wanted(const ngsld_ctx *c, uint64_t pending) {
 }
 
 // The individual-major copy for the lane-per-pair kernel, where the device has room for the matrix once more (NGSLD_REPLAY_LANES=0:
-// never -- the wavefront-per-pair kernel takes everything, as in the round's first sessions).  On stream st, synchronised.
-static hipError_t build_lane_store(ngsld_ctx *c, hipStream_t st) {
+// never -- the wavefront-per-pair kernel takes everything, as in the round's first sessions): its memory
+static bool alloc_lane_store(ngsld_ctx *c) {
   c->xT_ready = false;
   if (const char *e = std::getenv("NGSLD_REPLAY_LANES"))
-    if (std::strcmp(e, "0") == 0) return hipSuccess;
+    if (std::strcmp(e, "0") == 0) return false;
   const size_t elems = (size_t)c->n_sites * c->n_ind * 3;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < elems * sizeof(double) + (4ull << 30)) {
     (void)hipGetLastError();
-    return hipSuccess;
+    return false;
   }
   if (c->d_xT.resize(elems) != hipSuccess) {
     (void)hipGetLastError();
-    return hipSuccess;
+    return false;
   }
+  return true;
+}
+
+// ... and all of it at once from planes that are a store already (the alias forms), on stream st, synchronised
+static hipError_t build_lane_store(ngsld_ctx *c, hipStream_t st) {
+  if (!alloc_lane_store(c)) return hipSuccess;
   hipError_t e = launch_transpose_store(c->exact_alias ? c->d_planes.p : c->d_xplanes.p, 3ull * c->np, c->np, (uint32_t)c->n_ind, c->n_sites,
                                         c->d_xT.p, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -449,9 +455,20 @@ static hipError_t build_lane_store(ngsld_ctx *c, hipStream_t st) {
   return hipSuccess;
 }
 
+// a chunk of the store from pinned host memory into place (site_elems is even: np is a multiple of 8)
+__global__ __launch_bounds__(256) void store_chunk_kernel(const double *__restrict__ src, double *__restrict__ dst, uint64_t n,
+                                                          const double *__restrict__ src_maf, double *__restrict__ dst_maf, uint64_t n_maf) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, T = (uint64_t)gridDim.x * blockDim.x;
+  const double2 *s2 = reinterpret_cast<const double2 *>(src);
+  double2 *d2 = reinterpret_cast<double2 *>(dst);
+  for (uint64_t i = t; i < n / 2; i += T) d2[i] = s2[i];
+  if (t == 0 && (n & 1)) dst[n - 1] = src[n - 1];
+  for (uint64_t i = t; i < n_maf; i += T) dst_maf[i] = src_maf[i];
+}
+
 // The builder (ngsld_ctx::exact_thread): the registered source through the host's libm, chunk by chunk in site order -- two
-// pinned staging buffers, a chunk's upload beside the next chunk's arithmetic --, the frontier published as the uploads land;
-// then the lane kernel's copy.  Touches nothing of the context a run touches but the store's own buffers and atomics.
+// pinned staging buffers, a chunk's upload (and its transposition into the lane kernel's copy) beside the next chunk's
+// arithmetic --, the frontier published as the uploads land.  Touches nothing of the context a run touches but the store's own buffers and atomics.
 static void exact_builder(ngsld_ctx *c) {
   Range range_("ngsld:exact store (host libm -> device)");
   const auto t0 = std::chrono::steady_clock::now();
@@ -479,7 +496,17 @@ static void exact_builder(ngsld_ctx *c) {
       }
     } up;
     bool ok = !hip_bad(hipSetDevice(c->device), "exact store");
-    if (ok && c->exact_stream == nullptr) ok = !hip_bad(hipStreamCreateWithFlags(&c->exact_stream, hipStreamNonBlocking), "exact store stream");
+    if (ok && c->exact_stream == nullptr) {
+      // a HIGH-PRIORITY stream: the runtime gives it a hardware queue of that priority instead of a share in one of the run's
+      // four -- where a chunk's upload stood behind an 80 ms replay kernel of the run, which itself waited for the builder's
+      // frontier: one chunk per batch, 120,000 x 2,000 built in 5.1 s instead of 0.4
+      int least = 0, greatest = 0;
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+        (void)hipGetLastError();
+        least = greatest = 0;
+      }
+      ok = !hip_bad(hipStreamCreateWithPriority(&c->exact_stream, hipStreamNonBlocking, greatest), "exact store stream");
+    }
     for (int k = 0; k < 2 && ok; ++k) {
       ok = !hip_bad(c->h_xstage[k].resize((size_t)chunk * (site_elems + 1)), "exact store staging") &&  // (+ 1: the site's est_maf behind the planes)
            !hip_bad(hipEventCreateWithFlags(&up.e[k], hipEventDisableTiming), "exact store event");
@@ -525,10 +552,20 @@ static void exact_builder(ngsld_ctx *c) {
           ok = false;
         }
       if (!ok) break;
-      if (hip_bad(hipMemcpyAsync(c->d_xplanes.p + s0 * site_elems, stage, (size_t)m * site_elems * sizeof(double), hipMemcpyHostToDevice, st),
-                  "exact store upload") ||
-          hip_bad(hipMemcpyAsync(c->d_xmaf.p + s0, stage_maf, (size_t)m * sizeof(double), hipMemcpyHostToDevice, st), "exact store upload") ||
-          hip_bad(hipEventRecord(up.e[b], st), "exact store upload")) {
+      // (a KERNEL reads the pinned chunk over the host link, not hipMemcpyAsync: an SDMA copy can queue behind the run's text
+      // copies on that engine, each of which waits for its batch's kernels -- send_flag_head)
+      double *stage_dev = nullptr;
+      if (hip_bad(hipHostGetDevicePointer((void **)&stage_dev, stage, 0), "exact store upload")) {
+        ok = false;
+        break;
+      }
+      hipLaunchKernelGGL(store_chunk_kernel, dim3(512), dim3(256), 0, st, stage_dev, c->d_xplanes.p + s0 * site_elems, (uint64_t)m * site_elems,
+                         stage_dev + (size_t)chunk * site_elems, c->d_xmaf.p + s0, (uint64_t)m);
+      bool sent = !hip_bad(hipGetLastError(), "exact store upload");
+      if (sent && c->xT_ready.load())  // (the lane kernel's copy of these sites, behind their planes on the same stream)
+        sent = !hip_bad(launch_transpose_store(c->d_xplanes.p, site_elems, (uint32_t)np, (uint32_t)ni, n, c->d_xT.p, st, s0, s0 + m),
+                        "exact store, individual-major copy");
+      if (!sent || hip_bad(hipEventRecord(up.e[b], st), "exact store upload")) {
         ok = false;
         break;
       }
@@ -549,7 +586,6 @@ static void exact_builder(ngsld_ctx *c) {
     if (ok && !c->exact_cancel.load()) {
       c->exact_frontier.store(n);
       c->exact_cv.notify_all();
-      ok = !hip_bad(build_lane_store(c, c->exact_stream), "exact store, individual-major copy");
     }
     c->h_xstage[0].release();  // (64 MB of pinned host memory, used once per matrix)
     c->h_xstage[1].release();
@@ -608,6 +644,7 @@ int start_exact_store(ngsld_ctx *c) {
   }
   if (c->exact_thread.joinable()) c->exact_thread.join();  // (a builder that ended by itself)
   c->exact_alias = false;
+  c->xT_ready = alloc_lane_store(c);  // (filled chunk by chunk behind the planes: usable as far as the frontier, like them)
   c->exact_cancel.store(false);
   c->exact_frontier.store(0);
   c->exact_state.store(1);
@@ -706,6 +743,11 @@ int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t ou
   // milliseconds over ONE pair, four wavefronts to a SIMD, and such a launch has no second pair for most lanes: 6 ms a batch
   // against 4, profiles/r05/e2e_uncalled_lanes_on_text_batches.json)
   uint64_t lanes_from = 1ull << 22;
+  // ... but cohorts beyond 512 individuals, where SEVERAL wavefronts share a pair and all of them wait for the four lanes'
+  // chain (2,000 individuals: 6e6 replayed pairs/s), go to the lanes whatever the launch's size, with a cap on a lane's EM
+  // steps so that the launch does not last as long as its slowest pair (what is over the cap is the wavefront kernel's)
+  const bool big_cohort = replay_lkl_waves((uint32_t)c->n_ind) >= 2;
+  if (big_cohort) lanes_from = 0;
   if (const char *v = std::getenv("NGSLD_REPLAY_LANES_FROM")) lanes_from = std::strtoull(v, nullptr, 10);  // A/B
   if (c->xT_ready && n >= lanes_from) {
     a.after_lanes = 1;
@@ -723,7 +765,13 @@ int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t ou
     HIP_TRY(c, ls.temp.resize(temp_bytes ? temp_bytes : 1));
     HIP_TRY(c, launch_replay_expand(a, ls.list.p, list_cap, st));
     HIP_TRY(c, launch_replay_sort(a, ls.list.p, list_cap, ls.keys_a.p, ls.keys_b.p, ls.vals_a.p, ls.vals_b.p, ls.temp.p, temp_bytes, st));
-    HIP_TRY(c, launch_replay_lanes(a, ls.list.p, ls.vals_b.p, c->d_xT.p, c->n_cus, n >= (1ull << 22) ? 4 : 1, st));
+    int lane_waves = n >= (1ull << 22) ? 4 : 1;
+    if (n < (1ull << 22)) {
+      a.lane_iter_cap = 12;
+      if (const char *v = std::getenv("NGSLD_LANE_ITER_CAP")) a.lane_iter_cap = (uint32_t)std::strtoul(v, nullptr, 10);  // A/B
+      if (const char *v = std::getenv("NGSLD_LANE_WAVES")) lane_waves = std::atoi(v);                                   // A/B
+    }
+    HIP_TRY(c, launch_replay_lanes(a, ls.list.p, ls.vals_b.p, c->d_xT.p, c->n_cus, lane_waves, st));
   }
   HIP_TRY(c, launch_replay_lkl(a, c->n_cus, st));
   return NGSLD_OK;

@@ -47,6 +47,7 @@ struct ReplayLklArgs {
   uint64_t n_records;         // records in the launch
   uint32_t chunk_words;       // bitmap words per claim (set by launch_replay_lkl)
   uint32_t after_lanes;       // launch_replay_expand has run: flags[6] counts the bits it left in the bitmap
+  uint32_t lane_iter_cap;     // replay_lane_kernel: a pair not converged after this many EM steps goes back into the bitmap, for the wavefront-per-pair kernel (0: never)
   uint32_t only_if_overflow;  // launch_replay_expand: do nothing unless the launch flagged more pairs than its list holds (called genotypes)
   uint32_t *work;             // chunk counter of the persistent teams, zero at launch
   uint32_t *done;             // receives the number of pairs replayed (added to)
@@ -75,9 +76,9 @@ struct ReplayEntry {  // a flagged pair, located
   uint64_t slot;      // its record in the launch
   uint32_t s1, s2;
 };
-// individual-major copy of the exact store: xT[(i * n_sites + s) * 3 + g] = xplanes[s][g][i]
+// individual-major copy of the exact store: xT[(i * n_sites + s) * 3 + g] = xplanes[s][g][i], sites [site_begin, site_end)
 hipError_t launch_transpose_store(const double *xplanes, uint64_t site_stride, uint32_t np, uint32_t n_ind, uint64_t n_sites,
-                                  double *xT, hipStream_t stream);
+                                  double *xT, hipStream_t stream, uint64_t site_begin = 0, uint64_t site_end = ~0ull);
 // Walks the launch's bitmap (a thread per word), appends the pairs the lane-per-pair kernel takes to `list` (at most list_cap;
 // counter: flags[4]) and CLEARS their bits: what stays set -- pairs whose Pearson moment is ill conditioned, pairs beyond the
 // list's capacity -- is the wavefront-per-pair kernel's.

@@ -392,9 +392,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 // in memory (a monomorphic row's candidates: consecutive sites, 1.5 KB contiguous).
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_store_kernel(const double *__restrict__ xplanes, uint64_t site_stride, uint32_t np,
-                                                              uint32_t n_ind, uint64_t n_sites, double *__restrict__ xT) {
+                                                              uint32_t n_ind, uint64_t pitch_sites, double *__restrict__ xT, uint64_t site_begin,
+                                                              uint64_t n_sites) {
+  // (sites [site_begin, n_sites) of a matrix of pitch_sites sites: the builder moves the store chunk by chunk)
   __shared__ double tile[3][64][65];  // [genotype][site][individual]
-  const uint64_t s0 = (uint64_t)blockIdx.x * 64;
+  const uint64_t s0 = site_begin + (uint64_t)blockIdx.x * 64;
   const uint32_t i0 = blockIdx.y * 64;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int ls = w; ls < 64; ls += 4) {
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(256) void transpose_store_kernel(const double *__re
     if (i >= n_ind) continue;
     for (int t = lane; t < 192; t += 64) {
       const int ls = t / 3, g = t % 3;
-      if (s0 + ls < n_sites) xT[((uint64_t)i * n_sites + s0 + ls) * 3 + g] = tile[g][ls][li];
+      if (s0 + ls < n_sites) xT[((uint64_t)i * pitch_sites + s0 + ls) * 3 + g] = tile[g][ls][li];
     }
   }
 }
@@ -580,7 +582,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
       }
       bool finished = eps < kEps;             // gen_func.cpp:1054: break with n_iter = iter
       if (!finished && ++iter == (uint32_t)kMaxIter) finished = true;  // ... or the loop runs out: n_iter = ITER_MAX
-      if (finished) {
+      if (!finished && A.lane_iter_cap != 0 && iter >= A.lane_iter_cap) {
+        // a long pair in a short launch (a text batch of a large cohort: a lane takes ~0.4 ms an iteration over 2,000
+        // individuals and the launch would last as long as its slowest lane): handed to the wavefront-per-pair kernel behind
+        // this one -- its bit set again --, which starts it over
+        atomicOr(&A.bits[e.slot >> 5], 1u << (e.slot & 31u));
+        atomicAdd(&A.flags[6], 1u);
+        have = false;
+      } else if (finished) {
         const double hm0 = 1 - (f[0] + f[1]);  // ngsLD.cpp:296-306
         const double hm1 = 1 - (f[0] + f[2]);
         const double D = f[0] * f[3] - f[1] * f[2];
@@ -607,10 +616,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
 }  // namespace
 
 hipError_t launch_transpose_store(const double *xplanes, uint64_t site_stride, uint32_t np, uint32_t n_ind, uint64_t n_sites,
-                                  double *xT, hipStream_t stream) {
-  if (n_sites == 0 || n_ind == 0) return hipSuccess;
-  const dim3 grid((unsigned)((n_sites + 63) / 64), (unsigned)((n_ind + 63) / 64));
-  hipLaunchKernelGGL(transpose_store_kernel, grid, dim3(256), 0, stream, xplanes, site_stride, np, n_ind, n_sites, xT);
+                                  double *xT, hipStream_t stream, uint64_t site_begin, uint64_t site_end) {
+  if (site_end > n_sites) site_end = n_sites;
+  if (site_begin >= site_end || n_ind == 0) return hipSuccess;
+  const dim3 grid((unsigned)((site_end - site_begin + 63) / 64), (unsigned)((n_ind + 63) / 64));
+  hipLaunchKernelGGL(transpose_store_kernel, grid, dim3(256), 0, stream, xplanes, site_stride, np, n_ind, n_sites, xT, site_begin, site_end);
   return hipGetLastError();
 }
 

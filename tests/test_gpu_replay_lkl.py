@@ -347,3 +347,18 @@ def test_a_failing_replay_source_ends_the_run_that_built_the_store(monkeypatch):
         assert len(s1) == n and e.replay_info()["pairs_on_device"] > 100
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("n_ind,cap", [(700, "2"), (1500, "1"), (2000, "12")])
+def test_large_cohorts_take_the_lanes_on_short_launches_with_a_cap(eng, monkeypatch, n_ind, cap):
+    """Beyond 512 individuals several wavefronts share a pair in the wavefront-per-pair kernel and wait for its four chain lanes;
+    such cohorts go to the lane-per-pair kernel on launches of any size, and a lane gives a pair that has not converged after
+    `cap` EM steps back to the wavefront kernel (its bit set again), which starts it over.  Whatever the cap, the records are the
+    host replay's, bit for bit."""
+    raw = uncalled(260, n_ind, 4242 + n_ind, mono_frac=0.25, missing=True)
+    want = run_records(eng, raw, 0, max_snp_dist=30)
+    monkeypatch.setenv("NGSLD_LANE_ITER_CAP", cap)
+    got = run_records(eng, raw, 2, max_snp_dist=30)
+    assert got[4]["pairs_on_device"] > 500 and got[4]["pairs_on_host"] * 20 < got[4]["pairs_on_device"]
+    assert_same_records(got, want)
+    eng.set_exact_store(1)

@@ -112,10 +112,11 @@ PLANE_SHAPES = [(24, 24), (64, 64), (65, 80), (100, 112), (128, 128), (160, 160)
 
 @pytest.mark.parametrize("n_ind,np_want", PLANE_SHAPES)
 def test_budget_helper_sizes_slabs_with_the_engines_own_plane_layout(n_ind, np_want):
-    """ngsld_slab_sites_for_budget must count 24 * np + 64 bytes per site with the np the engine will really allocate
+    """ngsld_slab_sites_for_budget must count 3 x 24 * np + 64 bytes per site -- the planes and, since round 5, the exact store of
+    the device-side replay with its individual-major copy, which input that is not SNP-called has built -- with the np the engine will really allocate
     (round 2's helper took the a/b kernel's layout for 513..1024 while the engine ran the two-wavefront one: slabs up to
     11 % too large).  np is read back from the helper at two budgets -- and pins pair_config's shape boundaries on the CPU."""
     lo, hi = capi.slab_sites_for_budget(n_ind, 64 << 30), capi.slab_sites_for_budget(n_ind, 192 << 30)
     assert 0 < lo < hi
     per_site = (64 << 30) / (hi - lo)                      # d(budget / 2) / d(sites)
-    assert abs(per_site - (24 * np_want + 64)) < 1e-3 * per_site, (n_ind, per_site, (per_site - 64) / 24)
+    assert abs(per_site - (72 * np_want + 64)) < 1e-3 * per_site, (n_ind, per_site, (per_site - 64) / 72)

@@ -30,7 +30,7 @@ def md5(path):
 
 with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
     g, p = os.path.join(d, "in.glf"), os.path.join(d, "in.pos")
-    raw = synth.make_gl_torch(n_sites, n_ind, 5, torch.device("cuda", 0))
+    raw = synth.make_gl_torch(n_sites, n_ind, 5, torch.device("cuda", 0), mono_frac=float(os.environ.get("E2E_MONO", "0")))   # E2E_MONO=0.2: not SNP-called
     with open(g, "wb") as fh:
         for s in range(0, n_sites, 8192):
             fh.write(raw[s:s + 8192].cpu().numpy().tobytes())
