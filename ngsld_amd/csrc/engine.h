@@ -249,7 +249,7 @@ struct FlagRow {
   uint64_t rec, off;  // record index within the batch; first byte of its row in the batch's text
   uint32_t len, s1, s2, pad;
 };
-constexpr uint32_t kFlagRowsCap = 256;
+constexpr uint32_t kFlagRowsCap = 1024;
 
 struct ngsld_ctx {
   int device = 0;

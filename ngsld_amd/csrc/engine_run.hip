@@ -478,6 +478,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   std::vector<ngsld_rec_std> hp_std;
   std::vector<ngsld_rec_ext> hp_ext;
   std::vector<uint32_t> hp_row;  // recs[j]'s entry of the slot's h_flag_rows
+  std::vector<std::pair<uint64_t, uint32_t>> by_rec;
   auto batch_needs_host = [&](int k, size_t bi) -> bool {  // a value beyond the device formatter's fast path: the batch goes out as records
     bool needs_host = (c->h_text_meta[k].p[1] & 0xffffffffull) != 0;
     if (const char *e = std::getenv("NGSLD_TEXT_FALLBACK_EVERY")) {  // tests: every n-th batch takes the record path
@@ -497,10 +498,12 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     rep_s1.resize(recs.size());
     rep_s2.resize(recs.size());
     hp_row.resize(recs.size());
+    by_rec.resize(n);  // (the list is in the order the atomics landed in)
+    for (uint32_t q = 0; q < n; ++q) by_rec[q] = {rows[q].rec, q};
+    std::sort(by_rec.begin(), by_rec.end());
     for (size_t j = 0; j < recs.size(); ++j) {
-      uint32_t at = n;
-      for (uint32_t q = 0; q < n; ++q)
-        if (rows[q].rec == recs[j]) { at = q; break; }
+      const auto hit = std::lower_bound(by_rec.begin(), by_rec.end(), std::make_pair(recs[j], 0u));
+      const uint32_t at = hit != by_rec.end() && hit->first == recs[j] ? hit->second : n;
       if (at == n || rows[at].s1 >= c->n_sites || rows[at].s2 >= c->n_sites) return false;
       hp_row[j] = at;
       rep_s1[j] = rows[at].s1;

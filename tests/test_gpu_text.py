@@ -147,7 +147,7 @@ def test_host_replayed_rows_are_overwritten_in_the_hosts_text(monkeypatch, exten
         monkeypatch.delenv("NGSLD_TEXT_HOST_PATCH_FAIL_EVERY")
         assert fb0 == fb1 == fb2 == 0
         assert info0["pairs_on_host"] > 50 and info0["text_rows_patched"] == 0
-        # (a batch that leaves the host more than 256 pairs -- kFlagRowsCap -- goes the device's way)
+        # (a batch that leaves the host more than 1,024 pairs -- kFlagRowsCap -- goes the device's way)
         assert info1["pairs_on_host"] == info0["pairs_on_host"] and 1000 < info1["text_rows_patched"] <= info1["pairs_on_host"]
         assert 0 < info2["text_rows_patched"] < info1["text_rows_patched"] and info2["pairs_on_host"] == info0["pairs_on_host"]
         assert got == want and half == want
