@@ -60,6 +60,10 @@ int ngsld_host_read_geno_bin_range(const char *path, uint64_t n_ind, uint64_t si
  * text_semantics = 1 and log_scale = *out_log_scale (called genotypes are handed over as log triples). */
 int ngsld_host_read_geno_text(const char *path, int in_probs, int log_scale, uint64_t n_ind, uint64_t n_sites,
                               double *out_raw, int *out_log_scale, char *err, size_t errlen);
+/* What ngsld_host_read_geno_text stores, three times, for a missing call (-1) of a genotype file: log(1/3), read_data.cpp:94.
+ * A matrix whose individuals without data are exactly this triple (text semantics, log scale, no --call_geno) has the pairs of
+ * such sites replayed on the device like any other (ngsld.h, "Exact-order replay"). */
+double ngsld_host_missing_call_log(void);
 
 /* TSV text.  Both return the number of bytes written (no NUL needed), 0 if cap is too small.
  * NaN is printed as "-nan": every NaN the reference prints comes from an x86 invalid operation

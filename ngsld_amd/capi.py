@@ -90,7 +90,7 @@ SYMBOLS = [
     "ngsld_host_read_geno_bin_range",
     "ngsld_host_set_threads", "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos", "ngsld_host_pos_slice",
     "ngsld_host_geno_size_ok", "ngsld_host_read_geno_bin", "ngsld_host_read_geno_text", "ngsld_host_format_header", "ngsld_host_format_pair",
-    "ngsld_host_format_double", "ngsld_host_write_batch", "ngsld_host_replay_pair",
+    "ngsld_host_format_double", "ngsld_host_write_batch", "ngsld_host_replay_pair", "ngsld_host_missing_call_log",
     "ngsld_host_gz_open", "ngsld_host_gz_close",
 ]
 
@@ -538,6 +538,14 @@ def format_header(extend_out: bool) -> str:
     buf = C.create_string_buffer(512)
     n = lib().ngsld_host_format_header(buf, len(buf), int(extend_out))
     return buf.raw[:n].decode()
+
+
+def missing_call_log() -> float:
+    """log(1/3) as the text reader stores it for a missing call (ngsld_host_missing_call_log)."""
+    f = lib().ngsld_host_missing_call_log
+    f.restype = C.c_double
+    f.argtypes = []
+    return float(f())
 
 
 def format_pair(l1, l2, dist: float, std_rec: np.ndarray, ext_rec: np.ndarray | None, maf1: float, maf2: float) -> str:

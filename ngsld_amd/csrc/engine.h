@@ -269,7 +269,9 @@ struct ngsld_ctx {
   // hard-called matrices (kHard): per-site genotype bit sets
   DevBuf<uint64_t> d_hard_masks;
   DevBuf<double> d_hard_u;
-  DevBuf<int> d_all_hard;
+  DevBuf<int> d_all_hard, d_odd_missing;
+  int h_odd_missing = 0;
+  bool missing_canonical = false;  // text genotypes: every individual without data is the reader's own triple (PrepArgs::odd_missing)
   int h_all_hard = 0, h_prep_status = 0;
   uint32_t mask_words = 0;
 

@@ -87,6 +87,16 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   a.mean_e = c->d_mean.p;
   a.rsx = c->d_rsx.p;
   a.status = c->d_status.p;
+  // text genotypes: are the individuals without data the reader's own triple?  (then the device-side replay of called
+  // genotypes takes the pairs of their sites too, ld_replay.hip)
+  c->missing_canonical = false;
+  const bool look_for_odd_missing = o.text_semantics && log_scale && !o.call_geno && !normalised;
+  if (look_for_odd_missing) {
+    HIP_TRY(c, c->d_odd_missing.resize(1));
+    HIP_TRY(c, hipMemsetAsync(c->d_odd_missing.p, 0, sizeof(int), c->stream));
+    a.odd_missing = c->d_odd_missing.p;
+    a.missing_canon = replay_missing_raw_text();
+  }
   if (on_device) {
     a.raw = gl;
     a.maf_in = maf;
@@ -164,7 +174,11 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   status = 0;
   HIP_TRY(c, hipMemcpyAsync(c->h_maf.data(), c->d_maf.p, n_sites * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(&status, c->d_status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  c->h_odd_missing = 1;
+  if (look_for_odd_missing)
+    HIP_TRY(c, hipMemcpyAsync(&c->h_odd_missing, c->d_odd_missing.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->missing_canonical = look_for_odd_missing && c->h_odd_missing == 0;
   if (trace) std::fprintf(stderr, "[trace] set_geno: scalars packed, called-genotype check, maf on the host at %.2f ms\n", ms_since());
   if (status == NGSLD_ERR_NAN) return fail(c, NGSLD_ERR_NAN, "NaN found! Is the file format correct?");
   if (try_hard && all_hard) {

@@ -805,8 +805,13 @@ int device_replay(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_ba
   // "no data" individuals: only call_geno's triple is the same arithmetic on every individual (gen_func.cpp:903-905); a
   // matrix that came called from elsewhere may hold any three equal values -- its pairs at sites with missing data stay
   // with the host, which has the caller's raw values
-  a.miss_ok = c->gopts.call_geno && !c->normalised ? 1 : 0;
-  replay_missing_constants(&a.u_lkl, &a.u_pp);
+  // (text genotype files without --call_geno: the reader's own triple for a missing call, log(1/3) three times and then
+  // post_prob -- another two constants; the prep pass has looked at every individual without data, engine.hip)
+  a.miss_ok = (c->gopts.call_geno && !c->normalised) || c->missing_canonical ? 1 : 0;
+  if (c->missing_canonical)
+    replay_missing_constants_text(&a.u_lkl, &a.u_pp);
+  else
+    replay_missing_constants(&a.u_lkl, &a.u_pp);
   a.out_std = d_std;
   a.out_ext = d_ext;
   a.status = c->d_status.p;

@@ -539,6 +539,8 @@ int ngsld_host_read_geno_text(const char *path, int in_probs, int log_scale, uin
   return NGSLD_OK;
 } NGSLD_HOST_CATCH
 
+double ngsld_host_missing_call_log(void) { return std::log(1.0 / 3.0); }  // (the expression fill_site stores)
+
 size_t ngsld_host_format_header(char *buf, size_t cap, int extend_out) {
   const int n = std::snprintf(
       buf, cap, "site1\tsite2\tdist\tr2_ExpG\tD\tDp\tr2%s\n",

@@ -19,6 +19,11 @@ struct PrepArgs {
   double N_thresh, call_thresh;
   double *maf, *mean_e, *rsx;  // [n_sites]; rsx = 1/sqrt(sum (e - mean)^2)
   int *status;
+  // text genotypes (log scale, no --call_geno): *odd_missing is set when an individual without data -- three (nearly) equal raw
+  // values -- is anything but the reader's own triple, missing_canon three times (read_data.cpp:94: log(1/3) through the HOST's
+  // libm).  Null: not looked for.  What the device-side replay of called genotypes needs to know (ld_replay.hip: miss_ok).
+  int *odd_missing;
+  double missing_canon;
 };
 
 hipError_t launch_prep(const PrepArgs &a, hipStream_t stream);

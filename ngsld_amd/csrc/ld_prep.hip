@@ -330,8 +330,33 @@ __global__ __launch_bounds__(256) void prep_sites_kernel(PrepArgs A) {
   }
 }
 
+// see PrepArgs::odd_missing
+__global__ __launch_bounds__(256) void missing_check_kernel(const double *__restrict__ raw, uint64_t n_triples, double canon, int *odd) {
+  const uint64_t T = (uint64_t)gridDim.x * blockDim.x;
+  const unsigned long long cb = (unsigned long long)__double_as_longlong(canon);
+  bool bad = false;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_triples; t += T) {
+    const double g0 = raw[3 * t], g1 = raw[3 * t + 1], g2 = raw[3 * t + 2];
+    const double mn = fmin(g0, fmin(g1, g2)), mx = fmax(g0, fmax(g1, g2));
+    if (mx - mn < 1e-9) {  // (planes come out equal only where the raw values are equal to rounding; a NaN compares false and is the NaN check's)
+      const bool canonical = (unsigned long long)__double_as_longlong(g0) == cb && (unsigned long long)__double_as_longlong(g1) == cb &&
+                             (unsigned long long)__double_as_longlong(g2) == cb;
+      bad |= !canonical;
+    }
+  }
+  if (bad) *odd = 1;
+}
+
 hipError_t launch_prep(const PrepArgs &a, hipStream_t stream) {
   if (a.n_sites == 0) return hipSuccess;
+  if (a.odd_missing != nullptr) {
+    const uint64_t n_triples = a.n_sites * (uint64_t)a.n_ind;
+    const uint64_t wgs = (n_triples + 255) / 256;
+    hipLaunchKernelGGL(missing_check_kernel, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, stream, a.raw, n_triples, a.missing_canon,
+                       a.odd_missing);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
   if (a.np <= 2048) {
     const uint64_t wgs = (a.n_sites + 3) / 4;
     const unsigned grid = (unsigned)(wgs < 65536 ? wgs : 65536);

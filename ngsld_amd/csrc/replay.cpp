@@ -3,6 +3,8 @@
 // Every expression below keeps the association and the order of the reference line it cites.
 #include "replay.h"
 
+#include "../../include/ngsld_host.h"
+
 #include <cmath>
 #include <cstring>
 
@@ -206,6 +208,18 @@ void replay_site_planes(const double *raw, uint64_t n_ind, const ngsld_geno_opts
 void replay_missing_constants(double *u_lkl, double *u_pp) {
   double g[3];
   for (int k = 0; k < 3; ++k) g[k] = std::log((double)1 / 3);  // harden(): gen_func.cpp:903-905
+  *u_lkl = std::exp(g[0]);                                    // ngsLD.cpp:110
+  double pp[3] = {g[0], g[1], g[2]};
+  normalise_log(pp);                                          // site_maf(): post_prob, then exp
+  *u_pp = std::exp(pp[0]);
+}
+
+double replay_missing_raw_text() { return ngsld_host_missing_call_log(); }  // read_data.cpp:94: what host_io.cpp's reader stores
+
+void replay_missing_constants_text(double *u_lkl, double *u_pp) {
+  double g[3];
+  for (int k = 0; k < 3; ++k) g[k] = replay_missing_raw_text();
+  normalise_log(g);                                           // read_data.cpp:98
   *u_lkl = std::exp(g[0]);                                    // ngsLD.cpp:110
   double pp[3] = {g[0], g[1], g[2]};
   normalise_log(pp);                                          // site_maf(): post_prob, then exp

@@ -49,5 +49,9 @@ void replay_pair(const ReplaySite &a, const ReplaySite &b, uint64_t n_ind, bool 
 // values calc_pair_LD and est_maf see: u_lkl = exp(log(1/3)) (ngsLD.cpp:110), u_pp = the est_maf posterior of that triple
 // (gen_func.cpp:920-932, 986-990).  The device-side replay of called genotypes (ld_replay.hip) takes them as constants.
 void replay_missing_constants(double *u_lkl, double *u_pp);
+// ... and of a text genotype file's missing call (read_data.cpp:94-98: log(1/3) three times, THEN post_prob; no --call_geno):
+// the raw value the reader stores, and what the site's likelihood and est_maf's posterior of such an individual are
+double replay_missing_raw_text();
+void replay_missing_constants_text(double *u_lkl, double *u_pp);
 
 }  // namespace ngsld

@@ -196,3 +196,55 @@ def test_a_launch_that_overflows_its_flag_list_is_replayed_on_the_device_too(n_i
     assert np.array_equal(ed["hap"].view(np.uint64), eh["hap"].view(np.uint64))
     assert np.array_equal(ed["n_iter"], eh["n_iter"]) and np.array_equal(ed["n_ind_data"], eh["n_ind_data"])
     assert np.all(close(sd["r2_ExpG"], sh["r2_ExpG"], 1e-12))
+
+
+@pytest.mark.parametrize("n_ind,ignore,mono", [(500, False, 0.3), (500, True, 0.3), (130, True, 0.3), (1000, False, 0.2)])
+def test_text_genotypes_with_missing_calls_are_replayed_on_the_device(n_ind, ignore, mono, monkeypatch):
+    """A text genotype file ({-1, 0, 1, 2}, no --call_geno): read_geno stores log(1) for the called genotype over -INF and
+    log(1/3) three times for a missing call, then post_prob (read_data.cpp:88-98).  The prep pass sees that every individual without
+    data is that very triple (PrepArgs::odd_missing), so the device-side replay knows its likelihood and est_maf posterior -- two
+    constants from the host's libm (replay_missing_constants_text) -- and takes the pairs of sites with missing calls too (up to
+    round 5 they were the host's: 98,000 pairs of a 30,000-site matrix, 3.5x on the pass).  Device against host replay bit for
+    bit, both against the oracle; a matrix whose missing triple is anything else (1e-3 off) stays with the host."""
+    from ngsld_amd import capi
+    n_sites = 400
+    rng = np.random.default_rng(900 + n_ind)
+    g = synth.make_gl_numpy(n_sites, n_ind, 6100 + n_ind, depth=8.0).argmax(axis=2)
+    raw = np.full((n_sites, n_ind, 3), -1e15)
+    np.put_along_axis(raw, g[..., None], 0.0, axis=2)
+    if mono:
+        raw[rng.random(n_sites) < mono] = np.array([0.0, -1e15, -1e15])
+    missing = rng.random((n_sites, n_ind)) < 0.04
+    raw[missing] = capi.missing_call_log()                         # (log(1/3) as the reader stores it)
+    rec = orc.Oracle(raw, None, log_scale=True, ignore_miss_data=ignore, n_threads=32).run()
+    got = {}
+    for where in ("device", "host", "odd"):
+        monkeypatch.setenv("NGSLD_REPLAY_DEVICE", "0" if where == "host" else "1")
+        eng = capi.Engine(0)
+        try:
+            m = raw
+            if where == "odd":
+                m = raw.copy()
+                m[missing] = capi.missing_call_log() + 1e-3             # still "no data" to every kernel, but not the reader's triple
+            eng.set_geno_raw(m, log_scale=True, ignore_miss_data=ignore, text=True)
+            assert eng.pair_kernel() == "hard"
+            eng.set_pos_dist(None)
+            assert eng.plan(0, 0, 0.0, ignore, True) == len(rec)
+            s1, s2, std, ext = eng.run()
+            info = eng.replay_info()
+        finally:
+            eng.close()
+        if where != "odd":
+            check_records(std, ext, rec)
+        got[where] = (std, ext, info)
+    (sd, ed, idv), (sh, eh, ih), (_, _, io) = got["device"], got["host"], got["odd"]
+    assert idv["pairs_flagged"] == ih["pairs_flagged"] > 100 and ih["pairs_on_device"] == 0
+    assert idv["pairs_on_device"] > idv["pairs_flagged"] * 0.9, idv
+    assert io["pairs_on_host"] > io["pairs_flagged"] * 0.5, io       # (sites with missing calls: nearly all of them)
+    for col in ("D", "Dp", "r2"):
+        assert np.array_equal(sd[col].view(np.uint64), sh[col].view(np.uint64)), col
+    assert np.array_equal(ed["hap"].view(np.uint64), eh["hap"].view(np.uint64))
+    assert np.array_equal(ed["n_iter"], eh["n_iter"]) and np.array_equal(ed["n_ind_data"], eh["n_ind_data"])
+    assert np.all(close(sd["r2_ExpG"], sh["r2_ExpG"], 1e-12))
+    print(f"\n[text genotypes, missing calls] n_ind {n_ind} ignore {ignore} mono {mono}: {len(rec)} pairs, {idv['pairs_flagged']} flagged, "
+          f"{idv['pairs_on_device']} on the device ({io['pairs_on_device']} when the missing triple is not the reader's)")
