@@ -482,6 +482,10 @@ __global__ void replay_keys_kernel(ReplayLklArgs A, const ReplayEntry *list, uin
 
 constexpr uint32_t kLaneChunk = 256;  // sorted entries a wavefront claims at a time
 
+// (CAPPED: short launches of large cohorts, ReplayLklArgs::lane_iter_cap -- a template so that the long launches' instruction
+// stream is the one without the hand-back: with the test inside one kernel that stream came out 30 % slower, 447 against 343 ms
+// for configs[2]'s 31e6 pairs)
+template <bool CAPPED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void replay_lane_kernel(ReplayLklArgs A, const ReplayEntry *list,
                                                                                                       const uint32_t *order,
                                                                                                       const double *xT) {
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
       }
       bool finished = eps < kEps;             // gen_func.cpp:1054: break with n_iter = iter
       if (!finished && ++iter == (uint32_t)kMaxIter) finished = true;  // ... or the loop runs out: n_iter = ITER_MAX
-      if (!finished && A.lane_iter_cap != 0 && iter >= A.lane_iter_cap) {
+      if (CAPPED && !finished && iter >= A.lane_iter_cap) {
         // a long pair in a short launch (a text batch of a large cohort: a lane takes ~0.4 ms an iteration over 2,000
         // individuals and the launch would last as long as its slowest lane): handed to the wavefront-per-pair kernel behind
         // this one -- its bit set again --, which starts it over
@@ -662,7 +666,10 @@ hipError_t launch_replay_lanes(const ReplayLklArgs &a, const ReplayEntry *list, 
   uint64_t waves = (uint64_t)n_cus * 4 * (uint64_t)(waves_per_simd < 1 ? 1 : (waves_per_simd > 4 ? 4 : waves_per_simd));
   const uint64_t most = (a.n_records + 63) / 64;
   if (waves > most) waves = most;
-  hipLaunchKernelGGL(replay_lane_kernel, dim3((unsigned)waves), dim3(64), 0, stream, a, list, order, xT);
+  if (a.lane_iter_cap != 0)
+    hipLaunchKernelGGL(replay_lane_kernel<true>, dim3((unsigned)waves), dim3(64), 0, stream, a, list, order, xT);
+  else
+    hipLaunchKernelGGL(replay_lane_kernel<false>, dim3((unsigned)waves), dim3(64), 0, stream, a, list, order, xT);
   return hipGetLastError();
 }
 
