@@ -405,9 +405,15 @@ int reset_flags(ngsld_ctx *c, DevBuf<uint32_t> &buf, uint64_t n, uint32_t cap, h
 // ---------------------------------------------------------------------------------------------------------------
 // Likelihood matrices: the exact store and the device-side replay (ld_replay_lkl.hip)
 // ---------------------------------------------------------------------------------------------------------------
+static bool lanes_allowed() {
+  const char *e = std::getenv("NGSLD_REPLAY_LANES");
+  return e == nullptr || std::strcmp(e, "0") != 0;
+}
+
 bool lkl_device_eligible(const ngsld_ctx *c) {
+  // (beyond 4,096 individuals the wavefront-per-pair kernel has no shape: the lanes take such cohorts, where they may be had)
   return c->replay_on && c->replay_device && c->exact_mode != 0 && c->have_geno && c->cfg.kernel != kHard &&
-         replay_lkl_waves((uint32_t)c->n_ind) != 0;
+         (replay_lkl_waves((uint32_t)c->n_ind) != 0 || lanes_allowed());
 }
 
 // the planes ARE the store: the caller's own normal-space values (ngsld_set_geno_lkl), or no source to build another from
@@ -629,6 +635,10 @@ int start_exact_store(ngsld_ctx *c) {
     c->exact_frontier.store(c->n_sites);
     const hipError_t e = build_lane_store(c, replay_stream_of(c));
     if (e != hipSuccess) return hip_fail(c, e, "exact store, individual-major copy");
+    if (!c->xT_ready.load() && replay_lkl_waves((uint32_t)c->n_ind) == 0) {  // (no room for the copy the lanes read, and no other kernel for this cohort)
+      c->exact_failed = true;
+      return NGSLD_OK;
+    }
     c->exact_state.store(2);
     c->exact_ready = true;
     return NGSLD_OK;
@@ -645,6 +655,12 @@ int start_exact_store(ngsld_ctx *c) {
   if (c->exact_thread.joinable()) c->exact_thread.join();  // (a builder that ended by itself)
   c->exact_alias = false;
   c->xT_ready = alloc_lane_store(c);  // (filled chunk by chunk behind the planes: usable as far as the frontier, like them)
+  if (!c->xT_ready.load() && replay_lkl_waves((uint32_t)c->n_ind) == 0) {  // (see the alias form above)
+    c->d_xplanes.release();
+    c->d_xmaf.release();
+    c->exact_failed = true;
+    return NGSLD_OK;
+  }
   c->exact_cancel.store(false);
   c->exact_frontier.store(0);
   c->exact_state.store(1);
@@ -746,10 +762,12 @@ int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t ou
   // ... but cohorts beyond 512 individuals, where SEVERAL wavefronts share a pair and all of them wait for the four lanes'
   // chain (2,000 individuals: 6e6 replayed pairs/s), go to the lanes whatever the launch's size, with a cap on a lane's EM
   // steps so that the launch does not last as long as its slowest pair (what is over the cap is the wavefront kernel's)
-  const bool big_cohort = replay_lkl_waves((uint32_t)c->n_ind) >= 2;
+  const uint32_t team_waves = replay_lkl_waves((uint32_t)c->n_ind);  // (0: beyond 4,096 individuals -- the lanes or nothing)
+  const bool big_cohort = team_waves >= 2 || team_waves == 0;
   if (big_cohort) lanes_from = 0;
   if (const char *v = std::getenv("NGSLD_REPLAY_LANES_FROM")) lanes_from = std::strtoull(v, nullptr, 10);  // A/B
-  if (c->xT_ready && n >= lanes_from) {
+  if (team_waves == 0 && !c->xT_ready.load()) return fail(c, NGSLD_ERR_INVALID, "device-side replay without a kernel for this cohort");
+  if (c->xT_ready && (n >= lanes_from || team_waves == 0)) {
     a.after_lanes = 1;
     // one lane per pair wherever the individual-major copy is there: the launch's bitmap becomes a list of located pairs (the
     // bits listed are cleared), the lanes work through it; what stays in the bitmap -- ill-conditioned Pearson moments, pairs
@@ -766,14 +784,17 @@ int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t ou
     HIP_TRY(c, launch_replay_expand(a, ls.list.p, list_cap, st));
     HIP_TRY(c, launch_replay_sort(a, ls.list.p, list_cap, ls.keys_a.p, ls.keys_b.p, ls.vals_a.p, ls.vals_b.p, ls.temp.p, temp_bytes, st));
     int lane_waves = n >= (1ull << 22) ? 4 : 1;
-    if (n < (1ull << 22)) {
+    if (n < (1ull << 22) && team_waves != 0) {  // (no wavefront kernel to hand a long pair back to: no cap)
       a.lane_iter_cap = 12;
       if (const char *v = std::getenv("NGSLD_LANE_ITER_CAP")) a.lane_iter_cap = (uint32_t)std::strtoul(v, nullptr, 10);  // A/B
       if (const char *v = std::getenv("NGSLD_LANE_WAVES")) lane_waves = std::atoi(v);                                   // A/B
     }
     HIP_TRY(c, launch_replay_lanes(a, ls.list.p, ls.vals_b.p, c->d_xT.p, c->n_cus, lane_waves, st));
   }
-  HIP_TRY(c, launch_replay_lkl(a, c->n_cus, st));
+  if (team_waves == 0)
+    HIP_TRY(c, launch_replay_leftover(a, st));
+  else
+    HIP_TRY(c, launch_replay_lkl(a, c->n_cus, st));
   return NGSLD_OK;
 }
 

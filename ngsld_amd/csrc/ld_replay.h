@@ -97,6 +97,8 @@ hipError_t launch_replay_lanes(const ReplayLklArgs &a, const ReplayEntry *list, 
 
 // wavefronts per pair for a cohort of n_ind individuals (1 up to 512, then 2 / 4 / 8); 0: beyond the kernel (host replay)
 uint32_t replay_lkl_waves(uint32_t n_ind);
+// cohorts the wavefront-per-pair kernel does not take (replay_lkl_waves == 0): what the lanes left in the bitmap becomes the host's
+hipError_t launch_replay_leftover(const ReplayLklArgs &a, hipStream_t stream);
 // a persistent grid sized for n_cus compute units walks the bitmap
 hipError_t launch_replay_lkl(const ReplayLklArgs &a, int n_cus, hipStream_t stream);
 

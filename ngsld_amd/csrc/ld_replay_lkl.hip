@@ -673,6 +673,29 @@ hipError_t launch_replay_lanes(const ReplayLklArgs &a, const ReplayEntry *list, 
   return hipGetLastError();
 }
 
+// Cohorts beyond the wavefront-per-pair kernel's 4,096 individuals: what the lanes left in the bitmap -- pairs whose Pearson
+// moment is ill conditioned, pairs beyond the list -- is handed to the host (its own bitmap, its own list), a thread per word.
+__global__ __launch_bounds__(256) void replay_leftover_kernel(ReplayLklArgs A) {
+  const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t n_words = (A.n_records + 31) / 32;
+  if (w >= n_words) return;
+  uint32_t bits = A.bits[w] & ~A.host_bits[w];
+  if (w == n_words - 1 && (A.n_records & 31)) bits &= (1u << (A.n_records & 31)) - 1u;
+  if (!bits) return;
+  A.host_bits[w] |= bits;  // (this thread owns the word)
+  const uint32_t n = (uint32_t)__popc(bits);
+  uint32_t kh = atomicAdd(&A.flags[1], n);
+  for (uint32_t m = bits; m; m &= m - 1, ++kh)
+    if (kh < kFlagHostCap) reinterpret_cast<uint64_t *>(A.flags + kFlagListAt + 2u * A.flag_cap)[kh] = w * 32 + (uint64_t)(__ffs((int)m) - 1);
+}
+
+hipError_t launch_replay_leftover(const ReplayLklArgs &a, hipStream_t stream) {
+  if (a.bits == nullptr || a.n_records == 0) return hipSuccess;
+  const uint64_t n_words = (a.n_records + 31) / 32;
+  hipLaunchKernelGGL(replay_leftover_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
 uint32_t replay_lkl_waves(uint32_t n_ind) {
   const uint32_t per = 64u * kMaxSlots;
   for (uint32_t w = 1; w <= 8; w *= 2)

@@ -362,3 +362,18 @@ def test_large_cohorts_take_the_lanes_on_short_launches_with_a_cap(eng, monkeypa
     assert got[4]["pairs_on_device"] > 500 and got[4]["pairs_on_host"] * 20 < got[4]["pairs_on_device"]
     assert_same_records(got, want)
     eng.set_exact_store(1)
+
+
+@pytest.mark.parametrize("n_ind,n_sites", [(4200, 70), (8000, 40)])
+def test_cohorts_beyond_the_wavefront_kernel_are_replayed_by_the_lanes(eng, n_ind, n_sites):
+    """Beyond 4,096 individuals the wavefront-per-pair replay kernel has no shape (up to round 5 such cohorts kept the host's
+    replay: a third of the pairs of an un-called matrix at ~1e4 pairs/s).  The lane-per-pair kernel has no such limit: it takes
+    them on launches of any size, and what it leaves in the bitmap -- ill-conditioned Pearson moments -- is handed to the host
+    (replay_leftover_kernel).  Same records as the host's replay, bit for bit."""
+    raw = uncalled(n_sites, n_ind, 99 + n_ind, mono_frac=0.3)
+    want = run_records(eng, raw, 0)
+    got = run_records(eng, raw, 2)
+    assert want[4]["pairs_on_device"] == 0 and want[4]["pairs_on_host"] > 100, want[4]
+    assert got[4]["exact_store"] == 2 and got[4]["pairs_on_device"] > 100 and got[4]["pairs_on_host"] * 10 < got[4]["pairs_on_device"]
+    assert_same_records(got, want)
+    eng.set_exact_store(1)
