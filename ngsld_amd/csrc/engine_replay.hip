@@ -789,6 +789,7 @@ int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t ou
       if (const char *v = std::getenv("NGSLD_LANE_ITER_CAP")) a.lane_iter_cap = (uint32_t)std::strtoul(v, nullptr, 10);  // A/B
       if (const char *v = std::getenv("NGSLD_LANE_WAVES")) lane_waves = std::atoi(v);                                   // A/B
     }
+    if (const char *v = std::getenv("NGSLD_LANE_CAP_ALL")) a.lane_iter_cap = (uint32_t)std::strtoul(v, nullptr, 10);  // A/B: the capped kernel on long launches too
     HIP_TRY(c, launch_replay_lanes(a, ls.list.p, ls.vals_b.p, c->d_xT.p, c->n_cus, lane_waves, st));
   }
   if (team_waves == 0)

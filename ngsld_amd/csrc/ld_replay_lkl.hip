@@ -497,6 +497,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
   const double *pa = xT, *pb = xT;
   double f[4] = {0, 0, 0, 0};
   uint32_t iter = 0, pos = 0, end = 0;  // (pos, end: the wavefront's chunk of the sorted list, wave-uniform)
+  // (pairs this lane settled / handed back: added to the launch's counters ONCE, at the end -- as `atomicAdd(A.done, 1)` per pair
+  // the compiler turned it into one atomic per wavefront in the plain kernel but into one per LANE, all on one address, in the
+  // capped one: 447 against 343 ms for configs[2]'s 31e6 pairs)
+  uint32_t n_done = 0, n_back = 0;
   for (;;) {
     // lanes without a pair take the next entries of the wavefront's chunk, in lane order; a new chunk with one atomic
     for (;;) {
@@ -586,35 +590,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
       }
       bool finished = eps < kEps;             // gen_func.cpp:1054: break with n_iter = iter
       if (!finished && ++iter == (uint32_t)kMaxIter) finished = true;  // ... or the loop runs out: n_iter = ITER_MAX
-      if (CAPPED && !finished && iter >= A.lane_iter_cap) {
-        // a long pair in a short launch (a text batch of a large cohort: a lane takes ~0.4 ms an iteration over 2,000
-        // individuals and the launch would last as long as its slowest lane): handed to the wavefront-per-pair kernel behind
-        // this one -- its bit set again --, which starts it over
-        atomicOr(&A.bits[e.slot >> 5], 1u << (e.slot & 31u));
-        atomicAdd(&A.flags[6], 1u);
+      // (CAPPED) a long pair in a short launch (a text batch of a large cohort: a lane takes ~0.4 ms an iteration over 2,000
+      // individuals and the launch would last as long as its slowest lane) is handed to the wavefront-per-pair kernel behind
+      // this one -- its bit set again --, which starts it over
+      const bool hand_back = CAPPED && !finished && iter >= A.lane_iter_cap;
+      if (finished || hand_back) {
         have = false;
-      } else if (finished) {
-        const double hm0 = 1 - (f[0] + f[1]);  // ngsLD.cpp:296-306
-        const double hm1 = 1 - (f[0] + f[2]);
-        const double D = f[0] * f[3] - f[1] * f[2];
-        const double Dp = D / (D < 0 ? -ref_min(hm0 * hm1, (1 - hm0) * (1 - hm1)) : ref_min(hm0 * (1 - hm1), (1 - hm0) * hm1));
-        const double rr = D / __dsqrt_rn(hm0 * hm1 * (1 - hm0) * (1 - hm1));
-        ngsld_rec_std *o = A.out_std + e.slot;  // (r2_ExpG stays the pair kernel's: three stores, no read)
-        o->D = ref_nan(D);
-        o->Dp = ref_nan(Dp);
-        o->r2 = ref_nan(rr * rr);
-        if (A.out_ext != nullptr) {
-          ngsld_rec_ext r;
-          r.hap[0] = ref_nan(f[0]); r.hap[1] = ref_nan(f[1]); r.hap[2] = ref_nan(f[2]); r.hap[3] = ref_nan(f[3]);
-          r.n_ind_data = x;
-          r.n_iter = iter;
-          A.out_ext[e.slot] = r;
+        if (hand_back) {
+          atomicOr(&A.bits[e.slot >> 5], 1u << (e.slot & 31u));
+          ++n_back;
+        } else {
+          const double hm0 = 1 - (f[0] + f[1]);  // ngsLD.cpp:296-306
+          const double hm1 = 1 - (f[0] + f[2]);
+          const double D = f[0] * f[3] - f[1] * f[2];
+          const double Dp = D / (D < 0 ? -ref_min(hm0 * hm1, (1 - hm0) * (1 - hm1)) : ref_min(hm0 * (1 - hm1), (1 - hm0) * hm1));
+          const double rr = D / __dsqrt_rn(hm0 * hm1 * (1 - hm0) * (1 - hm1));
+          ngsld_rec_std *o = A.out_std + e.slot;  // (r2_ExpG stays the pair kernel's: three stores, no read)
+          o->D = ref_nan(D);
+          o->Dp = ref_nan(Dp);
+          o->r2 = ref_nan(rr * rr);
+          if (A.out_ext != nullptr) {
+            ngsld_rec_ext r;
+            r.hap[0] = ref_nan(f[0]); r.hap[1] = ref_nan(f[1]); r.hap[2] = ref_nan(f[2]); r.hap[3] = ref_nan(f[3]);
+            r.n_ind_data = x;
+            r.n_iter = iter;
+            A.out_ext[e.slot] = r;
+          }
+          ++n_done;
         }
-        atomicAdd(A.done, 1u);
-        have = false;
       }
     }
   }
+  if (n_done) atomicAdd(A.done, n_done);
+  if (CAPPED && n_back) atomicAdd(&A.flags[6], n_back);
 }
 
 }  // namespace
