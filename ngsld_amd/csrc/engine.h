@@ -29,7 +29,8 @@
 #include <vector>
 
 #include "../../include/ngsld.h"
-#include "ld_device.h"
+#include "ld_common.h"
+#include "ld_dispatch.h"
 #include "ld_prep.h"
 #include "ld_replay.h"
 #include "ld_text.h"

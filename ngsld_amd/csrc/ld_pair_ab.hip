@@ -33,7 +33,8 @@
 // into registers when the pair starts (a full-site buffer per wavefront would leave room for 4 wavefronts per CU).
 #include <type_traits>
 
-#include "ld_device.h"
+#include "ld_run_pipeline.h"
+#include "ld_dispatch.h"
 
 namespace ngsld {
 

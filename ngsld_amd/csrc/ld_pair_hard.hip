@@ -15,7 +15,9 @@
 // (one workgroup per run of <= 16 items of one row, the row's bit sets in LDS, claims from the run's list, result rings)
 // like pair_ld_group_kernel.  The step is the full four-value form with one reciprocal per combination; no allele
 // relabelling is needed for it.
-#include "ld_device.h"
+#include "ld_group_reduce.h"
+#include "ld_run_pipeline.h"
+#include "ld_dispatch.h"
 
 namespace ngsld {
 

@@ -5,7 +5,8 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "ld_device.h"
+#include "ld_kernel_stream.h"
+#include "ld_dispatch.h"
 
 namespace ngsld {
 

@@ -5,7 +5,10 @@
 #include <algorithm>
 #include <cstring>
 
-#include "ld_device.h"
+#include "ld_kernel_run.h"
+#include "ld_kernel_group.h"
+#include "ld_kernel_stream.h"
+#include "ld_dispatch.h"
 
 namespace ngsld {
 

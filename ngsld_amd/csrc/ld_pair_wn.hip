@@ -1,5 +1,6 @@
 // ld_pair_wn.hip -- instantiations of the multi-wavefront-per-pair kernel (960 < n_ind <= 5120; from 513 on with NGSLD_PAIR_KERNEL=multi).
-#include "ld_device.h"
+#include "ld_kernel_multi.h"
+#include "ld_dispatch.h"
 
 namespace ngsld {
 

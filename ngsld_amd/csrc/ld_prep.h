@@ -1,7 +1,7 @@
 // ld_prep.h -- launch interface of the per-site preprocessing / item kernels (see ld_prep.hip).
 #pragma once
 
-#include "ld_device.h"
+#include "ld_common.h"
 
 namespace ngsld {
 

@@ -18,7 +18,7 @@
 // that concerns it carry kFlagHostOnly and stay with the host.  "No data" individuals are taken with the HOST's values of
 // the triple --call_geno leaves (log(1/3) three times through the host's exp: handed in as constants); a matrix whose
 // missing triples may be anything else (miss_ok == 0) keeps the pairs of sites with missing individuals on the host.
-#include "ld_device.h"
+#include "ld_common.h"
 #include "ld_replay.h"
 
 namespace ngsld {

@@ -35,7 +35,7 @@
 // individuals, 2 / 4 / 8 beyond) claims chunks of kChunkWords words with one atomic, walks their set bits and maps a record
 // index to its pair through a cursor over the plan's items (one binary search per chunk, then steps) -- records of one chunk
 // are neighbours in (s1, s2) order, so the row's vector stays in registers from pair to pair.
-#include "ld_device.h"
+#include "ld_common.h"
 #include "ld_replay.h"
 
 #include <algorithm>
