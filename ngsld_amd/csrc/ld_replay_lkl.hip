@@ -89,7 +89,25 @@ struct FreqProducts {
   }
 };
 
-__device__ __forceinline__ void quotients(const FreqProducts &F, const double (&p)[3], const double (&q)[3], double (&out)[4]) {
+// An operand of an f64 division that V_DIV_SCALE_F64 hands through unchanged and without raising VCC, whatever the other
+// operand, provided that one passes this test too: a positive number in [2^-600, 2^100) -- the denominator is then neither
+// denormal nor is its reciprocal, the exponents differ by less than 768, the quotient is no denormal, and the numerator's
+// biased exponent is above 53 (the instruction's own list of cases, CDNA3 ISA 6.4 "V_DIV_SCALE_F64") -- or, for a numerator
+// (ZERO_OK), +0 exactly: n * r, fma(-d, +0, +0) and fma(+0, r, +0) are +0, which is what V_DIV_FIXUP_F64 makes of 0 / d.
+// Negative numbers, -0, NaN, infinities, denormals and anything tiny or huge fail: such an individual's quotients are the
+// compiler's own divisions.
+template <bool ZERO_OK>
+__device__ __forceinline__ int div_operand_plain(double v) {
+  constexpr uint32_t kHiMin = (1023u - 600u) << 20, kHiSpan = 700u << 20;
+  // (ints and | on purpose: as bools with || the compiler made a branch of every test)
+  const int in_range = (uint32_t)__double2hiint(v) - kHiMin < kHiSpan ? 1 : 0;
+  return ZERO_OK ? (in_range | (__double_as_longlong(v) == 0 ? 1 : 0)) : in_range;
+}
+
+// (counts: the caller uses this lane's quotients -- a padding lane, or an individual left out under --ignore_miss_data, whose
+// result is thrown away, must not send its wavefront down the slow way)
+__device__ __forceinline__ void quotients(const FreqProducts &F, const double (&p)[3], const double (&q)[3], double (&out)[4],
+                                          bool counts = true) {
   double J[3][3];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
@@ -105,12 +123,38 @@ __device__ __forceinline__ void quotients(const FreqProducts &F, const double (&
 #pragma unroll
   for (int kh = 1; kh < 16; ++kh) sum += t[FreqProducts::at(kh >> 2, kh & 3)];
   // gen_func.cpp:1098-1104
+  double tmp[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    double tmp = F.h2[FreqProducts::at(k, 0)] * J[geno1(0, k)][geno2(0, k)];
+    tmp[k] = F.h2[FreqProducts::at(k, 0)] * J[geno1(0, k)][geno2(0, k)];
 #pragma unroll
-    for (int h = 1; h < 4; ++h) tmp += F.h2[FreqProducts::at(k, h)] * J[geno1(h, k)][geno2(h, k)];
-    out[k] = tmp / sum;
+    for (int h = 1; h < 4; ++h) tmp[k] += F.h2[FreqProducts::at(k, h)] * J[geno1(h, k)][geno2(h, k)];
+  }
+  // The four IEEE divisions by ONE denominator.  What the compiler makes of `tmp / sum` on gfx950 is, per quotient:
+  // v_div_scale x 2, v_rcp_f64, two Newton steps on the reciprocal (4 FMAs), q0 = n * r, e = fma(-d, q0, n), v_div_fmas
+  // (fma(e, r, q0), then the scaling undone) and v_div_fixup (special operands) -- 11 instructions, one of them the quarter-rate
+  // v_rcp_f64: the four of them were 39 % of the issue cycles of an individual's step.  Where v_div_scale would hand both operands
+  // through unchanged and v_div_fixup would hand the quotient through -- denominator and numerators ordinary numbers well inside
+  // the exponent range, div_operands_plain below -- the refined reciprocal depends on the denominator only and is formed ONCE:
+  // the same instructions on the same operands as the compiler's sequence, hence the same bits (rcp + 4 FMAs, then mul + 2 FMAs
+  // per quotient).  A wavefront with one lane outside that range (likelihoods of ~1e-200, a frequency that has reached a
+  // denormal) takes the compiler's divisions for that individual, all lanes: tests/test_gpu_replay_lkl.py holds both ways to the
+  // host's quotients bit for bit.
+  int plain = div_operand_plain<false>(sum);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) plain &= div_operand_plain<true>(tmp[k]);
+  if (__builtin_amdgcn_ballot_w64(counts && plain == 0) == 0) {
+    double r = __builtin_amdgcn_rcp(sum);
+    r = fma(r, fma(-sum, r, 1.0), r);
+    r = fma(r, fma(-sum, r, 1.0), r);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double q0 = tmp[k] * r;
+      out[k] = fma(fma(-sum, q0, tmp[k]), r, q0);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = tmp[k] / sum;
   }
 }
 
@@ -298,8 +342,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
               for (int g = 0; g < 3; ++g) asm volatile("" : "+v"(b[j][g]));
               double o[4];
-              quotients(F, a[j], b[j], o);
               const bool on = (valid >> j) & 1u;
+              quotients(F, a[j], b[j], o, on);
               const int i = (wave * kSlots + j) * 64 + lane;
 #pragma unroll
               for (int k = 0; k < 4; ++k) quo[k * kRow + i] = on ? o[k] : 0.0;

@@ -377,3 +377,29 @@ def test_cohorts_beyond_the_wavefront_kernel_are_replayed_by_the_lanes(eng, n_in
     assert got[4]["exact_store"] == 2 and got[4]["pairs_on_device"] > 100 and got[4]["pairs_on_host"] * 10 < got[4]["pairs_on_device"]
     assert_same_records(got, want)
     eng.set_exact_store(1)
+
+
+@pytest.mark.parametrize("n_ind,ign", [(100, False), (500, False), (500, True), (700, False), (1500, True)])
+def test_quotients_outside_the_shared_reciprocals_range_take_the_plain_divisions(eng, n_ind, ign):
+    """The replay kernels form an individual's four quotients tmp_k / sum with ONE refined reciprocal where the hardware's
+    division sequence would hand its operands through unscaled (ld_replay_lkl.hip: div_operand_plain), and with the compiler's
+    own four divisions where it would not: numerators below 2^-600, products that underflowed to a denormal.  Likelihoods
+    of 1e-100 .. 1e-170 beside ordinary ones put individuals of both kinds -- and exact zeros -- into every pair; the records
+    are the host replay's (IEEE divisions on the CPU), bit for bit, on the wavefront-per-pair kernel (100, 500 individuals)
+    and on the lane-per-pair kernel (700, 1,500)."""
+    n_sites = 60 if n_ind <= 512 else 30
+    raw = uncalled(n_sites, n_ind, seed=777 + n_ind, depth=6.0, mono_frac=0.3, missing=ign)
+    rng = np.random.default_rng(4321 + n_ind)
+    tiny = rng.random((n_sites, n_ind)) < 0.15
+    scale = np.where(rng.random((n_sites, n_ind)) < 0.5, 1e-100, 1e-170)
+    major = np.argmax(raw, axis=2)
+    for g in range(3):                               # the two likelihoods that are not the individual's largest, scaled down
+        hit = tiny & (major != g) & ~np.all(raw == raw[:, :, :1], axis=2)
+        raw[:, :, g] = np.where(hit, raw[:, :, g] * scale, raw[:, :, g])
+    host = run_records(eng, raw, 0, ign)
+    dev = run_records(eng, raw, 2, ign)
+    assert host[4]["pairs_flagged"] == dev[4]["pairs_flagged"] > 50
+    assert dev[4]["exact_store"] == 2 and dev[4]["pairs_on_device"] > 50
+    assert dev[4]["pairs_on_device"] + dev[4]["pairs_on_host"] == dev[4]["pairs_replayed"] == host[4]["pairs_replayed"]
+    assert_same_records(host, dev)
+    eng.set_exact_store(1)
