@@ -387,7 +387,10 @@ def test_quotients_outside_the_shared_reciprocals_range_take_the_plain_divisions
     of 1e-100 .. 1e-170 beside ordinary ones put individuals of both kinds -- and exact zeros -- into every pair; the records
     are the host replay's (IEEE divisions on the CPU), bit for bit, on the wavefront-per-pair kernel (100, 500 individuals)
     and on the lane-per-pair kernel (700, 1,500)."""
-    n_sites = 60 if n_ind <= 512 else 30
+    # (large cohorts: the matrix of test_large_cohorts_take_the_lanes_on_short_launches_with_a_cap, whose 260 sites in windows of 30
+    # flag hundreds of pairs -- 30 sites of 1,500 individuals at this depth flag none)
+    n_sites = 60 if n_ind <= 512 else 260
+    plan = {} if n_ind <= 512 else {"max_snp_dist": 30}
     raw = uncalled(n_sites, n_ind, seed=777 + n_ind, depth=6.0, mono_frac=0.3, missing=ign)
     rng = np.random.default_rng(4321 + n_ind)
     tiny = rng.random((n_sites, n_ind)) < 0.15
@@ -396,10 +399,10 @@ def test_quotients_outside_the_shared_reciprocals_range_take_the_plain_divisions
     for g in range(3):                               # the two likelihoods that are not the individual's largest, scaled down
         hit = tiny & (major != g) & ~np.all(raw == raw[:, :, :1], axis=2)
         raw[:, :, g] = np.where(hit, raw[:, :, g] * scale, raw[:, :, g])
-    host = run_records(eng, raw, 0, ign)
-    dev = run_records(eng, raw, 2, ign)
-    assert host[4]["pairs_flagged"] == dev[4]["pairs_flagged"] > 50
-    assert dev[4]["exact_store"] == 2 and dev[4]["pairs_on_device"] > 50
+    host = run_records(eng, raw, 0, ign, **plan)
+    dev = run_records(eng, raw, 2, ign, **plan)
+    assert host[4]["pairs_flagged"] == dev[4]["pairs_flagged"] > 50, (host[4], dev[4])
+    assert dev[4]["exact_store"] == 2 and dev[4]["pairs_on_device"] > 50, dev[4]
     assert dev[4]["pairs_on_device"] + dev[4]["pairs_on_host"] == dev[4]["pairs_replayed"] == host[4]["pairs_replayed"]
     assert_same_records(host, dev)
     eng.set_exact_store(1)
