@@ -92,7 +92,7 @@ struct FreqProducts {
 // An operand of an f64 division that V_DIV_SCALE_F64 hands through unchanged and without raising VCC, whatever the other
 // operand, provided that one passes this test too: a positive number in [2^-600, 2^100) -- the denominator is then neither
 // denormal nor is its reciprocal, the exponents differ by less than 768, the quotient is no denormal, and the numerator's
-// biased exponent is above 53 (the instruction's own list of cases, CDNA3 ISA 6.4 "V_DIV_SCALE_F64") -- or, for a numerator
+// biased exponent is above 53 (the list of cases in the instruction set manual's description of V_DIV_SCALE_F64) -- or, for a numerator
 // (ZERO_OK), +0 exactly: n * r, fma(-d, +0, +0) and fma(+0, r, +0) are +0, which is what V_DIV_FIXUP_F64 makes of 0 / d.
 // Negative numbers, -0, NaN, infinities, denormals and anything tiny or huge fail: such an individual's quotients are the
 // compiler's own divisions.
@@ -132,14 +132,15 @@ __device__ __forceinline__ void quotients(const FreqProducts &F, const double (&
   }
   // The four IEEE divisions by ONE denominator.  What the compiler makes of `tmp / sum` on gfx950 is, per quotient:
   // v_div_scale x 2, v_rcp_f64, two Newton steps on the reciprocal (4 FMAs), q0 = n * r, e = fma(-d, q0, n), v_div_fmas
-  // (fma(e, r, q0), then the scaling undone) and v_div_fixup (special operands) -- 11 instructions, one of them the quarter-rate
-  // v_rcp_f64: the four of them were 39 % of the issue cycles of an individual's step.  Where v_div_scale would hand both operands
+  // (fma(e, r, q0), then the scaling undone) and v_div_fixup (special operands) -- 11 instructions: the four of them were 44 of
+  // the 135 instructions of an individual's step.  Where v_div_scale would hand both operands
   // through unchanged and v_div_fixup would hand the quotient through -- denominator and numerators ordinary numbers well inside
-  // the exponent range, div_operands_plain below -- the refined reciprocal depends on the denominator only and is formed ONCE:
+  // the exponent range, div_operand_plain above -- the refined reciprocal depends on the denominator only and is formed ONCE:
   // the same instructions on the same operands as the compiler's sequence, hence the same bits (rcp + 4 FMAs, then mul + 2 FMAs
-  // per quotient).  A wavefront with one lane outside that range (likelihoods of ~1e-200, a frequency that has reached a
-  // denormal) takes the compiler's divisions for that individual, all lanes: tests/test_gpu_replay_lkl.py holds both ways to the
-  // host's quotients bit for bit.
+  // per quotient; 33 instructions with the test).  A wavefront with one lane outside that range (likelihoods of ~1e-200, a
+  // frequency that has reached a denormal) takes the compiler's divisions for that individual, all lanes:
+  // tests/test_gpu_replay_lkl.py holds both ways to the host's quotients bit for bit.  Lane kernel 338 -> 315 ms for 31.2e6
+  // pairs (profiles/r05/late/shared_rcp); since then it is bound by the bytes it re-reads, not by its instructions.
   int plain = div_operand_plain<false>(sum);
 #pragma unroll
   for (int k = 0; k < 4; ++k) plain &= div_operand_plain<true>(tmp[k]);
