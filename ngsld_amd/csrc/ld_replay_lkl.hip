@@ -39,6 +39,8 @@
 #include "ld_replay.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include <hipcub/hipcub.hpp>
 
@@ -505,11 +507,16 @@ __global__ __launch_bounds__(256) void replay_expand_kernel(ReplayLklArgs A, Rep
   A.bits[w] &= ~take;  // (this thread owns the word)
 }
 
-// Sort keys of the listed pairs: (the pair's rarer site, its other site).  A wavefront's lanes take NEIGHBOURS of the sorted
-// list, so for one individual they read ONE triple of the site they share and triples of (nearly) consecutive other sites --
-// a monomorphic site's partners, whether it is the pair's row or its candidate; in list order half the pairs of an un-called
-// matrix (ordinary row, monomorphic candidate) had a cache line to themselves per lane and individual.
-__global__ void replay_keys_kernel(ReplayLklArgs A, const ReplayEntry *list, uint64_t list_cap, uint64_t *keys, uint32_t *vals, int site_bits) {
+// Sort keys of the listed pairs, from (the pair's rarer site, its other site).  A wavefront's lanes take NEIGHBOURS of the sorted
+// list; in list order half the pairs of an un-called matrix (ordinary row, monomorphic candidate) had a cache line to themselves
+// per lane and individual.  Sorted by (rarer site, other site) the 64 lanes read ONE triple of the site they share and 64
+// (nearly) consecutive others per individual -- and, re-reading them in every EM step from a copy no cache holds, the kernel ran
+// at what HBM delivers (1.6 TB a launch).  So the key is TILED: [rarer site / 2^tile_s][other / 2^tile_o][rarer %
+// 2^tile_s][other % 2^tile_o] -- the same bits in another order.  Rare sites that are neighbours have the same partners (their
+// windows overlap), so 64 neighbours of the sorted list are a block of a few rare sites x 8 of their partners: a dozen or two
+// distinct triples per individual instead of 65.  (tile_s = tile_o = 0: the plain order.)
+__global__ void replay_keys_kernel(ReplayLklArgs A, const ReplayEntry *list, uint64_t list_cap, uint64_t *keys, uint32_t *vals, int site_bits,
+                                   int tile_s, int tile_o) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= list_cap) return;
   vals[i] = (uint32_t)i;
@@ -522,7 +529,8 @@ __global__ void replay_keys_kernel(ReplayLklArgs A, const ReplayEntry *list, uin
   const double r1 = m1 <= 0.5 ? m1 : 1 - m1, r2 = m2 <= 0.5 ? m2 : 1 - m2;  // (NaN: compares false, the row's site is the shared one)
   const bool by2 = r2 < r1;
   const uint64_t shared = by2 ? e.s2 : e.s1, other = by2 ? e.s1 : e.s2;
-  keys[i] = (shared << site_bits) | other;
+  const uint64_t s_hi = shared >> tile_s, s_lo = shared & ((1ull << tile_s) - 1), o_hi = other >> tile_o, o_lo = other & ((1ull << tile_o) - 1);
+  keys[i] = (((s_hi << (site_bits - tile_o)) | o_hi) << (tile_s + tile_o)) | (s_lo << tile_o) | o_lo;
 }
 
 constexpr uint32_t kLaneChunk = 256;  // sorted entries a wavefront claims at a time
@@ -706,7 +714,18 @@ hipError_t launch_replay_sort(const ReplayLklArgs &a, const ReplayEntry *list, u
   if (list_cap == 0) return hipSuccess;
   if (list_cap > 0x7fffffffull) return hipErrorInvalidValue;
   const int bits = replay_site_bits(a.n_sites);
-  hipLaunchKernelGGL(replay_keys_kernel, dim3((unsigned)((list_cap + 255) / 256)), dim3(256), 0, stream, a, list, list_cap, keys_a, vals_a, bits);
+  int tile_s = 5, tile_o = 3;  // 32 consecutive sites (a handful of them rare) x 8 partners
+  if (const char *v = std::getenv("NGSLD_REPLAY_TILE")) {  // A/B: "s,o" (0,0 = sorted by rarer site, then the other)
+    int ts = 0, to = 0;
+    if (std::sscanf(v, "%d,%d", &ts, &to) == 2 && ts >= 0 && to >= 0) {
+      tile_s = ts;
+      tile_o = to;
+    }
+  }
+  tile_s = std::min(tile_s, bits);
+  tile_o = std::min(tile_o, bits);
+  hipLaunchKernelGGL(replay_keys_kernel, dim3((unsigned)((list_cap + 255) / 256)), dim3(256), 0, stream, a, list, list_cap, keys_a, vals_a, bits,
+                     tile_s, tile_o);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_a, keys_b, vals_a, vals_b, (int)list_cap, 0, 2 * bits, stream);
