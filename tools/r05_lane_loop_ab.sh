@@ -4,6 +4,7 @@
 #               ngsld_amd/ab/libngsld_v1.so  two register sets used in turn (142 registers: three wavefronts to a SIMD)
 #   baseline    ngsld_amd/ab/libngsld_rcp.so the tree before (shared reciprocal, staging set copied into place)
 #   (CANDIDATES=v3: the shared reciprocal without its per-individual branch -- the step taken again with plain divisions if a lane asks)
+#   (ROUNDS=1 NO_SUITE=1: the comparison alone, once)
 # Same-box bench.py --mono-frac 0.2 of the three, two rounds; the faster candidate, if it beats the baseline by 1 %, becomes
 # ngsld_amd/libngsld.so ON THE BOX and the GPU suite runs on it.  Output under gpurun_out/lane_loop/ (chosen.txt names it).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -14,7 +15,7 @@ one() {  # ms per step of bench.py --mono-frac 0.2 on library $1
     python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['config'].get('replay_rank0_last_step',{}); print('%.2f %.5g %s %s %s' % (d['ms_per_step'], d['value'], r.get('pairs_on_device'), r.get('pairs_on_host'), d['config']['rank_records'][0]['records_checksum_u64']))"
 }
 : > $O/ab.txt
-for r in 1 2; do for v in rcp ${CANDIDATES:-v2 v1}; do echo "round $r $v $(one $AB/libngsld_$v.so)" | tee -a $O/ab.txt; done; done
+for r in $(seq 1 ${ROUNDS:-2}); do for v in rcp ${CANDIDATES:-v2 v1}; do echo "round $r $v $(one $AB/libngsld_$v.so)" | tee -a $O/ab.txt; done; done
 best=$(python - <<PY
 import collections
 ms=collections.defaultdict(list); chk=collections.defaultdict(set)
@@ -27,7 +28,7 @@ print(min(ok, key=lambda k:m[k]) if ok else "none")
 PY
 )
 echo "chosen: $best" | tee $O/chosen.txt
-if [ "$best" != none ]; then
+if [ "$best" != none ] && [ -z "$NO_SUITE" ]; then
   cp $AB/libngsld_$best.so ngsld_amd/libngsld.so
   ( time python -m pytest tests -m gpu -q -p no:cacheprovider --maxfail=8 ) > $O/pytest_gpu.txt 2>&1
   grep -v "^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" $O/pytest_gpu.txt | tail -6
