@@ -46,9 +46,11 @@ def test_cohort_sizes_past_the_old_cliffs_keep_their_rate(n_ind, floor):
 # exact-order replay; on host threads (rounds 1-4) the pass ran at 2.2e6 pairs/s, on the device (ld_replay_lkl.hip) at 1.3e8
 # (2.15e8 with the log-uniform spectrum) on a 2.2 GHz box (profiles/r05/d); 1.27e8 / 1.78e8 on the pool's slowest
 # (profiles/r05/final_slow_box).  The floors were half of that; late in round 5 a hand-back test inside the lane kernel cost its
-# long launches 30 % (1.30e8 -> 1.14e8) and no test saw it -- they are 15 % under the slowest box now.
+# long launches 30 % (1.30e8 -> 1.14e8) and no test saw it -- they are 15 % under the slowest box now.  (Last session of round 5:
+# shared reciprocal and tiled sort key, 1.42e8 .. 1.46e8 / 2.27e8 on three boxes, profiles/r05/late/tile -- floors 1.15e8 / 1.6e8,
+# still more than 15 % under what the slowest box of the pool would show.)
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("flags,floor", [(["--mono-frac", "0.2"], 1.08e8), (["--sfs"], 1.5e8)])
+@pytest.mark.parametrize("flags,floor", [(["--mono-frac", "0.2"], 1.15e8), (["--sfs"], 1.6e8)])
 def test_uncalled_input_is_replayed_on_the_device(flags, floor):
     cmd = [sys.executable, "bench.py", "--config", "c2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-sink", "--no-e2e",
            "--no-traffic"] + flags
