@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the file -> TSV leg of the drop-in binary")
     ap.add_argument("--no-unfiltered", action="store_true",
                     help="skip the `unfiltered_input` leg (the same pass on 10,000 sites that are NOT SNP-called)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` leg (configs[1] whole, one rank's shard of configs[3] and configs[4], a pass each)")
     ap.add_argument("--ignore-miss", action="store_true", help="run the --ignore_miss_data kernels (not the headline config)")
     ap.add_argument("--rnd-sample", type=float, default=1.0, help="--rnd_sample of the plan (not the headline config)")
     ap.add_argument("--hard-calls", action="store_true",
@@ -309,7 +311,7 @@ def measure_traffic(args) -> dict | None:
     if not os.path.exists(exe):
         return None
     child = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--config", args.config, "--steps", "1",
-             "--warmup", "0", "--no-cpu", "--no-sink", "--no-e2e", "--no-traffic", "--no-unfiltered", "--sites", str(args.sites), "--ind",
+             "--warmup", "0", "--no-cpu", "--no-sink", "--no-e2e", "--no-traffic", "--no-unfiltered", "--no-other-configs", "--sites", str(args.sites), "--ind",
              str(args.ind), "--max-kb", str(args.max_kb), "--max-gap", str(args.max_gap), "--scaling", args.scaling,
              "--depth", repr(args.depth), "--seed", str(args.seed), "--rnd-sample", repr(args.rnd_sample),
              "--mono-frac", repr(args.mono_frac)]
@@ -400,6 +402,95 @@ def unfiltered_input_leg(n_sites: int, n_ind: int, max_kb: int, max_gap: int, de
             eng.close()
         del raw, host
         torch.cuda.empty_cache()
+    return out
+
+
+def other_configs_leg(dev_index: int, depth: float, seed: int, world: int = 8) -> dict:
+    """The other BASELINE configurations in front of the driver, one pass each on this one device, outside the timed region:
+    configs[1] at full size (5,000 x 100, all 12,497,500 pairs) and ONE rank's shard of the two 8-GPU configurations -- the rows
+    shard.split_rows deals to rank world // 2 of `world`, with the sites of their windows -- configs[3] (50,000 x 1,000, all
+    pairs) and configs[4] (1,000,000 x 2,000, 500 kb: the shard's own slab of sites is generated, 1 / world of the genome).  Per
+    configuration: pairs/s of the pass (ngsld_run_device + ngsld_finish_device, replay inside), the pair kernel's launch time
+    (HIP events on the launch stream), roofline.frac on algorithmic bytes, the FP64 VALU fraction (the binding roofline), and
+    the wrap-around checksum of every record word."""
+    import torch
+    from ngsld_amd import capi, shard, synth
+    dev = torch.device("cuda", dev_index)
+    out = {}
+    for key in ("c1", "c3", "c4"):
+        cfg = CONFIGS[key]
+        n_ind, max_kb = cfg["ind"], cfg["max_kb"]
+        t_all = time.perf_counter()
+        if key == "c1":
+            n_sites, lo, hi, slab_lo = cfg["sites"], 0, cfg["sites"], 0
+            chrs, pos = synth.make_positions(n_sites, seed, max_gap=cfg["max_gap"])
+            pd = shard.pos_dist_from_positions(chrs, pos)
+            raw = synth.make_gl_torch(n_sites, n_ind, seed, dev, depth=depth)
+            share = "the whole configuration"
+        else:
+            total = cfg["sites"]
+            chrs, pos = synth.make_positions(total, seed, max_gap=cfg["max_gap"])
+            pd_all = shard.pos_dist_from_positions(chrs, pos)
+            row_end = shard.row_ends(pd_all, max_kb, 0)
+            counts = row_end - (np.arange(total, dtype=np.int64) + 1)
+            lo, hi = shard.split_rows(counts, world)[world // 2]
+            slab_lo, slab_hi = shard.slab_for_rows(row_end, lo, hi)
+            n_sites = int(slab_hi - slab_lo)
+            pd = pd_all[slab_lo:slab_hi].copy()
+            # (the slab's own sites: a matrix of the slab's size with the configuration's generator -- the other ranks' sites are
+            # never looked at by this rank's rows)
+            raw = synth.make_gl_torch(n_sites, n_ind, seed + 1, dev, depth=depth)
+            share = f"rank {world // 2} of {world}: rows [{int(lo)}, {int(hi)}) of {total}, sites [{int(slab_lo)}, {int(slab_hi)})"
+        eng = capi.Engine(dev_index)
+        try:
+            eng.set_geno_raw(raw.data_ptr(), n_sites=n_sites, n_ind=n_ind)
+            if raw.numel() * 8 <= (2 << 30):
+                host = raw.cpu().numpy()
+                eng.set_replay_source(host)
+            del raw
+            torch.cuda.empty_cache()
+            eng.set_pos_dist(pd)
+            eng.plan(max_kb_dist=max_kb, extend_out=True)
+            row_off, _ = eng.plan_rows()
+            r0, r1 = int(lo - slab_lo), int(hi - slab_lo)
+            n_pairs = int(row_off[r1] - row_off[r0])
+            d_std = torch.empty(max(n_pairs, 1) * STD_BYTES, dtype=torch.uint8, device=dev)
+            d_ext = torch.empty(max(n_pairs, 1) * EXT_BYTES, dtype=torch.uint8, device=dev)
+            st = torch.cuda.current_stream().cuda_stream
+
+            def one():
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                eng.run_device(r0, r1, d_std.data_ptr(), d_ext.data_ptr(), st)
+                eng.finish_device()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                ms, nl, _ = eng.last_kernel_time()
+                return dt, ms, nl
+            one()
+            passes = [one() for _ in range(3 if key == "c1" else 1)]
+            dt, ms, nl = min(passes)
+            ext_i32 = d_ext.view(torch.int32).view(-1, EXT_BYTES // 4)
+            mean_exec = float(torch.clamp(ext_i32[:n_pairs, 9].to(torch.float64) + 1, max=100).mean()) if n_pairs else 0.0
+            words = int(d_std.view(torch.int64)[:n_pairs * (STD_BYTES // 8)].sum()) + int(d_ext.view(torch.int64)[:n_pairs * (EXT_BYTES // 8)].sum())
+            bytes_pair = 48 * n_ind + STD_BYTES + EXT_BYTES
+            kernel_s = ms / 1e3
+            tflops = 2.0 * n_pairs * n_ind * mean_exec * 20.0 / kernel_s / 1e12
+            out[key] = {"workload": f"{cfg['name']}: {cfg['sites']} sites x {n_ind} ind, --max_kb_dist {max_kb}; {share}",
+                        "pairs": n_pairs, "value": n_pairs / dt, "unit": "pairs/s", "ms_per_pass": dt * 1e3,
+                        "kernel": eng.pair_kernel(), "kernel_ms_per_pass": ms, "kernel_launches": nl,
+                        "mean_executed_em_iterations": round(mean_exec, 3),
+                        "roofline": {"bound": "hbm", "algorithmic_bytes_per_pair": bytes_pair,
+                                     "achieved": bytes_pair * n_pairs / kernel_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": bytes_pair * n_pairs / kernel_s / 1e9 / HBM_PEAK_GBS},
+                        "fp64_valu": {"achieved": tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_PEAK_TFLOPS},
+                        "records_checksum_u64": words % (1 << 64), "replay": eng.replay_info(),
+                        "leg_seconds": None}
+            del d_std, d_ext
+        finally:
+            eng.close()
+        torch.cuda.empty_cache()
+        out[key]["leg_seconds"] = round(time.perf_counter() - t_all, 2)
     return out
 
 
@@ -537,6 +628,10 @@ def main():
     # path can be exercised on a 1-GPU box; the driver's runs use one GPU per rank over RCCL (backend nccl).
     one_dev = os.environ.get("NGSLD_BENCH_ONE_DEVICE") == "1"
     dev_index = 0 if one_dev else local_rank
+    if world > 1 and not one_dev and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py --gpus {world}: rank {rank} (local rank {local_rank}) has no device of its own -- "
+                         f"{torch.cuda.device_count()} visible; one GPU per rank, or NGSLD_BENCH_ONE_DEVICE=1 for a dry run of the "
+                         "N > 1 path on one device (not a scaling measurement)")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -546,6 +641,12 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # every rank adds 1: what the collective library itself saw of the job (the SCALE record checks itself)
+    ranks_seen = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(one.item())
 
     strong = args.scaling == "strong"
     n_sites = args.sites if strong else args.sites * world
@@ -629,6 +730,9 @@ def main():
         unfiltered = unfiltered_input_leg(10_000, n_ind, args.max_kb, args.max_gap, args.depth, dev_index)
     del slab, raw
     torch.cuda.empty_cache()
+    other_configs = None
+    if rank == 0 and headline and not args.no_other_configs and args.config == "c2" and not args.custom and not profiled:
+        other_configs = other_configs_leg(dev_index, args.depth, args.seed)
 
     d_std = torch.empty(max(n_pairs, 1) * STD_BYTES, dtype=torch.uint8, device=dev)
     d_ext = torch.empty(max(n_pairs, 1) * EXT_BYTES, dtype=torch.uint8, device=dev)
@@ -732,7 +836,8 @@ def main():
             "sum_r2_finite": float(r2_col[torch.isfinite(r2_col)].sum()) if n_pairs else 0.0,
             "records_checksum_u64": (int(words_std.sum()) + int(words_ext.sum())) % (1 << 64) if n_pairs else 0,
             "mean_executed_iterations": round(mean_exec, 4), "kernel_ms_per_launch": kernel_ms / max(launches, 1),
-            "seconds": elapsed, "device": torch.cuda.get_device_name(dev), "device_index": dev_index}
+            "seconds": elapsed, "device": torch.cuda.get_device_name(dev), "device_index": dev_index,
+            "gl_broadcast_s": round(t_bc, 4)}
     rank_records = [mine]
     if world > 1:
         rank_records = [None] * world
@@ -769,6 +874,7 @@ def main():
                        "rank_records": rank_records,
                        "backend": ("gloo, every rank on GPU 0 (NGSLD_BENCH_ONE_DEVICE=1: a dry run of the N > 1 path, not a "
                                    "scaling measurement)" if one_dev else "nccl (RCCL)") if world > 1 else None,
+                       "rccl_ranks_seen": ranks_seen,   # an all_reduce of ones over the job's backend (1 when there is no collective to run)
                        "pairs_replayed_exact_order_rank0_last_step": replayed[0],
                        "replay_rank0_last_step": replay_info,
                        "first_pass_s_rank0": round(t_first, 4) if first_in_warmup else None,
@@ -782,6 +888,7 @@ def main():
                                   "ranks, MAX over ranks",
             "e2e_file_to_tsv_s": e2e,
             "unfiltered_input": unfiltered,
+            "other_configs": other_configs,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "traffic_per_pair": None, "traffic_detail": None,

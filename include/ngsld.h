@@ -235,6 +235,9 @@ typedef struct {
   int32_t exact_store;         /* 0 none, 1 the planes themselves serve as the store, 2 built from the replay source */
   int32_t text_rows_patched;   /* text runs: rows of pairs replayed on the host whose value columns were overwritten in the host's copy of the text */
   double exact_store_build_s;  /* host seconds the build took (once per matrix) */
+  uint64_t sites_degenerate;   /* (0.4.0) sites of the matrix marked degenerate -- their one-locus EM ends below 3e-6: the pair kernels leave
+                                  the EM of such a site's pairs to the exact-order replay, which was going to start them over (0 on SNP-called
+                                  input, or where the device cannot replay: nothing is skipped then) */
 } ngsld_replay_stats_t;
 int ngsld_replay_info(ngsld_ctx *ctx, ngsld_replay_stats_t *out);
 
@@ -305,6 +308,11 @@ int ngsld_plan_slabs(const double *pos_dist, uint64_t n_sites, const ngsld_param
  * the device-side replay with its individual-major copy, which input that is not SNP-called makes the library build); 0 when
  * the budget is too small for any. */
 uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes);
+/* (0.4.0) The same with the matrix priced `matrix_copies` times per context: 1 = the planes only -- what a run NEEDS (SNP-called
+ * input never builds the store; un-called input without room for it has its flagged pairs replayed on host threads, slower and
+ * the same bytes), 3 = ngsld_slab_sites_for_budget.  A caller that cannot stream (text input, no window) asks with 1 before it
+ * gives up. */
+uint64_t ngsld_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes, int matrix_copies);
 
 /* Free and total memory of HIP device `device`, in bytes. */
 int ngsld_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);

@@ -5,4 +5,4 @@ The product is the C-ABI library built from ``ngsld_amd/csrc`` (hand-written HIP
 thin host-side plumbing around that library: the ctypes binding, build helpers, the synthetic-input
 generator and the multi-GPU sharding helpers used by ``bench.py`` and the tests.
 """
-__version__ = "0.3.0"
+__version__ = "0.4.0"

@@ -86,7 +86,7 @@ SYMBOLS = [
     "ngsld_set_exact_store", "ngsld_replay_info",
     "ngsld_plan_parts", "ngsld_run_multi", "ngsld_multi_last_distribution", "ngsld_rccl_selftest",
     "ngsld_last_kernel_time", "ngsld_pair_kernel", "ngsld_describe_dispatch", "ngsld_set_tuning", "ngsld_selftest", "ngsld_reserve_text_buffers",
-    "ngsld_window_ends", "ngsld_plan_slabs", "ngsld_slab_sites_for_budget", "ngsld_device_memory", "ngsld_run_streamed", "ngsld_run_streamed_text",
+    "ngsld_window_ends", "ngsld_plan_slabs", "ngsld_slab_sites_for_budget", "ngsld_sites_for_budget", "ngsld_device_memory", "ngsld_run_streamed", "ngsld_run_streamed_text",
     "ngsld_host_read_geno_bin_range",
     "ngsld_host_set_threads", "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos", "ngsld_host_pos_slice",
     "ngsld_host_geno_size_ok", "ngsld_host_read_geno_bin", "ngsld_host_read_geno_text", "ngsld_host_format_header", "ngsld_host_format_pair",
@@ -99,7 +99,7 @@ class ReplayStats(C.Structure):
     """ngsld_replay_stats_t (include/ngsld.h)."""
     _fields_ = [("pairs_flagged", C.c_uint64), ("pairs_replayed", C.c_uint64), ("pairs_on_device", C.c_uint64),
                 ("pairs_on_host", C.c_uint64), ("sites_reevaluated", C.c_uint64), ("exact_store", C.c_int32),
-                ("text_rows_patched", C.c_int32), ("exact_store_build_s", C.c_double)]
+                ("text_rows_patched", C.c_int32), ("exact_store_build_s", C.c_double), ("sites_degenerate", C.c_uint64)]
 
 
 class NgsldError(RuntimeError):
@@ -165,6 +165,8 @@ def lib() -> C.CDLL:
         L.ngsld_plan_slabs.argtypes = [vp, u64, C.POINTER(Params), u64, vp, u64, C.POINTER(u64)]
         L.ngsld_slab_sites_for_budget.argtypes = [u64, u64]
         L.ngsld_slab_sites_for_budget.restype = u64
+        L.ngsld_sites_for_budget.argtypes = [u64, u64, C.c_int]
+        L.ngsld_sites_for_budget.restype = u64
         L.ngsld_device_memory.argtypes = [C.c_int, C.POINTER(u64), C.POINTER(u64)]
         L.ngsld_run_streamed.argtypes = [C.c_int, u64, u64, vp, C.POINTER(Params), C.POINTER(GenoOpts), u64, READ_FN, vp,
                                          vp, SINK_FN, vp, C.POINTER(u64), C.POINTER(u64), C.c_char_p, C.c_size_t]
@@ -277,6 +279,11 @@ def plan_slabs(pos_dist: np.ndarray | None, n_sites: int, max_slab_sites: int, *
 
 def slab_sites_for_budget(n_ind: int, budget_bytes: int) -> int:
     return int(lib().ngsld_slab_sites_for_budget(n_ind, budget_bytes))
+
+
+def sites_for_budget(n_ind: int, budget_bytes: int, matrix_copies: int) -> int:
+    """ngsld_sites_for_budget: the matrix priced matrix_copies times per context (1: the planes alone; 3: with the exact store)."""
+    return int(lib().ngsld_sites_for_budget(n_ind, budget_bytes, matrix_copies))
 
 
 def device_memory(device: int = 0) -> tuple[int, int]:

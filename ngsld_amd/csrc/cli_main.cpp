@@ -596,15 +596,21 @@ int main(int argc, char **argv) {
     budget = (uint64_t)(0.9 * (double)free_b);
     if (pars.max_gpu_mem > 0 && pars.max_gpu_mem * 1e9 < (double)budget) budget = (uint64_t)(pars.max_gpu_mem * 1e9);
   }
-  // resident = one context holding every site; ngsld_slab_sites_for_budget prices two, so ask with twice the budget
+  // resident = one context holding every site; the budget helpers price two, so ask with twice the budget.  `fits`: with room
+  // for the exact store of the device-side replay beside the planes (the matrix three times: un-called input builds it);
+  // `fits_bare`: the planes alone -- what a run needs; without room for the store its flagged pairs are replayed on host threads
   const bool fits = ngsld_slab_sites_for_budget(pars.n_ind, 2 * budget) >= pars.n_sites;
+  const bool fits_bare = fits || ngsld_sites_for_budget(pars.n_ind, 2 * budget, 1) >= pars.n_sites;
+  const bool streamable = pars.in_bin && (pars.max_kb_dist > 0 || pars.max_snp_dist > 0);
   uint64_t slab_sites = 0;  // > 0: run slab by slab
   if (const char *e = getenv("NGSLD_SLAB_SITES")) {  // tests: stream a small file in slabs of n sites
     if (pars.in_bin) slab_sites = strtoull(e, nullptr, 10);
-  } else if (!fits) {
+  } else if (!fits && !(fits_bare && !streamable)) {
+    // (a windowed run on binary input that fits only without the store is streamed too: every slab then has room for its own)
     if (!pars.in_bin)
       error(__FUNCTION__, "the genotype matrix does not fit the device memory budget (only binary input is streamed)");
     slab_sites = ngsld_slab_sites_for_budget(pars.n_ind, budget);
+    if (slab_sites < 2) slab_sites = ngsld_sites_for_budget(pars.n_ind, budget, 1);  // (slabs without room for the store before none at all)
     if (slab_sites < 2) error(__FUNCTION__, "the device memory budget is too small for this number of individuals");
   } else if (pars.in_bin && (pars.max_kb_dist > 0 || pars.max_snp_dist > 0) && (uint64_t)st.st_size >= (4ull << 30) &&
              !(getenv("NGSLD_PIPELINE") && strcmp(getenv("NGSLD_PIPELINE"), "0") == 0)) {
@@ -621,7 +627,7 @@ int main(int argc, char **argv) {
     early.started = early.pos_done = false;
     ngsld_destroy(ctx);
     ctx = nullptr;
-    if (run_streamed(pars, slab_sites, /*may_fall_back=*/fits)) return 0;
+    if (run_streamed(pars, slab_sites, /*may_fall_back=*/fits_bare)) return 0;
     if (ngsld_create(pars.device, &ctx) != NGSLD_OK) error("ngsld_create", ngsld_last_error(nullptr));
   }
 

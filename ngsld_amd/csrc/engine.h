@@ -275,6 +275,11 @@ struct ngsld_ctx {
   bool missing_canonical = false;  // text genotypes: every individual without data is the reader's own triple (PrepArgs::odd_missing)
   int h_all_hard = 0, h_prep_status = 0;
   uint32_t mask_words = 0;
+  // degenerate sites (ld_prep.hip, site_skip_kernel): marked per site, in sc4[.][3]; how many there are
+  DevBuf<uint8_t> d_skip;
+  DevBuf<uint32_t> d_skip_count;
+  uint32_t h_skip_count = 0;
+  bool skip_on = true;  // NGSLD_REPLAY_SKIP=0: the pair kernels run the EM of every pair (A/B, tests)
 
   // plan
   bool planned = false;
@@ -370,6 +375,8 @@ struct ngsld_ctx {
   DevBuf<double> d_xplanes, d_xmaf;
   DevBuf<double> d_xT;                 // the store once more, individual-major, for the lane-per-pair kernel (ld_replay_lkl.hip)
   std::atomic<bool> xT_ready{false};
+  DevBuf<uint32_t> d_xperm;            // ... where each site stands in it (rare sites first: ReplayLklArgs::xperm)
+  DevBuf<uint32_t> d_xdepth;              // ... and how small its sites' likelihoods get (ReplayLklArgs::xdepth)
   struct LaneScratch {   // what the lane-per-pair replay of one launch needs: the located pairs and their sorted order
     DevBuf<ReplayEntry> list;
     DevBuf<uint64_t> keys_a, keys_b;

@@ -42,6 +42,8 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   c->d_xplanes.release();
   c->d_xmaf.release();
   c->d_xT.release();
+  c->d_xdepth.release();
+  c->d_xperm.release();
   c->xT_ready = false;
   c->gopts = o;
   c->normalised = normalised;
@@ -150,7 +152,25 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
     if (rc != NGSLD_OK) return rc;
     if (e != hipSuccess) return hip_fail(c, e, "chunked genotype upload");
   }
-  HIP_TRY(c, launch_pack_scalars(c->d_maf.p, c->d_mean.p, c->d_rsx.p, c->d_sc4.p, n_sites, c->stream));
+  // degenerate sites (sites whose pairs the exact-order replay settles anyway: the pair kernels leave their EM out) -- looked
+  // for only where the device-side replay of likelihood matrices can take their pairs
+  c->h_skip_count = 0;
+  // (where it was measured to pay, profiles/r06/skip: one wavefront per pair +6.5 % at 500 individuals, two +4.6 % at 1,000; not the
+  // lockstep kernel -- a wavefront is spared only what all its groups skip: -7 % at 100 -- and not four wavefronts per pair: at
+  // 2,000 individuals a replayed pair costs 7x a computed one and the pairs marked without need outweigh the EM saved, -6 %)
+  const bool look_for_skip = c->skip_on && c->replay_on && c->replay_device && c->exact_mode != 0 &&
+                            (cfg.kernel == kRun || (cfg.kernel == kMulti && cfg.form == 0 && cfg.waves == 2));
+  if (look_for_skip) {
+    HIP_TRY(c, c->d_skip.resize(n_sites));
+    HIP_TRY(c, c->d_skip_count.resize(1));
+    HIP_TRY(c, hipMemsetAsync(c->d_skip_count.p, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, launch_site_skip(c->d_planes.p, 3ull * c->np, c->np, (uint32_t)n_ind, ignore_miss, c->d_maf.p, n_sites, c->d_skip.p,
+                                c->d_skip_count.p, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&c->h_skip_count, c->d_skip_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  } else {
+    c->d_skip.release();
+  }
+  HIP_TRY(c, launch_pack_scalars(c->d_maf.p, c->d_mean.p, c->d_rsx.p, c->d_skip.p, c->d_sc4.p, n_sites, c->stream));
   // Is every likelihood triple a called genotype or "no data" (text genotypes, --call_geno)?  Then the pairs run on the
   // 16 genotype-combination counts instead of the individuals (ld_pair_hard.hip).  NGSLD_HARD_KERNEL=0: never (A/B, tests).
   int &all_hard = c->h_all_hard;  // (ctx-owned: the asynchronous copies below must not target a stack frame an early return leaves)
@@ -198,7 +218,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
 
 extern "C" {
 
-const char *ngsld_version(void) { return "ngsld-amd 0.3.0 (gfx950; reference ngsLD 1.2.1)"; }
+const char *ngsld_version(void) { return "ngsld-amd 0.4.0 (gfx950; reference ngsLD 1.2.1)"; }
 
 int ngsld_create(int device, ngsld_ctx **out) {
   if (out == nullptr) return NGSLD_ERR_INVALID;
@@ -247,6 +267,7 @@ int ngsld_create(int device, ngsld_ctx **out) {
   if (const char *k = std::getenv("NGSLD_REPLAY")) c->replay_on = std::strcmp(k, "0") != 0;  // A/B, tests
   if (const char *k = std::getenv("NGSLD_REPLAY_THREADS")) c->replay_threads = std::atoi(k);
   if (const char *k = std::getenv("NGSLD_REPLAY_DEVICE")) c->replay_device = std::strcmp(k, "0") != 0;
+  if (const char *k = std::getenv("NGSLD_REPLAY_SKIP")) c->skip_on = std::strcmp(k, "0") != 0;  // A/B, tests
   if (const char *k = std::getenv("NGSLD_EXACT_STORE")) c->exact_mode = std::max(0, std::min(2, std::atoi(k)));  // ngsld_set_exact_store
   if (const char *k = std::getenv("NGSLD_RUN_DIRECT")) c->run_direct = std::strcmp(k, "0") != 0;  // A/B, tests (see ngsld_ctx)
   if (const char *k = std::getenv("NGSLD_RUN_TAPER")) c->run_taper = std::strcmp(k, "0") != 0;
@@ -272,9 +293,9 @@ void ngsld_destroy(ngsld_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   if (c->exact_stream) (void)hipStreamDestroy(c->exact_stream);
-  c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_rsx.release(); c->d_sc4.release(); c->d_runs.release();
+  c->d_planes.release(); c->d_maf.release(); c->d_mean.release(); c->d_rsx.release(); c->d_sc4.release(); c->d_runs.release(); c->d_skip.release(); c->d_skip_count.release();
   c->d_hard_masks.release(); c->d_hard_u.release(); c->d_all_hard.release();
-  c->d_xplanes.release(); c->d_xmaf.release(); c->d_xT.release(); c->h_xstage[0].release(); c->h_xstage[1].release();
+  c->d_xplanes.release(); c->d_xmaf.release(); c->d_xT.release(); c->d_xdepth.release(); c->d_xperm.release(); c->h_xstage[0].release(); c->h_xstage[1].release();
   c->lane_scratch_dev.release();
   for (int k = 0; k < ngsld_ctx::kSlots; ++k) c->lane_scratch[k].release();
   c->d_labels.release(); c->d_scan_tmp.release(); c->d_scan_tmp_b.release(); c->d_label_off.release(); c->d_cum.release(); c->d_infc.release();
@@ -434,7 +455,9 @@ int ngsld_selftest(ngsld_ctx *c) try {
   }
   return NGSLD_OK;
 } NGSLD_CATCH(c)
-uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes) {
+uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes) { return ngsld_sites_for_budget(n_ind, budget_bytes, 3); }
+
+uint64_t ngsld_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes, int matrix_copies) {
   PairConfig cfg, cfg_masked;
   // (the engine's own default selection: the slabs hold what it will allocate -- the wider of the two layouts a cohort size
   // can get, with and without --ignore_miss_data)
@@ -446,8 +469,9 @@ uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes) {
   const uint64_t per_ctx = budget_bytes / 2;
   if (per_ctx <= fixed) return 0;
   // (the matrix three times: the planes, and the exact store of the device-side replay with its individual-major copy, which
-  // un-called input has built -- engine_replay.hip)
-  return (per_ctx - fixed) / (72ull * cfg.np + 64ull);
+  // un-called input has built -- engine_replay.hip; once: the planes, what a run cannot do without)
+  const uint64_t copies = matrix_copies < 1 ? 1 : (matrix_copies > 3 ? 3 : (uint64_t)matrix_copies);
+  return (per_ctx - fixed) / (24ull * copies * cfg.np + 64ull);
 }
 
 int ngsld_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {

@@ -167,7 +167,7 @@ int ngsld_plan(ngsld_ctx *c, const ngsld_params *p, uint64_t *n_pairs) try {
     }
     if (changed) {
       HIP_TRY(c, hipMemcpy(c->d_maf.p, c->h_maf.data(), n * sizeof(double), hipMemcpyHostToDevice));
-      HIP_TRY(c, launch_pack_scalars(c->d_maf.p, c->d_mean.p, c->d_rsx.p, c->d_sc4.p, n, c->stream));
+      HIP_TRY(c, launch_pack_scalars(c->d_maf.p, c->d_mean.p, c->d_rsx.p, c->d_skip.p, c->d_sc4.p, n, c->stream));
     }
   }
   plan_rows(c->h_pos_dist, c->h_maf, *p, n, c->h_row_end);

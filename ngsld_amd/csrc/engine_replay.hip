@@ -443,8 +443,30 @@ static bool alloc_lane_store(ngsld_ctx *c) {
     (void)hipGetLastError();
     return false;
   }
-  if (c->d_xT.resize(elems) != hipSuccess) {
+  // The order of the sites in the copy: the RARE ones first (folded frequency below 1/32, or no frequency), the others behind,
+  // each class in site order.  The pairs the lanes replay are pairs with a (nearly) monomorphic site, a wavefront's 64 lanes hold
+  // a few neighbouring rare sites x 8 partners they share (replay_keys_kernel), and per individual the rare sites' triples are
+  // 24 bytes each out of a cache line of their own while they stand among 32 consecutive sites: the launch fetched 1.3 TB
+  // through an L2 that hit 18 % of the time (profiles/r06/replay_lane).  Standing together they share their lines: same-box
+  // 612.5 / 613.3 -> 601.2 / 602.5 ms a pass at 20 % monomorphic sites (profiles/r06/lane/perm_ab.txt).
+  std::vector<uint32_t> perm(c->n_sites);
+  {
+    uint32_t n_rare = 0;
+    auto rare = [&](uint64_t s) {
+      const double m = c->h_maf[s], r = m <= 0.5 ? m : 1 - m;
+      return !(r >= 0.03125);
+    };
+    for (uint64_t s = 0; s < c->n_sites; ++s) n_rare += rare(s) ? 1u : 0u;
+    uint32_t at_rare = 0, at_rest = n_rare;
+    for (uint64_t s = 0; s < c->n_sites; ++s) perm[s] = rare(s) ? at_rare++ : at_rest++;
+  }
+  if (c->d_xT.resize(elems) != hipSuccess || c->d_xdepth.resize(c->n_sites) != hipSuccess ||
+      hipMemset(c->d_xdepth.p, 0, c->n_sites * sizeof(uint32_t)) != hipSuccess ||
+      c->d_xperm.resize(c->n_sites) != hipSuccess ||
+      hipMemcpy(c->d_xperm.p, perm.data(), c->n_sites * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
     (void)hipGetLastError();
+    c->d_xT.release();
+    c->d_xperm.release();
     return false;
   }
   return true;
@@ -454,7 +476,7 @@ static bool alloc_lane_store(ngsld_ctx *c) {
 static hipError_t build_lane_store(ngsld_ctx *c, hipStream_t st) {
   if (!alloc_lane_store(c)) return hipSuccess;
   hipError_t e = launch_transpose_store(c->exact_alias ? c->d_planes.p : c->d_xplanes.p, 3ull * c->np, c->np, (uint32_t)c->n_ind, c->n_sites,
-                                        c->d_xT.p, st);
+                                        c->d_xT.p, c->d_xdepth.p, c->d_xperm.p, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) return e;
   c->xT_ready = true;
@@ -569,7 +591,7 @@ static void exact_builder(ngsld_ctx *c) {
                          stage_dev + (size_t)chunk * site_elems, c->d_xmaf.p + s0, (uint64_t)m);
       bool sent = !hip_bad(hipGetLastError(), "exact store upload");
       if (sent && c->xT_ready.load())  // (the lane kernel's copy of these sites, behind their planes on the same stream)
-        sent = !hip_bad(launch_transpose_store(c->d_xplanes.p, site_elems, (uint32_t)np, (uint32_t)ni, n, c->d_xT.p, st, s0, s0 + m),
+        sent = !hip_bad(launch_transpose_store(c->d_xplanes.p, site_elems, (uint32_t)np, (uint32_t)ni, n, c->d_xT.p, c->d_xdepth.p, c->d_xperm.p, st, s0, s0 + m),
                         "exact store, individual-major copy");
       if (!sent || hip_bad(hipEventRecord(up.e[b], st), "exact store upload")) {
         ok = false;
@@ -755,6 +777,8 @@ int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t ou
   a.out_ext = d_ext;
   a.status = c->d_status.p;
   a.xt_sites = c->n_sites;
+  a.xdepth = c->d_xdepth.p;
+  a.xperm = c->d_xperm.p;
   // (a launch of a few hundred thousand records -- a text batch -- stays with the wavefront-per-pair kernel: a lane takes
   // milliseconds over ONE pair, four wavefronts to a SIMD, and such a launch has no second pair for most lanes: 6 ms a batch
   // against 4, profiles/r05/e2e_uncalled_lanes_on_text_batches.json)
@@ -808,7 +832,8 @@ int device_replay(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_ba
   // A launch that flags more pairs than its list holds (every pair of a monomorphic called site): the bitmap is turned into a
   // list of located pairs and a second kernel works through that -- both leave at once unless the list did overflow
   ngsld_ctx::LaneScratch &ls = slot < 0 ? c->lane_scratch_dev : c->lane_scratch[slot];
-  const uint64_t list_cap = std::min<uint64_t>(n, 1ull << 26);
+  uint64_t list_cap = std::min<uint64_t>(n, 1ull << 26);
+  if (const char *v = std::getenv("NGSLD_TEST_REPLAY_LIST_CAP")) list_cap = std::min<uint64_t>(list_cap, std::max<uint64_t>(1, std::strtoull(v, nullptr, 10)));  // tests: a list that overflows
   HIP_TRY(c, ls.list.resize(list_cap));
   ReplayHardArgs a{};
   a.list = ls.list.p;
@@ -856,6 +881,10 @@ int device_replay(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_ba
     x.only_if_overflow = 1;
     HIP_TRY(c, launch_replay_expand(x, ls.list.p, list_cap, st));
     HIP_TRY(c, launch_replay_hard_list(a, c->n_cus, st));
+    // what the expansion could not list (a launch that flags more pairs than the list's 2^26 entries: only ngsld_run_device makes
+    // launches that large) is still in the bitmap, and flags[7] tells the host that everything but the host-only pairs is done:
+    // those pairs join the host-only bitmap and list (a no-op unless the launch overflowed)
+    HIP_TRY(c, launch_replay_leftover(x, st));
   }
   return NGSLD_OK;
 }
@@ -947,6 +976,7 @@ int ngsld_replay_info(ngsld_ctx *c, ngsld_replay_stats_t *out) {
   out->exact_store = c->exact_state.load() == 2 ? (c->exact_alias ? 1 : 2) : 0;
   out->text_rows_patched = (int32_t)std::min<uint64_t>(c->text_rows_patched, 0x7fffffffull);
   out->exact_store_build_s = c->exact_build_s;
+  out->sites_degenerate = c->h_skip_count;
   return NGSLD_OK;
 }
 

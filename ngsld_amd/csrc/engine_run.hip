@@ -32,6 +32,9 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
   a.flag_cap = flag_cap;
   a.flag_text = 1;
   a.pearson_on_device = lkl_device_eligible(c) ? 1 : 0;
+  // the pairs of degenerate sites (sc4[.][3]) skip their EM: every one of them is flagged and the exact-order replay is their
+  // only evaluation -- on while the device-side replay of likelihood matrices can take them
+  a.skip_degenerate = (d_flags != nullptr && c->h_skip_count > 0 && c->skip_on && lkl_device_eligible(c) && !c->exact_failed) ? 1 : 0;
   a.planes = c->d_planes.p;
   a.site_stride = 3ull * c->np;
   a.np = c->np;

@@ -135,6 +135,8 @@ struct PairArgs {
   uint32_t flag_text;  // also flag the pairs whose printed digits (six decimals) rounding noise could change
   uint32_t pearson_on_device;  // an ill-conditioned Pearson moment (kPearsonCond) is settled by the device-side replay of likelihood
                                // matrices (ld_replay_lkl.hip: two passes over the exact values); 0: such pairs are the host's
+  uint32_t skip_degenerate;    // the pairs of a degenerate site (sc4[.][3] != 0; ld_prep.hip, site_skip_kernel) are flagged without their EM
+                               // (sits in what was padding: the other members keep their offsets)
   // tiled workgroup order of the multi-wavefront kernel (launch_pair_kernel; tile_nk == 0: workgroup i takes item i):
   // rows [row0, row1) of the plan, tiles of tile_rows rows x 8 items, tile_nk tiles per row block; workgroup ids without an
   // item (row beyond row1, item index beyond the row's count) leave at once

@@ -17,7 +17,9 @@ namespace ngsld {
 // prefetch.  (Without the prefetch -- every pair starting with an L2 / HBM round trip -- the kernel measured 12 % slower.)
 // A cohort that does not fill all slots but the last (513 individuals on 2 x 5 slots: the second wavefront's fourth slot
 // holds ONE individual, its fifth none) needs nothing special: empty slots are ghosts (stage_pair).
-template <int SLOTS, int WAVES, bool MASKED>
+// SKIP: as in pair_ld_run_kernel -- a pair with a degenerate site (sc4[.][3]) is staged for its Pearson moment only, all
+// wavefronts of the pair leave its EM out together, the NaN frequencies flag it and the exact-order replay is its one evaluation.
+template <int SLOTS, int WAVES, bool MASKED, bool SKIP = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
   static_assert(WAVES == 2 || WAVES == 4 || WAVES == 8, "pair_ld_kernel: 2, 4 or 8 wavefronts per pair");
   constexpr int kSliceBytes = SLOTS * 64 * 3 * 8;
@@ -78,12 +80,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
   char *lds_b = smem + sub * kSliceBytes;
   // the scalars of the item's candidate sites come into LDS once, by one coalesced load per array, so the pair loop waits
   // for no ordinary global load (a ~2 us round trip per pair, and it would drain the slice copy in flight)
-  __shared__ double site_sc[3][64];
+  __shared__ double site_sc[SKIP ? 4 : 3][64];
+  const bool skip1 = SKIP && A.sc4[4 * (uint64_t)s1 + 3] != 0.0;
   if (threadIdx.x < it.count) {
     const uint32_t s2 = it.s2_begin + threadIdx.x;
     site_sc[0][threadIdx.x] = A.maf[s2];
     site_sc[1][threadIdx.x] = A.mean_e[s2];
     site_sc[2][threadIdx.x] = A.rsx[s2];
+    if (SKIP) site_sc[SKIP ? 3 : 0][threadIdx.x] = A.sc4[4 * (uint64_t)s2 + 3];
   }
   __syncthreads();
 
@@ -167,9 +171,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void pair_ld_kernel(PairArgs A) {
       x = (uint32_t)xs;
     }
     double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair<SLOTS, WAVES>(P, vbits, kParked ? A.inv_n : 1.0 / (double)x, rl.m1, rl.m2, f0, f1, f2, f3,
-                                                  xch, sub, lane, A.status, &xpar);
-    unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
+    uint32_t n_iter = 0;
+    if (SKIP && (skip1 || site_sc[SKIP ? 3 : 0][c] != 0.0)) {  // (the same in every wavefront of the pair)
+      f0 = f1 = f2 = f3 = __builtin_nan("");
+    } else {
+      n_iter = em_pair<SLOTS, WAVES>(P, vbits, kParked ? A.inv_n : 1.0 / (double)x, rl.m1, rl.m2, f0, f1, f2, f3, xch, sub, lane,
+                                     A.status, &xpar);
+      unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
+    }
     if (lane == 0 && sub == 0) {
       PairResult &r = res[c];
       r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;

@@ -6,7 +6,11 @@
 
 namespace ngsld {
 
-template <int SLOTS, bool MASKED>
+// SKIP (a launch over a matrix with degenerate sites, PairArgs::skip_degenerate): a pair with such a site -- marked in
+// sc4[.][3] by site_skip_kernel, ld_prep.hip -- is staged for its Pearson moment only; its frequencies are left NaN, which
+// write_pair flags, and the exact-order replay is the pair's one evaluation (it was going to start the pair over anyway).  A
+// variant of its own so that launches over SNP-called matrices keep the instruction stream they had.
+template <int SLOTS, bool MASKED, bool SKIP = false>
 __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
   constexpr int kSiteBytes = SLOTS * 64 * 3 * 8;
   constexpr int kBuf = kSiteBytes + 32;
@@ -26,6 +30,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
   const Item *g_items = A.items_all + run.first_item;
   const uint32_t s1 = g_items[0].s1;
   const double m1 = A.sc4[4 * (uint64_t)s1], mean1 = A.sc4[4 * (uint64_t)s1 + 1], rsx1 = A.sc4[4 * (uint64_t)s1 + 2];
+  const bool skip1 = SKIP && A.sc4[4 * (uint64_t)s1 + 3] != 0.0;
   char *lds_a = smem;
   char *lds_b = smem + kSiteBytes + wave * kBuf;
   RunResult *ring = reinterpret_cast<RunResult *>(smem + kRingOff) + wave * kRing;
@@ -72,6 +77,7 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's site copy (issued a pair ago) has landed
     const double *sc = reinterpret_cast<const double *>(lds_b + kSiteBytes);
     const double m2 = uniform(sc[0]), mean2 = uniform(sc[1]), rsx2 = uniform(sc[2]);
+    const bool skip = SKIP && (skip1 || uniform(sc[3]) != 0.0);  // (read here: the next site's copy is about to land on sc)
     double P[SLOTS][9];
     uint32_t vbits;
     double sxy;
@@ -86,9 +92,13 @@ __global__ __launch_bounds__(256, 2) void pair_ld_run_kernel(PairArgs A) {
     const double inv_x = MASKED ? 1.0 / (double)x : A.inv_n;
     sxy = fma(-(double)A.n_ind * rl.mean1, rl.mean2, wave_sum1_bcast(sxy));  // centred: sum e1 e2 - n mean1 mean2
     double f0, f1, f2, f3;
-    const uint32_t n_iter = em_pair<SLOTS, 1>(P, vbits, inv_x, rl.m1, rl.m2, f0, f1, f2, f3, (double (*)[1][4]) nullptr, 0,
-                                              lane, A.status);
-    unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
+    uint32_t n_iter = 0;
+    if (skip) {  // (wavefront-uniform)
+      f0 = f1 = f2 = f3 = __builtin_nan("");
+    } else {
+      n_iter = em_pair<SLOTS, 1>(P, vbits, inv_x, rl.m1, rl.m2, f0, f1, f2, f3, (double (*)[1][4]) nullptr, 0, lane, A.status);
+      unrelabel(rl.flip1, rl.flip2, f0, f1, f2, f3);
+    }
     if (lane == 0) {
       RunResult &r = ring[held];
       r.f[0] = f0; r.f[1] = f1; r.f[2] = f2; r.f[3] = f3;

@@ -135,6 +135,13 @@ static hipError_t launch_run(bool masked, const PairArgs &a, hipStream_t stream)
   if (a.n_runs == 0) return hipSuccess;
   if (a.n_runs > 0x7fffffffull) return hipErrorInvalidValue;
   const dim3 grid((unsigned)a.n_runs), block(256);
+  if (a.skip_degenerate && a.flags != nullptr) {  // (a matrix with degenerate sites: their pairs' EM is left to the replay)
+    if (masked)
+      hipLaunchKernelGGL((pair_ld_run_kernel<SLOTS, true, true>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((pair_ld_run_kernel<SLOTS, false, true>), grid, block, 0, stream, a);
+    return hipGetLastError();
+  }
   if (masked) {
     hipLaunchKernelGGL((pair_ld_run_kernel<SLOTS, true>), grid, block, 0, stream, a);
     return hipGetLastError();

@@ -10,6 +10,13 @@ static hipError_t launch_sw(bool masked, const PairArgs &a, hipStream_t stream) 
   if (blocks == 0) return hipSuccess;
   if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
   const dim3 grid((unsigned)blocks), block(WAVES * 64);
+  if (WAVES == 2 && a.skip_degenerate && a.flags != nullptr) {  // (a matrix with degenerate sites: their pairs' EM is left to the replay)
+    if (masked)
+      hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES == 2 ? 2 : WAVES, true, WAVES == 2>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES == 2 ? 2 : WAVES, false, WAVES == 2>), grid, block, 0, stream, a);
+    return hipGetLastError();
+  }
   if (masked)
     hipLaunchKernelGGL((pair_ld_kernel<SLOTS, WAVES, true>), grid, block, 0, stream, a);
   else

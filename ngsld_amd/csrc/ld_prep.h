@@ -44,8 +44,13 @@ struct ItemArgs {
   int count_only;
 };
 hipError_t launch_items(const ItemArgs &a, hipStream_t stream);
-hipError_t launch_pack_scalars(const double *maf, const double *mean_e, const double *rsx, double *sc4, uint64_t n,
+// skip (may be null): the sites site_skip_kernel marked, see ld_prep.hip
+hipError_t launch_pack_scalars(const double *maf, const double *mean_e, const double *rsx, const uint8_t *skip, double *sc4, uint64_t n,
                                hipStream_t stream);
+// skip[s] = 1 where the one-locus EM of site s ends below kSkipBelow (a site whose pairs the exact-order replay will settle:
+// the pair kernels leave their EM out); *count (preset to 0) = how many
+hipError_t launch_site_skip(const double *planes, uint64_t site_stride, uint32_t np, uint32_t n_ind, int ignore_miss, const double *maf,
+                            uint64_t n_sites, uint8_t *skip, uint32_t *count, hipStream_t stream);
 hipError_t launch_selftest(const double *in, double *out, hipStream_t stream);
 
 }  // namespace ngsld

@@ -373,20 +373,117 @@ hipError_t launch_prep(const PrepArgs &a, hipStream_t stream) {
   return hipGetLastError();
 }
 
-// {maf, mean_e, rsx, 0} of every site side by side: the run kernel fetches a site's scalars with one 32-byte copy.
-__global__ void pack_scalars_kernel(const double *maf, const double *mean_e, const double *rsx, double *sc4, uint64_t n) {
+// Which sites are DEGENERATE: sites whose every pair (nearly) the exact-order replay will settle anyway.  On a matrix that is
+// not SNP-called (README.md:73) a site monomorphic in the sample sends the pair EM's minor margins towards zero until eps <
+// EPSILON stops it, and D', r2 of such a pair are quotients by those margins: write_pair flags it once 2^-49 (1/q0 + 1/q1)
+// max(|D'|, r2) > 2.5e-10, i.e. q < 7e-6 max(|D'|, r2) -- and the replay starts the pair over.  The margin of a site in the
+// two-locus EM moves as the ONE-locus EM of that site does (exactly so without LD), so the predictor is that EM: from the
+// site's est_maf frequency (where haplo_freq starts, gen_func.cpp:1034-1037), HWE weights, until its own step is below
+// EPSILON (where the pair's loop would stop on this site's account, gen_func.cpp:1054); a site that ends below kSkipBelow is
+// marked.  The pair kernels then leave the EM of such a site's pairs out (NaN frequencies: flagged) and the replay, which is
+// exact for ANY pair, is their only evaluation: a wrong mark costs time, never a digit.  Measured on bench.py's generator, 500
+// individuals (profiles/r06/skip/predictor.txt): with 20 % monomorphic sites the mark catches 98.9 % of the flagged pairs and
+// 1.7 % of all pairs are marked without need; log-uniform spectrum 93.1 % / 0.6 %.
+constexpr double kSkipBelow = 3e-6;
+template <int MAXJ>  // individuals per lane kept in registers (0: the planes are read again in every step)
+__global__ __launch_bounds__(256) void site_skip_kernel(const double *__restrict__ planes, uint64_t site_stride, uint32_t np, uint32_t n_ind,
+                                                        int ignore_miss, const double *__restrict__ maf, uint64_t n_sites,
+                                                        uint8_t *__restrict__ skip, uint32_t *count) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint64_t site = (uint64_t)blockIdx.x * 4 + wave; site < n_sites; site += (uint64_t)gridDim.x * 4) {
+    const double *pl = planes + site * site_stride;
+    const double m_in = maf[site];
+    const bool flip = m_in > 0.5;  // (the minor allele's frequency is the one that goes to zero)
+    double m = flip ? 1.0 - m_in : m_in;
+    const double *p0 = pl + (flip ? 2ull * np : 0ull), *p1 = pl + np, *p2 = pl + (flip ? 0ull : 2ull * np);
+    constexpr int kRegs = MAXJ > 0 ? MAXJ : 1;
+    double a0[kRegs], a1[kRegs], a2[kRegs];
+    uint32_t valid = 0, x = 0;
+    const uint32_t n_slots = (n_ind + 63) / 64;
+    auto is_valid = [&](uint32_t i, double g0, double g1, double g2) {
+      return i < n_ind && !(ignore_miss && miss_data(g0, g1, g2));  // gen_func.cpp:1089 (normal space)
+    };
+    if (MAXJ > 0) {
+#pragma unroll
+      for (int j = 0; j < kRegs; ++j) {
+        const uint32_t i = (uint32_t)lane + 64u * (uint32_t)j;
+        const bool in = i < n_ind;
+        a0[j] = in ? p0[i] : 0.0;
+        a1[j] = in ? p1[i] : 0.0;
+        a2[j] = in ? p2[i] : 0.0;
+        if (is_valid(i, a0[j], a1[j], a2[j])) valid |= 1u << j;
+      }
+      x = 0;
+#pragma unroll
+      for (int j = 0; j < kRegs; ++j) x += (uint32_t)__popcll(__ballot((valid >> j) & 1u));
+    }
+    bool mark = false;
+    for (int iter = 0; iter < kIterMax; ++iter) {
+      const double w0 = (1 - m) * (1 - m), w1 = 2 * m * (1 - m), w2 = m * m;
+      double acc = 0.0;
+      uint32_t cnt = 0;
+      auto one = [&](double g0, double g1, double g2) {
+        const double s = fma(w2, g2, fma(w1, g1, w0 * g0));
+        acc = fma(fma(2.0 * w2, g2, w1 * g1), rcp_refined(s), acc);
+      };
+      if (MAXJ > 0) {
+#pragma unroll
+        for (int j = 0; j < kRegs; ++j)
+          if ((valid >> j) & 1u) one(a0[j], a1[j], a2[j]);
+        cnt = x;
+      } else {
+        for (uint32_t j = 0; j < n_slots; ++j) {
+          const uint32_t i = (uint32_t)lane + 64u * j;
+          const double g0 = i < n_ind ? p0[i] : 0.0, g1 = i < n_ind ? p1[i] : 0.0, g2 = i < n_ind ? p2[i] : 0.0;
+          const bool ok = is_valid(i, g0, g1, g2);
+          if (ok) one(g0, g1, g2);
+          cnt += (uint32_t)__popcll(__ballot(ok));
+        }
+      }
+      const double mn = wave_sum1(acc) / (2.0 * (double)cnt);
+      const bool stop = !(fabs(mn - m) >= kEpsilon);  // (a NaN stops too, and marks nothing)
+      m = mn;
+      if (stop) {
+        mark = m < kSkipBelow;
+        break;
+      }
+    }
+    if (lane == 0) {
+      skip[site] = mark ? 1 : 0;
+      if (mark) atomicAdd(count, 1u);
+    }
+  }
+}
+
+hipError_t launch_site_skip(const double *planes, uint64_t site_stride, uint32_t np, uint32_t n_ind, int ignore_miss, const double *maf,
+                            uint64_t n_sites, uint8_t *skip, uint32_t *count, hipStream_t stream) {
+  if (n_sites == 0) return hipSuccess;
+  const uint64_t wgs = (n_sites + 3) / 4;
+  const dim3 grid((unsigned)(wgs < 65536 ? wgs : 65536)), block(256);
+  if (np <= 512)
+    hipLaunchKernelGGL(site_skip_kernel<8>, grid, block, 0, stream, planes, site_stride, np, n_ind, ignore_miss, maf, n_sites, skip, count);
+  else if (np <= 1024)
+    hipLaunchKernelGGL(site_skip_kernel<16>, grid, block, 0, stream, planes, site_stride, np, n_ind, ignore_miss, maf, n_sites, skip, count);
+  else
+    hipLaunchKernelGGL(site_skip_kernel<0>, grid, block, 0, stream, planes, site_stride, np, n_ind, ignore_miss, maf, n_sites, skip, count);
+  return hipGetLastError();
+}
+
+// {maf, mean_e, rsx, degenerate} of every site side by side: the run kernel fetches a site's scalars with one 32-byte copy.
+// (degenerate: 1.0 where site_skip_kernel marked the site, 0.0 elsewhere or without marks)
+__global__ void pack_scalars_kernel(const double *maf, const double *mean_e, const double *rsx, const uint8_t *skip, double *sc4, uint64_t n) {
   const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   sc4[4 * s] = maf[s];
   sc4[4 * s + 1] = mean_e[s];
   sc4[4 * s + 2] = rsx[s];
-  sc4[4 * s + 3] = 0.0;
+  sc4[4 * s + 3] = (skip != nullptr && skip[s]) ? 1.0 : 0.0;
 }
 
-hipError_t launch_pack_scalars(const double *maf, const double *mean_e, const double *rsx, double *sc4, uint64_t n,
+hipError_t launch_pack_scalars(const double *maf, const double *mean_e, const double *rsx, const uint8_t *skip, double *sc4, uint64_t n,
                                hipStream_t stream) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(pack_scalars_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, maf, mean_e, rsx, sc4, n);
+  hipLaunchKernelGGL(pack_scalars_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, maf, mean_e, rsx, skip, sc4, n);
   return hipGetLastError();
 }
 

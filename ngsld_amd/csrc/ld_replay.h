@@ -64,6 +64,11 @@ struct ReplayLklArgs {
   uint32_t np;
   const double *xmaf;         // [n_sites]
   uint64_t xt_sites;          // sites of the individual-major copy (lane-per-pair kernel): xT[(i * xt_sites + s) * 3 + g]
+  const uint32_t *xperm;      // [n_sites] where a site stands in that copy (may be null: in place): rare sites first, the others behind, each
+                              // class in site order -- the rare sites of a stretch of the genome, the shared sites of a wavefront's pairs, are
+                              // then neighbours in memory instead of one cache line each (engine_replay.hip, alloc_lane_store)
+  const uint32_t *xdepth;     // [n_sites] how far below 1 the site's smallest nonzero likelihood lies, -floor(log2), or >= 4096 for a site with
+                              // a value that is no ordinary number in [0, 2) (ld_replay_lkl.hip, plain_depth; may be null: no site vouched for)
   uint32_t n_ind;
   int ignore_miss;
   ngsld_rec_std *out_std;     // the launch's records (device memory, or pinned host memory written in place)
@@ -77,8 +82,9 @@ struct ReplayEntry {  // a flagged pair, located
   uint32_t s1, s2;
 };
 // individual-major copy of the exact store: xT[(i * n_sites + s) * 3 + g] = xplanes[s][g][i], sites [site_begin, site_end)
+// xdepth (preset to zero, may be null), xperm (may be null): ReplayLklArgs::xdepth / xperm of the sites copied
 hipError_t launch_transpose_store(const double *xplanes, uint64_t site_stride, uint32_t np, uint32_t n_ind, uint64_t n_sites,
-                                  double *xT, hipStream_t stream, uint64_t site_begin = 0, uint64_t site_end = ~0ull);
+                                  double *xT, uint32_t *xdepth, const uint32_t *xperm, hipStream_t stream, uint64_t site_begin = 0, uint64_t site_end = ~0ull);
 // Walks the launch's bitmap (a thread per word), appends the pairs the lane-per-pair kernel takes to `list` (at most list_cap;
 // counter: flags[4]) and CLEARS their bits: what stays set -- pairs whose Pearson moment is ill conditioned, pairs beyond the
 // list's capacity -- is the wavefront-per-pair kernel's.

@@ -39,6 +39,7 @@
 #include "ld_replay.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -106,8 +107,24 @@ __device__ __forceinline__ int div_operand_plain(double v) {
   return ZERO_OK ? (in_range | (__double_as_longlong(v) == 0 ? 1 : 0)) : in_range;
 }
 
+// What quotients<LIGHT> asks of its operands (see there), as one number per value: how far below 1 a likelihood / a frequency
+// lies -- E = -floor(log2 v) for an ordinary number in (0, 2), 0 for +0 (a zero factor makes a zero term, which every test allows)
+// -- and kNotPlain for everything else (-0, negative numbers, NaN, infinities, denormals, 2 and above).
+constexpr uint32_t kNotPlain = 4096;
+__device__ __forceinline__ uint32_t plain_depth(double v) {
+  const uint32_t u = (uint32_t)__double2hiint(v) >> 20;  // sign and biased exponent
+  if (__double_as_longlong(v) == 0) return 0;
+  return (u - 1u < 1023u) ? 1023u - u : kNotPlain;          // (u == 0: a denormal)
+}
+
 // (counts: the caller uses this lane's quotients -- a padding lane, or an individual left out under --ignore_miss_data, whose
 // result is thrown away, must not send its wavefront down the slow way)
+// LIGHT: the caller vouches for the operands -- with Ea / Eb the largest plain_depth of a likelihood of either site (looked at
+// once per site, where the store is transposed: ReplayLklArgs::xdepth) and Ef that of the step's four frequencies, 2 Ef + Ea +
+// Eb <= 596: every product f f p q is then +0 or at least 2^-600 (and below 16), so are `sum` (16 such terms) and every `tmp`
+// (4 terms of 2 f f p q): all div_operand_plain but for a `sum` of exactly zero (0 / 0 in the reference), the one test left per
+// individual -- 1 instruction instead of 16.
+template <bool LIGHT = false>
 __device__ __forceinline__ void quotients(const FreqProducts &F, const double (&p)[3], const double (&q)[3], double (&out)[4],
                                           bool counts = true) {
   double J[3][3];
@@ -143,10 +160,16 @@ __device__ __forceinline__ void quotients(const FreqProducts &F, const double (&
   // frequency that has reached a denormal) takes the compiler's divisions for that individual, all lanes:
   // tests/test_gpu_replay_lkl.py holds both ways to the host's quotients bit for bit.  Lane kernel 338 -> 315 ms for 31.2e6
   // pairs (profiles/r05/late/shared_rcp); since then it is bound by the bytes it re-reads, not by its instructions.
-  int plain = div_operand_plain<false>(sum);
+  bool odd;
+  if (LIGHT) {
+    odd = !(sum > 0.0);
+  } else {
+    int plain = div_operand_plain<false>(sum);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) plain &= div_operand_plain<true>(tmp[k]);
-  if (__builtin_amdgcn_ballot_w64(counts && plain == 0) == 0) {
+    for (int k = 0; k < 4; ++k) plain &= div_operand_plain<true>(tmp[k]);
+    odd = plain == 0;
+  }
+  if (__builtin_amdgcn_ballot_w64(counts && odd) == 0) {
     double r = __builtin_amdgcn_rcp(sum);
     r = fma(r, fma(-sum, r, 1.0), r);
     r = fma(r, fma(-sum, r, 1.0), r);
@@ -440,7 +463,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_store_kernel(const double *__restrict__ xplanes, uint64_t site_stride, uint32_t np,
                                                               uint32_t n_ind, uint64_t pitch_sites, double *__restrict__ xT, uint64_t site_begin,
-                                                              uint64_t n_sites) {
+                                                              uint64_t n_sites, uint32_t *__restrict__ xdepth, const uint32_t *__restrict__ xperm) {
   // (sites [site_begin, n_sites) of a matrix of pitch_sites sites: the builder moves the store chunk by chunk)
   __shared__ double tile[3][64][65];  // [genotype][site][individual]
   const uint64_t s0 = site_begin + (uint64_t)blockIdx.x * 64;
@@ -449,8 +472,22 @@ __global__ __launch_bounds__(256) void transpose_store_kernel(const double *__re
   for (int ls = w; ls < 64; ls += 4) {
     const uint64_t s = s0 + ls;
     const uint32_t i = i0 + lane;
+    uint32_t depth = 0;
 #pragma unroll
-    for (int g = 0; g < 3; ++g) tile[g][ls][lane] = (s < n_sites && i < n_ind) ? xplanes[s * site_stride + (uint64_t)g * np + i] : 0.0;
+    for (int g = 0; g < 3; ++g) {
+      const double v = (s < n_sites && i < n_ind) ? xplanes[s * site_stride + (uint64_t)g * np + i] : 0.0;
+      tile[g][ls][lane] = v;
+      const uint32_t d = plain_depth(v);
+      depth = d > depth ? d : depth;
+    }
+    // (xdepth, preset to zero: the site's largest plain_depth, see quotients<LIGHT>)
+    if (xdepth != nullptr) {
+      for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)depth, off);
+        depth = o > depth ? o : depth;
+      }
+      if (lane == 0 && depth != 0 && s < n_sites) atomicMax(&xdepth[s], depth);
+    }
   }
   __syncthreads();
   // individual li of the tile: its 64 sites x 3 values are 192 consecutive doubles of xT
@@ -459,7 +496,7 @@ __global__ __launch_bounds__(256) void transpose_store_kernel(const double *__re
     if (i >= n_ind) continue;
     for (int t = lane; t < 192; t += 64) {
       const int ls = t / 3, g = t % 3;
-      if (s0 + ls < n_sites) xT[((uint64_t)i * pitch_sites + s0 + ls) * 3 + g] = tile[g][ls][li];
+      if (s0 + ls < n_sites) xT[((uint64_t)i * pitch_sites + (xperm != nullptr ? xperm[s0 + ls] : s0 + ls)) * 3 + g] = tile[g][ls][li];
     }
   }
 }
@@ -528,7 +565,9 @@ __global__ void replay_keys_kernel(ReplayLklArgs A, const ReplayEntry *list, uin
   const double m1 = A.xmaf[e.s1], m2 = A.xmaf[e.s2];
   const double r1 = m1 <= 0.5 ? m1 : 1 - m1, r2 = m2 <= 0.5 ? m2 : 1 - m2;  // (NaN: compares false, the row's site is the shared one)
   const bool by2 = r2 < r1;
-  const uint64_t shared = by2 ? e.s2 : e.s1, other = by2 ? e.s1 : e.s2;
+  // (positions in the individual-major copy, where the rare sites stand together: ReplayLklArgs::xperm)
+  const uint32_t p1 = A.xperm != nullptr ? A.xperm[e.s1] : e.s1, p2 = A.xperm != nullptr ? A.xperm[e.s2] : e.s2;
+  const uint64_t shared = by2 ? p2 : p1, other = by2 ? p1 : p2;
   const uint64_t s_hi = shared >> tile_s, s_lo = shared & ((1ull << tile_s) - 1), o_hi = other >> tile_o, o_lo = other & ((1ull << tile_o) - 1);
   keys[i] = (((s_hi << (site_bits - tile_o)) | o_hi) << (tile_s + tile_o)) | (s_lo << tile_o) | o_lo;
 }
@@ -546,6 +585,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
   const uint64_t row = A.xt_sites * 3;  // doubles from one individual to the next
   const uint32_t total = A.flags[4];
   bool have = false, dry = false;       // this lane holds a pair / the list has run out
+  uint32_t sites_depth = kNotPlain;     // plain_depth of the pair's two sites, added up (ReplayLklArgs::xdepth)
   ReplayEntry e{};
   const double *pa = xT, *pb = xT;
   double f[4] = {0, 0, 0, 0};
@@ -585,8 +625,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
           f[2] = m1 * (1 - m2);
           f[3] = m1 * m2;
         }
-        pa = xT + (uint64_t)e.s1 * 3;
-        pb = xT + (uint64_t)e.s2 * 3;
+        pa = xT + (uint64_t)(A.xperm != nullptr ? A.xperm[e.s1] : e.s1) * 3;
+        pb = xT + (uint64_t)(A.xperm != nullptr ? A.xperm[e.s2] : e.s2) * 3;
+        sites_depth = A.xdepth != nullptr ? A.xdepth[e.s1] + A.xdepth[e.s2] : kNotPlain;
         iter = 0;
         have = true;
       }
@@ -596,36 +637,59 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
     // ---- one EM step (gen_func.cpp:1076-1119) for every lane that holds a pair ----
     double ff[4] = {0, 0, 0, 0};
     uint32_t x = 0;
-    if (have) {
-      double a[3], b[3], an[3], bn[3];
+    // the step's individuals with the one-instruction operand test (quotients<LIGHT>) where EVERY lane's pair qualifies in this
+    // step, the general test otherwise
+    uint32_t f_depth = plain_depth(f[0]);
 #pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        an[g] = pa[g];
-        bn[g] = pb[g];
-      }
+    for (int k = 1; k < 4; ++k) {
+      const uint32_t d = plain_depth(f[k]);
+      f_depth = d > f_depth ? d : f_depth;
+    }
+    const bool light = __ballot(have && 2u * f_depth + sites_depth > 596u) == 0;
+    auto individuals = [&](auto light_tag) {
+      constexpr bool kLight = decltype(light_tag)::value;
       FreqProducts F;
       F.set(f);
-      for (uint32_t i = 0; i < A.n_ind; ++i) {
+      // The individuals in order, two register sets used in turn: the next individual's triples are on their way while this one
+      // is worked on, and nothing is copied from a staging set into place (154 registers, three wavefronts to a SIMD: -1.1 % of a
+      // pass against one set + staging at four, profiles/r06/lane/ab2.txt)
+      double a0[3], b0[3], a1[3], b1[3];
+      auto fetch = [&](double (&a)[3], double (&b)[3], uint32_t i) {
+        const double *qa = pa + (uint64_t)i * row, *qb = pb + (uint64_t)i * row;
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-          a[g] = an[g];
-          b[g] = bn[g];
+          a[g] = qa[g];
+          b[g] = qb[g];
         }
-        if (i + 1 < A.n_ind) {  // the next individual's triples are on their way while this one is worked on
-          const double *qa = pa + (uint64_t)(i + 1) * row, *qb = pb + (uint64_t)(i + 1) * row;
-#pragma unroll
-          for (int g = 0; g < 3; ++g) {
-            an[g] = qa[g];
-            bn[g] = qb[g];
-          }
+      };
+      auto step = [&](const double (&a)[3], const double (&b)[3]) {
+        if (ign) {
+          if (no_data(a) || no_data(b)) return;  // gen_func.cpp:1089
+          ++x;
         }
-        if (ign && (no_data(a) || no_data(b))) continue;  // gen_func.cpp:1089
-        ++x;
         double o[4];
-        quotients(F, a, b, o);
+        quotients<kLight>(F, a, b, o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) ff[k] += o[k];  // gen_func.cpp:1103, in the reference's order
+      };
+      fetch(a0, b0, 0);
+      uint32_t i = 0;
+      for (; i + 1 < A.n_ind; i += 2) {
+        fetch(a1, b1, i + 1);
+        step(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 2 < A.n_ind) fetch(a0, b0, i + 2);
+        step(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      if (i < A.n_ind) step(a0, b0);
+    };
+    if (have) {
+      if (light)
+        individuals(std::true_type());
+      else
+        individuals(std::false_type());
+      if (!ign) x = A.n_ind;
       const double twox = (double)(2 * (uint64_t)x);  // gen_func.cpp:1109
       double g4[4];
 #pragma unroll
@@ -681,11 +745,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
 }  // namespace
 
 hipError_t launch_transpose_store(const double *xplanes, uint64_t site_stride, uint32_t np, uint32_t n_ind, uint64_t n_sites,
-                                  double *xT, hipStream_t stream, uint64_t site_begin, uint64_t site_end) {
+                                  double *xT, uint32_t *xdepth, const uint32_t *xperm, hipStream_t stream, uint64_t site_begin,
+                                  uint64_t site_end) {
   if (site_end > n_sites) site_end = n_sites;
   if (site_begin >= site_end || n_ind == 0) return hipSuccess;
   const dim3 grid((unsigned)((site_end - site_begin + 63) / 64), (unsigned)((n_ind + 63) / 64));
-  hipLaunchKernelGGL(transpose_store_kernel, grid, dim3(256), 0, stream, xplanes, site_stride, np, n_ind, n_sites, xT, site_begin, site_end);
+  hipLaunchKernelGGL(transpose_store_kernel, grid, dim3(256), 0, stream, xplanes, site_stride, np, n_ind, n_sites, xT, site_begin, site_end, xdepth, xperm);
   return hipGetLastError();
 }
 
@@ -751,6 +816,7 @@ __global__ __launch_bounds__(256) void replay_leftover_kernel(ReplayLklArgs A) {
   const uint64_t w = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const uint64_t n_words = (A.n_records + 31) / 32;
   if (w >= n_words) return;
+  if (A.only_if_overflow && A.flags[0] <= A.flag_cap) return;  // (called genotypes: nothing was expanded, nothing is left over)
   uint32_t bits = A.bits[w] & ~A.host_bits[w];
   if (w == n_words - 1 && (A.n_records & 31)) bits &= (1u << (A.n_records & 31)) - 1u;
   if (!bits) return;

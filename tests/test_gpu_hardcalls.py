@@ -129,6 +129,10 @@ def test_device_replay_of_called_genotypes_is_the_hosts(n_ind, call, ignore, mis
     o = orc.Oracle(raw, None, ignore_miss_data=ignore, n_threads=32, call_geno=call)
     rec = o.run()
     got = {}
+    if tiny_list:
+        # the list of located pairs overflows too (in earnest only a launch of more than 2^26 flagged pairs does: ngsld_run_device on
+        # configs[3]'s size): what it cannot hold stays in the bitmap and must reach the host -- it used to be dropped, silently
+        monkeypatch.setenv("NGSLD_TEST_REPLAY_LIST_CAP", "3000")
     for where in ("device", "host"):
         monkeypatch.setenv("NGSLD_REPLAY_DEVICE", "1" if where == "device" else "0")
         eng = capi.Engine(0)
@@ -154,9 +158,10 @@ def test_device_replay_of_called_genotypes_is_the_hosts(n_ind, call, ignore, mis
     print(f"\n[device replay] n_ind {n_ind} call {call} ignore {ignore} miss {miss}: {len(rec)} pairs, {rd} replayed, {ties} with nIter <= 2")
 
 
-@pytest.mark.parametrize("n_ind,call,ignore,miss", [(200, None, False, 0.0), (500, (0.4, 0.4), False, 0.03), (500, (0.4, 0.4), True, 0.03),
-                                                  (500, None, False, 0.02)])
-def test_a_launch_that_overflows_its_flag_list_is_replayed_on_the_device_too(n_ind, call, ignore, miss, monkeypatch):
+@pytest.mark.parametrize("n_ind,call,ignore,miss,tiny_list", [(200, None, False, 0.0, False), (500, (0.4, 0.4), False, 0.03, False),
+                                                            (500, (0.4, 0.4), True, 0.03, False), (500, None, False, 0.02, False),
+                                                            (200, None, False, 0.0, True), (500, (0.4, 0.4), False, 0.03, True)])
+def test_a_launch_that_overflows_its_flag_list_is_replayed_on_the_device_too(n_ind, call, ignore, miss, tiny_list, monkeypatch):
     """A called-genotype matrix with MONOMORPHIC sites (a VCF that was never SNP-filtered; the reference's README.md:73) flags
     every pair of such a site: more than the launch's list holds.  Rounds 2-4 left ALL flagged pairs of such a launch to the host's
     threads; now the bitmap is turned into a list of located pairs on the device and a second kernel replays those
@@ -172,6 +177,10 @@ def test_a_launch_that_overflows_its_flag_list_is_replayed_on_the_device_too(n_i
         raw[rng.random((n_sites, n_ind)) < miss] = 1.0 / 3.0
     rec = orc.Oracle(raw, None, ignore_miss_data=ignore, n_threads=32, call_geno=call).run()
     got = {}
+    if tiny_list:
+        # the list of located pairs overflows too (in earnest only a launch of more than 2^26 flagged pairs does: ngsld_run_device on
+        # configs[3]'s size): what it cannot hold stays in the bitmap and must reach the host -- it used to be dropped, silently
+        monkeypatch.setenv("NGSLD_TEST_REPLAY_LIST_CAP", "3000")
     for where in ("device", "host"):
         monkeypatch.setenv("NGSLD_REPLAY_DEVICE", "1" if where == "device" else "0")
         eng = capi.Engine(0)
@@ -189,7 +198,9 @@ def test_a_launch_that_overflows_its_flag_list_is_replayed_on_the_device_too(n_i
     (sd, ed, idv), (sh, eh, ih) = got["device"], got["host"]
     assert idv["pairs_flagged"] == ih["pairs_flagged"] > max(4096, len(rec) // 256)          # (the list did overflow)
     assert ih["pairs_on_device"] == 0
-    if call is not None or not miss:
+    if tiny_list:
+        assert 0 < idv["pairs_on_device"] <= 3000 and idv["pairs_on_host"] == idv["pairs_flagged"] - idv["pairs_on_device"], idv
+    elif call is not None or not miss:
         assert idv["pairs_on_device"] > idv["pairs_flagged"] * 0.9, idv
     for col in ("D", "Dp", "r2"):
         assert np.array_equal(sd[col].view(np.uint64), sh[col].view(np.uint64)), col

@@ -88,6 +88,9 @@ def test_bench_two_ranks_add_up_to_the_one_rank_run():
         assert {r["device_index"] for r in recs} == {0, 1} and "nccl" in c2["backend"]
     else:
         assert "gloo" in c2["backend"]
+    # the record checks itself: an all_reduce of ones over the job's backend saw both ranks; every rank reports its broadcast
+    assert c2["rccl_ranks_seen"] == 2 and c1["rccl_ranks_seen"] == 1
+    assert all(r["gl_broadcast_s"] >= 0 for r in recs)
     print(f"\n[multi-ranks] {'RCCL, 2 GPUs' if two_gpus else 'one device, gloo dry run'}: {c2['pairs_per_step']} pairs, "
           f"ranks {lo} / {hi}, {tmin:.3f} / {tmax:.3f} s, checksum {whole['records_checksum_u64']:#018x}")
 
@@ -203,3 +206,20 @@ def test_torch_rccl_backend_runs_the_collectives_bench_uses():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", RCCL_ONE_RANK, REPO], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`--gpus N` with fewer visible devices than ranks is an error (a dry run on one device has to be asked for by name)."""
+    if capi.device_count() >= 2:
+        pytest.skip("two devices here: nothing to refuse")
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("NGSLD_BENCH_ONE_DEVICE", None)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29631", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--sites", "2000", "--no-cpu", "--no-sink", "--no-e2e", "--no-traffic"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    assert "has no device of its own" in (r.stderr + r.stdout)

@@ -18,8 +18,29 @@ from util import check_records, close, same_bits
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _every_pairs_em_in_the_pair_kernel(request, monkeypatch):
+    # (the tests of this file that create their contexts inside the library -- streamed slabs, parts of one process -- compare
+    # host-replay and device-replay runs bit for bit too: see `eng`)
+    if "eng_skip" not in request.fixturenames:
+        monkeypatch.setenv("NGSLD_REPLAY_SKIP", "0")
+
+
 @pytest.fixture()
-def eng():
+def eng(monkeypatch):
+    # Device replay against HOST replay, every record of a run bit for bit -- un-flagged pairs included: the pair kernels run
+    # the EM of every pair here.  (By default the pairs of a degenerate site skip theirs and take the replay's value, flagged
+    # or not -- the reference's bits, where the host-replay run keeps the kernel's for pairs it does not flag: the same number
+    # to 1e-9, not the same bits.  test_degenerate_sites_* below hold that path.)  Read at ngsld_create.
+    monkeypatch.setenv("NGSLD_REPLAY_SKIP", "0")
+    e = capi.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture()
+def eng_skip(monkeypatch):
+    monkeypatch.delenv("NGSLD_REPLAY_SKIP", raising=False)
     e = capi.Engine(0)
     yield e
     e.close()
@@ -406,3 +427,70 @@ def test_quotients_outside_the_shared_reciprocals_range_take_the_plain_divisions
     assert dev[4]["pairs_on_device"] + dev[4]["pairs_on_host"] == dev[4]["pairs_replayed"] == host[4]["pairs_replayed"]
     assert_same_records(host, dev)
     eng.set_exact_store(1)
+
+
+# ---- degenerate sites: the pair kernels leave the EM of their pairs to the replay (ld_prep.hip site_skip_kernel, PairArgs::skip_degenerate) ----
+# one wavefront per pair (1 .. 10 individuals per lane) and two (the shapes whose launches take the skip)
+@pytest.mark.parametrize("n_ind", [250, 330, 500, 512, 640, 1000])
+@pytest.mark.parametrize("ign", [False, True])
+def test_degenerate_sites_skip_their_em_and_the_records_are_the_oracles(eng, eng_skip, n_ind, ign):
+    n_sites = 80 if n_ind <= 640 else 40
+    raw = uncalled(n_sites, n_ind, seed=300 + n_ind, depth=8.0, mono_frac=0.3, missing=ign)
+    full = run_records(eng, raw, 2, ign)          # every pair's EM in the pair kernel
+    skip = run_records(eng_skip, raw, 2, ign)     # the marked sites' pairs: the replay only
+    assert full[4]["sites_degenerate"] == 0 and skip[4]["sites_degenerate"] >= n_sites // 8, (full[4], skip[4])
+    assert skip[4]["pairs_flagged"] >= full[4]["pairs_flagged"] > len(full[0]) // 10
+    assert skip[4]["pairs_on_device"] + skip[4]["pairs_on_host"] == skip[4]["pairs_replayed"] == skip[4]["pairs_flagged"]
+    want = orc.Oracle(raw, ignore_miss_data=ign, n_threads=4).run()
+    check_records(skip[2], skip[3], want)         # 1e-9 everywhere, the degenerate pairs bit for bit
+    # against the run without the skip: the same bits wherever both replayed or neither did; the pairs only the skip sent to the
+    # replay (marked site, outcome not decided by rounding) carry the reference's bits instead of the kernel's -- 1e-9, few
+    differ = np.zeros(len(full[0]), dtype=bool)
+    for col in ("D", "Dp", "r2"):
+        differ |= ~same_bits(full[2][col], skip[2][col])
+        assert close(full[2][col], skip[2][col]).all()
+    differ |= ~same_bits(full[3]["hap"], skip[3]["hap"]).all(axis=1)
+    assert close(full[3]["hap"], skip[3]["hap"]).all()
+    assert np.array_equal(full[3]["n_iter"], skip[3]["n_iter"]) and np.array_equal(full[3]["n_ind_data"], skip[3]["n_ind_data"])
+    assert same_bits(full[2]["r2_ExpG"], skip[2]["r2_ExpG"]).all()       # (the Pearson moment is the pair kernel's either way)
+    assert differ.sum() <= skip[4]["pairs_flagged"] - full[4]["pairs_flagged"]
+    assert differ.mean() < 0.15
+
+
+def test_snp_called_input_marks_no_site(eng_skip):
+    raw = synth.make_gl_numpy(300, 500, seed=12, depth=10.0)
+    r = run_records(eng_skip, raw, 1)
+    assert r[4]["sites_degenerate"] == 0
+
+
+@pytest.mark.parametrize("n_ind", [100, 2000])
+def test_shapes_that_do_not_take_the_skip_mark_no_site(eng_skip, n_ind):
+    """The lockstep kernel (a wavefront is spared only what ALL its groups skip) and four or more wavefronts per pair (a replayed
+    pair costs 7x a computed one there) measured slower with the skip: engine.hip, look_for_skip."""
+    raw = uncalled(40, n_ind, seed=17, mono_frac=0.3)
+    r = run_records(eng_skip, raw, 2)
+    assert r[4]["sites_degenerate"] == 0 and r[4]["pairs_on_device"] > 0
+
+
+def test_degenerate_sites_text_is_the_host_replays(eng, eng_skip):
+    """The TSV with the skip on is the TSV without it (and the host replay's) byte for byte: a pair only the skip sends to the
+    replay is one whose printed digits no rounding decides."""
+    raw = uncalled(300, 500, seed=91, depth=8.0, mono_frac=0.25)
+    chrs, pos = synth.make_positions(300, 9, max_gap=300)
+    labels = [f"{c}:{p}" for c, p in zip(chrs, pos)]
+    from ngsld_amd import shard
+    pd = shard.pos_dist_from_positions(chrs, pos)
+    md5 = {}
+    for name, e, mode in (("host", eng, 0), ("skip", eng_skip, 2), ("skip_auto", eng_skip, 1)):
+        e.set_exact_store(mode)
+        e.set_geno_raw(raw)
+        e.set_pos_dist(pd)
+        e.plan(max_kb_dist=20, extend_out=True)
+        e.set_text_output(labels)
+        t, fallbacks = e.run_text()
+        assert fallbacks == 0
+        md5[name] = hashlib.md5(t).hexdigest()
+        if name != "host":
+            assert e.replay_info()["sites_degenerate"] > 0
+        e.set_text_output(None, enable=False)
+    assert md5["host"] == md5["skip"] == md5["skip_auto"]

@@ -120,3 +120,14 @@ def test_budget_helper_sizes_slabs_with_the_engines_own_plane_layout(n_ind, np_w
     assert 0 < lo < hi
     per_site = (64 << 30) / (hi - lo)                      # d(budget / 2) / d(sites)
     assert abs(per_site - (72 * np_want + 64)) < 1e-3 * per_site, (n_ind, per_site, (per_site - 64) / 72)
+
+
+def test_budget_helper_prices_the_planes_alone_on_request():
+    """ngsld_sites_for_budget(..., 1): what a run NEEDS -- the planes; 3 is ngsld_slab_sites_for_budget.  The command line asks with
+    1 before it refuses a matrix it cannot stream (text input, no window): the exact store is optional (round 5 priced it into
+    the resident decision and such jobs aborted at a third of the memory they used to run in)."""
+    for n_ind in (100, 500, 2000):
+        three = capi.sites_for_budget(n_ind, 64 << 30, 3)
+        assert three == capi.slab_sites_for_budget(n_ind, 64 << 30) > 0
+        one, two = capi.sites_for_budget(n_ind, 64 << 30, 1), capi.sites_for_budget(n_ind, 64 << 30, 2)
+        assert three < two < one and 2.9 * three < one < 3.1 * three

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for SET in "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "FETCH_SIZE" "SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INST_CYCLES_VMEM TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"; do
   rm -rf /tmp/pmc_replay
-  rocprofv3 --pmc $SET --output-format csv -d /tmp/pmc_replay -o run -- python $R/bench.py --mono-frac 0.2 --no-cpu --no-sink --no-traffic --no-e2e --steps 1 --warmup 1 "$@" > /tmp/pmc_replay.log 2>&1
+  timeout 240 rocprofv3 --pmc $SET --output-format csv -d /tmp/pmc_replay -o run -- python $R/bench.py --mono-frac 0.2 --no-cpu --no-sink --no-traffic --no-e2e --steps 1 --warmup 1 "$@" > /tmp/pmc_replay.log 2>&1
   python - <<'PY'
 import csv, glob
 acc = {}

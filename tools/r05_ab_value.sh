@@ -8,7 +8,7 @@ for args in "$@"; do
   echo "== $args"
   for r in 1 2; do for v in "now=NGSLD_X=0" "old=NGSLD_LIB=$OLD"; do
     label=${v%%=*}; envs=${v#*=}
-    env $envs python bench.py $args --steps 3 --warmup 1 --no-cpu --no-e2e --no-traffic --no-sink --no-unfiltered 2>/dev/null | tail -1 | python -c "
+    env $envs python bench.py $args --steps 3 --warmup 1 --no-cpu --no-e2e --no-traffic --no-sink --no-unfiltered --no-other-configs 2>/dev/null | tail -1 | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); r=d['config'].get('replay_rank0_last_step',{}); print('round $r $label', '%.4g' % d['value'], '%.1f ms' % d['ms_per_step'], r.get('pairs_on_device'), r.get('pairs_on_host'))"
   done; done
 done

@@ -11,7 +11,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/lane_loop; mkdir -p $O
 AB=$PWD/ngsld_amd/ab
 one() {  # ms per step of bench.py --mono-frac 0.2 on library $1
-  NGSLD_LIB=$1 python bench.py --mono-frac 0.2 --steps 3 --warmup 1 --no-cpu --no-e2e --no-traffic --no-sink --no-unfiltered 2>/dev/null | tail -1 |
+  NGSLD_LIB=$1 python bench.py --mono-frac 0.2 --steps 3 --warmup 1 --no-cpu --no-e2e --no-traffic --no-sink --no-unfiltered --no-other-configs 2>/dev/null | tail -1 |
     python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['config'].get('replay_rank0_last_step',{}); print('%.2f %.5g %s %s %s' % (d['ms_per_step'], d['value'], r.get('pairs_on_device'), r.get('pairs_on_host'), d['config']['rank_records'][0]['records_checksum_u64']))"
 }
 : > $O/ab.txt

@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/tile; mkdir -p $O
 one() {  # $1 = tiling ("" = the library's default), $2.. = bench args
   local t=$1; shift
-  env ${t:+NGSLD_REPLAY_TILE=$t} python bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-e2e --no-traffic --no-sink --no-unfiltered 2>/dev/null | tail -1 |
+  env ${t:+NGSLD_REPLAY_TILE=$t} python bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-e2e --no-traffic --no-sink --no-unfiltered --no-other-configs 2>/dev/null | tail -1 |
     python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['config'].get('replay_rank0_last_step',{}); print('%.2f %.5g %s %s %s' % (d['ms_per_step'], d['value'], r.get('pairs_on_device'), r.get('pairs_on_host'), d['config']['rank_records'][0]['records_checksum_u64']))"
 }
 : > $O/ab.txt

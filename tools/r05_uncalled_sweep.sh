@@ -2,7 +2,7 @@
 # input that is NOT SNP-called beyond the two cases of the review: depth 2 (the survey's "stress" variant), half the sites monomorphic,
 # --ignore_miss_data, the large cohorts -- is there a cliff left anywhere?  One line per case: pass rate, pairs flagged / on device / on host.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-B="--steps 2 --warmup 1 --no-cpu --no-e2e --no-traffic --no-sink --no-unfiltered"
+B="--steps 2 --warmup 1 --no-cpu --no-e2e --no-traffic --no-sink --no-unfiltered --no-other-configs"
 run() { echo "== $*"; python bench.py $B "$@" 2>/dev/null | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); c=d['config']; r=c.get('replay_rank0_last_step',{})
