@@ -129,10 +129,6 @@ def test_device_replay_of_called_genotypes_is_the_hosts(n_ind, call, ignore, mis
     o = orc.Oracle(raw, None, ignore_miss_data=ignore, n_threads=32, call_geno=call)
     rec = o.run()
     got = {}
-    if tiny_list:
-        # the list of located pairs overflows too (in earnest only a launch of more than 2^26 flagged pairs does: ngsld_run_device on
-        # configs[3]'s size): what it cannot hold stays in the bitmap and must reach the host -- it used to be dropped, silently
-        monkeypatch.setenv("NGSLD_TEST_REPLAY_LIST_CAP", "3000")
     for where in ("device", "host"):
         monkeypatch.setenv("NGSLD_REPLAY_DEVICE", "1" if where == "device" else "0")
         eng = capi.Engine(0)
