@@ -314,6 +314,16 @@ uint64_t ngsld_slab_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes);
  * gives up. */
 uint64_t ngsld_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes, int matrix_copies);
 
+/* (0.4.0) ngsld_replay_info of the last ngsld_run_streamed / ngsld_run_streamed_text of this process, added up over its slabs
+ * (exact_store: the largest of the slabs' values; sites_degenerate counts a halo site once per slab that holds it). */
+int ngsld_streamed_replay_info(ngsld_replay_stats_t *out);
+
+/* (0.4.0) A cap, in bytes, on the device memory this PROCESS takes on `device` from now on (0: none) -- what the drop-in binary's
+ * --max_gpu_mem sets.  Slab sizes are the caller's to plan (ngsld_slab_sites_for_budget); the cap is looked at where the library
+ * allocates what it can do without: the exact store of the device-side replay (without room: flagged pairs on host threads) and
+ * its individual-major copy (without room: the wavefront-per-pair replay kernel, which reads the store's own layout). */
+int ngsld_set_memory_budget(int device, uint64_t bytes);
+
 /* Free and total memory of HIP device `device`, in bytes. */
 int ngsld_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
 

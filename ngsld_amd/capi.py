@@ -86,7 +86,7 @@ SYMBOLS = [
     "ngsld_set_exact_store", "ngsld_replay_info",
     "ngsld_plan_parts", "ngsld_run_multi", "ngsld_multi_last_distribution", "ngsld_rccl_selftest",
     "ngsld_last_kernel_time", "ngsld_pair_kernel", "ngsld_describe_dispatch", "ngsld_set_tuning", "ngsld_selftest", "ngsld_reserve_text_buffers",
-    "ngsld_window_ends", "ngsld_plan_slabs", "ngsld_slab_sites_for_budget", "ngsld_sites_for_budget", "ngsld_device_memory", "ngsld_run_streamed", "ngsld_run_streamed_text",
+    "ngsld_window_ends", "ngsld_plan_slabs", "ngsld_slab_sites_for_budget", "ngsld_sites_for_budget", "ngsld_streamed_replay_info", "ngsld_set_memory_budget", "ngsld_device_memory", "ngsld_run_streamed", "ngsld_run_streamed_text",
     "ngsld_host_read_geno_bin_range",
     "ngsld_host_set_threads", "ngsld_host_read_pos", "ngsld_host_pos_dist", "ngsld_host_label", "ngsld_host_free_pos", "ngsld_host_pos_slice",
     "ngsld_host_geno_size_ok", "ngsld_host_read_geno_bin", "ngsld_host_read_geno_text", "ngsld_host_format_header", "ngsld_host_format_pair",
@@ -284,6 +284,26 @@ def slab_sites_for_budget(n_ind: int, budget_bytes: int) -> int:
 def sites_for_budget(n_ind: int, budget_bytes: int, matrix_copies: int) -> int:
     """ngsld_sites_for_budget: the matrix priced matrix_copies times per context (1: the planes alone; 3: with the exact store)."""
     return int(lib().ngsld_sites_for_budget(n_ind, budget_bytes, matrix_copies))
+
+
+def streamed_replay_info() -> dict:
+    """ngsld_streamed_replay_info: where the flagged pairs of the last streamed job were replayed, summed over its slabs."""
+    st = ReplayStats()
+    L = lib()
+    L.ngsld_streamed_replay_info.argtypes = [C.POINTER(ReplayStats)]
+    rc = L.ngsld_streamed_replay_info(C.byref(st))
+    if rc != OK:
+        raise NgsldError(rc, "ngsld_streamed_replay_info")
+    return {k: getattr(st, k) for k, _ in ReplayStats._fields_}
+
+
+def set_memory_budget(device: int, n_bytes: int) -> None:
+    """ngsld_set_memory_budget: a cap on what this process takes of the device's memory from now on (0: none)."""
+    L = lib()
+    L.ngsld_set_memory_budget.argtypes = [C.c_int, C.c_uint64]
+    rc = L.ngsld_set_memory_budget(device, n_bytes)
+    if rc != OK:
+        raise NgsldError(rc, "ngsld_set_memory_budget")
 
 
 def device_memory(device: int = 0) -> tuple[int, int]:

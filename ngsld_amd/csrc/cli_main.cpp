@@ -356,6 +356,12 @@ bool run_streamed(Params &pars, uint64_t slab_sites, bool may_fall_back) {
   if (rc == NGSLD_ERR_NAN) error("read_geno", err);
   if (rc == NGSLD_ERR_MAF_RANGE) error("haplo_freq", err);
   if (rc != NGSLD_OK) error("ngsld_run_streamed", rs.err[0] ? rs.err : err);
+  if (pars.verbose >= 2) {  // (as the resident run's line, + where: a large host share means no room for the slabs' exact stores)
+    ngsld_replay_stats_t st;
+    if (ngsld_streamed_replay_info(&st) == NGSLD_OK)
+      fprintf(stderr, "==> %lu of %lu pairs replayed in the reference's operation order (%lu on the device, %lu on host threads)\n",
+              (unsigned long)st.pairs_replayed, (unsigned long)n_pairs, (unsigned long)st.pairs_on_device, (unsigned long)st.pairs_on_host);
+  }
   if (pars.verbose >= 1) fprintf(stderr, "==> Freeing memory...\n");
   close_output(pars.out_fh);
   ngsld_host_free_pos(pos);
@@ -595,29 +601,39 @@ int main(int argc, char **argv) {
       error("ngsld_device_memory", "cannot query the device memory");
     budget = (uint64_t)(0.9 * (double)free_b);
     if (pars.max_gpu_mem > 0 && pars.max_gpu_mem * 1e9 < (double)budget) budget = (uint64_t)(pars.max_gpu_mem * 1e9);
+    // (--max_gpu_mem holds for what the library allocates by itself too: the exact store of the device-side replay)
+    if (pars.max_gpu_mem > 0) (void)ngsld_set_memory_budget(pars.device, budget);
   }
   // resident = one context holding every site; the budget helpers price two, so ask with twice the budget.  `fits`: with room
-  // for the exact store of the device-side replay beside the planes (the matrix three times: un-called input builds it);
-  // `fits_bare`: the planes alone -- what a run needs; without room for the store its flagged pairs are replayed on host threads
-  const bool fits = ngsld_slab_sites_for_budget(pars.n_ind, 2 * budget) >= pars.n_sites;
+  // for what the device-side replay of un-called input builds beside the planes -- the exact store and, for the lane-per-pair
+  // replay kernel, its individual-major copy; this program's text batches of up to 512 individuals are the wavefront-per-pair
+  // kernel's, which reads the store's own layout: the matrix twice, three times beyond.  `fits_bare`: the planes alone -- what a
+  // run needs; without room for the store its flagged pairs are replayed on host threads (the same bytes, the reference's speed).
+  const int copies = pars.n_ind > 512 ? 3 : 2;
+  const bool fits = ngsld_sites_for_budget(pars.n_ind, 2 * budget, copies) >= pars.n_sites;
   const bool fits_bare = fits || ngsld_sites_for_budget(pars.n_ind, 2 * budget, 1) >= pars.n_sites;
   const bool streamable = pars.in_bin && (pars.max_kb_dist > 0 || pars.max_snp_dist > 0);
   uint64_t slab_sites = 0;  // > 0: run slab by slab
   if (const char *e = getenv("NGSLD_SLAB_SITES")) {  // tests: stream a small file in slabs of n sites
     if (pars.in_bin) slab_sites = strtoull(e, nullptr, 10);
-  } else if (!fits && !(fits_bare && !streamable)) {
-    // (a windowed run on binary input that fits only without the store is streamed too: every slab then has room for its own)
-    if (!pars.in_bin)
-      error(__FUNCTION__, "the genotype matrix does not fit the device memory budget (only binary input is streamed)");
-    slab_sites = ngsld_slab_sites_for_budget(pars.n_ind, budget);
-    if (slab_sites < 2) slab_sites = ngsld_sites_for_budget(pars.n_ind, budget, 1);  // (slabs without room for the store before none at all)
-    if (slab_sites < 2) error(__FUNCTION__, "the device memory budget is too small for this number of individuals");
+  } else if (!fits) {
+    // A windowed run on binary input that fits only without the store is streamed: every slab then has room for its own store.
+    // Where slabs cannot be had (text input, no window, a budget below two contexts) the matrix stays resident if its planes
+    // fit, without room for the store.
+    if (streamable) slab_sites = ngsld_sites_for_budget(pars.n_ind, budget, copies);
+    if (slab_sites < 2) slab_sites = 0;
+    if (slab_sites == 0 && !fits_bare) {
+      if (!pars.in_bin)
+        error(__FUNCTION__, "the genotype matrix does not fit the device memory budget (only binary input is streamed)");
+      slab_sites = ngsld_sites_for_budget(pars.n_ind, budget, 1);  // (slabs without room for the store before none at all)
+      if (slab_sites < 2) error(__FUNCTION__, "the device memory budget is too small for this number of individuals");
+    }
   } else if (pars.in_bin && (pars.max_kb_dist > 0 || pars.max_snp_dist > 0) && (uint64_t)st.st_size >= (4ull << 30) &&
              !(getenv("NGSLD_PIPELINE") && strcmp(getenv("NGSLD_PIPELINE"), "0") == 0)) {
     // a large windowed job that fits is still cut into about six slabs, only to overlap the file read and the
     // upload of one part with the pair kernels of the previous one (same output; falls back when a window is too wide).
     // From 4 GiB: a 1.2 GB file ran 0.5 s faster resident (2.2 s) than in slabs, a 5.8 GB one 0.5 s slower.
-    slab_sites = std::min<uint64_t>(ngsld_slab_sites_for_budget(pars.n_ind, budget), (pars.n_sites + 5) / 6);
+    slab_sites = std::min<uint64_t>(ngsld_sites_for_budget(pars.n_ind, budget, copies), (pars.n_sites + 5) / 6);
   }
   if (slab_sites > 0) {
     join_early();  // (an early read is only started for matrices far below these thresholds: normally nothing to wait for)
@@ -759,10 +775,10 @@ int main(int argc, char **argv) {
   if (rc != NGSLD_OK) error("ngsld_run", ngsld_last_error(ctx));
   if (pars.verbose >= 2) {  // (level 1 is the reference's default: its stderr stays what the reference prints.  A large share
                             // here means pairs computed at the host's speed: two nearly monomorphic sites each)
-    uint64_t rp = 0, rsites = 0;
-    ngsld_replay_stats(ctx, &rp, &rsites);
-    fprintf(stderr, "==> %lu of %lu pairs replayed in the reference's operation order\n", (unsigned long)rp,
-            (unsigned long)n_pairs);
+    ngsld_replay_stats_t st{};
+    (void)ngsld_replay_info(ctx, &st);
+    fprintf(stderr, "==> %lu of %lu pairs replayed in the reference's operation order (%lu on the device, %lu on host threads)\n",
+            (unsigned long)st.pairs_replayed, (unsigned long)n_pairs, (unsigned long)st.pairs_on_device, (unsigned long)st.pairs_on_host);
   }
 
   // ---- free memory (ngsLD.cpp:205-222) ----

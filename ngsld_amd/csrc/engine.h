@@ -512,6 +512,9 @@ int fetch_replay_site(ngsld_ctx *c, uint64_t s, std::vector<double> &tmp, Replay
 int flagged_records(ngsld_ctx *c, const uint32_t *h_head, const uint32_t *d_flags, uint32_t cap, uint64_t n,
                     std::vector<uint64_t> &recs, bool dev_applied = false);
 // likelihood matrices: can the flagged pairs of this context's runs be replayed on the device at all / right now?
+// room on the device for `need_bytes` more: hipMemGetInfo's free memory (less device_margin) and, where a cap is set
+// (ngsld_set_memory_budget), what the process has taken since against the cap (less budget_margin)
+bool room_for(uint64_t need_bytes, uint64_t device_margin, uint64_t budget_margin);
 bool lkl_device_eligible(const ngsld_ctx *c);
 bool exact_store_is_free(const ngsld_ctx *c);
 // the store there or on its way (device_replay_lkl may be asked for launches whose sites it covers)

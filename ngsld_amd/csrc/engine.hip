@@ -3,6 +3,8 @@
 // engine_plan.hip, engine_run.hip and engine_replay.hip; engine.h is what they share.
 #include "engine.h"
 
+#include <atomic>
+
 namespace ngsld {
 namespace eng {
 
@@ -472,6 +474,39 @@ uint64_t ngsld_sites_for_budget(uint64_t n_ind, uint64_t budget_bytes, int matri
   // un-called input has built -- engine_replay.hip; once: the planes, what a run cannot do without)
   const uint64_t copies = matrix_copies < 1 ? 1 : (matrix_copies > 3 ? 3 : (uint64_t)matrix_copies);
   return (per_ctx - fixed) / (24ull * copies * cfg.np + 64ull);
+}
+
+}  // extern "C"
+
+// A cap on what this process may take of a device's memory (the command line's --max_gpu_mem): counted from the moment it is set
+// -- free memory then, against free memory now -- and looked at where the library allocates what it can do without: the exact
+// store of the device-side replay and its individual-major copy (engine_replay.hip).  0: no cap but the device's own.
+namespace ngsld {
+namespace eng {
+static std::atomic<uint64_t> g_mem_budget{0}, g_mem_base_free{0};
+bool room_for(uint64_t need_bytes, uint64_t device_margin, uint64_t budget_margin) {
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  if ((uint64_t)free_b < need_bytes + device_margin) return false;
+  const uint64_t budget = g_mem_budget.load();
+  if (budget == 0) return true;
+  const uint64_t base = g_mem_base_free.load(), used = base > (uint64_t)free_b ? base - (uint64_t)free_b : 0;
+  return used + need_bytes + budget_margin <= budget;
+}
+}  // namespace eng
+}  // namespace ngsld
+
+extern "C" {
+
+int ngsld_set_memory_budget(int device, uint64_t bytes) {
+  uint64_t free_b = 0;
+  if (ngsld_device_memory(device, &free_b, nullptr) != NGSLD_OK) return NGSLD_ERR_DEVICE;
+  ngsld::eng::g_mem_base_free.store(free_b);
+  ngsld::eng::g_mem_budget.store(bytes);
+  return NGSLD_OK;
 }
 
 int ngsld_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes) {

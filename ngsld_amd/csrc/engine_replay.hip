@@ -438,11 +438,8 @@ static bool alloc_lane_store(ngsld_ctx *c) {
   if (const char *e = std::getenv("NGSLD_REPLAY_LANES"))
     if (std::strcmp(e, "0") == 0) return false;
   const size_t elems = (size_t)c->n_sites * c->n_ind * 3;
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < elems * sizeof(double) + (4ull << 30)) {
-    (void)hipGetLastError();
-    return false;
-  }
+  // (4 GB of the device left for what comes later -- text buffers, the lanes' list and sort scratch; under a cap: half a GB of it)
+  if (!room_for(elems * sizeof(double), 4ull << 30, 512ull << 20)) return false;
   // The order of the sites in the copy: the RARE ones first (folded frequency below 1/32, or no frequency), the others behind,
   // each class in site order.  The pairs the lanes replay are pairs with a (nearly) monomorphic site, a wavefront's 64 lanes hold
   // a few neighbouring rare sites x 8 partners they share (replay_keys_kernel), and per individual the rare sites' triples are
@@ -647,6 +644,12 @@ void stop_exact_store(ngsld_ctx *c) {
   c->exact_msg.clear();
   c->exact_ready = false;
   c->xT_ready = false;
+  // (a new source or matrix: nothing of the old store is of use, start_exact_store allocates what it needs)
+  c->d_xplanes.release();
+  c->d_xmaf.release();
+  c->d_xT.release();
+  c->d_xperm.release();
+  c->d_xdepth.release();
 }
 
 int start_exact_store(ngsld_ctx *c) {
@@ -667,7 +670,8 @@ int start_exact_store(ngsld_ctx *c) {
   }
   // (a device without room for the matrix once more: no store for this matrix -- its flagged pairs stay with the host's threads)
   const bool pretend = std::getenv("NGSLD_EXACT_STORE_NO_ROOM") != nullptr;  // tests
-  if (pretend || c->d_xplanes.resize((size_t)c->n_sites * 3 * c->np) != hipSuccess || c->d_xmaf.resize(c->n_sites) != hipSuccess) {
+  const bool no_room = !room_for((uint64_t)c->n_sites * (3ull * c->np + 1) * sizeof(double), 0, 256ull << 20);  // (ngsld_set_memory_budget)
+  if (pretend || no_room || c->d_xplanes.resize((size_t)c->n_sites * 3 * c->np) != hipSuccess || c->d_xmaf.resize(c->n_sites) != hipSuccess) {
     (void)hipGetLastError();
     c->d_xplanes.release();
     c->d_xmaf.release();
@@ -712,6 +716,10 @@ int wait_exact_store(ngsld_ctx *c, uint64_t need_sites, bool *have) {
       c->exact_failed = true;  // (not again for this matrix)
       c->d_xplanes.release();
       c->d_xmaf.release();
+      c->d_xT.release();
+      c->d_xperm.release();
+      c->d_xdepth.release();
+      c->xT_ready = false;
       return rc != NGSLD_OK ? fail(c, rc, msg.c_str()) : NGSLD_OK;
     }
   }

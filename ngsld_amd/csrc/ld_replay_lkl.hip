@@ -653,36 +653,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
       // The individuals in order, two register sets used in turn: the next individual's triples are on their way while this one
       // is worked on, and nothing is copied from a staging set into place (154 registers, three wavefronts to a SIMD: -1.1 % of a
       // pass against one set + staging at four, profiles/r06/lane/ab2.txt)
-      double a0[3], b0[3], a1[3], b1[3];
-      auto fetch = [&](double (&a)[3], double (&b)[3], uint32_t i) {
+#ifndef NGSLD_LANE_SETS
+#define NGSLD_LANE_SETS 2
+#endif
+      constexpr int D = NGSLD_LANE_SETS;  // register sets: an individual's triples are fetched D - 1 steps before they are used
+      double a[D][3], b[D][3];
+      auto fetch = [&](double (&pa_)[3], double (&pb_)[3], uint32_t i) {
         const double *qa = pa + (uint64_t)i * row, *qb = pb + (uint64_t)i * row;
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
-          a[g] = qa[g];
-          b[g] = qb[g];
+          pa_[g] = qa[g];
+          pb_[g] = qb[g];
         }
       };
-      auto step = [&](const double (&a)[3], const double (&b)[3]) {
+      auto step = [&](const double (&pa_)[3], const double (&pb_)[3]) {
         if (ign) {
-          if (no_data(a) || no_data(b)) return;  // gen_func.cpp:1089
+          if (no_data(pa_) || no_data(pb_)) return;  // gen_func.cpp:1089
           ++x;
         }
         double o[4];
-        quotients<kLight>(F, a, b, o);
+        quotients<kLight>(F, pa_, pb_, o);
 #pragma unroll
         for (int k = 0; k < 4; ++k) ff[k] += o[k];  // gen_func.cpp:1103, in the reference's order
       };
-      fetch(a0, b0, 0);
+#pragma unroll
+      for (int j = 0; j < D; ++j)
+        if ((uint32_t)j < A.n_ind) fetch(a[j], b[j], (uint32_t)j);
       uint32_t i = 0;
-      for (; i + 1 < A.n_ind; i += 2) {
-        fetch(a1, b1, i + 1);
-        step(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 2 < A.n_ind) fetch(a0, b0, i + 2);
-        step(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
+      for (; i + D <= A.n_ind; i += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          step(a[j], b[j]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + D + j < A.n_ind) fetch(a[j], b[j], i + D + j);
+        }
       }
-      if (i < A.n_ind) step(a0, b0);
+#pragma unroll
+      for (int j = 0; j < D - 1; ++j)
+        if (i + j < A.n_ind) step(a[j], b[j]);
     };
     if (have) {
       if (light)

@@ -51,6 +51,11 @@ int rebase_sink(void *user, const ngsld_batch *b) {
 
 }  // namespace
 
+namespace {
+std::mutex g_streamed_mu;
+ngsld_replay_stats_t g_streamed_replay{};  // the last streamed job of this process, summed over its slabs
+}  // namespace
+
 extern "C" {
 
 int ngsld_plan_slabs(const double *pos_dist, uint64_t n_sites, const ngsld_params *params, uint64_t max_slab_sites,
@@ -247,6 +252,10 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
   uint64_t total = 0;
   int run_rc = NGSLD_OK;
   std::string run_msg;
+  {
+    std::lock_guard<std::mutex> lk(g_streamed_mu);
+    g_streamed_replay = ngsld_replay_stats_t{};
+  }
   Rebase rb{0, sink, sink_user, {}};
   for (uint64_t k = 0; k < n_slabs; ++k) {
     const int b = (int)(k & 1);
@@ -258,6 +267,21 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
     rb.base = slabs[k].row_begin;
     run_rc = ngsld_run(ctx[b], 0, slabs[k].row_end - slabs[k].row_begin, rebase_sink, &rb);
     if (run_rc != NGSLD_OK) run_msg = ngsld_last_error(ctx[b]);
+    {  // where the slab's flagged pairs were replayed, added up over the job (ngsld_streamed_replay_info)
+      ngsld_replay_stats_t st;
+      if (run_rc == NGSLD_OK && ngsld_replay_info(ctx[b], &st) == NGSLD_OK) {
+        std::lock_guard<std::mutex> lk(g_streamed_mu);
+        g_streamed_replay.pairs_flagged += st.pairs_flagged;
+        g_streamed_replay.pairs_replayed += st.pairs_replayed;
+        g_streamed_replay.pairs_on_device += st.pairs_on_device;
+        g_streamed_replay.pairs_on_host += st.pairs_on_host;
+        g_streamed_replay.sites_reevaluated += st.sites_reevaluated;
+        g_streamed_replay.sites_degenerate += st.sites_degenerate;
+        g_streamed_replay.exact_store_build_s += st.exact_store_build_s;
+        g_streamed_replay.exact_store = std::max(g_streamed_replay.exact_store, st.exact_store);
+        g_streamed_replay.text_rows_patched += st.text_rows_patched;
+      }
+    }
     total += slab_pairs[k];
     std::lock_guard<std::mutex> lk(mu);
     if (run_rc != NGSLD_OK) stop = true;
@@ -282,6 +306,13 @@ int ngsld_run_streamed_text(int device, uint64_t n_sites, uint64_t n_ind, const 
     set_err(err, errlen, load_msg);
     return load_rc;
   }
+  return NGSLD_OK;
+}
+
+int ngsld_streamed_replay_info(ngsld_replay_stats_t *out) {
+  if (out == nullptr) return NGSLD_ERR_INVALID;
+  std::lock_guard<std::mutex> lk(g_streamed_mu);
+  *out = g_streamed_replay;
   return NGSLD_OK;
 }
 

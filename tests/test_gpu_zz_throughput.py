@@ -50,7 +50,10 @@ def test_cohort_sizes_past_the_old_cliffs_keep_their_rate(n_ind, floor):
 # shared reciprocal and tiled sort key, 1.42e8 .. 1.46e8 / 2.27e8 on three boxes, profiles/r05/late/tile -- floors 1.15e8 / 1.6e8,
 # still more than 15 % under what the slowest box of the pool would show.)
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("flags,floor", [(["--mono-frac", "0.2"], 1.15e8), (["--sfs"], 1.6e8)])
+# (Round 6: the pairs of degenerate sites skip their EM in the pair kernel, the lane replay tests its operands with one instruction,
+# uses two register sets in turn and reads a copy with its rare sites first: 1.50e8 .. 1.64e8 / 2.18e8 .. 2.34e8 on the boxes of the
+# round, profiles/r06 -- floors 1.35e8 / 1.9e8.)
+@pytest.mark.parametrize("flags,floor", [(["--mono-frac", "0.2"], 1.35e8), (["--sfs"], 1.9e8)])
 def test_uncalled_input_is_replayed_on_the_device(flags, floor):
     cmd = [sys.executable, "bench.py", "--config", "c2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-sink", "--no-e2e",
            "--no-traffic"] + flags
@@ -65,3 +68,52 @@ def test_uncalled_input_is_replayed_on_the_device(flags, floor):
     assert rep["pairs_on_host"] * 10_000 <= d["config"]["pairs_per_step"], "host-only share of the pairs above 1e-4"
     assert rep["pairs_on_device"] + rep["pairs_on_host"] == rep["pairs_flagged"]
     assert d["value"] >= floor, f"{flags}: {d['value']:.4g} pairs/s is below the floor of {floor:.3g}"
+
+
+# Round 6: the exact store priced.  The store is the matrix once more in device memory (and once more again for the lanes'
+# individual-major copy); `--max_gpu_mem` is a cap on all of it now (ngsld_set_memory_budget).  Under a budget of the fixed part + 1.5 x
+# the planes -- the planes fit, planes + store + copy do not -- the binary keeps the matrix resident, builds the store, goes without
+# the copy (text batches are the wavefront-per-pair kernel's anyway) and leaves next to nothing to the host's threads: 1.56 s for
+# configs[2]'s un-called twin, as without a cap (profiles/r06/store_budget.json).  (Without room for the store itself the flagged
+# pairs go to the host's threads at the reference's own speed: the cliff is still there below planes + store.)
+@pytest.mark.timeout(900)
+def test_uncalled_input_under_a_memory_budget_of_one_and_a_half_times_the_planes(tmp_path_factory):
+    import os
+    import re
+    import tempfile
+    import time
+
+    import torch
+
+    from ngsld_amd import shard, synth
+    n_sites, n_ind = 100_000, 500
+    chrs, pos = synth.make_positions(n_sites, 3)
+    n_pairs = int(shard.row_pair_counts(shard.pos_dist_from_positions(chrs, pos), 100, 0).sum())
+    planes_gb = n_sites * 3 * 512 * 8 / 1e9
+    budget = 2.58 + 1.5 * planes_gb            # (ngsld_sites_for_budget's fixed part of one context + 1.5 x the planes)
+    with tempfile.TemporaryDirectory(dir="/dev/shm") as d:
+        raw = synth.make_gl_torch(n_sites, n_ind, 3, torch.device("cuda", 0), mono_frac=0.2)
+        g, p = os.path.join(d, "in.glf"), os.path.join(d, "in.pos")
+        with open(g, "wb") as fh:
+            for lo in range(0, n_sites, 20000):
+                fh.write(raw[lo:lo + 20000].cpu().numpy().tobytes())
+        del raw
+        torch.cuda.empty_cache()
+        synth.write_pos(p, chrs, pos)
+        cmd = [capi.CLI_PATH, "--geno", g, "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--pos", p, "--max_kb_dist", "100",
+               "--extend_out", "--n_threads", "16", "--verbose", "2", "--out", "/dev/null", "--max_gpu_mem", f"{budget:.2f}"]
+        best, err = None, ""
+        for _ in range(2):
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            dt = time.perf_counter() - t0
+            assert r.returncode == 0, r.stderr[-2000:]
+            best, err = (dt if best is None else min(best, dt)), r.stderr
+    m = re.search(r"(\d+) of (\d+) pairs replayed .*\((\d+) on the device, (\d+) on host threads\)", err)
+    assert m, err[-1500:]
+    replayed, total, on_dev, on_host = (int(x) for x in m.groups())
+    print(f"\n[throughput] un-called configs[2] through the binary under --max_gpu_mem {budget:.2f} GB: {best:.3f} s = {n_pairs / best:.4g} pairs/s, "
+          f"{replayed} pairs replayed, {on_host} of them on host threads")
+    assert total == n_pairs and replayed > n_pairs // 10 and on_dev + on_host == replayed
+    assert on_host * 10_000 <= n_pairs, "host share of the pairs above 1e-4: no room was found for the exact store"
+    assert n_pairs / best >= 5e7
