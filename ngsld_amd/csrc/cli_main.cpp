@@ -27,6 +27,7 @@
 
 #include "../../include/ngsld.h"
 #include "../../include/ngsld_host.h"
+#include "knobs.h"
 #include "host_buf.h"
 
 namespace {
@@ -314,6 +315,12 @@ void fill_run_params(const Params &pars, ngsld_params *lp, ngsld_geno_opts *go) 
 
 // The out-of-core path (no counterpart in the reference): the same TSV, the matrix read slab by slab.
 // Returns false (nothing written yet) when may_fall_back and the slabs cannot hold a window.
+// NGSLD_HOST_TEXT=1: every row through the host formatter (the fallback of the device-side TSV; A/B, tests)
+static bool host_text_only() {
+  static const bool on = getenv("NGSLD_HOST_TEXT") && strcmp(getenv("NGSLD_HOST_TEXT"), "1") == 0;
+  return on;
+}
+
 bool run_streamed(Params &pars, uint64_t slab_sites, bool may_fall_back) {
   char err[512];
   ngsld_pos *pos = nullptr;
@@ -344,7 +351,7 @@ bool run_streamed(Params &pars, uint64_t slab_sites, bool may_fall_back) {
   }
   if (pars.verbose >= 1)
     fprintf(stderr, "==> Streaming the genotype matrix in slabs of up to %lu sites\n", (unsigned long)slab_sites);
-  const bool dev_text = !(getenv("NGSLD_HOST_TEXT") && strcmp(getenv("NGSLD_HOST_TEXT"), "1") == 0);
+  const bool dev_text = !host_text_only();
   std::vector<const char *> lab;
   if (pos && dev_text) {
     lab.resize(pars.n_sites);
@@ -434,7 +441,7 @@ void run_multi(Params &pars, const double *raw, int text_semantics, int log_scal
   ReadState rs;
   rs.pars = &pars;
   rs.err[0] = 0;
-  const bool dev_text = !(getenv("NGSLD_HOST_TEXT") && strcmp(getenv("NGSLD_HOST_TEXT"), "1") == 0);
+  const bool dev_text = !host_text_only();
   std::vector<const char *> lab;
   if (pos && dev_text) {
     lab.resize(pars.n_sites);
@@ -553,9 +560,8 @@ int main(int argc, char **argv) {
     ngsld_pos *pos = nullptr;
   } early;
   const uint64_t geno_bytes = (uint64_t)pars.n_sites * pars.n_ind * 3 * sizeof(double);
-  if (pars.in_bin && geno_bytes < (4ull << 30) && getenv("NGSLD_SLAB_SITES") == nullptr &&
-      (pars.max_gpu_mem <= 0 || pars.max_gpu_mem * 1e9 > 3.0 * (double)geno_bytes) &&
-      !(getenv("NGSLD_EARLY_READ") && strcmp(getenv("NGSLD_EARLY_READ"), "0") == 0)) {
+  if (pars.in_bin && geno_bytes < (4ull << 30) && ngsld::test_knob("SLAB_SITES") == nullptr &&
+      (pars.max_gpu_mem <= 0 || pars.max_gpu_mem * 1e9 > 3.0 * (double)geno_bytes)) {
     early.raw.reset(alloc_matrix((size_t)geno_bytes));
     if (early.raw) {
       early.started = true;
@@ -614,7 +620,7 @@ int main(int argc, char **argv) {
   const bool fits_bare = fits || ngsld_sites_for_budget(pars.n_ind, 2 * budget, 1) >= pars.n_sites;
   const bool streamable = pars.in_bin && (pars.max_kb_dist > 0 || pars.max_snp_dist > 0);
   uint64_t slab_sites = 0;  // > 0: run slab by slab
-  if (const char *e = getenv("NGSLD_SLAB_SITES")) {  // tests: stream a small file in slabs of n sites
+  if (const char *e = ngsld::test_knob("SLAB_SITES")) {  // tests: stream a small file in slabs of n sites
     if (pars.in_bin) slab_sites = strtoull(e, nullptr, 10);
   } else if (!fits) {
     // A windowed run on binary input that fits only without the store is streamed: every slab then has room for its own store.
@@ -651,7 +657,7 @@ int main(int argc, char **argv) {
   // and prepped (pinning ~0.7 GB costs ~0.1 s, which the first batches of the run used to wait for).  Only now that the run is
   // known to be resident: a streamed run uses contexts of its own, and destroying this one had to wait for the pinning to
   // finish only to undo it
-  if (!(getenv("NGSLD_HOST_TEXT") && strcmp(getenv("NGSLD_HOST_TEXT"), "1") == 0))
+  if (!host_text_only())
     (void)ngsld_reserve_text_buffers(ctx, pars.extend_out ? 190 : 95);
 
   // ---- read input data (ngsLD.cpp:85-114; the arithmetic runs on the device) ----
@@ -711,9 +717,9 @@ int main(int argc, char **argv) {
     memcpy(dst, r->raw + site_begin * r->n_ind * 3, n * r->n_ind * 3 * sizeof(double));
     return 0;
   };
-  if (getenv("NGSLD_REPLAY_SOURCE") && strcmp(getenv("NGSLD_REPLAY_SOURCE"), "0") == 0)
+  if (ngsld::test_knob_is("REPLAY_SOURCE", "0"))
     raw.reset();  // (tests: replay from the device's own planes)
-  else if (getenv("NGSLD_REPLAY_SOURCE") && strcmp(getenv("NGSLD_REPLAY_SOURCE"), "callback") == 0) {  // (tests: the callback form)
+  else if (ngsld::test_knob_is("REPLAY_SOURCE", "callback")) {  // (tests: the callback form)
     if (ngsld_set_replay_source(ctx, read_raw, &raw_src) != NGSLD_OK) error("ngsld_set_replay_source", ngsld_last_error(ctx));
   } else if (ngsld_set_replay_matrix(ctx, raw.get()) != NGSLD_OK)
     error("ngsld_set_replay_matrix", ngsld_last_error(ctx));
@@ -753,7 +759,7 @@ int main(int argc, char **argv) {
   // The rows are formatted on the device (the fprintf block of calc_pair_LD, ngsLD.cpp:310-352, at kernel rates); a
   // batch the device formatter cannot take arrives as records and goes through the --n_threads host formatter as
   // before.  NGSLD_HOST_TEXT=1 keeps everything on the host formatter (A/B, tests).
-  if (!(getenv("NGSLD_HOST_TEXT") && strcmp(getenv("NGSLD_HOST_TEXT"), "1") == 0)) {
+  if (!host_text_only()) {
     std::vector<const char *> lab;
     if (pos) {
       lab.resize(pars.n_sites);

@@ -6,6 +6,8 @@
 //   engine_replay.hip  exact-order replay: flag lists, host threads, the device-side replays, the exact-value store
 #pragma once
 
+#include "knobs.h"
+
 #include <hip/hip_runtime.h>
 #include <sched.h>
 #include <dlfcn.h>
@@ -304,7 +306,7 @@ struct ngsld_ctx {
   int kernel_choice = kChooseAuto;
   uint32_t pairs_per_item = 16;
   uint64_t batch_pairs = 1ull << 23;
-  bool batch_pairs_set = false;  // by the caller (ngsld_set_tuning / NGSLD_BATCH_PAIRS): taken as it is
+  bool batch_pairs_set = false;  // by the caller (ngsld_set_tuning / NGSLD_TEST_BATCH_PAIRS): taken as it is
 
   // batch pipeline: three slots for record batches, two of them for text batches
   static constexpr int kSlots = 3;
@@ -313,7 +315,7 @@ struct ngsld_ctx {
   PinBuf<ngsld_rec_std> h_std[kSlots];
   PinBuf<ngsld_rec_ext> h_ext[kSlots];
   hipEvent_t ev_kernel_done[kSlots] = {nullptr, nullptr, nullptr}, ev_copy_done[kSlots] = {nullptr, nullptr, nullptr};
-  // how record batches reach the host (ngsld_run without text output; NGSLD_RUN_DIRECT / NGSLD_RUN_TAPER):
+  // how record batches reach the host (ngsld_run without text output; NGSLD_TEST_RUN_DIRECT / NGSLD_TEST_RUN_TAPER):
   //   run_direct   the pair kernels write the records straight into the batch's pinned host buffers over the host link
   //                (72 B per pair at 2e8 pairs/s is 15 GB/s of posted writes; same-box A/B, profiles/r04/sink_ab.txt: the
   //                kernels take the same time) -- there is no device copy of the records and no D2H copy behind the last
@@ -321,7 +323,7 @@ struct ngsld_ctx {
   //   run_taper    the batches shrink towards the end of a run (a third of what is left, at least 2^19 pairs), so that the
   //                copy exposed behind the last kernel is small
   //   run_streams  1: one compute stream, every batch drains alone -- its last rows cut into short runs (build_runs), which
-  //                takes the loss from 1.4 to ~0.4 ms per launch.  2 (opt-in, NGSLD_RUN_STREAMS=2): consecutive record
+  //                takes the loss from 1.4 to ~0.4 ms per launch.  2 (opt-in, NGSLD_TEST_RUN_STREAMS=2): consecutive record
   //                batches on two compute streams HALF A BATCH OUT OF PHASE (the first batch is half a batch), so that
   //                whenever one stream's batch drains the other is in the middle of its own and fills the slots that fall
   //                free.  Measured on four boxes (profiles/r04/sink_rr*.txt, host-resident rate over the device-resident
@@ -472,7 +474,7 @@ inline int check_status(ngsld_ctx *c) {
   return NGSLD_OK;
 }
 
-// Rows per text batch (ngsld_run; a smaller NGSLD_BATCH_PAIRS / ngsld_set_tuning wins).  Round 4, configs[2] end to end on one
+// Rows per text batch (ngsld_run; a smaller NGSLD_TEST_BATCH_PAIRS / ngsld_set_tuning wins).  Round 4, configs[2] end to end on one
 // box (profiles/r04/e2e_batch_size.txt): 2^21 1.42-1.46 s, 2^20 1.25-1.35 s, 2^19 1.23-1.25 s -- the loop itself takes the
 // same 0.62 s whatever the count (a batch costs ~0.3 ms since its last rows go out as short runs and a replayed row no longer
 // has every length derived again), while the two pinned buffers (2 x 400 MB at 2^21) cost 0.1 s to pin -- beside the matrix

@@ -82,7 +82,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   a.text_semantics = o.text_semantics;
   a.call_geno = o.call_geno;
   {
-    const char *pe = std::getenv("NGSLD_PREP_EXACT");  // tests: every triple through the reference's log / exp chain
+    const char *pe = test_knob("PREP_EXACT");  // tests: every triple through the reference's log / exp chain
     a.exact_chain = (pe != nullptr && std::strcmp(pe, "0") != 0) ? 1 : 0;
   }
   a.N_thresh = o.N_thresh;
@@ -110,7 +110,7 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   } else {
     const uint64_t site_bytes = n_ind * 3 * sizeof(double);
     uint64_t stage_bytes = 64ull << 20;
-    if (const char *e = std::getenv("NGSLD_STAGE_BYTES")) stage_bytes = std::strtoull(e, nullptr, 10);  // tests: force many chunks
+    if (const char *e = test_knob("STAGE_BYTES")) stage_bytes = std::strtoull(e, nullptr, 10);  // tests: force many chunks
     uint64_t chunk = stage_bytes / site_bytes;
     if (chunk < 1) chunk = 1;
     if (chunk > n_sites) chunk = n_sites;
@@ -174,10 +174,10 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   }
   HIP_TRY(c, launch_pack_scalars(c->d_maf.p, c->d_mean.p, c->d_rsx.p, c->d_skip.p, c->d_sc4.p, n_sites, c->stream));
   // Is every likelihood triple a called genotype or "no data" (text genotypes, --call_geno)?  Then the pairs run on the
-  // 16 genotype-combination counts instead of the individuals (ld_pair_hard.hip).  NGSLD_HARD_KERNEL=0: never (A/B, tests).
+  // 16 genotype-combination counts instead of the individuals (ld_pair_hard.hip).  NGSLD_TEST_HARD_KERNEL=0: never (A/B, tests).
   int &all_hard = c->h_all_hard;  // (ctx-owned: the asynchronous copies below must not target a stack frame an early return leaves)
   all_hard = 0;
-  const char *hk = std::getenv("NGSLD_HARD_KERNEL");
+  const char *hk = test_knob("HARD_KERNEL");
   const bool try_hard = n_ind <= kHardMaxInd && !o.per_individual_only && !(hk != nullptr && std::strcmp(hk, "0") == 0);
   if (try_hard) {
     c->mask_words = (uint32_t)((n_ind + 63) / 64);
@@ -259,7 +259,7 @@ int ngsld_create(int device, ngsld_ctx **out) {
                           : (std::strcmp(k, "stream") == 0 ? kChoosePlainStream : (std::strcmp(k, "abm") == 0 ? kChooseABMulti
                                                                : (std::strcmp(k, "bres") == 0 ? kChooseResidentStream : kChooseAuto))));
   }
-  if (const char *k = std::getenv("NGSLD_BATCH_PAIRS")) {  // tests: many small batches through ngsld_run
+  if (const char *k = test_knob("BATCH_PAIRS")) {  // tests: many small batches through ngsld_run
     const uint64_t v = std::strtoull(k, nullptr, 10);
     if (v > 0) {
       c->batch_pairs = v;
@@ -271,9 +271,9 @@ int ngsld_create(int device, ngsld_ctx **out) {
   if (const char *k = std::getenv("NGSLD_REPLAY_DEVICE")) c->replay_device = std::strcmp(k, "0") != 0;
   if (const char *k = std::getenv("NGSLD_REPLAY_SKIP")) c->skip_on = std::strcmp(k, "0") != 0;  // A/B, tests
   if (const char *k = std::getenv("NGSLD_EXACT_STORE")) c->exact_mode = std::max(0, std::min(2, std::atoi(k)));  // ngsld_set_exact_store
-  if (const char *k = std::getenv("NGSLD_RUN_DIRECT")) c->run_direct = std::strcmp(k, "0") != 0;  // A/B, tests (see ngsld_ctx)
-  if (const char *k = std::getenv("NGSLD_RUN_TAPER")) c->run_taper = std::strcmp(k, "0") != 0;
-  if (const char *k = std::getenv("NGSLD_RUN_STREAMS")) c->run_streams = std::atoi(k) >= 2 ? 2 : 1;
+  if (const char *k = test_knob("RUN_DIRECT")) c->run_direct = std::strcmp(k, "0") != 0;  // A/B, tests (see ngsld_ctx)
+  if (const char *k = test_knob("RUN_TAPER")) c->run_taper = std::strcmp(k, "0") != 0;
+  if (const char *k = test_knob("RUN_STREAMS")) c->run_streams = std::atoi(k) >= 2 ? 2 : 1;
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
       (e = hipStreamCreate(&c->stream2)) != hipSuccess || (e = hipStreamCreate(&c->copy_stream)) != hipSuccess) {
     g_create_error = std::string("stream setup: ") + hipGetErrorString(e);

@@ -62,7 +62,7 @@ void plan_rows(const std::vector<double> &pos_dist, const std::vector<double> &m
 // Runs: a row's items cut into ceil(items / run_len) runs of near-equal length, one workgroup each.  run_len = kRunItems
 // (16 items = 1,024 candidates: a whole 100 kb row) is what the pair kernel likes best in one big launch; a run that goes
 // out in SMALL batches -- text batches are 2^21 pairs, i.e. only four rounds of such workgroups on 512 slots, each batch
-// ending in a ragged tail -- is cut finer (ngsld_run).  NGSLD_RUN_LEN overrides (tuning / A-B).
+// ending in a ragged tail -- is cut finer (ngsld_run).
 //
 // Tails.  A launch of equal workgroups of length L ends in a drain: the device's 2 x CUs workgroup slots finish evenly over
 // the last L (2.5 ms for whole-row runs at n_ind 500), i.e. L / 2 of the whole device is lost per launch -- 1.4 ms,
@@ -70,22 +70,18 @@ void plan_rows(const std::vector<double> &pos_dist, const std::vector<double> &m
 // launch are therefore cut into short runs (run_len / 8): as many of them as fill that triangle (CUs x one full run of
 // pairs), so that every slot that falls free during the drain still finds work and all of them end within one short
 // workgroup of each other.  `launch_ends` = the rows (exclusive, increasing) at which the launches this list is for end.
-// NGSLD_TAIL_LEN=0 turns the shaping off, NGSLD_TAIL_PAIRS / NGSLD_TAIL_LEN override its two numbers (A/B).
+// (tests: NGSLD_TEST_TAIL_LEN=0 turns the shaping off, NGSLD_TEST_TAIL_PAIRS / _TAIL_LEN override its two numbers)
 // (Also tried, round 4: the FIRST rows of a launch in runs of mixed lengths, so that the workgroups that start together do
 // not turn over together for their first generations -- no gain, 0.9884 against 0.9894 of the device-resident rate,
 // profiles/r04/sink_rr3.txt: dropped.)
 int build_runs(ngsld_ctx *c, uint64_t run_len, const std::vector<uint64_t> &launch_ends) {
-  if (const char *e = getenv("NGSLD_RUN_LEN")) {
-    const long v = atol(e);
-    if (v >= 1) run_len = (uint64_t)v;
-  }
   run_len = std::max<uint64_t>(1, std::min<uint64_t>(run_len, kRunItems));
   if (c->run_len == run_len && c->run_ends == launch_ends) return NGSLD_OK;
   const uint64_t n = c->n_sites;
   uint64_t tail_len = std::max<uint64_t>(1, run_len / 8);
   uint64_t tail_pairs = (uint64_t)c->n_cus * run_len * item_span(c->cfg, c->pairs_per_item);
-  if (const char *e = getenv("NGSLD_TAIL_LEN")) tail_len = (uint64_t)std::max(0l, atol(e));
-  if (const char *e = getenv("NGSLD_TAIL_PAIRS")) tail_pairs = std::strtoull(e, nullptr, 10);
+  if (const char *e = test_knob("TAIL_LEN")) tail_len = (uint64_t)std::max(0l, atol(e));
+  if (const char *e = test_knob("TAIL_PAIRS")) tail_pairs = std::strtoull(e, nullptr, 10);
   std::vector<uint8_t> in_tail(n, 0);
   if (tail_len > 0 && tail_len < run_len) {
     uint64_t begin = 0;

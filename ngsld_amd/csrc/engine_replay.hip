@@ -405,10 +405,7 @@ int reset_flags(ngsld_ctx *c, DevBuf<uint32_t> &buf, uint64_t n, uint32_t cap, h
 // ---------------------------------------------------------------------------------------------------------------
 // Likelihood matrices: the exact store and the device-side replay (ld_replay_lkl.hip)
 // ---------------------------------------------------------------------------------------------------------------
-static bool lanes_allowed() {
-  const char *e = std::getenv("NGSLD_REPLAY_LANES");
-  return e == nullptr || std::strcmp(e, "0") != 0;
-}
+static bool lanes_allowed() { return true; }
 
 bool lkl_device_eligible(const ngsld_ctx *c) {
   // (beyond 4,096 individuals the wavefront-per-pair kernel has no shape: the lanes take such cohorts, where they may be had)
@@ -431,12 +428,9 @@ bool exact_store_wanted(const ngsld_ctx *c, uint64_t pending) {
   return c->host_replayed_total + pending > std::max<uint64_t>(4096, c->n_sites / 2);
 }
 
-// The individual-major copy for the lane-per-pair kernel, where the device has room for the matrix once more (NGSLD_REPLAY_LANES=0:
-// never -- the wavefront-per-pair kernel takes everything, as in the round's first sessions): its memory
+// The individual-major copy for the lane-per-pair kernel, where the device has room for the matrix once more: its memory
 static bool alloc_lane_store(ngsld_ctx *c) {
   c->xT_ready = false;
-  if (const char *e = std::getenv("NGSLD_REPLAY_LANES"))
-    if (std::strcmp(e, "0") == 0) return false;
   const size_t elems = (size_t)c->n_sites * c->n_ind * 3;
   // (4 GB of the device left for what comes later -- text buffers, the lanes' list and sort scratch; under a cap: half a GB of it)
   if (!room_for(elems * sizeof(double), 4ull << 30, 512ull << 20)) return false;
@@ -510,8 +504,8 @@ static void exact_builder(ngsld_ctx *c) {
     const uint64_t n = c->n_sites, ni = c->n_ind, np = c->np, site_elems = 3 * np;
     uint64_t chunk = std::max<uint64_t>(1, (32ull << 20) / (site_elems * sizeof(double)));
     uint64_t slow_us = 0;  // tests: small chunks, a builder the run has to wait for
-    if (const char *e = std::getenv("NGSLD_EXACT_CHUNK_SITES")) chunk = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
-    if (const char *e = std::getenv("NGSLD_EXACT_SLOW_US")) slow_us = std::strtoull(e, nullptr, 10);
+    if (const char *e = test_knob("EXACT_CHUNK_SITES")) chunk = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10));
+    if (const char *e = test_knob("EXACT_SLOW_US")) slow_us = std::strtoull(e, nullptr, 10);
     if (chunk > n) chunk = n;
     struct Events {  // (destroyed on every way out)
       hipEvent_t e[2] = {nullptr, nullptr};
@@ -669,7 +663,7 @@ int start_exact_store(ngsld_ctx *c) {
     return NGSLD_OK;
   }
   // (a device without room for the matrix once more: no store for this matrix -- its flagged pairs stay with the host's threads)
-  const bool pretend = std::getenv("NGSLD_EXACT_STORE_NO_ROOM") != nullptr;  // tests
+  const bool pretend = test_knob("EXACT_STORE_NO_ROOM") != nullptr;
   const bool no_room = !room_for((uint64_t)c->n_sites * (3ull * c->np + 1) * sizeof(double), 0, 256ull << 20);  // (ngsld_set_memory_budget)
   if (pretend || no_room || c->d_xplanes.resize((size_t)c->n_sites * 3 * c->np) != hipSuccess || c->d_xmaf.resize(c->n_sites) != hipSuccess) {
     (void)hipGetLastError();
@@ -797,7 +791,6 @@ int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t ou
   const uint32_t team_waves = replay_lkl_waves((uint32_t)c->n_ind);  // (0: beyond 4,096 individuals -- the lanes or nothing)
   const bool big_cohort = team_waves >= 2 || team_waves == 0;
   if (big_cohort) lanes_from = 0;
-  if (const char *v = std::getenv("NGSLD_REPLAY_LANES_FROM")) lanes_from = std::strtoull(v, nullptr, 10);  // A/B
   if (team_waves == 0 && !c->xT_ready.load()) return fail(c, NGSLD_ERR_INVALID, "device-side replay without a kernel for this cohort");
   if (c->xT_ready && (n >= lanes_from || team_waves == 0)) {
     a.after_lanes = 1;
@@ -818,10 +811,8 @@ int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t ou
     int lane_waves = n >= (1ull << 22) ? 4 : 1;
     if (n < (1ull << 22) && team_waves != 0) {  // (no wavefront kernel to hand a long pair back to: no cap)
       a.lane_iter_cap = 12;
-      if (const char *v = std::getenv("NGSLD_LANE_ITER_CAP")) a.lane_iter_cap = (uint32_t)std::strtoul(v, nullptr, 10);  // A/B
-      if (const char *v = std::getenv("NGSLD_LANE_WAVES")) lane_waves = std::atoi(v);                                   // A/B
+      if (const char *v = test_knob("LANE_ITER_CAP")) a.lane_iter_cap = (uint32_t)std::strtoul(v, nullptr, 10);  // (tests: hand-backs on every pair)
     }
-    if (const char *v = std::getenv("NGSLD_LANE_CAP_ALL")) a.lane_iter_cap = (uint32_t)std::strtoul(v, nullptr, 10);  // A/B: the capped kernel on long launches too
     HIP_TRY(c, launch_replay_lanes(a, ls.list.p, ls.vals_b.p, c->d_xT.p, c->n_cus, lane_waves, st));
   }
   if (team_waves == 0)
@@ -841,7 +832,7 @@ int device_replay(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t out_ba
   // list of located pairs and a second kernel works through that -- both leave at once unless the list did overflow
   ngsld_ctx::LaneScratch &ls = slot < 0 ? c->lane_scratch_dev : c->lane_scratch[slot];
   uint64_t list_cap = std::min<uint64_t>(n, 1ull << 26);
-  if (const char *v = std::getenv("NGSLD_TEST_REPLAY_LIST_CAP")) list_cap = std::min<uint64_t>(list_cap, std::max<uint64_t>(1, std::strtoull(v, nullptr, 10)));  // tests: a list that overflows
+  if (const char *v = test_knob("REPLAY_LIST_CAP")) list_cap = std::min<uint64_t>(list_cap, std::max<uint64_t>(1, std::strtoull(v, nullptr, 10)));  // tests: a list that overflows
   HIP_TRY(c, ls.list.resize(list_cap));
   ReplayHardArgs a{};
   a.list = ls.list.p;

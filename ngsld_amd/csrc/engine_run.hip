@@ -259,13 +259,13 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   // on the device and copied.  Records: the pair kernels write them straight into the slot's pinned host buffers
   // (run_direct; nothing is left to copy behind the last kernel; twice the pairs per batch, half the launches), or into
   // device buffers with a D2H copy per batch, the batches then shrinking towards the end of the run (run_taper).
-  // NGSLD_RUN_STREAMS=2: three slots, two compute streams half a batch out of phase (see ngsld_ctx).
+  // NGSLD_TEST_RUN_STREAMS=2: three slots, two compute streams half a batch out of phase (see ngsld_ctx).
   const bool direct = !text && c->run_direct;
   // Text batches are small (2^19 rows: a 2.8 ms pair kernel, a tenth of it ramp and drain) and many: for them the two compute
   // streams half a batch out of phase DO pay, on every box -- while one stream's kernel drains the other's is in full
-  // flight: configs[2]'s loop 0.58-0.63 -> 0.546-0.551 s (profiles/r04/e2e_text_streams.txt).  NGSLD_TEXT_STREAMS=1: one stream.
+  // flight: configs[2]'s loop 0.58-0.63 -> 0.546-0.551 s (profiles/r04/e2e_text_streams.txt).  (tests: NGSLD_TEST_TEXT_STREAMS=1: one stream.)
   bool text_two = true;
-  if (const char *e = std::getenv("NGSLD_TEXT_STREAMS")) text_two = std::atoi(e) != 1;
+  if (const char *e = test_knob("TEXT_STREAMS")) text_two = std::atoi(e) != 1;
   const bool two_streams = text ? text_two : c->run_streams == 2;
   c->timed_overlap = two_streams;  // (ngsld_last_kernel_time: launches on two streams share the device -- first start .. last end)
   // (text on ONE stream with three slots, two batches queued ahead, measured no different from two slots: the compute stream
@@ -279,8 +279,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   // (kTextBatchPairs; round 1, configs[2] end to end: 2^23 pairs per batch 2.2 s, 2^21 1.5 s)
   // (records written by the kernels themselves: every launch costs ~0.4 ms of drain and nothing has to be staged on the
   // device, so the batches are twice the size -- 2 x 1.2 GB of pinned host memory with the extended record)
-  uint64_t text_batch = kTextBatchPairs;
-  if (const char *e = std::getenv("NGSLD_TEXT_BATCH_PAIRS")) text_batch = std::max<uint64_t>(1024, std::strtoull(e, nullptr, 10));  // A/B
+  const uint64_t text_batch = kTextBatchPairs;
   uint64_t batch_pairs = text ? std::min<uint64_t>(c->batch_pairs, text_batch)
                               : ((direct && !c->batch_pairs_set) ? 2 * c->batch_pairs : c->batch_pairs);
   const bool taper = !text && !direct && c->run_taper;
@@ -304,7 +303,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     // the batches' host buffers: pinned memory is the scarce kind -- a host that cannot pin two (three) buffers of this size
     // gets batches of half the size instead of an error, down to 2^20 pairs
     hipError_t e = hipSuccess;
-    if (const char *lim = std::getenv("NGSLD_PIN_LIMIT_BYTES"))  // tests: a host that cannot pin more than this per buffer
+    if (const char *lim = test_knob("PIN_LIMIT_BYTES"))  // tests: a host that cannot pin more than this per buffer
       if (cap * sizeof(ngsld_rec_std) > std::strtoull(lim, nullptr, 10)) e = hipErrorOutOfMemory;
     for (int k = 0; k < S && e == hipSuccess; ++k) {
       e = c->h_std[k].resize(cap);
@@ -475,7 +474,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run).count(); };
   // ---- what consuming a text batch is made of (see the loop below) ----
   const bool host_patch_on = [] {
-    const char *e = std::getenv("NGSLD_TEXT_HOST_PATCH");  // A/B: 0 = the replayed rows through the device again, as up to round 5
+    const char *e = test_knob("TEXT_HOST_PATCH");  // (tests: 0 = the replayed rows through the device again, the fallback of a patch that does not fit)
     return e == nullptr || std::strcmp(e, "0") != 0;
   }();
   std::vector<ngsld_rec_std> hp_std;
@@ -484,7 +483,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   std::vector<std::pair<uint64_t, uint32_t>> by_rec;
   auto batch_needs_host = [&](int k, size_t bi) -> bool {  // a value beyond the device formatter's fast path: the batch goes out as records
     bool needs_host = (c->h_text_meta[k].p[1] & 0xffffffffull) != 0;
-    if (const char *e = std::getenv("NGSLD_TEXT_FALLBACK_EVERY")) {  // tests: every n-th batch takes the record path
+    if (const char *e = test_knob("TEXT_FALLBACK_EVERY")) {  // tests: every n-th batch takes the record path
       const uint64_t every = std::strtoull(e, nullptr, 10);
       if (every > 0 && bi % every == every - 1) needs_host = true;
     }
@@ -517,7 +516,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   // the replayed records' value columns over the old ones in the text the host holds; false: a row has another length now (or
   // is not where it should be) -- the caller takes the device's way
   uint64_t patch_fail_every = 0;  // tests: every n-th patched batch pretends its last row changed length (the fallback's way out)
-  if (const char *e = std::getenv("NGSLD_TEXT_HOST_PATCH_FAIL_EVERY")) patch_fail_every = std::strtoull(e, nullptr, 10);
+  if (const char *e = test_knob("TEXT_HOST_PATCH_FAIL_EVERY")) patch_fail_every = std::strtoull(e, nullptr, 10);
   uint64_t patched_batches = 0;
   auto apply_host_patch = [&](int k) -> bool {
     const uint64_t total = c->h_text_meta[k].p[0];

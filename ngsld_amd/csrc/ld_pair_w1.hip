@@ -9,6 +9,7 @@
 #include "ld_kernel_group.h"
 #include "ld_kernel_stream.h"
 #include "ld_dispatch.h"
+#include "knobs.h"
 
 namespace ngsld {
 
@@ -158,33 +159,27 @@ static hipError_t launch_pair_chunk(const PairConfig &cfg, bool masked, const Pa
 // grid beyond that is not refused -- it silently wraps (50,000 x 1,000 all pairs on ONE device is 7.8e7 items of the
 // multi-wavefront kernel x 128 threads = 1.0e10: only the first 14 % of the items ran).  Workgroups have at most 512
 // threads, so one launch takes at most 2^22 of them; longer item / run lists go out as consecutive launches on the
-// same stream.  NGSLD_MAX_BLOCKS lowers the cap (tests).
+// same stream.  NGSLD_TEST_MAX_BLOCKS lowers the cap (tests).
 hipError_t launch_pair_kernel(const PairConfig &cfg, bool masked, const PairArgs &a, hipStream_t stream) {
   uint64_t max_blocks = 1ull << 22;
-  if (const char *e = std::getenv("NGSLD_MAX_BLOCKS")) {
+  if (const char *e = test_knob("MAX_BLOCKS")) {
     const uint64_t u = std::strtoull(e, nullptr, 10);
     if (u >= 1 && u < max_blocks) max_blocks = u;
   }
   // Multi-wavefront kernel over long rows: tiled workgroup order (see pair_ld_kernel), one launch per group of up to 512
   // rows so that the rows of a launch have nearly the same number of items (ids beyond a row's count are empty workgroups).
-  // NGSLD_TILES=0 keeps the plain item order (A/B).  So do rows of fewer than 32 items (windowed runs: neighbouring rows
+  // (tests: NGSLD_TEST_TILES=0 keeps the plain item order.)  So do rows of fewer than 32 items (windowed runs: neighbouring rows
   // share their candidates anyway; tiled, configs[4]'s rows of 7-9 items lost 9 % to empty workgroups) and matrices that
   // fit the 256 MB Infinity Cache (nothing to gain: 12,000 x 1,000 all pairs -0.4 %).
   if (cfg.kernel == kMulti && cfg.waves > 1 && a.h_item_off != nullptr && a.item_off != nullptr && a.row1 > a.row0 &&
-      !(std::getenv("NGSLD_TILES") && std::strcmp(std::getenv("NGSLD_TILES"), "0") == 0)) {
+      !test_knob_is("TILES", "0")) {
     uint64_t longest = 0;
     for (uint32_t r = a.row0; r < a.row1; ++r) longest = std::max<uint64_t>(longest, a.h_item_off[r + 1] - a.h_item_off[r]);
-    uint64_t min_items = 32;
-    if (const char *e = std::getenv("NGSLD_TILE_MIN")) min_items = std::strtoull(e, nullptr, 10);  // tuning knob
+    const uint64_t min_items = 32;
     uint64_t min_bytes = 256ull << 20;
-    if (const char *e = std::getenv("NGSLD_TILE_MIN_MB")) min_bytes = std::strtoull(e, nullptr, 10) << 20;  // tests
+    if (const char *e = test_knob("TILE_MIN_MB")) min_bytes = std::strtoull(e, nullptr, 10) << 20;  // tests
     if (longest >= min_items && a.planes_bytes >= min_bytes) {
-      uint32_t kTileRows = 64, kGroupRows = 512;
-      if (const char *e = std::getenv("NGSLD_TILE_ROWS")) {  // tuning knob: rows per tile (group = 8 tiles)
-        const unsigned long v = std::strtoul(e, nullptr, 10);
-        if (v >= 8 && v <= 1024) kTileRows = (uint32_t)v;
-        kGroupRows = std::max<uint32_t>(512, 4 * kTileRows);
-      }
+      const uint32_t kTileRows = 64, kGroupRows = 512;  // (rows per tile, per launch group: 8 tiles)
       for (uint32_t g0 = a.row0; g0 < a.row1; g0 += kGroupRows) {
         const uint32_t g1 = std::min<uint32_t>(a.row1, g0 + kGroupRows);
         uint64_t most = 0;

@@ -15,7 +15,7 @@ struct PrepArgs {
   uint32_t np, n_ind;
   int log_scale, ignore_miss, normalised_input;
   int text_semantics, call_geno;  // read_data.cpp:83-99 rules; ngsLD.cpp:92-98
-  int exact_chain;                // NGSLD_PREP_EXACT=1 (tests): every triple through the reference's log / exp chain, no fast path
+  int exact_chain;                // NGSLD_TEST_PREP_EXACT=1 (tests): every triple through the reference's log / exp chain, no fast path
   double N_thresh, call_thresh;
   double *maf, *mean_e, *rsx;  // [n_sites]; rsx = 1/sqrt(sum (e - mean)^2)
   int *status;

@@ -653,10 +653,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
       // The individuals in order, two register sets used in turn: the next individual's triples are on their way while this one
       // is worked on, and nothing is copied from a staging set into place (154 registers, three wavefronts to a SIMD: -1.1 % of a
       // pass against one set + staging at four, profiles/r06/lane/ab2.txt)
-#ifndef NGSLD_LANE_SETS
-#define NGSLD_LANE_SETS 2
-#endif
-      constexpr int D = NGSLD_LANE_SETS;  // register sets: an individual's triples are fetched D - 1 steps before they are used
+      // (D register sets: an individual's triples are fetched D - 1 steps before they are used.  Three and four measured +-0 at the
+      // same three wavefronts per SIMD, five and six -9 % at two: profiles/r06/lane/sets_ab.txt)
+      constexpr int D = 2;
       double a[D][3], b[D][3];
       auto fetch = [&](double (&pa_)[3], double (&pb_)[3], uint32_t i) {
         const double *qa = pa + (uint64_t)i * row, *qb = pb + (uint64_t)i * row;
@@ -787,14 +786,7 @@ hipError_t launch_replay_sort(const ReplayLklArgs &a, const ReplayEntry *list, u
   if (list_cap == 0) return hipSuccess;
   if (list_cap > 0x7fffffffull) return hipErrorInvalidValue;
   const int bits = replay_site_bits(a.n_sites);
-  int tile_s = 5, tile_o = 3;  // 32 consecutive sites (a handful of them rare) x 8 partners
-  if (const char *v = std::getenv("NGSLD_REPLAY_TILE")) {  // A/B: "s,o" (0,0 = sorted by rarer site, then the other)
-    int ts = 0, to = 0;
-    if (std::sscanf(v, "%d,%d", &ts, &to) == 2 && ts >= 0 && to >= 0) {
-      tile_s = ts;
-      tile_o = to;
-    }
-  }
+  int tile_s = 5, tile_o = 3;  // 32 consecutive sites x 8 partners (other tilings within 1 %: profiles/r05/late/tile, profiles/r06/lane/perm_ab.txt)
   tile_s = std::min(tile_s, bits);
   tile_o = std::min(tile_o, bits);
   hipLaunchKernelGGL(replay_keys_kernel, dim3((unsigned)((list_cap + 255) / 256)), dim3(256), 0, stream, a, list, list_cap, keys_a, vals_a, bits,

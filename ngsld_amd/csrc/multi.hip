@@ -13,7 +13,7 @@
 //   * windowed runs, or no RCCL: every part uploads its own slab from host memory over its own PCIe link -- no collective;
 //   * all-pairs runs on >= 2 distinct devices: the matrix goes to the first device once and ONE ncclBroadcast (RCCL over
 //     xGMI; librccl is loaded on demand, it is not a link-time dependency of this library) hands it to the others.
-//     NGSLD_MULTI_DIST=upload / broadcast overrides the choice.
+//     NGSLD_TEST_MULTI_DIST=upload / broadcast overrides the choice.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only: the five entry points used are resolved with dlsym
@@ -26,6 +26,8 @@
 #include <mutex>
 #include <new>
 #include <string>
+
+#include "knobs.h"
 #include <thread>
 #include <vector>
 
@@ -249,7 +251,7 @@ int ngsld_run_multi(const int *devices, int n_devices, uint64_t n_sites, uint64_
 
   // ---- all-pairs runs: the matrix once to the first device, one broadcast to the others ----
   const bool all_pairs = params->max_kb_dist == 0 && params->max_snp_dist == 0;
-  const char *dist = std::getenv("NGSLD_MULTI_DIST");
+  const char *dist = ngsld::test_knob("MULTI_DIST");
   bool broadcast = gl_raw != nullptr && n > 1 && all_pairs;
   if (dist != nullptr && std::strcmp(dist, "upload") == 0) broadcast = false;
   if (dist != nullptr && std::strcmp(dist, "broadcast") == 0) broadcast = gl_raw != nullptr && n > 1;

@@ -51,7 +51,7 @@ def test_hard_calls_and_rare_variants(engine, case, n_sites, n_ind, mode, ignore
     (4, 200, 5000, 0.1, False), (5, 300, 64, 0.5, True), (6, 300, 129, 0.0, False)])
 def test_called_genotypes_on_both_kernel_paths(case, n_sites, n_ind, miss, ignore, monkeypatch):
     """Hard-called matrices against the oracle twice: on the genotype-combination kernel (ld_pair_hard.hip) and, with
-    NGSLD_HARD_KERNEL=0, on the per-individual kernels; the two paths agree with each other far inside the tolerance."""
+    NGSLD_TEST_HARD_KERNEL=0, on the per-individual kernels; the two paths agree with each other far inside the tolerance."""
     from ngsld_amd import capi
     rng = np.random.default_rng(700 + case)
     raw = np.eye(3)[synth.make_gl_numpy(n_sites, n_ind, 700 + case, depth=4.0).argmax(axis=2)]
@@ -67,7 +67,7 @@ def test_called_genotypes_on_both_kernel_paths(case, n_sites, n_ind, miss, ignor
     got = {}
     for path in ("hard", "generic"):
         if path == "generic":
-            monkeypatch.setenv("NGSLD_HARD_KERNEL", "0")
+            monkeypatch.setenv("NGSLD_TEST_HARD_KERNEL", "0")
         eng = capi.Engine(0)
         try:
             eng.set_geno_raw(raw, ignore_miss_data=ignore)

@@ -18,14 +18,14 @@ def test_chunked_launches_are_bit_identical(engine, n_sites, n_ind, seed):
     out = []
     for cap in (None, "5"):
         if cap:
-            os.environ["NGSLD_MAX_BLOCKS"] = cap
+            os.environ["NGSLD_TEST_MAX_BLOCKS"] = cap
         try:
             engine.set_geno_raw(raw)
             engine.set_pos_dist(None)
             engine.plan(extend_out=True, rnd_sample=0.7, seed=99)
             out.append(engine.run())
         finally:
-            os.environ.pop("NGSLD_MAX_BLOCKS", None)
+            os.environ.pop("NGSLD_TEST_MAX_BLOCKS", None)
     assert len(out[0][0]) > 0
     for a, b in zip(*out):
         assert a.tobytes() == b.tobytes()
@@ -60,13 +60,13 @@ def test_more_than_2_to_32_threads_in_one_plan():
 def test_tiled_workgroup_order_of_the_multi_wavefront_kernel(n_ind, n_sites):
     """Rows of 32 and more items (2,048+ candidates) of the multi-wavefront kernel are worked through in tiles of 64 rows x 8
     items, ids without an item are empty workgroups (launch_pair_kernel): same records, bit for bit, as the plain item order
-    (NGSLD_TILES=0), through record batches and through ngsld_run_device; the first rows against the oracle."""
+    (NGSLD_TEST_TILES=0), through record batches and through ngsld_run_device; the first rows against the oracle."""
     import os
     import torch
     from oracle import orc
     from util import check_records
     raw = synth.make_gl_numpy(n_sites, n_ind, 77 + n_ind, depth=4.0)
-    os.environ["NGSLD_TILE_MIN_MB"] = "0"                       # (tiles are for matrices beyond the 256 MB Infinity Cache)
+    os.environ["NGSLD_TEST_TILE_MIN_MB"] = "0"                       # (tiles are for matrices beyond the 256 MB Infinity Cache)
     os.environ["NGSLD_PAIR_KERNEL"] = "multi"                   # (n_ind 520 would run on one wavefront per pair)
     try:
         eng = capi.Engine(0)
@@ -92,25 +92,25 @@ def test_tiled_workgroup_order_of_the_multi_wavefront_kernel(n_ind, n_sites):
             return d_std.cpu().numpy().tobytes(), d_ext.cpu().numpy().tobytes()
 
         tiled_dev = device_records()
-        os.environ["NGSLD_TILES"] = "0"
+        os.environ["NGSLD_TEST_TILES"] = "0"
         try:
             plain = eng.run()
             plain_dev = device_records()
         finally:
-            del os.environ["NGSLD_TILES"]
+            del os.environ["NGSLD_TEST_TILES"]
         for a, b in zip(tiled, plain):
             assert a.tobytes() == b.tobytes()
         assert tiled_dev == plain_dev
-        os.environ["NGSLD_MAX_BLOCKS"] = "300"                 # a tile grid beyond the launch cap: that row group in plain order, chunked
+        os.environ["NGSLD_TEST_MAX_BLOCKS"] = "300"                 # a tile grid beyond the launch cap: that row group in plain order, chunked
         try:
             assert device_records() == plain_dev
         finally:
-            del os.environ["NGSLD_MAX_BLOCKS"]
+            del os.environ["NGSLD_TEST_MAX_BLOCKS"]
         rows = 12
         want = orc.Oracle(raw, n_threads=8).run(0, rows)
         m = tiled[0] < rows
         assert m.sum() == len(want)
         check_records(tiled[2][m], tiled[3][m], want)
     finally:
-        del os.environ["NGSLD_TILE_MIN_MB"]
+        del os.environ["NGSLD_TEST_TILE_MIN_MB"]
         eng.close()

@@ -43,12 +43,12 @@ def test_parts_concatenate_to_the_single_device_run(n_parts, case, monkeypatch):
         kw.update(max_kb_dist=12, max_snp_dist=40, min_maf=0.12, rnd_sample=0.4, seed=77, ignore_miss_data=True)
         raw[::7, ::5] = 1.0 / 3.0
     if case == "all_pairs_upload":
-        monkeypatch.setenv("NGSLD_MULTI_DIST", "upload")
+        monkeypatch.setenv("NGSLD_TEST_MULTI_DIST", "upload")
     (s1, s2, std, ext), maf = single(raw, pd, **kw)
     parts, maf_m, per = capi.run_multi(raw, pd, [0] * n_parts, **kw)
     got = joined(parts)
     # one device listed several times: the broadcast buffer is copied device to device (RCCL needs distinct devices:
-    # tests/test_gpu_multi_ranks.py); windowed runs and NGSLD_MULTI_DIST=upload send every part its own slab
+    # tests/test_gpu_multi_ranks.py); windowed runs and NGSLD_TEST_MULTI_DIST=upload send every part its own slab
     assert capi.multi_last_distribution() == ("peer_copy" if case == "all_pairs" else "upload")
     assert sum(per) == len(s1) and [len(p[0]) for p in parts] == per
     assert np.array_equal(got[0], s1) and np.array_equal(got[1], s2)

@@ -375,15 +375,15 @@ def test_api_error_paths(engine):
 
 def test_chunked_host_ingestion(monkeypatch):
     """Host matrices enter the device in chunks of sites through two staging buffers; forced here to 3 sites per
-    chunk (NGSLD_STAGE_BYTES) so that 50 sites take 17 chunks -- results must equal the one-chunk run bit for bit."""
+    chunk (NGSLD_TEST_STAGE_BYTES) so that 50 sites take 17 chunks -- results must equal the one-chunk run bit for bit."""
     from ngsld_amd import capi
     raw = synth.make_gl_numpy(50, 70, 501, depth=5.0)
     outs = []
     for stage in (None, str(3 * 70 * 24), "1"):
         if stage is None:
-            monkeypatch.delenv("NGSLD_STAGE_BYTES", raising=False)
+            monkeypatch.delenv("NGSLD_TEST_STAGE_BYTES", raising=False)
         else:
-            monkeypatch.setenv("NGSLD_STAGE_BYTES", stage)
+            monkeypatch.setenv("NGSLD_TEST_STAGE_BYTES", stage)
         eng = capi.Engine(0)
         try:
             eng.set_geno_raw(raw)

@@ -12,22 +12,22 @@ pytestmark = pytest.mark.gpu
 
 VARIANTS = [
     {},                                                        # default: direct writes, one stream, tails shaped
-    {"NGSLD_RUN_DIRECT": "0"},                                 # device buffers + D2H, tapered batches
-    {"NGSLD_RUN_DIRECT": "0", "NGSLD_RUN_TAPER": "0"},
-    {"NGSLD_RUN_STREAMS": "2"},                                # two streams, first batch half a batch
-    {"NGSLD_RUN_STREAMS": "2", "NGSLD_RUN_DIRECT": "0"},
-    {"NGSLD_TAIL_LEN": "0"},                                   # no short runs at the launches' ends
-    {"NGSLD_TAIL_LEN": "1", "NGSLD_TAIL_PAIRS": "100000"},
-    {"NGSLD_BATCH_PAIRS": "40000"},                            # many small batches
-    {"NGSLD_BATCH_PAIRS": "40000", "NGSLD_RUN_STREAMS": "2"},
-    {"NGSLD_BATCH_PAIRS": "40000", "NGSLD_RUN_DIRECT": "0"},
-    {"NGSLD_PIN_LIMIT_BYTES": "2500000"},                      # pinned memory is scarce: batches halve until two buffers fit
+    {"NGSLD_TEST_RUN_DIRECT": "0"},                                 # device buffers + D2H, tapered batches
+    {"NGSLD_TEST_RUN_DIRECT": "0", "NGSLD_TEST_RUN_TAPER": "0"},
+    {"NGSLD_TEST_RUN_STREAMS": "2"},                                # two streams, first batch half a batch
+    {"NGSLD_TEST_RUN_STREAMS": "2", "NGSLD_TEST_RUN_DIRECT": "0"},
+    {"NGSLD_TEST_TAIL_LEN": "0"},                                   # no short runs at the launches' ends
+    {"NGSLD_TEST_TAIL_LEN": "1", "NGSLD_TEST_TAIL_PAIRS": "100000"},
+    {"NGSLD_TEST_BATCH_PAIRS": "40000"},                            # many small batches
+    {"NGSLD_TEST_BATCH_PAIRS": "40000", "NGSLD_TEST_RUN_STREAMS": "2"},
+    {"NGSLD_TEST_BATCH_PAIRS": "40000", "NGSLD_TEST_RUN_DIRECT": "0"},
+    {"NGSLD_TEST_PIN_LIMIT_BYTES": "2500000"},                      # pinned memory is scarce: batches halve until two buffers fit
 ]
 
 
 def _run(raw, pd, kw, env, monkeypatch, device_run=False):
-    for k in ("NGSLD_RUN_DIRECT", "NGSLD_RUN_TAPER", "NGSLD_RUN_STREAMS", "NGSLD_TAIL_LEN", "NGSLD_TAIL_PAIRS", "NGSLD_BATCH_PAIRS",
-              "NGSLD_REPLAY", "NGSLD_PIN_LIMIT_BYTES"):
+    for k in ("NGSLD_TEST_RUN_DIRECT", "NGSLD_TEST_RUN_TAPER", "NGSLD_TEST_RUN_STREAMS", "NGSLD_TEST_TAIL_LEN", "NGSLD_TEST_TAIL_PAIRS", "NGSLD_TEST_BATCH_PAIRS",
+              "NGSLD_REPLAY", "NGSLD_TEST_PIN_LIMIT_BYTES"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -83,9 +83,9 @@ def test_every_route_delivers_the_same_records(shape, monkeypatch):
 def test_reported_kernel_time_of_a_two_stream_run_is_a_span_not_a_sum(streams, monkeypatch):
     """ngsld_last_kernel_time after ngsld_run (round 4's advisor): launches on two compute streams share the device, so their time
     is first start .. last end -- the sum of their durations would exceed the wall time of the run.  Text batches (two streams by
-    default; NGSLD_TEXT_STREAMS=1: one) of a run long enough to measure."""
+    default; NGSLD_TEST_TEXT_STREAMS=1: one) of a run long enough to measure."""
     import time
-    monkeypatch.setenv("NGSLD_TEXT_STREAMS", streams)
+    monkeypatch.setenv("NGSLD_TEST_TEXT_STREAMS", streams)
     n_sites, n_ind = 6000, 200
     raw = synth.make_gl_numpy(n_sites, n_ind, seed=9, depth=8.0)
     chrs, pos = synth.make_positions(n_sites, 9)

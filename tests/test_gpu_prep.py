@@ -1,6 +1,6 @@
 """GPU: the per-site prep kernels (ld_prep.hip).  Likelihood triples take a quotient fast path, a_k = raw_k / sum, wherever
 the reference's chain of logs (read_data.cpp:37-45, gen_func.cpp:974-1009, ngsLD.cpp:110) has no special behaviour, and
-the chain itself everywhere else; NGSLD_PREP_EXACT=1 sends every triple through the chain.  Both must agree with the
+the chain itself everywhere else; NGSLD_TEST_PREP_EXACT=1 sends every triple through the chain.  Both must agree with the
 reference's compiled est_maf (the oracle, bit-checked against it) to 1e-12 and with each other far inside that, on ordinary
 triples and on every special one: zeros, all-zero triples, called genotypes, denormal and huge values."""
 import os
@@ -71,7 +71,7 @@ def test_fast_path_and_chain_agree_with_the_reference(n_ind, ignore_miss):
     got = {}
     for mode in ("fast", "chain"):
         if mode == "chain":
-            os.environ["NGSLD_PREP_EXACT"] = "1"
+            os.environ["NGSLD_TEST_PREP_EXACT"] = "1"
         try:
             eng = capi.Engine(0)
             try:
@@ -83,7 +83,7 @@ def test_fast_path_and_chain_agree_with_the_reference(n_ind, ignore_miss):
             finally:
                 eng.close()
         finally:
-            os.environ.pop("NGSLD_PREP_EXACT", None)
+            os.environ.pop("NGSLD_TEST_PREP_EXACT", None)
         assert np.all(close(maf, o.maf, MAF_TOL)), mode            # 1e-12 against the reference's est_maf
         check_records(std, ext, want)
         got[mode] = (maf, std, ext)
@@ -98,7 +98,7 @@ def test_nan_input_is_reported_on_both_paths():
     raw = synth.make_gl_numpy(20, 64, 7100, depth=4.0)
     raw[11, 5, 1] = -0.25                               # log of a negative value: NaN -> "NaN found!" (read_data.cpp:42-45)
     for exact in ("0", "1"):
-        os.environ["NGSLD_PREP_EXACT"] = exact
+        os.environ["NGSLD_TEST_PREP_EXACT"] = exact
         try:
             eng = capi.Engine(0)
             try:
@@ -108,7 +108,7 @@ def test_nan_input_is_reported_on_both_paths():
             finally:
                 eng.close()
         finally:
-            os.environ.pop("NGSLD_PREP_EXACT", None)
+            os.environ.pop("NGSLD_TEST_PREP_EXACT", None)
 
 
 def test_values_at_the_edges_of_the_double_range_end_like_the_reference_reader():

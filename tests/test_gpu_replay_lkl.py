@@ -285,10 +285,10 @@ def test_parts_of_one_process_build_their_own_stores(n_parts, monkeypatch):
 
 def test_a_device_without_room_for_the_store_leaves_the_pairs_to_the_host(eng, monkeypatch):
     """The store is the matrix once more in device memory; where that cannot be had the run does not fail -- its flagged pairs
-    are replayed on host threads as before (NGSLD_EXACT_STORE_NO_ROOM pretends)."""
+    are replayed on host threads as before (NGSLD_TEST_EXACT_STORE_NO_ROOM pretends)."""
     raw = uncalled(300, 60, seed=88, mono_frac=0.3)
     want = run_records(eng, raw, 0)
-    monkeypatch.setenv("NGSLD_EXACT_STORE_NO_ROOM", "1")
+    monkeypatch.setenv("NGSLD_TEST_EXACT_STORE_NO_ROOM", "1")
     got = run_records(eng, raw, 2)
     assert got[4]["exact_store"] == 0 and got[4]["pairs_on_device"] == 0 and got[4]["pairs_on_host"] == want[4]["pairs_on_host"] > 0
     for k in (2, 3):
@@ -309,8 +309,8 @@ def test_store_built_beside_the_run_in_site_order(eng, monkeypatch, callback):
     eng.set_tuning(batch_pairs=2500)
     want = run_records(eng, raw, 0, max_snp_dist=60)
     assert want[4]["pairs_on_host"] > 5000
-    monkeypatch.setenv("NGSLD_EXACT_CHUNK_SITES", "16")
-    monkeypatch.setenv("NGSLD_EXACT_SLOW_US", "1500")
+    monkeypatch.setenv("NGSLD_TEST_EXACT_CHUNK_SITES", "16")
+    monkeypatch.setenv("NGSLD_TEST_EXACT_SLOW_US", "1500")
     got = run_records(eng, raw, 2, max_snp_dist=60)
     assert got[4]["exact_store"] == 2 and got[4]["pairs_on_device"] > 5000 and got[4]["pairs_on_host"] * 20 < got[4]["pairs_on_device"]
     assert got[4]["exact_store_build_s"] > 0.05
@@ -354,13 +354,13 @@ def test_a_failing_replay_source_ends_the_run_that_built_the_store(monkeypatch):
 
         cb = capi.READ_FN(reader)
         e._check(e._L.ngsld_set_replay_source(e._h, cb, None))
-        monkeypatch.setenv("NGSLD_EXACT_CHUNK_SITES", "50")
+        monkeypatch.setenv("NGSLD_TEST_EXACT_CHUNK_SITES", "50")
         e.set_pos_dist(None)
         e.plan(max_snp_dist=40)
         with pytest.raises(capi.NgsldError) as err:
             e.run()
         assert "replay source" in str(err.value) and calls[0] >= 5
-        monkeypatch.delenv("NGSLD_EXACT_CHUNK_SITES")
+        monkeypatch.delenv("NGSLD_TEST_EXACT_CHUNK_SITES")
         e.set_geno_raw(raw)                                             # the array itself as the source: all is well
         e.set_pos_dist(None)
         n = e.plan(max_snp_dist=40)
@@ -378,7 +378,7 @@ def test_large_cohorts_take_the_lanes_on_short_launches_with_a_cap(eng, monkeypa
     host replay's, bit for bit."""
     raw = uncalled(260, n_ind, 4242 + n_ind, mono_frac=0.25, missing=True)
     want = run_records(eng, raw, 0, max_snp_dist=30)
-    monkeypatch.setenv("NGSLD_LANE_ITER_CAP", cap)
+    monkeypatch.setenv("NGSLD_TEST_LANE_ITER_CAP", cap)
     got = run_records(eng, raw, 2, max_snp_dist=30)
     assert got[4]["pairs_on_device"] > 500 and got[4]["pairs_on_host"] * 20 < got[4]["pairs_on_device"]
     assert_same_records(got, want)

@@ -157,7 +157,7 @@ def test_streamed_errors(engine):
                                    ["--max_kb_dist", "3", "--rnd_sample", "0.5", "--seed", "9", "--min_maf", "0.1"],
                                    ["--max_kb_dist", "3", "--probs", "--call_geno"]])
 def test_cli_streamed_output_is_identical(tmp_path, flags):
-    """The drop-in binary forced to stream (NGSLD_SLAB_SITES) writes the same bytes as the resident run."""
+    """The drop-in binary forced to stream (NGSLD_TEST_SLAB_SITES) writes the same bytes as the resident run."""
     n_sites, n_ind = 1500, 40
     raw = synth.make_gl_numpy(n_sites, n_ind, 47, depth=5.0)
     chrs, pos = synth.make_positions(n_sites, 47, n_chr=2)
@@ -167,12 +167,12 @@ def test_cli_streamed_output_is_identical(tmp_path, flags):
     cmd = [capi.CLI_PATH, "--geno", g, "--n_ind", str(n_ind), "--n_sites", str(n_sites), "--pos", p, "--verbose", "0",
            "--n_threads", "4"] + flags
     a = subprocess.run(cmd, capture_output=True)
-    b = subprocess.run(cmd, capture_output=True, env=dict(os.environ, NGSLD_SLAB_SITES="100"))
+    b = subprocess.run(cmd, capture_output=True, env=dict(os.environ, NGSLD_TEST_SLAB_SITES="100"))
     assert a.returncode == 0 and b.returncode == 0, (a.stderr, b.stderr)
     assert a.stdout == b.stdout and a.stdout.count(b"\n") > 1000
     # all pairs cannot be cut into slabs: a job that fits the device falls back to the resident run
     ap = cmd[:-len(flags)] + ["--max_kb_dist", "0", "--max_snp_dist", "30"]
-    c = subprocess.run(ap[:-1] + ["0"], capture_output=True, env=dict(os.environ, NGSLD_SLAB_SITES="100"))
+    c = subprocess.run(ap[:-1] + ["0"], capture_output=True, env=dict(os.environ, NGSLD_TEST_SLAB_SITES="100"))
     d = subprocess.run(ap[:-1] + ["0"], capture_output=True)
     assert c.returncode == 0 and d.returncode == 0 and c.stdout == d.stdout
     assert c.stdout.count(b"\n") == 1 + n_sites * (n_sites - 1) // 2

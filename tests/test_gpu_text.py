@@ -41,11 +41,11 @@ def test_cli_device_text_equals_host_text(tmp_path, case):
         args += ["--extend_out"]
     if case == "ext_filters":
         args += ["--min_maf", "0.1", "--rnd_sample", "0.5", "--seed", "42", "--ignore_miss_data"]
-    env = {"NGSLD_BATCH_PAIRS": "700"} if case == "many_batches" else {}
+    env = {"NGSLD_TEST_BATCH_PAIRS": "700"} if case == "many_batches" else {}
     if case == "mixed":                                             # every third batch falls back to records + host formatter
-        env = {"NGSLD_BATCH_PAIRS": "500", "NGSLD_TEXT_FALLBACK_EVERY": "3"}
+        env = {"NGSLD_TEST_BATCH_PAIRS": "500", "NGSLD_TEST_TEXT_FALLBACK_EVERY": "3"}
     if case == "slabs":                                             # the streamed path: slabs of 150 sites, text per slab
-        env = {"NGSLD_SLAB_SITES": "150", "NGSLD_BATCH_PAIRS": "900"}
+        env = {"NGSLD_TEST_SLAB_SITES": "150", "NGSLD_TEST_BATCH_PAIRS": "900"}
     host = _cli(args, dict(env, NGSLD_HOST_TEXT="1"))
     dev = _cli(args, env)
     assert len(host) > 1000 and host.count(b"\n") > 10
@@ -100,7 +100,7 @@ def test_cli_gz_output_is_the_plain_output_compressed(tmp_path):
     assert r.returncode == 0, r.stderr
     want = open(plain, "rb").read()
     assert want.count(b"\n") > 100_000
-    for tag, extra, env in (("resident", [], {}), ("slabs", [], {"NGSLD_SLAB_SITES": "700"}), ("devices", ["--devices", "0,0"], {})):
+    for tag, extra, env in (("resident", [], {}), ("slabs", [], {"NGSLD_TEST_SLAB_SITES": "700"}), ("devices", ["--devices", "0,0"], {})):
         out = str(tmp_path / f"{tag}.ld.gz")
         import os
         r = subprocess.run(base + extra + ["--out", out], capture_output=True, text=True, env=dict(os.environ, **env))
@@ -126,8 +126,8 @@ def _text_run(eng, raw, pd, labels, **plan):
 def test_host_replayed_rows_are_overwritten_in_the_hosts_text(monkeypatch, extend):
     """The pairs a text batch leaves to the host's exact-order replay (engine_run.hip: send_flag_rows / apply_host_patch): their
     rows' value columns are overwritten in the text the host has received -- nothing goes back to the device.  The text is the
-    one the device's way gives (NGSLD_TEXT_HOST_PATCH=0: records patched on the device, the batch written again), also when a
-    patched batch falls back to that way half-way through (NGSLD_TEXT_HOST_PATCH_FAIL_EVERY), with labels that hold TABs."""
+    one the device's way gives (NGSLD_TEST_TEXT_HOST_PATCH=0: records patched on the device, the batch written again), also when a
+    patched batch falls back to that way half-way through (NGSLD_TEST_TEXT_HOST_PATCH_FAIL_EVERY), with labels that hold TABs."""
     n_sites, n_ind = 500, 50
     raw = synth.make_gl_numpy(n_sites, n_ind, 123, depth=2.0, mono_frac=0.1)
     chrs, pos = synth.make_positions(n_sites, 123, n_chr=2)
@@ -138,13 +138,13 @@ def test_host_replayed_rows_are_overwritten_in_the_hosts_text(monkeypatch, exten
     try:
         eng.set_exact_store(0)            # (every flagged pair is the host's)
         eng.set_tuning(batch_pairs=3000)
-        monkeypatch.setenv("NGSLD_TEXT_HOST_PATCH", "0")
+        monkeypatch.setenv("NGSLD_TEST_TEXT_HOST_PATCH", "0")
         want, fb0, info0 = _text_run(eng, raw, pd, labels, **plan)
-        monkeypatch.delenv("NGSLD_TEXT_HOST_PATCH")
+        monkeypatch.delenv("NGSLD_TEST_TEXT_HOST_PATCH")
         got, fb1, info1 = _text_run(eng, raw, pd, labels, **plan)
-        monkeypatch.setenv("NGSLD_TEXT_HOST_PATCH_FAIL_EVERY", "2")
+        monkeypatch.setenv("NGSLD_TEST_TEXT_HOST_PATCH_FAIL_EVERY", "2")
         half, fb2, info2 = _text_run(eng, raw, pd, labels, **plan)
-        monkeypatch.delenv("NGSLD_TEXT_HOST_PATCH_FAIL_EVERY")
+        monkeypatch.delenv("NGSLD_TEST_TEXT_HOST_PATCH_FAIL_EVERY")
         assert fb0 == fb1 == fb2 == 0
         assert info0["pairs_on_host"] > 50 and info0["text_rows_patched"] == 0
         # (a batch that leaves the host more than 1,024 pairs -- kFlagRowsCap -- goes the device's way)

@@ -39,7 +39,7 @@ def same_tsv(got: str, want: str) -> str | None:
 
 
 def both_programs(flags: list[str], rec, n_sites: int, d: str, threads: int = 2, hip_flags=(), hip_env=None):
-    """hip_flags / hip_env: options only the drop-in binary knows (--devices, NGSLD_SLAB_SITES ...), for it alone."""
+    """hip_flags / hip_env: options only the drop-in binary knows (--devices, NGSLD_TEST_SLAB_SITES ...), for it alone."""
     out_ref = os.path.join(d, "ref.tsv")
     r = run_ref_program(rec, n_sites, flags, out_ref, d, threads)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -185,12 +185,12 @@ def test_random_text_input_through_both_programs(k, tmp_path):
 @pytest.mark.parametrize("how", ["slabs", "parts"])
 def test_streamed_and_multi_part_runs_through_both_programs(k, how, tmp_path):
     """The drop-in binary's own ways of cutting a job -- row slabs streamed through two alternating contexts
-    (NGSLD_SLAB_SITES: what --max_gpu_mem does to a matrix beyond the budget) and several parts in one process
+    (NGSLD_TEST_SLAB_SITES: what --max_gpu_mem does to a matrix beyond the budget) and several parts in one process
     (--devices 0,0,0: three parts on this box's one GPU) -- write the reference program's table too."""
     d = str(tmp_path)
     flags, rec, n_sites = case_files(k, d)
     if how == "slabs":
-        got, want = both_programs(flags, rec, n_sites, d, threads=2, hip_env={"NGSLD_SLAB_SITES": str(max(2, n_sites // 4))})
+        got, want = both_programs(flags, rec, n_sites, d, threads=2, hip_env={"NGSLD_TEST_SLAB_SITES": str(max(2, n_sites // 4))})
     else:
         got, want = both_programs(flags, rec, n_sites, d, threads=2, hip_flags=("--devices", "0,0,0"))
     assert same_tsv(got, want) is None, f"case {k} ({how}): {same_tsv(got, want)}\n{' '.join(flags)}"

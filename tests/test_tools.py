@@ -13,7 +13,10 @@ REPO = capi.REPO_DIR
 SCRIPTS = sorted(os.path.join(d, f) for d in ("tools", "profiles") for f in os.listdir(os.path.join(REPO, d)) if f.endswith(".sh"))
 GONE = ["NGSLD_FOLD_T3", "NGSLD_XCH_ASM", "NGSLD_PARKED", "NGSLD_MASK_DONE", "NGSLD_MFMA_REDUCE", "NGSLD_PAIR_RCP", "NGSLD_DROP0",
         "NGSLD_WN_ROWS", "NGSLD_EARLY_EPS", "NGSLD_GROUP_SUM3", "NGSLD_SLOTS9", "NGSLD_SLOTS10", "NGSLD_RUN_SLOTS",
-        "PAIR_KERNEL=item", "PAIR_KERNEL=wave", "PAIR_KERNEL=direct"]
+        "PAIR_KERNEL=item", "PAIR_KERNEL=wave", "PAIR_KERNEL=direct",
+        # round 6: the environment knobs of closed A/B experiments (the scripts that used them are under tools/archive/)
+        "NGSLD_REPLAY_LANES", "NGSLD_LANE_WAVES", "NGSLD_LANE_CAP_ALL", "NGSLD_REPLAY_TILE", "NGSLD_RUN_LEN", "NGSLD_TILE_ROWS",
+        "NGSLD_TEXT_BATCH_PAIRS", "NGSLD_EARLY_READ", "NGSLD_REPLAY_PERM"]
 
 
 @pytest.mark.parametrize("path", SCRIPTS)
@@ -41,3 +44,27 @@ def test_every_switch_of_the_hot_header_is_known_to_the_docs():
     design = open(os.path.join(REPO, "DESIGN.md")).read()
     for k in knobs:
         assert k in design or k.replace("NGSLD_PRIO_S", "NGSLD_PRIO_") in design, f"{k} is not documented"
+
+
+def test_the_environment_surface_stays_small():
+    """Round 6 pruned the knobs: the library and the binary read fourteen supported variables with getenv (ngsld_amd/csrc/knobs.h,
+    INTEGRATION.md), everything the suite needs to force a path goes through test_knob("<NAME>") as NGSLD_TEST_<NAME>."""
+    import glob
+    csrc = os.path.join(REPO, "ngsld_amd", "csrc")
+    srcs = [f for f in glob.glob(os.path.join(csrc, "*")) if f.endswith((".hip", ".cpp", ".h"))]
+    sites, names = 0, set()
+    for f in srcs:
+        for m in re.finditer(r'getenv\("(NGSLD_[A-Z0-9_]+)"\)', open(f).read()):
+            sites += 1
+            names.add(m.group(1))
+    assert sites <= 25, sites
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    knobs_h = open(os.path.join(csrc, "knobs.h")).read()
+    for n in sorted(names):
+        assert n in doc and n in knobs_h, f"{n} is read by the sources but not documented as supported"
+        assert not n.startswith("NGSLD_TEST_"), f"{n}: test knobs go through test_knob()"
+    used = set()
+    for f in srcs:
+        used |= set(re.findall(r'test_knob(?:_is)?\("([A-Z0-9_]+)"', open(f).read()))
+    for n in sorted(used):
+        assert n in knobs_h and n in doc, f"NGSLD_TEST_{n} is not listed in knobs.h / INTEGRATION.md"

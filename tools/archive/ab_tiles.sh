@@ -3,5 +3,5 @@
 for shape in ${SHAPES:-"--config_c3" "--config_c3_--sites_12000" "--config_c3_--sites_30000_--ind_2000"}; do
   shape=${shape//_/ }
   echo "== $shape"
-  BENCH_ARGS="--no-cpu --no-sink --no-e2e $shape --steps 1 --warmup 0" ROUNDS=2 tools/ab.sh "tiles=X=1" "plain=NGSLD_TILES=0"
+  BENCH_ARGS="--no-cpu --no-sink --no-e2e $shape --steps 1 --warmup 0" ROUNDS=2 tools/ab.sh "tiles=X=1" "plain=NGSLD_TEST_TILES=0"
 done

@@ -18,17 +18,17 @@ raw = synth.make_gl_torch(n_sites, n_ind, 3, dev)
 host = raw.cpu().numpy()
 chrs, pos = synth.make_positions(n_sites, 3)
 pd = shard.pos_dist_from_positions(chrs, pos)
-CONFIGS = [("2 streams, 2^22", dict(NGSLD_RUN_STREAMS="2", NGSLD_BATCH_PAIRS=str(1 << 22))),
-           ("2 streams, 2^21", dict(NGSLD_RUN_STREAMS="2", NGSLD_BATCH_PAIRS=str(1 << 21))),
-           ("2 streams, 2^22, run 16", dict(NGSLD_RUN_STREAMS="2", NGSLD_BATCH_PAIRS=str(1 << 22), NGSLD_RUN_LEN="16")),
-           ("2 streams, 2^23, run 8", dict(NGSLD_RUN_STREAMS="2", NGSLD_RUN_LEN="8")),
-           ("2 streams, 2^22, no tail", dict(NGSLD_RUN_STREAMS="2", NGSLD_BATCH_PAIRS=str(1 << 22), NGSLD_TAIL_LEN="0")),
-           ("1 stream, 2^22", dict(NGSLD_RUN_STREAMS="1", NGSLD_BATCH_PAIRS=str(1 << 22)))]
+CONFIGS = [("2 streams, 2^22", dict(NGSLD_TEST_RUN_STREAMS="2", NGSLD_TEST_BATCH_PAIRS=str(1 << 22))),
+           ("2 streams, 2^21", dict(NGSLD_TEST_RUN_STREAMS="2", NGSLD_TEST_BATCH_PAIRS=str(1 << 21))),
+           ("2 streams, 2^22, run 16", dict(NGSLD_TEST_RUN_STREAMS="2", NGSLD_TEST_BATCH_PAIRS=str(1 << 22), NGSLD_RUN_LEN="16")),
+           ("2 streams, 2^23, run 8", dict(NGSLD_TEST_RUN_STREAMS="2", NGSLD_RUN_LEN="8")),
+           ("2 streams, 2^22, no tail", dict(NGSLD_TEST_RUN_STREAMS="2", NGSLD_TEST_BATCH_PAIRS=str(1 << 22), NGSLD_TEST_TAIL_LEN="0")),
+           ("1 stream, 2^22", dict(NGSLD_TEST_RUN_STREAMS="1", NGSLD_TEST_BATCH_PAIRS=str(1 << 22)))]
 if len(sys.argv) > 2:
     CONFIGS = eval(open(sys.argv[2]).read())
 engines = []
 for name, env in CONFIGS:
-    for k in ("NGSLD_RUN_STREAMS", "NGSLD_BATCH_PAIRS", "NGSLD_TAIL_PAIRS", "NGSLD_RUN_DIRECT", "NGSLD_RUN_LEN", "NGSLD_TAIL_LEN", "NGSLD_HEAD"):
+    for k in ("NGSLD_TEST_RUN_STREAMS", "NGSLD_TEST_BATCH_PAIRS", "NGSLD_TEST_TAIL_PAIRS", "NGSLD_TEST_RUN_DIRECT", "NGSLD_RUN_LEN", "NGSLD_TEST_TAIL_LEN", "NGSLD_HEAD"):
         os.environ.pop(k, None)
     os.environ.update(env)
     e = capi.Engine(0)

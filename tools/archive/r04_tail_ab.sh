@@ -8,14 +8,14 @@ mkdir -p gpurun_out/r04
 B="python bench.py --steps 4 --warmup 1 --no-e2e --no-traffic --no-cpu"
 for v in "0 0" "2 262144" "1 262144" "2 131072" "2 524288" "4 262144" "1 524288"; do
   set -- $v
-  echo "== NGSLD_TAIL_LEN=$1 NGSLD_TAIL_PAIRS=$2" >> $out
-  NGSLD_TAIL_LEN=$1 NGSLD_TAIL_PAIRS=$2 $B 2>/dev/null | python -c "
+  echo "== NGSLD_TEST_TAIL_LEN=$1 NGSLD_TEST_TAIL_PAIRS=$2" >> $out
+  NGSLD_TEST_TAIL_LEN=$1 NGSLD_TEST_TAIL_PAIRS=$2 $B 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('value %.4e ms_per_step %.2f kernel_ms %.2f host_resident %.4e ratio %.4f checksum %d replayed %d' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms_per_launch'], d['value_host_resident'], d['value_host_resident']/d['value'], d['config']['rank_records'][0]['records_checksum_u64'], d['config']['pairs_replayed_exact_order_rank0_last_step']))" >> $out
 done
-echo "== default, copy mode (NGSLD_RUN_DIRECT=0)" >> $out
-NGSLD_RUN_DIRECT=0 python tools/sink_probe.py 2>&1 | grep -v amdgpu.ids | grep "pass [12]" >> $out
+echo "== default, copy mode (NGSLD_TEST_RUN_DIRECT=0)" >> $out
+NGSLD_TEST_RUN_DIRECT=0 python tools/sink_probe.py 2>&1 | grep -v amdgpu.ids | grep "pass [12]" >> $out
 echo "== default" >> $out
 python tools/sink_probe.py 2>&1 | grep -v amdgpu.ids | grep "pass [12]" >> $out
 cat $out

@@ -2,8 +2,8 @@ set -x
 mkdir -p gpurun_out/r04
 python tools/r04_sink_trace.py > gpurun_out/r04/alt_default.txt 2>&1
 NGSLD_REPLAY=0 python tools/r04_sink_trace.py > gpurun_out/r04/alt_noreplay.txt 2>&1
-NGSLD_BATCH_PAIRS=16777216 python tools/r04_sink_trace.py > gpurun_out/r04/alt_batch24.txt 2>&1
-NGSLD_TAIL_LEN=0 python tools/r04_sink_trace.py > gpurun_out/r04/alt_notail.txt 2>&1
+NGSLD_TEST_BATCH_PAIRS=16777216 python tools/r04_sink_trace.py > gpurun_out/r04/alt_batch24.txt 2>&1
+NGSLD_TEST_TAIL_LEN=0 python tools/r04_sink_trace.py > gpurun_out/r04/alt_notail.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r04/trace_sink -o sink -- python $GRAFT_REPO_ROOT/tools/r04_sink_trace.py 100000 500 2 > $GRAFT_REPO_ROOT/gpurun_out/r04/trace_sink.log 2>&1
 cd $GRAFT_REPO_ROOT

@@ -6,5 +6,5 @@ show() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split
 echo "== product"; E2E_ONLY=mono20,sfs python tools/e2e_uncalled.py 2>/dev/null | show
 for cap in 6 12 24; do for w in 1 2 4; do
   echo "== lanes on every batch, cap $cap, $w wavefronts per SIMD"
-  NGSLD_REPLAY_LANES_FROM=0 NGSLD_LANE_ITER_CAP=$cap NGSLD_LANE_WAVES=$w E2E_ONLY=mono20,sfs python tools/e2e_uncalled.py 2>/dev/null | show
+  NGSLD_REPLAY_LANES_FROM=0 NGSLD_TEST_LANE_ITER_CAP=$cap NGSLD_LANE_WAVES=$w E2E_ONLY=mono20,sfs python tools/e2e_uncalled.py 2>/dev/null | show
 done; done
