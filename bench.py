@@ -251,6 +251,10 @@ def reference_program(raw_head: np.ndarray, pos_dist_head: np.ndarray, max_kb: i
         dt_p = time.perf_counter() - t0
         assert pn == n_pairs
     return {"value": n_pairs / (dt + dt_p), "unit": "pairs/s", "cores": threads, "kind": "reference",
+            # definition 2 (round 5 on): program time + pearson_r's; rounds 1-4 reported the program alone (definition 1 =
+            # `value_without_pearson` here): speed-ups are comparable across rounds on that field only.  pearson_seconds is an
+            # UPPER bound on what the real binary would add -- timed after the program, not inside its thread pool and I/O overlap
+            "baseline_definition": 2,
             "value_without_pearson": n_pairs / dt, "program_seconds": round(dt, 2), "pearson_seconds": round(dt_p, 2),
             "sample": f"the first {n_file} sites of the same matrix as a binary GL file ({n_pairs} pairs, --extend_out, "
                       f"--n_threads {threads}): {dt:.1f} s from file to TSV on /dev/null for ngsLD.cpp's own main() and calc_pair_LD "

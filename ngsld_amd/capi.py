@@ -165,8 +165,9 @@ def lib() -> C.CDLL:
         L.ngsld_plan_slabs.argtypes = [vp, u64, C.POINTER(Params), u64, vp, u64, C.POINTER(u64)]
         L.ngsld_slab_sites_for_budget.argtypes = [u64, u64]
         L.ngsld_slab_sites_for_budget.restype = u64
-        L.ngsld_sites_for_budget.argtypes = [u64, u64, C.c_int]
-        L.ngsld_sites_for_budget.restype = u64
+        if hasattr(L, "ngsld_sites_for_budget"):  # (absent only from older A/B builds loaded through NGSLD_LIB)
+            L.ngsld_sites_for_budget.argtypes = [u64, u64, C.c_int]
+            L.ngsld_sites_for_budget.restype = u64
         L.ngsld_device_memory.argtypes = [C.c_int, C.POINTER(u64), C.POINTER(u64)]
         L.ngsld_run_streamed.argtypes = [C.c_int, u64, u64, vp, C.POINTER(Params), C.POINTER(GenoOpts), u64, READ_FN, vp,
                                          vp, SINK_FN, vp, C.POINTER(u64), C.POINTER(u64), C.c_char_p, C.c_size_t]

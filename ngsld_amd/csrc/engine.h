@@ -282,6 +282,7 @@ struct ngsld_ctx {
   DevBuf<uint32_t> d_skip_count;
   uint32_t h_skip_count = 0;
   bool skip_on = true;  // NGSLD_REPLAY_SKIP=0: the pair kernels run the EM of every pair (A/B, tests)
+  bool skip_kernels = false;  // this cohort's pair kernel has a variant that leaves the marked sites' EM out (engine.hip)
 
   // plan
   bool planned = false;
@@ -425,6 +426,9 @@ struct ngsld_ctx {
     hipStream_t st = nullptr;
     bool dev_applied = false;
   } dev_run;                                  // the last ngsld_run_device, until ngsld_finish_device has looked at its flags
+  bool dev_run_flag_text = false;             // ngsld_run_device's launches also flag what text output needs flagged (engine_run.hip, run_grouped)
+  DevBuf<ngsld_rec_std> d_group_std[2];       // run_grouped: the records of a group of text batches, two groups in turn
+  DevBuf<ngsld_rec_ext> d_group_ext[2];
 
   // timing of pair-kernel launches
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;

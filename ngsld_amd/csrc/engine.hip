@@ -157,11 +157,13 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   // degenerate sites (sites whose pairs the exact-order replay settles anyway: the pair kernels leave their EM out) -- looked
   // for only where the device-side replay of likelihood matrices can take their pairs
   c->h_skip_count = 0;
-  // (where it was measured to pay, profiles/r06/skip: one wavefront per pair +6.5 % at 500 individuals, two +4.6 % at 1,000; not the
-  // lockstep kernel -- a wavefront is spared only what all its groups skip: -7 % at 100 -- and not four wavefronts per pair: at
-  // 2,000 individuals a replayed pair costs 7x a computed one and the pairs marked without need outweigh the EM saved, -6 %)
-  const bool look_for_skip = c->skip_on && c->replay_on && c->replay_device && c->exact_mode != 0 &&
-                            (cfg.kernel == kRun || (cfg.kernel == kMulti && cfg.form == 0 && cfg.waves == 2));
+  // The marks are taken for every per-individual kernel (they also tell ngsld_run that the matrix is un-called: run_grouped); the
+  // pair kernels SKIP the marked sites' EM only where that was measured to pay (profiles/r06/skip): one wavefront per pair +6.5 %
+  // at 500 individuals, two +4.6 % at 1,000; not the lockstep kernel -- a wavefront is spared only what all its groups skip: -7 %
+  // at 100 -- and not four wavefronts per pair: at 2,000 individuals a replayed pair costs 7x a computed one and the pairs
+  // marked without need outweigh the EM saved, -6 %.
+  const bool look_for_skip = c->skip_on && c->replay_on && c->replay_device && c->exact_mode != 0;
+  c->skip_kernels = cfg.kernel == kRun || (cfg.kernel == kMulti && cfg.form == 0 && cfg.waves == 2);
   if (look_for_skip) {
     HIP_TRY(c, c->d_skip.resize(n_sites));
     HIP_TRY(c, c->d_skip_count.resize(1));

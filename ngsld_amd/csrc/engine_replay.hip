@@ -800,12 +800,22 @@ int device_replay_lkl(ngsld_ctx *c, uint32_t *d_flags, uint32_t cap, uint64_t ou
     ngsld_ctx::LaneScratch &ls = slot < 0 ? c->lane_scratch_dev : c->lane_scratch[slot];
     const uint64_t list_cap = std::min<uint64_t>(n, 1ull << 26);
     const size_t temp_bytes = replay_sort_temp_bytes(list_cap, (uint32_t)c->n_sites);
-    HIP_TRY(c, ls.list.resize(list_cap));
-    HIP_TRY(c, ls.keys_a.resize(list_cap));
-    HIP_TRY(c, ls.keys_b.resize(list_cap));
-    HIP_TRY(c, ls.vals_a.resize(list_cap));
-    HIP_TRY(c, ls.vals_b.resize(list_cap));
-    HIP_TRY(c, ls.temp.resize(temp_bytes ? temp_bytes : 1));
+    // (the lanes' scratch -- 40 bytes per record of the launch + the sort's own -- is something the run can do without: where the
+    // device has no room for it the launch stays with the wavefront-per-pair kernel, or the host where that has no shape)
+    const bool have_scratch = ls.list.resize(list_cap) == hipSuccess && ls.keys_a.resize(list_cap) == hipSuccess &&
+                              ls.keys_b.resize(list_cap) == hipSuccess && ls.vals_a.resize(list_cap) == hipSuccess &&
+                              ls.vals_b.resize(list_cap) == hipSuccess && ls.temp.resize(temp_bytes ? temp_bytes : 1) == hipSuccess;
+    if (!have_scratch) {
+      (void)hipGetLastError();
+      ls.list.release(); ls.keys_a.release(); ls.keys_b.release(); ls.vals_a.release(); ls.vals_b.release(); ls.temp.release();
+      a.after_lanes = 0;
+      if (team_waves == 0) {
+        HIP_TRY(c, launch_replay_leftover(a, st));
+        return NGSLD_OK;
+      }
+      HIP_TRY(c, launch_replay_lkl(a, c->n_cus, st));
+      return NGSLD_OK;
+    }
     HIP_TRY(c, launch_replay_expand(a, ls.list.p, list_cap, st));
     HIP_TRY(c, launch_replay_sort(a, ls.list.p, list_cap, ls.keys_a.p, ls.keys_b.p, ls.vals_a.p, ls.vals_b.p, ls.temp.p, temp_bytes, st));
     int lane_waves = n >= (1ull << 22) ? 4 : 1;
@@ -905,7 +915,7 @@ int finish_device_run(ngsld_ctx *c) {
     // a likelihood matrix that flags more pairs than the host should replay: the exact store is built (once per matrix) and
     // the pairs are replayed on the device, behind the kernels on their stream
     int rcx = try_device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, base, n, c->dev_run.d_std, c->dev_run.d_ext, c->dev_run.st,
-                                    false, -1, &applied, c->n_sites);
+                                    c->dev_run_flag_text, -1, &applied, c->n_sites);
     if (rcx != NGSLD_OK) return rcx;
     if (applied) {
       rcx = send_flag_head(c, c->d_flags_dev.p, c->h_flags_dev.p, c->flag_cap_dev, c->dev_run.st, false);

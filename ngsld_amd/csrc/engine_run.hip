@@ -34,7 +34,7 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
   a.pearson_on_device = lkl_device_eligible(c) ? 1 : 0;
   // the pairs of degenerate sites (sc4[.][3]) skip their EM: every one of them is flagged and the exact-order replay is their
   // only evaluation -- on while the device-side replay of likelihood matrices can take them
-  a.skip_degenerate = (d_flags != nullptr && c->h_skip_count > 0 && c->skip_on && lkl_device_eligible(c) && !c->exact_failed) ? 1 : 0;
+  a.skip_degenerate = (d_flags != nullptr && c->h_skip_count > 0 && c->skip_on && c->skip_kernels && lkl_device_eligible(c) && !c->exact_failed) ? 1 : 0;
   a.planes = c->d_planes.p;
   a.site_stride = 3ull * c->np;
   a.np = c->np;
@@ -157,7 +157,9 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
     PairArgs a = make_args(c, r0, r1, (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, c->replay_on ? c->d_flags_dev.p : nullptr,
                            c->flag_cap_dev, c->timed_pairs);
     a.out_base = c->h_row_off[s1_begin];
-    a.flag_text = 0;  // these records stay on the device: only numerically ill-conditioned pairs are replayed
+    // these records stay on the device: only numerically ill-conditioned pairs are replayed -- unless they are the records of
+    // a group of text batches (run_grouped below): then also the pairs whose printed digits rounding could change
+    a.flag_text = c->dev_run_flag_text ? 1 : 0;
     HIP_TRY(c, timed_launch(c, a, st));
     r0 = r1;
   }
@@ -170,7 +172,8 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
     // flag many pairs without one has it built in ngsld_finish_device
     if (lkl_device_eligible(c) && (exact_store_started(c) || exact_store_is_free(c))) {
       rcd = try_device_replay_lkl(c, c->d_flags_dev.p, c->flag_cap_dev, c->h_row_off[s1_begin], c->timed_pairs,
-                                  (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, st, false, -1, &c->dev_run.dev_applied, c->n_sites);
+                                  (ngsld_rec_std *)d_std, (ngsld_rec_ext *)d_ext, st, c->dev_run_flag_text, -1, &c->dev_run.dev_applied,
+                                  c->dev_run_flag_text ? exact_sites_needed(c, s1_begin, s1_end) : c->n_sites);
       if (rcd != NGSLD_OK) return rcd;
     }
     // which pairs the kernels flagged (and the device has not settled itself): the counter and the list come over behind
@@ -192,35 +195,41 @@ int ngsld_run_device(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, void *d_s
   return NGSLD_OK;  // (the caller's stream: the records are final after ngsld_finish_device)
 } NGSLD_CATCH(c)
 
-int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user) try {
-  if (c == nullptr || sink == nullptr) return NGSLD_ERR_INVALID;
-  if (!c->planned) return fail(c, NGSLD_ERR_INVALID, "ngsld_plan has not been called");
-  if (s1_begin > s1_end || s1_end > c->n_sites) return fail(c, NGSLD_ERR_INVALID, "row range out of bounds");
-  HIP_TRY(c, hipSetDevice(c->device));
-  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
-  Range range_("ngsld:run");
-  {
-    const int rcp = finish_device_run(c);  // (see ngsld_run_device)
-    if (rcp != NGSLD_OK) return rcp;
+}  // extern "C"
+
+namespace ngsld {
+namespace eng {
+// (a build of the exact store a run starts has ended when the run returns, whichever way: the registered source is read
+// during runs only -- include/ngsld.h, BUFFER LIFETIME)
+struct StoreGuard {
+  ngsld_ctx *c;
+  ~StoreGuard() {
+    std::unique_lock<std::mutex> lk(c->exact_mu);
+    while (c->exact_state.load() == 1) c->exact_cv.wait_for(lk, std::chrono::milliseconds(1));
   }
-  // (a build of the exact store this run starts has ended when the run returns, whichever way: the registered source is read
-  // during runs only -- include/ngsld.h, BUFFER LIFETIME)
-  struct StoreGuard {
-    ngsld_ctx *c;
-    ~StoreGuard() {
-      std::unique_lock<std::mutex> lk(c->exact_mu);
-      while (c->exact_state.load() == 1) c->exact_cv.wait_for(lk, std::chrono::milliseconds(1));
-    }
-  } store_guard{c};
+};
+
+// Records of rows that are FINAL in device memory already (run_grouped): record 0 = plan record `base`.
+struct ReadyRecords {
+  const ngsld_rec_std *std;
+  const ngsld_rec_ext *ext;
+  uint64_t base;
+};
+
+// Rows [s1_begin, s1_end) through the batch pipeline.  ready == nullptr: the whole of it -- pair kernels, replay, text or records,
+// sink.  ready != nullptr (text output only): the rows' records are there and final; only the text is made of them, batch by batch.
+static int run_range(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user, const ReadyRecords *ready) {
   const bool ext = c->params.extend_out != 0;
-  c->ev_used = 0;
-  c->timed_stream = c->stream;
-  c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
-  c->replayed_pairs = 0;
-  c->replayed_on_device = 0;
-  c->flagged_pairs = 0;
-  c->text_rows_patched = 0;
-  const bool replay = c->replay_on;
+  if (ready == nullptr) {
+    c->ev_used = 0;
+    c->timed_stream = c->stream;
+    c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
+    c->replayed_pairs = 0;
+    c->replayed_on_device = 0;
+    c->flagged_pairs = 0;
+    c->text_rows_patched = 0;
+  }
+  const bool replay = c->replay_on && ready == nullptr;
   if (c->reserve_thread.joinable()) c->reserve_thread.join();  // (ngsld_reserve_text_buffers: h_text[] is this thread's again)
 
   // Device-side TSV: the dist column needs prefix sums of pos_dist that are EXACT (the host writer adds the gaps one
@@ -264,8 +273,8 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   // Text batches are small (2^19 rows: a 2.8 ms pair kernel, a tenth of it ramp and drain) and many: for them the two compute
   // streams half a batch out of phase DO pay, on every box -- while one stream's kernel drains the other's is in full
   // flight: configs[2]'s loop 0.58-0.63 -> 0.546-0.551 s (profiles/r04/e2e_text_streams.txt).  (tests: NGSLD_TEST_TEXT_STREAMS=1: one stream.)
-  bool text_two = true;
-  if (const char *e = test_knob("TEXT_STREAMS")) text_two = std::atoi(e) != 1;
+  bool text_two = ready == nullptr;  // (ready records: no pair kernel to keep in flight, and stream2 carries the next group's)
+  if (const char *e = test_knob("TEXT_STREAMS")) text_two = text_two && std::atoi(e) != 1;
   const bool two_streams = text ? text_two : c->run_streams == 2;
   c->timed_overlap = two_streams;  // (ngsld_last_kernel_time: launches on two streams share the device -- first start .. last end)
   // (text on ONE stream with three slots, two batches queued ahead, measured no different from two slots: the compute stream
@@ -322,7 +331,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     }
     batch_pairs /= 2;
   }
-  if (uses_runs(c->cfg.kernel)) {
+  if (uses_runs(c->cfg.kernel) && ready == nullptr) {
     // every batch should be thousands of workgroups (512 run at a time): the smaller the batches, the shorter the runs.
     // configs[2] as text (48 batches of 2^21 pairs): 16 items per run 0.82 s for this loop, 8 0.72 s, 4 0.70 s
     uint64_t want = kRunItems;
@@ -333,7 +342,7 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     if (rcr != NGSLD_OK) return rcr;
   }
   for (int k = 0; k < S; ++k) {
-    if (!direct) {
+    if (!direct && ready == nullptr) {
       HIP_TRY(c, c->d_std[k].resize(cap));
       if (ext) HIP_TRY(c, c->d_ext[k].resize(cap));
     }
@@ -382,8 +391,8 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     t.n_items = c->h_item_off[b.r1] - c->h_item_off[b.r0];
     t.out_base = c->h_row_off[b.r0];
     t.n_pairs = b.n;
-    t.std_rec = c->d_std[k].p;
-    t.ext_rec = ext ? c->d_ext[k].p : nullptr;
+    t.std_rec = ready ? ready->std + (c->h_row_off[b.r0] - ready->base) : c->d_std[k].p;
+    t.ext_rec = !ext ? nullptr : (ready ? ready->ext + (c->h_row_off[b.r0] - ready->base) : c->d_ext[k].p);
     t.maf = c->d_maf.p;
     t.cum = c->d_cum.p;
     t.infc = c->d_infc.p;
@@ -409,8 +418,10 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       const int rcf = reset_flags(c, c->d_flags[k], b.n, c->flag_cap[k], st);
       if (rcf != NGSLD_OK) return rcf;
     }
-    PairArgs a = make_args(c, b.r0, b.r1, dev_std[k], dev_ext[k], replay ? c->d_flags[k].p : nullptr, c->flag_cap[k], b.n);
-    HIP_TRY(c, timed_launch(c, a, st));
+    if (ready == nullptr) {
+      PairArgs a = make_args(c, b.r0, b.r1, dev_std[k], dev_ext[k], replay ? c->d_flags[k].p : nullptr, c->flag_cap[k], b.n);
+      HIP_TRY(c, timed_launch(c, a, st));
+    }
     c->slot_dev_applied[k] = false;
     if (replay) {  // (called genotypes: the flagged pairs settled on the device, before anything reads the records)
       int rcd = device_replay(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], st, k);
@@ -578,11 +589,10 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
       HIP_TRY(c, c->h_std[k].resize(cap));
       if (ext) HIP_TRY(c, c->h_ext[k].resize(cap));
       if (b.n) {
-        HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, c->d_std[k].p, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost,
-                                  c->copy_stream));
+        const TextArgs tr = text_args(b, k);  // (where the batch's records lie: the slot's buffers, or the group's)
+        HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, tr.std_rec, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost, c->copy_stream));
         if (ext)
-          HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, c->d_ext[k].p, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost,
-                                    c->copy_stream));
+          HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, tr.ext_rec, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost, c->copy_stream));
       }
       HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
       const int rc1 = need_host_items();
@@ -736,16 +746,131 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
     if (sink(user, &out) != 0) rc = fail(c, NGSLD_ERR_SINK, "sink callback failed");
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream2));
+  if (ready == nullptr) HIP_TRY(c, hipStreamSynchronize(c->stream2));  // (ready records: stream2 is the next group's, run_grouped waits for it)
   if (c->text_stream) HIP_TRY(c, hipStreamSynchronize(c->text_stream));
   HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
   if (rc != NGSLD_OK) return rc;
+  if (ready != nullptr) return NGSLD_OK;
   if (c->exact_state.load() == 1) {  // (the store's builder is still at the sites behind this run's rows: its errors are this run's)
     bool have = false;
     const int rcs = wait_exact_store(c, c->n_sites, &have);
     if (rcs != NGSLD_OK) return rcs;
   }
   return check_status(c);
+}
+
+// Text output of a likelihood matrix that is NOT SNP-called (degenerate sites were found at ngsld_set_geno_*): a third of the
+// pairs will be replayed, and the replay that does that at speed -- a lane per pair -- wants launches of millions of records,
+// not a text batch's 2^19 (a wavefront per pair there: 5.4e7 replayed pairs/s against 1.3e8; configs[2]'s un-called twin
+// through the binary 1.57 s against 0.90 SNP-called).  So the rows go in GROUPS of up to 2^25 pairs: one launch of pair kernels
+// + one device-side replay per group into records in device memory, as ngsld_run_device + ngsld_finish_device make them (the
+// few pairs only the host settles patched in), on stream2; the text of group k is made of its records batch by batch
+// (run_range with ready records: lengths, prefix sums, rows, D2H, sink) while group k + 1 is computed.
+static int run_grouped(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user, uint64_t group_pairs) {
+  const bool ext = c->params.extend_out != 0;
+  struct Group {
+    uint64_t r0, r1, n;
+  };
+  std::vector<Group> groups;
+  uint64_t cap = 1;
+  for (uint64_t r0 = s1_begin; r0 < s1_end;) {
+    uint64_t r1 = r0 + 1;
+    while (r1 < s1_end && c->h_row_off[r1 + 1] - c->h_row_off[r0] <= group_pairs) ++r1;
+    groups.push_back({r0, r1, c->h_row_off[r1] - c->h_row_off[r0]});
+    cap = std::max(cap, groups.back().n);
+    r0 = r1;
+  }
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(c, c->d_group_std[k].resize(cap));
+    if (ext) HIP_TRY(c, c->d_group_ext[k].resize(cap));
+  }
+  struct FlagText {  // (ngsld_run_device's launches flag what text needs flagged while this run lasts)
+    ngsld_ctx *c;
+    ~FlagText() { c->dev_run_flag_text = false; }
+  } flag_text{c};
+  c->dev_run_flag_text = true;
+  // (the matrix is known to be un-called: the exact store is wanted, and its builder can start beside the first group's kernels
+  // instead of inside the first group's finish)
+  if (!exact_store_started(c) && !c->exact_failed) {
+    const int rcs = start_exact_store(c);
+    if (rcs != NGSLD_OK) return rcs;
+  }
+  uint64_t flagged = 0, replayed = 0, on_device = 0;
+  auto compute = [&](size_t g) -> int {  // group g's records, enqueued on stream2 (no host wait)
+    const int k = (int)(g & 1);
+    return ngsld_run_device(c, groups[g].r0, groups[g].r1, c->d_group_std[k].p, ext ? c->d_group_ext[k].p : nullptr, c->stream2);
+  };
+  int rc = groups.empty() ? NGSLD_OK : compute(0);
+  for (size_t g = 0; rc == NGSLD_OK && g < groups.size(); ++g) {
+    rc = finish_device_run(c);  // waits for group g's kernels; the host's few pairs replayed and patched into the records
+    if (rc != NGSLD_OK) break;
+    rc = check_status(c);
+    if (rc != NGSLD_OK) break;
+    flagged += c->flagged_pairs;
+    replayed += c->replayed_pairs;
+    on_device += c->replayed_on_device;
+    if (g + 1 < groups.size()) {
+      rc = compute(g + 1);
+      if (rc != NGSLD_OK) break;
+    }
+    const int k = (int)(g & 1);
+    const ReadyRecords ready{c->d_group_std[k].p, ext ? c->d_group_ext[k].p : nullptr, c->h_row_off[groups[g].r0]};
+    rc = run_range(c, groups[g].r0, groups[g].r1, sink, user, &ready);
+  }
+  if (rc != NGSLD_OK) {  // (nothing of this run stays pending behind an error)
+    (void)hipStreamSynchronize(c->stream2);
+    c->dev_run.pending = false;
+    return rc;
+  }
+  c->flagged_pairs = flagged;
+  c->replayed_pairs = replayed;
+  c->replayed_on_device = on_device;
+  c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
+  if (c->exact_state.load() == 1) {
+    bool have = false;
+    const int rcs = wait_exact_store(c, c->n_sites, &have);
+    if (rcs != NGSLD_OK) return rcs;
+  }
+  return check_status(c);
+}
+}  // namespace eng
+}  // namespace ngsld
+
+extern "C" {
+
+int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user) try {
+  if (c == nullptr || sink == nullptr) return NGSLD_ERR_INVALID;
+  if (!c->planned) return fail(c, NGSLD_ERR_INVALID, "ngsld_plan has not been called");
+  if (s1_begin > s1_end || s1_end > c->n_sites) return fail(c, NGSLD_ERR_INVALID, "row range out of bounds");
+  HIP_TRY(c, hipSetDevice(c->device));
+  (void)hipGetLastError();  // (a failure some earlier call already reported must not surface as a launch's "last error")
+  Range range_("ngsld:run");
+  {
+    const int rcp = finish_device_run(c);  // (see ngsld_run_device)
+    if (rcp != NGSLD_OK) return rcp;
+  }
+  StoreGuard store_guard{c};
+  // Groups (run_grouped) where the matrix is known to be un-called -- one site in 64 or more is degenerate --, the device can
+  // replay its pairs, the rows become text on the device and there are at least two text batches' worth of them; the groups'
+  // records (72 bytes a pair, two groups) must have room, halved down to 2^22 pairs a group before the run goes batch by batch.
+  const uint64_t n_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
+  bool grouped = c->text_mode && c->replay_on && c->h_skip_count * 64ull >= c->n_sites && c->h_skip_count > 0 && lkl_device_eligible(c) &&
+                 !c->exact_failed && (n_pairs >= (1ull << 21) || test_knob("TEXT_GROUP_PAIRS") != nullptr) && !test_knob_is("TEXT_GROUPS", "0");
+  if (grouped) {  // (text on the device needs exact prefix sums of the gaps: run_range falls back to records otherwise -- keep that path whole)
+    for (uint64_t s = 0; s < c->n_sites && grouped; ++s) {
+      const double g = c->h_pos_dist[s];
+      if (!(std::isinf(g) && g > 0) && (!(g >= 0.0) || g != std::floor(g))) grouped = false;
+    }
+  }
+  if (grouped) {
+    uint64_t group_pairs = 1ull << 25;
+    if (const char *e = test_knob("TEXT_GROUP_PAIRS")) group_pairs = std::max<uint64_t>(1024, std::strtoull(e, nullptr, 10));  // tests: many small groups
+    const uint64_t rec_bytes = sizeof(ngsld_rec_std) + (c->params.extend_out ? sizeof(ngsld_rec_ext) : 0);
+    while (group_pairs > (1ull << 22) && !room_for(2 * std::min(group_pairs, n_pairs) * rec_bytes, 8ull << 30, 1ull << 30)) group_pairs /= 2;
+    if (test_knob("TEXT_GROUP_PAIRS") != nullptr || room_for(2 * std::min(group_pairs, n_pairs) * rec_bytes, 4ull << 30, 512ull << 20))
+      return run_grouped(c, s1_begin, s1_end, sink, user, group_pairs);
+  }
+  return run_range(c, s1_begin, s1_end, sink, user, nullptr);
 } NGSLD_CATCH(c)
 
 int ngsld_last_kernel_time(ngsld_ctx *c, double *total_ms, uint64_t *n_launches, uint64_t *n_pairs) {

@@ -12,6 +12,7 @@
 //   BATCH_PAIRS, STAGE_BYTES, MAX_BLOCKS, PIN_LIMIT_BYTES, PREP_EXACT, HARD_KERNEL, SLAB_SITES, MULTI_DIST,
 //   RUN_DIRECT, RUN_TAPER, RUN_STREAMS, TAIL_LEN, TAIL_PAIRS, TILES, TILE_MIN_MB,
 //   TEXT_STREAMS, TEXT_HOST_PATCH, TEXT_HOST_PATCH_FAIL_EVERY, TEXT_FALLBACK_EVERY,
+//   TEXT_GROUPS, TEXT_GROUP_PAIRS,
 //   EXACT_CHUNK_SITES, EXACT_SLOW_US, EXACT_STORE_NO_ROOM, REPLAY_LIST_CAP, REPLAY_SOURCE, LANE_ITER_CAP
 // (The knobs of closed A/B experiments -- lane caps and waves, sort-key tilings, run lengths, tile rows, text batch sizes -- are
 // gone; their measurements are in HISTORY.md.)

@@ -469,7 +469,24 @@ def test_shapes_that_do_not_take_the_skip_mark_no_site(eng_skip, n_ind):
     pair costs 7x a computed one there) measured slower with the skip: engine.hip, look_for_skip."""
     raw = uncalled(40, n_ind, seed=17, mono_frac=0.3)
     r = run_records(eng_skip, raw, 2)
-    assert r[4]["sites_degenerate"] == 0 and r[4]["pairs_on_device"] > 0
+    # (the sites are marked -- the marks also tell ngsld_run that the matrix is un-called -- but these kernels compute every pair)
+    assert r[4]["sites_degenerate"] > 0 and r[4]["pairs_on_device"] > 0
+    e = capi.Engine(0)
+    try:
+        e.set_replay(True)
+        import os
+        os.environ["NGSLD_REPLAY_SKIP"] = "0"
+        e2 = capi.Engine(0)
+        try:
+            full = run_records(e2, raw, 2)
+        finally:
+            e2.close()
+            del os.environ["NGSLD_REPLAY_SKIP"]
+    finally:
+        e.close()
+    assert full[4]["pairs_flagged"] == r[4]["pairs_flagged"]
+    for k in (2, 3):
+        assert full[k].tobytes() == r[k].tobytes()
 
 
 def test_degenerate_sites_text_is_the_host_replays(eng, eng_skip):
@@ -494,3 +511,70 @@ def test_degenerate_sites_text_is_the_host_replays(eng, eng_skip):
             assert e.replay_info()["sites_degenerate"] > 0
         e.set_text_output(None, enable=False)
     assert md5["host"] == md5["skip"] == md5["skip_auto"]
+
+
+# ---- un-called input as TEXT goes in groups: one launch of pair kernels + one lane replay per group, the text of a group made of its
+# final records while the next group is computed (engine_run.hip, run_grouped) ----
+@pytest.mark.parametrize("group_pairs", ["7000", "1000000000"])
+@pytest.mark.parametrize("extend", [True, False])
+def test_text_in_groups_is_the_text_batch_by_batch(eng, eng_skip, monkeypatch, group_pairs, extend):
+    n_sites, n_ind = 500, 300
+    raw = uncalled(n_sites, n_ind, seed=123, depth=8.0, mono_frac=0.25)
+    chrs, pos = synth.make_positions(n_sites, 9, max_gap=300)
+    labels = [f"{c}:{p}" for c, p in zip(chrs, pos)]
+    from ngsld_amd import shard
+    pd = shard.pos_dist_from_positions(chrs, pos)
+
+    def text_of(e, mode):
+        e.set_exact_store(mode)
+        e.set_geno_raw(raw)
+        e.set_pos_dist(pd)
+        e.set_tuning(batch_pairs=3000)            # several text batches inside a group
+        e.plan(max_kb_dist=15, extend_out=extend)
+        e.set_text_output(labels)
+        t, fallbacks = e.run_text()
+        assert fallbacks == 0
+        info = e.replay_info()
+        e.set_text_output(None, enable=False)
+        return hashlib.md5(t).hexdigest(), len(t), info
+
+    monkeypatch.setenv("NGSLD_TEST_TEXT_GROUPS", "0")
+    host = text_of(eng, 0)                         # host replay, batch by batch, every pair's EM in the pair kernel
+    batchwise = text_of(eng_skip, 2)               # device replay, batch by batch
+    monkeypatch.delenv("NGSLD_TEST_TEXT_GROUPS")
+    monkeypatch.setenv("NGSLD_TEST_TEXT_GROUP_PAIRS", group_pairs)
+    grouped = text_of(eng_skip, 2)
+    again = text_of(eng_skip, 1)                   # (the default policy: the groups' own finish builds the store)
+    assert host[0] == batchwise[0] == grouped[0] == again[0] and host[1] == grouped[1]
+    assert grouped[2]["sites_degenerate"] > 0 and grouped[2]["pairs_on_device"] > grouped[2]["pairs_flagged"] * 0.9
+    assert grouped[2]["pairs_on_device"] + grouped[2]["pairs_on_host"] == grouped[2]["pairs_replayed"]
+
+
+def test_text_in_groups_through_the_host_formatter_fallback(eng_skip, monkeypatch, tmp_path):
+    """Every third text batch of a grouped run goes out as records (the device formatter's fallback) and is formatted on the host:
+    the records come from the group's buffers, the table is the same bytes."""
+    import os
+    n_sites, n_ind = 400, 260
+    raw = uncalled(n_sites, n_ind, seed=321, depth=8.0, mono_frac=0.25)
+
+    def table(path):
+        eng_skip.set_exact_store(2)
+        eng_skip.set_geno_raw(raw)
+        eng_skip.set_pos_dist(None)
+        eng_skip.set_tuning(batch_pairs=2500)
+        n = eng_skip.plan(extend_out=True)
+        eng_skip.set_text_output(None)
+        fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+        try:
+            assert eng_skip.run_to_fd(0, n_sites, fd, None, None, eng_skip.maf(), 2) == n
+        finally:
+            os.close(fd)
+        eng_skip.set_text_output(None, enable=False)
+        return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+    monkeypatch.setenv("NGSLD_TEST_TEXT_GROUPS", "0")
+    plain = table(str(tmp_path / "plain.tsv"))
+    monkeypatch.delenv("NGSLD_TEST_TEXT_GROUPS")
+    monkeypatch.setenv("NGSLD_TEST_TEXT_GROUP_PAIRS", "9000")
+    monkeypatch.setenv("NGSLD_TEST_TEXT_FALLBACK_EVERY", "3")
+    assert table(str(tmp_path / "grouped.tsv")) == plain
