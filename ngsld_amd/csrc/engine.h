@@ -429,6 +429,11 @@ struct ngsld_ctx {
   bool dev_run_flag_text = false;             // ngsld_run_device's launches also flag what text output needs flagged (engine_run.hip, run_grouped)
   DevBuf<ngsld_rec_std> d_group_std[2];       // run_grouped: the records of a group of text batches, two groups in turn
   DevBuf<ngsld_rec_ext> d_group_ext[2];
+  DevBuf<uint64_t> d_group_lens, d_group_offs, d_group_meta, d_group_first;  // ... its rows' lengths, their prefix sums, {total, .., .., overflow}, the batches' first records
+  DevBuf<int> d_group_needs;                  // ... per batch: a value beyond the device formatter's range (the batch goes out as records)
+  DevBuf<char> d_group_text;                  // ... its text
+  PinBuf<uint64_t> h_group_bounds;            // ... where each batch's text begins (+ the total)
+  PinBuf<int> h_group_needs;
 
   // timing of pair-kernel launches
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -527,6 +532,7 @@ bool exact_store_is_free(const ngsld_ctx *c);
 inline bool exact_store_started(const ngsld_ctx *c) { return c->exact_state.load() >= 1; }
 // starts the build where there is something to build (idempotent); the alias forms are complete at once
 int start_exact_store(ngsld_ctx *c);
+int reserve_device_run(ngsld_ctx *c, uint64_t n_records);  // ngsld_run_device's own buffers for launches of up to n records, once
 // waits until sites [0, need_sites) are on the device (need_sites >= n_sites: until the store is complete); *have = false when
 // there is no store to be had (no room on the device: host replay); an error of the build comes back as the return value
 int wait_exact_store(ngsld_ctx *c, uint64_t need_sites, bool *have);

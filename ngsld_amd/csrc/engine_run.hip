@@ -34,7 +34,7 @@ PairArgs make_args(ngsld_ctx *c, uint64_t r0, uint64_t r1, ngsld_rec_std *d_std,
   a.pearson_on_device = lkl_device_eligible(c) ? 1 : 0;
   // the pairs of degenerate sites (sc4[.][3]) skip their EM: every one of them is flagged and the exact-order replay is their
   // only evaluation -- on while the device-side replay of likelihood matrices can take them
-  a.skip_degenerate = (d_flags != nullptr && c->h_skip_count > 0 && c->skip_on && c->skip_kernels && lkl_device_eligible(c) && !c->exact_failed) ? 1 : 0;
+  a.skip_degenerate = (d_flags != nullptr && c->h_skip_count > 0 && c->skip_on && lkl_device_eligible(c) && !c->exact_failed) ? 1 : 0;
   a.planes = c->d_planes.p;
   a.site_stride = 3ull * c->np;
   a.np = c->np;
@@ -209,55 +209,51 @@ struct StoreGuard {
   }
 };
 
-// Records of rows that are FINAL in device memory already (run_grouped): record 0 = plan record `base`.
-struct ReadyRecords {
-  const ngsld_rec_std *std;
-  const ngsld_rec_ext *ext;
-  uint64_t base;
-};
-
-// Rows [s1_begin, s1_end) through the batch pipeline.  ready == nullptr: the whole of it -- pair kernels, replay, text or records,
-// sink.  ready != nullptr (text output only): the rows' records are there and final; only the text is made of them, batch by batch.
-static int run_range(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user, const ReadyRecords *ready) {
-  const bool ext = c->params.extend_out != 0;
-  if (ready == nullptr) {
-    c->ev_used = 0;
-    c->timed_stream = c->stream;
-    c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
-    c->replayed_pairs = 0;
-    c->replayed_on_device = 0;
-    c->flagged_pairs = 0;
-    c->text_rows_patched = 0;
+// Device-side TSV: the dist column needs prefix sums of pos_dist that are EXACT (the host writer adds the gaps one by one,
+// ngsLD.cpp:241), i.e. integer gaps as read_dist produces them; otherwise (*text = false) the batches go out as records.
+static int upload_text_prefix(ngsld_ctx *c, bool *text) {
+  const uint64_t n = c->n_sites;
+  std::vector<double> cum(n);
+  std::vector<uint32_t> infc(n);
+  double run = 0.0;
+  uint32_t ic = 0;
+  for (uint64_t s = 0; s < n && *text; ++s) {
+    const double g = c->h_pos_dist[s];
+    if (std::isinf(g) && g > 0) {
+      ++ic;
+    } else {
+      if (!(g >= 0.0) || g != std::floor(g) || run + g > 9.0e15) *text = false;
+      run += g;
+    }
+    cum[s] = run;
+    infc[s] = ic;
   }
-  const bool replay = c->replay_on && ready == nullptr;
+  if (*text) {
+    HIP_TRY(c, c->d_cum.resize(n));
+    HIP_TRY(c, c->d_infc.resize(n));
+    HIP_TRY(c, hipMemcpy(c->d_cum.p, cum.data(), n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_infc.p, infc.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  return NGSLD_OK;
+}
+
+// Rows [s1_begin, s1_end) through the batch pipeline: pair kernels, replay, text or records, sink -- batch by batch.
+static int run_range(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user) {
+  const bool ext = c->params.extend_out != 0;
+  c->ev_used = 0;
+  c->timed_stream = c->stream;
+  c->timed_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
+  c->replayed_pairs = 0;
+  c->replayed_on_device = 0;
+  c->flagged_pairs = 0;
+  c->text_rows_patched = 0;
+  const bool replay = c->replay_on;
   if (c->reserve_thread.joinable()) c->reserve_thread.join();  // (ngsld_reserve_text_buffers: h_text[] is this thread's again)
 
-  // Device-side TSV: the dist column needs prefix sums of pos_dist that are EXACT (the host writer adds the gaps one
-  // by one, ngsLD.cpp:241), i.e. integer gaps as read_dist produces them; otherwise the batches go out as records.
   bool text = c->text_mode;
   if (text) {
-    const uint64_t n = c->n_sites;
-    std::vector<double> cum(n);
-    std::vector<uint32_t> infc(n);
-    double run = 0.0;
-    uint32_t ic = 0;
-    for (uint64_t s = 0; s < n && text; ++s) {
-      const double g = c->h_pos_dist[s];
-      if (std::isinf(g) && g > 0) {
-        ++ic;
-      } else {
-        if (!(g >= 0.0) || g != std::floor(g) || run + g > 9.0e15) text = false;
-        run += g;
-      }
-      cum[s] = run;
-      infc[s] = ic;
-    }
-    if (text) {
-      HIP_TRY(c, c->d_cum.resize(n));
-      HIP_TRY(c, c->d_infc.resize(n));
-      HIP_TRY(c, hipMemcpy(c->d_cum.p, cum.data(), n * sizeof(double), hipMemcpyHostToDevice));
-      HIP_TRY(c, hipMemcpy(c->d_infc.p, infc.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
+    const int rct = upload_text_prefix(c, &text);
+    if (rct != NGSLD_OK) return rct;
   }
   auto need_host_items = [&]() -> int { return ensure_host_items(c); };
   if (!text) {  // (record batches carry their items to the sink; text batches need none -- the replay finds its pairs on the device)
@@ -273,8 +269,8 @@ static int run_range(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sin
   // Text batches are small (2^19 rows: a 2.8 ms pair kernel, a tenth of it ramp and drain) and many: for them the two compute
   // streams half a batch out of phase DO pay, on every box -- while one stream's kernel drains the other's is in full
   // flight: configs[2]'s loop 0.58-0.63 -> 0.546-0.551 s (profiles/r04/e2e_text_streams.txt).  (tests: NGSLD_TEST_TEXT_STREAMS=1: one stream.)
-  bool text_two = ready == nullptr;  // (ready records: no pair kernel to keep in flight, and stream2 carries the next group's)
-  if (const char *e = test_knob("TEXT_STREAMS")) text_two = text_two && std::atoi(e) != 1;
+  bool text_two = true;
+  if (const char *e = test_knob("TEXT_STREAMS")) text_two = std::atoi(e) != 1;
   const bool two_streams = text ? text_two : c->run_streams == 2;
   c->timed_overlap = two_streams;  // (ngsld_last_kernel_time: launches on two streams share the device -- first start .. last end)
   // (text on ONE stream with three slots, two batches queued ahead, measured no different from two slots: the compute stream
@@ -331,7 +327,7 @@ static int run_range(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sin
     }
     batch_pairs /= 2;
   }
-  if (uses_runs(c->cfg.kernel) && ready == nullptr) {
+  if (uses_runs(c->cfg.kernel)) {
     // every batch should be thousands of workgroups (512 run at a time): the smaller the batches, the shorter the runs.
     // configs[2] as text (48 batches of 2^21 pairs): 16 items per run 0.82 s for this loop, 8 0.72 s, 4 0.70 s
     uint64_t want = kRunItems;
@@ -342,7 +338,7 @@ static int run_range(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sin
     if (rcr != NGSLD_OK) return rcr;
   }
   for (int k = 0; k < S; ++k) {
-    if (!direct && ready == nullptr) {
+    if (!direct) {
       HIP_TRY(c, c->d_std[k].resize(cap));
       if (ext) HIP_TRY(c, c->d_ext[k].resize(cap));
     }
@@ -391,8 +387,8 @@ static int run_range(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sin
     t.n_items = c->h_item_off[b.r1] - c->h_item_off[b.r0];
     t.out_base = c->h_row_off[b.r0];
     t.n_pairs = b.n;
-    t.std_rec = ready ? ready->std + (c->h_row_off[b.r0] - ready->base) : c->d_std[k].p;
-    t.ext_rec = !ext ? nullptr : (ready ? ready->ext + (c->h_row_off[b.r0] - ready->base) : c->d_ext[k].p);
+    t.std_rec = c->d_std[k].p;
+    t.ext_rec = ext ? c->d_ext[k].p : nullptr;
     t.maf = c->d_maf.p;
     t.cum = c->d_cum.p;
     t.infc = c->d_infc.p;
@@ -418,10 +414,8 @@ static int run_range(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sin
       const int rcf = reset_flags(c, c->d_flags[k], b.n, c->flag_cap[k], st);
       if (rcf != NGSLD_OK) return rcf;
     }
-    if (ready == nullptr) {
-      PairArgs a = make_args(c, b.r0, b.r1, dev_std[k], dev_ext[k], replay ? c->d_flags[k].p : nullptr, c->flag_cap[k], b.n);
-      HIP_TRY(c, timed_launch(c, a, st));
-    }
+    PairArgs a = make_args(c, b.r0, b.r1, dev_std[k], dev_ext[k], replay ? c->d_flags[k].p : nullptr, c->flag_cap[k], b.n);
+    HIP_TRY(c, timed_launch(c, a, st));
     c->slot_dev_applied[k] = false;
     if (replay) {  // (called genotypes: the flagged pairs settled on the device, before anything reads the records)
       int rcd = device_replay(c, c->d_flags[k].p, c->flag_cap[k], c->h_row_off[b.r0], b.n, dev_std[k], dev_ext[k], st, k);
@@ -589,10 +583,11 @@ static int run_range(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sin
       HIP_TRY(c, c->h_std[k].resize(cap));
       if (ext) HIP_TRY(c, c->h_ext[k].resize(cap));
       if (b.n) {
-        const TextArgs tr = text_args(b, k);  // (where the batch's records lie: the slot's buffers, or the group's)
-        HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, tr.std_rec, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, c->d_std[k].p, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost,
+                                  c->copy_stream));
         if (ext)
-          HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, tr.ext_rec, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost, c->copy_stream));
+          HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, c->d_ext[k].p, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost,
+                                    c->copy_stream));
       }
       HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
       const int rc1 = need_host_items();
@@ -746,11 +741,10 @@ static int run_range(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sin
     if (sink(user, &out) != 0) rc = fail(c, NGSLD_ERR_SINK, "sink callback failed");
   }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  if (ready == nullptr) HIP_TRY(c, hipStreamSynchronize(c->stream2));  // (ready records: stream2 is the next group's, run_grouped waits for it)
+  HIP_TRY(c, hipStreamSynchronize(c->stream2));
   if (c->text_stream) HIP_TRY(c, hipStreamSynchronize(c->text_stream));
   HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
   if (rc != NGSLD_OK) return rc;
-  if (ready != nullptr) return NGSLD_OK;
   if (c->exact_state.load() == 1) {  // (the store's builder is still at the sites behind this run's rows: its errors are this run's)
     bool have = false;
     const int rcs = wait_exact_store(c, c->n_sites, &have);
@@ -759,13 +753,177 @@ static int run_range(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sin
   return check_status(c);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
 // Text output of a likelihood matrix that is NOT SNP-called (degenerate sites were found at ngsld_set_geno_*): a third of the
 // pairs will be replayed, and the replay that does that at speed -- a lane per pair -- wants launches of millions of records,
 // not a text batch's 2^19 (a wavefront per pair there: 5.4e7 replayed pairs/s against 1.3e8; configs[2]'s un-called twin
-// through the binary 1.57 s against 0.90 SNP-called).  So the rows go in GROUPS of up to 2^25 pairs: one launch of pair kernels
-// + one device-side replay per group into records in device memory, as ngsld_run_device + ngsld_finish_device make them (the
-// few pairs only the host settles patched in), on stream2; the text of group k is made of its records batch by batch
-// (run_range with ready records: lengths, prefix sums, rows, D2H, sink) while group k + 1 is computed.
+// through the binary 1.57 s against 0.90 SNP-called).  So the rows go in GROUPS of up to 2^25 pairs:
+//   A(g)  one launch of pair kernels + one device-side replay into records in device memory, as ngsld_run_device +
+//         ngsld_finish_device make them (the few pairs only the host settles patched in), on stream2;
+//   T(g)  the text of the whole group from its final records, on the device: lengths and rows batch by batch (a batch that meets
+//         a value beyond the formatter's range goes out as records, as in run_range), ONE prefix sum over the group;
+//   C(g)  the group's text to the host and the sink, batch by batch through the pinned buffers (SDMA copies: they do not care what
+//         the compute units do).
+// Order on the host: finish A(g) -> T(g) -> launch A(g+1) -> C(g).  T(g) goes BEFORE A(g+1) is launched: once a pair kernel's
+// grid is being dispatched no other queue's kernel gets a workgroup in, whatever its priority (measured: the first text kernels
+// of a group issued beside the next group's pair kernel waited 80-90 ms, the kernel's whole length); what is exposed instead is
+// T(g)'s own ~30 ms a group.
+// ---------------------------------------------------------------------------------------------------------------
+struct ReadyRecords {  // records that are final in device memory: record 0 = plan record `base`
+  const ngsld_rec_std *std;
+  const ngsld_rec_ext *ext;
+  uint64_t base;
+};
+
+__global__ void group_bounds_kernel(const uint64_t *offs, const uint64_t *first_rec, uint32_t n_batches, const uint64_t *total, const int *needs,
+                                    uint64_t *h_bounds, int *h_needs) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n_batches) {
+    h_bounds[j] = offs[first_rec[j]];
+    h_needs[j] = needs[j];
+  } else if (j == n_batches) {
+    h_bounds[j] = *total;
+  }
+}
+
+struct TextBatch {
+  uint64_t r0, r1, n, rec0;  // rows, pairs, first record relative to the group
+};
+
+// T(g): returns with every kernel of the group's text enqueued on c->stream and ev_kernel_done[0] recorded behind them
+static int group_text_kernels(ngsld_ctx *c, const ReadyRecords &rr, const std::vector<TextBatch> &tb, uint64_t n_group) {
+  const bool ext = c->params.extend_out != 0;
+  const uint32_t nb = (uint32_t)tb.size();
+  hipStream_t st = c->stream;
+  HIP_TRY(c, c->d_group_lens.resize(n_group ? n_group : 1));
+  HIP_TRY(c, c->d_group_offs.resize(n_group ? n_group : 1));
+  HIP_TRY(c, c->d_group_meta.resize(4));
+  HIP_TRY(c, c->d_group_needs.resize(nb + 1));
+  HIP_TRY(c, c->d_group_first.resize(nb + 1));
+  HIP_TRY(c, c->h_group_bounds.resize(nb + 1));
+  HIP_TRY(c, c->h_group_needs.resize(nb + 1));
+  const size_t scan_bytes = text_scan_temp_bytes(n_group);
+  HIP_TRY(c, c->d_scan_tmp.resize(scan_bytes ? scan_bytes : 1));
+  std::vector<uint64_t> first(nb + 1, 0);
+  for (uint32_t j = 0; j < nb; ++j) first[j] = tb[j].rec0;
+  HIP_TRY(c, hipMemcpyAsync(c->d_group_first.p, first.data(), (nb + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(c, hipMemsetAsync(c->d_group_needs.p, 0, (nb + 1) * sizeof(int), st));
+  HIP_TRY(c, hipMemsetAsync(c->d_group_meta.p, 0, 4 * sizeof(uint64_t), st));
+  auto args = [&](const TextBatch &b, uint32_t j) -> TextArgs {
+    TextArgs t{};
+    t.items = c->d_items.p + c->h_item_off[b.r0];
+    t.n_items = c->h_item_off[b.r1] - c->h_item_off[b.r0];
+    t.out_base = c->h_row_off[b.r0];
+    t.n_pairs = b.n;
+    t.std_rec = rr.std + b.rec0;
+    t.ext_rec = ext ? rr.ext + b.rec0 : nullptr;
+    t.maf = c->d_maf.p;
+    t.cum = c->d_cum.p;
+    t.infc = c->d_infc.p;
+    t.labels = c->have_labels ? c->d_labels.p : nullptr;
+    t.label_off = c->d_label_off.p;
+    t.lens = c->d_group_lens.p + b.rec0;
+    t.offs = c->d_group_offs.p + b.rec0;   // (prefix sums over the GROUP: offsets into the group's text)
+    t.text = c->d_group_text.p;
+    t.text_cap = 0;
+    t.overflow = c->d_group_meta.p + 3;
+    t.needs_host = c->d_group_needs.p + j;
+    return t;
+  };
+  for (uint32_t j = 0; j < nb; ++j) HIP_TRY(c, launch_text_lengths(args(tb[j], j), st));
+  HIP_TRY(c, text_scan(c->d_scan_tmp.p, scan_bytes, c->d_group_lens.p, c->d_group_offs.p, n_group, c->d_group_meta.p, st));
+  // the group's text length: the one thing the host has to know before the rows are written (their buffer)
+  uint64_t total = 0;
+  HIP_TRY(c, hipMemcpyAsync(&total, c->d_group_meta.p, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(c, hipStreamSynchronize(st));
+  if (total > c->d_group_text.n) HIP_TRY(c, c->d_group_text.resize(total + total / 16));
+  for (uint32_t j = 0; j < nb; ++j) {
+    TextArgs t = args(tb[j], j);
+    t.text = c->d_group_text.p;
+    HIP_TRY(c, launch_text_write(t, st));
+  }
+  uint64_t *hb = nullptr;
+  int *hn = nullptr;
+  HIP_TRY(c, hipHostGetDevicePointer((void **)&hb, c->h_group_bounds.p, 0));
+  HIP_TRY(c, hipHostGetDevicePointer((void **)&hn, c->h_group_needs.p, 0));
+  hipLaunchKernelGGL(group_bounds_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, c->d_group_offs.p, c->d_group_first.p, nb, c->d_group_meta.p,
+                     c->d_group_needs.p, hb, hn);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipEventRecord(c->ev_kernel_done[0], st));
+  return NGSLD_OK;
+}
+
+// C(g): the group's text (or, for a batch the formatter gave up on, its records) to the host and the sink, batch by batch
+static int group_text_to_sink(ngsld_ctx *c, const ReadyRecords &rr, const std::vector<TextBatch> &tb, ngsld_sink_fn sink, void *user) {
+  const bool ext = c->params.extend_out != 0;
+  const size_t nb = tb.size();
+  HIP_TRY(c, hipEventSynchronize(c->ev_kernel_done[0]));  // T(g) is through: bounds and fallbacks are in host memory
+  const uint64_t *bounds = c->h_group_bounds.p;
+  const int *needs = c->h_group_needs.p;
+  constexpr int S = ngsld_ctx::kSlots;
+  std::vector<Item> rel_items;
+  auto fallback = [&](size_t j) {
+    bool f = needs[j] != 0;
+    if (const char *e = test_knob("TEXT_FALLBACK_EVERY")) {  // tests: every n-th batch takes the record path
+      const uint64_t every = std::strtoull(e, nullptr, 10);
+      if (every > 0 && j % every == every - 1) f = true;
+    }
+    return f;
+  };
+  auto issue_copy = [&](size_t j) -> int {
+    const int k = (int)(j % (size_t)S);
+    const TextBatch &b = tb[j];
+    if (fallback(j)) {
+      HIP_TRY(c, c->h_std[k].resize(b.n ? b.n : 1));
+      if (ext) HIP_TRY(c, c->h_ext[k].resize(b.n ? b.n : 1));
+      if (b.n) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_std[k].p, rr.std + b.rec0, b.n * sizeof(ngsld_rec_std), hipMemcpyDeviceToHost, c->copy_stream));
+        if (ext) HIP_TRY(c, hipMemcpyAsync(c->h_ext[k].p, rr.ext + b.rec0, b.n * sizeof(ngsld_rec_ext), hipMemcpyDeviceToHost, c->copy_stream));
+      }
+    } else {
+      const uint64_t len = bounds[j + 1] - bounds[j];
+      if (len > c->h_text[k].n) HIP_TRY(c, c->h_text[k].resize(len + len / 8));
+      if (len) HIP_TRY(c, hipMemcpyAsync(c->h_text[k].p, c->d_group_text.p + bounds[j], len, hipMemcpyDeviceToHost, c->copy_stream));
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_copy_done[k], c->copy_stream));
+    return NGSLD_OK;
+  };
+  int rc = NGSLD_OK;
+  for (size_t j = 0; rc == NGSLD_OK && j + 1 < (size_t)S && j < nb; ++j) rc = issue_copy(j);
+  for (size_t j = 0; rc == NGSLD_OK && j < nb; ++j) {
+    const int k = (int)(j % (size_t)S);
+    if (j + (size_t)S - 1 < nb) {
+      rc = issue_copy(j + (size_t)S - 1);
+      if (rc != NGSLD_OK) break;
+    }
+    const TextBatch &b = tb[j];
+    Range range_wait("ngsld:consume batch (text of a group, D2H, sink)");
+    HIP_TRY(c, hipEventSynchronize(c->ev_copy_done[k]));
+    ngsld_batch out{};
+    out.s1_begin = b.r0;
+    out.s1_end = b.r1;
+    out.n_pairs = b.n;
+    if (fallback(j)) {
+      const int rci = ensure_host_items(c);
+      if (rci != NGSLD_OK) return rci;
+      const uint64_t i0 = c->h_item_off[b.r0], i1 = c->h_item_off[b.r1];
+      rel_items.assign(c->h_items.begin() + (ptrdiff_t)i0, c->h_items.begin() + (ptrdiff_t)i1);
+      for (auto &it : rel_items) it.first_record -= c->h_row_off[b.r0];
+      out.n_items = i1 - i0;
+      out.items = rel_items.data();
+      out.std = c->h_std[k].p;
+      out.ext = ext ? c->h_ext[k].p : nullptr;
+    } else {
+      out.text = c->h_text[k].p;
+      out.text_len = bounds[j + 1] - bounds[j];
+    }
+    Range range_sink("ngsld:sink");
+    if (sink(user, &out) != 0) rc = fail(c, NGSLD_ERR_SINK, "sink callback failed");
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+  return rc;
+}
+
 static int run_grouped(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn sink, void *user, uint64_t group_pairs) {
   const bool ext = c->params.extend_out != 0;
   struct Group {
@@ -774,16 +932,40 @@ static int run_grouped(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_s
   std::vector<Group> groups;
   uint64_t cap = 1;
   for (uint64_t r0 = s1_begin; r0 < s1_end;) {
+    // (the first group a quarter of the size: nothing overlaps its kernels, the sink waits for them)
+    const uint64_t target = groups.empty() ? std::max<uint64_t>(group_pairs / 4, std::min<uint64_t>(group_pairs, 1ull << 22)) : group_pairs;
     uint64_t r1 = r0 + 1;
-    while (r1 < s1_end && c->h_row_off[r1 + 1] - c->h_row_off[r0] <= group_pairs) ++r1;
+    while (r1 < s1_end && c->h_row_off[r1 + 1] - c->h_row_off[r0] <= target) ++r1;
     groups.push_back({r0, r1, c->h_row_off[r1] - c->h_row_off[r0]});
     cap = std::max(cap, groups.back().n);
     r0 = r1;
+  }
+  // (... and the last one small too: nothing overlaps the trip of its text to the host)
+  if (groups.size() >= 2 && groups.back().n > group_pairs / 3) {
+    Group last = groups.back();
+    uint64_t cut = last.r1;
+    while (cut > last.r0 + 1 && c->h_row_off[last.r1] - c->h_row_off[cut - 1] <= group_pairs / 4) --cut;
+    if (cut > last.r0 && cut < last.r1) {
+      groups.back() = {last.r0, cut, c->h_row_off[cut] - c->h_row_off[last.r0]};
+      groups.push_back({cut, last.r1, c->h_row_off[last.r1] - c->h_row_off[cut]});
+    }
   }
   for (int k = 0; k < 2; ++k) {
     HIP_TRY(c, c->d_group_std[k].resize(cap));
     if (ext) HIP_TRY(c, c->d_group_ext[k].resize(cap));
   }
+  HIP_TRY(c, c->d_group_lens.resize(cap));
+  HIP_TRY(c, c->d_group_offs.resize(cap));
+  {
+    // (the largest group's text too: ~170 bytes a row with the extended columns, labels on top -- grown if a group needs more)
+    const uint64_t row_guess = 2 * c->max_label + (ext ? 170 : 60);
+    HIP_TRY(c, c->d_group_text.resize(cap * row_guess));
+    const size_t scan_bytes = text_scan_temp_bytes(cap);
+    HIP_TRY(c, c->d_scan_tmp.resize(scan_bytes ? scan_bytes : 1));
+    const int rcr = reserve_device_run(c, cap);
+    if (rcr != NGSLD_OK) return rcr;
+  }
+  if (c->reserve_thread.joinable()) c->reserve_thread.join();  // (ngsld_reserve_text_buffers: h_text[] is this thread's again)
   struct FlagText {  // (ngsld_run_device's launches flag what text needs flagged while this run lasts)
     ngsld_ctx *c;
     ~FlagText() { c->dev_run_flag_text = false; }
@@ -795,30 +977,48 @@ static int run_grouped(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_s
     const int rcs = start_exact_store(c);
     if (rcs != NGSLD_OK) return rcs;
   }
+  const uint64_t text_batch = std::min<uint64_t>(c->batch_pairs, kTextBatchPairs);
   uint64_t flagged = 0, replayed = 0, on_device = 0;
-  auto compute = [&](size_t g) -> int {  // group g's records, enqueued on stream2 (no host wait)
+  auto compute = [&](size_t g) -> int {  // A(g), enqueued on stream2 (no host wait)
     const int k = (int)(g & 1);
     return ngsld_run_device(c, groups[g].r0, groups[g].r1, c->d_group_std[k].p, ext ? c->d_group_ext[k].p : nullptr, c->stream2);
   };
+  const bool trace = std::getenv("NGSLD_TRACE") != nullptr;  // dev: the groups' host timeline on stderr
+  const auto t_run = std::chrono::steady_clock::now();
+  auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run).count(); };
   int rc = groups.empty() ? NGSLD_OK : compute(0);
+  std::vector<TextBatch> tb;
   for (size_t g = 0; rc == NGSLD_OK && g < groups.size(); ++g) {
-    rc = finish_device_run(c);  // waits for group g's kernels; the host's few pairs replayed and patched into the records
-    if (rc != NGSLD_OK) break;
-    rc = check_status(c);
+    const double t_0 = now_ms();
+    rc = finish_device_run(c);  // waits for A(g); the host's few pairs replayed and patched into the records
+    if (rc == NGSLD_OK) rc = check_status(c);
     if (rc != NGSLD_OK) break;
     flagged += c->flagged_pairs;
     replayed += c->replayed_pairs;
     on_device += c->replayed_on_device;
-    if (g + 1 < groups.size()) {
-      rc = compute(g + 1);
-      if (rc != NGSLD_OK) break;
-    }
     const int k = (int)(g & 1);
     const ReadyRecords ready{c->d_group_std[k].p, ext ? c->d_group_ext[k].p : nullptr, c->h_row_off[groups[g].r0]};
-    rc = run_range(c, groups[g].r0, groups[g].r1, sink, user, &ready);
+    tb.clear();
+    for (uint64_t r0 = groups[g].r0; r0 < groups[g].r1;) {
+      uint64_t r1 = r0 + 1;
+      while (r1 < groups[g].r1 && c->h_row_off[r1 + 1] - c->h_row_off[r0] <= text_batch) ++r1;
+      tb.push_back({r0, r1, c->h_row_off[r1] - c->h_row_off[r0], c->h_row_off[r0] - ready.base});
+      r0 = r1;
+    }
+    const double t_1 = now_ms();
+    rc = group_text_kernels(c, ready, tb, groups[g].n);                 // T(g)
+    const double t_2 = now_ms();
+    if (rc == NGSLD_OK && g + 1 < groups.size()) rc = compute(g + 1);   // A(g+1)
+    const double t_3 = now_ms();
+    if (rc == NGSLD_OK) rc = group_text_to_sink(c, ready, tb, sink, user);  // C(g)
+    if (trace)
+      std::fprintf(stderr, "[trace] group %zu (%llu pairs, %zu batches): its records final %.1f..%.1f, text kernels enqueued (length known) %.1f, "
+                           "next group launched %.1f, text on the host and through the sink %.1f\n", g, (unsigned long long)groups[g].n, tb.size(), t_0, t_1, t_2, t_3, now_ms());
   }
   if (rc != NGSLD_OK) {  // (nothing of this run stays pending behind an error)
     (void)hipStreamSynchronize(c->stream2);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->copy_stream);
     c->dev_run.pending = false;
     return rc;
   }
@@ -851,26 +1051,26 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   }
   StoreGuard store_guard{c};
   // Groups (run_grouped) where the matrix is known to be un-called -- one site in 64 or more is degenerate --, the device can
-  // replay its pairs, the rows become text on the device and there are at least two text batches' worth of them; the groups'
-  // records (72 bytes a pair, two groups) must have room, halved down to 2^22 pairs a group before the run goes batch by batch.
+  // replay its pairs, the rows become text on the device and there are at least four text batches' worth of them; the groups'
+  // records, lengths, offsets and text (~360 bytes a pair, two groups of records) must have room: halved down to 2^22 pairs a
+  // group before the run goes batch by batch.
   const uint64_t n_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
   bool grouped = c->text_mode && c->replay_on && c->h_skip_count * 64ull >= c->n_sites && c->h_skip_count > 0 && lkl_device_eligible(c) &&
                  !c->exact_failed && (n_pairs >= (1ull << 21) || test_knob("TEXT_GROUP_PAIRS") != nullptr) && !test_knob_is("TEXT_GROUPS", "0");
-  if (grouped) {  // (text on the device needs exact prefix sums of the gaps: run_range falls back to records otherwise -- keep that path whole)
-    for (uint64_t s = 0; s < c->n_sites && grouped; ++s) {
-      const double g = c->h_pos_dist[s];
-      if (!(std::isinf(g) && g > 0) && (!(g >= 0.0) || g != std::floor(g))) grouped = false;
-    }
-  }
   if (grouped) {
     uint64_t group_pairs = 1ull << 25;
     if (const char *e = test_knob("TEXT_GROUP_PAIRS")) group_pairs = std::max<uint64_t>(1024, std::strtoull(e, nullptr, 10));  // tests: many small groups
-    const uint64_t rec_bytes = sizeof(ngsld_rec_std) + (c->params.extend_out ? sizeof(ngsld_rec_ext) : 0);
-    while (group_pairs > (1ull << 22) && !room_for(2 * std::min(group_pairs, n_pairs) * rec_bytes, 8ull << 30, 1ull << 30)) group_pairs /= 2;
-    if (test_knob("TEXT_GROUP_PAIRS") != nullptr || room_for(2 * std::min(group_pairs, n_pairs) * rec_bytes, 4ull << 30, 512ull << 20))
-      return run_grouped(c, s1_begin, s1_end, sink, user, group_pairs);
+    const uint64_t per_pair = 2 * (sizeof(ngsld_rec_std) + (c->params.extend_out ? sizeof(ngsld_rec_ext) : 0)) + 16 + 2 * c->max_label + 200;
+    while (group_pairs > (1ull << 22) && !room_for(std::min(group_pairs, n_pairs) * per_pair, 8ull << 30, 1ull << 30)) group_pairs /= 2;
+    grouped = test_knob("TEXT_GROUP_PAIRS") != nullptr || room_for(std::min(group_pairs, n_pairs) * per_pair, 4ull << 30, 512ull << 20);
+    if (grouped) {  // (text on the device needs exact prefix sums of the gaps -- made here, once, for all the groups; where they cannot
+                    // be had run_range sends records to the host formatter: that path stays whole)
+      const int rct = upload_text_prefix(c, &grouped);
+      if (rct != NGSLD_OK) return rct;
+    }
+    if (grouped) return run_grouped(c, s1_begin, s1_end, sink, user, group_pairs);
   }
-  return run_range(c, s1_begin, s1_end, sink, user, nullptr);
+  return run_range(c, s1_begin, s1_end, sink, user);
 } NGSLD_CATCH(c)
 
 int ngsld_last_kernel_time(ngsld_ctx *c, double *total_ms, uint64_t *n_launches, uint64_t *n_pairs) {
