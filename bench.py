@@ -728,6 +728,14 @@ def main():
     if rank == 0 and headline and not args.no_e2e and args.config == "c2" and not args.custom:
         torch.cuda.synchronize()
         e2e = e2e_file_to_tsv(raw, n_sites, n_ind, chrs, pos, args.max_kb, host_cpus()["threads_used"])
+        if e2e is not None and "seconds" in e2e and not args.no_unfiltered:
+            # the same through the binary on the un-called twin of the matrix (20 % of the sites monomorphic, README.md:73): text in
+            # groups, the flagged third of the pairs replayed on the device (engine_run.hip, run_grouped)
+            raw_u = synth.make_gl_torch(n_sites, n_ind, args.seed, dev, depth=args.depth, mono_frac=0.2)
+            torch.cuda.synchronize()
+            e2e["uncalled_mono_frac_0.2"] = e2e_file_to_tsv(raw_u, n_sites, n_ind, chrs, pos, args.max_kb, host_cpus()["threads_used"])
+            del raw_u
+            torch.cuda.empty_cache()
     unfiltered = None
     profiled = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX")) for k in os.environ)  # (its kernels would land in the profile)
     if rank == 0 and headline and not args.no_unfiltered and args.config == "c2" and not args.custom and not profiled:
