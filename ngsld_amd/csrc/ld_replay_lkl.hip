@@ -799,8 +799,9 @@ hipError_t launch_replay_sort(const ReplayLklArgs &a, const ReplayEntry *list, u
 hipError_t launch_replay_lanes(const ReplayLklArgs &a, const ReplayEntry *list, const uint32_t *order, const double *xT, int n_cus,
                                int waves_per_simd, hipStream_t stream) {
   if (list == nullptr || xT == nullptr || a.n_records == 0) return hipSuccess;
-  // a persistent grid: four wavefronts per SIMD (96 registers, no LDS: the gathers want the company); never more lanes than the launch has records
-  uint64_t waves = (uint64_t)n_cus * 4 * (uint64_t)(waves_per_simd < 1 ? 1 : (waves_per_simd > 4 ? 4 : waves_per_simd));
+  // a persistent grid: as many wavefronts as a SIMD holds of this kernel -- three, at 154 registers (round 6: two register sets; a
+  // fourth would only wait for a slot and find the list empty) --, never more lanes than the launch has records
+  uint64_t waves = (uint64_t)n_cus * 4 * (uint64_t)(waves_per_simd < 1 ? 1 : (waves_per_simd > 3 ? 3 : waves_per_simd));
   const uint64_t most = (a.n_records + 63) / 64;
   if (waves > most) waves = most;
   if (a.lane_iter_cap != 0)
