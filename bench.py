@@ -199,7 +199,8 @@ def cpu_baseline(raw_head: np.ndarray, pos_dist_head: np.ndarray, max_kb: int, t
     out["reference_program"] = rp
     if rp and "value" in rp:   # the baseline of the line is the reference's own program where it can run; the port stays beside it
         out["port"] = {k: out[k] for k in ("value", "unit", "cores", "kind", "sample")}
-        out.update(value=rp["value"], cores=rp["cores"], kind="reference", sample=rp["sample"])
+        out.update(value=rp["value"], cores=rp["cores"], kind="reference", sample=rp["sample"],
+                   baseline_definition=rp.get("baseline_definition"), value_without_pearson=rp.get("value_without_pearson"))
     return out
 
 

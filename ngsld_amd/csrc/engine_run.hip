@@ -971,12 +971,6 @@ static int run_grouped(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_s
     ~FlagText() { c->dev_run_flag_text = false; }
   } flag_text{c};
   c->dev_run_flag_text = true;
-  // (the matrix is known to be un-called: the exact store is wanted, and its builder can start beside the first group's kernels
-  // instead of inside the first group's finish)
-  if (!exact_store_started(c) && !c->exact_failed) {
-    const int rcs = start_exact_store(c);
-    if (rcs != NGSLD_OK) return rcs;
-  }
   const uint64_t text_batch = std::min<uint64_t>(c->batch_pairs, kTextBatchPairs);
   uint64_t flagged = 0, replayed = 0, on_device = 0;
   auto compute = [&](size_t g) -> int {  // A(g), enqueued on stream2 (no host wait)
@@ -1057,6 +1051,16 @@ int ngsld_run(ngsld_ctx *c, uint64_t s1_begin, uint64_t s1_end, ngsld_sink_fn si
   const uint64_t n_pairs = c->h_row_off[s1_end] - c->h_row_off[s1_begin];
   bool grouped = c->text_mode && c->replay_on && c->h_skip_count * 64ull >= c->n_sites && c->h_skip_count > 0 && lkl_device_eligible(c) &&
                  !c->exact_failed && (n_pairs >= (1ull << 21) || test_knob("TEXT_GROUP_PAIRS") != nullptr) && !test_knob_is("TEXT_GROUPS", "0");
+  if (grouped) {
+    // The store first -- the matrix is known to be un-called, so it is wanted, and its builder can work beside the first group's
+    // kernels -- and then the groups' buffers out of what is left: under a memory cap (ngsld_set_memory_budget) the store must not
+    // lose its room to them.  Without the lanes' individual-major copy a group has nothing over a batch: batch by batch then.
+    if (!exact_store_started(c) && !c->exact_failed) {
+      const int rcs = start_exact_store(c);
+      if (rcs != NGSLD_OK) return rcs;
+    }
+    grouped = !c->exact_failed && c->xT_ready.load();
+  }
   if (grouped) {
     uint64_t group_pairs = 1ull << 25;
     if (const char *e = test_knob("TEXT_GROUP_PAIRS")) group_pairs = std::max<uint64_t>(1024, std::strtoull(e, nullptr, 10));  // tests: many small groups
