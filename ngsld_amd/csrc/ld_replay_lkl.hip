@@ -77,7 +77,7 @@ __device__ __forceinline__ bool no_data(const double (&g)[3]) { return ref_abs(g
 // 9 + 20 + 10 multiplies, 15 + 12 additions, 4 divisions per individual and iteration (the literal loops: 9 + 32 + 16
 // multiplies, 16 + 16 + 16 additions); the records are the same bits (tests/test_gpu_replay_lkl.py: device against host replay).
 struct FreqProducts {
-  double g[10], h2[10];  // f[k] * f[h] for k <= h, and twice that
+  double g[10];  // f[k] * f[h] for k <= h (twice that where the reference doubles: 2 * g[.], exact, formed where it is used)
   __device__ __forceinline__ static constexpr int at(int k, int h) {  // index of the unordered pair {k, h}
     return (k <= h) ? (k * 4 - k * (k - 1) / 2 + (h - k)) : (h * 4 - h * (h - 1) / 2 + (k - h));
   }
@@ -87,7 +87,6 @@ struct FreqProducts {
 #pragma unroll
       for (int h = k; h < 4; ++h) {
         g[at(k, h)] = f[k] * f[h];
-        h2[at(k, h)] = 2 * g[at(k, h)];
       }
   }
 };
@@ -142,12 +141,23 @@ __device__ __forceinline__ void quotients(const FreqProducts &F, const double (&
 #pragma unroll
   for (int kh = 1; kh < 16; ++kh) sum += t[FreqProducts::at(kh >> 2, kh & 3)];
   // gen_func.cpp:1098-1104
+  // LIGHT: HALF the reference's tmp -- sum_h (f f) J instead of sum_h (2 f f) J.  Doubling commutes with every rounding where
+  // nothing is denormal (each term, each partial sum, the quotient by `sum` are exactly half the reference's), which the LIGHT
+  // bound guarantees (every product at least 2^-600); the caller adds the halves up and divides by x instead of 2 x at the end of
+  // the step -- the same real number, rounded once.  Ten registers of doubled products less per lane.
+  // (the general form doubles J, not the products of frequencies: (f f) (2 J) and (2 f f) J are the same real number rounded once,
+  // and J is the individual's own -- nothing for the compiler to keep in ten more registers across the loop)
+  double JJ[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) JJ[a][b] = LIGHT ? J[a][b] : J[a][b] + J[a][b];
   double tmp[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    tmp[k] = F.h2[FreqProducts::at(k, 0)] * J[geno1(0, k)][geno2(0, k)];
+    tmp[k] = F.g[FreqProducts::at(k, 0)] * JJ[geno1(0, k)][geno2(0, k)];
 #pragma unroll
-    for (int h = 1; h < 4; ++h) tmp[k] += F.h2[FreqProducts::at(k, h)] * J[geno1(h, k)][geno2(h, k)];
+    for (int h = 1; h < 4; ++h) tmp[k] += F.g[FreqProducts::at(k, h)] * JJ[geno1(h, k)][geno2(h, k)];
   }
   // The four IEEE divisions by ONE denominator.  What the compiler makes of `tmp / sum` on gfx950 is, per quotient:
   // v_div_scale x 2, v_rcp_f64, two Newton steps on the reciprocal (4 FMAs), q0 = n * r, e = fma(-d, q0, n), v_div_fmas
@@ -577,8 +587,12 @@ constexpr uint32_t kLaneChunk = 256;  // sorted entries a wavefront claims at a 
 // (CAPPED: short launches of large cohorts, ReplayLklArgs::lane_iter_cap -- a template so that the long launches' instruction
 // stream is the one without the hand-back: with the test inside one kernel that stream came out 30 % slower, 447 against 343 ms
 // for configs[2]'s 31e6 pairs)
+// Four wavefronts to a SIMD: 128 registers, which the kernel meets with two 16-byte spills per EM STEP (none inside the loop over
+// the individuals) once the doubled frequency products are gone (quotients<LIGHT>).  Same box, 20 % monomorphic sites: 136
+// registers at three wavefronts 627.9 ms a pass, 128 at four 613.7 (profiles/r06/lane/g_ab.txt).
+constexpr int kLaneWavesPerSimd = 4;
 template <bool CAPPED>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void replay_lane_kernel(ReplayLklArgs A, const ReplayEntry *list,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void replay_lane_kernel(ReplayLklArgs A, const ReplayEntry *list,
                                                                                                       const uint32_t *order,
                                                                                                       const double *xT) {
   const bool ign = A.ignore_miss != 0;
@@ -651,8 +665,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
       FreqProducts F;
       F.set(f);
       // The individuals in order, two register sets used in turn: the next individual's triples are on their way while this one
-      // is worked on, and nothing is copied from a staging set into place (154 registers, three wavefronts to a SIMD: -1.1 % of a
-      // pass against one set + staging at four, profiles/r06/lane/ab2.txt)
+      // is worked on, and nothing is copied from a staging set into place (-1.1 % of a pass, profiles/r06/lane/ab2.txt)
       // (D register sets: an individual's triples are fetched D - 1 steps before they are used.  Three and four measured +-0 at the
       // same three wavefronts per SIMD, five and six -9 % at two: profiles/r06/lane/sets_ab.txt)
       constexpr int D = 2;
@@ -697,7 +710,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
       else
         individuals(std::false_type());
       if (!ign) x = A.n_ind;
-      const double twox = (double)(2 * (uint64_t)x);  // gen_func.cpp:1109
+      const double twox = light ? (double)x : (double)(2 * (uint64_t)x);  // gen_func.cpp:1109 (light: the sums are half the reference's)
       double g4[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) g4[k] = ff[k] / twox;
@@ -799,9 +812,8 @@ hipError_t launch_replay_sort(const ReplayLklArgs &a, const ReplayEntry *list, u
 hipError_t launch_replay_lanes(const ReplayLklArgs &a, const ReplayEntry *list, const uint32_t *order, const double *xT, int n_cus,
                                int waves_per_simd, hipStream_t stream) {
   if (list == nullptr || xT == nullptr || a.n_records == 0) return hipSuccess;
-  // a persistent grid: as many wavefronts as a SIMD holds of this kernel -- three, at 154 registers (round 6: two register sets; a
-  // fourth would only wait for a slot and find the list empty) --, never more lanes than the launch has records
-  uint64_t waves = (uint64_t)n_cus * 4 * (uint64_t)(waves_per_simd < 1 ? 1 : (waves_per_simd > 3 ? 3 : waves_per_simd));
+  // a persistent grid: as many wavefronts as a SIMD holds of this kernel (kLaneWavesPerSimd), never more lanes than the launch has records
+  uint64_t waves = (uint64_t)n_cus * 4 * (uint64_t)(waves_per_simd < 1 ? 1 : (waves_per_simd > kLaneWavesPerSimd ? kLaneWavesPerSimd : waves_per_simd));
   const uint64_t most = (a.n_records + 63) / 64;
   if (waves > most) waves = most;
   if (a.lane_iter_cap != 0)
