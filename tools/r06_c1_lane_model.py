@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Round 6, verdict item 4 (CPU): would a lane-per-pair kernel beat the lockstep kernel on configs[1] (5,000 x 100, all pairs)?
+The part of the answer that is DATA: the tail.  With the candidate tile in LDS (64 sites x 100 individuals = 153.6 KB: one block
+per CU) a workgroup works through the 32 x 32 = 1,024 pairs of a block, its lanes taking the next pair of the block as they
+converge; the workgroup cannot retire before its slowest lane.  The executed EM steps per pair come from the CPU checker on the
+bench's generator; the schedule is simulated (greedy, pairs in row order) for 256 / 512 / 1,024 lanes per workgroup.
+
+    efficiency = useful lane-steps / (lanes x the block's makespan)
+
+Instruction model (counts, not measurements): lane per pair 31 VALU instructions per individual and step = 48.4 wavefront-
+instructions per pair and step at 100 individuals; the lockstep kernel 218 per step for 4 pairs = 54.5, x 1.16 measured
+lockstep tail = 63.2 (DESIGN / HISTORY 9.3).  speed-up = 63.2 / (48.4 / efficiency).
+
+    python tools/r06_c1_lane_model.py [n_sites]  ->  profiles/r06/c1_lane_per_pair_model.txt
+"""
+import sys
+import heapq
+
+import numpy as np
+
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+from ngsld_amd import synth  # noqa: E402
+from oracle import orc  # noqa: E402  (test infrastructure: this tool is not product code)
+
+n_sites = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+n_ind = 100
+raw = synth.make_gl_numpy(n_sites, n_ind, seed=3, depth=10.0)
+res = orc.Oracle(raw, n_threads=8).run()
+steps = np.minimum(res["n_iter"].astype(np.int64) + 1, 100)      # executed EM steps of every pair
+s1, s2 = res["s1"].astype(np.int64), res["s2"].astype(np.int64)
+print(f"configs[1]'s shape: {n_sites} sites x {n_ind} individuals, {len(res)} pairs; executed EM steps per pair: mean {steps.mean():.2f}, "
+      f"median {np.median(steps):.0f}, 99th percentile {np.percentile(steps, 99):.0f}, max {steps.max()}")
+# steps of pair (a, b), a < b, as a matrix for block lookups
+M = np.zeros((n_sites, n_sites), dtype=np.int16)
+M[s1, s2] = steps
+T = 32
+tiles = n_sites // T
+rng = np.random.default_rng(1)
+blocks = [(a, b) for a in range(tiles) for b in range(a + 1, tiles)]
+sample = [blocks[i] for i in rng.choice(len(blocks), size=min(600, len(blocks)), replace=False)]
+for lanes in (256, 512, 1024):
+    useful = spent = 0
+    for a, b in sample:
+        w = M[a * T:(a + 1) * T, b * T:(b + 1) * T].reshape(-1).astype(np.int64)   # 1,024 pairs, row order
+        free = [0] * lanes
+        heapq.heapify(free)
+        for c in w:
+            t = heapq.heappop(free)
+            heapq.heappush(free, t + int(c))
+        makespan = max(free)
+        useful += int(w.sum())
+        spent += lanes * makespan
+    eff = useful / spent
+    print(f"  {lanes:4d} lanes per workgroup ({lanes // 64} wavefronts, {lanes // 256} per SIMD): efficiency {eff:.3f}  ->  "
+          f"{48.4 / eff:.1f} wavefront-instructions per pair and step against the lockstep kernel's 63.2: x{63.2 / (48.4 / eff):.2f}")
+print("(+ what the model leaves out, all against the lane form: one block per CU at 256 lanes is ONE wavefront per SIMD -- dependent f64 "
+      "chains at 8 cycles an instruction, not 4; 153.6 KB to load per 1,024 pairs; record derivation per lane instead of per pair)")
