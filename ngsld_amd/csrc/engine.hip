@@ -47,6 +47,14 @@ int set_geno_common(ngsld_ctx *c, const double *gl, const double *maf, uint64_t 
   c->d_xdepth.release();
   c->d_xperm.release();
   c->xT_ready = false;
+  // (the buffers of a grouped text run -- records, lengths, text of up to 2^25 pairs -- belong to the matrix they were sized for)
+  for (int k = 0; k < 2; ++k) {
+    c->d_group_std[k].release();
+    c->d_group_ext[k].release();
+  }
+  c->d_group_lens.release();
+  c->d_group_offs.release();
+  c->d_group_text.release();
   c->gopts = o;
   c->normalised = normalised;
   c->n_sites = n_sites;

@@ -466,8 +466,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2
 // 4 x n_ind numbers one by one, and with several wavefronts per pair the others wait for that chain (n_ind 2,000: 6e6
 // replayed pairs/s against 5.4e7 at 500).  Here a LANE owns a pair and walks the individuals in the reference's own order --
 // no chain, no idle lanes: every pair has the same number of individuals, so the 64 lanes of a wavefront reach the end of
-// their EM iteration together, and a lane whose pair has converged takes its next pair there.  ~144 instructions per
-// individual and iteration for 64 pairs at once.  The lanes of a wavefront hold neighbouring pairs (claimed in list order),
+// their EM iteration together, and a lane whose pair has converged takes its next pair there.  ~101 executed VALU instructions
+// per individual and iteration for 64 pairs at once (round 6; 144 when the kernel was written).  The lanes of a wavefront hold neighbouring pairs (claimed in list order),
 // and the store is read individual-major -- xT[i][site][3] -- so that for one individual their 24-byte triples are neighbours
 // in memory (a monomorphic row's candidates: consecutive sites, 1.5 KB contiguous).
 // ---------------------------------------------------------------------------------------------------------------
