@@ -224,7 +224,12 @@ int ngsld_replay_stats(ngsld_ctx *ctx, uint64_t *pairs, uint64_t *sites);
  * ngsld_run that asked for it, in site order: a batch's replay waits only until the builder has passed the batch's last
  * window; the run returns when the build has ended (the source is read during runs only).  ngsld_finish_device builds it
  * before it replays.
- * mode: 0 never (host replay only), 1 as described (default), 2 build at the first flagged pair. */
+ * mode: 0 never (host replay only), 1 as described (default), 2 build at the first flagged pair.
+ * (0.4.0) Such a matrix is recognised when it is set: ngsld_set_geno_* marks the DEGENERATE sites -- the one-locus EM of the site,
+ * from its est_maf frequency, ends below 3e-6: every pair of such a site (nearly) is one the replay settles.  Where the device can
+ * replay (mode != 0) the pair kernels leave the EM of those pairs out -- the replay, exact for any pair, is their one evaluation --
+ * and ngsld_run with text output computes in groups of up to 2^25 pairs (one launch of pair kernels + one replay per group) instead
+ * of batch by batch; the sink sees the same batches.  ngsld_replay_stats_t.sites_degenerate; NGSLD_REPLAY_SKIP=0 turns the marks off. */
 int ngsld_set_exact_store(ngsld_ctx *ctx, int mode);
 typedef struct {
   uint64_t pairs_flagged;      /* pairs the kernels of the last run flagged */

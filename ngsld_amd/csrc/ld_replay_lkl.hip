@@ -582,7 +582,7 @@ __global__ void replay_keys_kernel(ReplayLklArgs A, const ReplayEntry *list, uin
   keys[i] = (((s_hi << (site_bits - tile_o)) | o_hi) << (tile_s + tile_o)) | (s_lo << tile_o) | o_lo;
 }
 
-constexpr uint32_t kLaneChunk = 256;  // sorted entries a wavefront claims at a time
+constexpr uint32_t kLaneChunk = 256;  // sorted entries a wavefront claims at a time (fewer where the launch has few per wavefront: see the kernel)
 
 // (CAPPED: short launches of large cohorts, ReplayLklArgs::lane_iter_cap -- a template so that the long launches' instruction
 // stream is the one without the hand-back: with the test inside one kernel that stream came out 30 % slower, 447 against 343 ms
@@ -598,6 +598,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   const bool ign = A.ignore_miss != 0;
   const uint64_t row = A.xt_sites * 3;  // doubles from one individual to the next
   const uint32_t total = A.flags[4];
+  // a claim: 256 neighbours of the sorted list (four pairs a lane: the lanes that refill stay inside the tile) where the launch has
+  // dozens of claims per wavefront; a short launch (the driver's 10,000-site matrix: 3.2e6 pairs, three claims of 256 per
+  // wavefront) ends with wavefronts idle beside others' last 256 -- there, down to 64
+  uint32_t chunk = (total / (gridDim.x * 8u)) & ~63u;
+  chunk = chunk < 64u ? 64u : (chunk > kLaneChunk ? kLaneChunk : chunk);
   bool have = false, dry = false;       // this lane holds a pair / the list has run out
   uint32_t sites_depth = kNotPlain;     // plain_depth of the pair's two sites, added up (ReplayLklArgs::xdepth)
   ReplayEntry e{};
@@ -615,14 +620,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       if (!need) break;
       if (pos == end) {
         uint32_t c0 = 0;
-        if ((uint32_t)__lane_id() == (uint32_t)(__ffsll((unsigned long long)need) - 1)) c0 = atomicAdd(&A.flags[5], kLaneChunk);
+        if ((uint32_t)__lane_id() == (uint32_t)(__ffsll((unsigned long long)need) - 1)) c0 = atomicAdd(&A.flags[5], chunk);
         c0 = (uint32_t)__builtin_amdgcn_readlane((int)c0, __ffsll((unsigned long long)need) - 1);
         if (c0 >= total) {
           if (!have) dry = true;
           break;
         }
         pos = c0;
-        end = c0 + kLaneChunk < total ? c0 + kLaneChunk : total;
+        end = c0 + chunk < total ? c0 + chunk : total;
       }
       const uint32_t rank = (uint32_t)__popcll(need & ((1ull << __lane_id()) - 1ull));
       const bool take = !have && !dry && pos + rank < end;
