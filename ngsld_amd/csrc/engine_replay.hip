@@ -405,12 +405,11 @@ int reset_flags(ngsld_ctx *c, DevBuf<uint32_t> &buf, uint64_t n, uint32_t cap, h
 // ---------------------------------------------------------------------------------------------------------------
 // Likelihood matrices: the exact store and the device-side replay (ld_replay_lkl.hip)
 // ---------------------------------------------------------------------------------------------------------------
-static bool lanes_allowed() { return true; }
 
 bool lkl_device_eligible(const ngsld_ctx *c) {
-  // (beyond 4,096 individuals the wavefront-per-pair kernel has no shape: the lanes take such cohorts, where they may be had)
-  return c->replay_on && c->replay_device && c->exact_mode != 0 && c->have_geno && c->cfg.kernel != kHard &&
-         (replay_lkl_waves((uint32_t)c->n_ind) != 0 || lanes_allowed());
+  // (beyond 4,096 individuals the wavefront-per-pair kernel has no shape: the lanes take such cohorts -- where their copy of the
+  // store cannot be had, start_exact_store gives the matrix up to the host)
+  return c->replay_on && c->replay_device && c->exact_mode != 0 && c->have_geno && c->cfg.kernel != kHard;
 }
 
 // the planes ARE the store: the caller's own normal-space values (ngsld_set_geno_lkl), or no source to build another from
