@@ -55,3 +55,54 @@ for lanes in (256, 512, 1024):
           f"{48.4 / eff:.1f} wavefront-instructions per pair and step against the lockstep kernel's 63.2: x{63.2 / (48.4 / eff):.2f}")
 print("(+ what the model leaves out, all against the lane form: one block per CU at 256 lanes is ONE wavefront per SIMD -- dependent f64 "
       "chains at 8 cycles an instruction, not 4; 153.6 KB to load per 1,024 pairs; record derivation per lane instead of per pair)")
+# The tail is the block's, not the form's: a STREAMED variant -- 16 / 32 row sites resident, the partners passing through a ring of 48 / 32
+# LDS slots, a lane taking the next pair of the oldest slot as it converges, a slot freed when its last pair is done -- has none.
+def streamed(lanes, rows_resident, ring, starts):
+    useful = spent = 0
+    for a0 in starts:
+        s1s = list(range(a0, min(a0 + rows_resident, n_sites)))
+        nxt = a0 + rows_resident
+        slots = []
+        rem = np.zeros(lanes, dtype=np.int64)
+        held = [None] * lanes
+        t = 0
+        while True:
+            while len(slots) < ring and nxt < n_sites:
+                slots.append({"s2": nxt, "q": list(s1s), "out": 0})
+                nxt += 1
+            for l in np.nonzero(rem == 0)[0]:
+                for sl in slots:
+                    if sl["q"]:
+                        rem[l] = M[sl["q"].pop(), sl["s2"]]
+                        held[l] = sl
+                        sl["out"] += 1
+                        useful += int(rem[l])
+                        break
+            if not (rem > 0).any():
+                break
+            t += 1
+            for l in np.nonzero(rem == 1)[0]:
+                held[l]["out"] -= 1
+            rem[rem > 0] -= 1
+            slots[:] = [sl for sl in slots if sl["q"] or sl["out"] > 0]
+        spent += lanes * t
+    return useful / spent
+
+
+print("streamed variant (no block: row sites resident, partners through a ring of LDS slots, lanes refill from the stream; every lane "
+      "steps together -- generous):")
+for lanes, rr, ring in ((256, 32, 32), (256, 16, 48), (512, 32, 32)):
+    eff = streamed(lanes, rr, ring, [0, n_sites // 4, n_sites // 2])
+    # per wavefront and step: 100 individuals x 34 issue slots (28 VALU + 6 LDS reads) + 55 of the step itself + ~200 of the
+    # record block, which some lane enters in almost every step = 3,655 for 64 pair-steps = 57.1
+    print(f"  {lanes:4d} lanes, {rr} row sites, ring of {ring}: efficiency {eff:.3f}  ->  {57.1 / eff:.1f} against 63.2: x{63.2 / (57.1 / eff):.2f}")
+print("operand feed (MI355X_MICROARCH.md: FP64 FMA 4 cycles a wavefront instruction; ds_read_b64 2 LDS cycles, 256 B a clock a CU): a lane "
+      "needs both sites' triples, 48 B, per individual and step, for 28 VALU instructions = 112 cycles of its SIMD.  From LDS that is 6 reads "
+      "= 12 cycles a wavefront, 0.43 of the LDS at four SIMDs: no limit, which is why the tile is in LDS -- whose 160 KB hold 64 sites of 100 "
+      "individuals (the block and its tail above, or the ring).  From the vector cache (four SIMDs ask for ~100 B a clock a CU; lanes that "
+      "refilled hold partners from two windows = twice the lines) the form is feed-bound.  The exact-order lane replay spends 101 "
+      "instructions on the same 48 B, which is why THAT kernel could be a lane per pair on plain loads.")
+print("=> the block form loses; the streamed form is +10 % ON PAPER for configs[1] (21 ms a pass) and only at ONE wavefront per SIMD -- its 57 "
+      "is a count with every issue slot used (no second wavefront to cover an LDS gather or the reciprocal's dependent chain), the lockstep "
+      "kernel's 63.2 is measured.  A new kernel family (ring of LDS slots, per-lane gathers, flags and records per lane) for that margin: "
+      "not built.")
