@@ -361,25 +361,26 @@ def measure_traffic(args) -> dict | None:
                       "included, an upper bound on HBM bytes"}
 
 
-def unfiltered_input_leg(n_sites: int, n_ind: int, max_kb: int, max_gap: int, depth: float, dev_index: int) -> dict:
+def unfiltered_input_leg(n_sites: int, n_ind: int, max_kb: int, max_gap: int, depth: float, dev_index: int, full_sites: int = 0) -> dict:
     """The same pass on a matrix that is NOT SNP-called (the reference's README.md:73: "these comparisons will show up as nan or
     inf"; its own examples/test.sh feeds such input): 20 % of the sites monomorphic in the population and, a second matrix, site
     frequencies log-uniform in [0.001, 0.5].  A third of the pairs (a fourteenth) are then pairs the reference's own rounding
     decides -- flagged by the pair kernels and replayed in the reference's operation order, on the DEVICE (ld_replay_lkl.hip) once the
-    exact store is built (host libm, once per matrix: inside `first_pass_s`).  Small (n_sites sites) so that the default line carries
-    it every round; `bench.py --mono-frac 0.2` / `--sfs` is the same at full size."""
+    exact store is built (host libm, once per matrix: inside `first_pass_s`).  Small (n_sites sites) as in round 5's line; `full_sites`
+    adds the first twin at the headline's own size (= `bench.py --mono-frac 0.2`)."""
     import torch
     from ngsld_amd import capi, shard, synth
     dev = torch.device("cuda", dev_index)
     out = {"n_sites": n_sites, "n_ind": n_ind, "max_kb_dist": max_kb}
-    chrs, pos = synth.make_positions(n_sites, 33, max_gap=max_gap)
-    pd = shard.pos_dist_from_positions(chrs, pos)
-    for name, kw in (("mono_frac_0.2", {"mono_frac": 0.2}), ("sfs", {"sfs": True})):
-        raw = synth.make_gl_torch(n_sites, n_ind, 33, dev, depth=depth, **kw)
+
+    def measure(m_sites: int, kw: dict) -> dict:
+        chrs, pos = synth.make_positions(m_sites, 33, max_gap=max_gap)
+        pd = shard.pos_dist_from_positions(chrs, pos)
+        raw = synth.make_gl_torch(m_sites, n_ind, 33, dev, depth=depth, **kw)
         host = raw.cpu().numpy()
         eng = capi.Engine(dev_index)
         try:
-            eng.set_geno_raw(raw.data_ptr(), n_sites=n_sites, n_ind=n_ind)
+            eng.set_geno_raw(raw.data_ptr(), n_sites=m_sites, n_ind=n_ind)
             eng.set_replay_source(host)
             eng.set_pos_dist(pd)
             n_pairs = eng.plan(max_kb_dist=max_kb, extend_out=True)
@@ -390,7 +391,7 @@ def unfiltered_input_leg(n_sites: int, n_ind: int, max_kb: int, max_gap: int, de
             def one():
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                eng.run_device(0, n_sites, d_std.data_ptr(), d_ext.data_ptr(), st)
+                eng.run_device(0, m_sites, d_std.data_ptr(), d_ext.data_ptr(), st)
                 eng.finish_device()
                 torch.cuda.synchronize()
                 return time.perf_counter() - t0
@@ -401,12 +402,20 @@ def unfiltered_input_leg(n_sites: int, n_ind: int, max_kb: int, max_gap: int, de
             eng.plan(max_kb_dist=max_kb, extend_out=True)
             one()
             off = min(one() for _ in range(2))
-            out[name] = {"pairs": n_pairs, "value": n_pairs / best, "unit": "pairs/s", "ms_per_pass": best * 1e3,
-                         "first_pass_s": round(first, 4), "value_replay_off": n_pairs / off, "replay": info}
+            return {"pairs": n_pairs, "value": n_pairs / best, "unit": "pairs/s", "ms_per_pass": best * 1e3,
+                    "first_pass_s": round(first, 4), "value_replay_off": n_pairs / off, "ratio_to_replay_off": round(off / best, 4),
+                    "replay": info}
         finally:
             eng.close()
-        del raw, host
-        torch.cuda.empty_cache()
+            del raw, host
+            torch.cuda.empty_cache()
+
+    for name, kw in (("mono_frac_0.2", {"mono_frac": 0.2}), ("sfs", {"sfs": True})):
+        out[name] = measure(n_sites, kw)
+    if full_sites:
+        # the same twin at the HEADLINE's size (configs[2]'s 100,000 sites): a launch of 3e6 flagged pairs is a dozen pairs a lane
+        # and pays the lane kernel's ramp and tail (+6 ms of 67); this is the rate a job of the headline's size sees
+        out["mono_frac_0.2_full_size"] = dict(measure(full_sites, {"mono_frac": 0.2}), n_sites=full_sites)
     return out
 
 
@@ -740,7 +749,8 @@ def main():
     unfiltered = None
     profiled = any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX")) for k in os.environ)  # (its kernels would land in the profile)
     if rank == 0 and headline and not args.no_unfiltered and args.config == "c2" and not args.custom and not profiled:
-        unfiltered = unfiltered_input_leg(10_000, n_ind, args.max_kb, args.max_gap, args.depth, dev_index)
+        unfiltered = unfiltered_input_leg(10_000, n_ind, args.max_kb, args.max_gap, args.depth, dev_index,
+                                          full_sites=args.sites if args.sites >= 50_000 else 0)
     del slab, raw
     torch.cuda.empty_cache()
     other_configs = None
