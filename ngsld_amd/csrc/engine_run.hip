@@ -775,11 +775,13 @@ struct ReadyRecords {  // records that are final in device memory: record 0 = pl
   uint64_t base;
 };
 
-__global__ void group_bounds_kernel(const uint64_t *offs, const uint64_t *first_rec, uint32_t n_batches, const uint64_t *total, const int *needs,
-                                    uint64_t *h_bounds, int *h_needs) {
+__global__ void group_bounds_kernel(const uint64_t *offs, const uint64_t *first_rec, uint32_t n_batches, uint64_t n_group, const uint64_t *total,
+                                    const int *needs, uint64_t *h_bounds, int *h_needs) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n_batches) {
-    h_bounds[j] = offs[first_rec[j]];
+    // (a batch of rows without a pair behind the group's last record -- a group of nothing but such rows has one -- starts where the text ends:
+    // offs[] has n_group entries)
+    h_bounds[j] = first_rec[j] < n_group ? offs[first_rec[j]] : *total;
     h_needs[j] = needs[j];
   } else if (j == n_batches) {
     h_bounds[j] = *total;
@@ -846,7 +848,7 @@ static int group_text_kernels(ngsld_ctx *c, const ReadyRecords &rr, const std::v
   int *hn = nullptr;
   HIP_TRY(c, hipHostGetDevicePointer((void **)&hb, c->h_group_bounds.p, 0));
   HIP_TRY(c, hipHostGetDevicePointer((void **)&hn, c->h_group_needs.p, 0));
-  hipLaunchKernelGGL(group_bounds_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, c->d_group_offs.p, c->d_group_first.p, nb, c->d_group_meta.p,
+  hipLaunchKernelGGL(group_bounds_kernel, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, c->d_group_offs.p, c->d_group_first.p, nb, n_group, c->d_group_meta.p,
                      c->d_group_needs.p, hb, hn);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipEventRecord(c->ev_kernel_done[0], st));
